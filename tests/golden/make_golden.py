@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- regenerate the golden fixtures in this directory.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  It imports the
+reference's own Python modules (model/network.py, model/ray_sampler.py, model/density.py,
+model/loss.py, hashencoder/hashgrid.py, utils/rend_util.py), with
+
+  * inert ``sys.modules`` placeholders for third-party imports that are absent here and
+    never executed on this path (cachetools, tkinter, imageio, skimage, cv2, trimesh),
+  * ``.cuda()`` turned into a no-op (the reference hard-codes it; there is no GPU here),
+  * ``hashencoder.backend._backend`` bound to the C oracle (oracle/hash_oracle.c), because
+    the reference's hash kernels are CUDA-only,
+  * ``utils.general`` reduced to ``get_class`` (the real module imports a dozen absent
+    packages at import time and nothing else of it is used by the path),
+
+drives one Stage-1 training iteration at small sizes, records every random draw in call
+order, and stores inputs + outputs as .npz.  Nothing of the reference (source or
+bytecode) is written anywhere; the fixtures are numbers only.
+
+Usage:  python tests/golden/make_golden.py            (from the repo root)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import hash_oracle  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- import shims
+def _install_reference():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("cachetools", cached=lambda *a, **k: (lambda f: f))
+    tk = mod("tkinter")
+    tk.messagebox = mod("tkinter.messagebox", NO="no")
+    for n in ("imageio", "skimage", "cv2", "trimesh"):
+        mod(n)
+    ident = lambda self, *a, **k: self  # noqa: E731
+    torch.Tensor.cuda = ident
+    torch.nn.Module.cuda = ident
+    sys.path.insert(0, REF)
+    mod("hashencoder.backend", _backend=hash_oracle.RefBackendShim)
+
+    def get_class(kls):
+        parts = kls.split(".")
+        m = __import__(".".join(parts[:-1]))
+        for comp in parts[1:]:
+            m = getattr(m, comp)
+        return m
+
+    import utils  # namespace package of the reference
+    utils.general = mod("utils.general", get_class=get_class)
+    from model.network import HoloSceneNetwork
+    from model.loss import HoloSceneLoss
+    return HoloSceneNetwork, HoloSceneLoss
+
+
+class Conf(dict):
+    """Minimal pyhocon-like accessor (pyhocon is not installed here)."""
+
+    def _get(self, key, default=KeyError):
+        cur = self
+        for part in key.split("."):
+            if not isinstance(cur, dict) or part not in cur:
+                if default is KeyError:
+                    raise KeyError(key)
+                return default
+            cur = cur[part]
+        return cur
+
+    def get_int(self, k, default=KeyError):
+        return int(self._get(k, default))
+
+    def get_float(self, k, default=KeyError):
+        return float(self._get(k, default))
+
+    def get_bool(self, k, default=KeyError):
+        return bool(self._get(k, default))
+
+    def get_list(self, k, default=KeyError):
+        return list(self._get(k, default))
+
+    def get_string(self, k, default=KeyError):
+        return str(self._get(k, default))
+
+    def get_config(self, k, default=KeyError):
+        v = self._get(k, default)
+        return Conf(v) if isinstance(v, dict) else v
+
+
+class DrawLog:
+    """Records the reference's random draws in call order."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._saved = (torch.rand, torch.rand_like, torch.randperm, torch.randint, torch.Tensor.uniform_, np.random.randint)
+        log = self.draws
+        s = self._saved
+
+        def wrap(name, fn):
+            def f(*a, **k):
+                out = fn(*a, **k)
+                log.append((name, out.clone() if torch.is_tensor(out) else np.array(out)))
+                return out
+            return f
+
+        torch.rand = wrap("rand", s[0])
+        torch.rand_like = wrap("rand_like", s[1])
+        torch.randperm = wrap("randperm", s[2])
+        torch.randint = wrap("randint", s[3])
+        torch.Tensor.uniform_ = wrap("uniform_", s[4])
+        np.random.randint = wrap("np_randint", s[5])
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.rand_like, torch.randperm, torch.randint, torch.Tensor.uniform_, np.random.randint = self._saved
+
+
+def small_conf(K, S, beta, L=4, base=4, end=32, logmap=10, width=64, feat=32, use_bg_reg=True):
+    return Conf(
+        feature_vector_size=feat, scene_bounding_sphere=1.0, use_bg_reg=use_bg_reg, render_bg_iter=10,
+        implicit_network=dict(d_in=3, d_out=K, dims=[width, width], geometric_init=True, bias=0.9, skip_in=[4], weight_norm=True,
+                              multires=6, inside_outside=True, use_grid_feature=True, divide_factor=1.0, sigmoid=10,
+                              color_grid_feature=True, base_size=base, end_size=end, logmap=logmap, num_levels=L, level_dim=2),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[width, width], weight_norm=True, multires_view=4, multires_point=4,
+                               multires_normal=4),
+        density=dict(params_init=dict(beta=beta), beta_min=0.0001),
+        ray_sampler=dict(near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10, max_total_iters=5),
+    )
+
+
+def look_at_pose(eye):
+    eye = np.asarray(eye, dtype=np.float64)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0.0, 0.0, 1.0]) if abs(fwd[2]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    P = np.eye(4)
+    P[:3, 0], P[:3, 1], P[:3, 2], P[:3, 3] = right, down, fwd, eye
+    return torch.from_numpy(P).float()[None]
+
+
+def batch(R, K, res, seed):
+    g = torch.Generator().manual_seed(seed)
+    uv = torch.randint(0, res, (1, R, 2), generator=g).float()
+    intr = torch.eye(4)[None].clone()
+    intr[0, 0, 0] = intr[0, 1, 1] = res / 2
+    intr[0, 0, 2] = intr[0, 1, 2] = res / 2
+    gt = dict(rgb=torch.rand(1, R, 3, generator=g), depth=torch.rand(1, R, 1, generator=g) * 0.9 + 0.1,
+              normal=torch.nn.functional.normalize(torch.randn(1, R, 3, generator=g), dim=-1), mask=torch.ones(1, R, 1),
+              segs=torch.randint(0, K, (1, R, 1), generator=g))
+    return uv, intr, gt
+
+
+def perturb(model, seed, scale=1e-2, emb_scale=2e-2):
+    """Leave the dead-gradient state of geometric init and make the grids matter."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        v = model.implicit_network.lin0.weight_v
+        v[:, 3:] = torch.randn(v[:, 3:].shape, generator=g) * scale
+        for enc in (model.implicit_network.encoding, model.implicit_network.color_encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * emb_scale)
+
+
+def to_np(prefix, d, out):
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[f"{prefix}{k}"] = v.detach().cpu().numpy().copy()
+
+
+def name_draws(draws, bg):
+    """Map the call-ordered draw log onto the names the oracle/product use."""
+    it = iter(draws)
+
+    def take(kind):
+        k, v = next(it)
+        assert k == kind, (k, kind)
+        return v
+
+    named = {"ray_offset": take("rand_like") - 0.5, "t_rand": take("rand"), "u_final": take("rand"),
+             "perm": take("randperm"), "eik_idx": take("randint"), "eik_uniform": take("uniform_"),
+             "eik_jitter": take("rand_like")}
+    if bg:
+        x0 = take("np_randint").reshape(-1)[0]
+        y0 = take("np_randint").reshape(-1)[0]
+        named["bg_xy0"] = np.array([x0, y0])
+        named.update({"bg.t_rand": take("rand"), "bg.u_final": take("rand"), "bg.perm": take("randperm"),
+                      "bg.eik_idx": take("randint")})
+    rest = list(it)
+    assert not rest, [k for k, _ in rest]
+    return named
+
+
+def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, seed, res=64, adam_steps=2):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    conf = small_conf(K, S, beta)
+    model = Net(conf=conf, graph_node_dict=None, num_images=4)
+    model.train()
+    perturb(model, seed + 1)
+    loss_fn = Loss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
+                   normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0,
+                   reg_vio_weight=0.01, bg_reg_weight=0.01, depth_type="marigold")
+    uv, intr, gt = batch(R, K, res, seed + 2)
+    pose = look_at_pose(eye)
+    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.iter_step": iter_step, "meta.call_reg": int(call_reg), "meta.res": res,
+           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+    to_np("state.", model.state_dict(), rec)
+    to_np("in.", dict(uv=uv, pose=pose, intrinsics=intr), rec)
+    to_np("gt.", gt, rec)
+    lr, lr_grid = 5e-4, 5e-4 * 20
+    opt = torch.optim.Adam([
+        {"params": list(model.implicit_network.grid_parameters()), "lr": lr_grid},
+        {"params": list(model.implicit_network.mlp_parameters()) + list(model.rendering_network.parameters()), "lr": lr},
+        {"params": list(model.density.parameters()), "lr": lr}], betas=(0.9, 0.99), eps=1e-15)
+    for step in range(adam_steps):
+        opt.zero_grad()
+        with DrawLog() as log:
+            out = model({"intrinsics": intr, "uv": uv.clone(), "pose": pose}, torch.tensor([0]), iter_step=iter_step)
+        out["iter_step"] = iter_step
+        lo = loss_fn(out, gt, call_reg=call_reg)
+        lo["loss"].backward()
+        if step == 0:
+            draws = name_draws(log.draws, bg="bg_depth_values" in out)
+            for k, v in draws.items():
+                rec[f"rand.{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+            to_np("out.", {k: v for k, v in out.items() if torch.is_tensor(v)}, rec)
+            to_np("loss.", lo, rec)
+            to_np("grad.", {k: p.grad for k, p in model.named_parameters() if p.grad is not None}, rec)
+            rec["meta.has_bg"] = int("bg_depth_values" in out)
+            # sampler round count is not exposed by the reference; recover it from the merged sample count
+        opt.step()
+        if step == 0:
+            to_np("adam1.", dict(model.named_parameters()), rec)
+        break  # later Adam steps need fresh draws; one step pins the optimiser arithmetic
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  loss={float(lo['loss']):.6f}  N={out['z_vals'].shape[1]}")
+
+
+def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
+    torch.manual_seed(seed)
+    conf = small_conf(K, S, beta)
+    model = Net(conf=conf, graph_node_dict=None, num_images=4)
+    model.train(train)
+    perturb(model, seed + 1, scale=1e-3, emb_scale=1e-3)
+    uv, intr, _ = batch(R, K, res, seed + 2)
+    pose = look_at_pose(eye)
+    from utils import rend_util
+    dirs, loc = rend_util.get_camera_params(uv.clone(), pose, intr)
+    d = dirs.reshape(-1, 3)
+    o = loc[:, None].repeat(1, R, 1).reshape(-1, 3)
+    # count rounds by counting SDF sweeps
+    calls = []
+    orig = model.implicit_network.get_sdf_vals
+    model.implicit_network.get_sdf_vals = lambda p: (calls.append(p.shape[0]), orig(p))[1]
+    with DrawLog() as log:
+        z, z_eik = model.ray_sampler.get_z_vals(d, o, model)
+    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.train": int(train), "meta.rounds": len(calls),
+           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+    to_np("state.", model.state_dict(), rec)
+    to_np("in.", dict(ray_dirs=d, cam_loc=o), rec)
+    names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
+    assert len(log.draws) == len(names), [k for k, _ in log.draws]
+    for n, (_, v) in zip(names, log.draws):
+        rec[f"rand.{n}"] = v.numpy()
+    to_np("out.", dict(z_vals=z, z_samples_eik=z_eik), rec)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  rounds={len(calls)}  z={tuple(z.shape)}")
+
+
+def run_hash(name, *, L, base, end, logmap, B, seed, D=3, C=2):
+    """Hash-kernel vectors straight from the C oracle (the reference kernels are CUDA-only)."""
+    g = torch.Generator().manual_seed(seed)
+    pls = hash_oracle.per_level_scale_for(base, end, L)
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, logmap, D))
+    emb = (torch.rand(int(offs[-1]), C, generator=g) * 2 - 1) * 0.5
+    x = torch.rand(B, D, generator=g) * 1.2 - 0.1            # some points outside [0,1]
+    x[:8] = torch.tensor([[0.0] * D, [1.0] * D, [0.5] * D, [1.0, 0.0, 0.5][:D], [0.0, 1.0, 1.0][:D], [0.25] * D, [0.75] * D,
+                          [1.0, 1.0, 0.0][:D]])
+    S, H = float(np.log2(pls)), base
+    out, dydx = hash_oracle.fwd(x, emb, offs, S, H, True)
+    grad = torch.randn(L, B, C, generator=g)
+    gx, gemb = hash_oracle.bwd(grad, x, emb, offs, S, H, True, dydx)
+    ggx = torch.randn(B, D, generator=g)
+    gg, g2 = hash_oracle.bwd2(grad, x, emb, offs, S, H, dydx, ggx)
+    scale, res, tab = hash_oracle.level_table(offs, S, H)
+    rec = dict(L=L, base=base, end=end, logmap=logmap, S=np.float32(S), x=x.numpy(), emb=emb.numpy(), offsets=offs.numpy(),
+               out=out.numpy(), dydx=dydx.numpy(), grad=grad.numpy(), grad_x=gx.numpy(), grad_emb=gemb.numpy(), ggx=ggx.numpy(),
+               grad_grad=gg.numpy(), grad2_emb=g2.numpy(), scale=scale.numpy(), resolution=res.numpy(), table=tab.numpy())
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_tables():
+    """Offsets/per-level-scale tables of the BASELINE configs from the reference's HashEncoder ctor."""
+    from hashencoder.hashgrid import HashEncoder
+    rec = {}
+    for tag, (L, base, end, logmap) in {"stock": (16, 16, 2048, 19), "c1": (8, 16, 256, 15), "tiny": (4, 4, 32, 10)}.items():
+        enc = HashEncoder(input_dim=3, num_levels=L, level_dim=2, per_level_scale=2, base_resolution=base, log2_hashmap_size=logmap,
+                          desired_resolution=end)
+        rec[f"{tag}.offsets"] = enc.offsets.numpy()
+        rec[f"{tag}.per_level_scale"] = np.float64(enc.per_level_scale)
+        rec[f"{tag}.cfg"] = np.array([L, base, end, logmap])
+    np.savez_compressed(os.path.join(HERE, "hash_tables.npz"), **rec)
+    print("hash_tables: ok")
+
+
+def main():
+    Net, Loss = _install_reference()
+    run_tables()
+    run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
+    run_hash("hash_mid", L=8, base=16, end=256, logmap=12, B=400, seed=1)
+    run_iteration(Net, Loss, "iter_k3_bg", K=3, S=16, R=40, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=10)
+    run_iteration(Net, Loss, "iter_k5", K=5, S=16, R=40, beta=0.1, eye=(0.0, 0.1, 0.6), iter_step=3, call_reg=False, seed=20)
+    # (S, beta, eye) chosen by a scan so the sampler takes 1, 2, 3, 4 and 5 rounds
+    cases = [(32, 0.3, (0.7, 0, 0)), (64, 0.1, (0.7, 0, 0)), (32, 0.1, (0, 0, 0.6)), (64, 0.01, (0, 0, 0.6)), (32, 0.01, (0.7, 0, 0))]
+    for i, (S, beta, eye) in enumerate(cases):
+        run_sampler(Net, f"sampler_{i}", K=2, S=S, R=24, beta=beta, eye=eye, seed=1)
+    run_sampler(Net, "sampler_eval", K=2, S=32, R=24, beta=0.1, eye=(0, 0, 0.6), seed=1, train=False)
+
+
+if __name__ == "__main__":
+    main()

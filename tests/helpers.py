@@ -1,0 +1,40 @@
+"""Shared loaders for the golden fixtures (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def section(rec, prefix, as_torch=True):
+    out = {}
+    for k, v in rec.items():
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(v) if as_torch else v
+    return out
+
+
+def oracle_cfg(rec, **extra):
+    from oracle.stage1_oracle import Cfg
+    m = {k[5:]: int(v) for k, v in rec.items() if k.startswith("meta.")}
+    beta = float(rec["state.density.beta"])
+    S = m["S"]
+    return Cfg(feature_vector_size=m["feat"], d_out=m["K"], dims=(m["width"],) * 2, render_dims=(m["width"],) * 2,
+               num_levels=m["L"], base_size=m["base"], end_size=m["end"], logmap=m["logmap"], beta_init=beta,
+               N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, **extra)
+
+
+def rand_dict(rec):
+    r = section(rec, "rand.")
+    out = {k: v for k, v in r.items() if not k.startswith("bg.")}
+    bg = {k[3:]: v for k, v in r.items() if k.startswith("bg.")}
+    if bg:
+        out["bg"] = bg
+    if "bg_xy0" in out:
+        out["bg_xy0"] = tuple(int(v) for v in out["bg_xy0"])
+    return out
