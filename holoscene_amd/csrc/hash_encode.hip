@@ -1,0 +1,574 @@
+// holoscene_amd/csrc/hash_encode.hip -- multiresolution hash-grid encoder for gfx950 (MI355X).
+//
+// Hand-written replacement for the reference's five CUDA kernels
+// (hashencoder/src/hashencoder.cu:104-595); results are bit-identical to
+// oracle/hash_oracle.c for the forward / dy_dx / input-backward / grad_grad
+// paths (same operation order, -ffp-contract=off) and equal up to float
+// atomic-add ordering for the two scatter paths.
+//
+// MI355X notes
+//  * one lane = one (point, level); a wave covers 64 consecutive points of ONE
+//    level, so coordinate loads and level-major stores are fully coalesced and
+//    every level parameter lives in SGPRs;
+//  * the 8 corner gathers of a lane are issued back to back (8 outstanding
+//    global_load_dwordx2) before the first use;
+//  * schedule 1 pins each level to one XCD (blocks are dealt to XCDs round
+//    robin), so a 4 MiB hashed level stays in that XCD's private 4 MiB L2
+//    instead of all 16 levels (48.8 MB) competing for every L2;
+//  * dy_dx may be written level-major ([L,B,D*C]) so that each wave writes one
+//    contiguous 64*D*C*4-byte run;
+//  * scatter uses hardware fp32 L2 atomics (global_atomic_add_f32); NULL
+//    outputs skip whole phases (no scatter when only d/dx is needed).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "holoscene_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct LevelScales {
+    float v[HS_MAX_LEVELS];
+};
+
+struct LevelInfo {
+    float scale;
+    uint32_t res;
+    uint32_t table;
+    uint32_t offset;
+    bool hashed;
+};
+
+__device__ __forceinline__ float smoothstep(float t) { return t * t * (3.0f - 2.0f * t); }
+__device__ __forceinline__ float smoothstep_d(float t) { return 6 * t * (1.0f - t); }
+
+// blockIdx.x -> (level, chunk).  Schedule 1: block b lands on XCD b%8; XCD x owns
+// levels {x, 15-x, 16+x, 31-x, ...} so cheap coarse and expensive fine levels pair up.
+__device__ __forceinline__ void decode_block(uint32_t L, uint32_t n_chunks, int schedule, uint32_t &level, uint32_t &chunk) {
+    const uint32_t bid = blockIdx.x;
+    if (schedule == 1) {
+        const uint32_t xcd = bid & 7u, j = bid >> 3;
+        const uint32_t slot = j / n_chunks;
+        chunk = j - slot * n_chunks;
+        level = (slot & 1u) ? (slot * 8u + 7u - xcd) : (slot * 8u + xcd);
+    } else {
+        level = bid / n_chunks;
+        chunk = bid - level * n_chunks;
+    }
+    (void)L;
+}
+
+template <int D>
+__device__ __forceinline__ LevelInfo level_info(const int32_t *__restrict__ offsets, uint32_t level, const LevelScales &sc) {
+    LevelInfo li;
+    li.offset = (uint32_t)offsets[level];
+    li.table = (uint32_t)offsets[level + 1] - li.offset;
+    li.scale = sc.v[level];
+    li.res = (uint32_t)ceilf(li.scale) + 1u;
+    uint32_t stride = 1;
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (stride <= li.table) stride *= li.res;
+    li.hashed = stride > li.table;
+    return li;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t cell_index(const LevelInfo &li, const uint32_t g[D]) {
+    uint32_t idx;
+    if (li.hashed) {
+        idx = g[0];
+        if (D > 1) idx ^= g[1] * 2654435761u;
+        if (D > 2) idx ^= g[2] * 805459861u;
+    } else {
+        uint32_t stride = 1;
+        idx = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            idx += g[d] * stride;
+            stride *= li.res;
+        }
+    }
+    if ((li.table & (li.table - 1u)) == 0u) return idx & (li.table - 1u);
+    return idx >= li.table ? idx % li.table : idx;
+}
+
+// returns false for points outside [0,1]^D
+template <int D>
+__device__ __forceinline__ bool locate(const float *__restrict__ x, const LevelInfo &li, uint32_t g[D], float w[D], float dw[D]) {
+    float p[D];
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        p[d] = x[d];
+        inside = inside && !(p[d] < 0.f || p[d] > 1.f);
+    }
+    if (!inside) return false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        float pos = p[d] * li.scale;
+        const float fl = floorf(pos);
+        g[d] = (uint32_t)fl;
+        pos -= (float)g[d];
+        dw[d] = smoothstep_d(pos);
+        w[d] = smoothstep(pos);
+    }
+    return true;
+}
+
+template <int C>
+struct Vec {
+    float v[C];
+};
+
+template <int C>
+__device__ __forceinline__ Vec<C> load_entry(const float *__restrict__ p) {
+    Vec<C> r;
+    if constexpr (C == 1) {
+        r.v[0] = p[0];
+    } else if constexpr (C == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; i += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + i);
+            r.v[i] = t.x; r.v[i + 1] = t.y; r.v[i + 2] = t.z; r.v[i + 3] = t.w;
+        }
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int D, int C, bool DYDX>
+__global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__ x, const float *__restrict__ emb,
+                                                        const int32_t *__restrict__ offsets, float *__restrict__ out,
+                                                        float *__restrict__ dydx, uint32_t B, uint32_t L, LevelScales sc,
+                                                        hsHashLayout lay, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    const uint32_t b = chunk * kThreads + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    const float *__restrict__ grid = emb + (size_t)li.offset * C;
+    float *o = out + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+    float *j = DYDX ? dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride : nullptr;
+
+    uint32_t g[D];
+    float w[D], dw[D];
+    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
+#pragma unroll
+        for (int c = 0; c < C; c++) o[c] = 0.f;
+        if (DYDX) {
+#pragma unroll
+            for (int i = 0; i < D * C; i++) j[i] = 0.f;
+        }
+        return;
+    }
+    // issue all 2^D gathers first
+    Vec<C> e[1 << D];
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
+        e[corner] = load_entry<C>(grid + (size_t)cell_index<D>(li, gl) * C);
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        float wt = 1.f;
+#pragma unroll
+        for (int d = 0; d < D; d++) wt *= ((corner >> d) & 1) ? w[d] : 1 - w[d];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] += wt * e[corner].v[c];
+    }
+    if constexpr (C == 2) {
+        *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) o[c] = acc[c];
+    }
+    if (DYDX) {
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            float ga[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) ga[c] = 0.f;
+#pragma unroll
+            for (int k = 0; k < (1 << (D - 1)); k++) {
+                float wt = li.scale;
+                int bits = 0;
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((k >> nd) & 1) { wt *= w[d]; bits |= 1 << d; }
+                    else wt *= 1 - w[d];
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) ga[c] += wt * (e[bits | (1 << gd)].v[c] - e[bits].v[c]) * dw[gd];
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) j[gd * C + c] = ga[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ first backward: scatter
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__restrict__ grad, const float *__restrict__ x,
+                                                                const int32_t *__restrict__ offsets, float *__restrict__ gemb,
+                                                                uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    const uint32_t b = chunk * kThreads + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    uint32_t g[D];
+    float w[D], dw[D];
+    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
+    const float *go = grad + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+    float gv[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) gv[c] = go[c];
+    float *gg = gemb + (size_t)li.offset * C;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        float wt = 1.f;
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int hi = (corner >> d) & 1;
+            wt *= hi ? w[d] : 1 - w[d];
+            gl[d] = g[d] + hi;
+        }
+        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, wt * gv[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ first backward: d/dx
+// grad_x[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (hashencoder.cu:347-372; same summation order)
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_input(const float *__restrict__ grad, const float *__restrict__ dydx,
+                                                              float *__restrict__ gx, uint32_t B, uint32_t L, hsHashLayout lay) {
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    float r[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) r[d] = 0.f;
+    for (uint32_t l = 0; l < L; l++) {
+        const float *go = grad + (int64_t)l * lay.level_stride + (int64_t)b * lay.point_stride;
+        const float *j = dydx + (int64_t)l * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float gc = go[c];
+#pragma unroll
+            for (int d = 0; d < D; d++) r[d] += gc * j[d * C + c];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) gx[(size_t)b * D + d] = r[d];
+}
+
+// ------------------------------------------------------------------------------------ second backward
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict__ grad, const float *__restrict__ x,
+                                                         const int32_t *__restrict__ offsets, const float *__restrict__ dydx,
+                                                         const float *__restrict__ ggx, float *__restrict__ grad_grad,
+                                                         float *__restrict__ g2emb, uint32_t B, uint32_t L, LevelScales sc,
+                                                         hsHashLayout lay, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    const uint32_t b = chunk * kThreads + threadIdx.x;
+    if (b >= B) return;
+    float gx[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) gx[d] = ggx[(size_t)b * D + d];
+    const int64_t foff = (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+    if (grad_grad) {  // hashencoder.cu:376-428
+        const float *j = dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            float r = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d++) r += gx[d] * j[d * C + c];
+            grad_grad[foff + c] = r;
+        }
+    }
+    if (!g2emb) return;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    uint32_t g[D];
+    float w[D], dw[D];
+    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
+    float gv[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) gv[c] = grad[foff + c];
+    float cache[(1 << D) * C];  // hashencoder.cu:507-549
+#pragma unroll
+    for (int i = 0; i < (1 << D) * C; i++) cache[i] = 0.f;
+#pragma unroll
+    for (int gd = 0; gd < D; gd++) {
+#pragma unroll
+        for (int k = 0; k < (1 << (D - 1)); k++) {
+            float wt = li.scale;
+            int bits = 0;
+#pragma unroll
+            for (int nd = 0; nd < D - 1; nd++) {
+                const int d = (nd >= gd) ? nd + 1 : nd;
+                if ((k >> nd) & 1) { wt *= w[d]; bits |= 1 << d; }
+                else wt *= 1 - w[d];
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float v = wt * gv[c] * gx[gd] * dw[gd];
+                cache[(bits | (1 << gd)) * C + c] += v;
+                cache[bits * C + c] -= v;
+            }
+        }
+    }
+    float *gg = g2emb + (size_t)li.offset * C;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
+        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, cache[corner * C + c]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------ value+Jacobian backward
+// grad_emb += d<feat, g_feat>/dE + d<dy_dx, g_dydx>/dE in ONE scatter pass.  The second term is the
+// reference's second-backward embedding kernel (hashencoder.cu:432-595) with its rank-one cotangent
+// grad[l,b,c]*ggx[b,d] generalised to an arbitrary g_dydx[l,b,d,c]; like the reference it ignores
+// d/dx of dy_dx (hashgrid.py:101).
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restrict__ g_feat, const float *__restrict__ g_dydx,
+                                                            const float *__restrict__ x, const int32_t *__restrict__ offsets,
+                                                            float *__restrict__ gemb, uint32_t B, uint32_t L, LevelScales sc,
+                                                            hsHashLayout lay, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    const uint32_t b = chunk * kThreads + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    uint32_t g[D];
+    float w[D], dw[D];
+    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
+    float cache[(1 << D) * C];
+#pragma unroll
+    for (int i = 0; i < (1 << D) * C; i++) cache[i] = 0.f;
+    if (g_feat) {
+        const float *go = g_feat + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+        float gv[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) gv[c] = go[c];
+#pragma unroll
+        for (int corner = 0; corner < (1 << D); corner++) {
+            float wt = 1.f;
+#pragma unroll
+            for (int d = 0; d < D; d++) wt *= ((corner >> d) & 1) ? w[d] : 1 - w[d];
+#pragma unroll
+            for (int c = 0; c < C; c++) cache[corner * C + c] = wt * gv[c];
+        }
+    }
+    if (g_dydx) {
+        const float *gj = g_dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
+        float G[D * C];
+#pragma unroll
+        for (int i = 0; i < D * C; i++) G[i] = gj[i];
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+#pragma unroll
+            for (int k = 0; k < (1 << (D - 1)); k++) {
+                float wt = li.scale;
+                int bits = 0;
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((k >> nd) & 1) { wt *= w[d]; bits |= 1 << d; }
+                    else wt *= 1 - w[d];
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float v = wt * G[gd * C + c] * dw[gd];
+                    cache[(bits | (1 << gd)) * C + c] += v;
+                    cache[bits * C + c] -= v;
+                }
+            }
+        }
+    }
+    float *gg = gemb + (size_t)li.offset * C;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
+        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, cache[corner * C + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+LevelScales make_scales(uint32_t L, float S, uint32_t H) {
+    LevelScales sc;
+    for (uint32_t l = 0; l < HS_MAX_LEVELS; l++) sc.v[l] = l < L ? exp2f((float)l * S) * (float)H - 1.0f : 0.f;  // hashencoder.cu:152
+    return sc;
+}
+
+hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    hsHashLayout lay;
+    lay.level_stride = (int64_t)B * C;  // [L,B,C]
+    lay.point_stride = C;
+    lay.dydx_level_stride = (int64_t)D * C;  // [B,L,D,C]
+    lay.dydx_point_stride = (int64_t)L * D * C;
+    lay.schedule = 0;
+    return lay;
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+bool dims_ok(uint32_t D, uint32_t C, uint32_t L) { return (D == 2 || D == 3) && (C == 1 || C == 2 || C == 4 || C == 8) && L >= 1 && L <= HS_MAX_LEVELS; }
+
+template <int V>
+using Int = std::integral_constant<int, V>;
+
+// Calls f(Int<D>{}, Int<C>{}) for the runtime (D, C) pair; dims_ok() has already vetted them.
+template <class F>
+void dispatch_dc(uint32_t D, uint32_t C, F &&f) {
+    auto with_c = [&](auto d) {
+        switch (C) {
+            case 1: f(d, Int<1>{}); break;
+            case 2: f(d, Int<2>{}); break;
+            case 4: f(d, Int<4>{}); break;
+            default: f(d, Int<8>{}); break;
+        }
+    };
+    if (D == 3) with_c(Int<3>{});
+    else with_c(Int<2>{});
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs, uint32_t B, uint32_t D,
+                uint32_t C, uint32_t L, float S, uint32_t H, float *dy_dx, const hsHashLayout *layout, void *stream) {
+    if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;  // empty batches carry NULL data pointers
+    if (!inputs || !embeddings || !offsets || !outputs || !layout) return HS_ERR_NULL;
+    hsHashLayout lay = *layout;
+    if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
+    const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
+    const LevelScales sc = make_scales(L, S, H);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(n_chunks * L), block(kThreads);
+    dispatch_dc(D, C, [&](auto d, auto c) {
+        constexpr int D_ = decltype(d)::value, C_ = decltype(c)::value;
+        if (dy_dx)
+            k_hash_fwd<D_, C_, true><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
+        else
+            k_hash_fwd<D_, C_, false><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
+    });
+    return check_launch();
+}
+
+int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
+                void *stream) {
+    if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!grad || !inputs || !offsets || !layout) return HS_ERR_NULL;
+    if (grad_inputs && !dy_dx) return HS_ERR_NULL;
+    hsHashLayout lay = *layout;
+    if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
+    const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_embeddings) {
+        const LevelScales sc = make_scales(L, S, H);
+        dispatch_dc(D, C, [&](auto d, auto c) {
+            k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
+                grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+        });
+    }
+    if (grad_inputs)
+        dispatch_dc(D, C, [&](auto d, auto c) {
+            k_hash_bwd_input<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks), dim3(kThreads), 0, st>>>(grad, dy_dx, grad_inputs, B, L, lay);
+        });
+    return check_launch();
+}
+
+int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                 float S, uint32_t H, const float *dy_dx, const float *grad_grad_inputs, float *grad_grad, float *grad2_embeddings,
+                 const hsHashLayout *layout, void *stream) {
+    if (!dims_ok(D, C, L) || C < 2) return HS_ERR_ARG;  // C == 1 unsupported, as in the reference (hashencoder.cu:678-684)
+    if (B == 0 || (!grad_grad && !grad2_embeddings)) return HS_OK;
+    if (!grad || !inputs || !offsets || !dy_dx || !grad_grad_inputs || !layout) return HS_ERR_NULL;
+    hsHashLayout lay = *layout;
+    if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
+    const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
+    const LevelScales sc = make_scales(L, S, H);
+    hipStream_t st = (hipStream_t)stream;
+    dispatch_dc(D, C, [&](auto d, auto c) {
+        k_hash_bwd2<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
+            grad, inputs, offsets, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, B, L, sc, lay, n_chunks);
+    });
+    return check_launch();
+}
+
+int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
+                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream) {
+    if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    if (B == 0 || (!g_feat && !g_dydx)) return HS_OK;
+    if (!inputs || !offsets || !grad_embeddings || !layout) return HS_ERR_NULL;
+    hsHashLayout lay = *layout;
+    if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
+    const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
+    const LevelScales sc = make_scales(L, S, H);
+    hipStream_t st = (hipStream_t)stream;
+    dispatch_dc(D, C, [&](auto d, auto c) {
+        k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
+            g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+    });
+    return check_launch();
+}
+
+// ---- reference-compatible entry points (hashencoder/src/bindings.cpp:5-9)
+int hs_hash_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs, uint32_t B, uint32_t D,
+                           uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, float *dy_dx, void *stream) {
+    if (B != 0 && calc_grad_inputs && !dy_dx) return HS_ERR_NULL;
+    const hsHashLayout lay = reference_layout(B, D, C, L);
+    return hs_hash_fwd(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs ? dy_dx : nullptr, &lay, stream);
+}
+
+int hs_hash_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, float *grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, const float *dy_dx,
+                            float *grad_inputs, void *stream) {
+    (void)embeddings;
+    if (B != 0 && (!grad_embeddings || (calc_grad_inputs && (!dy_dx || !grad_inputs)))) return HS_ERR_NULL;
+    const hsHashLayout lay = reference_layout(B, D, C, L);
+    return hs_hash_bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, calc_grad_inputs ? grad_inputs : nullptr, &lay, stream);
+}
+
+int hs_hash_encode_second_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets, uint32_t B,
+                                   uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, const float *dy_dx,
+                                   const float *grad_grad_inputs, float *grad_grad, float *grad2_embeddings, void *stream) {
+    (void)embeddings;
+    (void)calc_grad_inputs;
+    if (B != 0 && (!grad_grad || !grad2_embeddings)) return HS_ERR_NULL;
+    const hsHashLayout lay = reference_layout(B, D, C, L);
+    return hs_hash_bwd2(grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, &lay, stream);
+}
+
+}  // extern "C"

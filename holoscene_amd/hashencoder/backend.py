@@ -1,0 +1,149 @@
+"""ctypes binding of libholoscene_hip.so -- the MI355X stand-in for the reference's
+``hashencoder/backend.py`` (which JIT-builds the pybind11 module ``_hash_encoder``,
+backend.py:12-24).
+
+``_backend`` exposes the same three callables with the same positional signature as the
+reference module (hashencoder/src/bindings.cpp:5-9), taking torch tensors, plus the
+strided variants the fused Python layer uses.  There is NO CPU or PyTorch fallback: a
+missing library, a CPU tensor or a non-fp32 tensor raises ``RuntimeError`` (the reference
+raises the same type from TORCH_CHECK, hashencoder.cu:16-19).
+"""
+import ctypes
+import os
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libholoscene_hip.so")
+
+_ERRORS = {-1: "unsupported D/C/size combination (GridEncoding: D must be 2 or 3, C must be 1, 2, 4, or 8)",
+           -2: "HIP kernel launch failed", -3: "required pointer was NULL"}
+
+
+class hsHashLayout(ctypes.Structure):
+    _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
+                ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library (built by holoscene_amd.csrc.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m holoscene_amd.csrc.build` (hipcc, gfx950). "
+                               "There is no CPU fallback for the hash encoder.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.hs_target_arch.restype = ctypes.c_char_p
+        for name in dir_symbols():
+            if name != "hs_target_arch":
+                getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def dir_symbols():
+    """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
+    return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac"]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {_ERRORS.get(rc, rc)}")
+
+
+def _dev(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be a {dtype} tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
+
+
+def point_major_layout(C, L, D):
+    """features [B, L*C]; dy_dx [L, B, D*C] (level stride filled in per call)."""
+    return dict(level_stride=C, point_stride=L * C, dydx_point_stride=D * C)
+
+
+class _HipBackend:
+    # ---- reference-compatible trio (bindings.cpp:5-9)
+    @staticmethod
+    def hash_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx):
+        lib = load_library()
+        _check(lib.hs_hash_encode_forward(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
+                                          _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, int(bool(calc_grad_inputs)),
+                                          _dev(dy_dx, "dy_dx"), _stream()), "hash_encode_forward")
+
+    @staticmethod
+    def hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs):
+        lib = load_library()
+        _check(lib.hs_hash_encode_backward(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(embeddings, "embeddings"),
+                                           _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
+                                           ctypes.c_float(S), H, int(bool(calc_grad_inputs)), _dev(dy_dx, "dy_dx"),
+                                           _dev(grad_inputs, "grad_inputs"), _stream()), "hash_encode_backward")
+
+    @staticmethod
+    def hash_encode_second_backward(grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_grad_inputs,
+                                    grad_grad, grad2_embeddings):
+        lib = load_library()
+        _check(lib.hs_hash_encode_second_backward(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(embeddings, "embeddings"),
+                                                  _dev(offsets, "offsets", torch.int32), B, D, C, L, ctypes.c_float(S), H,
+                                                  int(bool(calc_grad_inputs)), _dev(dy_dx, "dy_dx"),
+                                                  _dev(grad_grad_inputs, "grad_grad_inputs"), _dev(grad_grad, "grad_grad"),
+                                                  _dev(grad2_embeddings, "grad2_embeddings"), _stream()), "hash_encode_second_backward")
+
+    # ---- strided / selective variants (include/holoscene_hip.h section 2); point-major features, level-major dy_dx
+    @staticmethod
+    def _layout(B, D, C, L):
+        return hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE)
+
+    @classmethod
+    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx):
+        lib = load_library()
+        lay = cls._layout(B, D, C, L)
+        _check(lib.hs_hash_fwd(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
+                               _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), ctypes.byref(lay),
+                               _stream()), "hs_hash_fwd")
+
+    @classmethod
+    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs):
+        lib = load_library()
+        lay = cls._layout(B, D, C, L)
+        _check(lib.hs_hash_bwd(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
+                               _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
+                               _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay), _stream()), "hs_hash_bwd")
+
+    @classmethod
+    def bwd2(cls, grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings):
+        lib = load_library()
+        lay = cls._layout(B, D, C, L)
+        _check(lib.hs_hash_bwd2(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32), B, D, C, L,
+                                ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), _dev(grad_grad_inputs, "grad_grad_inputs"),
+                                _dev(grad_grad, "grad_grad"), _dev(grad2_embeddings, "grad2_embeddings"), ctypes.byref(lay),
+                                _stream()), "hs_hash_bwd2")
+
+    @classmethod
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H):
+        lib = load_library()
+        lay = cls._layout(B, D, C, L)
+        _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
+                                   _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
+                                   ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")
+
+
+_backend = _HipBackend()
+
+__all__ = ["_backend", "load_library", "LIB_PATH"]

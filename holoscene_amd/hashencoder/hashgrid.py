@@ -1,0 +1,128 @@
+"""HashEncoder -- same constructor, parameters, buffers and forward contract as the
+reference module (hashencoder/hashgrid.py:107-166), backed by the gfx950 kernels in
+holoscene_amd/csrc/hash_encode.hip.
+
+Differences that do not change results:
+  * features are produced point-major ([B, L*C]) by the kernel, so the reference's
+    permute+reshape copy (hashgrid.py:44) and the [B,L*C]->[L,B,C] copy of the incoming
+    gradient (hashgrid.py:61) disappear;
+  * dy_dx is kept level-major ([L,B,D*C]) for coalesced access;
+  * work whose result autograd does not ask for is skipped (``ctx.needs_input_grad``):
+    e.g. ``autograd.grad(sdf, x, create_graph=True)`` no longer zero-fills and scatters a
+    48.8 MB embedding gradient that nobody reads (reference: hashgrid.py:75-82);
+  * the double-backward structure is unchanged: the first backward is itself a Function
+    whose backward runs the second-backward kernels and, like the reference
+    (hashgrid.py:101), returns no gradient for the inputs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import backend as _be
+
+
+class _hash_encode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+        inputs = inputs.contiguous()
+        embeddings = embeddings.contiguous()
+        offsets = offsets.contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=inputs.dtype)
+        dy_dx = torch.empty(L, B, D * C, device=inputs.device, dtype=inputs.dtype) if calc_grad_inputs else None
+        _be._backend.fwd(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H)
+        ctx.calc_grad_inputs = calc_grad_inputs
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        need_x = ctx.calc_grad_inputs and ctx.needs_input_grad[0]
+        need_e = ctx.needs_input_grad[1]
+        grad_inputs, grad_embeddings = _hash_encode_backward.apply(grad.contiguous(), inputs, embeddings, offsets, dy_dx, ctx.dims,
+                                                                   need_x, need_e)
+        return grad_inputs, grad_embeddings, None, None, None, None
+
+
+class _hash_encode_backward(Function):
+    @staticmethod
+    def forward(ctx, grad, inputs, embeddings, offsets, dy_dx, dims, need_x, need_e):
+        B, D, C, L, S, H = dims
+        grad_inputs = torch.empty_like(inputs) if need_x else None
+        grad_embeddings = torch.zeros_like(embeddings) if need_e else None
+        if need_x or need_e:
+            _be._backend.bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs)
+        ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
+        ctx.dims = dims
+        return grad_inputs, grad_embeddings
+
+    @staticmethod
+    def backward(ctx, grad_grad_inputs, _grad_grad_embeddings):
+        grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        if grad_grad_inputs is None or dy_dx is None:
+            return None, None, None, None, None, None, None, None
+        need_gg = ctx.needs_input_grad[0]
+        need_e2 = ctx.needs_input_grad[2]
+        grad_grad = torch.empty_like(grad) if need_gg else None
+        grad2_embeddings = torch.zeros_like(embeddings) if need_e2 else None
+        if need_gg or need_e2:
+            _be._backend.bwd2(grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs.contiguous(), grad_grad, grad2_embeddings)
+        return grad_grad, None, grad2_embeddings, None, None, None, None, None
+
+
+hash_encode = _hash_encode.apply
+
+
+def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size):
+    """Entry offsets of each level (reference: hashgrid.py:127-138)."""
+    cap = 2 ** log2_hashmap_size
+    offs = [0]
+    for i in range(num_levels):
+        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+        offs.append(offs[-1] + min(cap, resolution ** input_dim))
+    return np.asarray(offs, dtype=np.int32)
+
+
+class HashEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None):
+        super().__init__()
+        if desired_resolution is not None:  # overrides per_level_scale (hashgrid.py:112-113)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.max_params = 2 ** log2_hashmap_size
+        offsets = torch.from_numpy(level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size))
+        self.register_buffer("offsets", offsets)
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"HashEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"base_resolution={self.base_resolution} per_level_scale={self.per_level_scale} params={tuple(self.embeddings.shape)}")
+
+    def forward(self, inputs, size=1):
+        # inputs in [-size, size] -> [0, 1] (hashgrid.py:158)
+        inputs = (inputs + size) / (2 * size)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
+        return outputs.view(prefix_shape + [self.output_dim])

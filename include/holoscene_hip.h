@@ -1,0 +1,119 @@
+/*
+ * include/holoscene_hip.h -- C ABI of libholoscene_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for HoloScene's Stage-1 hot path.  Every entry
+ * point takes plain device pointers and sizes, runs asynchronously on the
+ * hipStream_t passed as `stream` (NULL = the null stream), never allocates,
+ * never synchronises, never throws.  Return value: 0 on success, <0 = error:
+ *
+ *   HS_ERR_ARG     (-1)  unsupported D / C / size combination (the reference
+ *                        throws std::runtime_error for these: hashencoder.cu:607,622)
+ *   HS_ERR_LAUNCH  (-2)  hipGetLastError() reported a failed launch
+ *   HS_ERR_NULL    (-3)  a required pointer was NULL
+ *
+ * Ownership follows the reference (hashencoder/hashgrid.py:34-41,75-76,93-94):
+ * the caller allocates every output; buffers documented as "accumulate" must be
+ * zeroed (or hold a running sum) before the call.
+ *
+ * Section 1 mirrors, one to one, the three functions the reference exports
+ * through pybind11 (hashencoder/src/bindings.cpp:5-9, prototypes
+ * hashencoder/src/hashencoder.h:13-15).  Sections 2+ are the fused entry points
+ * the MI355X build adds behind the same Python classes.
+ */
+#ifndef HOLOSCENE_HIP_H
+#define HOLOSCENE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_OK 0
+#define HS_ERR_ARG (-1)
+#define HS_ERR_LAUNCH (-2)
+#define HS_ERR_NULL (-3)
+
+#define HS_MAX_LEVELS 32
+
+/* ------------------------------------------------------------------ 0. library info */
+/* ABI version; bumped whenever a signature below changes. */
+int hs_abi_version(void);
+/* "gfx950" -- the only architecture this library is built for. */
+const char *hs_target_arch(void);
+
+/* ------------------------------------------------------------------ 1. reference-compatible hash encoder
+ *
+ * All tensors float32, contiguous.  offsets is a DEVICE int32[L+1] array (as in
+ * the reference, hashencoder.cu:107,120,151).  S = log2(per_level_scale),
+ * H = base resolution.  D in {2,3}; C in {1,2,4,8} (second backward: C >= 2,
+ * hashencoder.cu:678-684).
+ */
+
+/* Replaces hash_encode_forward (hashencoder.cu:728-751 -> kernel_grid :104-254).
+ *   inputs [B,D] in [0,1] (points outside produce zeros), embeddings [sum_l n_l, C],
+ *   outputs [L,B,C] (written), dy_dx [B, L*D*C] (written iff calc_grad_inputs). */
+int hs_hash_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,
+                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                           int calc_grad_inputs, float *dy_dx, void *stream);
+
+/* Replaces hash_encode_backward (hashencoder.cu:753-783 -> kernel_grid_backward :258-343,
+ * kernel_input_backward :347-372).
+ *   grad [L,B,C]; grad_embeddings [sum n_l, C] ACCUMULATE; grad_inputs [B,D] written iff calc_grad_inputs. */
+int hs_hash_encode_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets,
+                            float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            int calc_grad_inputs, const float *dy_dx, float *grad_inputs, void *stream);
+
+/* Replaces hash_encode_second_backward (hashencoder.cu:786-824 -> kernels :376-595).
+ *   grad_grad_inputs [B,D]; grad_grad [L,B,C] written; grad2_embeddings ACCUMULATE. */
+int hs_hash_encode_second_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets,
+                                   uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                   const float *dy_dx, const float *grad_grad_inputs, float *grad_grad, float *grad2_embeddings,
+                                   void *stream);
+
+/* ------------------------------------------------------------------ 2. strided / selective variants
+ *
+ * Same arithmetic, but (a) feature-like tensors are addressed as
+ *   t[level*level_stride + b*point_stride + c]
+ * so the kernel can read/write the point-major [B, L*C] layout the MLP consumes
+ * without the reference's permute copy (hashgrid.py:44,61), (b) dy_dx is addressed as
+ *   dy_dx[level*dydx_level_stride + b*dydx_point_stride + d*C + c]
+ * (level-major [L,B,D*C] gives coalesced writes), and (c) NULL output pointers
+ * skip the corresponding work (e.g. grad_embeddings == NULL skips the atomic
+ * scatter when only d/dx is wanted, as in autograd.grad(sdf, x)).
+ * `schedule`: 0 = level-major block order, 1 = XCD-affine (level l pinned to one
+ * XCD's L2; needs L % 8 == 0, silently falls back to 0 otherwise).
+ */
+typedef struct hsHashLayout {
+    int64_t level_stride;      /* features / grads */
+    int64_t point_stride;
+    int64_t dydx_level_stride; /* dy_dx */
+    int64_t dydx_point_stride;
+    int32_t schedule;
+} hsHashLayout;
+
+int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,
+                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                float *dy_dx /* NULL = skip */, const hsHashLayout *layout, void *stream);
+
+int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets,
+                float *grad_embeddings /* NULL = skip scatter */, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                const float *dy_dx, float *grad_inputs /* NULL = skip */, const hsHashLayout *layout, void *stream);
+
+int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets,
+                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                 const float *dy_dx, const float *grad_grad_inputs, float *grad_grad /* NULL = skip */,
+                 float *grad2_embeddings /* NULL = skip */, const hsHashLayout *layout, void *stream);
+
+/* Value+Jacobian backward: ONE scatter pass computing
+ *   grad_embeddings += d<features, g_feat>/dE + d<dy_dx, g_dydx>/dE        (ACCUMULATE)
+ * g_feat is addressed like features, g_dydx like dy_dx; either may be NULL.  With
+ * g_dydx[l,b,d,c] = grad[l,b,c]*ggx[b,d] the second term equals the reference's
+ * grad2_embeddings (hashencoder.cu:432-595); like the reference, d/dx of dy_dx is ignored. */
+int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
+                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOLOSCENE_HIP_H */

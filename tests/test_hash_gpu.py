@@ -1,0 +1,170 @@
+"""GPU: HIP hash-grid kernels (through the C ABI) vs the C oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load
+from oracle import hash_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _be():
+    from holoscene_amd.hashencoder.backend import _backend
+    return _backend
+
+
+def _cfg(r):
+    return float(r["S"]), int(r["base"])
+
+
+@pytest.mark.parametrize("name", ["hash_small", "hash_mid"])
+def test_reference_abi_vs_golden(name):
+    """hs_hash_encode_{forward,backward,second_backward}: reference layouts ([L,B,C], dy_dx [B,L*D*C])."""
+    r = load(name)
+    dev = "cuda"
+    x, emb, offs = (torch.from_numpy(r[k]).to(dev) for k in ("x", "emb", "offsets"))
+    S, H = _cfg(r)
+    B, D = x.shape
+    C, L = emb.shape[1], offs.numel() - 1
+    out = torch.empty(L, B, C, device=dev)
+    dydx = torch.empty(B, L * D * C, device=dev)
+    _be().hash_encode_forward(x, emb, offs, out, B, D, C, L, S, H, True, dydx)
+    assert torch.equal(out.cpu(), torch.from_numpy(r["out"])), "forward must be bit-exact"
+    assert torch.equal(dydx.cpu(), torch.from_numpy(r["dydx"])), "dy_dx must be bit-exact"
+    grad = torch.from_numpy(r["grad"]).to(dev)
+    gemb = torch.zeros_like(emb)
+    gx = torch.zeros_like(x)
+    _be().hash_encode_backward(grad, x, emb, offs, gemb, B, D, C, L, S, H, True, dydx, gx)
+    assert torch.equal(gx.cpu(), torch.from_numpy(r["grad_x"])), "input gradient must be bit-exact"
+    # scatter: float atomics, order differs -> tolerance scaled by the number of contributors
+    ref = torch.from_numpy(r["grad_emb"])
+    tol = 1e-6 * np.sqrt(B) * float(ref.abs().max())
+    assert (gemb.cpu() - ref).abs().max() <= tol
+    ggx = torch.from_numpy(r["ggx"]).to(dev)
+    gg = torch.zeros_like(grad)
+    g2 = torch.zeros_like(emb)
+    _be().hash_encode_second_backward(grad, x, emb, offs, B, D, C, L, S, H, True, dydx, ggx, gg, g2)
+    assert torch.equal(gg.cpu(), torch.from_numpy(r["grad_grad"]))
+    ref2 = torch.from_numpy(r["grad2_emb"])
+    assert (g2.cpu() - ref2).abs().max() <= 1e-6 * np.sqrt(B) * float(ref2.abs().max())
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("cfg", [dict(L=8, base=16, end=256, logmap=13, B=3001), dict(L=16, base=16, end=2048, logmap=19, B=20000)])
+def test_strided_variants_vs_oracle(cfg, schedule, monkeypatch):
+    """Point-major features / level-major dy_dx, both block schedules, ragged B, incl. OOB points."""
+    from holoscene_amd.hashencoder import backend
+    monkeypatch.setattr(backend, "SCHEDULE", schedule)
+    g = torch.Generator().manual_seed(7)
+    L, base = cfg["L"], cfg["base"]
+    pls = hash_oracle.per_level_scale_for(base, cfg["end"], L)
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, cfg["logmap"]))
+    emb = (torch.rand(int(offs[-1]), 2, generator=g) * 2 - 1)
+    B = cfg["B"]
+    x = torch.rand(B, 3, generator=g) * 1.1 - 0.05
+    x[:3] = torch.tensor([[0.0, 0, 0], [1.0, 1, 1], [1.0, 0.5, 0.0]])
+    S = float(np.log2(pls))
+    ref_out, ref_dydx = hash_oracle.fwd(x, emb, offs, S, base, True)
+    dev = "cuda"
+    xd, ed, od = x.to(dev), emb.to(dev), offs.to(dev)
+    out = torch.empty(B, L * 2, device=dev)
+    dydx = torch.empty(L, B, 6, device=dev)
+    _be().fwd(xd, ed, od, out, B, 3, 2, L, S, base, dydx)
+    assert torch.equal(out.cpu(), ref_out.permute(1, 0, 2).reshape(B, -1))
+    assert torch.equal(dydx.cpu(), ref_dydx.view(B, L, 6).permute(1, 0, 2))
+    out2 = torch.empty_like(out)
+    _be().fwd(xd, ed, od, out2, B, 3, 2, L, S, base, None)      # no dy_dx variant
+    assert torch.equal(out2, out)
+    grad = torch.randn(L, B, 2, generator=g)
+    ref_gx, ref_ge = hash_oracle.bwd(grad, x, emb, offs, S, base, True, ref_dydx)
+    gpm = grad.permute(1, 0, 2).reshape(B, -1).contiguous().to(dev)
+    ge = torch.zeros_like(ed)
+    gx = torch.empty_like(xd)
+    _be().bwd(gpm, xd, od, ge, B, 3, 2, L, S, base, dydx, gx)
+    assert torch.equal(gx.cpu(), ref_gx)
+    assert (ge.cpu() - ref_ge).abs().max() <= 2e-6 * np.sqrt(B) * float(ref_ge.abs().max())
+    gx_only = torch.empty_like(xd)
+    _be().bwd(gpm, xd, od, None, B, 3, 2, L, S, base, dydx, gx_only)  # scatter skipped
+    assert torch.equal(gx_only, gx)
+    ggx = torch.randn(B, 3, generator=g)
+    ref_gg, ref_g2 = hash_oracle.bwd2(grad, x, emb, offs, S, base, ref_dydx, ggx)
+    gg = torch.empty_like(gpm)
+    g2 = torch.zeros_like(ed)
+    _be().bwd2(gpm, xd, od, B, 3, 2, L, S, base, dydx, ggx.to(dev), gg, g2)
+    assert torch.equal(gg.cpu(), ref_gg.permute(1, 0, 2).reshape(B, -1))
+    assert (g2.cpu() - ref_g2).abs().max() <= 2e-6 * np.sqrt(B) * float(ref_g2.abs().max())
+
+
+@pytest.mark.parametrize("D,C", [(2, 1), (2, 2), (3, 1), (3, 4), (3, 8), (2, 8)])
+def test_other_dims_vs_oracle(D, C):
+    g = torch.Generator().manual_seed(D * 10 + C)
+    L, base = 5, 8
+    pls = 1.5
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, 11, D))
+    emb = torch.rand(int(offs[-1]), C, generator=g) - 0.5
+    B = 777
+    x = torch.rand(B, D, generator=g)
+    S = float(np.log2(pls))
+    ref_out, ref_dydx = hash_oracle.fwd(x, emb, offs, S, base, True)
+    dev = "cuda"
+    out = torch.empty(L, B, C, device=dev)
+    dydx = torch.empty(B, L * D * C, device=dev)
+    _be().hash_encode_forward(x.to(dev), emb.to(dev), offs.to(dev), out, B, D, C, L, S, base, True, dydx)
+    assert torch.equal(out.cpu(), ref_out) and torch.equal(dydx.cpu(), ref_dydx)
+    grad = torch.randn(L, B, C, generator=g)
+    ref_gx, ref_ge = hash_oracle.bwd(grad, x, emb, offs, S, base, True, ref_dydx)
+    ge = torch.zeros(emb.shape, device=dev)
+    gx = torch.zeros(B, D, device=dev)
+    _be().hash_encode_backward(grad.to(dev), x.to(dev), emb.to(dev), offs.to(dev), ge, B, D, C, L, S, base, True, dydx, gx)
+    assert torch.equal(gx.cpu(), ref_gx)
+    assert (ge.cpu() - ref_ge).abs().max() <= 2e-6 * np.sqrt(B) * float(ref_ge.abs().max())
+
+
+def test_empty_batch_and_bad_args():
+    dev = "cuda"
+    offs = torch.from_numpy(hash_oracle.level_offsets(4, 4, 2.0, 10)).to(dev)
+    emb = torch.zeros(int(offs[-1]), 2, device=dev)
+    out = torch.empty(0, 8, device=dev)
+    _be().fwd(torch.empty(0, 3, device=dev), emb, offs, out, 0, 3, 2, 4, 1.0, 4, None)
+    with pytest.raises(RuntimeError):
+        _be().fwd(torch.empty(4, 3, device=dev), emb.double(), offs, torch.empty(4, 8, device=dev), 4, 3, 2, 4, 1.0, 4, None)
+    with pytest.raises(RuntimeError):
+        _be().fwd(torch.empty(4, 5, device=dev), emb, offs, torch.empty(4, 8, device=dev), 4, 5, 2, 4, 1.0, 4, None)
+
+
+def test_full_size_properties():
+    """BASELINE config-2 size (131 072 sampler points, stock 16-level grid): size-independent checks."""
+    from holoscene_amd.hashencoder import HashEncoder
+    torch.manual_seed(0)
+    enc = HashEncoder(desired_resolution=2048).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    B = 1024 * 128
+    x = (torch.rand(B, 3, device="cuda") * 2 - 1)
+    y1 = enc(x)
+    assert y1.shape == (B, 32) and torch.isfinite(y1).all()
+    # linear in the table: enc_{2E}(x) == 2 enc_E(x) exactly (power-of-two scaling)
+    with torch.no_grad():
+        enc.embeddings.mul_(2)
+    assert torch.equal(enc(x), 2 * y1)
+    # points outside the cube give exactly zero
+    far = x.clone()
+    far[::2, 0] = 1.5
+    yz = enc(far)
+    assert (yz[::2] == 0).all() and torch.equal(yz[1::2], enc(x)[1::2])
+    # adjoint: <enc(x), g> == <E, dE>
+    g = torch.randn_like(y1)
+    xr = x.clone().requires_grad_(True)
+    y = enc(xr)
+    (ge,) = torch.autograd.grad(y, enc.embeddings, g, retain_graph=True)
+    lhs = (y.double() * g.double()).sum()
+    rhs = (enc.embeddings.double() * ge.double()).sum()
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+    # d/dx against central differences (interior points of a coarse-only table), via double-backward plumbing
+    (gx,) = torch.autograd.grad(y, xr, g, create_graph=True)
+    assert gx.shape == x.shape and torch.isfinite(gx).all()
+    v = torch.randn_like(gx)
+    (g2,) = torch.autograd.grad((gx * v).sum(), enc.embeddings)
+    # (gx . v) is linear in E: <E, d(gx.v)/dE> == gx.v
+    assert abs((enc.embeddings.double() * g2.double()).sum() - (gx.double() * v.double()).sum()) <= 1e-4 * abs((gx.double() * v.double()).sum())
