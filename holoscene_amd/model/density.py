@@ -1,0 +1,32 @@
+"""Laplace-CDF density of VolSDF (reference: model/density.py:5-30)."""
+import torch
+import torch.nn as nn
+
+
+def laplace_density(sdf, beta):
+    """sigma = (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))   (density.py:21-26)"""
+    return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+class Density(nn.Module):
+    def __init__(self, params_init={}):
+        super().__init__()
+        for name, value in params_init.items():
+            setattr(self, name, nn.Parameter(torch.tensor(value)))
+
+    def forward(self, sdf, beta=None):
+        return self.density_func(sdf, beta=beta)
+
+
+class LaplaceDensity(Density):
+    def __init__(self, params_init={}, beta_min=0.0001):
+        super().__init__(params_init=params_init)
+        self.register_buffer("beta_min", torch.tensor(beta_min), persistent=False)
+
+    def density_func(self, sdf, beta=None):
+        if beta is None:
+            beta = self.get_beta()
+        return laplace_density(sdf, beta)
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min

@@ -1,0 +1,185 @@
+"""Stage-1 objective: MonoSDFLoss / HoloSceneLoss with the reference's constructor arguments,
+``forward`` contract and returned keys (model/loss.py:196-346, :349-666).
+
+Written without data-dependent Python branches: where the reference tests a device scalar in an
+``if`` (``collision_cnt > 0`` loss.py:399, ``divisor == 0`` :533, ...) -- one host sync each -- this
+version divides by ``clamp(count, 1)`` so the value is identical and the stream never stalls.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils.conf import get_class
+
+
+def compute_scale_and_shift_batch(prediction, target):
+    """Least-squares (scale, shift) aligning prediction [B,N] to target [B,N] (loss.py:181-193)."""
+    ones = torch.ones_like(prediction)
+    a00 = (prediction * prediction).sum(1)
+    a01 = prediction.sum(1)
+    a11 = ones.sum(1)
+    b0 = (prediction * target).sum(1)
+    b1 = target.sum(1)
+    M = torch.stack([torch.stack([a00, a01], -1), torch.stack([a01, a11], -1)], -2)  # [B,2,2]
+    rs = (torch.inverse(M) @ torch.stack([b0, b1], -1).unsqueeze(-1)).squeeze(-1)
+    return rs[:, 0], rs[:, 1]
+
+
+def _resolve(cls_or_name):
+    if isinstance(cls_or_name, str):
+        if cls_or_name.startswith("torch.nn."):
+            return getattr(nn, cls_or_name.split(".")[-1])
+        return get_class(cls_or_name)
+    return cls_or_name
+
+
+class MonoSDFLoss(nn.Module):
+    def __init__(self, rgb_loss, eikonal_weight, smooth_weight=0.005, depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05,
+                 uncertainty_begin_iter=20000000, depth_type="marigold", phy_un_weight=50, end_step=-1):
+        super().__init__()
+        self.eikonal_weight = eikonal_weight
+        self.smooth_weight = smooth_weight
+        self.depth_weight = depth_weight
+        self.normal_l1_weight = normal_l1_weight
+        self.normal_cos_weight = normal_cos_weight
+        self.uncertainty_begin_iter = uncertainty_begin_iter
+        self.depth_type = depth_type
+        self.phy_un_weight = phy_un_weight
+        self.rgb_loss = _resolve(rgb_loss)(reduction="mean")
+        self.step = 0
+        self.end_step = end_step
+
+    def get_rgb_loss(self, rgb_values, rgb_gt):
+        return self.rgb_loss(rgb_values, rgb_gt.reshape(-1, 3))
+
+    def get_eikonal_loss(self, grad_theta):
+        return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
+
+    def get_smooth_loss(self, model_outputs):
+        g1, g2 = model_outputs["grad_theta"], model_outputs["grad_theta_nei"]
+        n1 = g1 / (g1.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        n2 = g2 / (g2.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        return torch.norm(n1 - n2, dim=-1).mean()
+
+    def get_depth_loss(self, depth_pred, depth_gt):
+        depth_pred = depth_pred.reshape(1, -1)
+        depth_gt = depth_gt.reshape(1, -1)
+        w, q = compute_scale_and_shift_batch(depth_pred, depth_gt)
+        diff = ((w.reshape(-1, 1) * depth_pred + q.reshape(-1, 1)) - depth_gt) ** 2
+        return torch.clip(diff, max=1).mean()
+
+    def get_normal_loss(self, normal_pred, normal_gt):
+        normal_gt = F.normalize(normal_gt, p=2, dim=-1)
+        normal_pred = F.normalize(normal_pred, p=2, dim=-1)
+        l1 = torch.abs(normal_pred - normal_gt).sum(dim=-1).mean()
+        cos = (1.0 - torch.sum(normal_pred * normal_gt, dim=-1)).mean()
+        return l1, cos
+
+    def forward(self, model_outputs, ground_truth):
+        dev = model_outputs["rgb_values"].device
+        rgb_gt = ground_truth["rgb"].to(dev)
+        depth_gt = ground_truth["depth"].to(dev)
+        normal_gt = ground_truth["normal"].to(dev)
+        zero = torch.zeros((), device=dev)
+        rgb_loss = self.get_rgb_loss(model_outputs["rgb_values"], rgb_gt)
+        eikonal_loss = self.get_eikonal_loss(model_outputs["grad_theta"]) if "grad_theta" in model_outputs else zero
+        # supervise normals only on rays that cross a surface (sign change of the SDF along the ray)
+        sdf = model_outputs["sdf"]
+        mask = ((sdf > 0.0).any(dim=-1) & (sdf < 0.0).any(dim=-1))[None, :, None] & (ground_truth["mask"].to(dev) > 0.5)
+        depth_loss = self.get_depth_loss(model_outputs["depth_values"], depth_gt) if self.depth_weight > 0 else zero
+        normal_l1, normal_cos = self.get_normal_loss(model_outputs["normal_map"][None] * mask, normal_gt)
+        smooth_loss = self.get_smooth_loss(model_outputs)
+        decay = math.exp(-self.step / self.end_step * 10.0) if self.end_step > 0 else 1.0
+        self.step += 1
+        loss = rgb_loss + self.eikonal_weight * eikonal_loss + self.smooth_weight * smooth_loss + decay * self.depth_weight * depth_loss \
+            + decay * self.normal_l1_weight * normal_l1 + decay * self.normal_cos_weight * normal_cos
+        return {"loss": loss, "rgb_loss": rgb_loss, "eikonal_loss": eikonal_loss, "smooth_loss": smooth_loss, "depth_loss": depth_loss,
+                "normal_l1": normal_l1, "normal_cos": normal_cos}
+
+
+class HoloSceneLoss(MonoSDFLoss):
+    def __init__(self, rgb_loss, eikonal_weight, semantic_weight=0.04, smooth_weight=0.005,
+                 semantic_loss=torch.nn.CrossEntropyLoss(ignore_index=-1), depth_weight=0.1, normal_l1_weight=0.05,
+                 normal_cos_weight=0.05, reg_vio_weight=0.1, use_obj_opacity=True, bg_reg_weight=0.1, depth_type="marigold", end_step=-1):
+        super().__init__(rgb_loss=rgb_loss, eikonal_weight=eikonal_weight, smooth_weight=smooth_weight, depth_weight=depth_weight,
+                         normal_l1_weight=normal_l1_weight, normal_cos_weight=normal_cos_weight, depth_type=depth_type, end_step=end_step)
+        self.semantic_weight = semantic_weight
+        self.bg_reg_weight = bg_reg_weight
+        if isinstance(semantic_loss, nn.Module):
+            self.semantic_loss = torch.nn.CrossEntropyLoss(ignore_index=-1, reduction="none")
+        else:
+            self.semantic_loss = _resolve(semantic_loss)(reduction="none")
+        self.reg_vio_weight = reg_vio_weight
+        self.use_obj_opacity = use_obj_opacity
+
+    def get_semantic_loss(self, semantic_value, semantic_gt):
+        return self.semantic_loss(semantic_value, semantic_gt.squeeze()).mean()
+
+    def object_distinct_loss(self, sdf_value, min_sdf):
+        """Penalise any non-minimal object that is also 'inside' where the scene SDF is negative (loss.py:389-403)."""
+        arg = sdf_value.argmin(dim=1, keepdim=True)
+        viol = torch.relu(-sdf_value - min_sdf.detach())
+        viol = viol.scatter(1, arg, 0.0)  # the minimal object itself is exempt
+        count = (viol > 0).sum()
+        return viol.sum() / count.clamp(min=1)
+
+    def object_opacity_loss(self, predict_opacity, gt_opacity, weight=None):
+        target = F.one_hot(gt_opacity.reshape(-1), num_classes=predict_opacity.shape[1]).float()
+        predict_opacity = torch.clip(predict_opacity, 1e-4, 1 - (1e-4))
+        return F.binary_cross_entropy(predict_opacity, target, reduction="none").mean(dim=-1).mean()
+
+    def compute_grad_error(self, x, mask):
+        """Multi-scale masked first-difference magnitude (loss.py:519-547)."""
+        total = torch.zeros((), device=x.device)
+        for i in range(4):
+            step = 2 ** i
+            m = mask[:, ::step, ::step]
+            v = m * x[:, ::step, ::step]
+            gx = (m[:, :, 1:] * m[:, :, :-1]) * torch.abs(v[:, :, 1:] - v[:, :, :-1])
+            gy = (m[:, 1:, :] * m[:, :-1, :]) * torch.abs(v[:, 1:, :] - v[:, :-1, :])
+            divisor = m[:1].sum()
+            total = total + torch.where(divisor > 0, (gx.sum() + gy.sum()) / divisor.clamp(min=1), torch.zeros_like(total))
+        return total
+
+    def get_bg_render_loss(self, bg_depth, bg_normal, mask):
+        bg_depth = bg_depth.reshape(1, 32, 32)
+        bg_normal = bg_normal.reshape(32, 32, 3).permute(2, 0, 1)
+        mask = mask.reshape(1, 32, 32)
+        return self.compute_grad_error(bg_depth, mask) + self.compute_grad_error(bg_normal, mask.repeat(3, 1, 1))
+
+    def forward(self, model_outputs, ground_truth, call_reg=False, call_bg_reg=False):
+        output = super().forward(model_outputs, ground_truth)
+        dev = output["loss"].device
+        zero = torch.zeros((), device=dev)
+        if "semantic_values" in model_outputs and not self.use_obj_opacity:
+            semantic_loss = self.get_semantic_loss(model_outputs["semantic_values"], ground_truth["segs"].to(dev).long())
+        elif "object_opacity" in model_outputs and self.use_obj_opacity:
+            semantic_loss = self.object_opacity_loss(model_outputs["object_opacity"], ground_truth["segs"].to(dev).long())
+        else:
+            semantic_loss = zero
+        if "sample_sdf" in model_outputs and call_reg:
+            if "collision_relations" in model_outputs:
+                raise NotImplementedError("scene-graph collision loss is driven by the Stage-2 trainer (loss.py:405-484)")
+            sample_sdf_loss = self.object_distinct_loss(model_outputs["sample_sdf"], model_outputs["sample_minsdf"])
+        else:
+            sample_sdf_loss = zero
+        if "bg_depth_values" in model_outputs:
+            if "bg_mask" in model_outputs:
+                bg_mask = (model_outputs["bg_mask"] != 0).int()  # smooth only where something occludes the background
+            else:
+                bg_mask = (ground_truth["segs"] != 0).to(dev)
+            background_reg_loss = self.get_bg_render_loss(model_outputs["bg_depth_values"], model_outputs["bg_normal_map"], bg_mask)
+        else:
+            background_reg_loss = zero
+        if "rgb_offset" in model_outputs:
+            rgb_offset_loss = torch.mean(model_outputs["rgb_offset"] ** 2)
+            output["loss"] = output["loss"] + rgb_offset_loss
+            output["rgb_offset_loss"] = rgb_offset_loss
+        output["semantic_loss"] = semantic_loss
+        output["collision_reg_loss"] = sample_sdf_loss
+        output["background_reg_loss"] = background_reg_loss
+        output["loss"] = output["loss"] + self.semantic_weight * semantic_loss + self.reg_vio_weight * sample_sdf_loss \
+            + self.bg_reg_weight * background_reg_loss
+        return output

@@ -1,0 +1,509 @@
+"""Stage-1 networks: ObjectImplicitNetworkGrid, RenderingNetwork, HoloSceneNetwork.
+
+Same class names, constructor arguments, state-dict keys and public methods as the reference
+(model/network.py:19-532, :535-614, :748-971, :1803-1824), re-designed around what the MI355X
+kernels want:
+
+  * value + Jacobian in ONE pass.  The reference obtains d sdf/dx by reverse-mode autograd with
+    ``create_graph=True`` -- once for the rendered points (network.py:293-299) and K+1 times in a
+    Python loop for the Eikonal set (:227-253) -- and then differentiates those graphs a second time
+    in ``loss.backward()``.  Here the SDF trunk carries three input tangents next to the value
+    (a 4-row GEMM per point), which yields the full Jacobian d sdf_k/dx for all K objects at once;
+    the min-SDF gradient is a gather of the arg-min row.  The result is the same function of the
+    parameters, so ordinary first-order backward gives the same parameter gradients.
+  * the hash encoders run as ``hash_encode_jac``: features and dy_dx out, one fused scatter pass
+    back (csrc/hash_encode.hip: k_hash_bwd_jac).
+  * SDF-only queries (the sampler's sweeps) skip the colour grid + colour MLP that the reference
+    evaluates and discards (network.py:177-179, 305-311).
+  * no per-iteration device->host syncs besides the sampler's convergence test.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..hashencoder.hashgrid import HashEncoder
+from ..hashencoder import backend as _be
+from ..utils import rend_util
+from .density import LaplaceDensity, laplace_density
+from .embedder import Embedder
+from .ray_sampler import ErrorBoundSampler
+
+
+# ------------------------------------------------------------------------------------------------
+class _hash_encode_jac(torch.autograd.Function):
+    """(x01, embeddings) -> (features [B, L*C], dy_dx [L, B, D*C]); once differentiable.
+
+    backward: grad_embeddings = d<features,g_f>/dE + d<dy_dx,g_j>/dE in one scatter pass; the
+    gradient w.r.t. x01 is <g_f, dy_dx> (the reference likewise drops d(dy_dx)/dx, hashgrid.py:101).
+    """
+
+    @staticmethod
+    def forward(ctx, x01, embeddings, offsets, S, H):
+        x01 = x01.contiguous()
+        B, D = x01.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        feat = torch.empty(B, L * C, device=x01.device, dtype=x01.dtype)
+        dydx = torch.empty(L, B, D * C, device=x01.device, dtype=x01.dtype)
+        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, H, dydx)
+        ctx.save_for_backward(x01, embeddings, offsets, dydx)
+        ctx.dims = (B, D, C, L, S, H)
+        return feat, dydx
+
+    @staticmethod
+    def backward(ctx, g_feat, g_dydx):
+        x01, embeddings, offsets, dydx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        g_emb = g_x = None
+        if ctx.needs_input_grad[1]:
+            g_emb = torch.zeros_like(embeddings)
+            _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(),
+                                 x01, offsets, g_emb, B, D, C, L, S, H)
+        if ctx.needs_input_grad[0] and g_feat is not None:
+            g_x = torch.empty_like(x01)
+            _be._backend.bwd(g_feat.contiguous(), x01, offsets, None, B, D, C, L, S, H, dydx, g_x)
+        return g_x, g_emb, None, None, None
+
+
+def hash_encode_jac(encoder, x, size=1.0):
+    """HashEncoder.forward plus the Jacobian w.r.t. the *unnormalised* input x:
+    returns feat [B, L*C] and jac [B, D, L*C] with jac[b,d,:] = d feat / d x_d."""
+    x01 = (x + size) / (2 * size)
+    feat, dydx = _hash_encode_jac.apply(x01.view(-1, encoder.input_dim), encoder.embeddings, encoder.offsets,
+                                        float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution))
+    L, B, _ = dydx.shape
+    D, C = encoder.input_dim, encoder.level_dim
+    jac = dydx.view(L, B, D, C).permute(1, 2, 0, 3).reshape(B, D, L * C) * (1.0 / (2 * size))
+    return feat, jac
+
+
+class WNLinear(nn.Module):
+    """Linear layer with weight normalisation, parameter names as ``nn.utils.weight_norm`` produces
+    them (bias, weight_g [out,1], weight_v [out,in]; W = g * v / ||v||_row) so reference checkpoints load."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        lin = nn.Linear(in_features, out_features)
+        self.in_features, self.out_features = in_features, out_features
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.weight_g = nn.Parameter(lin.weight.detach().norm(2, dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(lin.weight.detach().clone())
+
+    def reset_g(self):
+        with torch.no_grad():
+            self.weight_g.copy_(self.weight_v.norm(2, dim=1, keepdim=True))
+
+    @property
+    def weight(self):
+        return torch._weight_norm(self.weight_v, self.weight_g, 0)
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+def softplus100(a):
+    return F.softplus(a, beta=100)
+
+
+def softplus100_grad(a):
+    """d softplus(a; beta=100)/da = sigmoid(100 a) (exactly 1 in fp32 above PyTorch's linear threshold)."""
+    return torch.sigmoid(100.0 * a)
+
+
+class ObjectImplicitNetworkGrid(nn.Module):
+    def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True, bias=1.0, skip_in=(),
+                 weight_norm=True, multires=0, sphere_scale=1.0, inside_outside=False, base_size=16, end_size=2048, logmap=19,
+                 num_levels=16, level_dim=2, divide_factor=1.5, use_grid_feature=True, sigmoid=20, color_grid_feature=False):
+        super().__init__()
+        if not weight_norm or not use_grid_feature:
+            raise NotImplementedError("Stage-1 configs always use weight_norm=True and use_grid_feature=True (confs/*/*.conf)")
+        self.d_out = d_out
+        self.sigmoid = sigmoid
+        self.sdf_bounding_sphere = sdf_bounding_sphere
+        self.sphere_scale = sphere_scale
+        self.color_grid_feature = color_grid_feature
+        self.divide_factor = divide_factor
+        self.use_grid_feature = use_grid_feature
+        self.feature_vector_size = feature_vector_size
+        dims = [d_in] + list(dims) + [d_out if color_grid_feature else d_out + feature_vector_size]
+
+        print(f"[INFO]: using hash encoder with {num_levels} levels, each level with feature dim {level_dim}")
+        print(f"[INFO]: resolution:{base_size} -> {end_size} with hash map size {logmap}")
+        self.encoding = HashEncoder(input_dim=3, num_levels=num_levels, level_dim=level_dim, per_level_scale=2,
+                                    base_resolution=base_size, log2_hashmap_size=logmap, desired_resolution=end_size)
+        self.grid_feature_dim = num_levels * level_dim
+        dims[0] += self.grid_feature_dim
+        if color_grid_feature:
+            self.color_encoding = HashEncoder(input_dim=3, num_levels=num_levels, level_dim=level_dim, per_level_scale=2,
+                                              base_resolution=base_size, log2_hashmap_size=logmap, desired_resolution=end_size)
+            self.color_grid_feature_dim = num_levels * level_dim
+            self.color_grid_feature_map_mlp = nn.Sequential(nn.Linear(self.color_grid_feature_dim, 256), nn.ReLU(),
+                                                            nn.Linear(256, feature_vector_size))
+        self.embedder = None
+        self.embed_fn = None
+        if multires > 0:
+            self.embedder = Embedder(multires, d_in)
+            self.embed_fn = self.embedder.embed
+            dims[0] += self.embedder.out_dim - 3
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if l + 1 in self.skip_in else dims[l + 1]
+            lin = WNLinear(dims[l], out_dim)
+            if geometric_init:  # compositional-scene geometric init (network.py:135-156)
+                with torch.no_grad():
+                    v = lin.weight_v
+                    if l == self.num_layers - 2:
+                        # channel 0 = background (positive inside the room), others = objects of half radius
+                        v[:1].normal_(-math.sqrt(math.pi) / math.sqrt(dims[l]), 0.0001)
+                        v[1:].normal_(math.sqrt(math.pi) / math.sqrt(dims[l]), 0.0001)
+                        lin.bias[:1].fill_(bias)
+                        lin.bias[1:].fill_(-0.5 * bias)
+                    elif multires > 0 and l == 0:
+                        lin.bias.zero_()
+                        v[:, 3:].zero_()
+                        v[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+                    elif multires > 0 and l in self.skip_in:
+                        lin.bias.zero_()
+                        v.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+                        v[:, -(dims[0] - 3):].zero_()
+                    else:
+                        lin.bias.zero_()
+                        v.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+                lin.reset_g()
+            setattr(self, "lin" + str(l), lin)
+        self.softplus = nn.Softplus(beta=100)
+        self.cache_sdf = None
+
+    # ---------------------------------------------------------------- building blocks
+    def _lins(self):
+        return [getattr(self, "lin" + str(l)) for l in range(self.num_layers - 1)]
+
+    def _color_features(self, x):
+        return self.color_grid_feature_map_mlp(self.color_encoding(x / self.divide_factor))
+
+    def _trunk(self, x):
+        """SDF trunk only: x [B,3] -> [B, lin_last.out] (no colour branch)."""
+        feature = self.encoding(x / self.divide_factor)
+        inp = torch.cat((self.embed_fn(x) if self.embed_fn is not None else x, feature), dim=-1)
+        h = inp
+        lins = self._lins()
+        for l, lin in enumerate(lins):
+            if l in self.skip_in:
+                h = torch.cat([h, inp], 1) / np.sqrt(2)
+            h = lin(h)
+            if l < len(lins) - 1:
+                h = softplus100(h)
+        return h
+
+    def sdf_and_jacobian(self, x):
+        """x [B,3] (treated as constant) -> y [B,K'], J [B,K',3] with J[b,k,:] = d y_k / d x.
+        Differentiable w.r.t. every parameter by plain first-order autograd."""
+        x = x.detach()
+        feat, fjac = hash_encode_jac(self.encoding, x / self.divide_factor)
+        fjac = fjac / self.divide_factor
+        if self.embedder is not None:
+            emb, ejac = self.embedder.embed_jacobian(x)
+        else:
+            emb, ejac = x, torch.eye(3, device=x.device, dtype=x.dtype).expand(x.shape[0], 3, 3)
+        inp = torch.cat([emb, feat], -1)              # [B, F]
+        tin = torch.cat([ejac, fjac], -1)             # [B, 3, F]
+        h, t = inp, tin
+        lins = self._lins()
+        for l, lin in enumerate(lins):
+            if l in self.skip_in:
+                h = torch.cat([h, inp], 1) / np.sqrt(2)
+                t = torch.cat([t, tin], 2) / np.sqrt(2)
+            w = lin.weight
+            stacked = torch.cat([h.unsqueeze(1), t], 1)                  # [B,4,in]: value row + 3 tangent rows
+            out = torch.matmul(stacked, w.t())                          # one GEMM, M = 4B
+            a, t = out[:, 0] + lin.bias, out[:, 1:]
+            if l < len(lins) - 1:
+                h = softplus100(a)
+                t = t * softplus100_grad(a).unsqueeze(1)
+            else:
+                h = a
+        return h, t.transpose(1, 2)
+
+    # ---------------------------------------------------------------- reference API
+    def forward(self, input):
+        x = self._trunk(input)
+        if self.color_grid_feature:
+            x = torch.cat([x, self._color_features(input)], dim=-1)
+        return x
+
+    def _min_sdf(self, sdf_raw):
+        sdf, indices = sdf_raw.min(dim=-1, keepdim=True)
+        return sdf, indices
+
+    def gradient(self, x):
+        """[(K+1)*B, 3]: rows k*B..(k+1)*B-1 = d sdf_k/dx, last B rows = d min_k sdf_k/dx (network.py:212-254)."""
+        y, J = self.sdf_and_jacobian(x)
+        y, J = y[:, :self.d_out], J[:, :self.d_out]
+        _, idx = self._min_sdf(y)
+        g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        return torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
+
+    def gradient_obj_i(self, x, obj_i):
+        _, J = self.sdf_and_jacobian(x)
+        return J[:, obj_i]
+
+    def _outputs(self, x):
+        y, J = self.sdf_and_jacobian(x)
+        if self.color_grid_feature:
+            sdf_raw, feature_vectors = y, self._color_features(x)
+        else:
+            sdf_raw, feature_vectors = y[:, :self.d_out], y[:, self.d_out:]
+            J = J[:, :self.d_out]
+        sdf, idx = self._min_sdf(sdf_raw)
+        gradients = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        return sdf, feature_vectors, gradients, sdf_raw, idx, J
+
+    def get_outputs(self, x, beta=None):
+        sdf, feature_vectors, gradients, sdf_raw, _, _ = self._outputs(x)
+        if beta is None:
+            semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
+        else:
+            semantic = laplace_density(sdf_raw, beta)
+        return sdf, feature_vectors, gradients, semantic, sdf_raw
+
+    def get_outputs_and_indices(self, x):
+        sdf, feature_vectors, gradients, sdf_raw, idx, _ = self._outputs(x)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
+        return sdf, feature_vectors, gradients, semantic, sdf_raw, idx
+
+    def get_specific_outputs(self, x, idx):
+        sdf, feature_vectors, gradients, sdf_raw, _, _ = self._outputs(x)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
+        return sdf, feature_vectors, gradients, semantic, sdf_raw[:, idx]
+
+    def get_sdf_raw(self, x):
+        return self._trunk(x)[:, :self.d_out]
+
+    def get_sdf_vals(self, x):
+        return self._min_sdf(self.get_sdf_raw(x))[0]
+
+    def get_object_sdf_vals(self, x, idx):
+        return self._trunk(x)[:, idx]
+
+    def get_multi_object_sdf_vals(self, x, idxs):
+        return self._trunk(x)[:, idxs].min(dim=-1, keepdim=True)[0]
+
+    def get_sdf_vals_and_sdfs(self, x):
+        sdf_raw = self.get_sdf_raw(x)
+        return self._min_sdf(sdf_raw)[0], sdf_raw
+
+    def get_shift_sdf_raw(self, x):
+        """Raw SDFs with every non-minimal object pushed outside the minimal one where the scene SDF
+        is negative (used by the mesh extraction, network.py:460-479)."""
+        sdf_raw = self.get_sdf_raw(x)
+        sdf, idx = self._min_sdf(sdf_raw)
+        shifted = torch.where((sdf < 0).expand_as(sdf_raw), torch.max(sdf_raw, (-sdf).expand_as(sdf_raw)), sdf_raw)
+        return shifted.scatter(1, idx, sdf)
+
+    def mlp_parameters(self):
+        parameters = []
+        for lin in self._lins():
+            parameters += list(lin.parameters())
+        if self.color_grid_feature:
+            parameters += list(self.color_grid_feature_map_mlp.parameters())
+        return parameters
+
+    def grid_parameters(self, verbose=False):
+        if self.color_grid_feature:
+            return list(self.encoding.parameters()) + list(self.color_encoding.parameters())
+        return self.encoding.parameters()
+
+
+class RenderingNetwork(nn.Module):
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0, multires_point=0,
+                 multires_normal=0, num_images=1024):
+        super().__init__()
+        if not weight_norm:
+            raise NotImplementedError("Stage-1 configs always use weight_norm=True")
+        self.mode = mode
+        dims = [d_in + feature_vector_size] + list(dims) + [d_out]
+        self.embedview_fn = None
+        self.multires_view = multires_view
+        self.multires_point = multires_point
+        self.multires_normal = multires_normal
+        if multires_view > 0 or multires_point > 0 or multires_normal > 0:
+            emb = Embedder(multires_view, 3)  # one embedder (of multires_view) serves all three (network.py:559)
+            self.embedview_fn = emb.embed
+            if multires_view > 0:
+                dims[0] += emb.out_dim - 3
+            if multires_point > 0 and mode == "idr":
+                dims[0] += emb.out_dim - 3
+            if multires_normal > 0 and mode == "idr":
+                dims[0] += emb.out_dim - 3
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin" + str(l), WNLinear(dims[l], dims[l + 1]))
+        self.relu = nn.ReLU()
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, points, normals, view_dirs, feature_vectors, indices=None):
+        if self.multires_view > 0:
+            view_dirs = self.embedview_fn(view_dirs)
+        if self.multires_point > 0:
+            points = self.embedview_fn(points)
+        if self.multires_normal > 0:
+            normals = self.embedview_fn(normals)
+        if self.mode == "idr":
+            x = torch.cat([points, view_dirs, normals, feature_vectors], dim=-1)
+        elif self.mode == "nerf":
+            x = torch.cat([view_dirs, feature_vectors], dim=-1)
+        else:
+            raise NotImplementedError
+        for l in range(self.num_layers - 1):
+            x = getattr(self, "lin" + str(l))(x)
+            if l < self.num_layers - 2:
+                x = self.relu(x)
+        return self.sigmoid(x[:, :3])
+
+
+class HoloSceneNetwork(nn.Module):
+    def __init__(self, conf, plots_dir=None, graph_node_dict=None, ft_folder=None, num_images=1024):
+        super().__init__()
+        self.feature_vector_size = conf.get_int("feature_vector_size")
+        self.scene_bounding_sphere = conf.get_float("scene_bounding_sphere", default=1.0)
+        self.white_bkgd = conf.get_bool("white_bkgd", default=False)
+        self.register_buffer("bg_color", torch.tensor(conf.get_list("bg_color", default=[1.0, 1.0, 1.0])).float(), persistent=False)
+        self.use_bg_reg = conf.get_bool("use_bg_reg", default=False)
+        self.render_bg_iter = conf.get_int("render_bg_iter", default=10)
+        self.graph_node_dict = graph_node_dict
+        self.implicit_network = ObjectImplicitNetworkGrid(self.feature_vector_size, 0.0 if self.white_bkgd else self.scene_bounding_sphere,
+                                                          **conf.get_config("implicit_network"))
+        self.num_semantic = conf.get_int("implicit_network.d_out")
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, num_images=num_images, **conf.get_config("rendering_network"))
+        self.density = LaplaceDensity(**conf.get_config("density"))
+        self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config("ray_sampler"))
+        self.plots_dir = plots_dir
+        self.ft_folder = ft_folder
+        self.all_mesh_bbox_dict = None  # only ever set by the Stage-2 trainer (holoscene_train_post.py:715-731)
+
+    # ---------------------------------------------------------------- compositing (network.py:1803-1824)
+    def volume_rendering(self, z_vals, sdf):
+        density = self.density(sdf).reshape(-1, z_vals.shape[1])
+        dists = z_vals[:, 1:] - z_vals[:, :-1]
+        dists = torch.cat([dists, torch.full_like(dists[:, :1], 1e10)], -1)
+        free_energy = dists * density
+        shifted = torch.cat([torch.zeros_like(free_energy[:, :1]), free_energy[:, :-1]], dim=-1)
+        alpha = 1 - torch.exp(-free_energy)
+        transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
+        return alpha * transmittance, transmittance, dists
+
+    def occlusion_opacity(self, z_vals, transmittance, dists, sdf_raw):
+        obj_density = self.density(sdf_raw).transpose(0, 1).reshape(-1, dists.shape[0], dists.shape[1])  # [K, R, N]
+        return (1 - torch.exp(-dists * obj_density)) * transmittance
+
+    # ---------------------------------------------------------------- forward (network.py:778-971)
+    def forward(self, input, indices, iter_step=-1, rng=None):
+        """rng: optional dict of explicit random draws: 'ray_offset' [1,R,2] (already
+        minus 0.5), sampler draws 't_rand','u_final','perm','eik_idx', 'eik_uniform' [R,3], 'eik_jitter' [2R,3],
+        and for background iterations 'bg_xy0' + 'bg' (a second sampler dict)."""
+        rng = rng or {}
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        dev = uv.device
+        if self.training:
+            ray_offset = rng["ray_offset"] if "ray_offset" in rng else torch.rand_like(uv) - 0.5
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics, ray_offset=ray_offset)
+            # quirk Q1: the reference's first call shifted uv in place, so its depth-scale rays carry 2x the offset
+            ray_dirs_tmp, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics, ray_offset=2 * ray_offset)
+        else:
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            ray_dirs_tmp, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
+        depth_scale = ray_dirs_tmp[0, :, 2:]
+        batch_size, num_pixels, _ = ray_dirs.shape
+        cam_loc = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
+        ray_dirs = ray_dirs.reshape(-1, 3)
+
+        z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, rng=rng)
+        N_samples = z_vals.shape[1]
+        points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+        dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N_samples, -1).reshape(-1, 3)
+
+        sdf, feature_vectors, gradients, semantic, sdf_raw = self.implicit_network.get_outputs(points_flat, beta=None)
+        rgb = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors, indices).reshape(-1, N_samples, 3)
+        semantic = semantic.reshape(-1, N_samples, self.num_semantic)
+        weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
+        object_opacity = self.occlusion_opacity(z_vals, transmittance, dists, sdf_raw).sum(-1).transpose(0, 1)
+
+        rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
+        semantic_values = torch.sum(weights.unsqueeze(-1) * semantic, 1)
+        depth_values = depth_scale * (torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8))
+        if self.white_bkgd:
+            rgb_values = rgb_values + (1.0 - torch.sum(weights, -1)[..., None]) * self.bg_color.unsqueeze(0)
+
+        output = {
+            "rgb": rgb,
+            "semantic_values": semantic_values,
+            "object_opacity": object_opacity,
+            "rgb_values": rgb_values,
+            "depth_values": depth_values,
+            "z_vals": z_vals,
+            "depth_vals": z_vals * depth_scale,
+            "sdf": sdf.reshape(z_vals.shape),
+            "weights": weights,
+        }
+
+        if self.training:
+            n_eik = batch_size * num_pixels
+            if "eik_uniform" in rng:
+                eik = rng["eik_uniform"].to(dev)
+            else:
+                eik = torch.empty(n_eik, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere)
+            near_surface = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            eik = torch.cat([eik, near_surface], 0)
+            jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand_like(eik)
+            eik = torch.cat([eik, eik + (jitter - 0.5) * 0.01], 0)
+            if self.all_mesh_bbox_dict is not None:
+                raise NotImplementedError("collision-driven Eikonal sampling belongs to Stage 2 (network.py:868-902)")
+            # one value+Jacobian pass replaces gradient() + get_sdf_raw() + get_sdf_vals() (network.py:856-863)
+            y, J = self.implicit_network.sdf_and_jacobian(eik)
+            y, J = y[:, :self.implicit_network.d_out], J[:, :self.implicit_network.d_out]
+            min_sdf, idx = y.min(dim=-1, keepdim=True)
+            g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+            grad_theta = torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
+            output["sample_sdf"] = y
+            output["sample_minsdf"] = min_sdf
+            half = grad_theta.shape[0] // 2  # quirk Q2: halves of the stacked rows, not original/jittered
+            output["grad_theta"] = grad_theta[:half]
+            output["grad_theta_nei"] = grad_theta[half:]
+
+        normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N_samples, 3)
+        normal_map = torch.sum(weights.unsqueeze(-1) * normals, 1)
+        rot = pose[0, :3, :3].permute(1, 0).contiguous()
+        output["normal_map"] = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
+
+        if self.use_bg_reg and iter_step % self.render_bg_iter == 0:  # background-surface pass (network.py:916-968)
+            patch = 32
+            if "bg_xy0" in rng:
+                x0, y0 = (int(v) for v in rng["bg_xy0"])
+            else:
+                x0 = int(np.random.randint(0, int(float(intrinsics[0, 0, 2]) * 2.0) - patch + 1))
+                y0 = int(np.random.randint(0, int(float(intrinsics[0, 1, 2]) * 2.0) - patch + 1))
+            gy, gx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
+            uv0 = torch.stack([gx + x0, gy + y0], -1).reshape(1, -1, 2).float()
+            ray_dirs0, cam_loc0 = rend_util.get_camera_params(uv0, pose, intrinsics)
+            tmp0, _ = rend_util.get_camera_params(uv0, torch.eye(4, device=dev)[None], intrinsics)
+            depth_scale0 = tmp0[0, :, 2:]
+            n0 = ray_dirs0.shape[1]
+            cam_loc0 = cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3)
+            ray_dirs0 = ray_dirs0.reshape(-1, 3)
+            bg_z, _ = self.ray_sampler.get_z_vals(ray_dirs0, cam_loc0, self, idx=0, rng=rng.get("bg"))
+            n_bg = bg_z.shape[1]
+            bg_points = (cam_loc0.unsqueeze(1) + bg_z.unsqueeze(2) * ray_dirs0.unsqueeze(1)).reshape(-1, 3)
+            scene_sdf, _, bg_gradients, scene_semantic, bg_sdf = self.implicit_network.get_specific_outputs(bg_points, 0)
+            bg_weight, _, _ = self.volume_rendering(bg_z, bg_sdf)
+            scene_weight, _, _ = self.volume_rendering(bg_z, scene_sdf)  # semantics use the scene SDF
+            bg_semantic = torch.sum(scene_weight.unsqueeze(-1) * scene_semantic.reshape(-1, n_bg, self.num_semantic), 1)
+            output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
+            output["bg_depth_values"] = depth_scale0 * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
+            bg_normals = (bg_gradients / (bg_gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, n_bg, 3)
+            bg_normal_map = torch.sum(bg_weight.unsqueeze(-1) * bg_normals, 1)
+            output["bg_normal_map"] = (rot @ bg_normal_map.permute(1, 0)).permute(1, 0).contiguous()
+        return output

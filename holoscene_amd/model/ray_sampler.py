@@ -1,0 +1,230 @@
+"""Ray samplers of the Stage-1 path.
+
+Same classes, constructor arguments and ``get_z_vals`` contract as the reference
+(model/ray_sampler.py:16-102 ``UniformSampler``, :105-287 + :450-472 ``ErrorBoundSampler`` =
+VolSDF Algorithm 1), restructured for the GPU:
+
+  * no boolean-mask indexing (``d_star[mask] = ...`` in the reference forces a host sync per
+    assignment, ray_sampler.py:171-177); everything is ``torch.where`` on whole tensors;
+  * the only device->host sync per round is the convergence test the algorithm itself needs
+    (``beta.max() > beta0``, ray_sampler.py:204);
+  * SDF sweeps go through ``implicit_network.get_sdf_vals`` which, in this build, skips the
+    colour branch the reference evaluates and throws away (network.py:177-179);
+  * every random draw can be injected (``rng=`` dict) so CPU oracle, reference import and this
+    code can be driven by identical numbers.  Without injection the draws
+    come from the device generator (the reference draws on the CPU generator and copies,
+    ray_sampler.py:79,238,269,279) unless ``cpu_rng=True``.
+"""
+import abc
+
+import torch
+
+from .density import laplace_density
+
+
+def _rand(shape, device, cpu_rng):
+    if cpu_rng:
+        return torch.rand(shape).to(device)
+    return torch.rand(shape, device=device)
+
+
+class RaySampler(metaclass=abc.ABCMeta):
+    def __init__(self, near, far):
+        self.near = near
+        self.far = far
+
+    @abc.abstractmethod
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        pass
+
+
+class UniformSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, take_sphere_intersection=False, far=-1, cpu_rng=False):
+        super().__init__(near, 2.0 * scene_bounding_sphere * 1.75 if far == -1 else far)  # ray_sampler.py:19
+        self.N_samples = N_samples
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.take_sphere_intersection = take_sphere_intersection
+        self.cpu_rng = cpu_rng
+
+    def near_far_from_cube(self, rays_o, rays_d, bound):
+        """Slab test against [-bound, bound]^3 (ray_sampler.py:48-60)."""
+        tmin = (-bound - rays_o) / (rays_d + 1e-15)
+        tmax = (bound - rays_o) / (rays_d + 1e-15)
+        near = torch.minimum(tmin, tmax).max(dim=-1, keepdim=True)[0]
+        far = torch.maximum(tmin, tmax).min(dim=-1, keepdim=True)[0]
+        miss = far < near
+        near = torch.where(miss, torch.full_like(near, 1e9), near)
+        far = torch.where(miss, torch.full_like(far, 1e9), far)
+        return near.clamp(min=self.near), far.clamp(max=self.far)
+
+    def _stratify(self, near, far, training, t_rand=None):
+        t = torch.linspace(0.0, 1.0, steps=self.N_samples, device=near.device)
+        z = near * (1.0 - t) + far * t
+        if training:
+            mids = 0.5 * (z[..., 1:] + z[..., :-1])
+            upper = torch.cat([mids, z[..., -1:]], -1)
+            lower = torch.cat([z[..., :1], mids], -1)
+            if t_rand is None:
+                t_rand = _rand(z.shape, z.device, self.cpu_rng)
+            z = lower + (upper - lower) * t_rand
+        return z
+
+    def get_z_vals(self, ray_dirs, cam_loc, model, t_rand=None):
+        R = ray_dirs.shape[0]
+        near = torch.full((R, 1), float(self.near), device=ray_dirs.device)
+        if self.take_sphere_intersection:
+            _, far = self.near_far_from_cube(cam_loc, ray_dirs, bound=self.scene_bounding_sphere)
+        else:
+            far = torch.full((R, 1), float(self.far), device=ray_dirs.device)
+        return self._stratify(near, far, model.training, t_rand), near, far
+
+    def get_z_vals_near_far(self, ray_dirs, cam_loc, model, near, far, t_rand=None):
+        R = ray_dirs.shape[0]
+        near = near * torch.ones(R, 1, device=ray_dirs.device)
+        far = far * torch.ones(R, 1, device=ray_dirs.device)
+        return self._stratify(near, far, model.training, t_rand), near, far
+
+
+def opacity_error_bound(beta, sdf, dists, d_star):
+    """Upper bound of the opacity approximation error per ray (ray_sampler.py:450-458).
+    sdf [R,M]; dists, d_star [R,M-1]; beta scalar or [R,1]."""
+    sigma = laplace_density(sdf, beta)
+    free = torch.cumsum(dists * sigma[:, :-1], dim=-1)
+    integral = torch.cat([torch.zeros_like(free[:, :1]), free[:, :-1]], -1)  # energy up to the start of each section
+    err_int = torch.cumsum(torch.exp(-d_star / beta) * dists ** 2 / (4 * beta ** 2), dim=-1)
+    return ((torch.exp(err_int).clamp(max=1.0e6) - 1.0) * torch.exp(-integral)).max(-1)[0]
+
+
+def heron_distance_bound(sdf, dists):
+    """d* of VolSDF Theorem 1 for every section (ray_sampler.py:165-178)."""
+    a, b, c = dists, sdf[:, :-1].abs(), sdf[:, 1:].abs()
+    first = a ** 2 + b ** 2 <= c ** 2
+    second = a ** 2 + c ** 2 <= b ** 2
+    s = (a + b + c) / 2.0
+    height = 2.0 * torch.sqrt(s * (s - a) * (s - b) * (s - c)) / a
+    d_star = torch.where(first, b, torch.zeros_like(a))
+    d_star = torch.where(second, c, d_star)
+    d_star = torch.where(~first & ~second & (b + c - a > 0), height, d_star)
+    same_side = sdf[:, 1:].sign() * sdf[:, :-1].sign() == 1
+    return torch.where(same_side, d_star, torch.zeros_like(d_star))
+
+
+def invert_cdf(cdf, bins, u):
+    """Inverse-transform sampling with linear interpolation inside a bin (ray_sampler.py:241-253)."""
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    b0, b1 = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return b0 + (u - c0) / denom * (b1 - b0)
+
+
+class ErrorBoundSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters, max_total_iters,
+                 inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=1.0e-6, cpu_rng=False):
+        super().__init__(near, 2.0 * scene_bounding_sphere * 1.75)  # ray_sampler.py:110
+        self.N_samples = N_samples
+        self.N_samples_eval = N_samples_eval
+        self.take_sphere_intersection = True
+        self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_samples_eval, take_sphere_intersection=True, cpu_rng=cpu_rng)
+        self.N_samples_extra = N_samples_extra
+        self.eps = eps
+        self.beta_iters = beta_iters
+        self.max_total_iters = max_total_iters
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.add_tiny = add_tiny
+        self.cpu_rng = cpu_rng
+        self.inverse_sphere_bg = inverse_sphere_bg
+        if inverse_sphere_bg:
+            raise NotImplementedError("inverse_sphere_bg is not used by any Stage-1 config (confs/*: absent) and is not built")
+        self.last_rounds = 0  # realised Algorithm-1 rounds of the latest call (bench.py reports it)
+
+    def _query_sdf(self, model, points, idx):
+        net = model.implicit_network
+        if idx is None:
+            return net.get_sdf_vals(points)
+        if isinstance(idx, int):
+            return net.get_object_sdf_vals(points, idx).unsqueeze(-1)
+        return net.get_multi_object_sdf_vals(points, idx)
+
+    @torch.no_grad()
+    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None):
+        rng = rng or {}
+        dev = ray_dirs.device
+        R = ray_dirs.shape[0]
+        beta0 = model.density.get_beta().detach()
+        z_vals, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+        samples, order, sdf = z_vals, None, None
+        dists = z_vals[:, 1:] - z_vals[:, :-1]
+        # Lemma 2: beta that certainly satisfies the bound (fp32 log as the reference, :138-140)
+        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (dists ** 2.0).sum(-1))
+        rounds, unconverged = 0, True
+        while unconverged and rounds < self.max_total_iters:
+            points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            new_sdf = self._query_sdf(model, points, idx).reshape(R, -1)
+            if order is None:
+                sdf = new_sdf
+            else:  # bring old and new values into the merged sample order
+                sdf = torch.gather(torch.cat([sdf, new_sdf], -1), 1, order)
+            dists = z_vals[:, 1:] - z_vals[:, :-1]
+            d_star = heron_distance_bound(sdf, dists)
+            # line search for the smallest beta within the bound
+            err0 = opacity_error_bound(beta0, sdf, dists, d_star)
+            hi = torch.where(err0 <= self.eps, beta0.expand_as(beta), beta)
+            lo = beta0.expand_as(beta)
+            for _ in range(self.beta_iters):
+                mid = (lo + hi) / 2.0
+                ok = opacity_error_bound(mid.unsqueeze(-1), sdf, dists, d_star) <= self.eps
+                hi = torch.where(ok, mid, hi)
+                lo = torch.where(ok, lo, mid)
+            beta = hi
+            sigma = laplace_density(sdf, beta.unsqueeze(-1))
+            dists_inf = torch.cat([dists, torch.full((R, 1), 1e10, device=dev)], -1)
+            free_energy = dists_inf * sigma
+            shifted = torch.cat([torch.zeros(R, 1, device=dev), free_energy[:, :-1]], -1)
+            transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
+            weights = (1 - torch.exp(-free_energy)) * transmittance
+            rounds += 1
+            unconverged = bool(beta.max() > beta0)  # the one host sync Algorithm 1 needs per round
+            upsample = unconverged and rounds < self.max_total_iters
+            if upsample:  # more samples where the error bound is large
+                N = self.N_samples_eval
+                per_section = torch.exp(-d_star / beta.unsqueeze(-1)) * (dists ** 2.0) / (4 * beta.unsqueeze(-1) ** 2)
+                bound_opacity = (torch.exp(torch.cumsum(per_section, dim=-1)).clamp(max=1.0e6) - 1.0) * transmittance[:, :-1]
+                pdf = bound_opacity + self.add_tiny
+            else:  # final set, proportional to the rendering weights
+                N = self.N_samples
+                pdf = weights[..., :-1] + 1e-5
+            pdf = pdf / pdf.sum(-1, keepdim=True)
+            cdf = torch.cat([torch.zeros(R, 1, device=dev), torch.cumsum(pdf, -1)], -1)
+            if upsample or not model.training:
+                u = torch.linspace(0.0, 1.0, steps=N, device=dev).unsqueeze(0).repeat(R, 1)
+            else:
+                u = rng["u_final"] if "u_final" in rng else _rand((R, N), dev, self.cpu_rng)
+            samples = invert_cdf(cdf, z_vals, u.contiguous())
+            if upsample:
+                z_vals, order = torch.sort(torch.cat([z_vals, samples], -1), -1)
+        self.last_rounds = rounds
+        z_samples = samples
+        near = torch.full((R, 1), float(self.near), device=dev)
+        far = torch.full((R, 1), float(self.far), device=dev)
+        if self.N_samples_extra > 0:
+            if model.training:
+                perm = rng["perm"] if "perm" in rng else torch.randperm(z_vals.shape[1])
+                pick = perm[: self.N_samples_extra].to(dev)
+            else:
+                pick = torch.linspace(0, z_vals.shape[1] - 1, self.N_samples_extra, device=dev).long()
+            extra = torch.cat([near, far, z_vals[:, pick]], -1)
+        else:
+            extra = torch.cat([near, far], -1)
+        z_vals, _ = torch.sort(torch.cat([z_samples, extra], -1), -1)
+        if "eik_idx" in rng:
+            eik = rng["eik_idx"].to(dev)
+        elif self.cpu_rng:
+            eik = torch.randint(z_vals.shape[-1], (R,)).to(dev)
+        else:
+            eik = torch.randint(z_vals.shape[-1], (R,), device=dev)
+        z_samples_eik = torch.gather(z_vals, 1, eik.unsqueeze(-1))
+        return z_vals, z_samples_eik

@@ -1,0 +1,58 @@
+"""TEST-ONLY stand-in for holoscene_amd.hashencoder.backend._backend that runs the hash encoder on the
+CPU oracle, so the host-side model logic can be exercised by `-m "not gpu"` tests.  The product never
+imports this; on a GPU box the real backend (libholoscene_hip.so) is what runs."""
+import torch
+
+from oracle import hash_oracle
+
+
+def _lbc(t, B, L, C):  # point-major [B, L*C] -> level-major [L,B,C]
+    return t.view(B, L, C).permute(1, 0, 2).contiguous()
+
+
+class OracleBackend:
+    @staticmethod
+    def fwd(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx):
+        out, j = hash_oracle.fwd(inputs.contiguous(), embeddings.detach().contiguous(), offsets, S, H, dy_dx is not None)
+        outputs.copy_(out.permute(1, 0, 2).reshape(B, L * C))
+        if dy_dx is not None:
+            dy_dx.copy_(j.view(B, L, D * C).permute(1, 0, 2))
+
+    @staticmethod
+    def bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs):
+        j = dy_dx.permute(1, 0, 2).reshape(B, -1).contiguous() if dy_dx is not None else torch.empty(1)
+        emb_shape = (int(offsets[-1]), C)
+        gx, ge = hash_oracle.bwd(_lbc(grad, B, L, C), inputs, torch.zeros(emb_shape), offsets, S, H, grad_inputs is not None, j)
+        if grad_embeddings is not None:
+            grad_embeddings.add_(ge)
+        if grad_inputs is not None:
+            grad_inputs.copy_(gx)
+
+    @staticmethod
+    def bwd2(grad, inputs, offsets, B, D, C, L, S, H, dy_dx, ggx, grad_grad, grad2_embeddings):
+        j = dy_dx.permute(1, 0, 2).reshape(B, -1).contiguous()
+        gg, g2 = hash_oracle.bwd2(_lbc(grad, B, L, C), inputs, torch.zeros(int(offsets[-1]), C), offsets, S, H, j, ggx)
+        if grad_grad is not None:
+            grad_grad.copy_(gg.permute(1, 0, 2).reshape(B, L * C))
+        if grad2_embeddings is not None:
+            grad2_embeddings.add_(g2)
+
+    @staticmethod
+    def bwd_jac(g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H):
+        emb0 = torch.zeros(int(offsets[-1]), C)
+        if g_feat is not None:
+            _, ge = hash_oracle.bwd(_lbc(g_feat, B, L, C), inputs, emb0, offsets, S, H, False, torch.empty(1))
+            grad_embeddings.add_(ge)
+        if g_dydx is not None:  # general cotangent = sum over d of rank-one terms G[:,:,d,:] (x) e_d
+            G = g_dydx.view(L, B, D, C)
+            dummy = torch.zeros(B, L * D * C)
+            for d in range(D):
+                e = torch.zeros(B, D)
+                e[:, d] = 1
+                _, g2 = hash_oracle.bwd2(G[:, :, d, :].contiguous(), inputs, emb0, offsets, S, H, dummy, e)
+                grad_embeddings.add_(g2)
+
+
+def install(monkeypatch):
+    from holoscene_amd.hashencoder import backend
+    monkeypatch.setattr(backend, "_backend", OracleBackend)
