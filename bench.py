@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- Stage-1 training throughput (training rays/s) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full training iteration of the hot path: sampler, render, Eikonal set,
+loss, backward, gradient exchange (N>1), Adam, LR step, on synthetic inputs resident in HBM.
+Workload = BASELINE.json configs[1]: 1 024 rays x 128 samples (98 rendered points/ray), K=32 object
+channels, L=16 hash grid (T=2^19, 16->2048), fp32, beta=0.001 (5 sampler rounds).  Weak scaling:
+every rank renders its own 1 024 rays; value = global rays / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant hand-written kernel, timed live with
+HIP events on the launching stream) and "cpu_baseline" (the CPU oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--rays", type=int, default=1024)
+    p.add_argument("--samples", type=int, default=128)
+    p.add_argument("--objects", type=int, default=32)
+    p.add_argument("--beta", type=float, default=0.001)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    return p.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of one backend entry point, recorded on the stream the kernel is launched on."""
+
+    def __init__(self, backend_cls, name):
+        self.events, self.points = [], 0
+        self._orig = getattr(backend_cls, name)
+        self._cls, self._name = backend_cls, name
+        self.enabled = False
+
+    def __enter__(self):
+        orig, me = self._orig, self
+
+        def timed(*a, **k):
+            if not me.enabled:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            me.events.append((s, e, a[4]))  # a[4] = B (points)
+            return r
+
+        setattr(self._cls, self._name, staticmethod(timed))
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self._cls, self._name, self._orig)
+
+    def summary(self):
+        ms = [s.elapsed_time(e) for s, e, _ in self.events]
+        pts = [b for _, _, b in self.events]
+        return ms, pts
+
+
+def cpu_baseline(seconds):
+    """The CPU oracle (oracle/, a restatement of the reference: kind 'port') timed on this host's cores at
+    BASELINE configs[0]: 256 rays x 64 samples, K=2, L=8 grid; full iteration incl. backward + Adam."""
+    from oracle.stage1_oracle import Cfg, Stage1Oracle, make_state
+    cfg = Cfg(d_out=2, num_levels=8, base_size=16, end_size=256, logmap=15, N_samples=32, N_samples_eval=64, N_samples_extra=16,
+              beta_init=0.001)
+    sd = make_state(cfg, seed=42, perturb=1e-2)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    full = dict(sd)
+    full.update(params)
+    orc = Stage1Oracle(cfg, full)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
+    R, res = 256, 512
+    g = torch.Generator().manual_seed(1234)
+    from holoscene_amd.training.synthetic import look_at_pose
+    pose = look_at_pose((0.7, 0.0, 0.0))[None]
+    K = torch.eye(4)[None].clone()
+    K[0, 0, 0] = K[0, 1, 1] = K[0, 0, 2] = K[0, 1, 2] = res / 2
+    n, t0, rounds = 0, time.perf_counter(), 0
+    while True:
+        uv = torch.randint(0, res, (1, R, 2), generator=g).float()
+        rand = {"ray_offset": torch.rand(1, R, 2, generator=g) - 0.5, "t_rand": torch.rand(R, 64, generator=g),
+                "u_final": torch.rand(R, 32, generator=g), "perm": torch.randperm(64 * 5, generator=g), "eik_idx": torch.randint(0, 50, (R,), generator=g),
+                "eik_uniform": torch.rand(R, 3, generator=g) * 2 - 1, "eik_jitter": torch.rand(2 * R, 3, generator=g)}
+        gt = {"rgb": torch.rand(1, R, 3, generator=g), "depth": torch.rand(1, R, 1, generator=g) * 0.9 + 0.1,
+              "normal": torch.nn.functional.normalize(torch.randn(1, R, 3, generator=g), dim=-1), "mask": torch.ones(1, R, 1),
+              "segs": torch.randint(0, 2, (1, R, 1), generator=g)}
+        opt.zero_grad()
+        out = orc.forward(uv, pose, K, rand, iter_step=1)
+        lo = orc.loss(out, gt)
+        lo["loss"].backward()
+        opt.step()
+        rounds = out["sampler_rounds"]
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 2:
+            break
+    return {"value": round(R * n / el, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full iterations of BASELINE configs[0] (256 rays x 64 samples, K=2, L=8, fp32, {rounds} sampler rounds) "
+                      f"on the CPU oracle in {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from holoscene_amd.hashencoder import backend
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    from holoscene_amd.training import distributed as dist_util
+
+    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta)
+    tr = Stage1Trainer(conf, device=dev, world_size=world, seed=42)
+    benchmark_model_state(tr.model, args.beta)
+    if world > 1:
+        dist_util.broadcast_parameters(tr.model)
+    scene = SyntheticScene(args.rays, args.objects, seed=1234 + rank, device=dev)
+    rounds_seen = []
+
+    def step():
+        idx, mi, gt = scene.next_batch()
+        tr.train_step(idx, mi, gt)
+        rounds_seen.append(tr.model.ray_sampler.last_rounds)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with KernelTimer(backend._HipBackend, "fwd") as kt:
+        for _ in range(args.warmup):
+            step()
+        rounds_seen.clear()
+        barrier()
+        kt.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kt.enabled = False
+        ms, pts = kt.summary()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.rays * world * args.steps / elapsed
+
+    # roofline of the hash-encode forward kernel (k_hash_fwd): algorithmic bytes = L*8*C*4 B gathered per point
+    # (+ coordinates in, features out); launches = every hs_hash_fwd call in the timed region.
+    L, C = 16, 2
+    gather_per_point = L * 8 * C * 4
+    alg_bytes = sum(p * (gather_per_point + 12 + L * C * 4) for p in pts)
+    total_ms = sum(ms)
+    achieved = alg_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    roofline = {"kernel": "k_hash_fwd<3,2>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(ms),
+                "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2)}
+    if rank == 0:
+        line = {
+            "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
+                                   f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
+                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}",
+                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(rounds_seen) / max(1, len(rounds_seen)), 2),
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Frame-sharded data parallelism.  The reference is single-GPU; this is new.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+Every rank renders its own frame/rays; the only exchange is the parameter-gradient mean:
+  * the two 48.8 MB hash-grid gradients are reduced in place, one collective each (large payloads
+    ride RCCL's direct/ring algorithms at link rate; no bucketing copy);
+  * the ~40 small MLP/beta gradients are flattened into one buffer and reduced with one collective.
+Parity definition: the result equals one process averaging the gradients of the ranks' independent
+single-frame iterations, then taking one Adam step.
+"""
+import torch
+import torch.distributed as dist
+
+_SMALL = 1 << 20  # elements; tensors below this are coalesced
+
+
+def average_gradients(params, world_size, group=None):
+    grads = [p.grad for p in params if p.grad is not None]
+    big = [g for g in grads if g.numel() >= _SMALL]
+    small = [g for g in grads if g.numel() < _SMALL]
+    handles = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in big]
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world_size)
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    for h in handles:
+        h.wait()
+    for g in big:
+        g.mul_(1.0 / world_size)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

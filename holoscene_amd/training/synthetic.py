@@ -1,0 +1,76 @@
+"""Synthetic Stage-1 inputs (no dataset, no network in this environment) -- SURVEY.md section 8(d).
+
+Frames: H x W image, pinhole K (fx=fy=W/2, cx=cy=W/2 for the square case), F camera-to-world poses on a
+circle of radius 0.7 in the z=0 plane looking at the origin; instance mask = K vertical stripes;
+rgb ~ U[0,1], depth ~ U[0.1,1], unit normals from N(0,I), mask = 1.  Pixel batches follow the
+reference's class-balanced rule (datasets/ns_dataset.py:409-430): half of the rays split evenly over
+the classes present (background takes the remainder), the other half uniform over the image.
+Everything is generated once and kept resident in HBM; a ring of pre-drawn pixel batches stands in
+for the reference's DataLoader workers.
+"""
+import numpy as np
+import torch
+
+
+def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
+    eye = np.asarray(eye, dtype=np.float64)
+    fwd = np.asarray(target, dtype=np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    up = np.array([0.0, 0.0, 1.0]) if abs(fwd[2]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    P = np.eye(4)
+    P[:3, 0], P[:3, 1], P[:3, 2], P[:3, 3] = right, down, fwd, eye
+    return torch.from_numpy(P).float()
+
+
+class SyntheticScene:
+    def __init__(self, num_rays, num_classes, img_res=(512, 512), num_frames=8, ring=64, seed=1234, device="cuda"):
+        self.R, self.K = num_rays, num_classes
+        self.H, self.W = img_res
+        self.F = num_frames
+        self.device = torch.device(device)
+        g = torch.Generator().manual_seed(seed)
+        self.rng = np.random.RandomState(seed)
+        intr = torch.eye(4)
+        intr[0, 0] = intr[1, 1] = self.W / 2
+        intr[0, 2], intr[1, 2] = self.W / 2, self.H / 2
+        self.intrinsics = intr[None].to(self.device)
+        ang = np.linspace(0, 2 * np.pi, num_frames, endpoint=False)
+        self.poses = torch.stack([look_at_pose((0.7 * np.cos(a), 0.7 * np.sin(a), 0.0)) for a in ang]).to(self.device)
+        npix = self.H * self.W
+        cols = torch.arange(self.W) * num_classes // self.W                      # stripe id per column
+        self.segs = cols[None, :].expand(self.H, self.W).reshape(npix, 1).contiguous().to(self.device)
+        self.rgb = torch.rand(num_frames, npix, 3, generator=g).to(self.device)
+        self.depth = (torch.rand(num_frames, npix, 1, generator=g) * 0.9 + 0.1).to(self.device)
+        self.normal = torch.nn.functional.normalize(torch.randn(num_frames, npix, 3, generator=g), dim=-1).to(self.device)
+        ys, xs = torch.meshgrid(torch.arange(self.H), torch.arange(self.W), indexing="ij")
+        self.uv_all = torch.stack([xs, ys], -1).reshape(npix, 2).float().to(self.device)
+        self._class_pixels = [torch.nonzero(self.segs.cpu().reshape(-1) == c).reshape(-1) for c in range(num_classes)]
+        self._ring = [self._draw(g) for _ in range(ring)]
+        self._ring_dev = [(f, idx.to(self.device)) for f, idx in self._ring]
+        self._cursor = 0
+
+    def _draw(self, g):
+        """One (frame, pixel-index) batch, ns_dataset.py:383, 409-430."""
+        frame = int(self.rng.randint(0, self.F))
+        half = self.R // 2
+        per_class = half // self.K
+        n_bg = half - per_class * (self.K - 1)
+        chosen = []
+        for c, pix in enumerate(self._class_pixels):
+            want = n_bg if c == 0 else per_class
+            if len(pix) > want:
+                pix = pix[torch.randperm(len(pix), generator=g)[:want]]
+            chosen.append(pix)
+        chosen.append(torch.randperm(self.H * self.W, generator=g)[: self.R - half])
+        return frame, torch.cat(chosen)
+
+    def next_batch(self):
+        frame, idx = self._ring_dev[self._cursor % len(self._ring_dev)]
+        self._cursor += 1
+        model_input = {"uv": self.uv_all[idx][None], "intrinsics": self.intrinsics, "pose": self.poses[frame][None]}
+        gt = {"rgb": self.rgb[frame][idx][None], "depth": self.depth[frame][idx][None], "normal": self.normal[frame][idx][None],
+              "mask": torch.ones(1, idx.numel(), 1, device=self.device), "segs": self.segs[idx][None]}
+        return torch.tensor([frame]), model_input, gt

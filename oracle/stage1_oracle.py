@@ -290,7 +290,8 @@ class Stage1Oracle:
             far = torch.full((R, 1), c.far)
             if c.N_samples_extra > 0:
                 if self.training:
-                    pick = rand["perm"][: c.N_samples_extra]
+                    perm = rand["perm"]
+                    pick = perm[perm < z.shape[1]][: c.N_samples_extra]  # no-op filter when perm = randperm(len(z))
                 else:
                     pick = torch.linspace(0, z.shape[1] - 1, c.N_samples_extra).long()
                 extra = torch.cat([near, far, z[:, pick]], -1)
