@@ -220,6 +220,51 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------ wave-merged scatter
+// Neighbouring lanes are neighbouring samples of one ray, so on coarse levels (and wherever the sampler
+// concentrates samples near a surface) many lanes of a wave hit the SAME cell and their atomics would
+// serialise on one L2 address (measured: level 0 scatter 10x slower on ray-ordered than on random points).
+// Lanes whose base cell equals their predecessor's form a run; a segmented inclusive scan (wave shuffles)
+// sums the 2^D*C corner contributions over each run and only the run's last lane issues atomics.
+// All 64 lanes must call this (inactive lanes pass valid=false).
+template <int D, int C>
+__device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const LevelInfo &li, const uint32_t g[D], float cache[(1 << D) * C],
+                                             bool valid) {
+    const int lane = threadIdx.x & 63;
+    bool same_prev = valid && lane > 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t pg = __shfl_up(valid ? g[d] : 0xffffffffu, 1);
+        same_prev = same_prev && (pg == g[d]);
+    }
+    const unsigned long long heads = __ballot(!same_prev);
+    bool tail = valid;
+    if (heads != ~0ull) {  // wave-uniform: at least one run longer than one lane
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            // lane may absorb lane-off iff no run starts in (lane-off, lane]
+            const unsigned long long span = (~0ull >> (63 - lane)) & (~0ull << ((lane - off + 1) & 63));
+            const bool ok = lane >= off && (heads & span) == 0ull;
+#pragma unroll
+            for (int i = 0; i < (1 << D) * C; i++) {
+                const float t = __shfl_up(cache[i], off);
+                if (ok) cache[i] += t;
+            }
+        }
+        tail = valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
+    }
+    if (!tail) return;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
+        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, cache[corner * C + c]);
+    }
+}
+
 // ------------------------------------------------------------------------------------ first backward: scatter
 template <int D, int C>
 __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__restrict__ grad, const float *__restrict__ x,
@@ -228,30 +273,31 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
     uint32_t level, chunk;
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
-    if (b >= B) return;
     const LevelInfo li = level_info<D>(offsets, level, sc);
     uint32_t g[D];
     float w[D], dw[D];
-    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
-    const float *go = grad + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
-    float gv[C];
+    const bool valid = b < B && locate<D>(x + (size_t)b * D, li, g, w, dw);
+    float cache[(1 << D) * C];
+    if (valid) {
+        const float *go = grad + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+        float gv[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) gv[c] = go[c];
-    float *gg = gemb + (size_t)li.offset * C;
+        for (int c = 0; c < C; c++) gv[c] = go[c];
 #pragma unroll
-    for (int corner = 0; corner < (1 << D); corner++) {
-        float wt = 1.f;
-        uint32_t gl[D];
+        for (int corner = 0; corner < (1 << D); corner++) {
+            float wt = 1.f;
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int hi = (corner >> d) & 1;
-            wt *= hi ? w[d] : 1 - w[d];
-            gl[d] = g[d] + hi;
+            for (int d = 0; d < D; d++) wt *= ((corner >> d) & 1) ? w[d] : 1 - w[d];
+#pragma unroll
+            for (int c = 0; c < C; c++) cache[corner * C + c] = wt * gv[c];
         }
-        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
+    } else {
 #pragma unroll
-        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, wt * gv[c]);
+        for (int i = 0; i < (1 << D) * C; i++) cache[i] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
+    scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 
 // ------------------------------------------------------------------------------------ first backward: d/dx
@@ -288,12 +334,12 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict_
     uint32_t level, chunk;
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
-    if (b >= B) return;
+    const bool inb = b < B;
     float gx[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) gx[d] = ggx[(size_t)b * D + d];
+    for (int d = 0; d < D; d++) gx[d] = inb ? ggx[(size_t)b * D + d] : 0.f;
     const int64_t foff = (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
-    if (grad_grad) {  // hashencoder.cu:376-428
+    if (grad_grad && inb) {  // hashencoder.cu:376-428
         const float *j = dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -303,49 +349,44 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict_
             grad_grad[foff + c] = r;
         }
     }
-    if (!g2emb) return;
+    if (!g2emb) return;  // uniform
     const LevelInfo li = level_info<D>(offsets, level, sc);
     uint32_t g[D];
     float w[D], dw[D];
-    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
-    float gv[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) gv[c] = grad[foff + c];
+    const bool valid = inb && locate<D>(x + (size_t)b * D, li, g, w, dw);
     float cache[(1 << D) * C];  // hashencoder.cu:507-549
 #pragma unroll
     for (int i = 0; i < (1 << D) * C; i++) cache[i] = 0.f;
+    if (valid) {
+        float gv[C];
 #pragma unroll
-    for (int gd = 0; gd < D; gd++) {
+        for (int c = 0; c < C; c++) gv[c] = grad[foff + c];
 #pragma unroll
-        for (int k = 0; k < (1 << (D - 1)); k++) {
-            float wt = li.scale;
-            int bits = 0;
+        for (int gd = 0; gd < D; gd++) {
 #pragma unroll
-            for (int nd = 0; nd < D - 1; nd++) {
-                const int d = (nd >= gd) ? nd + 1 : nd;
-                if ((k >> nd) & 1) { wt *= w[d]; bits |= 1 << d; }
-                else wt *= 1 - w[d];
-            }
+            for (int k = 0; k < (1 << (D - 1)); k++) {
+                float wt = li.scale;
+                int bits = 0;
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float v = wt * gv[c] * gx[gd] * dw[gd];
-                cache[(bits | (1 << gd)) * C + c] += v;
-                cache[bits * C + c] -= v;
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((k >> nd) & 1) { wt *= w[d]; bits |= 1 << d; }
+                    else wt *= 1 - w[d];
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float v = wt * gv[c] * gx[gd] * dw[gd];
+                    cache[(bits | (1 << gd)) * C + c] += v;
+                    cache[bits * C + c] -= v;
+                }
             }
         }
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
-    float *gg = g2emb + (size_t)li.offset * C;
-#pragma unroll
-    for (int corner = 0; corner < (1 << D); corner++) {
-        uint32_t gl[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
-        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
-#pragma unroll
-        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, cache[corner * C + c]);
-    }
+    scatter_cell<D, C>(g2emb + (size_t)li.offset * C, li, g, cache, valid);
 }
-
 
 // ------------------------------------------------------------------------------------ value+Jacobian backward
 // grad_emb += d<feat, g_feat>/dE + d<dy_dx, g_dydx>/dE in ONE scatter pass.  The second term is the
@@ -360,15 +401,18 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
     uint32_t level, chunk;
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
-    if (b >= B) return;
     const LevelInfo li = level_info<D>(offsets, level, sc);
     uint32_t g[D];
     float w[D], dw[D];
-    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) return;
+    const bool valid = b < B && locate<D>(x + (size_t)b * D, li, g, w, dw);
     float cache[(1 << D) * C];
 #pragma unroll
     for (int i = 0; i < (1 << D) * C; i++) cache[i] = 0.f;
-    if (g_feat) {
+    if (!valid) {
+#pragma unroll
+        for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
+    }
+    if (valid && g_feat) {
         const float *go = g_feat + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
         float gv[C];
 #pragma unroll
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             for (int c = 0; c < C; c++) cache[corner * C + c] = wt * gv[c];
         }
     }
-    if (g_dydx) {
+    if (valid && g_dydx) {
         const float *gj = g_dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
         float G[D * C];
 #pragma unroll
@@ -408,16 +452,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             }
         }
     }
-    float *gg = gemb + (size_t)li.offset * C;
-#pragma unroll
-    for (int corner = 0; corner < (1 << D); corner++) {
-        uint32_t gl[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
-        float *e = gg + (size_t)cell_index<D>(li, gl) * C;
-#pragma unroll
-        for (int c = 0; c < C; c++) unsafeAtomicAdd(e + c, cache[corner * C + c]);
-    }
+    scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 
 // ------------------------------------------------------------------------------------ host side

@@ -168,3 +168,43 @@ def test_full_size_properties():
     (g2,) = torch.autograd.grad((gx * v).sum(), enc.embeddings)
     # (gx . v) is linear in E: <E, d(gx.v)/dE> == gx.v
     assert abs((enc.embeddings.double() * g2.double()).sum() - (gx.double() * v.double()).sum()) <= 1e-4 * abs((gx.double() * v.double()).sum())
+
+
+def test_scatter_with_ray_ordered_points_vs_oracle():
+    """Consecutive lanes in the same cell exercise the wave-merged scatter (runs of every length,
+    runs crossing wave boundaries, OOB lanes splitting runs, a ragged last block)."""
+    g = torch.Generator().manual_seed(11)
+    L, base, end, logmap = 8, 4, 128, 12
+    pls = hash_oracle.per_level_scale_for(base, end, L)
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, logmap))
+    emb = torch.rand(int(offs[-1]), 2, generator=g) - 0.5
+    R, N = 37, 98
+    o = torch.tensor([0.85, 0.5, 0.5])
+    d = torch.nn.functional.normalize(torch.tensor([-1.0, 0, 0]) + (torch.rand(R, 3, generator=g) - 0.5) * 0.6, dim=-1)
+    z = torch.sort(torch.rand(R, N, generator=g) ** 3 * 1.3, -1)[0]       # clustered near the origin of the ray
+    z[:, 10:20] = z[:, 10:11]                                               # exact duplicates
+    x = (o + z[..., None] * d[:, None]).reshape(-1, 3).contiguous()
+    B = x.shape[0]
+    S = float(np.log2(pls))
+    _, ref_dydx = hash_oracle.fwd(x, emb, offs, S, base, True)
+    grad = torch.randn(L, B, 2, generator=g)
+    ref_gx, ref_ge = hash_oracle.bwd(grad, x, emb, offs, S, base, True, ref_dydx)
+    ggx = torch.randn(B, 3, generator=g)
+    _, ref_g2 = hash_oracle.bwd2(grad, x, emb, offs, S, base, ref_dydx, ggx)
+    dev = "cuda"
+    xd, od = x.to(dev), offs.to(dev)
+    gpm = grad.permute(1, 0, 2).reshape(B, -1).contiguous().to(dev)
+    dydx = ref_dydx.view(B, L, 6).permute(1, 0, 2).contiguous().to(dev)
+    ge = torch.zeros(emb.shape, device=dev)
+    _be().bwd(gpm, xd, od, ge, B, 3, 2, L, S, base, None, None)
+    scale = float(ref_ge.abs().max())
+    assert (ge.cpu() - ref_ge).abs().max() <= 1e-5 * scale
+    g2 = torch.zeros(emb.shape, device=dev)
+    _be().bwd2(gpm, xd, od, B, 3, 2, L, S, base, dydx, ggx.to(dev), None, g2)
+    assert (g2.cpu() - ref_g2).abs().max() <= 1e-5 * float(ref_g2.abs().max())
+    # fused value+Jacobian scatter == first-backward scatter + rank-one second-backward scatter
+    G = (grad[:, :, None, :] * ggx[None, :, :, None]).reshape(L, B, 6).contiguous().to(dev)
+    gj = torch.zeros(emb.shape, device=dev)
+    _be().bwd_jac(gpm, G, xd, od, gj, B, 3, 2, L, S, base)
+    ref = ref_ge + ref_g2
+    assert (gj.cpu() - ref).abs().max() <= 1e-5 * float(ref.abs().max())
