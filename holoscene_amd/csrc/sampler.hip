@@ -1,0 +1,310 @@
+// holoscene_amd/csrc/sampler.hip -- per-ray kernels of the error-bounded sampler (VolSDF Algorithm 1) for gfx950.
+//
+// Replaces the ~540 tiny PyTorch kernels per sampler round of the reference's
+// ErrorBoundSampler.get_z_vals (model/ray_sampler.py:130-287, get_error_bound :450-458).
+//
+// One 64-lane wave owns one ray.  The ray's sorted sample depths, SDF values and
+// derived per-section quantities live in LDS (<= 6 arrays x M floats, M <= 1024);
+// every cumulative sum is a two-level scan (serial inside a lane's contiguous
+// chunk, wave shuffle scan across lanes), every max a wave shuffle reduction, the
+// 10-step beta bisection runs entirely in registers/LDS with no global traffic.
+//
+//   k_sampler_update  merge the round's new samples+SDFs into the sorted set (merge by
+//                     rank: both inputs are sorted), d* (Heron bound, :165-178), beta line
+//                     search (:181-190), global max(beta) for the convergence test (:204)
+//   k_sampler_draw    pdf/cdf from the error bound (:209-219) or from the rendering
+//                     weights (:224-232), inverse-CDF sampling (:241-253)
+//   k_sampler_final   near/far/extra samples + final sort (:261-276), Eikonal pick (:279-280)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "holoscene_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Laplace density sigma(s; beta) (model/density.py:21-26)
+__device__ __forceinline__ float laplace_sigma(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.f / beta) * (0.5f + 0.5f * sgn * expm1f(-fabsf(s) / beta));
+}
+
+// sections [lo, hi) handled by this lane
+__device__ __forceinline__ void lane_chunk(int n, int lane, int &lo, int &hi) {
+    const int ch = (n + kWave - 1) / kWave;
+    lo = min(lane * ch, n);
+    hi = min(lo + ch, n);
+}
+
+// max_i (min(exp(E_i), 1e6) - 1) * exp(-F_i), E inclusive cumsum of err terms, F exclusive cumsum of free energy
+// (ray_sampler.py:450-458).  sdf[0..n], dists/dstar[0..n)
+__device__ float error_bound(const float *__restrict__ sdf, const float *__restrict__ dists, const float *__restrict__ dstar, int n, float beta,
+                             int lane) {
+    int lo, hi;
+    lane_chunk(n, lane, lo, hi);
+    float fsum = 0.f, esum = 0.f;
+    for (int i = lo; i < hi; i++) {
+        fsum += dists[i] * laplace_sigma(sdf[i], beta);
+        esum += expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+    }
+    const float fpre = wave_incl_scan(fsum, lane) - fsum;  // exclusive across lanes
+    const float epre = wave_incl_scan(esum, lane) - esum;
+    float f = fpre, e = epre, best = -INFINITY;
+    for (int i = lo; i < hi; i++) {
+        e += expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+        const float b = (fminf(expf(e), 1.0e6f) - 1.0f) * expf(-f);
+        best = fmaxf(best, b);
+        f += dists[i] * laplace_sigma(sdf[i], beta);
+    }
+    return wave_max(best);
+}
+
+__device__ __forceinline__ int lower_bound(const float *a, int n, float v) {  // # elements < v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int upper_bound(const float *a, int n, float v) {  // # elements <= v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >= 0
+    atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+// ------------------------------------------------------------------------------------ update
+__global__ __launch_bounds__(kWave) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
+                                                           const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
+                                                           float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
+                                                           int beta_iters, float *__restrict__ beta_max, int R) {
+    extern __shared__ float lds[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= R) return;
+    const int m = m_old + s_new;
+    float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m;
+    float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
+    const float *nz = samples + (size_t)r * s_new, *ns = new_sdf + (size_t)r * s_new;
+    // stage old set (tz[0..m_old)) and new samples (tz[m_old..m))
+    for (int i = lane; i < m_old; i += kWave) { tz[i] = zr[i]; ts[i] = sr[i]; }
+    for (int i = lane; i < s_new; i += kWave) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
+    __syncthreads();
+    // stable merge by rank (old before new on ties)
+    for (int i = lane; i < m_old; i += kWave) {
+        const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
+        z[p] = tz[i]; sdf[p] = ts[i];
+    }
+    for (int i = lane; i < s_new; i += kWave) {
+        const int p = i + upper_bound(tz, m_old, tz[m_old + i]);
+        z[p] = tz[m_old + i]; sdf[p] = ts[m_old + i];
+    }
+    __syncthreads();
+    for (int i = lane; i < m; i += kWave) { zr[i] = z[i]; sr[i] = sdf[i]; }
+    const int n = m - 1;
+    for (int i = lane; i < n; i += kWave) {  // Theorem 1 bound d* per section
+        const float a = z[i + 1] - z[i], b = fabsf(sdf[i]), c = fabsf(sdf[i + 1]);
+        const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
+        float d = 0.f;
+        if (first) d = b;
+        if (second) d = c;
+        if (!first && !second && (b + c - a > 0.f)) {
+            const float s = (a + b + c) / 2.0f;
+            d = (2.0f * sqrtf(s * (s - a) * (s - b) * (s - c))) / a;
+        }
+        const float sa = (sdf[i] > 0.f) - (sdf[i] < 0.f), sb = (sdf[i + 1] > 0.f) - (sdf[i + 1] < 0.f);
+        dists[i] = a;
+        dstar[i] = (sa * sb == 1.f) ? d : 0.f;
+    }
+    __syncthreads();
+    const float beta0 = *beta0_p;
+    float hi = beta_io[r];
+    if (error_bound(sdf, dists, dstar, n, beta0, lane) <= eps) hi = beta0;
+    float lo = beta0;
+    for (int it = 0; it < beta_iters; it++) {
+        const float mid = (lo + hi) / 2.f;
+        const float err = error_bound(sdf, dists, dstar, n, mid, lane);
+        if (err <= eps) hi = mid;
+        else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
+    }
+    if (lane == 0) {
+        beta_io[r] = hi;
+        atomic_max_float(beta_max, hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------ draw
+// mode 0: pdf ~ error-bound opacity (+tiny); mode 1: pdf ~ rendering weights (+1e-5).  u: explicit [R,n_out] or NULL = linspace(0,1,n_out)
+__global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
+                                                         const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
+                                                         int n_out, float *__restrict__ out, int R) {
+    extern __shared__ float lds[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= R) return;
+    float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
+    const float *zr = z_in + (size_t)r * ld, *sr = sdf_in + (size_t)r * ld;
+    float *sdf = lds + 3 * m;
+    for (int i = lane; i < m; i += kWave) { z[i] = zr[i]; sdf[i] = sr[i]; }
+    __syncthreads();
+    const float beta = beta_in[r];
+    const int n = m - 1;
+    int lo, hi;
+    lane_chunk(n, lane, lo, hi);
+    // transmittance at the start of each section (exclusive scan of free energy)
+    float fsum = 0.f, esum = 0.f;
+    for (int i = lo; i < hi; i++) {
+        const float d = z[i + 1] - z[i];
+        fsum += d * laplace_sigma(sdf[i], beta);
+        if (mode == 0) {
+            const float a = d, b = fabsf(sdf[i]), c = fabsf(sdf[i + 1]);
+            const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
+            float ds = 0.f;
+            if (first) ds = b;
+            if (second) ds = c;
+            if (!first && !second && (b + c - a > 0.f)) {
+                const float s = (a + b + c) / 2.0f;
+                ds = (2.0f * sqrtf(s * (s - a) * (s - b) * (s - c))) / a;
+            }
+            const float sa = (sdf[i] > 0.f) - (sdf[i] < 0.f), sb = (sdf[i + 1] > 0.f) - (sdf[i + 1] < 0.f);
+            if (sa * sb != 1.f) ds = 0.f;
+            esum += expf(-ds / beta) * (d * d) / (4.f * beta * beta);
+            pdf[i] = ds;  // park d* for the second sweep
+        }
+    }
+    float f = wave_incl_scan(fsum, lane) - fsum;
+    float e = (mode == 0) ? wave_incl_scan(esum, lane) - esum : 0.f;
+    float psum = 0.f;
+    for (int i = lo; i < hi; i++) {
+        const float d = z[i + 1] - z[i];
+        const float fe = d * laplace_sigma(sdf[i], beta);
+        const float T = expf(-f);
+        float p;
+        if (mode == 0) {
+            e += expf(-pdf[i] / beta) * (d * d) / (4.f * beta * beta);
+            p = (fminf(expf(e), 1.0e6f) - 1.0f) * T + add_tiny;
+        } else {
+            p = (1.f - expf(-fe)) * T + 1e-5f;
+        }
+        pdf[i] = p;
+        psum += p;
+        f += fe;
+    }
+    const float total = wave_sum(psum);
+    // cdf[0] = 0, cdf[i+1] = cumsum(pdf/total)
+    float csum = 0.f;
+    for (int i = lo; i < hi; i++) { pdf[i] = pdf[i] / total; csum += pdf[i]; }
+    float c = wave_incl_scan(csum, lane) - csum;
+    for (int i = lo; i < hi; i++) { c += pdf[i]; cdf[i + 1] = c; }
+    if (lane == 0) cdf[0] = 0.f;
+    __syncthreads();
+    for (int j = lane; j < n_out; j += kWave) {
+        float u;
+        if (u_in) {
+            u = u_in[(size_t)r * n_out + j];
+        } else {  // torch.linspace(0, 1, n_out): symmetric evaluation around the midpoint
+            const float step = 1.0f / (float)(n_out - 1);
+            u = (j < n_out / 2) ? step * (float)j : 1.0f - step * (float)(n_out - 1 - j);
+        }
+        const int inds = upper_bound(cdf, m, u);  // searchsorted(right=True)
+        const int below = max(inds - 1, 0), above = min(inds, m - 1);
+        const float c0 = cdf[below], c1 = cdf[above], b0 = z[below], b1 = z[above];
+        float den = c1 - c0;
+        if (den < 1e-5f) den = 1.f;
+        out[(size_t)r * n_out + j] = b0 + (u - c0) / den * (b1 - b0);
+    }
+}
+
+// ------------------------------------------------------------------------------------ final
+// z_out = sort(cat(z_samples, near, far, z[:, pick])); z_eik = z_out[eik_idx]
+__global__ __launch_bounds__(kWave) void k_sampler_final(const float *__restrict__ z_samples, int n_s, const float *__restrict__ z_in, int ld,
+                                                          const int64_t *__restrict__ pick, int n_extra, float near, float far,
+                                                          const int64_t *__restrict__ eik_idx, float *__restrict__ z_out, float *__restrict__ z_eik,
+                                                          int R) {
+    extern __shared__ float lds[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= R) return;
+    const int n = n_s + 2 + n_extra;
+    float *v = lds, *sorted = lds + n;
+    for (int i = lane; i < n_s; i += kWave) v[i] = z_samples[(size_t)r * n_s + i];
+    if (lane == 0) { v[n_s] = near; v[n_s + 1] = far; }
+    for (int i = lane; i < n_extra; i += kWave) v[n_s + 2 + i] = z_in[(size_t)r * ld + pick[i]];
+    __syncthreads();
+    for (int i = lane; i < n; i += kWave) {  // rank sort (n ~ 100)
+        const float x = v[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (v[j] < x) || (v[j] == x && j < i);
+        sorted[rank] = x;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += kWave) z_out[(size_t)r * n + i] = sorted[i];
+    if (lane == 0 && z_eik) z_eik[r] = sorted[eik_idx[r]];
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, void *stream) {
+    if (R <= 0) return HS_OK;
+    if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
+    const int m = m_old + s_new;
+    if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
+    k_sampler_update<<<dim3(R), dim3(kWave), 6 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
+                                                                                           eps, beta_iters, beta_max, R);
+    return check_launch();
+}
+
+int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
+                    int32_t n_out, float *out, int32_t R, void *stream) {
+    if (R <= 0 || n_out <= 0) return HS_OK;
+    if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
+    if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
+    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R);
+    return check_launch();
+}
+
+int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
+                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream) {
+    if (R <= 0) return HS_OK;
+    if (!z_samples || !z || !z_out || (n_extra > 0 && !pick) || (z_eik && !eik_idx)) return HS_ERR_NULL;
+    const int n = n_s + 2 + n_extra;
+    if (n > 4096) return HS_ERR_ARG;
+    k_sampler_final<<<dim3(R), dim3(kWave), 2 * n * sizeof(float), (hipStream_t)stream>>>(z_samples, n_s, z, ld, pick, n_extra, near, far, eik_idx,
+                                                                                          z_out, z_eik, R);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -46,7 +46,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final"]
 
 
 def _check(rc, what):
@@ -142,6 +142,31 @@ class _HipBackend:
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")
+
+    # ---- per-ray sampler kernels (include/holoscene_hip.h section 3)
+    @staticmethod
+    def sampler_update(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max):
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_update(_dev(z, "z"), _dev(sdf, "sdf"), ld, m_old, _dev(samples, "samples"), _dev(new_sdf, "new_sdf"),
+                                     samples.shape[1], _dev(beta, "beta"), _dev(beta0, "beta0"), ctypes.c_float(eps), beta_iters,
+                                     _dev(beta_max, "beta_max"), R, _stream()), "hs_sampler_update")
+
+    @staticmethod
+    def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out):
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_draw(_dev(z, "z"), _dev(sdf, "sdf"), ld, m, _dev(beta, "beta"), mode, ctypes.c_float(add_tiny),
+                                   _dev(u, "u"), n_out, _dev(out, "out"), R, _stream()), "hs_sampler_draw")
+
+    @staticmethod
+    def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik):
+        lib = load_library()
+        R, ld = z.shape
+        n_extra = 0 if pick is None else pick.numel()
+        _check(lib.hs_sampler_final(_dev(z_samples, "z_samples"), z_samples.shape[1], _dev(z, "z"), ld, _dev(pick, "pick", torch.int64), n_extra,
+                                    ctypes.c_float(near), ctypes.c_float(far), _dev(eik_idx, "eik_idx", torch.int64), _dev(z_out, "z_out"),
+                                    _dev(z_eik, "z_eik"), R, _stream()), "hs_sampler_final")
 
 
 _backend = _HipBackend()

@@ -16,10 +16,17 @@ VolSDF Algorithm 1), restructured for the GPU:
     ray_sampler.py:79,238,269,279) unless ``cpu_rng=True``.
 """
 import abc
+import os
 
 import torch
 
+from ..hashencoder import backend as _be
 from .density import laplace_density
+
+# "hip": fused per-ray kernels (csrc/sampler.hip) -- the product path; raises without CUDA tensors / the library.
+# "torch": the pre-fusion whole-tensor formulation below, kept for A/B timing and for exercising the host
+#          logic on CPU in `-m "not gpu"` tests.  Never selected implicitly.
+SAMPLER_IMPL = os.environ.get("HOLOSCENE_SAMPLER_IMPL", "hip")
 
 
 def _rand(shape, device, cpu_rng):
@@ -151,7 +158,75 @@ class ErrorBoundSampler(RaySampler):
 
     @torch.no_grad()
     def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None):
-        rng = rng or {}
+        if SAMPLER_IMPL == "hip":
+            return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {})
+        if SAMPLER_IMPL != "torch":
+            raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
+        return self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng or {})
+
+    def _get_z_vals_hip(self, ray_dirs, cam_loc, model, idx, rng):
+        """Algorithm 1 with the per-ray arithmetic in three fused kernels per round (update / draw / final).
+        Per round: 1 SDF sweep, 2 kernel launches, one 4-byte device->host read for the convergence test."""
+        if not ray_dirs.is_cuda:
+            raise RuntimeError("ErrorBoundSampler: the fused sampler kernels need CUDA tensors "
+                               "(set HOLOSCENE_SAMPLER_IMPL=torch explicitly for the whole-tensor formulation)")
+        be = _be._backend
+        dev = ray_dirs.device
+        R = ray_dirs.shape[0]
+        S = self.N_samples_eval
+        ld = S * self.max_total_iters
+        beta0 = model.density.get_beta().detach().reshape(1).contiguous()
+        z0, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+        d0 = z0[:, 1:] - z0[:, :-1]
+        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
+        z = torch.empty(R, ld, device=dev)
+        sdf = torch.empty(R, ld, device=dev)
+        beta_max = torch.zeros(1, device=dev)
+        samples = z0.contiguous()
+        m, rounds = 0, 0
+        while True:
+            points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            new_sdf = self._query_sdf(model, points, idx).reshape(R, -1).contiguous()
+            beta_max.zero_()
+            be.sampler_update(z, sdf, m, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max)
+            m += samples.shape[1]
+            rounds += 1
+            unconverged = bool(beta_max > beta0)  # the one host sync Algorithm 1 needs per round
+            upsample = unconverged and rounds < self.max_total_iters
+            if upsample:
+                samples = torch.empty(R, S, device=dev)
+                be.sampler_draw(z, sdf, m, beta, 0, float(self.add_tiny), None, S, samples)
+            else:
+                n = self.N_samples
+                if model.training:
+                    u = (rng["u_final"].to(dev) if "u_final" in rng else _rand((R, n), dev, self.cpu_rng)).contiguous()
+                else:
+                    u = None
+                samples = torch.empty(R, n, device=dev)
+                be.sampler_draw(z, sdf, m, beta, 1, float(self.add_tiny), u, n, samples)
+                break
+        self.last_rounds = rounds
+        if self.N_samples_extra > 0:
+            if model.training:
+                perm = rng["perm"] if "perm" in rng else torch.randperm(m)
+                pick = perm[: self.N_samples_extra].to(dev).long().contiguous()
+            else:
+                pick = torch.linspace(0, m - 1, self.N_samples_extra, device=dev).long()
+        else:
+            pick = None
+        n_out = samples.shape[1] + 2 + self.N_samples_extra
+        if "eik_idx" in rng:
+            eik = rng["eik_idx"].to(dev).long().contiguous()
+        elif self.cpu_rng:
+            eik = torch.randint(n_out, (R,)).to(dev)
+        else:
+            eik = torch.randint(n_out, (R,), device=dev)
+        z_out = torch.empty(R, n_out, device=dev)
+        z_eik = torch.empty(R, 1, device=dev)
+        be.sampler_final(samples, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
+        return z_out, z_eik
+
+    def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng):
         dev = ray_dirs.device
         R = ray_dirs.shape[0]
         beta0 = model.density.get_beta().detach()

@@ -113,6 +113,33 @@ int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets,
 int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream);
 
+/* ------------------------------------------------------------------ 3. error-bounded ray sampler (per-ray kernels)
+ *
+ * Fused replacements for the per-ray arithmetic of ErrorBoundSampler.get_z_vals
+ * (model/ray_sampler.py:130-287, get_error_bound :450-458): one wavefront per ray, all
+ * per-section arrays in LDS.  R rays; row r of every [R, *] array belongs to ray r.
+ */
+#define HS_SAMPLER_MAX_M 1024
+
+/* One Algorithm-1 round, part 1 (ray_sampler.py:156-190, 204):
+ *   z/sdf [R, ld]: in = sorted sample set of m_old entries per ray, out = merged set of m_old+s_new
+ *   (samples/new_sdf [R, s_new] ascending per ray); beta [R]: in = current upper bound, out = the
+ *   smallest beta within eps found by `beta_iters` bisection steps from *beta0 (device scalar);
+ *   *beta_max = max(*beta_max, beta_r) via atomics (zero it before the call). */
+int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, void *stream);
+
+/* Inverse-CDF sampling (ray_sampler.py:206-253): mode 0 = pdf ~ error-bound opacity + add_tiny,
+ * mode 1 = pdf ~ rendering weights + 1e-5.  u [R, n_out] explicit, or NULL = linspace(0,1,n_out).
+ * out [R, n_out]. */
+int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
+                    int32_t n_out, float *out, int32_t R, void *stream);
+
+/* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
+ * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */
+int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
+                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

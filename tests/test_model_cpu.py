@@ -12,6 +12,8 @@ from model_helpers import build_model, build_loss, close, z_close
 @pytest.fixture(autouse=True)
 def _oracle_hash(monkeypatch):
     oracle_backend.install(monkeypatch)
+    from holoscene_amd.model import ray_sampler
+    monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", "torch")  # explicit opt-in: host-logic check of the whole-tensor formulation
 
 
 @pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])
@@ -91,3 +93,13 @@ def test_reference_style_double_backward_matches_jacobian_path():
             assert float(p1[k].grad.abs().max()) == 0.0, k
         else:
             close(p2[k].grad, p1[k].grad, 2e-3, 1e-4 * float(p1[k].grad.abs().max()), k)
+
+
+def test_fused_sampler_refuses_cpu_tensors(monkeypatch):
+    from holoscene_amd.model import ray_sampler
+    monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", "hip")
+    rec = load("sampler_0")
+    model = build_model(rec)
+    ins = section(rec, "in.")
+    with pytest.raises(RuntimeError, match="CUDA tensors"):
+        model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model)

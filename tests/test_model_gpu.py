@@ -15,8 +15,11 @@ def _dev(d):
             for k, v in d.items()}
 
 
+@pytest.mark.parametrize("impl", ["hip", "torch"])
 @pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])
-def test_sampler(name):
+def test_sampler(name, impl, monkeypatch):
+    from holoscene_amd.model import ray_sampler
+    monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", impl)
     rec = load(name)
     model = build_model(rec, DEV)
     model.train(bool(rec["meta.train"]))
@@ -24,6 +27,9 @@ def test_sampler(name):
     z, z_eik = model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model, rng=_dev(rand_dict(rec)))
     assert model.ray_sampler.last_rounds == int(rec["meta.rounds"])
     z_close(z, torch.from_numpy(rec["out.z_vals"]), frac_loose=0.05)
+    assert z_eik.shape == rec["out.z_samples_eik"].shape
+    eik_idx = torch.from_numpy(rec["rand.eik_idx"]).to(DEV)
+    assert torch.equal(z_eik, torch.gather(z, 1, eik_idx[:, None]))
 
 
 @pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5"])
