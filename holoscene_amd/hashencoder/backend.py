@@ -46,7 +46,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd"]
 
 
 def _check(rc, what):
@@ -167,6 +167,21 @@ class _HipBackend:
         _check(lib.hs_sampler_final(_dev(z_samples, "z_samples"), z_samples.shape[1], _dev(z, "z"), ld, _dev(pick, "pick", torch.int64), n_extra,
                                     ctypes.c_float(near), ctypes.c_float(far), _dev(eik_idx, "eik_idx", torch.int64), _dev(z_out, "z_out"),
                                     _dev(z_eik, "z_eik"), R, _stream()), "hs_sampler_final")
+
+    # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
+    @staticmethod
+    def softplus_tangent_fwd(A, bias, out):
+        lib = load_library()
+        B, rows, W = A.shape
+        _check(lib.hs_softplus_tangent_fwd(_dev(A, "A"), _dev(bias, "bias"), _dev(out, "out"), ctypes.c_int64(B), rows, W, _stream()),
+               "hs_softplus_tangent_fwd")
+
+    @staticmethod
+    def softplus_tangent_bwd(A, bias, G, gA, gbias):
+        lib = load_library()
+        B, rows, W = A.shape
+        _check(lib.hs_softplus_tangent_bwd(_dev(A, "A"), _dev(bias, "bias"), _dev(G, "G"), _dev(gA, "gA"), _dev(gbias, "gbias"),
+                                           ctypes.c_int64(B), rows, W, _stream()), "hs_softplus_tangent_bwd")
 
 
 _backend = _HipBackend()

@@ -104,6 +104,30 @@ class WNLinear(nn.Module):
         return F.linear(x, self.weight, self.bias)
 
 
+class _softplus_tangent(torch.autograd.Function):
+    """[B,rows,W] pre-activations (row 0 = value, rest = tangents) + bias -> activations, one fused pass
+    each way (csrc/mlp_ops.hip)."""
+
+    @staticmethod
+    def forward(ctx, A, bias):
+        A = A.contiguous()
+        out = torch.empty_like(A)
+        _be._backend.softplus_tangent_fwd(A, bias, out)
+        ctx.save_for_backward(A, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        A, bias = ctx.saved_tensors
+        gA = torch.empty_like(A)
+        gbias = torch.zeros_like(bias) if ctx.needs_input_grad[1] else None
+        _be._backend.softplus_tangent_bwd(A, bias, G.contiguous(), gA, gbias)
+        return gA, gbias
+
+
+softplus_tangent = _softplus_tangent.apply
+
+
 def softplus100(a):
     return F.softplus(a, beta=100)
 
@@ -201,7 +225,10 @@ class ObjectImplicitNetworkGrid(nn.Module):
 
     def sdf_and_jacobian(self, x):
         """x [B,3] (treated as constant) -> y [B,K'], J [B,K',3] with J[b,k,:] = d y_k / d x.
-        Differentiable w.r.t. every parameter by plain first-order autograd."""
+        Differentiable w.r.t. every parameter by plain first-order autograd.
+
+        Each point carries 4 rows through the trunk: the value and its three input tangents.  A Linear acts
+        on all rows alike (one GEMM with M = 4B); Softplus becomes the fused `softplus_tangent` stage."""
         x = x.detach()
         feat, fjac = hash_encode_jac(self.encoding, x / self.divide_factor)
         fjac = fjac / self.divide_factor
@@ -209,24 +236,17 @@ class ObjectImplicitNetworkGrid(nn.Module):
             emb, ejac = self.embedder.embed_jacobian(x)
         else:
             emb, ejac = x, torch.eye(3, device=x.device, dtype=x.dtype).expand(x.shape[0], 3, 3)
-        inp = torch.cat([emb, feat], -1)              # [B, F]
-        tin = torch.cat([ejac, fjac], -1)             # [B, 3, F]
-        h, t = inp, tin
+        inp = torch.cat([torch.cat([emb, feat], -1).unsqueeze(1), torch.cat([ejac, fjac], -1)], 1)   # [B,4,F]
+        h = inp
         lins = self._lins()
         for l, lin in enumerate(lins):
             if l in self.skip_in:
-                h = torch.cat([h, inp], 1) / np.sqrt(2)
-                t = torch.cat([t, tin], 2) / np.sqrt(2)
-            w = lin.weight
-            stacked = torch.cat([h.unsqueeze(1), t], 1)                  # [B,4,in]: value row + 3 tangent rows
-            out = torch.matmul(stacked, w.t())                          # one GEMM, M = 4B
-            a, t = out[:, 0] + lin.bias, out[:, 1:]
+                h = torch.cat([h, inp], 2) / np.sqrt(2)
+            out = torch.matmul(h, lin.weight.t())                       # one GEMM, M = 4B
             if l < len(lins) - 1:
-                h = softplus100(a)
-                t = t * softplus100_grad(a).unsqueeze(1)
+                h = softplus_tangent(out, lin.bias)
             else:
-                h = a
-        return h, t.transpose(1, 2)
+                return out[:, 0] + lin.bias, out[:, 1:].transpose(1, 2)
 
     # ---------------------------------------------------------------- reference API
     def forward(self, input):

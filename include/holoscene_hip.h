@@ -140,6 +140,15 @@ int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, con
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
                      const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream);
 
+/* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
+ *
+ * A, out, G, gA: [B, rows, W] f32 (rows = 1 value row + up to 3 tangent rows), W % 4 == 0.
+ * forward : v = A[b,0,:]+bias; out[b,0,:] = Softplus(beta=100)(v) (model/network.py:163); out[b,d,:] = sigmoid(100 v)*A[b,d,:]
+ * backward: gA = d<out,G>/dA, gbias (ACCUMULATE, may be NULL) += sum_b gA[b,0,:]. */
+int hs_softplus_tangent_fwd(const float *A, const float *bias, float *out, int64_t B, int32_t rows, int32_t W, void *stream);
+int hs_softplus_tangent_bwd(const float *A, const float *bias, const float *G, float *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

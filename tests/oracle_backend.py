@@ -52,6 +52,22 @@ class OracleBackend:
                 _, g2 = hash_oracle.bwd2(G[:, :, d, :].contiguous(), inputs, emb0, offsets, S, H, dummy, e)
                 grad_embeddings.add_(g2)
 
+    # elementwise trunk stages: plain torch restatement (test-only)
+    @staticmethod
+    def softplus_tangent_fwd(A, bias, out):
+        v = A[:, 0] + bias
+        out[:, 0] = torch.nn.functional.softplus(v, beta=100)
+        out[:, 1:] = torch.sigmoid(100 * v).unsqueeze(1) * A[:, 1:]
+
+    @staticmethod
+    def softplus_tangent_bwd(A, bias, G, gA, gbias):
+        v = A[:, 0] + bias
+        s = torch.sigmoid(100 * v)
+        gA[:, 1:] = s.unsqueeze(1) * G[:, 1:]
+        gA[:, 0] = s * G[:, 0] + 100 * s * (1 - s) * (A[:, 1:] * G[:, 1:]).sum(1)
+        if gbias is not None:
+            gbias.add_(gA[:, 0].sum(0))
+
 
 def install(monkeypatch):
     from holoscene_amd.hashencoder import backend

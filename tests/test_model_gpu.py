@@ -81,3 +81,22 @@ def test_full_size_iteration_properties():
     assert torch.isfinite(lo["loss"]) and "bg_depth_values" in out  # iteration 0 renders the background patch
     after = tr.model.implicit_network.encoding.embeddings.detach()
     assert float((after - before).abs().max()) > 0, "Adam must have moved the geometry grid"
+
+
+@pytest.mark.parametrize("rows,W,B", [(4, 256, 1000), (4, 64, 333), (1, 256, 65), (3, 128, 64)])
+def test_softplus_tangent_kernels(rows, W, B):
+    """Fused trunk stage vs plain torch ops (fp32 reference of the same op), forward and backward."""
+    from holoscene_amd.model.network import softplus_tangent
+    g = torch.Generator().manual_seed(rows * 100 + W)
+    A = (torch.randn(B, rows, W, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    A.data[0, 0, :8] = torch.tensor([0.3, -0.3, 0.2001, 0.1999, 0.0, 1e-4, -1e-4, 5.0])  # both softplus branches
+    bias = (torch.randn(W, generator=g) * 0.01).to(DEV).requires_grad_(True)
+    G = torch.randn(B, rows, W, generator=g).to(DEV)
+    out = softplus_tangent(A, bias)
+    v = A[:, 0] + bias
+    ref = torch.cat([torch.nn.functional.softplus(v, beta=100).unsqueeze(1), torch.sigmoid(100 * v).unsqueeze(1) * A[:, 1:]], 1)
+    close(out, ref, 1e-5, 1e-6, "fwd")
+    gA, gb = torch.autograd.grad(out, (A, bias), G)
+    rA, rb = torch.autograd.grad(ref, (A, bias), G)
+    close(gA, rA, 1e-4, 1e-5, "gA")
+    close(gb, rb, 1e-4, 1e-4 * float(rb.abs().max()), "gbias")
