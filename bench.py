@@ -36,6 +36,8 @@ def parse():
     p.add_argument("--samples", type=int, default=128)
     p.add_argument("--objects", type=int, default=32)
     p.add_argument("--beta", type=float, default=0.001)
+    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                   help="MLP GEMM operand precision (BASELINE configs[1] names bf16; fp32 is the reference's own precision)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -132,7 +134,7 @@ def main():
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
     from holoscene_amd.training import distributed as dist_util
 
-    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta)
+    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision)
     tr = Stage1Trainer(conf, device=dev, world_size=world, seed=42)
     benchmark_model_state(tr.model, args.beta)
     if world > 1:
@@ -184,10 +186,11 @@ def main():
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
-                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}",
+                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}, "
+                                   f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
                        "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(rounds_seen) / max(1, len(rounds_seen)), 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,

@@ -16,9 +16,36 @@
 
 #include "holoscene_hip.h"
 
+#include <hip/hip_bf16.h>
+
 namespace {
 
 constexpr int kThreads = 256;
+
+// 4 consecutive features as fp32, whatever the storage type (fp32: 16 B, bf16: 8 B per lane)
+template <class T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Quad<__hip_bfloat16> {
+    static __device__ __forceinline__ float4 load(const __hip_bfloat16 *p) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ uint32_t rne(float f) {  // round-to-nearest-even fp32 -> bf16 bits
+        const uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16 *p, float4 v) {
+        uint2 r;
+        r.x = rne(v.x) | (rne(v.y) << 16);
+        r.y = rne(v.z) | (rne(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = r;
+    }
+};
 constexpr int kPointsPerBlock = 64;
 
 __device__ __forceinline__ float softplus100(float v) {  // torch.nn.Softplus(beta=100, threshold=20)
@@ -29,33 +56,33 @@ __device__ __forceinline__ float softplus100(float v) {  // torch.nn.Softplus(be
 __device__ __forceinline__ float sigmoid100(float v) { return 1.f / (1.f + expf(-100.f * v)); }
 
 // A, out: [B, rows, W]; one thread = one (point, 4 consecutive features); rows = 1 + number of tangents (1..4)
-template <int ROWS>
-__global__ __launch_bounds__(kThreads) void k_softplus_tangent_fwd(const float *__restrict__ A, const float *__restrict__ bias,
-                                                                    float *__restrict__ out, int64_t B, int W) {
+template <int ROWS, class T>
+__global__ __launch_bounds__(kThreads) void k_softplus_tangent_fwd(const T *__restrict__ A, const float *__restrict__ bias,
+                                                                    T *__restrict__ out, int64_t B, int W) {
     const int quads = W >> 2;
     const int64_t total = B * quads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         const int64_t b = i / quads;
         const int q = (int)(i - b * quads);
         const float4 bi = reinterpret_cast<const float4 *>(bias)[q];
-        const float4 *src = reinterpret_cast<const float4 *>(A + b * ROWS * W) + q;
-        float4 *dst = reinterpret_cast<float4 *>(out + b * ROWS * W) + q;
-        float4 a0 = src[0];
+        const T *src = A + b * ROWS * W + 4 * q;
+        T *dst = out + b * ROWS * W + 4 * q;
+        float4 a0 = Quad<T>::load(src);
         a0.x += bi.x; a0.y += bi.y; a0.z += bi.z; a0.w += bi.w;
-        dst[0] = make_float4(softplus100(a0.x), softplus100(a0.y), softplus100(a0.z), softplus100(a0.w));
+        Quad<T>::store(dst, make_float4(softplus100(a0.x), softplus100(a0.y), softplus100(a0.z), softplus100(a0.w)));
         const float4 s = make_float4(sigmoid100(a0.x), sigmoid100(a0.y), sigmoid100(a0.z), sigmoid100(a0.w));
 #pragma unroll
         for (int r = 1; r < ROWS; r++) {
-            const float4 t = src[(size_t)r * quads];
-            dst[(size_t)r * quads] = make_float4(s.x * t.x, s.y * t.y, s.z * t.z, s.w * t.w);
+            const float4 t = Quad<T>::load(src + (size_t)r * W);
+            Quad<T>::store(dst + (size_t)r * W, make_float4(s.x * t.x, s.y * t.y, s.z * t.z, s.w * t.w));
         }
     }
 }
 
 // grid: ceil(B / kPointsPerBlock) blocks; thread = (point slot tid / quads_per_pass ..., quad)
-template <int ROWS>
-__global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const float *__restrict__ A, const float *__restrict__ bias,
-                                                                    const float *__restrict__ G, float *__restrict__ gA,
+template <int ROWS, class T>
+__global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const T *__restrict__ A, const float *__restrict__ bias,
+                                                                    const T *__restrict__ G, T *__restrict__ gA,
                                                                     float *__restrict__ gbias, int64_t B, int W) {
     extern __shared__ float red[];  // [kThreads][4] partial bias sums
     const int quads = W >> 2;
@@ -68,26 +95,26 @@ __global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const float *
         const int64_t b = b0 + i / quads;
         const int q = (int)(i % quads);
         const float4 bi = reinterpret_cast<const float4 *>(bias)[q];
-        const float4 *a = reinterpret_cast<const float4 *>(A + b * ROWS * W) + q;
-        const float4 *g = reinterpret_cast<const float4 *>(G + b * ROWS * W) + q;
-        float4 *o = reinterpret_cast<float4 *>(gA + b * ROWS * W) + q;
-        float4 v = a[0];
+        const T *a = A + b * ROWS * W + 4 * q;
+        const T *g = G + b * ROWS * W + 4 * q;
+        T *o = gA + b * ROWS * W + 4 * q;
+        float4 v = Quad<T>::load(a);
         v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
         const float4 s = make_float4(sigmoid100(v.x), sigmoid100(v.y), sigmoid100(v.z), sigmoid100(v.w));
-        const float4 g0 = g[0];
+        const float4 g0 = Quad<T>::load(g);
         float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 1; r < ROWS; r++) {
-            const float4 t = a[(size_t)r * quads], gr = g[(size_t)r * quads];
+            const float4 t = Quad<T>::load(a + (size_t)r * W), gr = Quad<T>::load(g + (size_t)r * W);
             dot.x += t.x * gr.x; dot.y += t.y * gr.y; dot.z += t.z * gr.z; dot.w += t.w * gr.w;
-            o[(size_t)r * quads] = make_float4(s.x * gr.x, s.y * gr.y, s.z * gr.z, s.w * gr.w);
+            Quad<T>::store(o + (size_t)r * W, make_float4(s.x * gr.x, s.y * gr.y, s.z * gr.z, s.w * gr.w));
         }
         float4 r0;
         r0.x = s.x * g0.x + 100.f * s.x * (1.f - s.x) * dot.x;
         r0.y = s.y * g0.y + 100.f * s.y * (1.f - s.y) * dot.y;
         r0.z = s.z * g0.z + 100.f * s.z * (1.f - s.z) * dot.z;
         r0.w = s.w * g0.w + 100.f * s.w * (1.f - s.w) * dot.w;
-        o[0] = r0;
+        Quad<T>::store(o, r0);
         if (kThreads % quads == 0) {
             acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
         } else if (gbias) {
@@ -113,42 +140,53 @@ __global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const float *
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
-}  // namespace
-
-extern "C" {
-
-int hs_softplus_tangent_fwd(const float *A, const float *bias, float *out, int64_t B, int32_t rows, int32_t W, void *stream) {
-    if (rows < 1 || rows > 4 || W <= 0 || (W & 3)) return HS_ERR_ARG;
-    if (B == 0) return HS_OK;
-    if (!A || !bias || !out) return HS_ERR_NULL;
+template <class T>
+int launch_fwd(const T *A, const float *bias, T *out, int64_t B, int rows, int W, hipStream_t st) {
     const int64_t total = B * (W >> 2);
     const int64_t want = (total + kThreads - 1) / kThreads;
     const int grid = (int)(want < 256 * 16 ? want : 256 * 16);
-    hipStream_t st = (hipStream_t)stream;
     switch (rows) {
-        case 1: k_softplus_tangent_fwd<1><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
-        case 2: k_softplus_tangent_fwd<2><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
-        case 3: k_softplus_tangent_fwd<3><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
-        default: k_softplus_tangent_fwd<4><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
+        case 1: k_softplus_tangent_fwd<1, T><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
+        case 2: k_softplus_tangent_fwd<2, T><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
+        case 3: k_softplus_tangent_fwd<3, T><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
+        default: k_softplus_tangent_fwd<4, T><<<grid, kThreads, 0, st>>>(A, bias, out, B, W); break;
     }
     return check_launch();
 }
 
-int hs_softplus_tangent_bwd(const float *A, const float *bias, const float *G, float *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
-                            void *stream) {
-    if (rows < 1 || rows > 4 || W <= 0 || (W & 3)) return HS_ERR_ARG;
-    if (B == 0) return HS_OK;
-    if (!A || !bias || !G || !gA) return HS_ERR_NULL;
+template <class T>
+int launch_bwd(const T *A, const float *bias, const T *G, T *gA, float *gbias, int64_t B, int rows, int W, hipStream_t st) {
     const int grid = (int)((B + kPointsPerBlock - 1) / kPointsPerBlock);
     const size_t lds = kThreads * 4 * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
     switch (rows) {
-        case 1: k_softplus_tangent_bwd<1><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
-        case 2: k_softplus_tangent_bwd<2><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
-        case 3: k_softplus_tangent_bwd<3><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
-        default: k_softplus_tangent_bwd<4><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
+        case 1: k_softplus_tangent_bwd<1, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
+        case 2: k_softplus_tangent_bwd<2, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
+        case 3: k_softplus_tangent_bwd<3, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
+        default: k_softplus_tangent_bwd<4, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
     }
     return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_softplus_tangent_fwd(const void *A, const float *bias, void *out, int64_t B, int32_t rows, int32_t W, int32_t dtype, void *stream) {
+    if (rows < 1 || rows > 4 || W <= 0 || (W & 3) || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!A || !bias || !out) return HS_ERR_NULL;
+    if (dtype == HS_F32) return launch_fwd<float>((const float *)A, bias, (float *)out, B, rows, W, (hipStream_t)stream);
+    return launch_fwd<__hip_bfloat16>((const __hip_bfloat16 *)A, bias, (__hip_bfloat16 *)out, B, rows, W, (hipStream_t)stream);
+}
+
+int hs_softplus_tangent_bwd(const void *A, const float *bias, const void *G, void *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
+                            int32_t dtype, void *stream) {
+    if (rows < 1 || rows > 4 || W <= 0 || (W & 3) || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!A || !bias || !G || !gA) return HS_ERR_NULL;
+    if (dtype == HS_F32) return launch_bwd<float>((const float *)A, bias, (const float *)G, (float *)gA, gbias, B, rows, W, (hipStream_t)stream);
+    return launch_bwd<__hip_bfloat16>((const __hip_bfloat16 *)A, bias, (const __hip_bfloat16 *)G, (__hip_bfloat16 *)gA, gbias, B, rows, W,
+                                      (hipStream_t)stream);
 }
 
 }  // extern "C"

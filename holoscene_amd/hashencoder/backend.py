@@ -26,6 +26,7 @@ class hsHashLayout(ctypes.Structure):
 
 
 _lib = None
+_DTYPES = {torch.float32: 0, torch.bfloat16: 1}  # HS_F32 / HS_BF16
 
 
 def load_library():
@@ -173,15 +174,17 @@ class _HipBackend:
     def softplus_tangent_fwd(A, bias, out):
         lib = load_library()
         B, rows, W = A.shape
-        _check(lib.hs_softplus_tangent_fwd(_dev(A, "A"), _dev(bias, "bias"), _dev(out, "out"), ctypes.c_int64(B), rows, W, _stream()),
-               "hs_softplus_tangent_fwd")
+        dt = A.dtype
+        _check(lib.hs_softplus_tangent_fwd(_dev(A, "A", dt), _dev(bias, "bias"), _dev(out, "out", dt), ctypes.c_int64(B), rows, W,
+                                           _DTYPES[dt], _stream()), "hs_softplus_tangent_fwd")
 
     @staticmethod
     def softplus_tangent_bwd(A, bias, G, gA, gbias):
         lib = load_library()
         B, rows, W = A.shape
-        _check(lib.hs_softplus_tangent_bwd(_dev(A, "A"), _dev(bias, "bias"), _dev(G, "G"), _dev(gA, "gA"), _dev(gbias, "gbias"),
-                                           ctypes.c_int64(B), rows, W, _stream()), "hs_softplus_tangent_bwd")
+        dt = A.dtype
+        _check(lib.hs_softplus_tangent_bwd(_dev(A, "A", dt), _dev(bias, "bias"), _dev(G, "G", dt), _dev(gA, "gA", dt), _dev(gbias, "gbias"),
+                                           ctypes.c_int64(B), rows, W, _DTYPES[dt], _stream()), "hs_softplus_tangent_bwd")
 
 
 _backend = _HipBackend()

@@ -36,6 +36,10 @@ extern "C" {
 
 #define HS_MAX_LEVELS 32
 
+/* storage types of activation tensors */
+#define HS_F32 0
+#define HS_BF16 1
+
 /* ------------------------------------------------------------------ 0. library info */
 /* ABI version; bumped whenever a signature below changes. */
 int hs_abi_version(void);
@@ -142,12 +146,13 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
- * A, out, G, gA: [B, rows, W] f32 (rows = 1 value row + up to 3 tangent rows), W % 4 == 0.
+ * A, out, G, gA: [B, rows, W], storage type `dtype` = HS_F32 or HS_BF16 (arithmetic is fp32 either way; bias and
+ * gbias are always f32); rows = 1 value row + up to 3 tangent rows; W % 4 == 0.
  * forward : v = A[b,0,:]+bias; out[b,0,:] = Softplus(beta=100)(v) (model/network.py:163); out[b,d,:] = sigmoid(100 v)*A[b,d,:]
  * backward: gA = d<out,G>/dA, gbias (ACCUMULATE, may be NULL) += sum_b gA[b,0,:]. */
-int hs_softplus_tangent_fwd(const float *A, const float *bias, float *out, int64_t B, int32_t rows, int32_t W, void *stream);
-int hs_softplus_tangent_bwd(const float *A, const float *bias, const float *G, float *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
-                            void *stream);
+int hs_softplus_tangent_fwd(const void *A, const float *bias, void *out, int64_t B, int32_t rows, int32_t W, int32_t dtype, void *stream);
+int hs_softplus_tangent_bwd(const void *A, const float *bias, const void *G, void *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
+                            int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }
