@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--beta", type=float, default=0.001)
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                    help="MLP GEMM operand precision (BASELINE configs[1] names bf16; fp32 is the reference's own precision)")
+    p.add_argument("--no-graph", action="store_true", help="run the post-sampler part eagerly instead of as a captured HIP graph")
+    p.add_argument("--optimizer", choices=["flat", "torch"], default="flat")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -135,7 +137,8 @@ def main():
     from holoscene_amd.training import distributed as dist_util
 
     conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision)
-    tr = Stage1Trainer(conf, device=dev, world_size=world, seed=42)
+    tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
+                       graph=(not args.no_graph) and args.optimizer == "flat")
     benchmark_model_state(tr.model, args.beta)
     if world > 1:
         dist_util.broadcast_parameters(tr.model)

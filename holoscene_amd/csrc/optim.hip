@@ -1,0 +1,94 @@
+// holoscene_amd/csrc/optim.hip -- fused dense Adam over one flat parameter buffer (gfx950).
+//
+// The reference steps torch.optim.Adam over 24.7 M parameters in three groups (hash grids at lr*20, MLPs and
+// beta at lr; betas (0.9, 0.99), eps 1e-15) followed by an ExponentialLR step (training/holoscene_train.py:156-169,
+// 374, 428).  Here all parameters, gradients and both moments live in four flat fp32 buffers; one streaming kernel
+// (16 B per lane, 7 x 4 B of HBM traffic per parameter = the algorithmic minimum) applies the update, reading the
+// step count, bias corrections and per-group learning rates from a small device-resident state block that a
+// one-thread "tick" kernel advances -- so the whole optimiser is two launches with no host involvement and can sit
+// inside a captured HIP graph.  A [begin, end) element range lets each rank update only its shard (ZeRO-1).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "holoscene_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// advance step, bias corrections and learning rates (lr_g = lr0_g * gamma^(step-1): ExponentialLR stepped after each update)
+__global__ void k_adam_tick(hsAdamState *st, float beta1, float beta2, double gamma) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t step = st->step + 1;
+    st->step = step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double decay = pow(gamma, (double)(step - 1));
+    for (int g = 0; g < HS_ADAM_MAX_GROUPS; g++) {
+        const double lr = (double)st->lr0[g] * decay;
+        st->lr[g] = (float)lr;
+        st->step_size[g] = (float)(lr / bc1);
+    }
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float step_size, float bc2_sqrt, float beta1, float beta2, float eps,
+                                      float gscale) {
+    g *= gscale;
+    m = m + (1.f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * beta2 + (1.f - beta2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - step_size * (m / denom);                 // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(kThreads) void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, int64_t begin, int64_t end, const hsAdamState *__restrict__ st,
+                                                         float beta1, float beta2, float eps, float gscale) {
+    const float bc2_sqrt = st->bc2_sqrt;
+    const int64_t e0 = st->group_end[0], e1 = st->group_end[1];
+    const float s0 = st->step_size[0], s1 = st->step_size[1], s2 = st->step_size[2];
+    const int64_t q0 = begin >> 2, q1 = end >> 2;  // begin, end are multiples of 4 (checked by the host wrapper)
+    for (int64_t q = q0 + (int64_t)blockIdx.x * kThreads + threadIdx.x; q < q1; q += (int64_t)gridDim.x * kThreads) {
+        float4 pp = reinterpret_cast<float4 *>(p)[q], mm = reinterpret_cast<float4 *>(m)[q], vv = reinterpret_cast<float4 *>(v)[q];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[q];
+        const int64_t i = q << 2;
+        float ss[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ss[k] = (i + k < e0) ? s0 : ((i + k < e1) ? s1 : s2);
+        adam1(pp.x, gg.x, mm.x, vv.x, ss[0], bc2_sqrt, beta1, beta2, eps, gscale);
+        adam1(pp.y, gg.y, mm.y, vv.y, ss[1], bc2_sqrt, beta1, beta2, eps, gscale);
+        adam1(pp.z, gg.z, mm.z, vv.z, ss[2], bc2_sqrt, beta1, beta2, eps, gscale);
+        adam1(pp.w, gg.w, mm.w, vv.w, ss[3], bc2_sqrt, beta1, beta2, eps, gscale);
+        reinterpret_cast<float4 *>(p)[q] = pp;
+        reinterpret_cast<float4 *>(m)[q] = mm;
+        reinterpret_cast<float4 *>(v)[q] = vv;
+    }
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, void *stream) {
+    if (!state) return HS_ERR_NULL;
+    k_adam_tick<<<1, 1, 0, (hipStream_t)stream>>>(state, beta1, beta2, gamma);
+    return check_launch();
+}
+
+int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, const hsAdamState *state, float beta1, float beta2,
+                 float eps, float grad_scale, void *stream) {
+    if (end <= begin) return HS_OK;
+    if ((begin & 3) || (end & 3)) return HS_ERR_ARG;  // flat buffers are padded to whole 16-byte quads
+    if (!p || !g || !m || !v || !state) return HS_ERR_NULL;
+    const int64_t quads = (end - begin) >> 2;
+    int64_t want = (quads + kThreads - 1) / kThreads;
+    if (want < 1) want = 1;
+    const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
+    k_adam_flat<<<grid, kThreads, 0, (hipStream_t)stream>>>(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale);
+    return check_launch();
+}
+
+}  // extern "C"

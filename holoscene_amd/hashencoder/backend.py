@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat"]
 
 
 def _check(rc, what):
@@ -72,6 +72,12 @@ def _stream():
 
 
 SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
+
+# When True and a table already has a `.grad` buffer attached (flat gradient storage, training/flat.py), the
+# scatter kernels accumulate straight into it and the autograd Functions return no table gradient -- this removes
+# the per-call 48.8 MB zero-fill + AccumulateGrad add of the reference (hashgrid.py:75-76).  Off by default so that
+# torch.autograd.grad(..., embeddings) keeps its meaning.
+ACCUMULATE_INTO_GRAD = False
 
 
 def point_major_layout(C, L, D):
@@ -185,6 +191,25 @@ class _HipBackend:
         dt = A.dtype
         _check(lib.hs_softplus_tangent_bwd(_dev(A, "A", dt), _dev(bias, "bias"), _dev(G, "G", dt), _dev(gA, "gA", dt), _dev(gbias, "gbias"),
                                            ctypes.c_int64(B), rows, W, _DTYPES[dt], _stream()), "hs_softplus_tangent_bwd")
+
+    # ---- fused Adam (include/holoscene_hip.h section 5); `state` is a uint8 CUDA tensor holding an hsAdamState
+    @staticmethod
+    def adam_tick(state, beta1, beta2, gamma):
+        lib = load_library()
+        _check(lib.hs_adam_tick(_dev(state, "state", torch.uint8), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_double(gamma),
+                                _stream()), "hs_adam_tick")
+
+    @staticmethod
+    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale):
+        lib = load_library()
+        _check(lib.hs_adam_flat(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), ctypes.c_int64(begin), ctypes.c_int64(end),
+                                _dev(state, "state", torch.uint8), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                ctypes.c_float(grad_scale), _stream()), "hs_adam_flat")
+
+
+class hsAdamState(ctypes.Structure):
+    _fields_ = [("step", ctypes.c_int64), ("group_end", ctypes.c_int64 * 2), ("lr0", ctypes.c_float * 3), ("lr", ctypes.c_float * 3),
+                ("step_size", ctypes.c_float * 3), ("bc2_sqrt", ctypes.c_float)]
 
 
 _backend = _HipBackend()

@@ -25,6 +25,7 @@ from . import backend as _be
 class _hash_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+        embeddings_param = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         inputs = inputs.contiguous()
         embeddings = embeddings.contiguous()
         offsets = offsets.contiguous()
@@ -39,6 +40,7 @@ class _hash_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H)
         ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.table = embeddings_param if embeddings_param is not None else None
         return outputs
 
     @staticmethod
@@ -46,6 +48,12 @@ class _hash_encode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         need_x = ctx.calc_grad_inputs and ctx.needs_input_grad[0]
         need_e = ctx.needs_input_grad[1]
+        table = ctx.table
+        if need_e and _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None and not torch.is_grad_enabled():
+            B, D, C, L, S, H = ctx.dims
+            gx = torch.empty_like(inputs) if need_x else None
+            _be._backend.bwd(grad.contiguous(), inputs, offsets, table.grad, B, D, C, L, S, H, dy_dx, gx)
+            return gx, None, None, None, None, None
         grad_inputs, grad_embeddings = _hash_encode_backward.apply(grad.contiguous(), inputs, embeddings, offsets, dy_dx, ctx.dims,
                                                                    need_x, need_e)
         return grad_inputs, grad_embeddings, None, None, None, None

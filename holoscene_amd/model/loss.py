@@ -22,9 +22,10 @@ def compute_scale_and_shift_batch(prediction, target):
     a11 = ones.sum(1)
     b0 = (prediction * target).sum(1)
     b1 = target.sum(1)
-    M = torch.stack([torch.stack([a00, a01], -1), torch.stack([a01, a11], -1)], -2)  # [B,2,2]
-    rs = (torch.inverse(M) @ torch.stack([b0, b1], -1).unsqueeze(-1)).squeeze(-1)
-    return rs[:, 0], rs[:, 1]
+    # closed-form inverse of the 2x2 normal matrix (the reference calls torch.inverse, loss.py:190; an LU routine
+    # with a host-side status check is neither needed for 2x2 nor capturable in a HIP graph)
+    det = a00 * a11 - a01 * a01
+    return (a11 * b0 - a01 * b1) / det, (a00 * b1 - a01 * b0) / det
 
 
 def _resolve(cls_or_name):

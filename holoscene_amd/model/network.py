@@ -43,6 +43,7 @@ class _hash_encode_jac(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x01, embeddings, offsets, S, H):
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         x01 = x01.contiguous()
         B, D = x01.shape
         L = offsets.shape[0] - 1
@@ -60,9 +61,12 @@ class _hash_encode_jac(torch.autograd.Function):
         B, D, C, L, S, H = ctx.dims
         g_emb = g_x = None
         if ctx.needs_input_grad[1]:
-            g_emb = torch.zeros_like(embeddings)
+            table = ctx.table
+            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            target = table.grad if inplace else torch.zeros_like(embeddings)
             _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(),
-                                 x01, offsets, g_emb, B, D, C, L, S, H)
+                                 x01, offsets, target, B, D, C, L, S, H)
+            g_emb = None if inplace else target
         if ctx.needs_input_grad[0] and g_feat is not None:
             g_x = torch.empty_like(x01)
             _be._backend.bwd(g_feat.contiguous(), x01, offsets, None, B, D, C, L, S, H, dydx, g_x)
@@ -515,11 +519,11 @@ class HoloSceneNetwork(nn.Module):
         obj_density = self.density(sdf_raw).transpose(0, 1).reshape(-1, dists.shape[0], dists.shape[1])  # [K, R, N]
         return (1 - torch.exp(-dists * obj_density)) * transmittance
 
-    # ---------------------------------------------------------------- forward (network.py:778-971)
-    def forward(self, input, indices, iter_step=-1, rng=None):
-        """rng: optional dict of explicit random draws (SURVEY appendix B): 'ray_offset' [1,R,2] (already
-        minus 0.5), sampler draws 't_rand','u_final','perm','eik_idx', 'eik_uniform' [R,3], 'eik_jitter' [2R,3],
-        and for background iterations 'bg_xy0' + 'bg' (a second sampler dict)."""
+    # ---------------------------------------------------------------- forward (network.py:778-971), in stages
+    # forward() = prepare_rays -> sample -> (prepare_background) -> render.  The stages exist so the trainer can
+    # run the data-dependent part (rays + Algorithm-1 sampler, which needs a host decision per round) eagerly and
+    # replay everything after it -- render, loss, backward, Adam -- as one captured HIP graph.
+    def prepare_rays(self, input, rng=None):
         rng = rng or {}
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         dev = uv.device
@@ -531,12 +535,55 @@ class HoloSceneNetwork(nn.Module):
         else:
             ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
             ray_dirs_tmp, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics)
-        depth_scale = ray_dirs_tmp[0, :, 2:]
-        batch_size, num_pixels, _ = ray_dirs.shape
-        cam_loc = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
-        ray_dirs = ray_dirs.reshape(-1, 3)
+        num_pixels = ray_dirs.shape[1]
+        return {"ray_dirs": ray_dirs.reshape(-1, 3).contiguous(),
+                "cam_loc": cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3).contiguous(),
+                "depth_scale": ray_dirs_tmp[0, :, 2:].contiguous(),
+                "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
 
-        z_vals, z_samples_eik = self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self, rng=rng)
+    def sample(self, rays, rng=None, idx=None):
+        return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng)
+
+    def wants_background(self, iter_step):
+        return bool(self.use_bg_reg and iter_step % self.render_bg_iter == 0)
+
+    def prepare_background(self, input, rng=None):
+        """Rays and depths of the 32x32 background patch (network.py:919-942)."""
+        rng = rng or {}
+        intrinsics, pose = input["intrinsics"], input["pose"]
+        dev = pose.device
+        patch = 32
+        if "bg_xy0" in rng:
+            xy0 = torch.tensor([int(v) for v in rng["bg_xy0"]], device=dev, dtype=torch.float32)
+        else:  # device-side draw of the patch origin: no host read of the intrinsics
+            span = (intrinsics[0, :2, 2] * 2.0).floor() - patch + 1
+            xy0 = torch.floor(torch.rand(2, device=dev) * span)
+        gy, gx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
+        uv0 = (torch.stack([gx, gy], -1).reshape(1, -1, 2).float() + xy0)
+        ray_dirs0, cam_loc0 = rend_util.get_camera_params(uv0, pose, intrinsics)
+        tmp0, _ = rend_util.get_camera_params(uv0, torch.eye(4, device=dev)[None], intrinsics)
+        n0 = ray_dirs0.shape[1]
+        bg = {"ray_dirs": ray_dirs0.reshape(-1, 3).contiguous(),
+              "cam_loc": cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3).contiguous(),
+              "depth_scale": tmp0[0, :, 2:].contiguous()}
+        bg["z_vals"], _ = self.ray_sampler.get_z_vals(bg["ray_dirs"], bg["cam_loc"], self, idx=0, rng=rng.get("bg"))
+        return bg
+
+    def forward(self, input, indices, iter_step=-1, rng=None):
+        """rng: optional dict of explicit random draws (SURVEY appendix B): 'ray_offset' [1,R,2] (already
+        minus 0.5), sampler draws 't_rand','u_final','perm','eik_idx', 'eik_uniform' [R,3], 'eik_jitter' [2R,3],
+        and for background iterations 'bg_xy0' + 'bg' (a second sampler dict)."""
+        rng = rng or {}
+        rays = self.prepare_rays(input, rng)
+        z_vals, z_samples_eik = self.sample(rays, rng)
+        bg = self.prepare_background(input, rng) if self.wants_background(iter_step) else None
+        return self.render(rays, z_vals, z_samples_eik, indices, rng=rng, bg=bg)
+
+    def render(self, rays, z_vals, z_samples_eik, indices=None, rng=None, bg=None):
+        rng = rng or {}
+        ray_dirs, cam_loc, depth_scale, rot = rays["ray_dirs"], rays["cam_loc"], rays["depth_scale"], rays["rot"]
+        dev = ray_dirs.device
+        num_rays = ray_dirs.shape[0]
         N_samples = z_vals.shape[1]
         points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
         dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N_samples, -1).reshape(-1, 3)
@@ -566,11 +613,10 @@ class HoloSceneNetwork(nn.Module):
         }
 
         if self.training:
-            n_eik = batch_size * num_pixels
             if "eik_uniform" in rng:
                 eik = rng["eik_uniform"].to(dev)
             else:
-                eik = torch.empty(n_eik, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere)
+                eik = torch.empty(num_rays, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere)
             near_surface = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
             eik = torch.cat([eik, near_surface], 0)
             jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand_like(eik)
@@ -591,25 +637,10 @@ class HoloSceneNetwork(nn.Module):
 
         normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N_samples, 3)
         normal_map = torch.sum(weights.unsqueeze(-1) * normals, 1)
-        rot = pose[0, :3, :3].permute(1, 0).contiguous()
         output["normal_map"] = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
 
-        if self.use_bg_reg and iter_step % self.render_bg_iter == 0:  # background-surface pass (network.py:916-968)
-            patch = 32
-            if "bg_xy0" in rng:
-                x0, y0 = (int(v) for v in rng["bg_xy0"])
-            else:
-                x0 = int(np.random.randint(0, int(float(intrinsics[0, 0, 2]) * 2.0) - patch + 1))
-                y0 = int(np.random.randint(0, int(float(intrinsics[0, 1, 2]) * 2.0) - patch + 1))
-            gy, gx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
-            uv0 = torch.stack([gx + x0, gy + y0], -1).reshape(1, -1, 2).float()
-            ray_dirs0, cam_loc0 = rend_util.get_camera_params(uv0, pose, intrinsics)
-            tmp0, _ = rend_util.get_camera_params(uv0, torch.eye(4, device=dev)[None], intrinsics)
-            depth_scale0 = tmp0[0, :, 2:]
-            n0 = ray_dirs0.shape[1]
-            cam_loc0 = cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3)
-            ray_dirs0 = ray_dirs0.reshape(-1, 3)
-            bg_z, _ = self.ray_sampler.get_z_vals(ray_dirs0, cam_loc0, self, idx=0, rng=rng.get("bg"))
+        if bg is not None:  # background-surface pass (network.py:943-968)
+            bg_z, ray_dirs0, cam_loc0 = bg["z_vals"], bg["ray_dirs"], bg["cam_loc"]
             n_bg = bg_z.shape[1]
             bg_points = (cam_loc0.unsqueeze(1) + bg_z.unsqueeze(2) * ray_dirs0.unsqueeze(1)).reshape(-1, 3)
             scene_sdf, _, bg_gradients, scene_semantic, bg_sdf = self.implicit_network.get_specific_outputs(bg_points, 0)
@@ -617,7 +648,7 @@ class HoloSceneNetwork(nn.Module):
             scene_weight, _, _ = self.volume_rendering(bg_z, scene_sdf)  # semantics use the scene SDF
             bg_semantic = torch.sum(scene_weight.unsqueeze(-1) * scene_semantic.reshape(-1, n_bg, self.num_semantic), 1)
             output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
-            output["bg_depth_values"] = depth_scale0 * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
+            output["bg_depth_values"] = bg["depth_scale"] * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
             bg_normals = (bg_gradients / (bg_gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, n_bg, 3)
             bg_normal_map = torch.sum(bg_weight.unsqueeze(-1) * bg_normals, 1)
             output["bg_normal_map"] = (rot @ bg_normal_map.permute(1, 0)).permute(1, 0).contiguous()

@@ -36,3 +36,22 @@ def average_gradients(params, world_size, group=None):
 def broadcast_parameters(module, src=0, group=None):
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+def exchange_and_step_flat(flat, world_size, zero1=True, group=None):
+    """Data-parallel step over flat buffers (training/flat.py).
+
+    zero1=True (default): reduce-scatter the flat gradient (each rank receives the SUM of its 1/N slice), run the
+    fused Adam on that slice only (gradient scaled by 1/N inside the kernel), all-gather the updated parameter
+    slices.  Per rank this moves (N-1)/N of the buffer twice -- the same volume as a ring all-reduce -- but cuts the
+    optimiser's HBM traffic and moment storage use by N.  Element-for-element identical to "all-reduce mean, full Adam".
+    zero1=False: one all-reduce over the flat gradient, full Adam on every rank."""
+    if zero1:
+        b, e = flat.shard
+        shard_g = flat.flat_g[b:e]
+        dist.reduce_scatter_tensor(shard_g, flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+        flat.step(grad_scale=1.0 / world_size, shard_only=True)
+        dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e], group=group)
+    else:
+        dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+        flat.step(grad_scale=1.0 / world_size)

@@ -45,31 +45,141 @@ def benchmark_model_state(model, beta, seed=42):
 
 
 class Stage1Trainer:
-    def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, fused_adam=None):
+    """One Stage-1 training iteration, three execution strategies (same arithmetic):
+
+    * ``optimizer="torch"``: torch.optim.Adam + ExponentialLR exactly as the reference wires them (parity tests).
+    * ``optimizer="flat"`` (default): parameters/gradients in flat buffers, fused Adam kernel (training/flat.py),
+      hash-table gradients scattered straight into the flat gradient buffer.
+    * ``graph=True`` (needs "flat"): everything after the sampler -- render, Eikonal set, loss, backward, Adam --
+      is captured once per variant (background pass on/off, collision term on/off) as a HIP graph and replayed;
+      only rays + the data-dependent sampler run eagerly.  ~1 100 kernel launches per iteration collapse into one
+      graph launch, which is what removes the host-side launch gaps (45 % of the iteration before).
+    """
+
+    def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, rank=0, optimizer="flat", graph=False, zero1=True,
+                 freeze_parameters=False):
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
-        self.world_size = world_size
+        self.world_size, self.rank = world_size, rank
         self.model = HoloSceneNetwork(conf=conf.get_config("model"), graph_node_dict=None, num_images=num_images).to(self.device)
         self.loss = HoloSceneLoss(**conf.get_config("loss"))
         self.lr = conf.get_float("train.learning_rate")
-        self.optimizer = build_optimizer(self.model, self.lr, conf.get_float("train.lr_factor_for_grid", default=1.0), fused=fused_adam)
+        lr_factor = conf.get_float("train.lr_factor_for_grid", default=1.0)
+        decay_rate = conf.get_float("train.sched_decay_rate", default=0.1)
         # nepochs * ds_len with ds_len = fix_length: decay_steps == max_total_iters (holoscene_train.py:110-116, 166-169)
-        self.scheduler = build_scheduler(self.optimizer, conf.get_float("train.sched_decay_rate", default=0.1),
-                                         conf.get_int("train.max_total_iters", default=200000))
+        decay_steps = conf.get_int("train.max_total_iters", default=200000)
+        self.flat = None
+        if optimizer == "flat":
+            from ..hashencoder import backend
+            from .flat import FlatAdam
+            self.flat = FlatAdam(self.model, self.lr, lr_factor, decay_rate, decay_steps, world_size=world_size, rank=rank)
+            backend.ACCUMULATE_INTO_GRAD = True
+            self.optimizer = self.scheduler = None
+        elif optimizer == "torch":
+            self.optimizer = build_optimizer(self.model, self.lr, lr_factor)
+            self.scheduler = build_scheduler(self.optimizer, decay_rate, decay_steps)
+        else:
+            raise ValueError(optimizer)
+        if graph and self.flat is None:
+            raise ValueError("graph=True needs optimizer='flat'")
+        self.use_graph = graph
+        self.freeze_parameters = freeze_parameters  # tests: compute gradients but skip the update
+        self.zero1 = zero1 and world_size > 1
         self.add_objectvio_iter = conf.get_int("train.add_objectvio_iter", default=100000)
         self.iter_step = 0
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ eager path
+    def _exchange_and_step(self):
+        if self.flat is not None:
+            if self.world_size > 1:
+                dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+            else:
+                self.flat.step()
+        else:
+            if self.world_size > 1:
+                dist_util.average_gradients(self.model.parameters(), self.world_size)
+            self.optimizer.step()
+            self.scheduler.step()
 
     def train_step(self, indices, model_input, ground_truth, rng=None):
+        if self.use_graph and rng is None:
+            return self._train_step_graph(indices, model_input, ground_truth)
         self.model.train()
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.flat is not None:
+            self.flat.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         out = self.model(model_input, indices, iter_step=self.iter_step, rng=rng)
         out["iter_step"] = self.iter_step
         loss_out = self.loss(out, ground_truth, call_reg=self.iter_step >= self.add_objectvio_iter)
         loss_out["loss"].backward()
-        if self.world_size > 1:
-            dist_util.average_gradients(self.model.parameters(), self.world_size)
-        self.optimizer.step()
-        self.scheduler.step()
+        self._exchange_and_step()
         self.iter_step += 1
         return out, loss_out
+
+    # ------------------------------------------------------------------ graph path
+    def _graph_body(self, st, with_bg, call_reg):
+        self.flat.zero_grad()
+        bg = st["bg"] if with_bg else None
+        out = self.model.render(st["rays"], st["z_vals"], st["z_eik"], None, bg=bg)
+        out["iter_step"] = 0
+        loss_out = self.loss(out, st["gt"], call_reg=call_reg)
+        loss_out["loss"].backward()
+        if self.world_size == 1 and not self.freeze_parameters:
+            self.flat.step()
+        return out, loss_out
+
+    def _capture(self, key, fresh):
+        """fresh: dict of live tensors with the shapes of this variant; becomes the static input block."""
+        with_bg, call_reg = key
+        st = {"rays": {k: v.clone() for k, v in fresh["rays"].items()}, "z_vals": fresh["z_vals"].clone(), "z_eik": fresh["z_eik"].clone(),
+              "gt": {k: v.clone() for k, v in fresh["gt"].items()}}
+        if with_bg:
+            st["bg"] = {k: v.clone() for k, v in fresh["bg"].items()}
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up on a side stream (these are real training steps on the current batch)
+            for _ in range(2):
+                self._graph_body(st, with_bg, call_reg)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out, loss_out = self._graph_body(st, with_bg, call_reg)
+        entry = {"graph": g, "static": st, "out": out, "loss": loss_out}
+        self._graphs[key] = entry
+        return entry
+
+    @staticmethod
+    def _copy_into(dst, src):
+        for k, v in src.items():
+            dst[k].copy_(v, non_blocking=True)
+
+    def _train_step_graph(self, indices, model_input, ground_truth):
+        model = self.model
+        model.train()
+        with torch.no_grad():
+            rays = model.prepare_rays(model_input)
+            z_vals, z_eik = model.sample(rays)
+            with_bg = model.wants_background(self.iter_step)
+            bg = model.prepare_background(model_input) if with_bg else None
+        key = (with_bg, self.iter_step >= self.add_objectvio_iter)
+        fresh = {"rays": rays, "z_vals": z_vals, "z_eik": z_eik, "gt": {k: v for k, v in ground_truth.items()}, "bg": bg}
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(key, fresh)   # capture replays nothing: run the body once more via replay below
+        st = entry["static"]
+        self._copy_into(st["rays"], rays)
+        st["z_vals"].copy_(z_vals)
+        st["z_eik"].copy_(z_eik)
+        self._copy_into(st["gt"], fresh["gt"])
+        if with_bg:
+            self._copy_into(st["bg"], bg)
+        entry["graph"].replay()
+        if self.world_size > 1:
+            dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+        self.iter_step += 1
+        return entry["out"], entry["loss"]

@@ -154,6 +154,28 @@ int hs_softplus_tangent_fwd(const void *A, const float *bias, void *out, int64_t
 int hs_softplus_tangent_bwd(const void *A, const float *bias, const void *G, void *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
                             int32_t dtype, void *stream);
 
+/* ------------------------------------------------------------------ 5. fused dense Adam over a flat parameter buffer
+ *
+ * Replaces torch.optim.Adam(betas, eps) + ExponentialLR (training/holoscene_train.py:156-169, 374, 428).
+ * p/g/m/v: flat f32 buffers of the same length; parameters of group 0 occupy [0, group_end[0]), group 1
+ * [group_end[0], group_end[1]), group 2 the rest.  hsAdamState lives in DEVICE memory; initialise step = 0 and
+ * lr0[] before the first step.  hs_adam_tick advances it (step += 1, bias corrections, lr_g = lr0_g * gamma^(step-1));
+ * hs_adam_flat then updates elements [begin, end) (both multiples of 4) with gradients scaled by grad_scale (1/world_size after a sum
+ * all-reduce).  Both are plain launches: no host reads, graph-capturable. */
+#define HS_ADAM_MAX_GROUPS 3
+typedef struct hsAdamState {
+    int64_t step;
+    int64_t group_end[2];
+    float lr0[HS_ADAM_MAX_GROUPS];
+    float lr[HS_ADAM_MAX_GROUPS];        /* current learning rates (written by hs_adam_tick) */
+    float step_size[HS_ADAM_MAX_GROUPS]; /* lr / (1 - beta1^step) */
+    float bc2_sqrt;                      /* sqrt(1 - beta2^step) */
+} hsAdamState;
+
+int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, void *stream);
+int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, const hsAdamState *state, float beta1, float beta2,
+                 float eps, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
