@@ -1,0 +1,314 @@
+// holoscene_amd/csrc/composite.hip -- fused per-ray volume-rendering composite, forward and backward (gfx950).
+//
+// Replaces HoloSceneNetwork.volume_rendering + occlusion_opacity + the weighted sums of forward()
+// (model/network.py:1803-1824, :815-824, :904-906) and their autograd backward -- about 60 + 120 small PyTorch
+// kernels and the [K,R,N] temporaries -- by one kernel each way.  One workgroup per ray, one lane per sample:
+//
+//   sigma_i = Laplace(sdf_i; beta)               (model/density.py:21-26)
+//   fe_i    = (z_{i+1}-z_i) * sigma_i            (last interval 1e10)
+//   T_i     = exp(-sum_{j<i} fe_j)               block exclusive scan
+//   w_i     = (1-exp(-fe_i)) * T_i
+//   rgb = sum w rgb_i ; depth = ds * sum w z / (sum w + 1e-8) ; normal = sum w g_i/(|g_i|+1e-6)
+//   semantic_k = sum_i w_i * s*sigmoid(-s*raw_ik) ; opacity_k = sum_i (1-exp(-d_i*Laplace(raw_ik; beta))) * T_i
+//
+// The backward recomputes the forward quantities from the inputs (cheaper than storing them) and returns the
+// gradients w.r.t. sdf, raw, rgb, g and beta; the beta gradient is reduced per block and added atomically.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "holoscene_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct Lap { float sigma, ds, db; };  // value, d/ds, d/dbeta
+
+__device__ __forceinline__ float lap_sigma(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.f / beta) * (0.5f + 0.5f * sgn * expm1f(-fabsf(s) / beta));
+}
+
+__device__ __forceinline__ Lap lap_full(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    const float a = fabsf(s), ib = 1.f / beta;
+    const float em1 = expm1f(-a * ib), e = em1 + 1.f;
+    const float psi = 0.5f + 0.5f * sgn * em1;
+    Lap r;
+    r.sigma = ib * psi;
+    r.ds = -0.5f * sgn * sgn * e * ib * ib;
+    r.db = -psi * ib * ib + ib * (0.5f * sgn * e * a * ib * ib);
+    return r;
+}
+
+// inclusive scan over the block (BLOCK = 64 * nwaves <= 256); scratch holds one float per wave
+template <int BLOCK>
+__device__ __forceinline__ float block_incl_scan(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    if (BLOCK > kWave) {
+        if (lane == 63) scratch[wave] = v;
+        __syncthreads();
+        float add = 0.f;
+        for (int w = 0; w < wave; w++) add += scratch[w];
+        v += add;
+        __syncthreads();
+    }
+    return v;
+}
+
+// exclusive scan; computed by shifting the inclusive scan, NOT as inclusive - v: the last interval's free energy is
+// ~1e10 * sigma, and subtracting it back would wipe out the accumulated sum of all earlier intervals
+template <int BLOCK>
+__device__ __forceinline__ float block_excl_scan(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0.f;
+    if (BLOCK > kWave) {
+        if (lane == 63) scratch[wave] = incl;
+        __syncthreads();
+        float add = 0.f;
+        for (int w = 0; w < wave; w++) add += scratch[w];
+        excl += add;
+        __syncthreads();
+    }
+    return excl;
+}
+
+// exclusive suffix sum: result_i = sum_{j>i} v_j, again by shifting (the consumer multiplies by the 1e10 interval, so a
+// "total - inclusive" residue of one ulp would become a gradient of thousands)
+template <int BLOCK>
+__device__ __forceinline__ float block_excl_suffix(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float t = __shfl_down(incl, off);
+        if (lane + off < kWave) incl += t;
+    }
+    float excl = __shfl_down(incl, 1);
+    if (lane == 63) excl = 0.f;
+    if (BLOCK > kWave) {
+        if (lane == 0) scratch[wave] = incl;
+        __syncthreads();
+        float add = 0.f;
+        for (int w = wave + 1; w < BLOCK / kWave; w++) add += scratch[w];
+        excl += add;
+        __syncthreads();
+    }
+    return excl;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (BLOCK > kWave) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) scratch[wave] = v;
+        __syncthreads();
+        float t = 0.f;
+        for (int w = 0; w < BLOCK / kWave; w++) t += scratch[w];
+        __syncthreads();
+        v = t;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict__ z, const float *__restrict__ sdf, const float *__restrict__ raw,
+                                                          const float *__restrict__ rgb, const float *__restrict__ g, const float *__restrict__ beta_p,
+                                                          const float *__restrict__ depth_scale, float sem_scale, int N, int K,
+                                                          float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ rgb_out,
+                                                          float *__restrict__ depth_out, float *__restrict__ normal_out, float *__restrict__ sem_out,
+                                                          float *__restrict__ opac_out) {
+    extern __shared__ float lds[];
+    const int r = blockIdx.x, i = threadIdx.x;
+    const int C = 8 + 2 * K;
+    float *scratch = lds;            // [4]
+    float *contrib = lds + 4;        // [N][C]
+    const bool act = i < N;
+    const float beta = *beta_p;
+    const size_t p = (size_t)r * N + (act ? i : 0);
+    float zi = 0.f, d = 0.f, fe = 0.f;
+    if (act) {
+        zi = z[p];
+        d = (i + 1 < N) ? z[p + 1] - zi : 1e10f;
+        fe = d * lap_sigma(sdf[p], beta);
+    }
+    const float S = block_excl_scan<BLOCK>(fe, scratch);
+    const float T = expf(-S);
+    const float w = (1.f - expf(-fe)) * T;
+    if (act) {
+        weights[p] = w;
+        if (trans) trans[p] = T;
+        float *c = contrib + (size_t)i * C;
+        c[0] = w * rgb[3 * p]; c[1] = w * rgb[3 * p + 1]; c[2] = w * rgb[3 * p + 2];
+        c[3] = w * zi; c[4] = w;
+        const float gx = g[3 * p], gy = g[3 * p + 1], gz = g[3 * p + 2];
+        const float inv = 1.f / (sqrtf(gx * gx + gy * gy + gz * gz) + 1e-6f);
+        c[5] = w * gx * inv; c[6] = w * gy * inv; c[7] = w * gz * inv;
+        const float *rw = raw + p * K;
+        for (int k = 0; k < K; k++) {
+            const float s = rw[k];
+            c[8 + k] = w * sem_scale / (1.f + expf(sem_scale * s));           // s*sigmoid(-s*raw)
+            c[8 + K + k] = (1.f - expf(-d * lap_sigma(s, beta))) * T;
+        }
+    }
+    __syncthreads();
+    for (int j = i; j < C; j += BLOCK) {  // column sums -> outputs
+        if (j == 4) continue;            // folded into the depth column
+        float acc = 0.f, acc_w = 0.f;
+        for (int n = 0; n < N; n++) {
+            acc += contrib[(size_t)n * C + j];
+            if (j == 3) acc_w += contrib[(size_t)n * C + 4];
+        }
+        if (j < 3) rgb_out[3 * r + j] = acc;
+        else if (j == 3) depth_out[r] = depth_scale[r] * (acc / (acc_w + 1e-8f));
+        else if (j < 8) normal_out[3 * r + (j - 5)] = acc;
+        else if (j < 8 + K) sem_out[(size_t)r * K + (j - 8)] = acc;
+        else opac_out[(size_t)r * K + (j - 8 - K)] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict__ z, const float *__restrict__ sdf, const float *__restrict__ raw,
+                                                          const float *__restrict__ rgb, const float *__restrict__ g, const float *__restrict__ beta_p,
+                                                          const float *__restrict__ depth_scale, float sem_scale, int N, int K,
+                                                          const float *__restrict__ g_w, const float *__restrict__ g_rgb_out,
+                                                          const float *__restrict__ g_depth, const float *__restrict__ g_normal,
+                                                          const float *__restrict__ g_sem, const float *__restrict__ g_opac,
+                                                          float *__restrict__ d_sdf, float *__restrict__ d_raw, float *__restrict__ d_rgb,
+                                                          float *__restrict__ d_g, float *__restrict__ d_beta) {
+    extern __shared__ float lds[];
+    const int r = blockIdx.x, i = threadIdx.x;
+    float *scratch = lds;          // [4]
+    float *gs = lds + 4;           // g_sem[K]
+    float *go = lds + 4 + K;       // g_opac[K]
+    for (int k = i; k < K; k += BLOCK) {
+        gs[k] = g_sem ? g_sem[(size_t)r * K + k] : 0.f;
+        go[k] = g_opac ? g_opac[(size_t)r * K + k] : 0.f;
+    }
+    __syncthreads();
+    const bool act = i < N;
+    const float beta = *beta_p;
+    const size_t p = (size_t)r * N + (act ? i : 0);
+    float zi = 0.f, d = 0.f, fe = 0.f;
+    Lap ls = {0.f, 0.f, 0.f};
+    if (act) {
+        zi = z[p];
+        d = (i + 1 < N) ? z[p + 1] - zi : 1e10f;
+        ls = lap_full(sdf[p], beta);
+        fe = d * ls.sigma;
+    }
+    const float S = block_excl_scan<BLOCK>(fe, scratch);
+    const float T = expf(-S);
+    const float efe = expf(-fe);
+    const float alpha = 1.f - efe;
+    const float w = alpha * T;
+    const float Wsum = block_sum<BLOCK>(act ? w : 0.f, scratch);
+    const float Dsum = block_sum<BLOCK>(act ? w * zi : 0.f, scratch);
+    // dL/dw_i from the composited outputs
+    float gw = 0.f, gT_obj = 0.f, gbeta = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f, rn = 0.f;
+    if (act) {
+        const float gr0 = g_rgb_out ? g_rgb_out[3 * r] : 0.f, gr1 = g_rgb_out ? g_rgb_out[3 * r + 1] : 0.f, gr2 = g_rgb_out ? g_rgb_out[3 * r + 2] : 0.f;
+        gw = gr0 * rgb[3 * p] + gr1 * rgb[3 * p + 1] + gr2 * rgb[3 * p + 2];
+        if (d_rgb) { d_rgb[3 * p] = w * gr0; d_rgb[3 * p + 1] = w * gr1; d_rgb[3 * p + 2] = w * gr2; }
+        if (g_depth) {
+            const float den = Wsum + 1e-8f;
+            gw += g_depth[r] * depth_scale[r] * (zi * den - Dsum) / (den * den);
+        }
+        gx = g[3 * p]; gy = g[3 * p + 1]; gz = g[3 * p + 2];
+        rn = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float inv = 1.f / (rn + 1e-6f);
+        const float n0 = g_normal ? g_normal[3 * r] : 0.f, n1 = g_normal ? g_normal[3 * r + 1] : 0.f, n2 = g_normal ? g_normal[3 * r + 2] : 0.f;
+        gw += (n0 * gx + n1 * gy + n2 * gz) * inv;
+        if (d_g) {  // n = g/(|g|+eps): dn/dg = I/(r+eps) - g g^T / (r (r+eps)^2)
+            const float dot = (n0 * gx + n1 * gy + n2 * gz) * w;
+            const float c2 = rn > 0.f ? dot * inv * inv / rn : 0.f;
+            d_g[3 * p] = w * n0 * inv - gx * c2;
+            d_g[3 * p + 1] = w * n1 * inv - gy * c2;
+            d_g[3 * p + 2] = w * n2 * inv - gz * c2;
+        }
+        if (g_w) gw += g_w[p];
+        const float *rw = raw + p * K;
+        float *dr = d_raw + p * K;
+        for (int k = 0; k < K; k++) {
+            const float s = rw[k];
+            const float ex = expf(sem_scale * s);
+            const float sem = sem_scale / (1.f + ex);
+            gw += gs[k] * sem;
+            const Lap lk = lap_full(s, beta);
+            const float ek = expf(-d * lk.sigma);
+            gT_obj += go[k] * (1.f - ek);
+            const float gsig = go[k] * T * d * ek;                    // dL/dsigma_ik
+            // d sem/d raw = -s^2 * sigmoid(-s raw) * (1 - sigmoid(-s raw)) = -sem * s*ex/(1+ex)
+            dr[k] = gsig * lk.ds + gs[k] * w * (-sem * sem_scale * ex / (1.f + ex));
+            gbeta += gsig * lk.db;
+        }
+    }
+    const float gT = gw * alpha + gT_obj;
+    const float gS = -gT * T;                                            // T = exp(-S)
+    // dL/dfe_j = sum_{i>j} gS_i + gw_j * T_j * exp(-fe_j)
+    const float gfe = block_excl_suffix<BLOCK>(act ? gS : 0.f, scratch) + gw * T * efe;
+    if (act) {
+        const float gsig = gfe * d;
+        d_sdf[p] = gsig * ls.ds;
+        gbeta += gsig * ls.db;
+    }
+    const float gb = block_sum<BLOCK>(act ? gbeta : 0.f, scratch);
+    if (i == 0 && d_beta) unsafeAtomicAdd(d_beta, gb);
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
+                     const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, float *weights, float *transmittance,
+                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, void *stream) {
+    if (R <= 0) return HS_OK;
+    if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
+    if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !weights || !rgb_out || !depth_out || !normal_out || !sem_out || !opac_out)
+        return HS_ERR_NULL;
+    const size_t lds = (4 + (size_t)N * (8 + 2 * K)) * sizeof(float);
+    if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix must fit the default dynamic-LDS window
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 64) k_composite_fwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
+    else if (N <= 128) k_composite_fwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
+    else k_composite_fwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
+    return check_launch();
+}
+
+int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
+                     const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, const float *g_weights, const float *g_rgb_out,
+                     const float *g_depth, const float *g_normal, const float *g_sem, const float *g_opac, float *d_sdf, float *d_raw,
+                     float *d_rgb, float *d_g, float *d_beta, void *stream) {
+    if (R <= 0) return HS_OK;
+    if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
+    if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !d_sdf || !d_raw) return HS_ERR_NULL;
+    const size_t lds = (4 + 2 * (size_t)K) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 64) k_composite_bwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
+    else if (N <= 128) k_composite_bwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
+    else k_composite_bwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd"]
 
 
 def _check(rc, what):
@@ -205,6 +205,30 @@ class _HipBackend:
         _check(lib.hs_adam_flat(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), ctypes.c_int64(begin), ctypes.c_int64(end),
                                 _dev(state, "state", torch.uint8), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
                                 ctypes.c_float(grad_scale), _stream()), "hs_adam_flat")
+
+    # ---- fused compositing (include/holoscene_hip.h section 6)
+    @staticmethod
+    def composite_fwd(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out):
+        lib = load_library()
+        R, N = z.shape
+        K = raw.shape[-1]
+        _check(lib.hs_composite_fwd(_dev(z, "z"), _dev(sdf, "sdf"), _dev(raw, "raw"), _dev(rgb, "rgb"), _dev(g, "g"), _dev(beta, "beta"),
+                                    _dev(depth_scale, "depth_scale"), ctypes.c_float(sem_scale), R, N, K, _dev(weights, "weights"),
+                                    _dev(trans, "trans"), _dev(rgb_out, "rgb_out"), _dev(depth_out, "depth_out"),
+                                    _dev(normal_out, "normal_out"), _dev(sem_out, "sem_out"), _dev(opac_out, "opac_out"), _stream()),
+               "hs_composite_fwd")
+
+    @staticmethod
+    def composite_bwd(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, g_w, g_rgb, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb,
+                      d_g, d_beta):
+        lib = load_library()
+        R, N = z.shape
+        K = raw.shape[-1]
+        _check(lib.hs_composite_bwd(_dev(z, "z"), _dev(sdf, "sdf"), _dev(raw, "raw"), _dev(rgb, "rgb"), _dev(g, "g"), _dev(beta, "beta"),
+                                    _dev(depth_scale, "depth_scale"), ctypes.c_float(sem_scale), R, N, K, _dev(g_w, "g_w"),
+                                    _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_normal, "g_normal"), _dev(g_sem, "g_sem"),
+                                    _dev(g_opac, "g_opac"), _dev(d_sdf, "d_sdf"), _dev(d_raw, "d_raw"), _dev(d_rgb, "d_rgb"),
+                                    _dev(d_g, "d_g"), _dev(d_beta, "d_beta"), _stream()), "hs_composite_bwd")
 
 
 class hsAdamState(ctypes.Structure):

@@ -147,6 +147,52 @@ def linear_rows(x, weight, bias=None, bf16=False):
     return y.view(*lead, weight.shape[0])
 
 
+# "hip": fused per-ray compositing kernels (csrc/composite.hip); "torch": the whole-tensor formulation
+# (HoloSceneNetwork.volume_rendering / occlusion_opacity), kept for A/B and for CPU host-logic tests.
+COMPOSITE_IMPL = os.environ.get("HOLOSCENE_COMPOSITE_IMPL", "hip")
+
+
+class _composite(torch.autograd.Function):
+    """(z, sdf, raw, rgb, g, beta, depth_scale) -> weights, transmittance, rgb_values, depth_values, normal_map
+    (un-rotated), semantic_values, object_opacity -- one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, z, sdf, raw, rgb, g, beta, depth_scale, sem_scale):
+        z, sdf, raw, rgb, g = z.contiguous(), sdf.contiguous(), raw.contiguous(), rgb.contiguous(), g.contiguous()
+        depth_scale = depth_scale.contiguous()
+        beta1 = beta.detach().reshape(1).contiguous()
+        R, N = z.shape
+        K = raw.shape[-1]
+        dev = z.device
+        weights = torch.empty(R, N, device=dev)
+        trans = torch.empty(R, N, device=dev)
+        rgb_out = torch.empty(R, 3, device=dev)
+        depth_out = torch.empty(R, 1, device=dev)
+        normal_out = torch.empty(R, 3, device=dev)
+        sem_out = torch.empty(R, K, device=dev)
+        opac_out = torch.empty(R, K, device=dev)
+        _be._backend.composite_fwd(z, sdf, raw, rgb, g, beta1, depth_scale, float(sem_scale), weights, trans, rgb_out, depth_out, normal_out,
+                                   sem_out, opac_out)
+        ctx.save_for_backward(z, sdf, raw, rgb, g, beta1, depth_scale)
+        ctx.sem_scale = float(sem_scale)
+        ctx.beta_shape = beta.shape
+        ctx.mark_non_differentiable(trans)
+        return weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out
+
+    @staticmethod
+    def backward(ctx, g_w, _g_t, g_rgb, g_depth, g_normal, g_sem, g_opac):
+        z, sdf, raw, rgb, g, beta1, depth_scale = ctx.saved_tensors
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        d_sdf = torch.empty_like(sdf)
+        d_raw = torch.empty_like(raw)
+        d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[3] else None
+        d_g = torch.empty_like(g) if ctx.needs_input_grad[4] else None
+        d_beta = torch.zeros(1, device=z.device) if ctx.needs_input_grad[5] else None
+        _be._backend.composite_bwd(z, sdf, raw, rgb, g, beta1, depth_scale, ctx.sem_scale, c(g_w), c(g_rgb), c(g_depth), c(g_normal), c(g_sem),
+                                   c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta)
+        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.reshape(ctx.beta_shape)), None, None
+
+
 def default_mlp_precision():
     return os.environ.get("HOLOSCENE_MLP_PRECISION", "fp32")
 
@@ -588,15 +634,26 @@ class HoloSceneNetwork(nn.Module):
         points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
         dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N_samples, -1).reshape(-1, 3)
 
-        sdf, feature_vectors, gradients, semantic, sdf_raw = self.implicit_network.get_outputs(points_flat, beta=None)
+        net = self.implicit_network
+        sdf, feature_vectors, gradients, sdf_raw, _, _ = net._outputs(points_flat)   # = get_outputs() minus the semantic map
         rgb = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors, indices).reshape(-1, N_samples, 3)
-        semantic = semantic.reshape(-1, N_samples, self.num_semantic)
-        weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
-        object_opacity = self.occlusion_opacity(z_vals, transmittance, dists, sdf_raw).sum(-1).transpose(0, 1)
-
-        rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
-        semantic_values = torch.sum(weights.unsqueeze(-1) * semantic, 1)
-        depth_values = depth_scale * (torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8))
+        if COMPOSITE_IMPL == "hip":
+            if not z_vals.is_cuda:
+                raise RuntimeError("fused compositing needs CUDA tensors (set HOLOSCENE_COMPOSITE_IMPL=torch explicitly for the "
+                                   "whole-tensor formulation)")
+            weights, _, rgb_values, depth_values, normal_world, semantic_values, object_opacity = _composite.apply(
+                z_vals, sdf, sdf_raw, rgb.reshape(-1, 3), gradients, self.density.get_beta(), depth_scale, self.implicit_network.sigmoid)
+        elif COMPOSITE_IMPL == "torch":
+            semantic = (net.sigmoid * torch.sigmoid(-net.sigmoid * sdf_raw)).reshape(-1, N_samples, self.num_semantic)
+            weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
+            object_opacity = self.occlusion_opacity(z_vals, transmittance, dists, sdf_raw).sum(-1).transpose(0, 1)
+            rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
+            semantic_values = torch.sum(weights.unsqueeze(-1) * semantic, 1)
+            depth_values = depth_scale * (torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8))
+            normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N_samples, 3)
+            normal_world = torch.sum(weights.unsqueeze(-1) * normals, 1)
+        else:
+            raise RuntimeError(f"unknown HOLOSCENE_COMPOSITE_IMPL={COMPOSITE_IMPL!r}")
         if self.white_bkgd:
             rgb_values = rgb_values + (1.0 - torch.sum(weights, -1)[..., None]) * self.bg_color.unsqueeze(0)
 
@@ -635,9 +692,7 @@ class HoloSceneNetwork(nn.Module):
             output["grad_theta"] = grad_theta[:half]
             output["grad_theta_nei"] = grad_theta[half:]
 
-        normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N_samples, 3)
-        normal_map = torch.sum(weights.unsqueeze(-1) * normals, 1)
-        output["normal_map"] = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
+        output["normal_map"] = (rot @ normal_world.permute(1, 0)).permute(1, 0).contiguous()
 
         if bg is not None:  # background-surface pass (network.py:943-968)
             bg_z, ray_dirs0, cam_loc0 = bg["z_vals"], bg["ray_dirs"], bg["cam_loc"]

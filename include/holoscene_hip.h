@@ -176,6 +176,24 @@ int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, voi
 int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, const hsAdamState *state, float beta1, float beta2,
                  float eps, float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------ 6. fused volume-rendering composite
+ *
+ * One workgroup per ray.  Replaces volume_rendering / occlusion_opacity and the weighted sums of
+ * HoloSceneNetwork.forward (model/network.py:815-824, 904-906, 1803-1824) and their backward.
+ *   z [R,N]; sdf [R*N] (scene min-SDF); raw [R*N,K] per-object SDFs; rgb [R*N,3]; g [R*N,3] (d sdf/dx);
+ *   beta: device scalar; depth_scale [R]; sem_scale = implicit_network.sigmoid.
+ * forward writes weights [R,N], transmittance [R,N] (may be NULL), rgb_out [R,3], depth_out [R] (already multiplied by
+ * depth_scale), normal_out [R,3] (world frame, un-rotated), sem_out [R,K], opac_out [R,K].  N <= 256, N*(8+2K) floats <= 64 KB.
+ * backward takes the cotangents of those outputs (any may be NULL = zero) and writes d_sdf [R*N], d_raw [R*N,K],
+ * d_rgb [R*N,3] (may be NULL), d_g [R*N,3] (may be NULL), and ACCUMULATES d_beta (device scalar, may be NULL). */
+int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
+                     const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, float *weights, float *transmittance,
+                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, void *stream);
+int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
+                     const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, const float *g_weights, const float *g_rgb_out,
+                     const float *g_depth, const float *g_normal, const float *g_sem, const float *g_opac, float *d_sdf, float *d_raw,
+                     float *d_rgb, float *d_g, float *d_beta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
