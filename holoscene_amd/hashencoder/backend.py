@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd"]
 
 
 def _check(rc, what):
@@ -229,6 +229,15 @@ class _HipBackend:
                                     _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_normal, "g_normal"), _dev(g_sem, "g_sem"),
                                     _dev(g_opac, "g_opac"), _dev(d_sdf, "d_sdf"), _dev(d_raw, "d_raw"), _dev(d_rgb, "d_rgb"),
                                     _dev(d_g, "d_g"), _dev(d_beta, "d_beta"), _stream()), "hs_composite_bwd")
+
+    # ---- fused SDF-trunk inference (include/holoscene_hip.h section 7)
+    @staticmethod
+    def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw):
+        lib = load_library()
+        bf = torch.bfloat16
+        _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
+                                  _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
+                                  ctypes.c_int64(x.shape[0]), _stream()), "hs_sdf_mlp_fwd")
 
 
 class hsAdamState(ctypes.Structure):

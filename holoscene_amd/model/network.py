@@ -354,6 +354,39 @@ class ObjectImplicitNetworkGrid(nn.Module):
                 h = linear_rows(h, lin.weight, None, self.mlp_bf16).float() + lin.bias
         return h
 
+    # ---------------------------------------------------------------- fused matrix-core inference (bf16 mode)
+    def _fused_sdf_supported(self, x):
+        lins = self._lins()
+        return (self.mlp_bf16 and x.is_cuda and not torch.is_grad_enabled() and len(lins) == 3 and self.embedder is not None
+                and self.embedder.multires == 6 and self.grid_feature_dim == 32 and lins[0].out_features == 256
+                and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features <= 64
+                and not any(l in self.skip_in for l in range(3)))
+
+    def _packed_weights(self):
+        """bf16 images of the three weight-normalised matrices in the layout csrc/sdf_mlp.hip reads (rebuilt per call:
+        three tiny cast kernels; the weights change every optimiser step)."""
+        l0, l1, l2 = self._lins()
+        dev = l0.weight_v.device
+        w0 = torch.zeros(256, 96, device=dev, dtype=torch.bfloat16)
+        w0[:, :l0.in_features] = l0.weight.to(torch.bfloat16)
+        n2 = 32 * ((l2.out_features + 31) // 32)
+        w2 = torch.zeros(n2, 256, device=dev, dtype=torch.bfloat16)
+        w2[:l2.out_features] = l2.weight.to(torch.bfloat16)
+        return (w0, l0.bias.detach().float().contiguous(), l1.weight.to(torch.bfloat16).contiguous(), l1.bias.detach().float().contiguous(),
+                w2, l2.bias.detach().float().contiguous())
+
+    def _sdf_fused(self, x, select=-1, want_raw=False):
+        """min_k sdf_k (or sdf_select) [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
+        x = x.contiguous()
+        feat = self.encoding(x / self.divide_factor)
+        B = x.shape[0]
+        d_out = self._lins()[2].out_features
+        out = torch.empty(B, 1, device=x.device)
+        raw = torch.empty(B, d_out, device=x.device) if want_raw else None
+        w0, b0, w1, b1, w2, b2 = self._packed_weights()
+        _be._backend.sdf_mlp_fwd(x, feat.contiguous(), w0, b0, w1, b1, w2, b2, d_out, select, out, raw)
+        return out, raw
+
     def sdf_and_jacobian(self, x):
         """x [B,3] (treated as constant) -> y [B,K'], J [B,K',3] with J[b,k,:] = d y_k / d x.
         Differentiable w.r.t. every parameter by plain first-order autograd.
@@ -433,12 +466,18 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return sdf, feature_vectors, gradients, semantic, sdf_raw[:, idx]
 
     def get_sdf_raw(self, x):
+        if self.color_grid_feature and self._fused_sdf_supported(x):
+            return self._sdf_fused(x, want_raw=True)[1]
         return self._trunk(x)[:, :self.d_out]
 
     def get_sdf_vals(self, x):
+        if self.color_grid_feature and self._fused_sdf_supported(x):
+            return self._sdf_fused(x)[0]
         return self._min_sdf(self.get_sdf_raw(x))[0]
 
     def get_object_sdf_vals(self, x, idx):
+        if self.color_grid_feature and isinstance(idx, int) and self._fused_sdf_supported(x):
+            return self._sdf_fused(x, select=idx)[0].squeeze(-1)
         return self._trunk(x)[:, idx]
 
     def get_multi_object_sdf_vals(self, x, idxs):

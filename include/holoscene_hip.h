@@ -194,6 +194,17 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
                      const float *g_depth, const float *g_normal, const float *g_sem, const float *g_opac, float *d_sdf, float *d_raw,
                      float *d_rgb, float *d_g, float *d_beta, void *stream);
 
+/* ------------------------------------------------------------------ 7. fused SDF-trunk inference on the matrix cores
+ *
+ * SDF branch of ObjectImplicitNetworkGrid.forward (model/network.py:169-210) for no-grad queries (the sampler's
+ * sweeps, get_sdf_vals / get_object_sdf_vals :305-318), bf16 operands / fp32 accumulation:
+ *   x [B,3] f32, feat [B,32] f32 (hash features) -> posenc(6) ++ feat (71, zero-padded to 96) -> 256 -> 256 -> d_out.
+ *   W0 [256,96] bf16 (columns >= 71 zero), W1 [256,256] bf16, W2 [32*ceil(d_out/32), 256] bf16 (rows >= d_out zero),
+ *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
+ *   out_min [B] = min_k y_k (select < 0) or y_select; out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
+int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
+                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

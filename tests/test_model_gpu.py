@@ -281,3 +281,32 @@ def test_fused_composite_matches_torch_formulation(R, N, K):
     for a, b, n_ in zip(g_out, g_ref, ("d_sdf", "d_raw", "d_rgb", "d_g", "d_beta")):
         scale = float(b.abs().max())
         close(a, b, 2e-3, 2e-5 * max(scale, 1e-6), n_)
+
+
+@pytest.mark.parametrize("d_out,B", [(32, 131072), (21, 1000), (2, 129), (40, 4096)])
+def test_fused_mfma_sdf_kernel_vs_torch(d_out, B):
+    """csrc/sdf_mlp.hip (bf16 MFMA, fp32 accumulate) vs the plain fp32 PyTorch SDF trunk on the same weights.
+    Tolerance: bf16 operand rounding (2^-8 relative per product, 256-term sums) -> 1e-2 of the value scale."""
+    from holoscene_amd.model.network import ObjectImplicitNetworkGrid
+    torch.manual_seed(d_out)
+    net = ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                    divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+    x = (torch.rand(B, 3, device=DEV) * 2.4 - 1.2)
+    with torch.no_grad():
+        net.set_mlp_precision("fp32")
+        ref_raw = net.get_sdf_raw(x)
+        ref_min = net.get_sdf_vals(x)
+        net.set_mlp_precision("bf16")
+        assert net._fused_sdf_supported(x)
+        got_min = net.get_sdf_vals(x)
+        got_raw = net.get_sdf_raw(x)
+        got_sel = net.get_object_sdf_vals(x, d_out - 1)
+    scale = float(ref_raw.abs().max())
+    assert got_raw.shape == ref_raw.shape and got_min.shape == ref_min.shape
+    assert (got_raw - ref_raw).abs().max() < 1e-2 * scale, float((got_raw - ref_raw).abs().max())
+    assert (got_min - ref_min).abs().max() < 1e-2 * scale
+    assert torch.equal(got_min, got_raw.min(-1, keepdim=True)[0]), "min output must be the min of the raw outputs of the same launch"
+    assert torch.equal(got_sel, got_raw[:, d_out - 1])
