@@ -15,10 +15,13 @@
 // W . H^T, so both operands are 16-byte row reads from row-major LDS images (weights [neuron][k], activations
 // [point][k]) and each lane ends up with 4 consecutive neurons of ONE point per accumulator quad -> the epilogue
 // (bias, softplus, bf16 pack) writes 8-byte runs straight back into the activation tile.
-//   LDS: activation tile 128 x (256+8) bf16 = 66 KB (in place across layers) + double-buffered weight chunks
-//   2 x 256 x (32+8) bf16 = 40 KB; row pitches of +8 bf16 make every ds_read_b128 conflict-free.
-//   4 waves = 2 (neuron halves) x 2 (point halves): 64 points x 128 neurons per wave, 8 accumulator tiles (128 VGPR);
-//   weight chunks stream L2 -> registers -> LDS one chunk ahead of the MFMAs.
+//   LDS: activation tile 128 x (256+8) bf16 = 66 KB (updated in place layer by layer) + double-buffered weight
+//   chunks 2 x 256 x (32+8) bf16 = 40 KB + biases; the +8 row pitches make every ds_read_b128 conflict-free.
+//   8 waves (2 per SIMD, so one wave's LDS latency hides under the other's MFMAs) = 4 neuron quarters x 2 point
+//   halves: 64 neurons x 64 points per wave, 4 accumulator tiles; operand fragments are double-buffered in registers
+//   one k-step ahead; weight chunks stream L2 -> registers -> LDS one chunk ahead.
+//   Measured history (131 072 points, MI355X): 276 us (libm sinf/cosf staging) -> 132 us (hardware sincos) ->
+//   see DESIGN.md for the current figure.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <math.h>
@@ -31,97 +34,132 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int BM = 128;           // points per tile
 constexpr int HID = 256;          // hidden width
 constexpr int HP = HID + 8;       // activation row pitch (bf16)
 constexpr int KC = 32;            // weight chunk depth
 constexpr int WP = KC + 8;        // weight chunk row pitch (bf16)
 constexpr int K0 = 96;            // padded input width (71 -> 96)
-constexpr int NFREQ = 6;
-constexpr int NPE = 3 + 6 * NFREQ;  // 39
+constexpr int NPE = 39;           // 3 + 6*6 positional-encoding values
 constexpr int NFEAT = 32;
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
+__device__ __forceinline__ uint32_t f2bf(float f) {  // round-to-nearest-even; inputs are finite here
     const uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-__device__ __forceinline__ float softplus100(float v) {
+__device__ __forceinline__ float softplus100(float v) {  // branch-free Softplus(beta=100, threshold=20)
+#ifdef HS_EXP_NO_EPILOGUE
+    return v;
+#endif
+    // raw v_exp_f32 / v_log_f32 (base 2): the log argument is in [1, 1+e^20], so the denormal-scaling wrapper that
+    // __logf carries (cmp + cndmask + ldexp per value) is dead weight here
     const float t = v * 100.f;
-    if (t > 20.f) return v;
-    return __logf(1.f + __expf(t)) * 0.01f;
+    const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
+    const float sp = __builtin_amdgcn_logf(1.f + e) * (0.69314718f * 0.01f);
+    return t > 20.f ? v : sp;
 }
 
-// stage rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix: 16 KB = 64 B per thread
-struct ChunkRegs { uint4 v[4]; };
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even)
+    const float2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t *>(&r);
+}
+
+// rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix = 16 KB = 32 B per thread
+struct ChunkRegs { uint4 v[2]; };
 
 __device__ __forceinline__ ChunkRegs load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
     ChunkRegs r;
-    // thread t -> row t (256 rows), 4 x 16 B = the row's 32 bf16
-    const uint16_t *src = W + (size_t)threadIdx.x * ldw + k0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r.v[i] = *reinterpret_cast<const uint4 *>(src + 8 * i);
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const uint16_t *src = W + (size_t)row * ldw + k0 + half * 16;
+    r.v[0] = *reinterpret_cast<const uint4 *>(src);
+    r.v[1] = *reinterpret_cast<const uint4 *>(src + 8);
     return r;
 }
 
 __device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs &r) {
-    uint16_t *dst = Wc + (size_t)threadIdx.x * WP;
-#pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4 *>(dst + 8 * i) = r.v[i];
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    uint16_t *dst = Wc + (size_t)row * WP + half * 16;
+    *reinterpret_cast<uint4 *>(dst) = r.v[0];
+    *reinterpret_cast<uint4 *>(dst + 8) = r.v[1];
 }
 
-// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T over K (multiple of KC), all 256 neurons, BM points.
-// wave -> neurons [nh*128, +128), points [ph*64, +64)
-__device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[4][2],
-                                          int nh, int ph, int lane) {
+struct Frags { bf16x8 a[2], b[2]; };
+
+// operand fragments of k-step `s` (16 wide): weights from the chunk buffer, activations from H
+__device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *H, int s, int nq, int ph, int lane) {
+    Frags f;
+    const uint16_t *wbuf = Wc + (size_t)((s >> 1) & 1) * HID * WP + (s & 1) * 16 + (lane >> 5) * 8;
+    const uint16_t *hrow = H + s * 16 + (lane >> 5) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        f.a[i] = *reinterpret_cast<const bf16x8 *>(wbuf + (size_t)(nq * 64 + i * 32 + (lane & 31)) * WP);
+        f.b[i] = *reinterpret_cast<const bf16x8 *>(hrow + (size_t)(ph * 64 + i * 32 + (lane & 31)) * HP);
+    }
+    return f;
+}
+
+// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KC.  wave -> neurons [nq*64,+64), points [ph*64,+64)
+__device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
+                                          int nq, int ph, int lane) {
     const int nchunks = K / KC;
     ChunkRegs pre = load_chunk(W, ldw, 0);
     store_chunk(Wc, pre);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
-        uint16_t *cur = Wc + (size_t)(c & 1) * HID * WP;
-        uint16_t *nxt = Wc + (size_t)((c + 1) & 1) * HID * WP;
+#ifndef HS_EXP_NO_WLOAD
         if (c + 1 < nchunks) pre = load_chunk(W, ldw, (c + 1) * KC);
+#endif
+#ifndef HS_EXP_NO_MMA
+        Frags f0 = load_frags(Wc, H, 2 * c, nq, ph, lane);
+        Frags f1 = load_frags(Wc, H, 2 * c + 1, nq, ph, lane);   // in flight while f0's MFMAs run
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ks++) {
-            bf16x8 b[2];
+        for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int pt = 0; pt < 2; pt++)
-                b[pt] = *reinterpret_cast<const bf16x8 *>(H + (size_t)(ph * 64 + pt * 32 + (lane & 31)) * HP + c * KC + ks * 16 + (lane >> 5) * 8);
+            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a[nt], f0.b[pt], acc[nt][pt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(cur + (size_t)(nh * 128 + nt * 32 + (lane & 31)) * WP + ks * 16 + (lane >> 5) * 8);
+        for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-                for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[pt], acc[nt][pt], 0, 0, 0);
-            }
-        }
-        if (c + 1 < nchunks) store_chunk(nxt, pre);
+            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.a[nt], f1.b[pt], acc[nt][pt], 0, 0, 0);
+#endif
+        if (c + 1 < nchunks) store_chunk(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
         __syncthreads();
     }
 }
 
 // bias + softplus + bf16 pack, written back into the activation tile (all waves have passed the barrier that ends layer_mma)
-__device__ __forceinline__ void epilogue_softplus(const float *__restrict__ bias, uint16_t *H, f32x16 acc[4][2], int nh, int ph, int lane) {
+__device__ __forceinline__ void epilogue_softplus(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
+    for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int n0 = nh * 128 + nt * 32 + q * 8 + 4 * (lane >> 5);  // 4 consecutive neurons
-            const float4 bi = *reinterpret_cast<const float4 *>(bias + n0);
+            const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);  // 4 consecutive neurons
+            const float4 bi = *reinterpret_cast<const float4 *>(bias_lds + n0);
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
                 const int p = ph * 64 + pt * 32 + (lane & 31);
                 const float v0 = softplus100(acc[nt][pt][q * 4 + 0] + bi.x), v1 = softplus100(acc[nt][pt][q * 4 + 1] + bi.y);
                 const float v2 = softplus100(acc[nt][pt][q * 4 + 2] + bi.z), v3 = softplus100(acc[nt][pt][q * 4 + 3] + bi.w);
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
             }
         }
     }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 acc[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
 }
 
 template <int NOUT_TILES>  // d_out padded to 32 * NOUT_TILES
@@ -131,88 +169,102 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
                                                        const float *__restrict__ b2, int d_out, int select, float *__restrict__ out_min,
                                                        float *__restrict__ out_raw, int64_t B) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t *H = lds;                      // [BM][HP]
-    uint16_t *Wc = lds + (size_t)BM * HP;   // 2 x [HID][WP]  (also holds W2 [32*NOUT_TILES][HP] for the last layer)
+    uint16_t *H = lds;                                  // [BM][HP]
+    uint16_t *Wc = lds + (size_t)BM * HP;               // 2 x [HID][WP]  (re-used for W2 [32*NOUT_TILES][HP] in the last layer)
+    float *bias = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);   // b0[256] b1[256] b2[64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nh = wave & 1, ph = wave >> 1;
+    const int nq = wave & 3, ph = wave >> 2;
+    if (threadIdx.x < HID) { bias[threadIdx.x] = b0[threadIdx.x]; bias[HID + threadIdx.x] = b1[threadIdx.x]; }
+    if (threadIdx.x < 64) bias[2 * HID + threadIdx.x] = (int)threadIdx.x < d_out ? b2[threadIdx.x] : 0.f;
     const int64_t ntiles = (B + BM - 1) / BM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");  // keep the per-tile weight loads inside the loop (hoisted they would pin ~90 VGPRs)
         const int64_t p0 = tile * BM;
-        // ---- input features: H[p][0..K0)
-        for (int idx = threadIdx.x; idx < BM * K0; idx += kThreads) {
-            const int p = idx / K0, c = idx - p * K0;
+        // ---- input features: H[p][0..K0).  Four threads per point; sin/cos pairs from the hardware v_sin/v_cos units
+        //      (arguments <= 2^5 * 1.75 rad, well inside their range; the bf16 destination keeps 8 bits anyway).
+        {
+            const int p = threadIdx.x & (BM - 1), part = threadIdx.x >> 7;   // part 0..3
             const int64_t gp = p0 + p;
-            float v = 0.f;
-            if (gp < B) {
-                if (c < 3) v = x[gp * 3 + c];
-                else if (c < NPE) {
-                    const int k = (c - 3) / 6, r = (c - 3) - 6 * k;
-                    const float a = x[gp * 3 + (r % 3)] * (float)(1 << k);
-                    v = (r < 3) ? sinf(a) : cosf(a);
-                } else if (c < NPE + NFEAT) v = feat[gp * NFEAT + (c - NPE)];
+            const bool ok = gp < B;
+            uint16_t *row = H + (size_t)p * HP;
+            float xv[3] = {0.f, 0.f, 0.f};
+            if (ok) { xv[0] = x[gp * 3]; xv[1] = x[gp * 3 + 1]; xv[2] = x[gp * 3 + 2]; }
+            if (part == 0) { row[0] = (uint16_t)f2bf(xv[0]); row[1] = (uint16_t)f2bf(xv[1]); row[2] = (uint16_t)f2bf(xv[2]); }
+            if (part < 3) {
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    const int k = part * 2 + kk;
+                    const float f = (float)(1 << k);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        float sn, cs;
+                        __sincosf(xv[d] * f, &sn, &cs);
+                        row[3 + 6 * k + d] = (uint16_t)f2bf(sn);
+                        row[3 + 6 * k + 3 + d] = (uint16_t)f2bf(cs);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = NPE + NFEAT; c < K0; c++) row[c] = 0;
             }
-            H[(size_t)p * HP + c] = f2bf(v);
+            const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * NFEAT + part * 8);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const float4 v = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                uint16_t *dst = row + NPE + part * 8 + 4 * i;   // odd column -> 2-byte stores
+                dst[0] = (uint16_t)f2bf(v.x); dst[1] = (uint16_t)f2bf(v.y); dst[2] = (uint16_t)f2bf(v.z); dst[3] = (uint16_t)f2bf(v.w);
+            }
         }
         __syncthreads();
-        f32x16 acc[4][2];
-        // ---- layer 0
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
-        layer_mma(W0, K0, K0, H, Wc, acc, nh, ph, lane);
-        epilogue_softplus(b0, H, acc, nh, ph, lane);
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        layer_mma(W0, K0, K0, H, Wc, acc, nq, ph, lane);
+        epilogue_softplus(bias, H, acc, nq, ph, lane);
         __syncthreads();
-        // ---- layer 1
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
-        layer_mma(W1, HID, HID, H, Wc, acc, nh, ph, lane);
-        epilogue_softplus(b1, H, acc, nh, ph, lane);
+        zero_acc(acc);
+        layer_mma(W1, HID, HID, H, Wc, acc, nq, ph, lane);
+        epilogue_softplus(bias + HID, H, acc, nq, ph, lane);
         // ---- layer 2: stage W2 [32*NOUT_TILES][HID] with pitch HP into the chunk area
         for (int idx = threadIdx.x; idx < 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
             const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
         }
         __syncthreads();
-        f32x16 y[NOUT_TILES];
+        if (wave < 4) {  // 4 point tiles of 32; waves 4..7 have nothing to do in the narrow last layer
+            f32x16 y[NOUT_TILES];
 #pragma unroll
-        for (int t = 0; t < NOUT_TILES; t++)
+            for (int t = 0; t < NOUT_TILES; t++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) y[t][i] = 0.f;
-        const int prow = wave * 32 + (lane & 31);  // this wave's 32 points
+                for (int i = 0; i < 16; i++) y[t][i] = 0.f;
+            const int prow = wave * 32 + (lane & 31);
 #pragma unroll 4
-        for (int ks = 0; ks < HID / 16; ks++) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(H + (size_t)prow * HP + ks * 16 + (lane >> 5) * 8);
+            for (int ks = 0; ks < HID / 16; ks++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(H + (size_t)prow * HP + ks * 16 + (lane >> 5) * 8);
 #pragma unroll
-            for (int t = 0; t < NOUT_TILES; t++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(t * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
-                y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[t], 0, 0, 0);
-            }
-        }
-        // lane holds, for point prow, neurons t*32 + (i&3) + 8*(i>>2) + 4*(lane>>5)
-        const int64_t gp = p0 + prow;
-        float best = INFINITY;
-#pragma unroll
-        for (int t = 0; t < NOUT_TILES; t++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int n = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (n < d_out) {
-                    const float v = y[t][i] + b2[n];
-                    if (out_raw && gp < B) out_raw[gp * d_out + n] = v;
-                    if (select < 0) best = fminf(best, v);
-                    else if (n == select) best = v;
+                for (int t = 0; t < NOUT_TILES; t++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(t * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
+                    y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[t], 0, 0, 0);
                 }
             }
-        const float other = __shfl_xor(best, 32);
-        best = fminf(best, other);  // for `select`, exactly one half holds the value, the other +inf
-        if (lane < 32 && gp < B) out_min[gp] = best;
+            // lane holds, for point prow, neurons t*32 + (i&3) + 8*(i>>2) + 4*(lane>>5)
+            const int64_t gp = p0 + prow;
+            float best = INFINITY;
+#pragma unroll
+            for (int t = 0; t < NOUT_TILES; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int n = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    if (n < d_out) {
+                        const float v = y[t][i] + bias[2 * HID + n];
+                        if (out_raw && gp < B) out_raw[gp * d_out + n] = v;
+                        if (select < 0) best = fminf(best, v);
+                        else if (n == select) best = v;
+                    }
+                }
+            const float other = __shfl_xor(best, 32);
+            best = fminf(best, other);  // for `select`, exactly one half holds the value, the other +inf
+            if (lane < 32 && gp < B) out_min[gp] = best;
+        }
         __syncthreads();  // H and the chunk area are rewritten by the next tile
     }
 }
@@ -228,9 +280,9 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
     if (d_out < 1 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!x || !feat || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out_min) return HS_ERR_NULL;
-    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
+    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
     const int64_t ntiles = (B + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (108 KB LDS), tiles strided across the grid
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (111 KB LDS), tiles strided across the grid
     hipStream_t st = (hipStream_t)stream;
     if (d_out <= 32) {
         static bool attr1 = false;
