@@ -1,0 +1,201 @@
+// holoscene_amd/csrc/encode_ops.hip -- fused input builders for the SDF trunk and the rendering network (gfx950).
+//
+// The reference assembles network inputs from dozens of tiny ops: Embedder.embed loops over frequencies with one
+// sin, one cos and two muls each (model/embedder.py:22-36), then torch.cat (network.py:181-185, 586-596).  With the
+// value+Jacobian trunk the tangent rows need the same again for the derivative.  Per iteration that was ~250 of the
+// ~850 kernel launches.  Here each network input is written by ONE kernel, and its backward by one more.
+//
+//  trunk input   [B,4,F], F = 3+6*nf+LC:   row 0 = [x, sin(2^k x), cos(2^k x) ..., feat]
+//                                          row 1+d = d(row 0)/dx_d = [e_d, 2^k cos(2^k x_i) d_id, -2^k sin(2^k x_i) d_id ..., dydx_d * s]
+//                backward: g_feat[b,:] = G[b,0,P:], g_dydx[l,b,d*C+c] = s * G[b,1+d,P+l*C+c]   (x is not differentiated)
+//  render input  [B, 3*(3+6*nf)+Fv]:       [pe(points), pe(view_dirs), pe(normals), feature_vectors]
+//                backward: d_normals = pe'(normals)^T G[:, 2P:3P], d_feat = G[:, 3P:]
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "holoscene_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <class T> struct IO;
+template <> struct IO<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct IO<__hip_bfloat16> {
+    static __device__ __forceinline__ float ld(const __hip_bfloat16 *p) { return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t *>(p)) << 16); }
+    static __device__ __forceinline__ void st(__hip_bfloat16 *p, float v) {
+        const uint32_t u = __float_as_uint(v);
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+};
+
+// one thread per (point, column) of the [4, F] block
+template <class T>
+__global__ __launch_bounds__(kThreads) void k_trunk_input_fwd(const float *__restrict__ x, const float *__restrict__ feat,
+                                                               const float *__restrict__ dydx, T *__restrict__ out, int64_t B, int nf, int L, int C,
+                                                               float jac_scale) {
+    const int P = 3 + 6 * nf, LC = L * C, F = P + LC;
+    const int64_t total = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / F;
+        const int c = (int)(i - b * F);
+        T *o = out + b * 4 * F + c;
+        float v0, t[3] = {0.f, 0.f, 0.f};
+        if (c < 3) {
+            v0 = x[b * 3 + c];
+            t[c] = 1.f;
+        } else if (c < P) {
+            const int k = (c - 3) / 6, r = (c - 3) - 6 * k, d = r % 3;
+            const float f = (float)(1 << k), a = x[b * 3 + d] * f;
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            if (r < 3) { v0 = sn; t[d] = f * cs; }
+            else { v0 = cs; t[d] = -f * sn; }
+        } else {
+            const int lc = c - P, l = lc / C, ch = lc - l * C;
+            v0 = feat[b * LC + lc];
+            const float *j = dydx + ((int64_t)l * B + b) * 3 * C + ch;
+            t[0] = j[0] * jac_scale; t[1] = j[C] * jac_scale; t[2] = j[2 * C] * jac_scale;
+        }
+        IO<T>::st(o, v0);
+        IO<T>::st(o + F, t[0]);
+        IO<T>::st(o + 2 * F, t[1]);
+        IO<T>::st(o + 3 * F, t[2]);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kThreads) void k_trunk_input_bwd(const T *__restrict__ G, float *__restrict__ g_feat, float *__restrict__ g_dydx,
+                                                               int64_t B, int nf, int L, int C, float jac_scale) {
+    const int P = 3 + 6 * nf, LC = L * C, F = P + LC;
+    const int64_t total = B * LC;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / LC;
+        const int lc = (int)(i - b * LC), l = lc / C, ch = lc - l * C;
+        const T *g = G + b * 4 * F + P + lc;
+        g_feat[b * LC + lc] = IO<T>::ld(g);
+        float *j = g_dydx + ((int64_t)l * B + b) * 3 * C + ch;
+        j[0] = IO<T>::ld(g + F) * jac_scale;
+        j[C] = IO<T>::ld(g + 2 * F) * jac_scale;
+        j[2 * C] = IO<T>::ld(g + 3 * F) * jac_scale;
+    }
+}
+
+// posenc value of column c (0 <= c < P) of a 3-vector v, and optionally its derivative w.r.t. v[d]
+__device__ __forceinline__ float pe_col(const float v[3], int c, int &d, float &deriv) {
+    if (c < 3) { d = c; deriv = 1.f; return v[c]; }
+    const int k = (c - 3) / 6, r = (c - 3) - 6 * k;
+    d = r % 3;
+    const float f = (float)(1 << k);
+    float sn, cs;
+    sincosf(v[d] * f, &sn, &cs);
+    if (r < 3) { deriv = f * cs; return sn; }
+    deriv = -f * sn;
+    return cs;
+}
+
+template <class T>
+__global__ __launch_bounds__(kThreads) void k_render_input_fwd(const float *__restrict__ pts, const float *__restrict__ dirs,
+                                                                const float *__restrict__ nrm, const T *__restrict__ fv, T *__restrict__ out,
+                                                                int64_t B, int nf, int Fv) {
+    const int P = 3 + 6 * nf, W = 3 * P + Fv;
+    const int64_t total = B * W;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / W;
+        const int c = (int)(i - b * W);
+        if (c >= 3 * P) { out[i] = fv[b * Fv + (c - 3 * P)]; continue; }
+        const int which = c / P, cc = c - which * P;
+        const float *src = (which == 0 ? pts : (which == 1 ? dirs : nrm)) + b * 3;
+        const float v[3] = {src[0], src[1], src[2]};
+        int d; float deriv;
+        IO<T>::st(out + i, pe_col(v, cc, d, deriv));
+    }
+}
+
+// d_normals[b,d] = sum_c G[b, 2P+c] * d pe_c/d n_d  (one thread per point; 3P columns are few) ; d_feat = G[:, 3P:]
+template <class T>
+__global__ __launch_bounds__(kThreads) void k_render_input_bwd(const T *__restrict__ G, const float *__restrict__ nrm, float *__restrict__ d_nrm,
+                                                                T *__restrict__ d_fv, int64_t B, int nf, int Fv) {
+    const int P = 3 + 6 * nf, W = 3 * P + Fv;
+    const int64_t total = B * (Fv + 1);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = i / (Fv + 1);
+        const int c = (int)(i - b * (Fv + 1));
+        if (c < Fv) { d_fv[b * Fv + c] = G[b * W + 3 * P + c]; continue; }
+        const float v[3] = {nrm[b * 3], nrm[b * 3 + 1], nrm[b * 3 + 2]};
+        float acc[3] = {0.f, 0.f, 0.f};
+        const T *g = G + b * W + 2 * P;
+        for (int cc = 0; cc < P; cc++) {
+            int d; float deriv;
+            (void)pe_col(v, cc, d, deriv);
+            acc[d] += IO<T>::ld(g + cc) * deriv;
+        }
+        d_nrm[b * 3] = acc[0]; d_nrm[b * 3 + 1] = acc[1]; d_nrm[b * 3 + 2] = acc[2];
+    }
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+int grid_for(int64_t total) {
+    const int64_t want = (total + kThreads - 1) / kThreads;
+    return (int)(want < 1 ? 1 : (want < 256 * 16 ? want : 256 * 16));
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_trunk_input_fwd(const float *x, const float *feat, const float *dydx, void *out, int64_t B, int32_t nfreq, int32_t L, int32_t C,
+                       float jac_scale, int32_t dtype, void *stream) {
+    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!x || !feat || !dydx || !out) return HS_ERR_NULL;
+    const int64_t total = B * (3 + 6 * nfreq + L * C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HS_F32) k_trunk_input_fwd<float><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (float *)out, B, nfreq, L, C, jac_scale);
+    else k_trunk_input_fwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (__hip_bfloat16 *)out, B, nfreq, L, C, jac_scale);
+    return check_launch();
+}
+
+int hs_trunk_input_bwd(const void *G, float *g_feat, float *g_dydx, int64_t B, int32_t nfreq, int32_t L, int32_t C, float jac_scale, int32_t dtype,
+                       void *stream) {
+    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!G || !g_feat || !g_dydx) return HS_ERR_NULL;
+    const int64_t total = B * L * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HS_F32) k_trunk_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale);
+    else k_trunk_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale);
+    return check_launch();
+}
+
+int hs_render_input_fwd(const float *points, const float *view_dirs, const float *normals, const void *feature_vectors, void *out, int64_t B,
+                        int32_t nfreq, int32_t Fv, int32_t dtype, void *stream) {
+    if (nfreq < 0 || nfreq > 16 || Fv < 0 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!points || !view_dirs || !normals || !feature_vectors || !out) return HS_ERR_NULL;
+    const int64_t total = B * (3 * (3 + 6 * nfreq) + Fv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HS_F32) k_render_input_fwd<float><<<grid_for(total), kThreads, 0, st>>>(points, view_dirs, normals, (const float *)feature_vectors, (float *)out, B, nfreq, Fv);
+    else k_render_input_fwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>(points, view_dirs, normals, (const __hip_bfloat16 *)feature_vectors, (__hip_bfloat16 *)out, B, nfreq, Fv);
+    return check_launch();
+}
+
+int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, void *d_feature_vectors, int64_t B, int32_t nfreq, int32_t Fv,
+                        int32_t dtype, void *stream) {
+    if (nfreq < 0 || nfreq > 16 || Fv < 0 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!G || !normals || !d_normals || !d_feature_vectors) return HS_ERR_NULL;
+    const int64_t total = B * (Fv + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HS_F32) k_render_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, normals, d_normals, (float *)d_feature_vectors, B, nfreq, Fv);
+    else k_render_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, normals, d_normals, (__hip_bfloat16 *)d_feature_vectors, B, nfreq, Fv);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd"]
 
 
 def _check(rc, what):
@@ -238,6 +238,36 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                   ctypes.c_int64(x.shape[0]), _stream()), "hs_sdf_mlp_fwd")
+
+    # ---- fused network-input builders (include/holoscene_hip.h section 8)
+    @staticmethod
+    def trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, jac_scale):
+        lib = load_library()
+        dt = out.dtype
+        _check(lib.hs_trunk_input_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(out, "out", dt), ctypes.c_int64(x.shape[0]),
+                                      nfreq, L, C, ctypes.c_float(jac_scale), _DTYPES[dt], _stream()), "hs_trunk_input_fwd")
+
+    @staticmethod
+    def trunk_input_bwd(G, g_feat, g_dydx, nfreq, L, C, jac_scale):
+        lib = load_library()
+        dt = G.dtype
+        _check(lib.hs_trunk_input_bwd(_dev(G, "G", dt), _dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), ctypes.c_int64(G.shape[0]), nfreq, L, C,
+                                      ctypes.c_float(jac_scale), _DTYPES[dt], _stream()), "hs_trunk_input_bwd")
+
+    @staticmethod
+    def render_input_fwd(points, dirs, normals, fv, out, nfreq):
+        lib = load_library()
+        dt = out.dtype
+        _check(lib.hs_render_input_fwd(_dev(points, "points"), _dev(dirs, "view_dirs"), _dev(normals, "normals"), _dev(fv, "feature_vectors", dt),
+                                       _dev(out, "out", dt), ctypes.c_int64(points.shape[0]), nfreq, fv.shape[1], _DTYPES[dt], _stream()),
+               "hs_render_input_fwd")
+
+    @staticmethod
+    def render_input_bwd(G, normals, d_normals, d_fv, nfreq):
+        lib = load_library()
+        dt = G.dtype
+        _check(lib.hs_render_input_bwd(_dev(G, "G", dt), _dev(normals, "normals"), _dev(d_normals, "d_normals"), _dev(d_fv, "d_fv", dt),
+                                       ctypes.c_int64(G.shape[0]), nfreq, d_fv.shape[1], _DTYPES[dt], _stream()), "hs_render_input_bwd")
 
 
 class hsAdamState(ctypes.Structure):

@@ -85,6 +85,72 @@ def hash_encode_jac(encoder, x, size=1.0):
     return feat, jac
 
 
+class _trunk_input(torch.autograd.Function):
+    """x [B,3] (constant) + hash table -> the 4-row trunk input [B,4,F] (value row + d/dx rows) in two kernels:
+    hash encode (features + dy_dx) and the fused posenc/Jacobian/concat builder (csrc/encode_ops.hip).
+    backward: one slicing kernel + the fused value+Jacobian scatter into the table gradient."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, offsets, S, H, nfreq, divide_factor, out_dtype):
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        x = x.contiguous()
+        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()   # HashEncoder.forward's mapping to [0,1] (hashgrid.py:158)
+        B, D = x01.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        feat = torch.empty(B, L * C, device=x.device, dtype=x.dtype)
+        dydx = torch.empty(L, B, D * C, device=x.device, dtype=x.dtype)
+        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, H, dydx)
+        jac_scale = 0.5 / divide_factor
+        out = torch.empty(B, 4, 3 + 6 * nfreq + L * C, device=x.device, dtype=out_dtype)
+        _be._backend.trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, jac_scale)
+        ctx.save_for_backward(x01, embeddings, offsets)
+        ctx.cfg = (B, D, C, L, S, H, nfreq, jac_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        x01, embeddings, offsets = ctx.saved_tensors
+        B, D, C, L, S, H, nfreq, jac_scale = ctx.cfg
+        g_emb = None
+        if ctx.needs_input_grad[1]:
+            g_feat = torch.empty(B, L * C, device=G.device, dtype=torch.float32)
+            g_dydx = torch.empty(L, B, D * C, device=G.device, dtype=torch.float32)
+            _be._backend.trunk_input_bwd(G.contiguous(), g_feat, g_dydx, nfreq, L, C, jac_scale)
+            table = ctx.table
+            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
+            g_emb = None if inplace else target
+        return None, g_emb, None, None, None, None, None, None
+
+
+class _render_input(torch.autograd.Function):
+    """[posenc(points), posenc(view_dirs), posenc(normals), feature_vectors] in one kernel; the backward returns
+    the gradients of the two differentiable inputs (normals, feature_vectors)."""
+
+    @staticmethod
+    def forward(ctx, points, view_dirs, normals, feature_vectors, nfreq):
+        points, view_dirs, normals = points.contiguous().float(), view_dirs.contiguous().float(), normals.contiguous().float()
+        fv = feature_vectors.contiguous()
+        B, Fv = fv.shape
+        out = torch.empty(B, 3 * (3 + 6 * nfreq) + Fv, device=fv.device, dtype=fv.dtype)
+        _be._backend.render_input_fwd(points, view_dirs, normals, fv, out, nfreq)
+        ctx.save_for_backward(normals)
+        ctx.cfg = (nfreq, Fv)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        (normals,) = ctx.saved_tensors
+        nfreq, Fv = ctx.cfg
+        G = G.contiguous()
+        d_n = torch.empty_like(normals)
+        d_fv = torch.empty(G.shape[0], Fv, device=G.device, dtype=G.dtype)
+        _be._backend.render_input_bwd(G, normals, d_n, d_fv, nfreq)
+        return None, None, d_n, d_fv, None
+
+
 def _split_rows(M):
     """Number of row slices for the weight-gradient reduction over M rows (M = 4 x points reaches 4e5)."""
     for s in (128, 64, 32, 16, 8, 4, 2):
@@ -394,13 +460,10 @@ class ObjectImplicitNetworkGrid(nn.Module):
         Each point carries 4 rows through the trunk: the value and its three input tangents.  A Linear acts
         on all rows alike (one GEMM with M = 4B); Softplus becomes the fused `softplus_tangent` stage."""
         x = x.detach()
-        feat, fjac = hash_encode_jac(self.encoding, x / self.divide_factor)
-        fjac = fjac / self.divide_factor
-        if self.embedder is not None:
-            emb, ejac = self.embedder.embed_jacobian(x)
-        else:
-            emb, ejac = x, torch.eye(3, device=x.device, dtype=x.dtype).expand(x.shape[0], 3, 3)
-        inp = torch.cat([torch.cat([emb, feat], -1).unsqueeze(1), torch.cat([ejac, fjac], -1)], 1)   # [B,4,F]
+        enc = self.encoding
+        inp = _trunk_input.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                                 self.embedder.multires if self.embedder is not None else 0, float(self.divide_factor),
+                                 torch.bfloat16 if self.mlp_bf16 else torch.float32)                      # [B,4,F]
         h = inp
         lins = self._lins()
         for l, lin in enumerate(lins):
@@ -545,19 +608,23 @@ class RenderingNetwork(nn.Module):
             getattr(self, "lin" + str(l)).bf16 = self.mlp_bf16
 
     def forward(self, points, normals, view_dirs, feature_vectors, indices=None):
-        if self.multires_view > 0:
-            view_dirs = self.embedview_fn(view_dirs)
-        if self.multires_point > 0:
-            points = self.embedview_fn(points)
-        if self.multires_normal > 0:
-            normals = self.embedview_fn(normals)
-        dt = feature_vectors.dtype
-        if self.mode == "idr":
-            x = torch.cat([points.to(dt), view_dirs.to(dt), normals.to(dt), feature_vectors], dim=-1)
-        elif self.mode == "nerf":
-            x = torch.cat([view_dirs.to(dt), feature_vectors], dim=-1)
+        fused = (self.mode == "idr" and self.multires_view > 0 and self.multires_point > 0 and self.multires_normal > 0)
+        if fused:
+            x = _render_input.apply(points, view_dirs, normals, feature_vectors, self.multires_view)
         else:
-            raise NotImplementedError
+            if self.multires_view > 0:
+                view_dirs = self.embedview_fn(view_dirs)
+            if self.multires_point > 0:
+                points = self.embedview_fn(points)
+            if self.multires_normal > 0:
+                normals = self.embedview_fn(normals)
+            dt = feature_vectors.dtype
+            if self.mode == "idr":
+                x = torch.cat([points.to(dt), view_dirs.to(dt), normals.to(dt), feature_vectors], dim=-1)
+            elif self.mode == "nerf":
+                x = torch.cat([view_dirs.to(dt), feature_vectors], dim=-1)
+            else:
+                raise NotImplementedError
         for l in range(self.num_layers - 1):
             x = getattr(self, "lin" + str(l))(x)
             if l < self.num_layers - 2:

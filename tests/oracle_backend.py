@@ -68,6 +68,43 @@ class OracleBackend:
         if gbias is not None:
             gbias.add_(gA[:, 0].sum(0))
 
+    # fused input builders: plain torch restatement (test-only)
+    @staticmethod
+    def _pe(v, nfreq):
+        parts, jac = [v], [torch.diag_embed(torch.ones_like(v))]
+        for k in range(nfreq):
+            f = 2.0 ** k
+            s, c = torch.sin(v * f), torch.cos(v * f)
+            parts += [s, c]
+            jac += [torch.diag_embed(c * f), torch.diag_embed(-s * f)]
+        return torch.cat(parts, -1), torch.cat(jac, -1)
+
+    @classmethod
+    def trunk_input_fwd(cls, x, feat, dydx, out, nfreq, L, C, jac_scale):
+        B = x.shape[0]
+        pe, pj = cls._pe(x, nfreq)
+        fj = dydx.view(L, B, 3, C).permute(1, 2, 0, 3).reshape(B, 3, L * C) * jac_scale
+        out[:, 0] = torch.cat([pe, feat], -1).to(out.dtype)
+        out[:, 1:] = torch.cat([pj, fj], -1).to(out.dtype)
+
+    @staticmethod
+    def trunk_input_bwd(G, g_feat, g_dydx, nfreq, L, C, jac_scale):
+        B = G.shape[0]
+        P = 3 + 6 * nfreq
+        g_feat.copy_(G[:, 0, P:].float())
+        g_dydx.copy_((G[:, 1:, P:].float() * jac_scale).reshape(B, 3, L, C).permute(2, 0, 1, 3).reshape(L, B, 3 * C))
+
+    @classmethod
+    def render_input_fwd(cls, points, dirs, normals, fv, out, nfreq):
+        out.copy_(torch.cat([cls._pe(points, nfreq)[0], cls._pe(dirs, nfreq)[0], cls._pe(normals, nfreq)[0], fv.float()], -1).to(out.dtype))
+
+    @classmethod
+    def render_input_bwd(cls, G, normals, d_normals, d_fv, nfreq):
+        P = 3 + 6 * nfreq
+        _, pj = cls._pe(normals, nfreq)                      # [B,3,P]
+        d_normals.copy_(torch.einsum("bdp,bp->bd", pj, G[:, 2 * P:3 * P].float()))
+        d_fv.copy_(G[:, 3 * P:])
+
 
 def install(monkeypatch):
     from holoscene_amd.hashencoder import backend

@@ -310,3 +310,44 @@ def test_fused_mfma_sdf_kernel_vs_torch(d_out, B):
     assert (got_min - ref_min).abs().max() < 1e-2 * scale
     assert torch.equal(got_min, got_raw.min(-1, keepdim=True)[0]), "min output must be the min of the raw outputs of the same launch"
     assert torch.equal(got_sel, got_raw[:, d_out - 1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_input_builders_vs_torch(dtype):
+    """csrc/encode_ops.hip vs the plain torch formulation (Embedder + cat), forward and backward."""
+    from holoscene_amd.hashencoder import backend
+    from holoscene_amd.model.embedder import Embedder
+    be = backend._backend
+    g = torch.Generator().manual_seed(3)
+    B, nf, L, C = 777, 6, 16, 2
+    x = (torch.rand(B, 3, generator=g) * 2 - 1).to(DEV)
+    feat = torch.randn(B, L * C, generator=g).to(DEV)
+    dydx = torch.randn(L, B, 3 * C, generator=g).to(DEV)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    out = torch.empty(B, 4, 3 + 6 * nf + L * C, device=DEV, dtype=dtype)
+    be.trunk_input_fwd(x, feat, dydx, out, nf, L, C, 0.5)
+    emb, ejac = Embedder(nf, 3).embed_jacobian(x)
+    fj = dydx.view(L, B, 3, C).permute(1, 2, 0, 3).reshape(B, 3, L * C) * 0.5
+    ref = torch.cat([torch.cat([emb, feat], -1).unsqueeze(1), torch.cat([ejac, fj], -1)], 1)
+    assert torch.allclose(out.float(), ref, **tol)
+    G = torch.randn(B, 4, out.shape[-1], generator=g).to(DEV).to(dtype)
+    gf = torch.empty(B, L * C, device=DEV)
+    gj = torch.empty(L, B, 3 * C, device=DEV)
+    be.trunk_input_bwd(G, gf, gj, nf, L, C, 0.5)
+    P = 3 + 6 * nf
+    assert torch.allclose(gf, G[:, 0, P:].float())
+    assert torch.allclose(gj, (G[:, 1:, P:].float() * 0.5).reshape(B, 3, L, C).permute(2, 0, 1, 3).reshape(L, B, 3 * C))
+    # rendering-network input
+    from holoscene_amd.model.network import _render_input
+    pts, dirs = x, torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(DEV)
+    nrm = torch.randn(B, 3, generator=g).to(DEV).requires_grad_(True)
+    fv = torch.randn(B, 256, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    got = _render_input.apply(pts, dirs, nrm, fv, 4)
+    e = Embedder(4, 3)
+    ref = torch.cat([e.embed(pts), e.embed(dirs), e.embed(nrm), fv.float()], -1)
+    assert torch.allclose(got.float(), ref, **tol)
+    cot = torch.randn(ref.shape, generator=g).to(DEV)
+    g_n, g_f = torch.autograd.grad(got, (nrm, fv), cot.to(dtype))
+    r_n, r_f = torch.autograd.grad(ref, (nrm, fv), cot.to(dtype).float())
+    assert torch.allclose(g_n, r_n, rtol=1e-4 if dtype == torch.float32 else 3e-2, atol=1e-4 if dtype == torch.float32 else 0.3)
+    assert torch.allclose(g_f.float(), r_f.float(), **tol)
