@@ -40,6 +40,7 @@ def parse():
                    help="MLP GEMM operand precision (BASELINE configs[1] names bf16; fp32 is the reference's own precision)")
     p.add_argument("--no-graph", action="store_true", help="run the post-sampler part eagerly instead of as a captured HIP graph")
     p.add_argument("--optimizer", choices=["flat", "torch"], default="flat")
+    p.add_argument("--roofline-steps", type=int, default=6, help="eager iterations after the timed region used to time single kernels")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -48,8 +49,9 @@ def parse():
 class KernelTimer:
     """HIP-event timing of one backend entry point, recorded on the stream the kernel is launched on."""
 
-    def __init__(self, backend_cls, name):
+    def __init__(self, backend_cls, name, size_arg=4):
         self.events, self.points = [], 0
+        self.size_arg = size_arg
         self._orig = getattr(backend_cls, name)
         self._cls, self._name = backend_cls, name
         self.enabled = False
@@ -64,7 +66,7 @@ class KernelTimer:
             s.record()
             r = orig(*a, **k)
             e.record()
-            me.events.append((s, e, a[4]))  # a[4] = B (points)
+            me.events.append((s, e, a[me.size_arg]))  # number of points of this launch
             return r
 
         setattr(self._cls, self._name, staticmethod(timed))
@@ -155,19 +157,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    with KernelTimer(backend._HipBackend, "fwd") as kt:
-        for _ in range(args.warmup):
-            step()
-        rounds_seen.clear()
-        barrier()
-        kt.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        kt.enabled = False
-        ms, pts = kt.summary()
+    for _ in range(args.warmup):
+        step()
+    rounds_seen.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -175,16 +173,45 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.rays * world * args.steps / elapsed
 
-    # roofline of the hash-encode forward kernel (k_hash_fwd): algorithmic bytes = L*8*C*4 B gathered per point
-    # (+ coordinates in, features out); launches = every hs_hash_fwd call in the timed region.
+    # ---- roofline of the dominant hand-written kernel: k_hash_bwd_jac, the fused value+Jacobian scatter into the
+    # geometry-grid gradient (largest single kernel of the iteration in profiles/).  Kernels inside a replayed HIP
+    # graph cannot be bracketed by events, so the same iteration is run eagerly a few times right after the timed
+    # region and every launch of the kernel is timed with HIP events on the launching stream.
+    # Algorithmic bytes per point (SURVEY 8d, G = L*8*C*4 = 1024 B): read-modify-write of the 8 corner entries on all
+    # levels = 2G, plus the cotangents g_feat (L*C*4 = 128 B), g_dydx (L*3*C*4 = 384 B) and the coordinates (12 B).
     L, C = 16, 2
-    gather_per_point = L * 8 * C * 4
-    alg_bytes = sum(p * (gather_per_point + 12 + L * C * 4) for p in pts)
+    G = L * 8 * C * 4
+    bytes_per_point = 2 * G + L * C * 4 + L * 3 * C * 4 + 12
+    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2)
+    tr.use_graph = False
+    with KernelTimer(backend._HipBackend, "bwd_jac", size_arg=5) as kt, KernelTimer(backend._HipBackend, "sdf_mlp_fwd", size_arg=0) as km:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        kt.enabled = km.enabled = True
+        for _ in range(args.roofline_steps):
+            step()
+        torch.cuda.synchronize()
+        kt.enabled = km.enabled = False
+        ms = [t for t, b in zip(*kt.summary()) if b == n_main]
+        mfma_ms = km.summary()[0]
+        mfma_pts = [int(x_.shape[0]) for x_ in km.summary()[1]]
     total_ms = sum(ms)
-    achieved = alg_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
-    roofline = {"kernel": "k_hash_fwd<3,2>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(ms),
-                "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2)}
+    achieved = bytes_per_point * n_main * len(ms) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (corrected as the microarch guide says)
+        traffic = json.load(open(pmc_file)).get("k_hash_bwd_jac_main_launch_bytes")
+    roofline = {"kernel": "k_hash_bwd_jac<3,2> (fused value+Jacobian scatter, geometry grid, main render set)", "bound": "hbm",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches": len(ms), "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2),
+                "algorithmic_bytes_per_launch": bytes_per_point * n_main,
+                "note": "float-atomic scatter: bounded by the L2 atomic rate (~19 G atomics/s measured), not by HBM bandwidth"}
+    if mfma_ms:  # the matrix-core kernel of the path (sampler SDF sweeps), for the MFMA side of the roofline
+        flops = sum(p * 2 * (96 * 256 + 256 * 256 + 256 * 32) for p in mfma_pts)
+        roofline["mfma_kernel"] = {"kernel": "k_sdf_mlp<1> (bf16 MFMA fused SDF trunk)", "achieved": round(flops / (sum(mfma_ms) * 1e-3) / 1e12, 1),
+                                   "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / (sum(mfma_ms) * 1e-3) / 1e12 / 2500.0, 4),
+                                   "launches": len(mfma_ms), "avg_launch_us": round(sum(mfma_ms) / len(mfma_ms) * 1e3, 2)}
     if rank == 0:
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
