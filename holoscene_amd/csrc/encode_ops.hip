@@ -117,16 +117,18 @@ __global__ __launch_bounds__(kThreads) void k_render_input_fwd(const float *__re
     }
 }
 
-// d_normals[b,d] = sum_c G[b, 2P+c] * d pe_c/d n_d  (one thread per point; 3P columns are few) ; d_feat = G[:, 3P:]
+// d_normals[b,d] = sum_c G[b, 2P+c] * d pe_c/d n_d (one thread per point; P columns are few).  d_feat = G[:, 3P:] is copied
+// only when the caller wants a packed tensor (d_fv != NULL); the Python layer hands autograd a strided view instead.
 template <class T>
 __global__ __launch_bounds__(kThreads) void k_render_input_bwd(const T *__restrict__ G, const float *__restrict__ nrm, float *__restrict__ d_nrm,
                                                                 T *__restrict__ d_fv, int64_t B, int nf, int Fv) {
     const int P = 3 + 6 * nf, W = 3 * P + Fv;
-    const int64_t total = B * (Fv + 1);
+    const int per = d_fv ? Fv + 1 : 1;
+    const int64_t total = B * per;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        const int64_t b = i / (Fv + 1);
-        const int c = (int)(i - b * (Fv + 1));
-        if (c < Fv) { d_fv[b * Fv + c] = G[b * W + 3 * P + c]; continue; }
+        const int64_t b = i / per;
+        const int c = (int)(i - b * per);
+        if (c + 1 < per) { d_fv[b * Fv + c] = G[b * W + 3 * P + c]; continue; }
         const float v[3] = {nrm[b * 3], nrm[b * 3 + 1], nrm[b * 3 + 2]};
         float acc[3] = {0.f, 0.f, 0.f};
         const T *g = G + b * W + 2 * P;
@@ -190,8 +192,8 @@ int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, v
                         int32_t dtype, void *stream) {
     if (nfreq < 0 || nfreq > 16 || Fv < 0 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
-    if (!G || !normals || !d_normals || !d_feature_vectors) return HS_ERR_NULL;
-    const int64_t total = B * (Fv + 1);
+    if (!G || !normals || !d_normals) return HS_ERR_NULL;
+    const int64_t total = B * (d_feature_vectors ? Fv + 1 : 1);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HS_F32) k_render_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, normals, d_normals, (float *)d_feature_vectors, B, nfreq, Fv);
     else k_render_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, normals, d_normals, (__hip_bfloat16 *)d_feature_vectors, B, nfreq, Fv);

@@ -263,11 +263,11 @@ class _HipBackend:
                "hs_render_input_fwd")
 
     @staticmethod
-    def render_input_bwd(G, normals, d_normals, d_fv, nfreq):
+    def render_input_bwd(G, normals, d_normals, d_fv, nfreq, Fv):
         lib = load_library()
         dt = G.dtype
         _check(lib.hs_render_input_bwd(_dev(G, "G", dt), _dev(normals, "normals"), _dev(d_normals, "d_normals"), _dev(d_fv, "d_fv", dt),
-                                       ctypes.c_int64(G.shape[0]), nfreq, d_fv.shape[1], _DTYPES[dt], _stream()), "hs_render_input_bwd")
+                                       ctypes.c_int64(G.shape[0]), nfreq, Fv, _DTYPES[dt], _stream()), "hs_render_input_bwd")
 
 
 class hsAdamState(ctypes.Structure):

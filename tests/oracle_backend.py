@@ -99,11 +99,12 @@ class OracleBackend:
         out.copy_(torch.cat([cls._pe(points, nfreq)[0], cls._pe(dirs, nfreq)[0], cls._pe(normals, nfreq)[0], fv.float()], -1).to(out.dtype))
 
     @classmethod
-    def render_input_bwd(cls, G, normals, d_normals, d_fv, nfreq):
+    def render_input_bwd(cls, G, normals, d_normals, d_fv, nfreq, Fv):
         P = 3 + 6 * nfreq
         _, pj = cls._pe(normals, nfreq)                      # [B,3,P]
         d_normals.copy_(torch.einsum("bdp,bp->bd", pj, G[:, 2 * P:3 * P].float()))
-        d_fv.copy_(G[:, 3 * P:])
+        if d_fv is not None:
+            d_fv.copy_(G[:, 3 * P:])
 
 
 def install(monkeypatch):
