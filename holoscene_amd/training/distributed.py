@@ -48,10 +48,12 @@ def exchange_and_step_flat(flat, world_size, zero1=True, group=None):
     zero1=False: one all-reduce over the flat gradient, full Adam on every rank."""
     if zero1:
         b, e = flat.shard
-        shard_g = flat.flat_g[b:e]
-        dist.reduce_scatter_tensor(shard_g, flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_backend(group) == "gloo":   # gloo (CPU tests) has no reduce_scatter: same sums via all_reduce
+            dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce_scatter_tensor(flat.flat_g[b:e], flat.flat_g, op=dist.ReduceOp.SUM, group=group)
         flat.step(grad_scale=1.0 / world_size, shard_only=True)
-        dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e], group=group)
+        dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e].clone(), group=group)
     else:
         dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
         flat.step(grad_scale=1.0 / world_size)

@@ -67,3 +67,114 @@ def test_gradient_mean_and_adam_step_match_single_process():
     for p, n0, n1 in zip(ref, new0, new1):
         assert torch.allclose(p.detach(), torch.from_numpy(n0), rtol=1e-6, atol=1e-7)
         assert (n0 == n1).all()
+
+
+class _TorchAdamKernels:
+    """TEST-ONLY torch restatement of csrc/optim.hip so the ZeRO-1 exchange logic can run on CPU/gloo."""
+
+    @staticmethod
+    def adam_tick(state, beta1, beta2, gamma):
+        from holoscene_amd.hashencoder.backend import hsAdamState
+        import ctypes
+        st = hsAdamState.from_buffer_copy(bytes(state.numpy().tobytes()))
+        st.step += 1
+        bc1, bc2 = 1 - beta1 ** st.step, 1 - beta2 ** st.step
+        for g in range(3):
+            lr = st.lr0[g] * gamma ** (st.step - 1)
+            st.lr[g] = lr
+            st.step_size[g] = lr / bc1
+        st.bc2_sqrt = bc2 ** 0.5
+        state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+
+    @staticmethod
+    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale):
+        from holoscene_amd.hashencoder.backend import hsAdamState
+        st = hsAdamState.from_buffer_copy(bytes(state.numpy().tobytes()))
+        idx = torch.arange(begin, end)
+        step = torch.where(idx < st.group_end[0], torch.tensor(st.step_size[0]),
+                           torch.where(idx < st.group_end[1], torch.tensor(st.step_size[1]), torch.tensor(st.step_size[2])))
+        gg = g[begin:end] * grad_scale
+        m[begin:end] += (1 - beta1) * (gg - m[begin:end])
+        v[begin:end] = v[begin:end] * beta2 + (1 - beta2) * gg * gg
+        p[begin:end] -= step * (m[begin:end] / (v[begin:end].sqrt() / st.bc2_sqrt + eps))
+
+
+class _TinyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.grid = torch.nn.Parameter(torch.randn(1001, 2))
+        self.net = torch.nn.Linear(7, 5)
+        self.beta = torch.nn.Parameter(torch.tensor(0.1))
+        me = self
+
+        class NS:
+            pass
+        self.implicit_network, self.rendering_network, self.density = NS(), NS(), NS()
+        self.implicit_network.grid_parameters = lambda: [me.grid]
+        self.implicit_network.mlp_parameters = lambda: list(me.net.parameters())
+        self.rendering_network.parameters = lambda: []
+        self.density.parameters = lambda: [me.beta]
+
+
+def _flat_worker(rank, world, port, q, zero1):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from holoscene_amd.hashencoder import backend
+    from holoscene_amd.training.distributed import exchange_and_step_flat
+    from holoscene_amd.training.flat import FlatAdam
+    for name in ("adam_tick", "adam_flat"):
+        setattr(backend._HipBackend, name, staticmethod(getattr(_TorchAdamKernels, name)))
+    torch.manual_seed(0)            # identical replicas
+    model = _TinyModel()
+    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank)
+    g = torch.Generator().manual_seed(50 + rank)
+    hist = []
+    for _ in range(2):
+        flat.zero_grad()
+        local = torch.randn(flat.padded, generator=g)
+        local[flat.numel:] = 0
+        flat.flat_g.copy_(local)
+        hist.append(local.clone())
+        exchange_and_step_flat(flat, world, zero1=zero1)
+    q.put((rank, [h.numpy() for h in hist], flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_flat_exchange_equals_single_process_mean_gradient(zero1):
+    """reduce-scatter -> shard-local Adam -> all-gather (ZeRO-1) and all-reduce -> full Adam both equal one process
+    applying Adam to the mean of the ranks' gradients; replicas stay bit-identical."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q, zero1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, h0, flat0, params0), (_, h1, flat1, _) = res
+    assert (flat0 == flat1).all(), "replicas diverged"
+    # single-process reference with torch.optim.Adam on the same groups
+    torch.manual_seed(0)
+    ref = _TinyModel()
+    opt = torch.optim.Adam([{"params": [ref.grid], "lr": 5e-4 * 20}, {"params": list(ref.net.parameters()), "lr": 5e-4},
+                            {"params": [ref.beta], "lr": 5e-4}], betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.1 ** (1 / 1000))
+    plist = [ref.grid] + list(ref.net.parameters()) + [ref.beta]
+    for a, b in zip(h0, h1):
+        mean = (torch.from_numpy(a) + torch.from_numpy(b)) / 2
+        off = 0
+        for p in plist:
+            p.grad = mean[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        opt.step()
+        sched.step()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(p.detach(), torch.from_numpy(params0[n]), rtol=1e-5, atol=1e-7), n
