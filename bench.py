@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=15)
     p.add_argument("--rays", type=int, default=1024)
     p.add_argument("--samples", type=int, default=128)
     p.add_argument("--objects", type=int, default=32)
@@ -182,7 +182,7 @@ def main():
     L, C = 16, 2
     G = L * 8 * C * 4
     bytes_per_point = 2 * G + L * C * 4 + L * 3 * C * 4 + 12
-    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2)
+    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2) + 4 * args.rays   # rendered points + Eikonal set, one launch
     tr.use_graph = False
     with KernelTimer(backend._HipBackend, "bwd_jac", size_arg=5) as kt, KernelTimer(backend._HipBackend, "sdf_mlp_fwd", size_arg=0) as km:
         for _ in range(2):
@@ -202,7 +202,7 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
     if os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (corrected as the microarch guide says)
         traffic = json.load(open(pmc_file)).get("k_hash_bwd_jac_main_launch_bytes")
-    roofline = {"kernel": "k_hash_bwd_jac<3,2> (fused value+Jacobian scatter, geometry grid, main render set)", "bound": "hbm",
+    roofline = {"kernel": "k_hash_bwd_jac<3,2> (fused value+Jacobian scatter, geometry grid; rendered points + Eikonal set)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": len(ms), "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2),
                 "algorithmic_bytes_per_launch": bytes_per_point * n_main,
