@@ -34,15 +34,17 @@ template <> struct Quad<__hip_bfloat16> {
         return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                            __uint_as_float(r.y & 0xffff0000u));
     }
-    static __device__ __forceinline__ uint32_t rne(float f) {  // round-to-nearest-even fp32 -> bf16 bits
-        const uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float float2_t __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-safe)
+        const float2_t v = {a, b};
+        const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+        return *reinterpret_cast<const uint32_t *>(&r);
     }
     static __device__ __forceinline__ void store(__hip_bfloat16 *p, float4 v) {
         uint2 r;
-        r.x = rne(v.x) | (rne(v.y) << 16);
-        r.y = rne(v.z) | (rne(v.w) << 16);
+        r.x = pack(v.x, v.y);
+        r.y = pack(v.z, v.w);
         *reinterpret_cast<uint2 *>(p) = r;
     }
 };
@@ -54,14 +56,14 @@ constexpr int kPointsPerBlock = 64;
 // derivative <= 1e-7 -- below fp32 round-off of the GEMMs on either side.  The libm log1pf/expf pair made this
 // stage ALU-bound (133 us for 131 072 x 256 bf16 values vs 34 us of HBM time).
 struct SpPair { float sp, ds; };
-__device__ __forceinline__ SpPair softplus100_pair(float v) {
+__device__ __forceinline__ SpPair softplus100_pair(float v) {  // branch-free; raw v_exp_f32 / v_log_f32 (base 2)
     const float t = v * 100.f;
+    const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
+    const float one_e = 1.f + e;
     SpPair r;
-    if (t > 20.f) { r.sp = v; r.ds = 1.f; return r; }
-    const float e = __expf(t);
-    const float inv = __frcp_rn(1.f + e);
-    r.sp = __logf(1.f + e) * 0.01f;
-    r.ds = e * inv;
+    const bool lin = t > 20.f;
+    r.sp = lin ? v : __builtin_amdgcn_logf(one_e) * (0.69314718f * 0.01f);
+    r.ds = lin ? 1.f : e * __builtin_amdgcn_rcpf(one_e);
     return r;
 }
 
