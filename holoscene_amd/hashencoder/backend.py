@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal"]
 
 
 def _check(rc, what):
@@ -268,6 +268,24 @@ class _HipBackend:
         dt = G.dtype
         _check(lib.hs_render_input_bwd(_dev(G, "G", dt), _dev(normals, "normals"), _dev(d_normals, "d_normals"), _dev(d_fv, "d_fv", dt),
                                        ctypes.c_int64(G.shape[0]), nfreq, Fv, _DTYPES[dt], _stream()), "hs_render_input_bwd")
+
+    # ---- fused objective (include/holoscene_hip.h section 9)
+    @staticmethod
+    def loss_rays(rgb, rgb_gt, depth, depth_gt, nmap, n_gt, gt_mask, sdf, opac, segs, weights, out5, g_rgb, g_depth, g_nmap, g_opac):
+        lib = load_library()
+        R, N = sdf.shape
+        K = opac.shape[1]
+        w = [ctypes.c_float(float(x)) for x in weights]
+        _check(lib.hs_loss_rays(_dev(rgb, "rgb"), _dev(rgb_gt, "rgb_gt"), _dev(depth, "depth"), _dev(depth_gt, "depth_gt"), _dev(nmap, "normal_map"),
+                                _dev(n_gt, "normal_gt"), _dev(gt_mask, "gt_mask"), _dev(sdf, "sdf"), _dev(opac, "opacity"),
+                                _dev(segs, "segs", torch.int64), R, N, K, *w, _dev(out5, "out5"), _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"),
+                                _dev(g_nmap, "g_normal_map"), _dev(g_opac, "g_opacity"), _stream()), "hs_loss_rays")
+
+    @staticmethod
+    def loss_eikonal(g1, g2, w_eik, w_smooth, acc2, d_g1, d_g2):
+        lib = load_library()
+        _check(lib.hs_loss_eikonal(_dev(g1, "g1"), _dev(g2, "g2"), ctypes.c_int64(g1.shape[0]), ctypes.c_float(w_eik), ctypes.c_float(w_smooth),
+                                   _dev(acc2, "acc2"), _dev(d_g1, "d_g1"), _dev(d_g2, "d_g2"), _stream()), "hs_loss_eikonal")
 
 
 class hsAdamState(ctypes.Structure):

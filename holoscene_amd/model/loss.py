@@ -6,12 +6,54 @@ Written without data-dependent Python branches: where the reference tests a devi
 version divides by ``clamp(count, 1)`` so the value is identical and the stream never stalls.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..hashencoder import backend as _be
 from ..utils.conf import get_class
+
+# "hip": value + analytic gradient of the per-ray and Eikonal/smoothness terms in two fused kernels (csrc/loss.hip);
+# "torch": the whole-tensor formulation below (A/B reference, and what CPU host-logic tests select explicitly).
+LOSS_IMPL = os.environ.get("HOLOSCENE_LOSS_IMPL", "hip")
+
+
+_WEIGHT_CACHE = {}
+
+
+class _fused_core_loss(torch.autograd.Function):
+    """(rgb_values, depth_values, normal_map, object_opacity, grad_theta, grad_theta_nei) -> weighted sum of the rgb,
+    depth, normal, opacity, Eikonal and smoothness terms + the 7 unweighted terms (for logging, not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, nmap, opac, g1, g2, sdf, rgb_gt, depth_gt, n_gt, gt_mask, segs, weights):
+        w_rgb, w_depth, w_l1, w_cos, w_opac, w_eik, w_smooth = weights
+        dev = rgb.device
+        R = rgb.shape[0]
+        c = lambda t: t.detach().contiguous().float()  # noqa: E731
+        rgb_, depth_, nmap_, opac_, g1_, g2_ = c(rgb), c(depth).reshape(-1), c(nmap), c(opac), c(g1), c(g2)
+        out5 = torch.empty(5, device=dev)
+        acc2 = torch.zeros(2, device=dev)
+        g_rgb, g_depth, g_nmap, g_opac = torch.empty_like(rgb_), torch.empty_like(depth_), torch.empty_like(nmap_), torch.empty_like(opac_)
+        d_g1, d_g2 = torch.empty_like(g1_), torch.empty_like(g2_)
+        be = _be._backend
+        be.loss_rays(rgb_, c(rgb_gt).reshape(-1, 3), depth_, c(depth_gt).reshape(-1), nmap_, c(n_gt).reshape(-1, 3), c(gt_mask).reshape(-1),
+                     c(sdf), opac_, segs.reshape(-1).long().contiguous(), (w_rgb, w_depth, w_l1, w_cos, w_opac), out5, g_rgb, g_depth, g_nmap, g_opac)
+        be.loss_eikonal(g1_, g2_, w_eik, w_smooth, acc2, d_g1, d_g2)
+        terms = torch.cat([out5, acc2 / g1_.shape[0]])   # rgb, depth, n_l1, n_cos, opacity, eikonal, smooth
+        key = (str(dev), tuple(float(x) for x in weights))
+        wvec = _WEIGHT_CACHE.get(key)
+        if wvec is None:   # built once (during the eager warm-up), so that graph capture never sees a host->device copy
+            wvec = _WEIGHT_CACHE[key] = torch.tensor(key[1], device=dev)
+        ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_g1, d_g2)
+        ctx.mark_non_differentiable(terms)
+        return (terms * wvec).sum(), terms
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        return tuple(t * g for t in ctx.saved_tensors) + (None,) * 7
 
 
 def compute_scale_and_shift_batch(prediction, target):
@@ -150,11 +192,33 @@ class HoloSceneLoss(MonoSDFLoss):
         mask = mask.reshape(1, 32, 32)
         return self.compute_grad_error(bg_depth, mask) + self.compute_grad_error(bg_normal, mask.repeat(3, 1, 1))
 
+    def _forward_fused(self, model_outputs, ground_truth):
+        """MonoSDFLoss.forward + the opacity term through csrc/loss.hip (same keys, same values)."""
+        decay = math.exp(-self.step / self.end_step * 10.0) if self.end_step > 0 else 1.0
+        self.step += 1
+        weights = (1.0, decay * self.depth_weight, decay * self.normal_l1_weight, decay * self.normal_cos_weight,
+                   self.semantic_weight, self.eikonal_weight, self.smooth_weight)
+        total, t = _fused_core_loss.apply(model_outputs["rgb_values"], model_outputs["depth_values"], model_outputs["normal_map"],
+                                          model_outputs["object_opacity"], model_outputs["grad_theta"], model_outputs["grad_theta_nei"],
+                                          model_outputs["sdf"], ground_truth["rgb"], ground_truth["depth"], ground_truth["normal"],
+                                          ground_truth["mask"], ground_truth["segs"], weights)
+        return {"loss": total, "rgb_loss": t[0], "depth_loss": t[1], "normal_l1": t[2], "normal_cos": t[3], "eikonal_loss": t[5],
+                "smooth_loss": t[6]}, t[4]
+
     def forward(self, model_outputs, ground_truth, call_reg=False, call_bg_reg=False):
-        output = super().forward(model_outputs, ground_truth)
+        fused = (LOSS_IMPL == "hip" and self.use_obj_opacity and "object_opacity" in model_outputs and "grad_theta" in model_outputs
+                 and self.depth_weight > 0 and isinstance(self.rgb_loss, nn.L1Loss) and "rgb_offset" not in model_outputs)
+        if fused:
+            if not model_outputs["rgb_values"].is_cuda:
+                raise RuntimeError("fused loss needs CUDA tensors (set HOLOSCENE_LOSS_IMPL=torch explicitly for the whole-tensor formulation)")
+            output, fused_semantic = self._forward_fused(model_outputs, ground_truth)
+        else:
+            output, fused_semantic = super().forward(model_outputs, ground_truth), None
         dev = output["loss"].device
         zero = torch.zeros((), device=dev)
-        if "semantic_values" in model_outputs and not self.use_obj_opacity:
+        if fused_semantic is not None:
+            semantic_loss = fused_semantic
+        elif "semantic_values" in model_outputs and not self.use_obj_opacity:
             semantic_loss = self.get_semantic_loss(model_outputs["semantic_values"], ground_truth["segs"].to(dev).long())
         elif "object_opacity" in model_outputs and self.use_obj_opacity:
             semantic_loss = self.object_opacity_loss(model_outputs["object_opacity"], ground_truth["segs"].to(dev).long())
@@ -181,6 +245,7 @@ class HoloSceneLoss(MonoSDFLoss):
         output["semantic_loss"] = semantic_loss
         output["collision_reg_loss"] = sample_sdf_loss
         output["background_reg_loss"] = background_reg_loss
-        output["loss"] = output["loss"] + self.semantic_weight * semantic_loss + self.reg_vio_weight * sample_sdf_loss \
-            + self.bg_reg_weight * background_reg_loss
+        if fused_semantic is None:   # (the fused core already contains semantic_weight * semantic_loss)
+            output["loss"] = output["loss"] + self.semantic_weight * semantic_loss
+        output["loss"] = output["loss"] + self.reg_vio_weight * sample_sdf_loss + self.bg_reg_weight * background_reg_loss
         return output

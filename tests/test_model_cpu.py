@@ -16,6 +16,8 @@ def _oracle_hash(monkeypatch):
     monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", "torch")  # explicit opt-in: host-logic check of the whole-tensor formulation
     from holoscene_amd.model import network
     monkeypatch.setattr(network, "COMPOSITE_IMPL", "torch")
+    from holoscene_amd.model import loss
+    monkeypatch.setattr(loss, "LOSS_IMPL", "torch")
 
 
 @pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])

@@ -351,3 +351,33 @@ def test_fused_input_builders_vs_torch(dtype):
     r_n, r_f = torch.autograd.grad(ref, (nrm, fv), cot.to(dtype).float())
     assert torch.allclose(g_n, r_n, rtol=1e-4 if dtype == torch.float32 else 3e-2, atol=1e-4 if dtype == torch.float32 else 0.3)
     assert torch.allclose(g_f.float(), r_f.float(), **tol)
+
+
+@pytest.mark.parametrize("R,N,K", [(1024, 98, 32), (40, 14, 5), (2048, 50, 21)])
+def test_fused_loss_matches_torch_formulation(R, N, K, monkeypatch):
+    """csrc/loss.hip (value + analytic gradient) vs the whole-tensor torch loss + autograd on random inputs."""
+    from holoscene_amd.model import loss as loss_mod
+    g = torch.Generator().manual_seed(R + K)
+    H = (K + 1) * 2 * R
+    outs = {"rgb_values": torch.rand(R, 3, generator=g), "depth_values": torch.rand(R, 1, generator=g) * 2 + 0.2,
+            "normal_map": torch.randn(R, 3, generator=g) * 0.5, "object_opacity": torch.rand(R, K, generator=g) ** 3,
+            "grad_theta": torch.randn(H, 3, generator=g), "grad_theta_nei": torch.randn(H, 3, generator=g),
+            "sdf": torch.randn(R, N, generator=g), "iter_step": 5}
+    outs["object_opacity"][0, :] = torch.tensor([0.0, 1.0] + [5e-5] * (K - 2))   # clip boundaries
+    outs["sdf"][: R // 4] = outs["sdf"][: R // 4].abs()                         # rays that never cross a surface
+    gt = {"rgb": torch.rand(1, R, 3, generator=g), "depth": torch.rand(1, R, 1, generator=g) + 0.1,
+          "normal": torch.randn(1, R, 3, generator=g), "mask": (torch.rand(1, R, 1, generator=g) > 0.2).float(),
+          "segs": torch.randint(0, K, (1, R, 1), generator=g)}
+    gt = {k: v.to(DEV) for k, v in gt.items()}
+    names = ("rgb_values", "depth_values", "normal_map", "object_opacity", "grad_theta", "grad_theta_nei")
+    res = {}
+    for impl in ("torch", "hip"):
+        monkeypatch.setattr(loss_mod, "LOSS_IMPL", impl)
+        o = {k: (v.to(DEV).clone().requires_grad_(k in names) if torch.is_tensor(v) else v) for k, v in outs.items()}
+        lo = build_loss()(o, gt)
+        grads = torch.autograd.grad(lo["loss"], [o[k] for k in names])
+        res[impl] = (lo, grads)
+    for k in ("loss", "rgb_loss", "depth_loss", "normal_l1", "normal_cos", "semantic_loss", "eikonal_loss", "smooth_loss"):
+        close(res["hip"][0][k], res["torch"][0][k], 2e-4, 1e-6, k)
+    for n_, a, b in zip(names, res["hip"][1], res["torch"][1]):
+        close(a, b, 2e-3, 2e-5 * max(1e-6, float(b.abs().max())), "d/d" + n_)
