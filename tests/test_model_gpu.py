@@ -381,3 +381,26 @@ def test_fused_loss_matches_torch_formulation(R, N, K, monkeypatch):
         close(res["hip"][0][k], res["torch"][0][k], 2e-4, 1e-6, k)
     for n_, a, b in zip(names, res["hip"][1], res["torch"][1]):
         close(a, b, 2e-3, 2e-5 * max(1e-6, float(b.abs().max())), "d/d" + n_)
+
+
+@pytest.mark.parametrize("rays,S,K,precision", [(1024, 128, 21, "fp32"), (2048, 192, 32, "bf16"), (512, 128, 32, "bf16")])
+def test_other_baseline_config_shapes(rays, S, K, precision):
+    """BASELINE configs[3] (K=21 on the shared net), configs[4] (2 048 rays x 192 samples -> 146 pts/ray) and the per-rank
+    shape of configs[2] (512 rays): two graph-replayed training iterations, size-independent invariants."""
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    tr = Stage1Trainer(stock_conf(num_rays=rays, S=S, d_out=K, beta=0.01, mlp_precision=precision), device=DEV, optimizer="flat", graph=True)
+    benchmark_model_state(tr.model, 0.01)
+    scene = SyntheticScene(rays, K, num_frames=2, ring=4, device=DEV)
+    N = S // 2 + S // 4 + 2
+    for it in range(2):
+        idx, mi, gt = scene.next_batch()
+        out, lo = tr.train_step(idx, mi, gt)
+        torch.cuda.synchronize()
+        z = out["z_vals"]
+        assert z.shape == (rays, N) and bool((z[:, 1:] >= z[:, :-1]).all()) and float(z.max()) <= 3.5 + 1e-6
+        w = out["weights"]
+        assert bool((w >= -1e-6).all()) and bool((w.sum(-1) <= 1 + 1e-3).all())
+        assert out["object_opacity"].shape == (rays, K) and out["grad_theta"].shape == ((K + 1) * 2 * rays, 3)
+        assert bool(torch.isfinite(lo["loss"])) and float(lo["eikonal_loss"]) >= 0
+        assert bool(torch.isfinite(tr.flat.flat_p).all())
