@@ -180,10 +180,9 @@ class _linear_rows(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bf16 = bf16
-        y = x @ w.t()
         if bias is not None:
-            y += bias.to(y.dtype)
-        return y
+            return torch.addmm(bias.to(w.dtype), x, w.t())   # bias rides the GEMM epilogue (no separate pass over [M, out])
+        return x @ w.t()
 
     @staticmethod
     def backward(ctx, g):
