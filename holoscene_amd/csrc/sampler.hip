@@ -270,6 +270,78 @@ __global__ __launch_bounds__(kWave) void k_sampler_final(const float *__restrict
     if (lane == 0 && z_eik) z_eik[r] = sorted[eik_idx[r]];
 }
 
+
+// ------------------------------------------------------------------------------------ ray setup
+// Camera rays + stratified uniform depths + initial beta in ONE launch (one wave per ray), replacing ~70 ATen launches:
+// rend_util.get_camera_params x2 (utils/rend_util.py:56-125, incl. quirk Q1: the depth-scale rays see twice the pixel
+// offset), UniformSampler.get_z_vals with the cube exit (model/ray_sampler.py:48-83), Lemma-2 beta (:136-140).
+__global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ uv, const float *__restrict__ offset, const float *__restrict__ pose,
+                                                      const float *__restrict__ intr, const float *__restrict__ t_rand, int S, float near,
+                                                      float far_cap, float bound, float eps, float *__restrict__ ray_dirs,
+                                                      float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
+                                                      float *__restrict__ beta_init, int R) {
+    extern __shared__ float lds[];  // [S] stratified depths of this ray
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= R) return;
+    const float fx = intr[0], sk = intr[1], cx = intr[2], fy = intr[5], cy = intr[6];
+    const float ox = offset ? offset[2 * r] : 0.f, oy = offset ? offset[2 * r + 1] : 0.f;
+    const float u = uv[2 * r], v = uv[2 * r + 1];
+    // lift (rend_util.py:112-125) at depth 1, then camera-to-world
+    const float x1 = u + ox, y1 = v + oy;
+    const float xl = (x1 - cx + cy * sk / fy - sk * y1 / fy) / fx, yl = (y1 - cy) / fy;
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = pose[4 * i] * xl + pose[4 * i + 1] * yl + pose[4 * i + 2] + pose[4 * i + 3];
+    const float o[3] = {pose[3], pose[7], pose[11]};
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = w[i] / w[3] - o[i];
+    const float dn = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] /= dn;
+    // depth scale: z component of the normalised camera-frame ray, with 2x the offset in training (quirk Q1)
+    const float x2 = u + 2.f * ox, y2 = v + 2.f * oy;
+    const float xl2 = (x2 - cx + cy * sk / fy - sk * y2 / fy) / fx, yl2 = (y2 - cy) / fy;
+    const float ds = 1.f / fmaxf(sqrtf(xl2 * xl2 + yl2 * yl2 + 1.f), 1e-12f);
+    // exit from the cube [-bound, bound]^3 (ray_sampler.py:48-60), capped at far_cap
+    float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float a = (-bound - o[i]) / (d[i] + 1e-15f), b = (bound - o[i]) / (d[i] + 1e-15f);
+        tn = fmaxf(tn, fminf(a, b));
+        tf = fminf(tf, fmaxf(a, b));
+    }
+    if (tf < tn) tf = 1e9f;
+    const float far = fminf(tf, far_cap);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { ray_dirs[3 * r + i] = d[i]; cam_loc[3 * r + i] = o[i]; }
+        depth_scale[r] = ds;
+    }
+    // stratified depths
+    const float step = 1.0f / (float)(S - 1);
+    for (int i = lane; i < S; i += kWave) {
+        auto zlin = [&](int k) {
+            const float t = (k < S / 2) ? step * (float)k : 1.0f - step * (float)(S - 1 - k);   // torch.linspace
+            return near * (1.f - t) + far * t;
+        };
+        const float zi = zlin(i);
+        float val = zi;
+        if (t_rand) {
+            const float lower = (i == 0) ? zi : 0.5f * (zi + zlin(i - 1));
+            const float upper = (i == S - 1) ? zi : 0.5f * (zlin(i + 1) + zi);
+            val = lower + (upper - lower) * t_rand[(size_t)r * S + i];
+        }
+        lds[i] = val;
+        z0[(size_t)r * S + i] = val;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int i = lane; i + 1 < S; i += kWave) { const float dd = lds[i + 1] - lds[i]; acc += dd * dd; }
+    acc = wave_sum(acc);
+    if (lane == 0) beta_init[r] = sqrtf((1.0f / (4.0f * logf(eps + 1.0f))) * acc);
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 }  // namespace
@@ -304,6 +376,17 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
     if (n > 4096) return HS_ERR_ARG;
     k_sampler_final<<<dim3(R), dim3(kWave), 2 * n * sizeof(float), (hipStream_t)stream>>>(z_samples, n_s, z, ld, pick, n_extra, near, far, eik_idx,
                                                                                           z_out, z_eik, R);
+    return check_launch();
+}
+
+int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
+                 float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
+                 void *stream) {
+    if (R <= 0) return HS_OK;
+    if (S < 2 || S > 4096) return HS_ERR_ARG;
+    if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
+    k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
+                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R);
     return check_launch();
 }
 

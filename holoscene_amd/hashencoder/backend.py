@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup"]
 
 
 def _check(rc, what):
@@ -174,6 +174,14 @@ class _HipBackend:
         _check(lib.hs_sampler_final(_dev(z_samples, "z_samples"), z_samples.shape[1], _dev(z, "z"), ld, _dev(pick, "pick", torch.int64), n_extra,
                                     ctypes.c_float(near), ctypes.c_float(far), _dev(eik_idx, "eik_idx", torch.int64), _dev(z_out, "z_out"),
                                     _dev(z_eik, "z_eik"), R, _stream()), "hs_sampler_final")
+
+    @staticmethod
+    def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init):
+        lib = load_library()
+        _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
+                                _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
+                                ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
+                                _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], _stream()), "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
     @staticmethod

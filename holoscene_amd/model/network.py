@@ -446,6 +446,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
     def _packed_weights(self):
         """bf16 images of the three weight-normalised matrices in the layout csrc/sdf_mlp.hip reads (rebuilt per call:
         three tiny cast kernels; the weights change every optimiser step)."""
+        if getattr(self, "_packed_cache", None) is not None:
+            return self._packed_cache
         l0, l1, l2 = self._lins()
         dev = l0.weight_v.device
         w0 = torch.zeros(256, 96, device=dev, dtype=torch.bfloat16)
@@ -453,8 +455,13 @@ class ObjectImplicitNetworkGrid(nn.Module):
         n2 = 32 * ((l2.out_features + 31) // 32)
         w2 = torch.zeros(n2, 256, device=dev, dtype=torch.bfloat16)
         w2[:l2.out_features] = l2.weight.to(torch.bfloat16)
-        return (w0, l0.bias.detach().float().contiguous(), l1.weight.to(torch.bfloat16).contiguous(), l1.bias.detach().float().contiguous(),
-                w2, l2.bias.detach().float().contiguous())
+        self._packed_cache = (w0, l0.bias.detach().float().contiguous(), l1.weight.to(torch.bfloat16).contiguous(),
+                              l1.bias.detach().float().contiguous(), w2, l2.bias.detach().float().contiguous())
+        return self._packed_cache
+
+    def invalidate_packed_weights(self):
+        """The packed bf16 images are valid for one parameter state; the sampler drops them at the start of every call."""
+        self._packed_cache = None
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
         """min_k sdf_k (or sdf_select) [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
@@ -695,6 +702,12 @@ class HoloSceneNetwork(nn.Module):
         dev = uv.device
         if self.training:
             ray_offset = rng["ray_offset"] if "ray_offset" in rng else torch.rand_like(uv) - 0.5
+        else:
+            ray_offset = None
+        from . import ray_sampler as _rs
+        if _rs.SAMPLER_IMPL == "hip" and uv.is_cuda and pose.shape[1] != 7 and uv.shape[0] == 1:
+            return self._setup_rays_fused(uv, ray_offset, pose, intrinsics, rng.get("t_rand"))
+        if self.training:
             ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics, ray_offset=ray_offset)
             # quirk Q1: the reference's first call shifted uv in place, so its depth-scale rays carry 2x the offset
             ray_dirs_tmp, _ = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], intrinsics, ray_offset=2 * ray_offset)
@@ -707,8 +720,28 @@ class HoloSceneNetwork(nn.Module):
                 "depth_scale": ray_dirs_tmp[0, :, 2:].contiguous(),
                 "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
 
+    def _setup_rays_fused(self, uv, ray_offset, pose, intrinsics, t_rand=None):
+        """Rays, depth scale, the sampler's first (stratified uniform) depths and its Lemma-2 beta from one kernel
+        (csrc/sampler.hip: k_ray_setup)."""
+        dev = uv.device
+        R = uv.shape[1]
+        sm = self.ray_sampler
+        S = sm.N_samples_eval
+        if self.training and t_rand is None:
+            t_rand = torch.rand(R, S, device=dev)
+        out = {"ray_dirs": torch.empty(R, 3, device=dev), "cam_loc": torch.empty(R, 3, device=dev), "depth_scale": torch.empty(R, 1, device=dev),
+               "z0": torch.empty(R, S, device=dev), "beta_init": torch.empty(R, device=dev),
+               "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
+        _be._backend.ray_setup(uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
+                               pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
+                               None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
+                               float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
+                               out["depth_scale"], out["z0"], out["beta_init"])
+        return out
+
     def sample(self, rays, rng=None, idx=None):
-        return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng)
+        return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng, z0=rays.get("z0"),
+                                           beta_init=rays.get("beta_init"))
 
     def wants_background(self, iter_step):
         return bool(self.use_bg_reg and iter_step % self.render_bg_iter == 0)
@@ -726,13 +759,19 @@ class HoloSceneNetwork(nn.Module):
             xy0 = torch.floor(torch.rand(2, device=dev) * span)
         gy, gx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
         uv0 = (torch.stack([gx, gy], -1).reshape(1, -1, 2).float() + xy0)
-        ray_dirs0, cam_loc0 = rend_util.get_camera_params(uv0, pose, intrinsics)
-        tmp0, _ = rend_util.get_camera_params(uv0, torch.eye(4, device=dev)[None], intrinsics)
-        n0 = ray_dirs0.shape[1]
-        bg = {"ray_dirs": ray_dirs0.reshape(-1, 3).contiguous(),
-              "cam_loc": cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3).contiguous(),
-              "depth_scale": tmp0[0, :, 2:].contiguous()}
-        bg["z_vals"], _ = self.ray_sampler.get_z_vals(bg["ray_dirs"], bg["cam_loc"], self, idx=0, rng=rng.get("bg"))
+        from . import ray_sampler as _rs
+        if _rs.SAMPLER_IMPL == "hip" and uv0.is_cuda and pose.shape[1] != 7:
+            bg = self._setup_rays_fused(uv0, None, pose, intrinsics, (rng.get("bg") or {}).get("t_rand"))
+        else:
+            ray_dirs0, cam_loc0 = rend_util.get_camera_params(uv0, pose, intrinsics)
+            tmp0, _ = rend_util.get_camera_params(uv0, torch.eye(4, device=dev)[None], intrinsics)
+            n0 = ray_dirs0.shape[1]
+            bg = {"ray_dirs": ray_dirs0.reshape(-1, 3).contiguous(),
+                  "cam_loc": cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3).contiguous(),
+                  "depth_scale": tmp0[0, :, 2:].contiguous()}
+        bg["z_vals"], _ = self.ray_sampler.get_z_vals(bg["ray_dirs"], bg["cam_loc"], self, idx=0, rng=rng.get("bg"), z0=bg.pop("z0", None),
+                                                      beta_init=bg.pop("beta_init", None))
+        bg.pop("rot", None)
         return bg
 
     def forward(self, input, indices, iter_step=-1, rng=None):

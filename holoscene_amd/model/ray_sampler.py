@@ -157,14 +157,16 @@ class ErrorBoundSampler(RaySampler):
         return net.get_multi_object_sdf_vals(points, idx)
 
     @torch.no_grad()
-    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None):
+    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None, z0=None, beta_init=None):
+        """z0 / beta_init: optionally the first uniform depths and Lemma-2 beta already produced by the fused ray-setup
+        kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference."""
         if SAMPLER_IMPL == "hip":
-            return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {})
+            return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
         if SAMPLER_IMPL != "torch":
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
         return self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng or {})
 
-    def _get_z_vals_hip(self, ray_dirs, cam_loc, model, idx, rng):
+    def _get_z_vals_hip(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None):
         """Algorithm 1 with the per-ray arithmetic in three fused kernels per round (update / draw / final).
         Per round: 1 SDF sweep, 2 kernel launches, one 4-byte device->host read for the convergence test."""
         if not ray_dirs.is_cuda:
@@ -176,9 +178,14 @@ class ErrorBoundSampler(RaySampler):
         S = self.N_samples_eval
         ld = S * self.max_total_iters
         beta0 = model.density.get_beta().detach().reshape(1).contiguous()
-        z0, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
-        d0 = z0[:, 1:] - z0[:, :-1]
-        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
+        if hasattr(model.implicit_network, "invalidate_packed_weights"):
+            model.implicit_network.invalidate_packed_weights()
+        if z0 is None or beta_init is None:
+            z0, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+            d0 = z0[:, 1:] - z0[:, :-1]
+            beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
+        else:
+            beta = beta_init.clone()
         z = torch.empty(R, ld, device=dev)
         sdf = torch.empty(R, ld, device=dev)
         beta_max = torch.zeros(1, device=dev)

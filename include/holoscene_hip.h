@@ -144,6 +144,14 @@ int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, con
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
                      const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream);
 
+/* Camera rays + first (uniform, stratified) depths + Lemma-2 beta in one launch (utils/rend_util.py:56-125 twice incl. the
+ * 2x-offset depth-scale rays, model/ray_sampler.py:48-83 and :136-140).  uv [R,2] pixels; ray_offset [R,2] or NULL; pose,
+ * intrinsics: DEVICE 4x4 row-major; t_rand [R,S] or NULL (= no stratified jitter, eval mode).
+ * Outputs: ray_dirs [R,3], cam_loc [R,3], depth_scale [R], z0 [R,S], beta_init [R]. */
+int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
+                 float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
+                 void *stream);
+
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
  * A, out, G, gA: [B, rows, W], storage type `dtype` = HS_F32 or HS_BF16 (arithmetic is fp32 either way; bias and

@@ -430,3 +430,28 @@ def test_dense_sdf_volume_fused_vs_fp32():
     assert torch.allclose(sh.min(-1)[0], mn.squeeze(-1), atol=1e-6)           # the minimal object keeps its value
     srt = torch.sort(sh[inside], -1)[0]
     assert bool((srt[:, 1] >= -srt[:, 0] - 1e-6).all())                       # every other object pushed outside it
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_ray_setup_vs_torch_formulation(train):
+    """k_ray_setup vs rend_util.get_camera_params (x2, with the 2x-offset depth-scale rays) + UniformSampler + Lemma-2 beta."""
+    from holoscene_amd.utils import rend_util
+    rec = load("iter_k5")
+    model = build_model(rec, DEV).train(train)
+    ins = _dev(section(rec, "in."))
+    g = torch.Generator().manual_seed(9)
+    R = ins["uv"].shape[1]
+    S = model.ray_sampler.N_samples_eval
+    off = (torch.rand(1, R, 2, generator=g) - 0.5).to(DEV) if train else None
+    t_rand = torch.rand(R, S, generator=g).to(DEV) if train else None
+    fused = model._setup_rays_fused(ins["uv"], off, ins["pose"], ins["intrinsics"], t_rand)
+    dirs, loc = rend_util.get_camera_params(ins["uv"], ins["pose"], ins["intrinsics"], ray_offset=off)
+    tmp, _ = rend_util.get_camera_params(ins["uv"], torch.eye(4, device=DEV)[None], ins["intrinsics"], ray_offset=None if off is None else 2 * off)
+    close(fused["ray_dirs"], dirs[0], 1e-5, 1e-6, "ray_dirs")
+    close(fused["cam_loc"], loc.expand(R, 3), 0, 0, "cam_loc")
+    close(fused["depth_scale"], tmp[0, :, 2:], 1e-5, 1e-6, "depth_scale")
+    z_ref, _, _ = model.ray_sampler.uniform_sampler.get_z_vals(dirs[0], loc.expand(R, 3).contiguous(), model, t_rand=t_rand)
+    close(fused["z0"], z_ref, 1e-5, 1e-6, "z0")
+    d0 = z_ref[:, 1:] - z_ref[:, :-1]
+    beta_ref = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(model.ray_sampler.eps + 1.0)))) * (d0 ** 2).sum(-1))
+    close(fused["beta_init"], beta_ref, 1e-5, 1e-7, "beta_init")
