@@ -38,13 +38,17 @@ template <> struct IO<__hip_bfloat16> {
 template <class T>
 __global__ __launch_bounds__(kThreads) void k_trunk_input_fwd(const float *__restrict__ x, const float *__restrict__ feat,
                                                                const float *__restrict__ dydx, T *__restrict__ out, int64_t B, int nf, int L, int C,
-                                                               float jac_scale) {
-    const int P = 3 + 6 * nf, LC = L * C, F = P + LC;
+                                                               float jac_scale, int pitch) {
+    const int P = 3 + 6 * nf, LC = L * C, F = pitch;   // columns >= P+LC (row padding for aligned MFMA operands) are zero-filled
     const int64_t total = B * F;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         const int64_t b = i / F;
         const int c = (int)(i - b * F);
         T *o = out + b * 4 * F + c;
+        if (c >= P + LC) {
+            IO<T>::st(o, 0.f); IO<T>::st(o + F, 0.f); IO<T>::st(o + 2 * F, 0.f); IO<T>::st(o + 3 * F, 0.f);
+            continue;
+        }
         float v0, t[3] = {0.f, 0.f, 0.f};
         if (c < 3) {
             v0 = x[b * 3 + c];
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(kThreads) void k_trunk_input_fwd(const float *__res
 
 template <class T>
 __global__ __launch_bounds__(kThreads) void k_trunk_input_bwd(const T *__restrict__ G, float *__restrict__ g_feat, float *__restrict__ g_dydx,
-                                                               int64_t B, int nf, int L, int C, float jac_scale) {
-    const int P = 3 + 6 * nf, LC = L * C, F = P + LC;
+                                                               int64_t B, int nf, int L, int C, float jac_scale, int pitch) {
+    const int P = 3 + 6 * nf, LC = L * C, F = pitch;
     const int64_t total = B * LC;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         const int64_t b = i / LC;
@@ -153,26 +157,26 @@ int grid_for(int64_t total) {
 extern "C" {
 
 int hs_trunk_input_fwd(const float *x, const float *feat, const float *dydx, void *out, int64_t B, int32_t nfreq, int32_t L, int32_t C,
-                       float jac_scale, int32_t dtype, void *stream) {
-    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+                       float jac_scale, int32_t pitch, int32_t dtype, void *stream) {
+    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || pitch < 3 + 6 * nfreq + L * C || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!x || !feat || !dydx || !out) return HS_ERR_NULL;
-    const int64_t total = B * (3 + 6 * nfreq + L * C);
+    const int64_t total = B * pitch;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HS_F32) k_trunk_input_fwd<float><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (float *)out, B, nfreq, L, C, jac_scale);
-    else k_trunk_input_fwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (__hip_bfloat16 *)out, B, nfreq, L, C, jac_scale);
+    if (dtype == HS_F32) k_trunk_input_fwd<float><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (float *)out, B, nfreq, L, C, jac_scale, pitch);
+    else k_trunk_input_fwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>(x, feat, dydx, (__hip_bfloat16 *)out, B, nfreq, L, C, jac_scale, pitch);
     return check_launch();
 }
 
-int hs_trunk_input_bwd(const void *G, float *g_feat, float *g_dydx, int64_t B, int32_t nfreq, int32_t L, int32_t C, float jac_scale, int32_t dtype,
-                       void *stream) {
-    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+int hs_trunk_input_bwd(const void *G, float *g_feat, float *g_dydx, int64_t B, int32_t nfreq, int32_t L, int32_t C, float jac_scale, int32_t pitch,
+                       int32_t dtype, void *stream) {
+    if (nfreq < 0 || nfreq > 16 || L < 1 || C < 1 || pitch < 3 + 6 * nfreq + L * C || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!G || !g_feat || !g_dydx) return HS_ERR_NULL;
     const int64_t total = B * L * C;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HS_F32) k_trunk_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale);
-    else k_trunk_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale);
+    if (dtype == HS_F32) k_trunk_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale, pitch);
+    else k_trunk_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, g_feat, g_dydx, B, nfreq, L, C, jac_scale, pitch);
     return check_launch();
 }
 

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(kThreads) void k_softplus_tangent_fwd(const T *__re
 }
 
 // grid: ceil(B / kPointsPerBlock) blocks; thread = (point slot tid / quads_per_pass ..., quad)
-template <int ROWS, class T>
+// FROM_H: `A` holds the layer's OUTPUT instead (value row h = softplus100(v), tangent rows s*A_d) -- what the fused
+// matrix-core trunk keeps (sdf_mlp.hip, k_trunk_fwd).  Then s = 1 - exp(-100 h) and s' * A_d = 100 (1-s) * H_d, so the
+// pre-activations are never needed (and never stored).
+template <int ROWS, class T, bool FROM_H = false>
 __global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const T *__restrict__ A, const float *__restrict__ bias,
                                                                     const T *__restrict__ G, T *__restrict__ gA,
                                                                     float *__restrict__ gbias, int64_t B, int W) {
@@ -107,13 +110,23 @@ __global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const T *__re
     for (int64_t i = threadIdx.x; i < work; i += kThreads) {
         const int64_t b = b0 + i / quads;
         const int q = (int)(i % quads);
-        const float4 bi = reinterpret_cast<const float4 *>(bias)[q];
         const T *a = A + b * ROWS * W + 4 * q;
         const T *g = G + b * ROWS * W + 4 * q;
         T *o = gA + b * ROWS * W + 4 * q;
         float4 v = Quad<T>::load(a);
-        v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
-        const float4 s = make_float4(softplus100_pair(v.x).ds, softplus100_pair(v.y).ds, softplus100_pair(v.z).ds, softplus100_pair(v.w).ds);
+        float4 s, c;   // s = sigmoid(100 v); c = the factor of sum_d A_d g_d in the value-row gradient
+        if (FROM_H) {
+            const float k = -100.f * 1.44269504f;
+            const float4 e = make_float4(__builtin_amdgcn_exp2f(v.x * k), __builtin_amdgcn_exp2f(v.y * k), __builtin_amdgcn_exp2f(v.z * k),
+                                         __builtin_amdgcn_exp2f(v.w * k));
+            s = make_float4(1.f - e.x, 1.f - e.y, 1.f - e.z, 1.f - e.w);
+            c = make_float4(100.f * e.x, 100.f * e.y, 100.f * e.z, 100.f * e.w);
+        } else {
+            const float4 bi = reinterpret_cast<const float4 *>(bias)[q];
+            v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+            s = make_float4(softplus100_pair(v.x).ds, softplus100_pair(v.y).ds, softplus100_pair(v.z).ds, softplus100_pair(v.w).ds);
+            c = make_float4(100.f * s.x * (1.f - s.x), 100.f * s.y * (1.f - s.y), 100.f * s.z * (1.f - s.z), 100.f * s.w * (1.f - s.w));
+        }
         const float4 g0 = Quad<T>::load(g);
         float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -123,10 +136,10 @@ __global__ __launch_bounds__(kThreads) void k_softplus_tangent_bwd(const T *__re
             Quad<T>::store(o + (size_t)r * W, make_float4(s.x * gr.x, s.y * gr.y, s.z * gr.z, s.w * gr.w));
         }
         float4 r0;
-        r0.x = s.x * g0.x + 100.f * s.x * (1.f - s.x) * dot.x;
-        r0.y = s.y * g0.y + 100.f * s.y * (1.f - s.y) * dot.y;
-        r0.z = s.z * g0.z + 100.f * s.z * (1.f - s.z) * dot.z;
-        r0.w = s.w * g0.w + 100.f * s.w * (1.f - s.w) * dot.w;
+        r0.x = s.x * g0.x + c.x * dot.x;
+        r0.y = s.y * g0.y + c.y * dot.y;
+        r0.z = s.z * g0.z + c.z * dot.z;
+        r0.w = s.w * g0.w + c.w * dot.w;
         Quad<T>::store(o, r0);
         if (kThreads % quads == 0) {
             acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
@@ -171,6 +184,10 @@ template <class T>
 int launch_bwd(const T *A, const float *bias, const T *G, T *gA, float *gbias, int64_t B, int rows, int W, hipStream_t st) {
     const int grid = (int)((B + kPointsPerBlock - 1) / kPointsPerBlock);
     const size_t lds = kThreads * 4 * sizeof(float);
+    if (!bias) {  // activations-only form (rows == 4, checked by the caller)
+        k_softplus_tangent_bwd<4, T, true><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W);
+        return check_launch();
+    }
     switch (rows) {
         case 1: k_softplus_tangent_bwd<1, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
         case 2: k_softplus_tangent_bwd<2, T><<<grid, kThreads, lds, st>>>(A, bias, G, gA, gbias, B, W); break;
@@ -199,6 +216,15 @@ int hs_softplus_tangent_bwd(const void *A, const float *bias, const void *G, voi
     if (!A || !bias || !G || !gA) return HS_ERR_NULL;
     if (dtype == HS_F32) return launch_bwd<float>((const float *)A, bias, (const float *)G, (float *)gA, gbias, B, rows, W, (hipStream_t)stream);
     return launch_bwd<__hip_bfloat16>((const __hip_bfloat16 *)A, bias, (const __hip_bfloat16 *)G, (__hip_bfloat16 *)gA, gbias, B, rows, W,
+                                      (hipStream_t)stream);
+}
+
+int hs_softplus_tangent_bwd_h(const void *H, const void *G, void *gA, float *gbias, int64_t B, int32_t W, int32_t dtype, void *stream) {
+    if (W <= 0 || (W & 3) || (dtype != HS_F32 && dtype != HS_BF16)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!H || !G || !gA) return HS_ERR_NULL;
+    if (dtype == HS_F32) return launch_bwd<float>((const float *)H, nullptr, (const float *)G, (float *)gA, gbias, B, 4, W, (hipStream_t)stream);
+    return launch_bwd<__hip_bfloat16>((const __hip_bfloat16 *)H, nullptr, (const __hip_bfloat16 *)G, (__hip_bfloat16 *)gA, gbias, B, 4, W,
                                       (hipStream_t)stream);
 }
 

@@ -269,6 +269,130 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Training trunk: the same three layers over value+Jacobian rows (4 rows per point: value, d/dx, d/dy, d/dz -- DESIGN
+// V1), keeping what the backward pass needs.  Row r of a tile is row type r & 3; the accumulator layout puts the four
+// rows of one point in the four lanes of one DPP quad, so the tangent rule  out_d = sigmoid(100 v) * acc_d  is a
+// quad broadcast of the value lane's sigmoid -- no LDS round trip.
+//   X  [M][K0] bf16 (k_trunk_input, zero-padded columns)      H0, H1 [M][256] bf16 = layer OUTPUTS (value row: softplus,
+//   tangent rows: s * pre-activation; hs_softplus_tangent_bwd_h consumes exactly that)     Y [M][d_out] fp32
+__device__ __forceinline__ float quad_bcast0(float v) {  // value held by lane (lane & ~3) of each quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float tangent_act(float acc, float bias, bool is_value) {
+    const float v = acc + bias;
+    const float t = v * 100.f;
+    const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
+    const float one_e = 1.f + e;
+    const bool lin = t > 20.f;
+    const float sp = lin ? v : __builtin_amdgcn_logf(one_e) * (0.69314718f * 0.01f);
+    const float ds = lin ? 1.f : e * __builtin_amdgcn_rcpf(one_e);
+    const float s = quad_bcast0(ds);   // tangent lanes computed garbage of their own; they take the value lane's
+    return is_value ? sp : s * acc;
+}
+
+__device__ __forceinline__ void epilogue_tangent(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+    const bool is_value = (lane & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);
+            const float4 bi = *reinterpret_cast<const float4 *>(bias_lds + n0);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const int p = ph * 64 + pt * 32 + (lane & 31);
+                const float v0 = tangent_act(acc[nt][pt][q * 4 + 0], bi.x, is_value), v1 = tangent_act(acc[nt][pt][q * 4 + 1], bi.y, is_value);
+                const float v2 = tangent_act(acc[nt][pt][q * 4 + 2], bi.z, is_value), v3 = tangent_act(acc[nt][pt][q * 4 + 3], bi.w, is_value);
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
+            }
+        }
+    }
+}
+
+// activation tile -> global, 16 B per lane, rows contiguous (coalesced 512 B per row)
+__device__ __forceinline__ void store_tile(const uint16_t *H, uint16_t *__restrict__ dst, int64_t r0, int64_t M) {
+    for (int idx = threadIdx.x; idx < BM * (HID / 8); idx += kThreads) {
+        const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
+        if (r0 + row < M) *reinterpret_cast<uint4 *>(dst + (size_t)(r0 + row) * HID + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+    }
+}
+
+template <int NOUT_TILES>
+__global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W0, const float *__restrict__ b0,
+                                                         const uint16_t *__restrict__ W1, const float *__restrict__ b1,
+                                                         const uint16_t *__restrict__ W2, const float *__restrict__ b2, int d_out,
+                                                         uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *H = lds;
+    uint16_t *Wc = lds + (size_t)BM * HP;
+    float *bias = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = wave & 3, ph = wave >> 2;
+    if (threadIdx.x < HID) { bias[threadIdx.x] = b0[threadIdx.x]; bias[HID + threadIdx.x] = b1[threadIdx.x]; }
+    if (threadIdx.x < 64) bias[2 * HID + threadIdx.x] = (int)threadIdx.x < d_out ? b2[threadIdx.x] : 0.f;
+    const int64_t ntiles = (M + BM - 1) / BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int64_t r0 = tile * BM;
+        for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {
+            const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r0 + row < M) v = *reinterpret_cast<const uint4 *>(X + (size_t)(r0 + row) * K0 + seg * 8);
+            *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        layer_mma(W0, K0, K0, H, Wc, acc, nq, ph, lane);
+        epilogue_tangent(bias, H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, H0, r0, M);   // reads of H; the next epilogue's writes sit behind layer_mma's barriers
+        zero_acc(acc);
+        layer_mma(W1, HID, HID, H, Wc, acc, nq, ph, lane);
+        epilogue_tangent(bias + HID, H, acc, nq, ph, lane);
+        for (int idx = threadIdx.x; idx < 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
+            const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
+            *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
+        }
+        __syncthreads();
+        store_tile(H, H1, r0, M);
+        if (wave < 4) {
+            f32x16 y[NOUT_TILES];
+#pragma unroll
+            for (int t = 0; t < NOUT_TILES; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) y[t][i] = 0.f;
+            const int prow = wave * 32 + (lane & 31);
+#pragma unroll 4
+            for (int ks = 0; ks < HID / 16; ks++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(H + (size_t)prow * HP + ks * 16 + (lane >> 5) * 8);
+#pragma unroll
+                for (int t = 0; t < NOUT_TILES; t++) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(t * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
+                    y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[t], 0, 0, 0);
+                }
+            }
+            const int64_t gr = r0 + prow;
+            const bool is_value = (lane & 3) == 0;
+            if (gr < M) {
+#pragma unroll
+                for (int t = 0; t < NOUT_TILES; t++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int n = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                        if (n < d_out) Y[gr * d_out + n] = y[t][i] + (is_value ? bias[2 * HID + n] : 0.f);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 }  // namespace
@@ -294,6 +418,29 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
                                                    out_min, out_raw, B);
+    }
+    return check_launch();
+}
+
+int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2, const float *b2,
+                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, void *stream) {
+    if (d_out < 1 || d_out > 64 || (M & 3)) return HS_ERR_ARG;
+    if (M == 0) return HS_OK;
+    if (!X || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !H0 || !H1 || !Y) return HS_ERR_NULL;
+    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
+    const int64_t ntiles = (M + BM - 1) / BM;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d_out <= 32) {
+        static bool attr1 = false;
+        if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        k_trunk_fwd<1><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
+                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+        k_trunk_fwd<2><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
+                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M);
     }
     return check_launch();
 }

@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup"]
 
 
 def _check(rc, what):
@@ -247,20 +247,36 @@ class _HipBackend:
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                   ctypes.c_int64(x.shape[0]), _stream()), "hs_sdf_mlp_fwd")
 
+    @staticmethod
+    def trunk_mlp_fwd(X, W0, b0, W1, b1, W2, b2, d_out, H0, H1, Y):
+        lib = load_library()
+        bf = torch.bfloat16
+        _check(lib.hs_trunk_mlp_fwd(_dev(X, "X", bf), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"), _dev(W2, "W2", bf),
+                                    _dev(b2, "b2"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y"), ctypes.c_int64(Y.shape[0]),
+                                    _stream()), "hs_trunk_mlp_fwd")
+
+    @staticmethod
+    def softplus_tangent_bwd_h(H, G, gA, gbias):
+        """H, G, gA: [4*points, W] rows grouped by point (value, d/dx, d/dy, d/dz)."""
+        lib = load_library()
+        dt = H.dtype
+        _check(lib.hs_softplus_tangent_bwd_h(_dev(H, "H", dt), _dev(G, "G", dt), _dev(gA, "gA", dt), _dev(gbias, "gbias"),
+                                             ctypes.c_int64(H.shape[0] // 4), H.shape[-1], _DTYPES[dt], _stream()), "hs_softplus_tangent_bwd_h")
+
     # ---- fused network-input builders (include/holoscene_hip.h section 8)
     @staticmethod
     def trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, jac_scale):
         lib = load_library()
         dt = out.dtype
         _check(lib.hs_trunk_input_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(out, "out", dt), ctypes.c_int64(x.shape[0]),
-                                      nfreq, L, C, ctypes.c_float(jac_scale), _DTYPES[dt], _stream()), "hs_trunk_input_fwd")
+                                      nfreq, L, C, ctypes.c_float(jac_scale), out.shape[-1], _DTYPES[dt], _stream()), "hs_trunk_input_fwd")
 
     @staticmethod
     def trunk_input_bwd(G, g_feat, g_dydx, nfreq, L, C, jac_scale):
         lib = load_library()
         dt = G.dtype
         _check(lib.hs_trunk_input_bwd(_dev(G, "G", dt), _dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), ctypes.c_int64(G.shape[0]), nfreq, L, C,
-                                      ctypes.c_float(jac_scale), _DTYPES[dt], _stream()), "hs_trunk_input_bwd")
+                                      ctypes.c_float(jac_scale), G.shape[-1], _DTYPES[dt], _stream()), "hs_trunk_input_bwd")
 
     @staticmethod
     def render_input_fwd(points, dirs, normals, fv, out, nfreq):

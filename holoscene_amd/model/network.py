@@ -125,6 +125,99 @@ class _trunk_input(torch.autograd.Function):
         return None, g_emb, None, None, None, None, None, None
 
 
+# "mfma": the bf16 trunk forward runs in ONE matrix-core kernel (csrc/sdf_mlp.hip, k_trunk_fwd) when the layer shapes are the
+# stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
+TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
+_TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+
+
+def _wgrad_rows(g, x):
+    """g^T @ x over M rows as a split-M batched GEMM (see _linear_rows) -> fp32 [g.shape[1], x.shape[1]]."""
+    M = x.shape[0]
+    S = _split_rows(M)
+    if S > 1:
+        return torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
+    return (g.t() @ x).float()
+
+
+class _fused_trunk(torch.autograd.Function):
+    """x [B,3] (constant), hash table, the three effective weight matrices and biases -> y [B,K] f32, J [B,K,3] f32.
+
+    forward: hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd (3 layers on the matrix cores, activations never
+    leave the CU between layers; the layer outputs H0, H1 are written once for the backward).
+    backward: library GEMMs for the data/weight gradients, hs_softplus_tangent_bwd_h between them (works from H, so
+    the pre-activations are never stored), then the fused value+Jacobian scatter into the table gradient."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        x = x.contiguous()
+        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+        B, D = x01.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        dev, bf = x.device, torch.bfloat16
+        feat = torch.empty(B, L * C, device=dev, dtype=x.dtype)
+        dydx = torch.empty(L, B, D * C, device=dev, dtype=x.dtype)
+        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
+        jac_scale = 0.5 / divide_factor
+        X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
+        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
+        F_in, d_out = W0.shape[1], W2.shape[0]
+        w0 = torch.zeros(256, _TRUNK_PITCH, device=dev, dtype=bf)
+        w0[:, :F_in] = W0
+        w1 = W1.to(bf).contiguous()
+        w2 = torch.zeros(32 * ((d_out + 31) // 32), 256, device=dev, dtype=bf)
+        w2[:d_out] = W2
+        M = 4 * B
+        H0 = torch.empty(M, 256, device=dev, dtype=bf)
+        H1 = torch.empty(M, 256, device=dev, dtype=bf)
+        Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
+        _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
+                                   b2.detach().float().contiguous(), d_out, H0, H1, Y)
+        ctx.save_for_backward(x01, embeddings, offsets, X, H0, H1, w0, w1, w2)
+        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
+        Y = Y.view(B, 4, d_out)
+        return Y[:, 0].contiguous(), Y[:, 1:].transpose(1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy, gJ):
+        x01, embeddings, offsets, X, H0, H1, w0, w1, w2 = ctx.saved_tensors
+        B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
+        dev, bf = X.device, torch.bfloat16
+        M = 4 * B
+        if gy is None:
+            gy = torch.zeros(B, d_out, device=dev)
+        if gJ is None:
+            gJ = torch.zeros(B, d_out, 3, device=dev)
+        g = torch.cat([gy.unsqueeze(1), gJ.transpose(1, 2)], 1).to(bf).view(M, d_out)
+        need_w = ctx.needs_input_grad[7]
+        gW2 = _wgrad_rows(g, H1) if need_w else None
+        gb2 = gy.sum(0) if ctx.needs_input_grad[12] else None
+        G = g @ w2[:d_out]
+        gA1 = torch.empty_like(G)
+        gb1 = torch.zeros(256, device=dev)
+        _be._backend.softplus_tangent_bwd_h(H1, G, gA1, gb1)
+        gW1 = _wgrad_rows(gA1, H0) if need_w else None
+        G = gA1 @ w1
+        gA0 = torch.empty_like(G)
+        gb0 = torch.zeros(256, device=dev)
+        _be._backend.softplus_tangent_bwd_h(H0, G, gA0, gb0)
+        gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
+        g_emb = None
+        if ctx.needs_input_grad[1]:
+            gX = (gA0 @ w0).view(B, 4, _TRUNK_PITCH)
+            g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
+            g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
+            _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
+            table = ctx.table
+            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
+            g_emb = None if inplace else target
+        return None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
+
+
 class _render_input(torch.autograd.Function):
     """[posenc(points), posenc(view_dirs), posenc(normals), feature_vectors] in one kernel; the backward returns
     the gradients of the two differentiable inputs (normals, feature_vectors)."""
@@ -436,12 +529,15 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return h
 
     # ---------------------------------------------------------------- fused matrix-core inference (bf16 mode)
-    def _fused_sdf_supported(self, x):
+    def _fused_trunk_supported(self, x):
         lins = self._lins()
-        return (self.mlp_bf16 and x.is_cuda and not torch.is_grad_enabled() and len(lins) == 3 and self.embedder is not None
+        return (self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None
                 and self.embedder.multires == 6 and self.grid_feature_dim == 32 and lins[0].out_features == 256
                 and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features <= 64
                 and not any(l in self.skip_in for l in range(3)))
+
+    def _fused_sdf_supported(self, x):
+        return not torch.is_grad_enabled() and self._fused_trunk_supported(x)
 
     def _packed_weights(self):
         """bf16 images of the three weight-normalised matrices in the layout csrc/sdf_mlp.hip reads (rebuilt per call:
@@ -483,6 +579,11 @@ class ObjectImplicitNetworkGrid(nn.Module):
         on all rows alike (one GEMM with M = 4B); Softplus becomes the fused `softplus_tangent` stage."""
         x = x.detach()
         enc = self.encoding
+        if TRUNK_IMPL == "mfma" and self._fused_trunk_supported(x):
+            l0, l1, l2 = self._lins()
+            return _fused_trunk.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                                      self.embedder.multires, float(self.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias,
+                                      l2.weight, l2.bias)
         inp = _trunk_input.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                                  self.embedder.multires if self.embedder is not None else 0, float(self.divide_factor),
                                  torch.bfloat16 if self.mlp_bf16 else torch.float32)                      # [B,4,F]

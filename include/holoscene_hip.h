@@ -161,6 +161,8 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
 int hs_softplus_tangent_fwd(const void *A, const float *bias, void *out, int64_t B, int32_t rows, int32_t W, int32_t dtype, void *stream);
 int hs_softplus_tangent_bwd(const void *A, const float *bias, const void *G, void *gA, float *gbias, int64_t B, int32_t rows, int32_t W,
                             int32_t dtype, void *stream);
+/* Same backward from the layer OUTPUT H (as hs_trunk_mlp_fwd keeps it) instead of the pre-activation: 4 rows per point. */
+int hs_softplus_tangent_bwd_h(const void *H, const void *G, void *gA, float *gbias, int64_t B, int32_t W, int32_t dtype, void *stream);
 
 /* ------------------------------------------------------------------ 5. fused dense Adam over a flat parameter buffer
  *
@@ -213,21 +215,31 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
                    const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, void *stream);
 
+/* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
+ * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).
+ *   X  [M, 96] bf16: hs_trunk_input_fwd output with pitch 96 (M = 4 * points, M % 4 == 0)
+ *   W0 [256, 96], W1 [256, 256], W2 [32*ceil(d_out/32), 256] bf16 (zero-padded), biases fp32
+ *   H0, H1 [M, 256] bf16: layer outputs kept for the backward pass (value rows softplus100(v), tangent rows
+ *   sigmoid(100 v) * pre-activation);   Y [M, d_out] fp32 (b2 added on value rows only). */
+int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2, const float *b2,
+                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
  * (model/network.py:181-185, 586-596) in one pass.  `dtype` (HS_F32/HS_BF16) is the storage type of out/G/feature_vectors.
  *
- * trunk input:  out [B,4,F], F = 3+6*nfreq+L*C.  Row 0 = [posenc(x), feat]; row 1+d = its derivative w.r.t. x_d, the hash
+ * trunk input:  out [B,4,pitch], pitch >= F = 3+6*nfreq+L*C (columns >= F are zero: row padding for aligned matrix-core
+ *   operands).  Row 0 = [posenc(x), feat]; row 1+d = its derivative w.r.t. x_d, the hash
  *   part being jac_scale * dydx[l,b,d*C+c] (dydx level-major [L,B,3*C] as written by hs_hash_fwd).
  *   backward (x is a constant): g_feat [B,L*C] = G[b,0,P:], g_dydx [L,B,3*C] = jac_scale * G[b,1+d,P+l*C+c]  -- both f32, in
  *   the layouts hs_hash_bwd_jac consumes.
  * render input: out [B, 3*(3+6*nfreq)+Fv] = [posenc(points), posenc(view_dirs), posenc(normals), feature_vectors];
  *   backward: d_normals [B,3] f32, d_feature_vectors [B,Fv] (dtype). */
 int hs_trunk_input_fwd(const float *x, const float *feat, const float *dydx, void *out, int64_t B, int32_t nfreq, int32_t L, int32_t C,
-                       float jac_scale, int32_t dtype, void *stream);
-int hs_trunk_input_bwd(const void *G, float *g_feat, float *g_dydx, int64_t B, int32_t nfreq, int32_t L, int32_t C, float jac_scale, int32_t dtype,
-                       void *stream);
+                       float jac_scale, int32_t pitch, int32_t dtype, void *stream);
+int hs_trunk_input_bwd(const void *G, float *g_feat, float *g_dydx, int64_t B, int32_t nfreq, int32_t L, int32_t C, float jac_scale, int32_t pitch,
+                       int32_t dtype, void *stream);
 int hs_render_input_fwd(const float *points, const float *view_dirs, const float *normals, const void *feature_vectors, void *out, int64_t B,
                         int32_t nfreq, int32_t Fv, int32_t dtype, void *stream);
 int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, void *d_feature_vectors, int64_t B, int32_t nfreq, int32_t Fv,

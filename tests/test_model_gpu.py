@@ -455,3 +455,44 @@ def test_fused_ray_setup_vs_torch_formulation(train):
     d0 = z_ref[:, 1:] - z_ref[:, :-1]
     beta_ref = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(model.ray_sampler.eps + 1.0)))) * (d0 ** 2).sum(-1))
     close(fused["beta_init"], beta_ref, 1e-5, 1e-7, "beta_init")
+
+
+@pytest.mark.parametrize("d_out,B", [(32, 25088), (5, 1000), (21, 37)])
+def test_fused_mfma_training_trunk_vs_gemm_path(d_out, B, monkeypatch):
+    """k_trunk_fwd + the H-based backward vs (a) the library-GEMM bf16 trunk and (b) the fp32 trunk, same weights:
+    values, Jacobians and the gradients of every parameter.  Tolerances: bf16 operand rounding -- 1e-2 of the scale
+    of each quantity against fp32; the two bf16 paths round at different places, so they get the same bound."""
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+    x = (torch.rand(B, 3, device=DEV) * 2.4 - 1.2)
+    cy, cJ = torch.randn(B, d_out, device=DEV), torch.randn(B, d_out, 3, device=DEV)
+    params = [net.encoding.embeddings] + [p for l in net._lins() for p in (l.weight_v, l.weight_g, l.bias)]
+    names = ["table"] + [f"lin{i}.{n}" for i in range(3) for n in ("v", "g", "bias")]
+
+    def run(prec, impl):
+        net.set_mlp_precision(prec)
+        monkeypatch.setattr(N, "TRUNK_IMPL", impl)
+        y, J = net.sdf_and_jacobian(x)
+        gr = torch.autograd.grad((y * cy).sum() + (J * cJ).sum(), params)
+        return y.detach(), J.detach(), [g.float() for g in gr]
+
+    ref = run("fp32", "gemm")
+    gem = run("bf16", "gemm")
+    assert net._fused_trunk_supported(x)
+    got = run("bf16", "mfma")
+    def errs(a, b):
+        return float((a - b).abs().max()), float(b.abs().max()), float((a - b).norm() / (b.norm() + 1e-20))
+
+    flat = lambda r: [r[0], r[1]] + r[2]  # noqa: E731
+    for a, g, b, n in zip(flat(got), flat(gem), flat(ref), ["y", "J"] + names):
+        err, scale, rel = errs(a, b)
+        gerr, _, grel = errs(g, b)
+        print(f"{n:10s} mfma-vs-fp32 max {err:.3e} (scale {scale:.3e}) rel_l2 {rel:.3e} | gemm-bf16-vs-fp32 max {gerr:.3e} rel_l2 {grel:.3e}")
+        # the fused path may not be worse than the established bf16 path by more than 2x, and both stay within 2e-2 of scale
+        assert err <= 2e-2 * scale + 1e-6 and rel < 2e-2, (n, err, scale, rel)
+        assert rel <= 2.0 * grel + 1e-3, (n, rel, grel)
