@@ -393,6 +393,132 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward data path of the training trunk: cotangent of the outputs -> cotangents of both hidden pre-activations,
+// one kernel.  Per 128-row tile:   G1 = g . W2        (matrix cores, K = padded d_out)
+//                                  gA1 = softplus-tangent backward of G1 at H1     (epilogue, in LDS)    -> global
+//                                  G0 = gA1 . W1 ;  gA0 = ... at H0                                       -> global
+// The library path needs 2 GEMM launches + 2 elementwise launches and moves 2.2 GB for this (DESIGN); here every
+// operand is read once and every result written once (0.9 GB).  Weight operands arrive TRANSPOSED ([in][out] row-major),
+// so the same D = W . H^T machinery applies.  The value-row rule  gA_v = s*g_v + 100(1-s) * sum_d H_d*g_d  needs the three
+// tangent lanes of the quad: two DPP quad_perm adds.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+
+struct TileRegs { uint4 v[BM * (HID / 8) / kThreads]; };   // one [BM][HID] bf16 tile spread over the workgroup (8 x 16 B per thread)
+
+__device__ __forceinline__ TileRegs load_tile_regs(const uint16_t *__restrict__ src, int64_t r0, int64_t M) {
+    TileRegs t;
+#pragma unroll
+    for (int i = 0; i < BM * (HID / 8) / kThreads; i++) {
+        const int idx = threadIdx.x + i * kThreads, row = idx / (HID / 8), seg = idx - row * (HID / 8);
+        t.v[i] = r0 + row < M ? *reinterpret_cast<const uint4 *>(src + (size_t)(r0 + row) * HID + seg * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    return t;
+}
+
+__device__ __forceinline__ void store_tile_regs(uint16_t *H, const TileRegs &t) {
+#pragma unroll
+    for (int i = 0; i < BM * (HID / 8) / kThreads; i++) {
+        const int idx = threadIdx.x + i * kThreads, row = idx / (HID / 8), seg = idx - row * (HID / 8);
+        *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = t.v[i];
+    }
+}
+
+__device__ __forceinline__ float bwd_act(float G, float h, bool is_value) {
+    const float e = __builtin_amdgcn_exp2f(h * (-100.f * 1.44269504f));   // value lanes: 1 - sigmoid(100 v), from h = softplus100(v)
+    const float s = quad_bcast0(1.f - e), c = quad_bcast0(100.f * e);
+    const float prod = is_value ? 0.f : h * G;
+    const float d1 = prod + dpp_quad<0xB1>(prod);     // quad_perm [1,0,3,2]
+    const float dot = d1 + dpp_quad<0x4E>(d1);        // quad_perm [2,3,0,1]
+    return is_value ? s * G + c * dot : s * G;
+}
+
+// H holds the layer-output tile on entry and the pre-activation cotangent tile on exit (same element, same lane: in place)
+__device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+    const bool is_value = (lane & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const int p = ph * 64 + pt * 32 + (lane & 31);
+                uint2 *cell = reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0);
+                const uint2 hv = *cell;
+                const float v0 = bwd_act(acc[nt][pt][q * 4 + 0], __uint_as_float(hv.x << 16), is_value);
+                const float v1 = bwd_act(acc[nt][pt][q * 4 + 1], __uint_as_float(hv.x & 0xffff0000u), is_value);
+                const float v2 = bwd_act(acc[nt][pt][q * 4 + 2], __uint_as_float(hv.y << 16), is_value);
+                const float v3 = bwd_act(acc[nt][pt][q * 4 + 3], __uint_as_float(hv.y & 0xffff0000u), is_value);
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                *cell = pk;
+            }
+        }
+    }
+}
+
+// bias gradient: column sums over the VALUE rows (every 4th) of the cotangent tile
+__device__ __forceinline__ float value_row_colsum(const uint16_t *H) {
+    float s = 0.f;
+    if (threadIdx.x < HID) {
+#pragma unroll 8
+        for (int r = 0; r < BM; r += 4) s += __uint_as_float((uint32_t)H[(size_t)r * HP + threadIdx.x] << 16);
+    }
+    return s;
+}
+
+template <int KP>  // padded d_out: 32 or 64
+__global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restrict__ g, const uint16_t *__restrict__ H1, const uint16_t *__restrict__ H0,
+                                                         const uint16_t *__restrict__ W2t, const uint16_t *__restrict__ W1t,
+                                                         uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
+                                                         float *__restrict__ gb0, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *H = lds;
+    uint16_t *Wc = lds + (size_t)BM * HP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = wave & 3, ph = wave >> 2;
+    float sum1 = 0.f, sum0 = 0.f;
+    const int64_t ntiles = (M + BM - 1) / BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int64_t r0 = tile * BM;
+        for (int idx = threadIdx.x; idx < BM * (KP / 8); idx += kThreads) {
+            const int row = idx / (KP / 8), seg = idx - row * (KP / 8);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r0 + row < M) v = *reinterpret_cast<const uint4 *>(g + (size_t)(r0 + row) * KP + seg * 8);
+            *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+        TileRegs hr = load_tile_regs(H1, r0, M);   // in flight under the matrix product
+        zero_acc(acc);
+        layer_mma(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
+        store_tile_regs(H, hr);
+        __syncthreads();
+        epilogue_bwd(H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, gA1, r0, M);
+        sum1 += value_row_colsum(H);
+        hr = load_tile_regs(H0, r0, M);
+        zero_acc(acc);
+        layer_mma(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        store_tile_regs(H, hr);
+        __syncthreads();
+        epilogue_bwd(H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, gA0, r0, M);
+        sum0 += value_row_colsum(H);
+        __syncthreads();
+    }
+    if (threadIdx.x < HID) {
+        if (gb1) unsafeAtomicAdd(gb1 + threadIdx.x, sum1);
+        if (gb0) unsafeAtomicAdd(gb0 + threadIdx.x, sum0);
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 }  // namespace
@@ -441,6 +567,29 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_fwd<2><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
                                                      d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M);
+    }
+    return check_launch();
+}
+
+int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
+                     float *gb1, float *gb0, int64_t M, void *stream) {
+    if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
+    if (M == 0) return HS_OK;
+    if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0) return HS_ERR_NULL;
+    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
+    const int64_t ntiles = (M + BM - 1) / BM;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_pitch == 32) {
+        static bool attr1 = false;
+        if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, M);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+        k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, M);
     }
     return check_launch();
 }

@@ -169,40 +169,41 @@ class _fused_trunk(torch.autograd.Function):
         w1 = W1.to(bf).contiguous()
         w2 = torch.zeros(32 * ((d_out + 31) // 32), 256, device=dev, dtype=bf)
         w2[:d_out] = W2
+        w2t = w2.t().contiguous()          # [256, KP]: the backward kernel multiplies by the transposes
+        w1t = w1.t().contiguous()
         M = 4 * B
         H0 = torch.empty(M, 256, device=dev, dtype=bf)
         H1 = torch.empty(M, 256, device=dev, dtype=bf)
         Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
         _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
                                    b2.detach().float().contiguous(), d_out, H0, H1, Y)
-        ctx.save_for_backward(x01, embeddings, offsets, X, H0, H1, w0, w1, w2)
+        ctx.save_for_backward(x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t)
         ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
         Y = Y.view(B, 4, d_out)
         return Y[:, 0].contiguous(), Y[:, 1:].transpose(1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, gy, gJ):
-        x01, embeddings, offsets, X, H0, H1, w0, w1, w2 = ctx.saved_tensors
+        x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t = ctx.saved_tensors
         B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
         dev, bf = X.device, torch.bfloat16
         M = 4 * B
-        if gy is None:
-            gy = torch.zeros(B, d_out, device=dev)
-        if gJ is None:
-            gJ = torch.zeros(B, d_out, 3, device=dev)
-        g = torch.cat([gy.unsqueeze(1), gJ.transpose(1, 2)], 1).to(bf).view(M, d_out)
+        KP = w2t.shape[1]
+        g = torch.zeros(B, 4, KP, device=dev, dtype=bf)
+        if gy is not None:
+            g[:, 0, :d_out] = gy
+        if gJ is not None:
+            g[:, 1:, :d_out] = gJ.transpose(1, 2)
+        g = g.view(M, KP)
         need_w = ctx.needs_input_grad[7]
-        gW2 = _wgrad_rows(g, H1) if need_w else None
-        gb2 = gy.sum(0) if ctx.needs_input_grad[12] else None
-        G = g @ w2[:d_out]
-        gA1 = torch.empty_like(G)
+        gb2 = gy.sum(0) if ctx.needs_input_grad[12] and gy is not None else None
+        gA1 = torch.empty(M, 256, device=dev, dtype=bf)
+        gA0 = torch.empty(M, 256, device=dev, dtype=bf)
         gb1 = torch.zeros(256, device=dev)
-        _be._backend.softplus_tangent_bwd_h(H1, G, gA1, gb1)
-        gW1 = _wgrad_rows(gA1, H0) if need_w else None
-        G = gA1 @ w1
-        gA0 = torch.empty_like(G)
         gb0 = torch.zeros(256, device=dev)
-        _be._backend.softplus_tangent_bwd_h(H0, G, gA0, gb0)
+        _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0)
+        gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
+        gW1 = _wgrad_rows(gA1, H0) if need_w else None
         gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
         g_emb = None
         if ctx.needs_input_grad[1]:

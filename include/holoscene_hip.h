@@ -224,6 +224,14 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
 int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2, const float *b2,
                      int32_t d_out, void *H0, void *H1, float *Y, int64_t M, void *stream);
 
+/* Backward data path of hs_trunk_mlp_fwd in one kernel.
+ *   g [M, g_pitch] bf16: cotangent of Y, zero-padded to g_pitch = 32 or 64 columns
+ *   W2t [256, g_pitch] = W2^T (zero-padded), W1t [256, 256] = W1^T, both bf16
+ *   gA1, gA0 [M, 256] bf16: cotangents of the two hidden pre-activations (feed the weight-gradient GEMMs and, for gA0,
+ *   the input-gradient GEMM);  gb1, gb0 [256] fp32 (+=): bias gradients (may be NULL). */
+int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
+                     float *gb1, float *gb0, int64_t M, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
