@@ -36,12 +36,18 @@ def parse():
     p.add_argument("--samples", type=int, default=128)
     p.add_argument("--objects", type=int, default=32)
     p.add_argument("--beta", type=float, default=0.001)
+    p.add_argument("--lr-scale", type=float, default=1e-6,
+                   help="learning-rate multiplier.  The synthetic targets are noise, and at the reference's rates (grid lr 1e-2 per step on "
+                        "tables initialised at 1e-4) three Adam steps wipe out the measurement state of SURVEY 8(d) (the surfaces vanish and the "
+                        "sampler stops after one round).  Adam's arithmetic does not depend on the rate, so the default keeps the full update "
+                        "but makes it small enough that all timed steps see the 8(d) state (5 sampler rounds at beta=0.001).  1.0 = stock rates.")
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                    help="MLP GEMM operand precision (BASELINE configs[1] names bf16; fp32 is the reference's own precision)")
     p.add_argument("--no-graph", action="store_true", help="run the post-sampler part eagerly instead of as a captured HIP graph")
     p.add_argument("--optimizer", choices=["flat", "torch"], default="flat")
     p.add_argument("--roofline-steps", type=int, default=6, help="eager iterations after the timed region used to time single kernels")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-second-point", action="store_true", help="skip the beta=0.1 (1 sampler round, dense gradients) point of SURVEY 8(d)")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
 
@@ -53,6 +59,7 @@ class KernelTimer:
         self.events, self.points = [], 0
         self.size_arg = size_arg
         self._orig = getattr(backend_cls, name)
+        self._raw = backend_cls.__dict__[name]   # the descriptor (staticmethod/classmethod) to put back
         self._cls, self._name = backend_cls, name
         self.enabled = False
 
@@ -73,7 +80,7 @@ class KernelTimer:
         return self
 
     def __exit__(self, *exc):
-        setattr(self._cls, self._name, self._orig)
+        setattr(self._cls, self._name, self._raw)
 
     def summary(self):
         ms = [s.elapsed_time(e) for s, e, _ in self.events]
@@ -138,7 +145,8 @@ def main():
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
     from holoscene_amd.training import distributed as dist_util
 
-    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision)
+    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision,
+                      learning_rate=5.0e-4 * args.lr_scale)
     tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
                        graph=(not args.no_graph) and args.optimizer == "flat")
     benchmark_model_state(tr.model, args.beta)
@@ -212,6 +220,35 @@ def main():
         roofline["mfma_kernel"] = {"kernel": "k_sdf_mlp<1> (bf16 MFMA fused SDF trunk)", "achieved": round(flops / (sum(mfma_ms) * 1e-3) / 1e12, 1),
                                    "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / (sum(mfma_ms) * 1e-3) / 1e12 / 2500.0, 4),
                                    "launches": len(mfma_ms), "avg_launch_us": round(sum(mfma_ms) / len(mfma_ms) * 1e3, 2)}
+    # ---- SURVEY 8(d)'s second reported point: beta = 0.1 (1 sampler round; no sample has an exactly-zero cotangent, so the
+    # scatter kernels issue every atomic).  Same code path, shorter run, reported beside the headline value.
+    second = None
+    if not args.no_second_point:
+        del tr
+        conf2 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=0.1, mlp_precision=args.precision,
+                           learning_rate=5.0e-4 * args.lr_scale)
+        tr2 = Stage1Trainer(conf2, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
+                            graph=(not args.no_graph) and args.optimizer == "flat")
+        benchmark_model_state(tr2.model, 0.1)
+        if world > 1:
+            dist_util.broadcast_parameters(tr2.model)
+        r2 = []
+        n2 = max(10, args.steps // 2)
+        for i in range(8 + n2):
+            if i == 8:
+                barrier()
+                t0 = time.perf_counter()
+            idx, mi, gt = scene.next_batch()
+            tr2.train_step(idx, mi, gt)
+            r2.append(tr2.model.ray_sampler.last_rounds)
+        barrier()
+        e2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            e2 = float(t)
+        second = {"beta": 0.1, "value": round(args.rays * world * n2 / e2, 1), "unit": "rays/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
+                  "sampler_rounds_mean": round(sum(r2[8:]) / n2, 2)}
     if rank == 0:
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
@@ -219,12 +256,14 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
-                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}, "
+                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
                        "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(rounds_seen) / max(1, len(rounds_seen)), 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
+        if second is not None:
+            line["config"]["second_point"] = second
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line))

@@ -14,11 +14,11 @@ from .optim import build_optimizer, build_scheduler
 
 
 def stock_conf(num_rays=1024, S=128, d_out=32, num_levels=16, base_size=16, end_size=2048, logmap=19, beta=0.1, use_bg_reg=True,
-               mlp_precision="fp32"):
+               mlp_precision="fp32", learning_rate=5.0e-4):
     """confs/replica/room_0/replica_room_0.conf with 'R rays x S samples' mapped as SURVEY D5:
     N_samples_eval=S, N_samples=S/2, N_samples_extra=S/4."""
     return Conf(
-        train=Conf(learning_rate=5.0e-4, lr_factor_for_grid=20.0, num_pixels=num_rays, add_objectvio_iter=25000, max_total_iters=200000,
+        train=Conf(learning_rate=learning_rate, lr_factor_for_grid=20.0, num_pixels=num_rays, add_objectvio_iter=25000, max_total_iters=200000,
                    stop_iter=100000, sched_decay_rate=0.1),
         loss=Conf(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
                   normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0, reg_vio_weight=0.01,

@@ -29,3 +29,8 @@ agg = collections.Counter()
 for r in it: agg[short(r['Kernel_Name'])[:60]] += dur(r)
 print('--- top by total time')
 for k, v in agg.most_common(12): print(f"{v/1e6:7.3f} ms  {k}")
+print('--- kernels below the threshold, by name')
+small = collections.Counter(); cnt = collections.Counter()
+for r in it:
+    if dur(r) / 1e3 <= thr: small[short(r['Kernel_Name'])[:110]] += dur(r); cnt[short(r['Kernel_Name'])[:110]] += 1
+for k, v in small.most_common(40): print(f"{v/1e3:7.1f} us  x{cnt[k]:3d}  {k}")
