@@ -59,27 +59,62 @@ __device__ __forceinline__ void lane_chunk(int n, int lane, int &lo, int &hi) {
     hi = min(lo + ch, n);
 }
 
+// ---- workgroup-wide (kUpd threads = 4 waves per ray) scan / max for the beta line search.  One wave per ray left the
+// chip at one wave per SIMD with every lane walking ~10 sections serially through libm exp/expm1: 100 us at 640 sections.
+constexpr int kUpd = 256;
+constexpr int kUpdWaves = kUpd / kWave;
+
+__device__ __forceinline__ void chunk_of(int n, int tid, int nthreads, int &lo, int &hi) {
+    const int ch = (n + nthreads - 1) / nthreads;
+    lo = min(tid * ch, n);
+    hi = min(lo + ch, n);
+}
+
+// exclusive prefix sums of (a, b) over the workgroup's threads; sc: 2*kUpdWaves floats
+__device__ __forceinline__ void block_excl_scan2(float &a, float &b, float *sc, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    const float ai = wave_incl_scan(a, lane), bi = wave_incl_scan(b, lane);
+    if (lane == 63) { sc[w] = ai; sc[kUpdWaves + w] = bi; }
+    __syncthreads();
+    float pa = 0.f, pb = 0.f;
+    for (int j = 0; j < w; j++) { pa += sc[j]; pb += sc[kUpdWaves + j]; }
+    a = pa + (ai - a);
+    b = pb + (bi - b);
+}
+
+__device__ __forceinline__ float block_max(float v, float *sc, int tid) {   // sc: kUpdWaves floats, distinct from the scan's
+    v = wave_max(v);
+    if ((tid & 63) == 0) sc[tid >> 6] = v;
+    __syncthreads();
+    float r = sc[0];
+#pragma unroll
+    for (int j = 1; j < kUpdWaves; j++) r = fmaxf(r, sc[j]);
+    return r;
+}
+
 // max_i (min(exp(E_i), 1e6) - 1) * exp(-F_i), E inclusive cumsum of err terms, F exclusive cumsum of free energy
-// (ray_sampler.py:450-458).  sdf[0..n], dists/dstar[0..n)
-__device__ float error_bound(const float *__restrict__ sdf, const float *__restrict__ dists, const float *__restrict__ dstar, int n, float beta,
-                             int lane) {
+// (ray_sampler.py:450-458).  sdf[0..n], dists/dstar[0..n); fe/ee: per-section scratch (each thread touches only its chunk)
+__device__ float error_bound(const float *__restrict__ sdf, const float *__restrict__ dists, const float *__restrict__ dstar,
+                             float *__restrict__ fe, float *__restrict__ ee, int n, float beta, int tid, float *sc) {
     int lo, hi;
-    lane_chunk(n, lane, lo, hi);
+    chunk_of(n, tid, kUpd, lo, hi);
     float fsum = 0.f, esum = 0.f;
     for (int i = lo; i < hi; i++) {
-        fsum += dists[i] * laplace_sigma(sdf[i], beta);
-        esum += expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+        const float f_i = dists[i] * laplace_sigma(sdf[i], beta);
+        const float e_i = expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+        fe[i] = f_i; ee[i] = e_i;
+        fsum += f_i; esum += e_i;
     }
-    const float fpre = wave_incl_scan(fsum, lane) - fsum;  // exclusive across lanes
-    const float epre = wave_incl_scan(esum, lane) - esum;
-    float f = fpre, e = epre, best = -INFINITY;
+    float f = fsum, e = esum;
+    block_excl_scan2(f, e, sc, tid);
+    float best = -INFINITY;
     for (int i = lo; i < hi; i++) {
-        e += expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+        e += ee[i];
         const float b = (fminf(expf(e), 1.0e6f) - 1.0f) * expf(-f);
         best = fmaxf(best, b);
-        f += dists[i] * laplace_sigma(sdf[i], beta);
+        f += fe[i];
     }
-    return wave_max(best);
+    return block_max(best, sc + 2 * kUpdWaves, tid);
 }
 
 __device__ __forceinline__ int lower_bound(const float *a, int n, float v) {  // # elements < v
@@ -105,34 +140,34 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
 }
 
 // ------------------------------------------------------------------------------------ update
-__global__ __launch_bounds__(kWave) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
+__global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
                                                            const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
                                                            float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
                                                            int beta_iters, float *__restrict__ beta_max, int R) {
     extern __shared__ float lds[];
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
     if (r >= R) return;
     const int m = m_old + s_new;
-    float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m;
+    float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m, *sc = lds + 6 * m;
     float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
     const float *nz = samples + (size_t)r * s_new, *ns = new_sdf + (size_t)r * s_new;
     // stage old set (tz[0..m_old)) and new samples (tz[m_old..m))
-    for (int i = lane; i < m_old; i += kWave) { tz[i] = zr[i]; ts[i] = sr[i]; }
-    for (int i = lane; i < s_new; i += kWave) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
+    for (int i = lane; i < m_old; i += kUpd) { tz[i] = zr[i]; ts[i] = sr[i]; }
+    for (int i = lane; i < s_new; i += kUpd) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
     __syncthreads();
     // stable merge by rank (old before new on ties)
-    for (int i = lane; i < m_old; i += kWave) {
+    for (int i = lane; i < m_old; i += kUpd) {
         const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
         z[p] = tz[i]; sdf[p] = ts[i];
     }
-    for (int i = lane; i < s_new; i += kWave) {
+    for (int i = lane; i < s_new; i += kUpd) {
         const int p = i + upper_bound(tz, m_old, tz[m_old + i]);
         z[p] = tz[m_old + i]; sdf[p] = ts[m_old + i];
     }
     __syncthreads();
-    for (int i = lane; i < m; i += kWave) { zr[i] = z[i]; sr[i] = sdf[i]; }
+    for (int i = lane; i < m; i += kUpd) { zr[i] = z[i]; sr[i] = sdf[i]; }
     const int n = m - 1;
-    for (int i = lane; i < n; i += kWave) {  // Theorem 1 bound d* per section
+    for (int i = lane; i < n; i += kUpd) {  // Theorem 1 bound d* per section
         const float a = z[i + 1] - z[i], b = fabsf(sdf[i]), c = fabsf(sdf[i + 1]);
         const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
         float d = 0.f;
@@ -149,11 +184,11 @@ __global__ __launch_bounds__(kWave) void k_sampler_update(float *__restrict__ z_
     __syncthreads();
     const float beta0 = *beta0_p;
     float hi = beta_io[r];
-    if (error_bound(sdf, dists, dstar, n, beta0, lane) <= eps) hi = beta0;
+    if (error_bound(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
     float lo = beta0;
     for (int it = 0; it < beta_iters; it++) {
         const float mid = (lo + hi) / 2.f;
-        const float err = error_bound(sdf, dists, dstar, n, mid, lane);
+        const float err = error_bound(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
         if (err <= eps) hi = mid;
         else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
     }
@@ -354,7 +389,7 @@ int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const flo
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_old + s_new;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
-    k_sampler_update<<<dim3(R), dim3(kWave), 6 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
+    k_sampler_update<<<dim3(R), dim3(kUpd), (6 * m + 3 * kUpdWaves) * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
                                                                                            eps, beta_iters, beta_max, R);
     return check_launch();
 }
