@@ -145,6 +145,24 @@ __global__ __launch_bounds__(kThreads) void k_render_input_bwd(const T *__restri
     }
 }
 
+// x = o + z*d per (ray, sample) and its image in the hash grid's unit cube, x01 = (x/divide_factor + 1)/2 -- the five whole-tensor
+// passes the sampler made per round before each SDF sweep (ray_sampler.py:151-153, network.py:176, hashgrid.py:158).
+// Same operation order and roundings as those passes (no contraction; a tensor divided by a scalar is computed by ATen
+// as a multiplication by the scalar's fp32 reciprocal, reproduced here).
+__global__ __launch_bounds__(kThreads) void k_ray_points(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ z,
+                                                          float *__restrict__ x, float *__restrict__ x01, int64_t R, int S, float divide_factor) {
+    const int64_t total = R * S * 3;
+    const float inv_df = __fdiv_rn(1.0f, divide_factor);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = i / 3;
+        const int c = (int)(i - p * 3);
+        const int64_t r = p / S;
+        const float v = __fadd_rn(o[r * 3 + c], __fmul_rn(z[p], d[r * 3 + c]));
+        x[i] = v;
+        x01[i] = __fmul_rn(__fadd_rn(__fmul_rn(v, inv_df), 1.0f), 0.5f);
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 int grid_for(int64_t total) {
@@ -201,6 +219,15 @@ int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, v
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HS_F32) k_render_input_bwd<float><<<grid_for(total), kThreads, 0, st>>>((const float *)G, normals, d_normals, (float *)d_feature_vectors, B, nfreq, Fv);
     else k_render_input_bwd<__hip_bfloat16><<<grid_for(total), kThreads, 0, st>>>((const __hip_bfloat16 *)G, normals, d_normals, (__hip_bfloat16 *)d_feature_vectors, B, nfreq, Fv);
+    return check_launch();
+}
+
+int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, float *x, float *x01, int64_t R, int32_t S, float divide_factor,
+                  void *stream) {
+    if (S < 0 || divide_factor == 0.f) return HS_ERR_ARG;
+    if (R == 0 || S == 0) return HS_OK;
+    if (!cam_loc || !ray_dirs || !z || !x || !x01) return HS_ERR_NULL;
+    k_ray_points<<<grid_for(R * S * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z, x, x01, R, S, divide_factor);
     return check_launch();
 }
 

@@ -47,7 +47,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points"]
 
 
 def _check(rc, what):
@@ -246,6 +246,12 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                   ctypes.c_int64(x.shape[0]), _stream()), "hs_sdf_mlp_fwd")
+
+    @staticmethod
+    def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor):
+        lib = load_library()
+        _check(lib.hs_ray_points(_dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"), _dev(z, "z"), _dev(x, "x"), _dev(x01, "x01"),
+                                 ctypes.c_int64(z.shape[0]), z.shape[1], ctypes.c_float(divide_factor), _stream()), "hs_ray_points")
 
     @staticmethod
     def trunk_mlp_fwd(X, W0, b0, W1, b1, W2, b2, d_out, H0, H1, Y):

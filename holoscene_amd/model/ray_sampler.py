@@ -188,13 +188,19 @@ class ErrorBoundSampler(RaySampler):
             beta = beta_init.clone()
         z = torch.empty(R, ld, device=dev)
         sdf = torch.empty(R, ld, device=dev)
-        beta_max = torch.zeros(1, device=dev)
+        beta_max_all = torch.zeros(self.max_total_iters + 1, device=dev)   # one slot per round: no re-zeroing inside the loop
         samples = z0.contiguous()
+        net = model.implicit_network
+        cam = cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc
+        rays_fused = (idx is None or isinstance(idx, int)) and getattr(net, "color_grid_feature", False) and net._fused_sdf_supported(samples)
         m, rounds = 0, 0
         while True:
-            points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-            new_sdf = self._query_sdf(model, points, idx).reshape(R, -1).contiguous()
-            beta_max.zero_()
+            if rays_fused:
+                new_sdf = net.sdf_along_rays(cam, ray_dirs, samples, -1 if idx is None else idx)
+            else:
+                points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+                new_sdf = self._query_sdf(model, points, idx).reshape(R, -1).contiguous()
+            beta_max = beta_max_all[rounds:rounds + 1]
             be.sampler_update(z, sdf, m, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max)
             m += samples.shape[1]
             rounds += 1

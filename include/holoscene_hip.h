@@ -152,6 +152,11 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
                  void *stream);
 
+/* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
+ * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
+int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, float *x, float *x01, int64_t R, int32_t S, float divide_factor,
+                  void *stream);
+
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
  * A, out, G, gA: [B, rows, W], storage type `dtype` = HS_F32 or HS_BF16 (arithmetic is fp32 either way; bias and

@@ -496,3 +496,24 @@ def test_fused_mfma_training_trunk_vs_gemm_path(d_out, B, monkeypatch):
         # the fused path may not be worse than the established bf16 path by more than 2x, and both stay within 2e-2 of scale
         assert err <= 2e-2 * scale + 1e-6 and rel < 2e-2, (n, err, scale, rel)
         assert rel <= 2.0 * grel + 1e-3, (n, rel, grel)
+
+
+@pytest.mark.parametrize("select", [-1, 3])
+def test_ray_mode_sdf_query_is_bit_identical_to_point_mode(select):
+    """hs_ray_points + hash encode + fused trunk == the same query on explicitly built points (same roundings)."""
+    from holoscene_amd.model.network import ObjectImplicitNetworkGrid
+    torch.manual_seed(5)
+    net = ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=7, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                    divide_factor=1.5, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    net.set_mlp_precision("bf16")
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+        R, S = 333, 17
+        o = torch.randn(R, 3, device=DEV) * 0.3
+        d = torch.nn.functional.normalize(torch.randn(R, 3, device=DEV), dim=-1)
+        z = torch.rand(R, S, device=DEV).sort(-1)[0] * 3.5
+        pts = (o.unsqueeze(1) + z.unsqueeze(2) * d.unsqueeze(1)).reshape(-1, 3)
+        ref = (net.get_sdf_vals(pts) if select < 0 else net.get_object_sdf_vals(pts, select)).reshape(R, S)
+        got = net.sdf_along_rays(o, d, z, select)
+    assert torch.equal(got, ref)
