@@ -7,8 +7,10 @@
 A "step" is one full training iteration of the hot path: sampler, render, Eikonal set,
 loss, backward, gradient exchange (N>1), Adam, LR step, on synthetic inputs resident in HBM.
 Workload = BASELINE.json configs[1]: 1 024 rays x 128 samples (98 rendered points/ray), K=32 object
-channels, L=16 hash grid (T=2^19, 16->2048), fp32, beta=0.001 (5 sampler rounds).  Weak scaling:
-every rank renders its own 1 024 rays; value = global rays / max-over-ranks time.
+channels, L=16 hash grid (T=2^19, 16->2048), bf16 MLP operands (--precision), beta=0.001 with the measurement state
+held (--lr-scale, see its help) so that the sampler runs the 5 rounds SURVEY 8(d) specifies; the beta=0.1 second point
+is measured in the same run (config.second_point).  Weak scaling: every rank renders its own 1 024 rays;
+value = global rays / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant hand-written kernel, timed live with
 HIP events on the launching stream) and "cpu_baseline" (the CPU oracle on the host cores, bounded sample).
@@ -214,7 +216,7 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": len(ms), "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2),
                 "algorithmic_bytes_per_launch": bytes_per_point * n_main,
-                "note": "float-atomic scatter: bounded by the L2 atomic rate (~19 G atomics/s measured), not by HBM bandwidth"}
+                "note": "float-atomic scatter: bounded by the global atomic issue rate (1 lane-op/clk/XCD = ~21 G/s measured, tools/exp/atomic_xcd.hip), not by HBM bandwidth; exactly-zero contributions are skipped but counted as algorithmic bytes"}
     if mfma_ms:  # the matrix-core kernel of the path (sampler SDF sweeps), for the MFMA side of the roofline
         flops = sum(p * 2 * (96 * 256 + 256 * 256 + 256 * 32) for p in mfma_pts)
         roofline["mfma_kernel"] = {"kernel": "k_sdf_mlp<1> (bf16 MFMA fused SDF trunk)", "achieved": round(flops / (sum(mfma_ms) * 1e-3) / 1e12, 1),

@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$C -o $C -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 2 > $OUT/bench_$C.log 2>&1 || true
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$C -o $C -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-graph --steps 3 --warmup 2 > $OUT/bench_$C.log 2>&1 || true
   python - <<PY
 import csv, glob, collections
 f = glob.glob('/tmp/pmc_${TAG}_$C/*counter_collection.csv')
