@@ -33,11 +33,15 @@ class FlatAdam:
         self.flat_m = torch.zeros(self.padded, device=dev)
         self.flat_v = torch.zeros(self.padded, device=dev)
         off = 0
-        for p in self.params:
+        self.small = []          # (parameter, gradient view) of everything that is not a hash table
+        n_tables = len(groups[0])
+        for i, p in enumerate(self.params):
             n = p.numel()
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + n].view_as(p)
             p.grad = self.flat_g[off:off + n].view_as(p)
+            if i >= n_tables:
+                self.small.append((p, p.grad))
             off += n
         self.betas, self.eps = betas, eps
         self.gamma = float(decay_rate) ** (1.0 / float(decay_steps))
@@ -54,7 +58,20 @@ class FlatAdam:
 
     # ---- gradients
     def zero_grad(self):
+        """One memset; the hash tables keep their gradient views attached (the scatter kernels accumulate into them in
+        place), the ~30 small MLP tensors are detached so that autograd hands over each gradient tensor as is instead of
+        launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy."""
         self.flat_g.zero_()
+        for p, _ in self.small:
+            p.grad = None
+
+    def gather_grads(self):
+        src = [p.grad for p, _ in self.small if p.grad is not None]
+        dst = [v for p, v in self.small if p.grad is not None]
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in self.small:
+            p.grad = v
 
     def read_state(self):
         return _be.hsAdamState.from_buffer_copy(bytes(self.state.cpu().numpy().tobytes()))

@@ -115,6 +115,8 @@ class Stage1Trainer:
         out["iter_step"] = self.iter_step
         loss_out = self.loss(out, ground_truth, call_reg=self.iter_step >= self.add_objectvio_iter)
         loss_out["loss"].backward()
+        if self.flat is not None:
+            self.flat.gather_grads()
         self._exchange_and_step()
         self.iter_step += 1
         return out, loss_out
@@ -127,6 +129,7 @@ class Stage1Trainer:
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         loss_out["loss"].backward()
+        self.flat.gather_grads()
         if self.world_size == 1 and not self.freeze_parameters:
             self.flat.step()
         return out, loss_out

@@ -174,8 +174,12 @@ def test_fused_flat_adam_matches_torch_adam():
         flat.zero_grad()
         for n in names:
             grad = (torch.randn(pm[n].shape, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))).to(DEV)
-            pm[n].grad.copy_(grad)
+            if pm[n].grad is None:      # small tensors are detached by zero_grad and handed over like autograd does
+                pm[n].grad = grad.clone()
+            else:                       # hash tables keep their flat view attached
+                pm[n].grad.copy_(grad)
             pr[n].grad = grad.clone()
+        flat.gather_grads()
         flat.step()
         opt.step()
         sched.step()
