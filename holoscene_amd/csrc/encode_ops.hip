@@ -150,7 +150,8 @@ __global__ __launch_bounds__(kThreads) void k_render_input_bwd(const T *__restri
 // Same operation order and roundings as those passes (no contraction; a tensor divided by a scalar is computed by ATen
 // as a multiplication by the scalar's fp32 reciprocal, reproduced here).
 __global__ __launch_bounds__(kThreads) void k_ray_points(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ z,
-                                                          float *__restrict__ x, float *__restrict__ x01, int64_t R, int S, float divide_factor) {
+                                                          float *__restrict__ x, float *__restrict__ x01, int64_t R, int S, float divide_factor, hsGate gate) {
+    if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
     const int64_t total = R * S * 3;
     const float inv_df = __fdiv_rn(1.0f, divide_factor);
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
@@ -223,11 +224,11 @@ int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, v
 }
 
 int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, float *x, float *x01, int64_t R, int32_t S, float divide_factor,
-                  void *stream) {
+                  const hsGate *gate, void *stream) {
     if (S < 0 || divide_factor == 0.f) return HS_ERR_ARG;
     if (R == 0 || S == 0) return HS_OK;
     if (!cam_loc || !ray_dirs || !z || !x || !x01) return HS_ERR_NULL;
-    k_ray_points<<<grid_for(R * S * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z, x, x01, R, S, divide_factor);
+    k_ray_points<<<grid_for(R * S * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z, x, x01, R, S, divide_factor, gate ? *gate : hsGate{nullptr, nullptr});
     return check_launch();
 }
 

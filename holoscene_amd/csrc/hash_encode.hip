@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
                                                         float *__restrict__ dydx, uint32_t B, uint32_t L, LevelScales sc,
                                                         hsHashLayout lay, uint32_t n_chunks) {
     uint32_t level, chunk;
+    if (lay.gate.a != nullptr && !(*lay.gate.a > *lay.gate.b)) return;   // hsGate: this sampler round was not needed
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
     if (b >= B) return;
@@ -475,6 +476,8 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.dydx_level_stride = (int64_t)D * C;  // [B,L,D,C]
     lay.dydx_point_stride = (int64_t)L * D * C;
     lay.schedule = 0;
+    lay.gate.a = nullptr;
+    lay.gate.b = nullptr;
     return lay;
 }
 

@@ -23,6 +23,8 @@
 
 namespace {
 
+__device__ __forceinline__ bool gate_closed(const hsGate &g) { return g.a != nullptr && !(*g.a > *g.b); }
+
 constexpr int kWave = 64;
 
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
@@ -143,8 +145,9 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
 __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
                                                            const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
                                                            float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
-                                                           int beta_iters, float *__restrict__ beta_max, int R) {
+                                                           int beta_iters, float *__restrict__ beta_max, int R, hsGate gate) {
     extern __shared__ float lds[];
+    if (gate_closed(gate)) return;
     const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
     if (r >= R) return;
     const int m = m_old + s_new;
@@ -202,8 +205,9 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
 // mode 0: pdf ~ error-bound opacity (+tiny); mode 1: pdf ~ rendering weights (+1e-5).  u: explicit [R,n_out] or NULL = linspace(0,1,n_out)
 __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
                                                          const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
-                                                         int n_out, float *__restrict__ out, int R) {
+                                                         int n_out, float *__restrict__ out, int R, hsGate gate) {
     extern __shared__ float lds[];
+    if (gate_closed(gate)) return;
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
@@ -384,22 +388,22 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 extern "C" {
 
 int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
-                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, void *stream) {
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate, void *stream) {
     if (R <= 0) return HS_OK;
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_old + s_new;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
     k_sampler_update<<<dim3(R), dim3(kUpd), (6 * m + 3 * kUpdWaves) * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
-                                                                                           eps, beta_iters, beta_max, R);
+                                                                                           eps, beta_iters, beta_max, R, gate ? *gate : hsGate{nullptr, nullptr});
     return check_launch();
 }
 
 int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
-                    int32_t n_out, float *out, int32_t R, void *stream) {
+                    int32_t n_out, float *out, int32_t R, const hsGate *gate, void *stream) {
     if (R <= 0 || n_out <= 0) return HS_OK;
     if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R);
+    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr});
     return check_launch();
 }
 

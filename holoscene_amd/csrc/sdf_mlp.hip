@@ -167,8 +167,9 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
                                                        const float *__restrict__ b0, const uint16_t *__restrict__ W1,
                                                        const float *__restrict__ b1, const uint16_t *__restrict__ W2,
                                                        const float *__restrict__ b2, int d_out, int select, float *__restrict__ out_min,
-                                                       float *__restrict__ out_raw, int64_t B) {
+                                                       float *__restrict__ out_raw, int64_t B, hsGate gate) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
     uint16_t *H = lds;                                  // [BM][HP]
     uint16_t *Wc = lds + (size_t)BM * HP;               // 2 x [HID][WP]  (re-used for W2 [32*NOUT_TILES][HP] in the last layer)
     float *bias = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);   // b0[256] b1[256] b2[64]
@@ -526,7 +527,7 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 extern "C" {
 
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, void *stream) {
+                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate, void *stream) {
     if (d_out < 1 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!x || !feat || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out_min) return HS_ERR_NULL;
@@ -538,12 +539,12 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_sdf_mlp<1><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
-                                                   out_min, out_raw, B);
+                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr});
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
-                                                   out_min, out_raw, B);
+                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr});
     }
     return check_launch();
 }

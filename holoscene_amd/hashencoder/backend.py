@@ -20,9 +20,25 @@ _ERRORS = {-1: "unsupported D/C/size combination (GridEncoding: D must be 2 or 3
            -2: "HIP kernel launch failed", -3: "required pointer was NULL"}
 
 
+class hsGate(ctypes.Structure):
+    """Device-side launch gate (include/holoscene_hip.h): run only if *a > *b."""
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p)]
+
+
 class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
-                ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32)]
+                ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate)]
+
+
+ABI_VERSION = 2
+
+
+def _gate(gate):
+    """gate: None or (a, b) one-element float32 device tensors -> hsGate (kept alive by the caller's references)."""
+    if gate is None:
+        return hsGate(None, None)
+    a, b = gate
+    return hsGate(_dev(a, "gate.a").value, _dev(b, "gate.b").value)
 
 
 _lib = None
@@ -41,6 +57,9 @@ def load_library():
         for name in dir_symbols():
             if name != "hs_target_arch":
                 getattr(_lib, name).restype = ctypes.c_int
+        if _lib.hs_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {_lib.hs_abi_version()}, this package needs {ABI_VERSION} -- rebuild "
+                               "(python -m holoscene_amd.csrc.build)")
     return _lib
 
 
@@ -114,13 +133,13 @@ class _HipBackend:
 
     # ---- strided / selective variants (include/holoscene_hip.h section 2); point-major features, level-major dy_dx
     @staticmethod
-    def _layout(B, D, C, L):
-        return hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE)
+    def _layout(B, D, C, L, gate=None):
+        return hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate))
 
     @classmethod
-    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx):
+    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L)
+        lay = cls._layout(B, D, C, L, gate)
         _check(lib.hs_hash_fwd(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
                                _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), ctypes.byref(lay),
                                _stream()), "hs_hash_fwd")
@@ -152,19 +171,19 @@ class _HipBackend:
 
     # ---- per-ray sampler kernels (include/holoscene_hip.h section 3)
     @staticmethod
-    def sampler_update(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max):
+    def sampler_update(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max, gate=None):
         lib = load_library()
         R, ld = z.shape
         _check(lib.hs_sampler_update(_dev(z, "z"), _dev(sdf, "sdf"), ld, m_old, _dev(samples, "samples"), _dev(new_sdf, "new_sdf"),
                                      samples.shape[1], _dev(beta, "beta"), _dev(beta0, "beta0"), ctypes.c_float(eps), beta_iters,
-                                     _dev(beta_max, "beta_max"), R, _stream()), "hs_sampler_update")
+                                     _dev(beta_max, "beta_max"), R, ctypes.byref(_gate(gate)), _stream()), "hs_sampler_update")
 
     @staticmethod
-    def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out):
+    def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out, gate=None):
         lib = load_library()
         R, ld = z.shape
         _check(lib.hs_sampler_draw(_dev(z, "z"), _dev(sdf, "sdf"), ld, m, _dev(beta, "beta"), mode, ctypes.c_float(add_tiny),
-                                   _dev(u, "u"), n_out, _dev(out, "out"), R, _stream()), "hs_sampler_draw")
+                                   _dev(u, "u"), n_out, _dev(out, "out"), R, ctypes.byref(_gate(gate)), _stream()), "hs_sampler_draw")
 
     @staticmethod
     def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik):
@@ -240,18 +259,19 @@ class _HipBackend:
 
     # ---- fused SDF-trunk inference (include/holoscene_hip.h section 7)
     @staticmethod
-    def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw):
+    def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw, gate=None):
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
-                                  ctypes.c_int64(x.shape[0]), _stream()), "hs_sdf_mlp_fwd")
+                                  ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), _stream()), "hs_sdf_mlp_fwd")
 
     @staticmethod
-    def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor):
+    def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor, gate=None):
         lib = load_library()
         _check(lib.hs_ray_points(_dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"), _dev(z, "z"), _dev(x, "x"), _dev(x01, "x01"),
-                                 ctypes.c_int64(z.shape[0]), z.shape[1], ctypes.c_float(divide_factor), _stream()), "hs_ray_points")
+                                 ctypes.c_int64(z.shape[0]), z.shape[1], ctypes.c_float(divide_factor), ctypes.byref(_gate(gate)), _stream()),
+               "hs_ray_points")
 
     @staticmethod
     def trunk_mlp_fwd(X, W0, b0, W1, b1, W2, b2, d_out, H0, H1, Y):

@@ -572,23 +572,25 @@ class ObjectImplicitNetworkGrid(nn.Module):
         _be._backend.sdf_mlp_fwd(x, feat.contiguous(), w0, b0, w1, b1, w2, b2, d_out, select, out, raw)
         return out, raw
 
-    def sdf_along_rays(self, cam_loc, ray_dirs, z, select=-1):
+    def sdf_along_rays(self, cam_loc, ray_dirs, z, select=-1, gate=None):
         """Scene SDF (select < 0: min over objects; else that object's) at cam_loc + z*ray_dirs, [R,S] -> [R,S]: the sampler's
-        per-round query (ray_sampler.py:151-157) in three launches -- positions, hash encode, fused matrix-core trunk."""
+        per-round query (ray_sampler.py:151-157) in three launches -- positions, hash encode, fused matrix-core trunk.
+        gate: optional device-side launch gate (backend.hsGate) shared by the three kernels."""
         R, S = z.shape
         dev = z.device
         x = torch.empty(R * S, 3, device=dev)
         x01 = torch.empty(R * S, 3, device=dev)
         be = _be._backend
-        be.ray_points(cam_loc.contiguous(), ray_dirs.contiguous(), z.contiguous(), x, x01, float(self.divide_factor))
+        be.ray_points(cam_loc.contiguous(), ray_dirs.contiguous(), z.contiguous(), x, x01, float(self.divide_factor), gate=gate)
         enc = self.encoding
         L, C = enc.num_levels, enc.level_dim
         feat = torch.empty(R * S, L * C, device=dev)
-        be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None)
+        be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+               gate=gate)
         d_out = self._lins()[2].out_features
         out = torch.empty(R, S, device=dev)
         w0, b0, w1, b1, w2, b2 = self._packed_weights()
-        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, None)
+        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, None, gate=gate)
         return out
 
     def sdf_and_jacobian(self, x):

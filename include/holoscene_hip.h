@@ -88,12 +88,21 @@ int hs_hash_encode_second_backward(const float *grad, const float *inputs, const
  * `schedule`: 0 = level-major block order, 1 = XCD-affine (level l pinned to one
  * XCD's L2; needs L % 8 == 0, silently falls back to 0 otherwise).
  */
+/* Device-side launch gate: a gated kernel returns at once unless *a > *b (two device floats); a == NULL = always run.
+ * The sampler uses it to enqueue round r+1 of Algorithm 1 (gate: max beta of round r > beta0, ray_sampler.py:204) BEFORE
+ * the host has read round r's convergence flag, so the device never idles on that read. */
+typedef struct hsGate {
+    const float *a;
+    const float *b;
+} hsGate;
+
 typedef struct hsHashLayout {
     int64_t level_stride;      /* features / grads */
     int64_t point_stride;
     int64_t dydx_level_stride; /* dy_dx */
     int64_t dydx_point_stride;
     int32_t schedule;
+    hsGate gate;               /* honoured by hs_hash_fwd only */
 } hsHashLayout;
 
 int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,
@@ -131,13 +140,14 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
  *   smallest beta within eps found by `beta_iters` bisection steps from *beta0 (device scalar);
  *   *beta_max = max(*beta_max, beta_r) via atomics (zero it before the call). */
 int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
-                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, void *stream);
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate /* NULL = none */,
+                      void *stream);
 
 /* Inverse-CDF sampling (ray_sampler.py:206-253): mode 0 = pdf ~ error-bound opacity + add_tiny,
  * mode 1 = pdf ~ rendering weights + 1e-5.  u [R, n_out] explicit, or NULL = linspace(0,1,n_out).
  * out [R, n_out]. */
 int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
-                    int32_t n_out, float *out, int32_t R, void *stream);
+                    int32_t n_out, float *out, int32_t R, const hsGate *gate /* NULL = none */, void *stream);
 
 /* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
  * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */
@@ -155,7 +165,7 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
 int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, float *x, float *x01, int64_t R, int32_t S, float divide_factor,
-                  void *stream);
+                  const hsGate *gate /* NULL = none */, void *stream);
 
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
@@ -218,7 +228,7 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
  *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
  *   out_min [B] = min_k y_k (select < 0) or y_select; out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, void *stream);
+                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate /* NULL = none */, void *stream);
 
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
  * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).

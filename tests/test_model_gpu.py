@@ -521,3 +521,21 @@ def test_ray_mode_sdf_query_is_bit_identical_to_point_mode(select):
         ref = (net.get_sdf_vals(pts) if select < 0 else net.get_object_sdf_vals(pts, select)).reshape(R, S)
         got = net.sdf_along_rays(o, d, z, select)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("name", ["sampler_1", "sampler_3", "sampler_4"])
+def test_speculative_sampler_rounds_equal_sequential_rounds(name, monkeypatch):
+    """Device-gated one-round-ahead pipeline vs strictly sequential rounds (bf16 fused SDF queries in both): identical depths
+    and the same realised round count, for states that stop after 1..5 rounds."""
+    from holoscene_amd.model import ray_sampler as RS
+    rec = load(name)
+    model = build_model(rec, DEV).train()
+    model.implicit_network.set_mlp_precision("bf16")
+    ins = _dev(section(rec, "in."))
+    res = {}
+    for spec in (True, False):
+        monkeypatch.setattr(RS, "SPECULATE", spec)
+        z, z_eik = model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model, rng=_dev(rand_dict(rec)))
+        res[spec] = (z, z_eik, model.ray_sampler.last_rounds)
+    assert res[True][2] == res[False][2]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
