@@ -1,0 +1,415 @@
+// holoscene_amd/csrc/appearance_mlp.hip -- the colour branch of a rendered sample, fused on the CDNA4 matrix cores (gfx950).
+//
+// Reference (per rendered point, model/network.py):
+//   fv  = Linear(256,256)(ReLU(Linear(32,256)(colour hash features)))                   :186-188  (colour_grid_feature_map_mlp :99-101)
+//   x   = [posenc4(point), posenc4(view dir), posenc4(normal), fv]            337       :586-596
+//   rgb = sigmoid(W2 ReLU(W1 ReLU(W0 x + b0) + b1) + b2)                      337->256->256->3      :598-612
+// = 5 GEMMs + 2 concatenations + 5 elementwise passes forward and ~20 launches backward in the reference's formulation, each
+// bouncing a [100 352, 256] activation through HBM.  Here one kernel per direction walks a 128-point tile through all five
+// layers (csrc/mfma_mlp.h machinery): the feature vector never leaves LDS between the colour MLP and the rendering MLP; the
+// 81 positional-encoding inputs sit in a second small LDS tile and enter layer R0 as a second matrix product into the same
+// accumulators.  What the weight-gradient GEMMs (library, split-M) need is written once: layer outputs forward, pre-activation
+// cotangents backward.
+//
+//   k_appear_fwd : featc, points, dirs, normals -> rgb;  keeps xin = [featc | posenc] , hc, fv, r0, r1 (bf16)
+//   k_appear_bwd : d rgb -> g_y, gA_r1, gA_r0, g_fv, gA_hc (bf16), d normals, d featc (fp32), bias gradients
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "holoscene_hip.h"
+#include "mfma_mlp.h"
+
+namespace {
+
+constexpr int NFC = 32;        // colour hash features per point (L*C)
+constexpr int NF = 4;          // posenc frequencies of the rendering network (multires_view = 4)
+constexpr int NPE1 = 3 + 6 * NF;   // 27 values per encoded vector
+constexpr int PW = 96;         // 3 x 27 = 81 posenc inputs, zero-padded
+constexpr int PP = PW + 8;     // LDS pitch of the posenc tile
+constexpr int XW = NFC + PW;   // row of the saved input image: [featc(32) | posenc(96)]
+constexpr int SP = 33;         // fp32 scratch pitch
+
+template <int ACT>  // 0: linear, 1: ReLU
+__device__ __forceinline__ void epilogue_act(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);
+            const float4 bi = *reinterpret_cast<const float4 *>(bias_lds + n0);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const int p = ph * 64 + pt * 32 + (lane & 31);
+                float v0 = acc[nt][pt][q * 4 + 0] + bi.x, v1 = acc[nt][pt][q * 4 + 1] + bi.y;
+                float v2 = acc[nt][pt][q * 4 + 2] + bi.z, v3 = acc[nt][pt][q * 4 + 3] + bi.w;
+                if (ACT == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
+            }
+        }
+    }
+}
+
+// MASK = 1: H holds the layer's ReLU output r on entry; exit: (r > 0 ? acc : 0) in place.  MASK = 0: H = acc.
+template <int MASK>
+__device__ __forceinline__ void epilogue_grad(uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const int p = ph * 64 + pt * 32 + (lane & 31);
+                uint2 *cell = reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0);
+                float v0 = acc[nt][pt][q * 4 + 0], v1 = acc[nt][pt][q * 4 + 1], v2 = acc[nt][pt][q * 4 + 2], v3 = acc[nt][pt][q * 4 + 3];
+                if (MASK == 1) {   // bf16 bit patterns: positive <=> sign clear and not zero
+                    const uint2 r = *cell;
+                    v0 = (int16_t)(r.x & 0xffffu) > 0 ? v0 : 0.f;
+                    v1 = (int32_t)r.x > 0xffff ? v1 : 0.f;
+                    v2 = (int16_t)(r.y & 0xffffu) > 0 ? v2 : 0.f;
+                    v3 = (int32_t)r.y > 0xffff ? v3 : 0.f;
+                }
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                *cell = pk;
+            }
+        }
+    }
+}
+
+// narrow layers (<= 32 outputs): W [32][HID] bf16 staged with pitch HP into the chunk area; waves 0..3 take 32 rows each
+__device__ __forceinline__ void stage_small(uint16_t *Wc, const uint16_t *__restrict__ W) {
+    for (int idx = threadIdx.x; idx < 32 * (HID / 8); idx += kThreads) {
+        const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
+        *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W + (size_t)row * HID + seg * 8);
+    }
+}
+
+// lane result: row wave*32 + (lane&31), outputs n = (i&3) + 8*(i>>2) + 4*(lane>>5), i < 16
+__device__ __forceinline__ f32x16 small_mma(const uint16_t *Wc, const uint16_t *H, int wave, int lane) {
+    f32x16 y;
+#pragma unroll
+    for (int i = 0; i < 16; i++) y[i] = 0.f;
+    const int prow = wave * 32 + (lane & 31);
+#pragma unroll 4
+    for (int ks = 0; ks < HID / 16; ks++) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(H + (size_t)prow * HP + ks * 16 + (lane >> 5) * 8);
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(lane & 31) * HP + ks * 16 + (lane >> 5) * 8);
+        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y, 0, 0, 0);
+    }
+    return y;
+}
+
+__global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict__ featc, const float *__restrict__ pts, const float *__restrict__ dirs,
+                                                          const float *__restrict__ nrm, const uint16_t *__restrict__ Wc0,
+                                                          const uint16_t *__restrict__ Wc1, const uint16_t *__restrict__ Wr0f,
+                                                          const uint16_t *__restrict__ Wr0p, const uint16_t *__restrict__ Wr1,
+                                                          const uint16_t *__restrict__ Wr2, const float *__restrict__ bc0, const float *__restrict__ bc1,
+                                                          const float *__restrict__ br0, const float *__restrict__ br1, const float *__restrict__ br2,
+                                                          uint16_t *__restrict__ xin, uint16_t *__restrict__ hc, uint16_t *__restrict__ fv,
+                                                          uint16_t *__restrict__ r0o, uint16_t *__restrict__ r1o, float *__restrict__ rgb, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *H = lds;                                   // [BM][HP]
+    uint16_t *Wc = H + (size_t)BM * HP;                  // 2 x [HID][WP]
+    uint16_t *P = Wc + 2 * (size_t)HID * WP;             // [BM][PP]
+    float *bias = reinterpret_cast<float *>(P + (size_t)BM * PP);   // bc0 | bc1 | br0 | br1 | br2(4)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = wave & 3, ph = wave >> 2;
+    if (threadIdx.x < HID) {
+        bias[threadIdx.x] = bc0[threadIdx.x]; bias[HID + threadIdx.x] = bc1[threadIdx.x];
+        bias[2 * HID + threadIdx.x] = br0[threadIdx.x]; bias[3 * HID + threadIdx.x] = br1[threadIdx.x];
+    }
+    if (threadIdx.x < 4) bias[4 * HID + threadIdx.x] = threadIdx.x < 3 ? br2[threadIdx.x] : 0.f;
+    const int64_t ntiles = (B + BM - 1) / BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int64_t p0 = tile * BM;
+        {   // ---- inputs: parts 0..2 encode one vector each into P, part 3 converts the colour features into H[:, 0:32)
+            const int p = threadIdx.x & (BM - 1), part = threadIdx.x >> 7;
+            const int64_t gp = p0 + p;
+            const bool ok = gp < B;
+            if (part < 3) {
+                const float *src = part == 0 ? pts : (part == 1 ? dirs : nrm);
+                float v[3] = {0.f, 0.f, 0.f};
+                if (ok) { v[0] = src[gp * 3]; v[1] = src[gp * 3 + 1]; v[2] = src[gp * 3 + 2]; }
+                uint16_t *row = P + (size_t)p * PP + part * NPE1;
+                row[0] = (uint16_t)f2bf(v[0]); row[1] = (uint16_t)f2bf(v[1]); row[2] = (uint16_t)f2bf(v[2]);
+#pragma unroll
+                for (int k = 0; k < NF; k++) {
+                    const float f = (float)(1 << k);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        float sn, cs;
+                        __sincosf(v[d] * f, &sn, &cs);
+                        row[3 + 6 * k + d] = (uint16_t)f2bf(sn);
+                        row[3 + 6 * k + 3 + d] = (uint16_t)f2bf(cs);
+                    }
+                }
+            } else {
+                uint16_t *prow = P + (size_t)p * PP;
+#pragma unroll
+                for (int c = 3 * NPE1; c < PW; c++) prow[c] = 0;
+                const float4 *fp = reinterpret_cast<const float4 *>(featc + (ok ? gp : 0) * NFC);
+                uint16_t *hrow = H + (size_t)p * HP;
+#pragma unroll
+                for (int i = 0; i < NFC / 4; i++) {
+                    const float4 f = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    uint2 pk;
+                    pk.x = pack_bf16(f.x, f.y);
+                    pk.y = pack_bf16(f.z, f.w);
+                    *reinterpret_cast<uint2 *>(hrow + 4 * i) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // saved input image for the weight gradients: xin[p] = [featc(32) | posenc(96)], 16 x 16 B per row
+        for (int idx = threadIdx.x; idx < BM * (XW / 8); idx += kThreads) {
+            const int row = idx / (XW / 8), seg = idx - row * (XW / 8);
+            if (p0 + row < B) {
+                const uint4 v = seg < NFC / 8 ? *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8)
+                                              : *reinterpret_cast<const uint4 *>(P + (size_t)row * PP + (seg - NFC / 8) * 8);
+                *reinterpret_cast<uint4 *>(xin + (size_t)(p0 + row) * XW + seg * 8) = v;
+            }
+        }
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        layer_mma(Wc0, NFC, NFC, H, Wc, acc, nq, ph, lane);
+        epilogue_act<1>(bias, H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, hc, p0, B);
+        zero_acc(acc);
+        layer_mma(Wc1, HID, HID, H, Wc, acc, nq, ph, lane);
+        epilogue_act<0>(bias + HID, H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, fv, p0, B);
+        zero_acc(acc);
+        layer_mma(Wr0f, HID, HID, H, Wc, acc, nq, ph, lane);          // feature-vector columns 81..336 of W_R0
+        layer_mma<PP>(Wr0p, PW, PW, P, Wc, acc, nq, ph, lane);        // + positional-encoding columns 0..80
+        epilogue_act<1>(bias + 2 * HID, H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, r0o, p0, B);
+        zero_acc(acc);
+        layer_mma(Wr1, HID, HID, H, Wc, acc, nq, ph, lane);
+        epilogue_act<1>(bias + 3 * HID, H, acc, nq, ph, lane);
+        stage_small(Wc, Wr2);
+        __syncthreads();
+        store_tile(H, r1o, p0, B);
+        if (wave < 4) {
+            const f32x16 y = small_mma(Wc, H, wave, lane);
+            const int64_t gp = p0 + wave * 32 + (lane & 31);
+            if (lane < 32 && gp < B) {   // outputs 0..2 live in accumulator entries 0..2 of the lower half-wave
+#pragma unroll
+                for (int n = 0; n < 3; n++) rgb[gp * 3 + n] = 1.f / (1.f + __expf(-(y[n] + bias[4 * HID + n])));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict__ g_rgb, const float *__restrict__ rgb, const float *__restrict__ nrm,
+                                                          const uint16_t *__restrict__ r1, const uint16_t *__restrict__ r0, const uint16_t *__restrict__ hc,
+                                                          const uint16_t *__restrict__ Wr2t, const uint16_t *__restrict__ Wr1t,
+                                                          const uint16_t *__restrict__ Wr0ft, const uint16_t *__restrict__ Wr0nt,
+                                                          const uint16_t *__restrict__ Wc1t, const uint16_t *__restrict__ Wc0t,
+                                                          uint16_t *__restrict__ gy, uint16_t *__restrict__ gA_r1, uint16_t *__restrict__ gA_r0,
+                                                          uint16_t *__restrict__ g_fv, uint16_t *__restrict__ gA_hc, float *__restrict__ d_nrm,
+                                                          float *__restrict__ g_featc, float *__restrict__ gb, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *H = lds;
+    uint16_t *Wc = H + (size_t)BM * HP;
+    float *S = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);   // [BM][SP] fp32 scratch for the narrow products
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = wave & 3, ph = wave >> 2;
+    float s_r1 = 0.f, s_r0 = 0.f, s_c1 = 0.f, s_c0 = 0.f;
+    const int64_t ntiles = (B + BM - 1) / BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int64_t p0 = tile * BM;
+        {   // ---- cotangent of the pre-sigmoid outputs, padded to 32 columns: one 16-byte segment per thread
+            const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
+            const int64_t gp = p0 + row;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (seg == 0 && gp < B) {
+                float g[3];
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const float c = rgb[gp * 3 + n];
+                    g[n] = g_rgb[gp * 3 + n] * c * (1.f - c);
+                }
+                v.x = pack_bf16(g[0], g[1]);
+                v.y = pack_bf16(g[2], 0.f);
+            }
+            *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+            if (gp < B) *reinterpret_cast<uint4 *>(gy + (size_t)gp * 32 + seg * 8) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+        TileRegs hr = load_tile_regs(r1, p0, B);
+        zero_acc(acc);
+        layer_mma(Wr2t, 32, 32, H, Wc, acc, nq, ph, lane);
+        store_tile_regs(H, hr);
+        __syncthreads();
+        epilogue_grad<1>(H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, gA_r1, p0, B);
+        s_r1 += tile_colsum<1>(H);
+        hr = load_tile_regs(r0, p0, B);
+        zero_acc(acc);
+        layer_mma(Wr1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        store_tile_regs(H, hr);
+        __syncthreads();
+        epilogue_grad<1>(H, acc, nq, ph, lane);
+        stage_small(Wc, Wr0nt);
+        __syncthreads();
+        store_tile(H, gA_r0, p0, B);
+        s_r0 += tile_colsum<1>(H);
+        // ---- normals: cotangent of the 27 encoded-normal inputs (columns 54..80 of W_R0), then the posenc chain rule
+        if (wave < 4) {
+            const f32x16 y = small_mma(Wc, H, wave, lane);
+            float *srow = S + (size_t)(wave * 32 + (lane & 31)) * SP;
+#pragma unroll
+            for (int i = 0; i < 16; i++) srow[(i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)] = y[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < BM * 3) {
+            const int row = threadIdx.x / 3, d = threadIdx.x - row * 3;
+            const int64_t gp = p0 + row;
+            if (gp < B) {
+                const float *y = S + (size_t)row * SP;
+                const float x = nrm[gp * 3 + d];
+                float r = y[d];
+#pragma unroll
+                for (int k = 0; k < NF; k++) {
+                    const float f = (float)(1 << k);
+                    float sn, cs;
+                    __sincosf(x * f, &sn, &cs);
+                    r += f * (cs * y[3 + 6 * k + d] - sn * y[3 + 6 * k + 3 + d]);
+                }
+                d_nrm[gp * 3 + d] = r;
+            }
+        }
+        // ---- feature vector: g_fv = gA_r0 . W_R0[:, 81:]  (no activation between the colour MLP and the rendering MLP)
+        zero_acc(acc);
+        layer_mma(Wr0ft, HID, HID, H, Wc, acc, nq, ph, lane);   // its first barrier also fences the scratch reads above
+        epilogue_grad<0>(H, acc, nq, ph, lane);
+        __syncthreads();
+        store_tile(H, g_fv, p0, B);
+        s_c1 += tile_colsum<1>(H);
+        hr = load_tile_regs(hc, p0, B);
+        zero_acc(acc);
+        layer_mma(Wc1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        store_tile_regs(H, hr);
+        __syncthreads();
+        epilogue_grad<1>(H, acc, nq, ph, lane);
+        stage_small(Wc, Wc0t);
+        __syncthreads();
+        store_tile(H, gA_hc, p0, B);
+        s_c0 += tile_colsum<1>(H);
+        if (wave < 4) {
+            const f32x16 y = small_mma(Wc, H, wave, lane);
+            float *srow = S + (size_t)(wave * 32 + (lane & 31)) * SP;
+#pragma unroll
+            for (int i = 0; i < 16; i++) srow[(i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)] = y[i];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BM * NFC; idx += kThreads) {   // coalesced fp32 rows for the hash scatter
+            const int row = idx >> 5, c = idx & 31;
+            if (p0 + row < B) g_featc[(size_t)(p0 + row) * NFC + c] = S[(size_t)row * SP + c];
+        }
+        __syncthreads();
+    }
+    if (gb && threadIdx.x < HID) {
+        unsafeAtomicAdd(gb + threadIdx.x, s_r1);
+        unsafeAtomicAdd(gb + HID + threadIdx.x, s_r0);
+        unsafeAtomicAdd(gb + 2 * HID + threadIdx.x, s_c1);
+        unsafeAtomicAdd(gb + 3 * HID + threadIdx.x, s_c0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- weight packing
+// fp32 master matrices -> the bf16 operand images the fused kernels read (sub-blocks, zero padding, transposes): one launch
+// instead of ~20 slice / cast / transpose / pad kernels per iteration.
+struct PackJobs { hsPackJob j[HS_PACK_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_pack_bf16(PackJobs jobs) {
+    const hsPackJob jb = jobs.j[blockIdx.y];
+    const int total = jb.dst_rows * jb.dst_cols;
+    uint16_t *dst = reinterpret_cast<uint16_t *>(jb.dst);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / jb.dst_cols, c = i - r * jb.dst_cols;
+        float v = 0.f;
+        if (r < jb.rows && c < jb.cols)
+            v = jb.transpose ? jb.src[(size_t)(jb.row0 + c) * jb.ld + jb.col0 + r] : jb.src[(size_t)(jb.row0 + r) * jb.ld + jb.col0 + c];
+        dst[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
+int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
+
+constexpr size_t kLdsFwd = ((size_t)BM * HP + 2 * (size_t)HID * WP + (size_t)BM * PP) * sizeof(uint16_t) + (4 * HID + 4) * sizeof(float);
+constexpr size_t kLdsBwd = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (size_t)BM * SP * sizeof(float);
+
+}  // namespace
+
+extern "C" {
+
+int hs_appearance_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *Wc0, const void *Wc1,
+                      const void *Wr0f, const void *Wr0p, const void *Wr1, const void *Wr2, const float *bc0, const float *bc1, const float *br0,
+                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B, void *stream) {
+    if (B == 0) return HS_OK;
+    if (!featc || !points || !dirs || !normals || !Wc0 || !Wc1 || !Wr0f || !Wr0p || !Wr1 || !Wr2 || !bc0 || !bc1 || !br0 || !br1 || !br2 || !xin ||
+        !hc || !fv || !r0 || !r1 || !rgb)
+        return HS_ERR_NULL;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFwd); attr = true; }
+    const int64_t ntiles = (B + BM - 1) / BM;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    k_appear_fwd<<<grid, kThreads, kLdsFwd, (hipStream_t)stream>>>(
+        featc, points, dirs, normals, (const uint16_t *)Wc0, (const uint16_t *)Wc1, (const uint16_t *)Wr0f, (const uint16_t *)Wr0p, (const uint16_t *)Wr1,
+        (const uint16_t *)Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)xin, (uint16_t *)hc, (uint16_t *)fv, (uint16_t *)r0, (uint16_t *)r1, rgb, B);
+    return check_launch();
+}
+
+int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
+                      const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
+                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, void *stream) {
+    if (B == 0) return HS_OK;
+    if (!g_rgb || !rgb || !normals || !r1 || !r0 || !hc || !Wr2t || !Wr1t || !Wr0ft || !Wr0nt || !Wc1t || !Wc0t || !gy || !gA_r1 || !gA_r0 || !g_fv ||
+        !gA_hc || !d_normals || !g_featc)
+        return HS_ERR_NULL;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBwd); attr = true; }
+    const int64_t ntiles = (B + BM - 1) / BM;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    k_appear_bwd<<<grid, kThreads, kLdsBwd, (hipStream_t)stream>>>(
+        g_rgb, rgb, normals, (const uint16_t *)r1, (const uint16_t *)r0, (const uint16_t *)hc, (const uint16_t *)Wr2t, (const uint16_t *)Wr1t,
+        (const uint16_t *)Wr0ft, (const uint16_t *)Wr0nt, (const uint16_t *)Wc1t, (const uint16_t *)Wc0t, (uint16_t *)gy, (uint16_t *)gA_r1,
+        (uint16_t *)gA_r0, (uint16_t *)g_fv, (uint16_t *)gA_hc, d_normals, g_featc, gbias, B);
+    return check_launch();
+}
+
+int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream) {
+    if (n_jobs < 0 || n_jobs > HS_PACK_MAX_JOBS) return HS_ERR_ARG;
+    if (n_jobs == 0) return HS_OK;
+    if (!jobs) return HS_ERR_NULL;
+    PackJobs pj;
+    int max_total = 1;
+    for (int i = 0; i < n_jobs; i++) {
+        pj.j[i] = jobs[i];
+        if (!jobs[i].src || !jobs[i].dst) return HS_ERR_NULL;
+        if (jobs[i].rows > jobs[i].dst_rows || jobs[i].cols > jobs[i].dst_cols || jobs[i].dst_rows <= 0 || jobs[i].dst_cols <= 0) return HS_ERR_ARG;
+        const int t = jobs[i].dst_rows * jobs[i].dst_cols;
+        max_total = t > max_total ? t : max_total;
+    }
+    const int gx = (max_total + 255) / 256 < 64 ? (max_total + 255) / 256 : 64;
+    k_pack_bf16<<<dim3(gx, n_jobs), 256, 0, (hipStream_t)stream>>>(pj);
+    return check_launch();
+}
+
+}  // extern "C"

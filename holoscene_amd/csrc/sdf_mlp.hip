@@ -28,26 +28,12 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "mfma_mlp.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-constexpr int kThreads = 512;
-constexpr int BM = 128;           // points per tile
-constexpr int HID = 256;          // hidden width
-constexpr int HP = HID + 8;       // activation row pitch (bf16)
-constexpr int KC = 32;            // weight chunk depth
-constexpr int WP = KC + 8;        // weight chunk row pitch (bf16)
-constexpr int K0 = 96;            // padded input width (71 -> 96)
 constexpr int NPE = 39;           // 3 + 6*6 positional-encoding values
 constexpr int NFEAT = 32;
-
-__device__ __forceinline__ uint32_t f2bf(float f) {  // round-to-nearest-even; inputs are finite here
-    const uint32_t u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 
 __device__ __forceinline__ float softplus100(float v) {  // branch-free Softplus(beta=100, threshold=20)
 #ifdef HS_EXP_NO_EPILOGUE
@@ -61,75 +47,6 @@ __device__ __forceinline__ float softplus100(float v) {  // branch-free Softplus
     return t > 20.f ? v : sp;
 }
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even)
-    const float2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *reinterpret_cast<const uint32_t *>(&r);
-}
-
-// rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix = 16 KB = 32 B per thread
-struct ChunkRegs { uint4 v[2]; };
-
-__device__ __forceinline__ ChunkRegs load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
-    ChunkRegs r;
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const uint16_t *src = W + (size_t)row * ldw + k0 + half * 16;
-    r.v[0] = *reinterpret_cast<const uint4 *>(src);
-    r.v[1] = *reinterpret_cast<const uint4 *>(src + 8);
-    return r;
-}
-
-__device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs &r) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    uint16_t *dst = Wc + (size_t)row * WP + half * 16;
-    *reinterpret_cast<uint4 *>(dst) = r.v[0];
-    *reinterpret_cast<uint4 *>(dst + 8) = r.v[1];
-}
-
-struct Frags { bf16x8 a[2], b[2]; };
-
-// operand fragments of k-step `s` (16 wide): weights from the chunk buffer, activations from H
-__device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *H, int s, int nq, int ph, int lane) {
-    Frags f;
-    const uint16_t *wbuf = Wc + (size_t)((s >> 1) & 1) * HID * WP + (s & 1) * 16 + (lane >> 5) * 8;
-    const uint16_t *hrow = H + s * 16 + (lane >> 5) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        f.a[i] = *reinterpret_cast<const bf16x8 *>(wbuf + (size_t)(nq * 64 + i * 32 + (lane & 31)) * WP);
-        f.b[i] = *reinterpret_cast<const bf16x8 *>(hrow + (size_t)(ph * 64 + i * 32 + (lane & 31)) * HP);
-    }
-    return f;
-}
-
-// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KC.  wave -> neurons [nq*64,+64), points [ph*64,+64)
-__device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
-                                          int nq, int ph, int lane) {
-    const int nchunks = K / KC;
-    ChunkRegs pre = load_chunk(W, ldw, 0);
-    store_chunk(Wc, pre);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-#ifndef HS_EXP_NO_WLOAD
-        if (c + 1 < nchunks) pre = load_chunk(W, ldw, (c + 1) * KC);
-#endif
-#ifndef HS_EXP_NO_MMA
-        Frags f0 = load_frags(Wc, H, 2 * c, nq, ph, lane);
-        Frags f1 = load_frags(Wc, H, 2 * c + 1, nq, ph, lane);   // in flight while f0's MFMAs run
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a[nt], f0.b[pt], acc[nt][pt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.a[nt], f1.b[pt], acc[nt][pt], 0, 0, 0);
-#endif
-        if (c + 1 < nchunks) store_chunk(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
-        __syncthreads();
-    }
-}
 
 // bias + softplus + bf16 pack, written back into the activation tile (all waves have passed the barrier that ends layer_mma)
 __device__ __forceinline__ void epilogue_softplus(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
@@ -151,15 +68,6 @@ __device__ __forceinline__ void epilogue_softplus(const float *bias_lds, uint16_
             }
         }
     }
-}
-
-__device__ __forceinline__ void zero_acc(f32x16 acc[2][2]) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
 }
 
 template <int NOUT_TILES>  // d_out padded to 32 * NOUT_TILES
@@ -277,10 +185,6 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
 // quad broadcast of the value lane's sigmoid -- no LDS round trip.
 //   X  [M][K0] bf16 (k_trunk_input, zero-padded columns)      H0, H1 [M][256] bf16 = layer OUTPUTS (value row: softplus,
 //   tangent rows: s * pre-activation; hs_softplus_tangent_bwd_h consumes exactly that)     Y [M][d_out] fp32
-__device__ __forceinline__ float quad_bcast0(float v) {  // value held by lane (lane & ~3) of each quad
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, true));
-}
-
 __device__ __forceinline__ float tangent_act(float acc, float bias, bool is_value) {
     const float v = acc + bias;
     const float t = v * 100.f;
@@ -312,14 +216,6 @@ __device__ __forceinline__ void epilogue_tangent(const float *bias_lds, uint16_t
                 *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
             }
         }
-    }
-}
-
-// activation tile -> global, 16 B per lane, rows contiguous (coalesced 512 B per row)
-__device__ __forceinline__ void store_tile(const uint16_t *H, uint16_t *__restrict__ dst, int64_t r0, int64_t M) {
-    for (int idx = threadIdx.x; idx < BM * (HID / 8); idx += kThreads) {
-        const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
-        if (r0 + row < M) *reinterpret_cast<uint4 *>(dst + (size_t)(r0 + row) * HID + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
     }
 }
 
@@ -403,29 +299,6 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
 // operand is read once and every result written once (0.9 GB).  Weight operands arrive TRANSPOSED ([in][out] row-major),
 // so the same D = W . H^T machinery applies.  The value-row rule  gA_v = s*g_v + 100(1-s) * sum_d H_d*g_d  needs the three
 // tangent lanes of the quad: two DPP quad_perm adds.
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
-
-struct TileRegs { uint4 v[BM * (HID / 8) / kThreads]; };   // one [BM][HID] bf16 tile spread over the workgroup (8 x 16 B per thread)
-
-__device__ __forceinline__ TileRegs load_tile_regs(const uint16_t *__restrict__ src, int64_t r0, int64_t M) {
-    TileRegs t;
-#pragma unroll
-    for (int i = 0; i < BM * (HID / 8) / kThreads; i++) {
-        const int idx = threadIdx.x + i * kThreads, row = idx / (HID / 8), seg = idx - row * (HID / 8);
-        t.v[i] = r0 + row < M ? *reinterpret_cast<const uint4 *>(src + (size_t)(r0 + row) * HID + seg * 8) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    return t;
-}
-
-__device__ __forceinline__ void store_tile_regs(uint16_t *H, const TileRegs &t) {
-#pragma unroll
-    for (int i = 0; i < BM * (HID / 8) / kThreads; i++) {
-        const int idx = threadIdx.x + i * kThreads, row = idx / (HID / 8), seg = idx - row * (HID / 8);
-        *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = t.v[i];
-    }
-}
-
 __device__ __forceinline__ float bwd_act(float G, float h, bool is_value) {
     const float e = __builtin_amdgcn_exp2f(h * (-100.f * 1.44269504f));   // value lanes: 1 - sigmoid(100 v), from h = softplus100(v)
     const float s = quad_bcast0(1.f - e), c = quad_bcast0(100.f * e);
@@ -461,16 +334,6 @@ __device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int 
     }
 }
 
-// bias gradient: column sums over the VALUE rows (every 4th) of the cotangent tile
-__device__ __forceinline__ float value_row_colsum(const uint16_t *H) {
-    float s = 0.f;
-    if (threadIdx.x < HID) {
-#pragma unroll 8
-        for (int r = 0; r < BM; r += 4) s += __uint_as_float((uint32_t)H[(size_t)r * HP + threadIdx.x] << 16);
-    }
-    return s;
-}
-
 template <int KP>  // padded d_out: 32 or 64
 __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restrict__ g, const uint16_t *__restrict__ H1, const uint16_t *__restrict__ H0,
                                                          const uint16_t *__restrict__ W2t, const uint16_t *__restrict__ W1t,
@@ -502,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         epilogue_bwd(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, gA1, r0, M);
-        sum1 += value_row_colsum(H);
+        sum1 += tile_colsum<4>(H);
         hr = load_tile_regs(H0, r0, M);
         zero_acc(acc);
         layer_mma(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
@@ -511,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         epilogue_bwd(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, gA0, r0, M);
-        sum0 += value_row_colsum(H);
+        sum0 += tile_colsum<4>(H);
         __syncthreads();
     }
     if (threadIdx.x < HID) {

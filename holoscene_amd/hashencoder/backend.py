@@ -30,6 +30,12 @@ class hsHashLayout(ctypes.Structure):
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate)]
 
 
+class hsPackJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ld", ctypes.c_int32), ("row0", ctypes.c_int32), ("col0", ctypes.c_int32),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_rows", ctypes.c_int32), ("dst_cols", ctypes.c_int32),
+                ("transpose", ctypes.c_int32)]
+
+
 ABI_VERSION = 2
 
 
@@ -66,7 +72,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
 
 
 def _check(rc, what):
@@ -265,6 +271,39 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                   ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), _stream()), "hs_sdf_mlp_fwd")
+
+    @staticmethod
+    def pack_bf16(jobs):
+        """jobs: list of (src fp32 2-D tensor, dst bf16 2-D tensor, row0, col0, rows, cols, transpose); rows/cols = valid extent
+        in destination orientation, the rest of dst is zero-filled."""
+        lib = load_library()
+        arr = (hsPackJob * len(jobs))()
+        for a, (src, dst, row0, col0, rows, cols, tr) in zip(arr, jobs):
+            a.src, a.dst = _dev(src, "src").value, _dev(dst, "dst", torch.bfloat16).value
+            a.ld, a.row0, a.col0, a.rows, a.cols = src.shape[1], row0, col0, rows, cols
+            a.dst_rows, a.dst_cols, a.transpose = dst.shape[0], dst.shape[1], int(tr)
+        _check(lib.hs_pack_bf16(arr, len(jobs), _stream()), "hs_pack_bf16")
+
+    @staticmethod
+    def appearance_fwd(featc, points, dirs, normals, W, biases, xin, hc, fv, r0, r1, rgb):
+        """W: dict of packed bf16 operands (Wc0, Wc1, Wr0f, Wr0p, Wr1, Wr2); biases: (bc0, bc1, br0, br1, br2) fp32."""
+        lib = load_library()
+        bf = torch.bfloat16
+        _check(lib.hs_appearance_fwd(_dev(featc, "featc"), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
+                                     *[_dev(W[k], k, bf) for k in ("Wc0", "Wc1", "Wr0f", "Wr0p", "Wr1", "Wr2")],
+                                     *[_dev(b, "bias") for b in biases], _dev(xin, "xin", bf), _dev(hc, "hc", bf), _dev(fv, "fv", bf),
+                                     _dev(r0, "r0", bf), _dev(r1, "r1", bf), _dev(rgb, "rgb"), ctypes.c_int64(featc.shape[0]), _stream()),
+               "hs_appearance_fwd")
+
+    @staticmethod
+    def appearance_bwd(g_rgb, rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gbias):
+        lib = load_library()
+        bf = torch.bfloat16
+        _check(lib.hs_appearance_bwd(_dev(g_rgb, "g_rgb"), _dev(rgb, "rgb"), _dev(normals, "normals"), _dev(r1, "r1", bf), _dev(r0, "r0", bf),
+                                     _dev(hc, "hc", bf), *[_dev(W[k], k, bf) for k in ("Wr2t", "Wr1t", "Wr0ft", "Wr0nt", "Wc1t", "Wc0t")],
+                                     _dev(gy, "gy", bf), _dev(gA_r1, "gA_r1", bf), _dev(gA_r0, "gA_r0", bf), _dev(g_fv, "g_fv", bf),
+                                     _dev(gA_hc, "gA_hc", bf), _dev(d_normals, "d_normals"), _dev(g_featc, "g_featc"), _dev(gbias, "gbias"),
+                                     ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance_bwd")
 
     @staticmethod
     def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor, gate=None):

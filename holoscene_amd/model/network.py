@@ -219,6 +219,78 @@ class _fused_trunk(torch.autograd.Function):
         return None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
 
 
+# "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
+# bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
+APPEARANCE_IMPL = os.environ.get("HOLOSCENE_APPEARANCE_IMPL", "mfma")
+
+
+class _fused_appearance(torch.autograd.Function):
+    """(points, view dirs, normals, colour hash table, colour-MLP and rendering-MLP weights) -> rgb [B,3].
+
+    forward: colour hash encode -> k_appear_fwd (5 layers, activations stay on the CU; layer outputs written once).
+    backward: k_appear_bwd (whole data-gradient chain incl. d/d normals and d/d colour features + bias sums), library
+    split-M GEMMs for the five weight gradients, scatter into the colour table gradient."""
+
+    @staticmethod
+    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2):
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        be = _be._backend
+        points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
+        x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
+        B = points.shape[0]
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        dev, bf = points.device, torch.bfloat16
+        featc = torch.empty(B, L * C, device=dev)
+        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None)
+        new = lambda r, c: torch.empty(r, c, device=dev, dtype=bf)  # noqa: E731
+        W = {"Wc0": new(256, 32), "Wc1": new(256, 256), "Wr0f": new(256, 256), "Wr0p": new(256, 96), "Wr1": new(256, 256), "Wr2": new(32, 256),
+             "Wr2t": new(256, 32), "Wr1t": new(256, 256), "Wr0ft": new(256, 256), "Wr0nt": new(32, 256), "Wc1t": new(256, 256), "Wc0t": new(32, 256)}
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        wc0, wc1, wr0, wr1, wr2 = f32(Wc0), f32(Wc1), f32(Wr0), f32(Wr1), f32(Wr2)
+        be.pack_bf16([(wc0, W["Wc0"], 0, 0, 256, 32, False), (wc1, W["Wc1"], 0, 0, 256, 256, False), (wr0, W["Wr0f"], 0, 81, 256, 256, False),
+                      (wr0, W["Wr0p"], 0, 0, 256, 81, False), (wr1, W["Wr1"], 0, 0, 256, 256, False), (wr2, W["Wr2"], 0, 0, 3, 256, False),
+                      (wr2, W["Wr2t"], 0, 0, 256, 3, True), (wr1, W["Wr1t"], 0, 0, 256, 256, True), (wr0, W["Wr0ft"], 0, 81, 256, 256, True),
+                      (wr0, W["Wr0nt"], 0, 54, 27, 256, True), (wc1, W["Wc1t"], 0, 0, 256, 256, True), (wc0, W["Wc0t"], 0, 0, 32, 256, True)])
+        xin, hc, fv, r0, r1 = new(B, 128), new(B, 256), new(B, 256), new(B, 256), new(B, 256)
+        rgb = torch.empty(B, 3, device=dev)
+        be.appearance_fwd(featc, points, dirs, normals, W, (f32(bc0), f32(bc1), f32(br0), f32(br1), f32(br2)), xin, hc, fv, r0, r1, rgb)
+        ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, xin, hc, fv, r0, r1, *[W[k] for k in ("Wr2t", "Wr1t", "Wr0ft", "Wr0nt", "Wc1t", "Wc0t")])
+        ctx.cfg = (B, C, L, S, Hres)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        x01, embeddings, offsets, normals, rgb, xin, hc, fv, r0, r1, Wr2t, Wr1t, Wr0ft, Wr0nt, Wc1t, Wc0t = ctx.saved_tensors
+        B, C, L, S, Hres = ctx.cfg
+        be = _be._backend
+        dev, bf = rgb.device, torch.bfloat16
+        new = lambda c: torch.empty(B, c, device=dev, dtype=bf)  # noqa: E731
+        gy, gA_r1, gA_r0, g_fv, gA_hc = new(32), new(256), new(256), new(256), new(256)
+        d_normals = torch.empty(B, 3, device=dev)
+        g_featc = torch.empty(B, L * C, device=dev)
+        gb = torch.zeros(4, 256, device=dev)
+        W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
+        be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb)
+        need_w = ctx.needs_input_grad[8]
+        gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbr2 = None
+        if need_w:
+            gWr2 = _wgrad_rows(gy, r1)[:3]
+            Sg = _split_rows(B)
+            gbr2 = gy.view(Sg, B // Sg, 32).sum(1, dtype=torch.float32).sum(0)[:3]
+            gWr1 = _wgrad_rows(gA_r1, r0)
+            gWr0 = torch.cat([_wgrad_rows(gA_r0, xin)[:, 32:113], _wgrad_rows(gA_r0, fv)], 1)
+            gWc1 = _wgrad_rows(g_fv, hc)
+            gWc0 = _wgrad_rows(gA_hc, xin)[:, :32]
+        g_emb = None
+        if ctx.needs_input_grad[3]:
+            table = ctx.table
+            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
+            g_emb = None if inplace else target
+        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2)
+
+
 class _render_input(torch.autograd.Function):
     """[posenc(points), posenc(view_dirs), posenc(normals), feature_vectors] in one kernel; the backward returns
     the gradients of the two differentiable inputs (normals, feature_vectors)."""
@@ -801,6 +873,16 @@ class HoloSceneNetwork(nn.Module):
         self.all_mesh_bbox_dict = None  # only ever set by the Stage-2 trainer (holoscene_train_post.py:715-731)
 
     # ---------------------------------------------------------------- compositing (network.py:1803-1824)
+    def _fused_appearance_supported(self, x):
+        net, rn = self.implicit_network, self.rendering_network
+        if not (x.is_cuda and net.mlp_bf16 and rn.mlp_bf16 and net.color_grid_feature and rn.mode == "idr" and rn.num_layers == 4):
+            return False
+        mlp = net.color_grid_feature_map_mlp
+        return (rn.multires_view == 4 and rn.multires_point == 4 and rn.multires_normal == 4 and net.color_grid_feature_dim == 32
+                and tuple(mlp[0].weight.shape) == (256, 32) and tuple(mlp[2].weight.shape) == (256, 256)
+                and tuple(rn.lin0.weight_v.shape) == (256, 337) and tuple(rn.lin1.weight_v.shape) == (256, 256)
+                and tuple(rn.lin2.weight_v.shape) == (3, 256))
+
     def volume_rendering(self, z_vals, sdf):
         density = self.density(sdf).reshape(-1, z_vals.shape[1])
         dists = z_vals[:, 1:] - z_vals[:, :-1]
@@ -937,11 +1019,17 @@ class HoloSceneNetwork(nn.Module):
         sdf_raw, J_main = y_all[:n_main], J_all[:n_main]
         sdf, idx_min = sdf_raw.min(dim=-1, keepdim=True)
         gradients = torch.gather(J_main, 1, idx_min.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
-        if net.color_grid_feature:
-            feature_vectors = net._color_features(points_flat)
-        else:
+        if not net.color_grid_feature:
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
-        rgb = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors, indices).reshape(-1, N_samples, 3)
+        if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
+            enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
+            rgb = _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
+                                          int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
+                                          mlp[2].bias, rn.lin0.weight, rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias)
+            rgb = rgb.reshape(-1, N_samples, 3)
+        else:
+            feature_vectors = net._color_features(points_flat)
+            rgb = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors, indices).reshape(-1, N_samples, 3)
         if COMPOSITE_IMPL == "hip":
             if not z_vals.is_cuda:
                 raise RuntimeError("fused compositing needs CUDA tensors (set HOLOSCENE_COMPOSITE_IMPL=torch explicitly for the "

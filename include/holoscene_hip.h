@@ -247,6 +247,43 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, int64_t M, void *stream);
 
+/* ------------------------------------------------------------------ 7b. fused colour branch of a rendered sample
+ * Replaces, per rendered point: color_grid_feature_map_mlp (model/network.py:99-101, 186-188), the posenc + concat of
+ * RenderingNetwork.forward (:586-596) and its three weight-normalised Linear layers + ReLU + sigmoid (:598-612), and
+ * their autograd backward.  bf16 operands, fp32 accumulation.  B points.
+ *   featc [B,32] fp32 colour hash features; points, dirs, normals [B,3] fp32
+ *   Wc0 [256,32], Wc1 [256,256]: colour MLP;  W_R0 [256,337] split into Wr0p [256,96] (columns 0..80 = encoded point |
+ *   view dir | normal, zero-padded) and Wr0f [256,256] (columns 81..336 = feature vector);  Wr1 [256,256];  Wr2 [32,256]
+ *   (rows 0..2 used).  All bf16 row-major (hs_pack_bf16 builds them); biases fp32 (br2: 3 values).
+ *   Kept for the backward pass / weight gradients, all bf16: xin [B,128] = [featc | encoded inputs], hc, fv, r0, r1 [B,256]
+ *   (layer outputs).  rgb [B,3] fp32 = sigmoid(...). */
+int hs_appearance_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *Wc0, const void *Wc1,
+                      const void *Wr0f, const void *Wr0p, const void *Wr1, const void *Wr2, const float *bc0, const float *bc1, const float *br0,
+                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B, void *stream);
+
+/* Backward data path.  Transposed bf16 weights: Wr2t [256,32], Wr1t [256,256], Wr0ft [256,256] (= Wr0f^T), Wr0nt [32,256]
+ * (rows j < 27 = column 54+j of W_R0: the encoded-normal inputs), Wc1t [256,256], Wc0t [32,256].
+ * Outputs: gy [B,32] bf16 (cotangent of the pre-sigmoid outputs, columns 0..2), gA_r1, gA_r0, g_fv, gA_hc [B,256] bf16
+ * (pre-activation cotangents; g_fv = cotangent of the feature vector), d_normals [B,3], g_featc [B,32] fp32,
+ * gbias [4,256] fp32 (+=; rows: br1, br0, bc1, bc0; may be NULL). */
+int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
+                      const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
+                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, void *stream);
+
+/* fp32 master matrices -> bf16 operand images in ONE launch: dst [dst_rows, dst_cols] (row-major bf16) receives the
+ * [rows, cols] block of src (leading dimension ld) starting at (row0, col0) -- or, with transpose != 0, its transpose
+ * (dst[r][c] = src[row0+c][col0+r]) -- zero-padded to the destination shape. */
+#define HS_PACK_MAX_JOBS 16
+typedef struct hsPackJob {
+    const float *src;
+    void *dst;
+    int32_t ld, row0, col0;
+    int32_t rows, cols;         /* valid extent, in destination orientation */
+    int32_t dst_rows, dst_cols;
+    int32_t transpose;
+} hsPackJob;
+int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
