@@ -164,13 +164,13 @@ class _fused_trunk(torch.autograd.Function):
         X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
         _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
         F_in, d_out = W0.shape[1], W2.shape[0]
-        w0 = torch.zeros(256, _TRUNK_PITCH, device=dev, dtype=bf)
-        w0[:, :F_in] = W0
-        w1 = W1.to(bf).contiguous()
-        w2 = torch.zeros(32 * ((d_out + 31) // 32), 256, device=dev, dtype=bf)
-        w2[:d_out] = W2
-        w2t = w2.t().contiguous()          # [256, KP]: the backward kernel multiplies by the transposes
-        w1t = w1.t().contiguous()
+        KP = 32 * ((d_out + 31) // 32)
+        w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
+                      torch.empty(KP, 256, device=dev, dtype=bf))
+        w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
+        f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
+        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
+                                (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True)])
         M = 4 * B
         H0 = torch.empty(M, 256, device=dev, dtype=bf)
         H1 = torch.empty(M, 256, device=dev, dtype=bf)
@@ -618,14 +618,15 @@ class ObjectImplicitNetworkGrid(nn.Module):
         if getattr(self, "_packed_cache", None) is not None:
             return self._packed_cache
         l0, l1, l2 = self._lins()
-        dev = l0.weight_v.device
-        w0 = torch.zeros(256, 96, device=dev, dtype=torch.bfloat16)
-        w0[:, :l0.in_features] = l0.weight.to(torch.bfloat16)
+        dev, bf = l0.weight_v.device, torch.bfloat16
         n2 = 32 * ((l2.out_features + 31) // 32)
-        w2 = torch.zeros(n2, 256, device=dev, dtype=torch.bfloat16)
-        w2[:l2.out_features] = l2.weight.to(torch.bfloat16)
-        self._packed_cache = (w0, l0.bias.detach().float().contiguous(), l1.weight.to(torch.bfloat16).contiguous(),
-                              l1.bias.detach().float().contiguous(), w2, l2.bias.detach().float().contiguous())
+        w0, w1, w2 = torch.empty(256, 96, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf), torch.empty(n2, 256, device=dev, dtype=bf)
+        with torch.no_grad():
+            f0, f1, f2 = l0.weight.float().contiguous(), l1.weight.float().contiguous(), l2.weight.float().contiguous()
+        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False), (f1, w1, 0, 0, 256, 256, False),
+                                (f2, w2, 0, 0, l2.out_features, 256, False)])
+        self._packed_cache = (w0, l0.bias.detach().float().contiguous(), w1, l1.bias.detach().float().contiguous(), w2,
+                              l2.bias.detach().float().contiguous())
         return self._packed_cache
 
     def invalidate_packed_weights(self):
