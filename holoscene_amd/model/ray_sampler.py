@@ -265,7 +265,12 @@ class ErrorBoundSampler(RaySampler):
         self.last_rounds = rounds
         if self.N_samples_extra > 0:
             if model.training:
-                perm = rng["perm"] if "perm" in rng else torch.randperm(m)
+                if "perm" in rng:
+                    perm = rng["perm"]
+                elif self.cpu_rng:
+                    perm = torch.randperm(m)
+                else:   # device draw: no pageable host->device copy in the launch-bound tail of the sampler
+                    perm = torch.randperm(m, device=dev)
                 pick = perm[: self.N_samples_extra].to(dev).long().contiguous()
             else:
                 pick = torch.linspace(0, m - 1, self.N_samples_extra, device=dev).long()

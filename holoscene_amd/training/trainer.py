@@ -175,12 +175,20 @@ class Stage1Trainer:
         if entry is None:
             entry = self._capture(key, fresh)   # capture replays nothing: run the body once more via replay below
         st = entry["static"]
-        self._copy_into(st["rays"], rays)
-        st["z_vals"].copy_(z_vals)
-        st["z_eik"].copy_(z_eik)
-        self._copy_into(st["gt"], fresh["gt"])
+        # all live inputs -> the graph's static input block in ONE multi-tensor copy (was ~14 copy launches in the
+        # launch-bound stretch between the sampler's last host sync and the graph launch)
+        pairs = [(st["z_vals"], z_vals), (st["z_eik"], z_eik)]
+        pairs += [(st["rays"][k], rays[k]) for k in ("ray_dirs", "cam_loc", "depth_scale", "rot")]
+        pairs += [(st["gt"][k], v) for k, v in fresh["gt"].items()]
         if with_bg:
-            self._copy_into(st["bg"], bg)
+            pairs += [(st["bg"][k], v) for k, v in bg.items() if torch.is_tensor(v)]
+        groups = {}
+        for d, s_ in pairs:
+            groups.setdefault((d.dtype, s_.dtype), ([], []))
+            groups[(d.dtype, s_.dtype)][0].append(d)
+            groups[(d.dtype, s_.dtype)][1].append(s_)
+        for dl, sl in groups.values():
+            torch._foreach_copy_(dl, sl)
         entry["graph"].replay()
         if self.world_size > 1:
             dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
