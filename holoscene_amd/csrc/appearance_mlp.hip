@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
         asm volatile("" ::: "memory");
         const int64_t p0 = tile * BM;
         {   // ---- inputs: parts 0..2 encode one vector each into P, part 3 converts the colour features into H[:, 0:32)
-            const int p = threadIdx.x & (BM - 1), part = threadIdx.x >> 7;
+            const int p = threadIdx.x & (BM - 1), part = threadIdx.x / BM;
             const int64_t gp = p0 + p;
             const bool ok = gp < B;
             if (part < 3) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
         stage_small(Wc, Wr2);
         __syncthreads();
         store_tile(H, r1o, p0, B);
-        if (wave < 4) {
+        if (wave < kRowWaves) {
             const f32x16 y = small_mma(Wc, H, wave, lane);
             const int64_t gp = p0 + wave * 32 + (lane & 31);
             if (lane < 32 && gp < B) {   // outputs 0..2 live in accumulator entries 0..2 of the lower half-wave
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         store_tile(H, gA_r0, p0, B);
         s_r0 += tile_colsum<1>(H);
         // ---- normals: cotangent of the 27 encoded-normal inputs (columns 54..80 of W_R0), then the posenc chain rule
-        if (wave < 4) {
+        if (wave < kRowWaves) {
             const f32x16 y = small_mma(Wc, H, wave, lane);
             float *srow = S + (size_t)(wave * 32 + (lane & 31)) * SP;
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         __syncthreads();
         store_tile(H, gA_hc, p0, B);
         s_c0 += tile_colsum<1>(H);
-        if (wave < 4) {
+        if (wave < kRowWaves) {
             const f32x16 y = small_mma(Wc, H, wave, lane);
             float *srow = S + (size_t)(wave * 32 + (lane & 31)) * SP;
 #pragma unroll
@@ -369,7 +369,7 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFwd); attr = true; }
     const int64_t ntiles = (B + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     k_appear_fwd<<<grid, kThreads, kLdsFwd, (hipStream_t)stream>>>(
         featc, points, dirs, normals, (const uint16_t *)Wc0, (const uint16_t *)Wc1, (const uint16_t *)Wr0f, (const uint16_t *)Wr0p, (const uint16_t *)Wr1,
         (const uint16_t *)Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)xin, (uint16_t *)hc, (uint16_t *)fv, (uint16_t *)r0, (uint16_t *)r1, rgb, B);
@@ -386,7 +386,7 @@ int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBwd); attr = true; }
     const int64_t ntiles = (B + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     k_appear_bwd<<<grid, kThreads, kLdsBwd, (hipStream_t)stream>>>(
         g_rgb, rgb, normals, (const uint16_t *)r1, (const uint16_t *)r0, (const uint16_t *)hc, (const uint16_t *)Wr2t, (const uint16_t *)Wr1t,
         (const uint16_t *)Wr0ft, (const uint16_t *)Wr0nt, (const uint16_t *)Wc1t, (const uint16_t *)Wc0t, (uint16_t *)gy, (uint16_t *)gA_r1,

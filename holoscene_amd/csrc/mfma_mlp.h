@@ -16,8 +16,13 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kThreads = 512;
-constexpr int BM = 128;           // points per tile
+#ifndef HS_MLP_BM
+#define HS_MLP_BM 128
+#endif
+constexpr int BM = HS_MLP_BM;     // rows per tile: 128 (8 waves, one workgroup per CU) or 64 (4 waves, two workgroups per CU)
+constexpr int kThreads = 4 * BM;
+constexpr int kRowWaves = BM / 32;  // waves that take part in a narrow (<= 32 outputs) last layer: 32 rows each
+constexpr int kGridCap = 256 * (128 / BM);
 constexpr int HID = 256;          // hidden width
 constexpr int HP = HID + 8;       // activation row pitch (bf16)
 constexpr int KC = 32;            // weight chunk depth
@@ -37,23 +42,25 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // one v_cvt_
     return *reinterpret_cast<const uint32_t *>(&r);
 }
 
-// rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix = 16 KB = 32 B per thread
-struct ChunkRegs { uint4 v[2]; };
+// rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix = 16 KB, spread over the workgroup
+constexpr int kChunkTPR = kThreads / HID;            // threads per weight row: 2 (512 threads) or 1 (256 threads)
+constexpr int kChunkVec = KC / 8 / kChunkTPR;        // 16-byte vectors per thread: 2 or 4
+struct ChunkRegs { uint4 v[kChunkVec]; };
 
 __device__ __forceinline__ ChunkRegs load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
     ChunkRegs r;
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const uint16_t *src = W + (size_t)row * ldw + k0 + half * 16;
-    r.v[0] = *reinterpret_cast<const uint4 *>(src);
-    r.v[1] = *reinterpret_cast<const uint4 *>(src + 8);
+    const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
+    const uint16_t *src = W + (size_t)row * ldw + k0 + part * (8 * kChunkVec);
+#pragma unroll
+    for (int i = 0; i < kChunkVec; i++) r.v[i] = *reinterpret_cast<const uint4 *>(src + 8 * i);
     return r;
 }
 
 __device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs &r) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-    uint16_t *dst = Wc + (size_t)row * WP + half * 16;
-    *reinterpret_cast<uint4 *>(dst) = r.v[0];
-    *reinterpret_cast<uint4 *>(dst + 8) = r.v[1];
+    const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
+    uint16_t *dst = Wc + (size_t)row * WP + part * (8 * kChunkVec);
+#pragma unroll
+    for (int i = 0; i < kChunkVec; i++) *reinterpret_cast<uint4 *>(dst + 8 * i) = r.v[i];
 }
 
 struct Frags { bf16x8 a[2], b[2]; };
@@ -142,6 +149,9 @@ __device__ __forceinline__ void store_tile_regs(uint16_t *H, const TileRegs &t) 
 
 // activation tile -> global, 16 B per lane, rows contiguous (coalesced 512 B per row)
 __device__ __forceinline__ void store_tile(const uint16_t *H, uint16_t *__restrict__ dst, int64_t r0, int64_t M) {
+#ifdef HS_EXP_NO_STORE
+    if (r0 >= 0) return;
+#endif
     for (int idx = threadIdx.x; idx < BM * (HID / 8); idx += kThreads) {
         const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
         if (r0 + row < M) *reinterpret_cast<uint4 *>(dst + (size_t)(r0 + row) * HID + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
         // ---- input features: H[p][0..K0).  Four threads per point; sin/cos pairs from the hardware v_sin/v_cos units
         //      (arguments <= 2^5 * 1.75 rad, well inside their range; the bf16 destination keeps 8 bits anyway).
         {
-            const int p = threadIdx.x & (BM - 1), part = threadIdx.x >> 7;   // part 0..3
+            const int p = threadIdx.x & (BM - 1), part = threadIdx.x / BM;   // part 0..3
             const int64_t gp = p0 + p;
             const bool ok = gp < B;
             uint16_t *row = H + (size_t)p * HP;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
         }
         __syncthreads();
-        if (wave < 4) {  // 4 point tiles of 32; waves 4..7 have nothing to do in the narrow last layer
+        if (wave < kRowWaves) {  // 4 point tiles of 32; waves 4..7 have nothing to do in the narrow last layer
             f32x16 y[NOUT_TILES];
 #pragma unroll
             for (int t = 0; t < NOUT_TILES; t++)
@@ -186,6 +186,9 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
 //   X  [M][K0] bf16 (k_trunk_input, zero-padded columns)      H0, H1 [M][256] bf16 = layer OUTPUTS (value row: softplus,
 //   tangent rows: s * pre-activation; hs_softplus_tangent_bwd_h consumes exactly that)     Y [M][d_out] fp32
 __device__ __forceinline__ float tangent_act(float acc, float bias, bool is_value) {
+#ifdef HS_EXP_NO_EPILOGUE
+    return acc + bias;
+#endif
     const float v = acc + bias;
     const float t = v * 100.f;
     const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
         }
         __syncthreads();
         store_tile(H, H1, r0, M);
-        if (wave < 4) {
+        if (wave < kRowWaves) {
             f32x16 y[NOUT_TILES];
 #pragma unroll
             for (int t = 0; t < NOUT_TILES; t++)
@@ -300,6 +303,9 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
 // so the same D = W . H^T machinery applies.  The value-row rule  gA_v = s*g_v + 100(1-s) * sum_d H_d*g_d  needs the three
 // tangent lanes of the quad: two DPP quad_perm adds.
 __device__ __forceinline__ float bwd_act(float G, float h, bool is_value) {
+#ifdef HS_EXP_NO_EPILOGUE
+    return G + h;
+#endif
     const float e = __builtin_amdgcn_exp2f(h * (-100.f * 1.44269504f));   // value lanes: 1 - sigmoid(100 v), from h = softplus100(v)
     const float s = quad_bcast0(1.f - e), c = quad_bcast0(100.f * e);
     const float prod = is_value ? 0.f : h * G;
@@ -396,7 +402,7 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
     if (!x || !feat || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out_min) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
     const int64_t ntiles = (B + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (111 KB LDS), tiles strided across the grid
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);  // one workgroup per CU (111 KB LDS), tiles strided across the grid
     hipStream_t st = (hipStream_t)stream;
     if (d_out <= 32) {
         static bool attr1 = false;
@@ -419,7 +425,7 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
     if (!X || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !H0 || !H1 || !Y) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
     const int64_t ntiles = (M + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     hipStream_t st = (hipStream_t)stream;
     if (d_out <= 32) {
         static bool attr1 = false;
@@ -442,7 +448,7 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
     if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
     const int64_t ntiles = (M + BM - 1) / BM;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     hipStream_t st = (hipStream_t)stream;
     if (g_pitch == 32) {
         static bool attr1 = false;
