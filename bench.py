@@ -160,7 +160,8 @@ def main():
     def step():
         idx, mi, gt = scene.next_batch()
         tr.train_step(idx, mi, gt)
-        rounds_seen.append(tr.model.ray_sampler.last_rounds)
+        r_ = tr.model.ray_sampler._rounds       # int, or a device tensor (device-controlled sampler): no sync inside the loop
+        rounds_seen.append(r_.clone() if torch.is_tensor(r_) else r_)
 
     def barrier():
         if world > 1:
@@ -242,7 +243,8 @@ def main():
                 t0 = time.perf_counter()
             idx, mi, gt = scene.next_batch()
             tr2.train_step(idx, mi, gt)
-            r2.append(tr2.model.ray_sampler.last_rounds)
+            r_ = tr2.model.ray_sampler._rounds
+            r2.append(r_.clone() if torch.is_tensor(r_) else r_)
         barrier()
         e2 = time.perf_counter() - t0
         if world > 1:
@@ -250,7 +252,7 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             e2 = float(t)
         second = {"beta": 0.1, "value": round(args.rays * world * n2 / e2, 1), "unit": "rays/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
-                  "sampler_rounds_mean": round(sum(r2[8:]) / n2, 2)}
+                  "sampler_rounds_mean": round(sum(int(r_) for r_ in r2[8:]) / n2, 2)}
     if rank == 0:
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
@@ -260,7 +262,7 @@ def main():
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
                                    f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
-                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(rounds_seen) / max(1, len(rounds_seen)), 2),
+                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(int(r_) for r_ in rounds_seen) / max(1, len(rounds_seen)), 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }

@@ -145,11 +145,12 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
 __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
                                                            const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
                                                            float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
-                                                           int beta_iters, float *__restrict__ beta_max, int R, hsGate gate) {
+                                                           int beta_iters, float *__restrict__ beta_max, int R, hsGate gate, const int32_t *__restrict__ m_dev) {
     extern __shared__ float lds[];
     if (gate_closed(gate)) return;
     const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
     if (r >= R) return;
+    if (m_dev) m_old = *m_dev;                      // device-controlled rounds: the merged count lives in hsSamplerCtl
     const int m = m_old + s_new;
     float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m, *sc = lds + 6 * m;
     float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
@@ -201,13 +202,52 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     }
 }
 
+
+// ------------------------------------------------------------------------------------ device-side round control
+// Algorithm 1's loop test (ray_sampler.py:204, 130-287) without the host: after round r's update kernel, one thread
+// advances the counters and clears `running` when max beta no longer exceeds beta0 or the round budget is spent.
+// Every later kernel of the (fully unrolled) loop is gated on `running` and returns at once.
+__global__ void k_sampler_step(hsSamplerCtl *ctl, const float *__restrict__ beta_max, const float *__restrict__ beta0, int s_new, int max_rounds) {
+    if (!(ctl->running > ctl->half)) return;
+    ctl->m += s_new;
+    ctl->rounds += 1;
+    if (!(*beta_max > *beta0) || ctl->rounds >= max_rounds) ctl->running = 0.f;
+}
+
+// n_extra DISTINCT indices uniformly from [0, m): the first n_extra entries of a random permutation (ray_sampler.py:269,
+// torch.randperm(m)[:n_extra]) by a partial Fisher-Yates shuffle driven by u[j] ~ U[0,1); u == NULL: eval mode,
+// torch.linspace(0, m-1, n_extra).long() (:271).
+__global__ void k_sampler_pick(const hsSamplerCtl *__restrict__ ctl, const float *__restrict__ u, int n_extra, int64_t *__restrict__ pick) {
+    __shared__ int idx[HS_SAMPLER_MAX_M];
+    const int m = ctl->m;
+    if (u == nullptr) {
+        for (int j = threadIdx.x; j < n_extra; j += blockDim.x) {
+            const float step = (float)(m - 1) / (float)(n_extra - 1 > 0 ? n_extra - 1 : 1);
+            const float v = j < n_extra / 2 ? step * (float)j : (float)(m - 1) - step * (float)(n_extra - 1 - j);
+            pick[j] = (int64_t)v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) idx[i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < n_extra && j < m; j++) {
+            int k = j + (int)(u[j] * (float)(m - j));
+            k = k > m - 1 ? m - 1 : k;
+            const int t = idx[j]; idx[j] = idx[k]; idx[k] = t;
+            pick[j] = idx[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ draw
 // mode 0: pdf ~ error-bound opacity (+tiny); mode 1: pdf ~ rendering weights (+1e-5).  u: explicit [R,n_out] or NULL = linspace(0,1,n_out)
 __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
                                                          const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
-                                                         int n_out, float *__restrict__ out, int R, hsGate gate) {
+                                                         int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev) {
     extern __shared__ float lds[];
     if (gate_closed(gate)) return;
+    if (m_dev) m = *m_dev;
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
@@ -388,22 +428,37 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 extern "C" {
 
 int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
-                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate, void *stream) {
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate, const int32_t *m_dev,
+                      void *stream) {
     if (R <= 0) return HS_OK;
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
-    const int m = m_old + s_new;
+    const int m = m_dev ? ld : m_old + s_new;   // device-side count: size the scratch for the row capacity
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
     k_sampler_update<<<dim3(R), dim3(kUpd), (6 * m + 3 * kUpdWaves) * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
-                                                                                           eps, beta_iters, beta_max, R, gate ? *gate : hsGate{nullptr, nullptr});
+                                                                                           eps, beta_iters, beta_max, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev);
     return check_launch();
 }
 
 int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
-                    int32_t n_out, float *out, int32_t R, const hsGate *gate, void *stream) {
+                    int32_t n_out, float *out, int32_t R, const hsGate *gate, const int32_t *m_dev, void *stream) {
     if (R <= 0 || n_out <= 0) return HS_OK;
     if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
+    if (m_dev) m = ld;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr});
+    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev);
+    return check_launch();
+}
+
+int hs_sampler_step(hsSamplerCtl *ctl, const float *beta_max, const float *beta0, int32_t s_new, int32_t max_rounds, void *stream) {
+    if (!ctl || !beta_max || !beta0) return HS_ERR_NULL;
+    k_sampler_step<<<1, 1, 0, (hipStream_t)stream>>>(ctl, beta_max, beta0, s_new, max_rounds);
+    return check_launch();
+}
+
+int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, int64_t *pick, void *stream) {
+    if (n_extra <= 0) return HS_OK;
+    if (!ctl || !pick) return HS_ERR_NULL;
+    k_sampler_pick<<<1, 256, 0, (hipStream_t)stream>>>(ctl, u, n_extra, pick);
     return check_launch();
 }
 

@@ -72,7 +72,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
 
 
 def _check(rc, what):
@@ -177,19 +177,33 @@ class _HipBackend:
 
     # ---- per-ray sampler kernels (include/holoscene_hip.h section 3)
     @staticmethod
-    def sampler_update(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max, gate=None):
+    def sampler_update(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max, gate=None, m_dev=None):
         lib = load_library()
         R, ld = z.shape
         _check(lib.hs_sampler_update(_dev(z, "z"), _dev(sdf, "sdf"), ld, m_old, _dev(samples, "samples"), _dev(new_sdf, "new_sdf"),
                                      samples.shape[1], _dev(beta, "beta"), _dev(beta0, "beta0"), ctypes.c_float(eps), beta_iters,
-                                     _dev(beta_max, "beta_max"), R, ctypes.byref(_gate(gate)), _stream()), "hs_sampler_update")
+                                     _dev(beta_max, "beta_max"), R, ctypes.byref(_gate(gate)), _dev(m_dev, "m_dev", torch.int32), _stream()),
+               "hs_sampler_update")
 
     @staticmethod
-    def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out, gate=None):
+    def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out, gate=None, m_dev=None):
         lib = load_library()
         R, ld = z.shape
         _check(lib.hs_sampler_draw(_dev(z, "z"), _dev(sdf, "sdf"), ld, m, _dev(beta, "beta"), mode, ctypes.c_float(add_tiny),
-                                   _dev(u, "u"), n_out, _dev(out, "out"), R, ctypes.byref(_gate(gate)), _stream()), "hs_sampler_draw")
+                                   _dev(u, "u"), n_out, _dev(out, "out"), R, ctypes.byref(_gate(gate)), _dev(m_dev, "m_dev", torch.int32),
+                                   _stream()), "hs_sampler_draw")
+
+    @staticmethod
+    def sampler_step(ctl, beta_max, beta0, s_new, max_rounds):
+        """ctl: float32[4] device tensor holding an hsSamplerCtl {running, half, m (int32 bits), rounds (int32 bits)}."""
+        lib = load_library()
+        _check(lib.hs_sampler_step(_dev(ctl, "ctl"), _dev(beta_max, "beta_max"), _dev(beta0, "beta0"), s_new, max_rounds, _stream()),
+               "hs_sampler_step")
+
+    @staticmethod
+    def sampler_pick(ctl, u, n_extra, pick):
+        lib = load_library()
+        _check(lib.hs_sampler_pick(_dev(ctl, "ctl"), _dev(u, "u"), n_extra, _dev(pick, "pick", torch.int64), _stream()), "hs_sampler_pick")
 
     @staticmethod
     def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik):

@@ -31,6 +31,11 @@ SAMPLER_IMPL = os.environ.get("HOLOSCENE_SAMPLER_IMPL", "hip")
 # Measured on MI355X (same box, full bench): the sampler phase alone gets 12 % shorter (1.38 -> 1.21 ms at 5 rounds) but the
 # whole iteration does not (5.26 vs 5.28 ms) and a 1-round state pays 0.3 ms for the gated-out launches -> off by default.
 SPECULATE = os.environ.get("HOLOSCENE_SAMPLER_SPECULATE", "0") != "0"
+# "device": Algorithm 1's loop test runs on the GPU (hsSamplerCtl + gated kernels, loop unrolled max_total_iters times): no
+#           host sync at all, so the sampler -- and with it the whole training iteration -- can live inside one HIP graph.
+#           Needs the fused ray-mode SDF query (bf16 MLP mode, stock trunk shape); other configurations use "host".
+# "host":   the host reads one convergence flag per round (the reference's control flow, ray_sampler.py:204).
+CONTROL = os.environ.get("HOLOSCENE_SAMPLER_CONTROL", "device")
 
 
 def _rand(shape, device, cpu_rng):
@@ -150,7 +155,22 @@ class ErrorBoundSampler(RaySampler):
         self.inverse_sphere_bg = inverse_sphere_bg
         if inverse_sphere_bg:
             raise NotImplementedError("inverse_sphere_bg is not used by any Stage-1 config (confs/*: absent) and is not built")
-        self.last_rounds = 0  # realised Algorithm-1 rounds of the latest call (bench.py reports it)
+        self._rounds = 0       # realised Algorithm-1 rounds of the latest call: an int, or a 1-element device tensor
+        self._ctl_init = None
+
+    @property
+    def last_rounds(self):
+        """Realised Algorithm-1 rounds of the latest call (reading it after a device-controlled call synchronises)."""
+        return int(self._rounds)
+
+    @last_rounds.setter
+    def last_rounds(self, v):
+        self._rounds = v
+
+    def device_control_ok(self, model, idx=None):
+        net = model.implicit_network
+        return (CONTROL == "device" and SAMPLER_IMPL == "hip" and (idx is None or isinstance(idx, int)) and getattr(net, "color_grid_feature", False)
+                and hasattr(net, "_fused_trunk_supported") and net._fused_trunk_supported(net.encoding.embeddings))
 
     def _query_sdf(self, model, points, idx):
         net = model.implicit_network
@@ -165,6 +185,8 @@ class ErrorBoundSampler(RaySampler):
         """z0 / beta_init: optionally the first uniform depths and Lemma-2 beta already produced by the fused ray-setup
         kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference."""
         if SAMPLER_IMPL == "hip":
+            if ray_dirs.is_cuda and self.device_control_ok(model, idx):
+                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
             return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
         if SAMPLER_IMPL != "torch":
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
@@ -286,6 +308,73 @@ class ErrorBoundSampler(RaySampler):
         z_out = torch.empty(R, n_out, device=dev)
         z_eik = torch.empty(R, 1, device=dev)
         be.sampler_final(samples, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
+        if hasattr(model.implicit_network, "invalidate_packed_weights"):
+            model.implicit_network.invalidate_packed_weights()   # the images belong to this parameter state only
+        return z_out, z_eik
+
+
+    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None):
+        """Algorithm 1 with device-side loop control: max_total_iters unrolled rounds of gated kernels, zero host syncs."""
+        be = _be._backend
+        dev = ray_dirs.device
+        R = ray_dirs.shape[0]
+        S = self.N_samples_eval
+        ld = S * self.max_total_iters
+        net = model.implicit_network
+        beta0 = model.density.get_beta().detach().reshape(1).contiguous()
+        net.invalidate_packed_weights()
+        if z0 is None or beta_init is None:
+            z0, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+            d0 = z0[:, 1:] - z0[:, :-1]
+            beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
+        else:
+            beta = beta_init.clone()
+        if self._ctl_init is None or self._ctl_init.device != dev:
+            self._ctl_init = torch.tensor([1.0, 0.5, 0.0, 0.0], device=dev)     # hsSamplerCtl {running, half, m = 0, rounds = 0}
+        ctl = self._ctl_init.clone()
+        ci = ctl.view(torch.int32)
+        m_dev, gate = ci[2:3], (ctl[0:1], ctl[1:2])
+        z = torch.empty(R, ld, device=dev)
+        sdf = torch.empty(R, ld, device=dev)
+        beta_max_all = torch.zeros(self.max_total_iters, device=dev)
+        cam = (cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc).contiguous()
+        dirs = ray_dirs.contiguous()
+        sel = -1 if idx is None else idx
+        samples = z0.contiguous()
+        for r in range(self.max_total_iters):
+            new_sdf = net.sdf_along_rays(cam, dirs, samples, sel, gate=gate)
+            be.sampler_update(z, sdf, 0, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1], gate=gate,
+                              m_dev=m_dev)
+            be.sampler_step(ctl, beta_max_all[r:r + 1], beta0, S, self.max_total_iters)
+            if r + 1 < self.max_total_iters:
+                samples = torch.empty(R, S, device=dev)
+                be.sampler_draw(z, sdf, 0, beta, 0, float(self.add_tiny), None, S, samples, gate=gate, m_dev=m_dev)
+        n = self.N_samples
+        u = None
+        if model.training:
+            u = (rng["u_final"].to(dev) if "u_final" in rng else _rand((R, n), dev, self.cpu_rng)).contiguous()
+        final = torch.empty(R, n, device=dev)
+        be.sampler_draw(z, sdf, 0, beta, 1, float(self.add_tiny), u, n, final, m_dev=m_dev)
+        pick = None
+        if self.N_samples_extra > 0:
+            if "perm" in rng:   # explicit permutation of the (then host-known) merged set: parity tests
+                pick = rng["perm"][: self.N_samples_extra].to(dev).long().contiguous()
+            else:
+                pick = torch.empty(self.N_samples_extra, device=dev, dtype=torch.int64)
+                up = _rand((self.N_samples_extra,), dev, self.cpu_rng) if model.training else None
+                be.sampler_pick(ctl, up, self.N_samples_extra, pick)
+        n_out = n + 2 + self.N_samples_extra
+        if "eik_idx" in rng:
+            eik = rng["eik_idx"].to(dev).long().contiguous()
+        elif self.cpu_rng:
+            eik = torch.randint(n_out, (R,)).to(dev)
+        else:
+            eik = torch.randint(n_out, (R,), device=dev)
+        z_out = torch.empty(R, n_out, device=dev)
+        z_eik = torch.empty(R, 1, device=dev)
+        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
+        net.invalidate_packed_weights()
+        self._rounds = ci[3:4]
         return z_out, z_eik
 
     def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng):

@@ -134,6 +134,62 @@ class Stage1Trainer:
             self.flat.step()
         return out, loss_out
 
+    # ------------------------------------------------------------------ whole-iteration graph
+    def _full_graph_ok(self):
+        """Rays, sampler (device-side loop control), render, loss, backward and Adam in ONE graph: possible whenever the sampler
+        can run without host syncs (ray_sampler.CONTROL == "device", bf16 fused SDF queries)."""
+        sm = self.model.ray_sampler
+        return hasattr(sm, "device_control_ok") and sm.device_control_ok(self.model) and sm.device_control_ok(self.model, 0)
+
+    def _full_body(self, st, with_bg, call_reg):
+        model = self.model
+        self.flat.zero_grad()
+        with torch.no_grad():
+            rays = model.prepare_rays(st["input"])
+            z_vals, z_eik = model.sample(rays)
+            rounds = model.ray_sampler._rounds
+            bg = model.prepare_background(st["input"]) if with_bg else None
+            model.ray_sampler._rounds = rounds      # report the main pass, not the background patch
+        out = model.render(rays, z_vals, z_eik, None, bg=bg)
+        out["iter_step"] = 0
+        loss_out = self.loss(out, st["gt"], call_reg=call_reg)
+        loss_out["loss"].backward()
+        self.flat.gather_grads()
+        if self.world_size == 1 and not self.freeze_parameters:
+            self.flat.step()
+        return out, loss_out
+
+    def _train_step_full_graph(self, model_input, ground_truth):
+        self.model.train()
+        with_bg = self.model.wants_background(self.iter_step)
+        key = ("full", with_bg, self.iter_step >= self.add_objectvio_iter)
+        entry = self._graphs.get(key)
+        if entry is None:
+            st = {"input": {k: v.clone() for k, v in model_input.items()}, "gt": {k: v.clone() for k, v in ground_truth.items()}}
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):  # warm-up on a side stream (these are real training steps on the current batch)
+                for _ in range(2):
+                    self._full_body(st, key[1], key[2])
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out, loss_out = self._full_body(st, key[1], key[2])
+            entry = {"graph": g, "static": st, "out": out, "loss": loss_out, "rounds": self.model.ray_sampler._rounds}
+            self._graphs[key] = entry
+        st = entry["static"]
+        dl = [st["input"][k] for k in model_input] + [st["gt"][k] for k in ground_truth]
+        sl = list(model_input.values()) + list(ground_truth.values())
+        torch._foreach_copy_(dl, sl)
+        entry["graph"].replay()
+        self.model.ray_sampler._rounds = entry["rounds"]
+        if self.world_size > 1:
+            dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+        self.iter_step += 1
+        return entry["out"], entry["loss"]
+
     def _capture(self, key, fresh):
         """fresh: dict of live tensors with the shapes of this variant; becomes the static input block."""
         with_bg, call_reg = key
@@ -162,6 +218,8 @@ class Stage1Trainer:
             dst[k].copy_(v, non_blocking=True)
 
     def _train_step_graph(self, indices, model_input, ground_truth):
+        if self._full_graph_ok():
+            return self._train_step_full_graph(model_input, ground_truth)
         model = self.model
         model.train()
         with torch.no_grad():

@@ -141,13 +141,28 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
  *   *beta_max = max(*beta_max, beta_r) via atomics (zero it before the call). */
 int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
                       float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate /* NULL = none */,
-                      void *stream);
+                      const int32_t *m_dev /* NULL, or device count overriding m_old (hsSamplerCtl.m) */, void *stream);
 
 /* Inverse-CDF sampling (ray_sampler.py:206-253): mode 0 = pdf ~ error-bound opacity + add_tiny,
  * mode 1 = pdf ~ rendering weights + 1e-5.  u [R, n_out] explicit, or NULL = linspace(0,1,n_out).
  * out [R, n_out]. */
 int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
-                    int32_t n_out, float *out, int32_t R, const hsGate *gate /* NULL = none */, void *stream);
+                    int32_t n_out, float *out, int32_t R, const hsGate *gate /* NULL = none */,
+                    const int32_t *m_dev /* NULL, or device count overriding m */, void *stream);
+
+/* Device-side control of Algorithm 1's rounds, so that the whole sampler (and with it the whole training iteration) can be
+ * captured in one HIP graph: the loop is unrolled max_rounds times, every kernel of round r+1 is gated on `running`
+ * (hsGate{&ctl->running, &ctl->half}) and reads the merged sample count from ctl->m.
+ *   hs_sampler_step: after a round's hs_sampler_update: m += s_new, rounds += 1, running = 0 when *beta_max <= *beta0
+ *   (ray_sampler.py:204) or rounds == max_rounds.  Initialise ctl to {1.0f, 0.5f, 0, 0}.
+ *   hs_sampler_pick: the n_extra extra-sample indices (ray_sampler.py:267-271): a partial Fisher-Yates shuffle of [0, m) driven
+ *   by u [n_extra] ~ U[0,1) (train), or linspace(0, m-1, n_extra) truncated (u == NULL, eval). */
+typedef struct hsSamplerCtl {
+    float running, half;
+    int32_t m, rounds;
+} hsSamplerCtl;
+int hs_sampler_step(hsSamplerCtl *ctl, const float *beta_max, const float *beta0, int32_t s_new, int32_t max_rounds, void *stream);
+int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, int64_t *pick, void *stream);
 
 /* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
  * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */

@@ -524,22 +524,50 @@ def test_ray_mode_sdf_query_is_bit_identical_to_point_mode(select):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("name", ["sampler_1", "sampler_3", "sampler_4"])
-def test_speculative_sampler_rounds_equal_sequential_rounds(name, monkeypatch):
-    """Device-gated one-round-ahead pipeline vs strictly sequential rounds (bf16 fused SDF queries in both): identical depths
-    and the same realised round count, for states that stop after 1..5 rounds."""
+@pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])
+def test_sampler_control_variants_agree(name, monkeypatch):
+    """Three ways to drive Algorithm 1's loop over the same kernels (bf16 fused SDF queries): host reads a flag per round
+    (reference control flow), host one round ahead of device-gated kernels, and the loop test entirely on the device
+    (hsSamplerCtl, what the whole-iteration HIP graph replays).  Identical depths and realised round counts, for states that
+    stop after 1..5 rounds, train and eval."""
     from holoscene_amd.model import ray_sampler as RS
     rec = load(name)
-    model = build_model(rec, DEV).train()
+    model = build_model(rec, DEV)
+    model.train(bool(rec["meta.train"]))
     model.implicit_network.set_mlp_precision("bf16")
     ins = _dev(section(rec, "in."))
     res = {}
-    for spec in (True, False):
+    for control, spec in (("host", False), ("host", True), ("device", False)):
+        monkeypatch.setattr(RS, "CONTROL", control)
         monkeypatch.setattr(RS, "SPECULATE", spec)
         z, z_eik = model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model, rng=_dev(rand_dict(rec)))
-        res[spec] = (z, z_eik, model.ray_sampler.last_rounds)
-    assert res[True][2] == res[False][2]
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        res[(control, spec)] = (z, z_eik, model.ray_sampler.last_rounds)
+    ref = res[("host", False)]
+    for k, v in res.items():
+        assert v[2] == ref[2], (k, v[2], ref[2])
+        assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k
+
+
+def test_device_side_extra_sample_pick():
+    """hs_sampler_pick: n distinct indices in [0, m) from uniforms (partial Fisher-Yates), and the eval-mode linspace."""
+    from holoscene_amd.hashencoder import backend
+    be = backend._backend
+    for m in (128, 640, 37):
+        ctl = torch.tensor([1.0, 0.5, 0.0, 0.0], device=DEV)
+        ctl.view(torch.int32)[2] = m
+        n = 32
+        u = torch.rand(n, device=DEV)
+        pick = torch.empty(n, device=DEV, dtype=torch.int64)
+        be.sampler_pick(ctl, u, n, pick)
+        p = pick.cpu().tolist()
+        assert len(set(p)) == n and min(p) >= 0 and max(p) < m
+        arr, uh = list(range(m)), u.cpu().tolist()      # the same shuffle on the host
+        for j in range(n):
+            k = min(j + int(torch.tensor(uh[j], dtype=torch.float32) * torch.tensor(float(m - j), dtype=torch.float32)), m - 1)
+            arr[j], arr[k] = arr[k], arr[j]
+        assert p == arr[:n]
+        be.sampler_pick(ctl, None, n, pick)
+        assert torch.equal(pick.cpu(), torch.linspace(0, m - 1, n).long())
 
 
 @pytest.mark.parametrize("B", [25088, 1000, 37])
