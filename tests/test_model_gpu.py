@@ -617,3 +617,56 @@ def test_fused_mfma_appearance_vs_gemm_path(B):
         # quantities deep in the chain (d/d normals, table); the criterion is therefore relative to the established path
         assert rel < 0.1, (n, err, scale, rel)
         assert rel <= 1.5 * grel + 1e-3, (n, rel, grel)
+
+
+def _full_graph_trainer(beta, freeze, rays=256):
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    tr = Stage1Trainer(stock_conf(num_rays=rays, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=beta, mlp_precision="bf16"), device=DEV,
+                       optimizer="flat", graph=True, freeze_parameters=freeze)
+    benchmark_model_state(tr.model, beta)
+    assert tr._full_graph_ok()
+    return tr, SyntheticScene(rays, 4, img_res=(64, 64), num_frames=3, ring=4, device=DEV)
+
+
+@pytest.mark.parametrize("beta", [0.05, 0.002])
+def test_whole_iteration_graph_matches_eager_execution(beta):
+    """Rays + device-controlled sampler + render + loss + backward captured as ONE graph vs the eager execution of the same
+    body on the same static inputs and generator state: same realised sampler rounds, same depths, outputs and gradients."""
+    tr, scene = _full_graph_trainer(beta, True)
+    for key_iter in (0, 3):  # iteration 0 renders the background patch, iteration 3 does not
+        tr.iter_step = key_iter
+        idx, mi, gt = scene.next_batch()
+        tr.train_step(idx, mi, gt)
+        entry = tr._graphs[("full", key_iter == 0, False)]
+        torch.cuda.manual_seed(7)
+        entry["graph"].replay()
+        torch.cuda.synchronize()
+        g_graph = tr.flat.flat_g.clone()
+        out_graph = {k: v.clone() for k, v in entry["out"].items() if torch.is_tensor(v)}
+        loss_graph, rounds_graph = float(entry["loss"]["loss"]), int(entry["rounds"])
+        torch.cuda.manual_seed(7)
+        out_eager, loss_eager = tr._full_body(entry["static"], key_iter == 0, False)
+        g_eager = tr.flat.flat_g.clone()
+        assert rounds_graph == tr.model.ray_sampler.last_rounds and 1 <= rounds_graph <= 5
+        assert torch.equal(out_graph["z_vals"], out_eager["z_vals"])
+        z = out_graph["z_vals"]
+        assert bool((z[:, 1:] >= z[:, :-1]).all()) and float(z.min()) >= 0 and float(z.max()) <= 3.5 + 1e-6
+        assert abs(loss_graph - float(loss_eager["loss"])) <= 1e-4 * abs(loss_graph)
+        for k in ("rgb_values", "depth_values", "normal_map", "grad_theta", "sample_sdf"):
+            close(out_graph[k], out_eager[k], 1e-4, 1e-5, k)
+        assert float(g_graph.abs().max()) > 0
+        rel = float((g_graph - g_eager).norm() / g_eager.norm())
+        assert rel < 1e-3, rel
+
+
+def test_whole_iteration_graph_training_reduces_loss():
+    tr, scene = _full_graph_trainer(0.05, False)
+    losses = []
+    for _ in range(40):
+        idx, mi, gt = scene.next_batch()
+        _, lo = tr.train_step(idx, mi, gt)
+        losses.append(float(lo["loss"]))
+    assert all(l == l and abs(l) < 1e6 for l in losses)
+    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5
+    assert tr.flat.read_state().step >= 40
