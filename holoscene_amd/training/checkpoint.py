@@ -1,0 +1,94 @@
+"""Checkpoints in the reference's on-disk layout (training/holoscene_train.py:226-246 save, :174-197 load), so that a run
+can be resumed by either code base:
+
+    <checkpoints>/ModelParameters/{<epoch>,latest}.pth      {"epoch", "model_state_dict"}
+    <checkpoints>/OptimizerParameters/{<epoch>,latest}.pth  {"epoch", "optimizer_state_dict"}   torch.optim.Adam format, 3 groups
+    <checkpoints>/SchedulerParameters/{<epoch>,latest}.pth  {"epoch", "scheduler_state_dict"}   ExponentialLR format
+
+The flat fused optimiser (training/flat.py) keeps its moments in two flat buffers and its step / learning rates in a
+device struct; here they are converted to and from the per-parameter ``torch.optim.Adam`` state the reference stores.
+Correspondence after n updates:  Adam state["step"] = n for every parameter;  param_group["lr"] = initial_lr * gamma^n
+(the scheduler has been stepped n times, :428);  scheduler.last_epoch = n;  hsAdamState.step = n, lr0 = initial_lr.
+"""
+import os
+
+import torch
+
+from .optim import build_optimizer, build_scheduler
+
+MODEL_DIR, OPTIMIZER_DIR, SCHEDULER_DIR = "ModelParameters", "OptimizerParameters", "SchedulerParameters"
+
+
+def _torch_pair(trainer):
+    opt = build_optimizer(trainer.model, trainer.lr, trainer.lr_factor)
+    return opt, build_scheduler(opt, trainer.decay_rate, trainer.decay_steps)
+
+
+def optimizer_state_dicts(trainer):
+    """(optimizer_state_dict, scheduler_state_dict) in torch.optim.Adam / ExponentialLR format."""
+    if trainer.flat is None:
+        return trainer.optimizer.state_dict(), trainer.scheduler.state_dict()
+    flat = trainer.flat
+    opt, sched = _torch_pair(trainer)
+    n = int(flat.read_state().step)
+    if n > 0:
+        for p, (m, v) in zip(flat.params, flat.moment_views()):
+            opt.state[p] = {"step": torch.tensor(float(n)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+    for grp in opt.param_groups:
+        grp["lr"] = grp["initial_lr"] * flat.gamma ** n
+    sched.last_epoch = n
+    sched._step_count = n + 1
+    sched._last_lr = [grp["lr"] for grp in opt.param_groups]
+    return opt.state_dict(), sched.state_dict()
+
+
+def load_optimizer_state(trainer, optimizer_state_dict, scheduler_state_dict):
+    if trainer.flat is None:
+        trainer.optimizer.load_state_dict(optimizer_state_dict)
+        trainer.scheduler.load_state_dict(scheduler_state_dict)
+        return int(scheduler_state_dict.get("last_epoch", 0))
+    flat = trainer.flat
+    opt, _ = _torch_pair(trainer)
+    opt.load_state_dict(optimizer_state_dict)       # maps the saved per-index state onto this model's parameters, checks group sizes
+    gamma = float(scheduler_state_dict["gamma"])
+    if abs(gamma - flat.gamma) > 1e-12 * abs(flat.gamma):
+        raise ValueError(f"checkpoint decays the learning rate by {gamma!r} per step, this run by {flat.gamma!r}")
+    n = int(scheduler_state_dict.get("last_epoch", 0))
+    steps = {int(s["step"]) for s in opt.state.values() if "step" in s}
+    if steps and steps != {n}:
+        raise ValueError(f"optimizer steps {sorted(steps)} do not match scheduler.last_epoch = {n}")
+    with torch.no_grad():
+        for p, (m, v) in zip(flat.params, flat.moment_views()):
+            st = opt.state.get(p)
+            if st:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+            else:
+                m.zero_()
+                v.zero_()
+    flat.set_state(n, [float(g.get("initial_lr", g["lr"] / gamma ** n)) for g in opt.param_groups])
+    return n
+
+
+def save_checkpoints(trainer, checkpoints_path, epoch):
+    opt_sd, sched_sd = optimizer_state_dicts(trainer)
+    payloads = {MODEL_DIR: {"epoch": epoch, "model_state_dict": trainer.model.state_dict()},
+                OPTIMIZER_DIR: {"epoch": epoch, "optimizer_state_dict": opt_sd},
+                SCHEDULER_DIR: {"epoch": epoch, "scheduler_state_dict": sched_sd}}
+    for sub, payload in payloads.items():
+        os.makedirs(os.path.join(checkpoints_path, sub), exist_ok=True)
+        for name in (str(epoch), "latest"):
+            torch.save(payload, os.path.join(checkpoints_path, sub, name + ".pth"))
+
+
+def load_checkpoints(trainer, checkpoints_path, checkpoint="latest", map_location=None):
+    """Returns the stored epoch.  Model keys may carry DataParallel's 'module.' prefix (holoscene_train.py:182-185)."""
+    dev = map_location or trainer.device
+    saved = torch.load(os.path.join(checkpoints_path, MODEL_DIR, str(checkpoint) + ".pth"), map_location=dev)
+    trainer.model.load_state_dict({k.replace("module.", ""): v for k, v in saved["model_state_dict"].items()})
+    opt = torch.load(os.path.join(checkpoints_path, OPTIMIZER_DIR, str(checkpoint) + ".pth"), map_location=dev)
+    sched = torch.load(os.path.join(checkpoints_path, SCHEDULER_DIR, str(checkpoint) + ".pth"), map_location=dev)
+    trainer.iter_step = load_optimizer_state(trainer, opt["optimizer_state_dict"], sched["scheduler_state_dict"])
+    if hasattr(trainer.model.implicit_network, "invalidate_packed_weights"):
+        trainer.model.implicit_network.invalidate_packed_weights()
+    return saved["epoch"]

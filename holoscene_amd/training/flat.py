@@ -73,6 +73,24 @@ class FlatAdam:
         for p, v in self.small:
             p.grad = v
 
+    def moment_views(self):
+        """[(exp_avg, exp_avg_sq)] per parameter, views into the flat moment buffers, in optimiser order."""
+        out, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            out.append((self.flat_m[off:off + n].view_as(p), self.flat_v[off:off + n].view_as(p)))
+            off += n
+        return out
+
+    def set_state(self, step, lr0):
+        """Resume: `step` updates done so far, lr0 = the three groups' initial learning rates (checkpoint.py)."""
+        st = self.read_state()
+        st.step = int(step)
+        for i, v in enumerate(lr0):
+            st.lr0[i] = v
+            st.lr[i] = v * self.gamma ** max(int(step) - 1, 0)
+        self.state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+
     def read_state(self):
         return _be.hsAdamState.from_buffer_copy(bytes(self.state.cpu().numpy().tobytes()))
 

@@ -65,10 +65,10 @@ class Stage1Trainer:
         self.model = HoloSceneNetwork(conf=conf.get_config("model"), graph_node_dict=None, num_images=num_images).to(self.device)
         self.loss = HoloSceneLoss(**conf.get_config("loss"))
         self.lr = conf.get_float("train.learning_rate")
-        lr_factor = conf.get_float("train.lr_factor_for_grid", default=1.0)
-        decay_rate = conf.get_float("train.sched_decay_rate", default=0.1)
+        self.lr_factor = lr_factor = conf.get_float("train.lr_factor_for_grid", default=1.0)
+        self.decay_rate = decay_rate = conf.get_float("train.sched_decay_rate", default=0.1)
         # nepochs * ds_len with ds_len = fix_length: decay_steps == max_total_iters (holoscene_train.py:110-116, 166-169)
-        decay_steps = conf.get_int("train.max_total_iters", default=200000)
+        self.decay_steps = decay_steps = conf.get_int("train.max_total_iters", default=200000)
         self.flat = None
         if optimizer == "flat":
             from ..hashencoder import backend
