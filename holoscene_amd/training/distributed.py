@@ -50,8 +50,11 @@ def exchange_and_step_flat(flat, world_size, zero1=True, group=None):
         b, e = flat.shard
         if dist.get_backend(group) == "gloo":   # gloo (CPU tests) has no reduce_scatter: same sums via all_reduce
             dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
-        else:
-            dist.reduce_scatter_tensor(flat.flat_g[b:e], flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+        else:   # out of place (a staging slice of 1/N of the buffer): no reliance on in-place aliasing rules of the backend
+            if getattr(flat, "_shard_g", None) is None:
+                flat._shard_g = torch.empty(e - b, device=flat.flat_g.device, dtype=flat.flat_g.dtype)
+            dist.reduce_scatter_tensor(flat._shard_g, flat.flat_g, op=dist.ReduceOp.SUM, group=group)
+            flat.flat_g[b:e].copy_(flat._shard_g)
         flat.step(grad_scale=1.0 / world_size, shard_only=True)
         dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e].clone(), group=group)
     else:
