@@ -202,20 +202,29 @@ class _fused_trunk(torch.autograd.Function):
         gb1 = torch.zeros(256, device=dev)
         gb0 = torch.zeros(256, device=dev)
         _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0)
-        gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
-        gW1 = _wgrad_rows(gA1, H0) if need_w else None
-        gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
-        g_emb = None
-        if ctx.needs_input_grad[1]:
+        def table_branch():
             gX = (gA0 @ w0).view(B, 4, _TRUNK_PITCH)
             g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
             g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
             _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
+            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
+
+        g_emb = target = None
+        if ctx.needs_input_grad[1]:
             table = ctx.table
             inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
             target = table.grad if inplace else torch.zeros_like(embeddings)
-            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
             g_emb = None if inplace else target
+            if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
+                # input-gradient GEMM + slicing + atomic-bound scatter on a parallel branch; the weight-gradient GEMMs below
+                # (matrix-core-bound) proceed on this stream.  Joined by the optimiser (backend.join_side_stream).
+                with torch.cuda.stream(_be.fork_side_stream(gA0, w0, x01, offsets, target)):
+                    table_branch()
+            else:
+                table_branch()
+        gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
+        gW1 = _wgrad_rows(gA1, H0) if need_w else None
+        gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
         return None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
 
 
@@ -286,7 +295,11 @@ class _fused_appearance(torch.autograd.Function):
             table = ctx.table
             inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
             target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
+            if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):   # the scatter is atomic-issue-bound: let the trunk's matrix-core backward run beside it
+                with torch.cuda.stream(_be.fork_side_stream(g_featc, x01, offsets, target)):
+                    be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
+            else:
+                be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
             g_emb = None if inplace else target
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2)
 

@@ -42,6 +42,8 @@ class FlatAdam:
             p.grad = self.flat_g[off:off + n].view_as(p)
             if i >= n_tables:
                 self.small.append((p, p.grad))
+            else:
+                p._hs_flat_owner = True   # its gradient is consumed through gather_grads() only: scatters may use the side stream
             off += n
         self.betas, self.eps = betas, eps
         self.gamma = float(decay_rate) ** (1.0 / float(decay_steps))
@@ -66,6 +68,7 @@ class FlatAdam:
             p.grad = None
 
     def gather_grads(self):
+        _be.join_side_stream()   # table scatters may still be running on the side branch (backend.OVERLAP_SCATTER)
         src = [p.grad for p, _ in self.small if p.grad is not None]
         dst = [v for p, v in self.small if p.grad is not None]
         if src:
