@@ -185,19 +185,31 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
 // quad broadcast of the value lane's sigmoid -- no LDS round trip.
 //   X  [M][K0] bf16 (k_trunk_input, zero-padded columns)      H0, H1 [M][256] bf16 = layer OUTPUTS (value row: softplus,
 //   tangent rows: s * pre-activation; hs_softplus_tangent_bwd_h consumes exactly that)     Y [M][d_out] fp32
-__device__ __forceinline__ float tangent_act(float acc, float bias, bool is_value) {
+// Softplus and its derivative are needed for the VALUE row only, but the four rows of a point sit in the four lanes of a quad,
+// so a lane-wise evaluation would run the exp/log/rcp sequence on all four lanes and use one.  Instead lane j of the quad takes
+// neuron j of the value lane's four consecutive neurons (4 DPP broadcasts + select), evaluates ONE softplus pair, and the
+// results travel back by quad_perm [j,j,j,j]: a quarter of the transcendental work for 12 DPP moves per 4 elements
+// (ablation: the lane-wise form cost 106 us of k_trunk_fwd's 328).
+__device__ __forceinline__ void tangent_quad(const float a[4], const float4 bi, int lane, bool is_value, float out[4]) {
 #ifdef HS_EXP_NO_EPILOGUE
-    return acc + bias;
+    out[0] = a[0] + bi.x; out[1] = a[1] + bi.y; out[2] = a[2] + bi.z; out[3] = a[3] + bi.w;
+    return;
 #endif
-    const float v = acc + bias;
+    const float t0 = quad_bcast0(a[0] + bi.x), t1 = quad_bcast0(a[1] + bi.y), t2 = quad_bcast0(a[2] + bi.z), t3 = quad_bcast0(a[3] + bi.w);
+    const int j = lane & 3;
+    const float v = j == 0 ? t0 : (j == 1 ? t1 : (j == 2 ? t2 : t3));   // pre-activation of neuron j of the point's value row
     const float t = v * 100.f;
     const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
     const float one_e = 1.f + e;
     const bool lin = t > 20.f;
     const float sp = lin ? v : __builtin_amdgcn_logf(one_e) * (0.69314718f * 0.01f);
     const float ds = lin ? 1.f : e * __builtin_amdgcn_rcpf(one_e);
-    const float s = quad_bcast0(ds);   // tangent lanes computed garbage of their own; they take the value lane's
-    return is_value ? sp : s * acc;
+    const float s0 = dpp_quad<0x00>(ds), s1 = dpp_quad<0x55>(ds), s2 = dpp_quad<0xAA>(ds), s3 = dpp_quad<0xFF>(ds);
+    const float p0 = dpp_quad<0x00>(sp), p1 = dpp_quad<0x55>(sp), p2 = dpp_quad<0xAA>(sp), p3 = dpp_quad<0xFF>(sp);
+    out[0] = is_value ? p0 : s0 * a[0];
+    out[1] = is_value ? p1 : s1 * a[1];
+    out[2] = is_value ? p2 : s2 * a[2];
+    out[3] = is_value ? p3 : s3 * a[3];
 }
 
 __device__ __forceinline__ void epilogue_tangent(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
@@ -211,11 +223,12 @@ __device__ __forceinline__ void epilogue_tangent(const float *bias_lds, uint16_t
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
                 const int p = ph * 64 + pt * 32 + (lane & 31);
-                const float v0 = tangent_act(acc[nt][pt][q * 4 + 0], bi.x, is_value), v1 = tangent_act(acc[nt][pt][q * 4 + 1], bi.y, is_value);
-                const float v2 = tangent_act(acc[nt][pt][q * 4 + 2], bi.z, is_value), v3 = tangent_act(acc[nt][pt][q * 4 + 3], bi.w, is_value);
+                const float a[4] = {acc[nt][pt][q * 4 + 0], acc[nt][pt][q * 4 + 1], acc[nt][pt][q * 4 + 2], acc[nt][pt][q * 4 + 3]};
+                float o[4];
+                tangent_quad(a, bi, lane, is_value, o);
                 uint2 pk;
-                pk.x = pack_bf16(v0, v1);
-                pk.y = pack_bf16(v2, v3);
+                pk.x = pack_bf16(o[0], o[1]);
+                pk.y = pack_bf16(o[2], o[3]);
                 *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
             }
         }
