@@ -47,14 +47,46 @@ __device__ float block_sum(float v, float *scratch) {
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 
+// Ray-local heavy parts, one wave per ray: the foreground flag (does the SDF change sign along the ray, loss.py:313-315: N
+// values) and the opacity BCE with its gradient (K values).  The single-workgroup kernel below used to walk both per thread
+// (1 024 threads striding 392-byte rows on ONE CU: 100 us); here they are coalesced wave reads spread over the chip.
+__global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
+                                                         const float *__restrict__ gt_mask, int R, int N, int K, float w_opac,
+                                                         float *__restrict__ fg, float *__restrict__ bce, float *__restrict__ g_opac) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    bool pos = false, neg = false;
+    for (int i = lane; i < N; i += 64) {
+        const float s = sdf[(size_t)r * N + i];
+        pos |= s > 0.f;
+        neg |= s < 0.f;
+    }
+    const bool any_pos = __ballot(pos) != 0ull, any_neg = __ballot(neg) != 0ull;
+    const int lab = (int)segs[r];
+    const float scale = w_opac / (float)R / (float)K;
+    float s_op = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float o = opac[(size_t)r * K + k];
+        const float p = fminf(fmaxf(o, 1e-4f), 1.f - 1e-4f);
+        const bool inside = o >= 1e-4f && o <= 1.f - 1e-4f;
+        if (k == lab) { s_op += -fmaxf(logf(p), -100.f); g_opac[(size_t)r * K + k] = inside ? -scale / p : 0.f; }
+        else { s_op += -fmaxf(logf(1.f - p), -100.f); g_opac[(size_t)r * K + k] = inside ? scale / (1.f - p) : 0.f; }
+    }
+    s_op = wave_sum(s_op);
+    if (lane == 0) {
+        fg[r] = (any_pos && any_neg && gt_mask[r] > 0.5f) ? 1.f : 0.f;
+        bce[r] = s_op;
+    }
+}
+
 // out[0..4] = rgb, depth, normal_l1, normal_cos, opacity losses (unweighted)
 __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ rgb, const float *__restrict__ rgb_gt, const float *__restrict__ depth,
                                                       const float *__restrict__ depth_gt, const float *__restrict__ nmap,
-                                                      const float *__restrict__ n_gt, const float *__restrict__ gt_mask,
-                                                      const float *__restrict__ sdf, const float *__restrict__ opac,
-                                                      const int64_t *__restrict__ segs, int R, int N, int K, float w_rgb, float w_depth,
-                                                      float w_l1, float w_cos, float w_opac, float *__restrict__ out, float *__restrict__ g_rgb,
-                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap, float *__restrict__ g_opac) {
+                                                      const float *__restrict__ n_gt, const float *__restrict__ fg,
+                                                      const float *__restrict__ bce, int R, int K, float w_rgb, float w_depth,
+                                                      float w_l1, float w_cos, float *__restrict__ out, float *__restrict__ g_rgb,
+                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap) {
     __shared__ float scratch[kBlock / 64];
     const float invR = 1.f / (float)R;
     // ---- pass 1: rgb, normals, opacity (ray-local), and the five sums of the depth least-squares system
@@ -66,14 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
             s_rgb += fabsf(d);
             g_rgb[3 * r + c] = w_rgb * sgn(d) * invR * (1.f / 3.f);
         }
-        // foreground = the SDF changes sign along the ray (loss.py:313-315), and the prior's mask
-        bool pos = false, neg = false;
-        for (int i = 0; i < N; i++) {
-            const float s = sdf[(size_t)r * N + i];
-            pos |= s > 0.f;
-            neg |= s < 0.f;
-        }
-        const float m = (pos && neg && gt_mask[r] > 0.5f) ? 1.f : 0.f;
+        const float m = fg[r];   // foreground flag (k_loss_ray_local)
         float v[3], t[3];
         float vn = 0.f, tn = 0.f;
 #pragma unroll
@@ -104,16 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
             const float gv = (vn >= 1e-12f) ? (gn[c] - np[c] * ndg) / den : gn[c] / den;
             g_nmap[3 * r + c] = gv * m;
         }
-        // opacity BCE against the one-hot label
-        const int lab = (int)segs[r];
-        const float scale = w_opac * invR / (float)K;
-        for (int k = 0; k < K; k++) {
-            const float o = opac[(size_t)r * K + k];
-            const float p = fminf(fmaxf(o, 1e-4f), 1.f - 1e-4f);
-            const bool inside = o >= 1e-4f && o <= 1.f - 1e-4f;
-            if (k == lab) { s_op += -fmaxf(logf(p), -100.f); g_opac[(size_t)r * K + k] = inside ? -scale / p : 0.f; }
-            else { s_op += -fmaxf(logf(1.f - p), -100.f); g_opac[(size_t)r * K + k] = inside ? scale / (1.f - p) : 0.f; }
-        }
+        s_op += bce[r];
         const float p = depth[r], tt = depth_gt[r];
         sA += p * p; sB += p; sD += p * tt; sE += tt;
     }
@@ -207,13 +223,14 @@ extern "C" {
 int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, const float *depth_gt, const float *normal_map, const float *normal_gt,
                  const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, float w_rgb,
                  float w_depth, float w_l1, float w_cos, float w_opac, float *out5, float *g_rgb, float *g_depth, float *g_normal_map,
-                 float *g_opacity, void *stream) {
+                 float *g_opacity, float *scratch, void *stream) {
     if (R < 1 || N < 1 || K < 1) return HS_ERR_ARG;
     if (!rgb || !rgb_gt || !depth || !depth_gt || !normal_map || !normal_gt || !gt_mask || !sdf || !opacity || !segs || !out5 || !g_rgb || !g_depth ||
-        !g_normal_map || !g_opacity)
+        !g_normal_map || !g_opacity || !scratch)
         return HS_ERR_NULL;
-    k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, gt_mask, sdf, opacity, segs, R, N, K, w_rgb,
-                                                        w_depth, w_l1, w_cos, w_opac, out5, g_rgb, g_depth, g_normal_map, g_opacity);
+    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w_opac, scratch, scratch + R, g_opacity);
+    k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, scratch, scratch + R, R, K, w_rgb, w_depth, w_l1,
+                                                        w_cos, out5, g_rgb, g_depth, g_normal_map);
     return check_launch();
 }
 

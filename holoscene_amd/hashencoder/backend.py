@@ -416,10 +416,11 @@ class _HipBackend:
         R, N = sdf.shape
         K = opac.shape[1]
         w = [ctypes.c_float(float(x)) for x in weights]
+        scratch = torch.empty(2 * R, device=rgb.device)
         _check(lib.hs_loss_rays(_dev(rgb, "rgb"), _dev(rgb_gt, "rgb_gt"), _dev(depth, "depth"), _dev(depth_gt, "depth_gt"), _dev(nmap, "normal_map"),
                                 _dev(n_gt, "normal_gt"), _dev(gt_mask, "gt_mask"), _dev(sdf, "sdf"), _dev(opac, "opacity"),
                                 _dev(segs, "segs", torch.int64), R, N, K, *w, _dev(out5, "out5"), _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"),
-                                _dev(g_nmap, "g_normal_map"), _dev(g_opac, "g_opacity"), _stream()), "hs_loss_rays")
+                                _dev(g_nmap, "g_normal_map"), _dev(g_opac, "g_opacity"), _dev(scratch, "scratch"), _stream()), "hs_loss_rays")
 
     @staticmethod
     def loss_eikonal(g1, g2, w_eik, w_smooth, acc2, d_g1, d_g2):

@@ -324,7 +324,8 @@ int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, v
  *
  * Terms of MonoSDFLoss / HoloSceneLoss (model/loss.py:211-346, 487-492) that depend on per-ray outputs, and the two terms
  * over the stacked SDF gradients.  Every g_* / d_* output is dLoss/dinput already multiplied by the term's weight.
- * hs_loss_rays (one workgroup): rgb [R,3], depth [R], normal_map [R,3] (camera frame), opacity [R,K], sdf [R,N] (only its
+ * hs_loss_rays (a wave-per-ray pass for the foreground flags and the opacity term, then one workgroup for the global
+ *   reductions and the depth least-squares solve): rgb [R,3], depth [R], normal_map [R,3] (camera frame), opacity [R,K], sdf [R,N] (only its
  *   signs are used: foreground mask), priors rgb_gt/depth_gt/normal_gt/gt_mask [R,*], segs [R] int64.
  *   out5 = {rgb L1, scale-shift-invariant clipped depth MSE, normal L1, normal 1-cos, opacity BCE} (unweighted means).
  * hs_loss_eikonal: g1, g2 [H,3] = first / second half of the stacked gradient rows; acc2 (zeroed by the caller) receives
@@ -332,7 +333,7 @@ int hs_render_input_bwd(const void *G, const float *normals, float *d_normals, v
 int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, const float *depth_gt, const float *normal_map, const float *normal_gt,
                  const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, float w_rgb,
                  float w_depth, float w_l1, float w_cos, float w_opac, float *out5, float *g_rgb, float *g_depth, float *g_normal_map,
-                 float *g_opacity, void *stream);
+                 float *g_opacity, float *scratch /* [2R] work space */, void *stream);
 int hs_loss_eikonal(const float *g1, const float *g2, int64_t H, float w_eik, float w_smooth, float *acc2, float *d_g1, float *d_g2, void *stream);
 
 #ifdef __cplusplus
