@@ -164,6 +164,67 @@ __global__ __launch_bounds__(kThreads) void k_ray_points(const float *__restrict
     }
 }
 
+// ---- consumers of the trunk's value+Jacobian output Y [4*B, K] (rows per point: value, d/dx, d/dy, d/dz), one wave per point.
+// Rendered points (b < n_main) need the per-object SDFs, their minimum with its index, and the gradient OF THE MINIMUM only
+// (network.py:289-299); Eikonal points (b >= n_main) need everything (network.py:856-866).  Replaces the [B,K,3] Jacobian
+// materialisation + min + gather (forward) and the zero-fill / scatter / slice-pad kernels autograd runs for them (backward).
+__global__ __launch_bounds__(256) void k_trunk_split_fwd(const float *__restrict__ Y, int64_t B, int64_t n_main, int K, float *__restrict__ sdf_raw,
+                                                          float *__restrict__ sdf, int64_t *__restrict__ idx, float *__restrict__ grad,
+                                                          float *__restrict__ y_eik, float *__restrict__ J_eik) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        const float *y = Y + b * 4 * K;
+        const float v = lane < K ? y[lane] : INFINITY;
+        if (b < n_main) {
+            float best = v;
+            int bi = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {   // minimum, lowest index among equals
+                const float ov = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane < K) sdf_raw[b * K + lane] = v;
+            if (lane == 0) { sdf[b] = best; idx[b] = bi; }
+            if (lane < 3) grad[b * 3 + lane] = y[(1 + lane) * K + bi];
+        } else {
+            const int64_t e = b - n_main;
+            if (lane < K) {
+                y_eik[e * K + lane] = v;
+#pragma unroll
+                for (int d = 0; d < 3; d++) J_eik[(e * K + lane) * 3 + d] = y[(1 + d) * K + lane];
+            }
+        }
+    }
+}
+
+// cotangent of Y as the bf16 [4*B, KP] image k_trunk_bwd reads (columns >= K zero); any input may be NULL (= zero)
+__global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx,
+                                                          const float *__restrict__ g_grad, const float *__restrict__ g_yeik,
+                                                          const float *__restrict__ g_Jeik, int64_t B, int64_t n_main, int K, int KP,
+                                                          __hip_bfloat16 *__restrict__ g) {
+    const int64_t total = B * 4 * KP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % KP);
+        const int64_t row = i / KP, b = row >> 2;
+        const int r = (int)(row & 3);
+        float v = 0.f;
+        if (k < K) {
+            if (b < n_main) {
+                const bool hit = k == (int)idx[b];
+                if (r == 0) v = (g_raw ? g_raw[b * K + k] : 0.f) + (hit && g_sdf ? g_sdf[b] : 0.f);
+                else if (hit && g_grad) v = g_grad[b * 3 + (r - 1)];
+            } else {
+                const int64_t e = b - n_main;
+                if (r == 0) v = g_yeik ? g_yeik[e * K + k] : 0.f;
+                else v = g_Jeik ? g_Jeik[(e * K + k) * 3 + (r - 1)] : 0.f;
+            }
+        }
+        g[i] = __float2bfloat16(v);
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 int grid_for(int64_t total) {
@@ -229,6 +290,26 @@ int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, f
     if (R == 0 || S == 0) return HS_OK;
     if (!cam_loc || !ray_dirs || !z || !x || !x01) return HS_ERR_NULL;
     k_ray_points<<<grid_for(R * S * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z, x, x01, R, S, divide_factor, gate ? *gate : hsGate{nullptr, nullptr});
+    return check_launch();
+}
+
+int hs_trunk_split_fwd(const float *Y, int64_t B, int64_t n_main, int32_t K, float *sdf_raw, float *sdf, int64_t *idx, float *grad, float *y_eik,
+                       float *J_eik, void *stream) {
+    if (K < 1 || K > 64 || n_main < 0 || n_main > B) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!Y || (n_main > 0 && (!sdf_raw || !sdf || !idx || !grad)) || (n_main < B && (!y_eik || !J_eik))) return HS_ERR_NULL;
+    const int64_t want = (B + 3) / 4;
+    k_trunk_split_fwd<<<(int)(want < 8192 ? want : 8192), 256, 0, (hipStream_t)stream>>>(Y, B, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik);
+    return check_launch();
+}
+
+int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t *idx, const float *g_grad, const float *g_y_eik, const float *g_J_eik,
+                       int64_t B, int64_t n_main, int32_t K, int32_t KP, void *g, void *stream) {
+    if (K < 1 || K > KP || n_main < 0 || n_main > B) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!g || (n_main > 0 && !idx)) return HS_ERR_NULL;
+    k_trunk_split_bwd<<<grid_for(B * 4 * KP), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_J_eik, B, n_main, K, KP,
+                                                                             (__hip_bfloat16 *)g);
     return check_launch();
 }
 

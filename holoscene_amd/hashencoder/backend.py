@@ -72,7 +72,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
 
 
 def _check(rc, what):
@@ -370,6 +370,20 @@ class _HipBackend:
         _check(lib.hs_trunk_mlp_bwd(_dev(g, "g", bf), g.shape[-1], _dev(H1, "H1", bf), _dev(H0, "H0", bf), _dev(W2t, "W2t", bf),
                                     _dev(W1t, "W1t", bf), _dev(gA1, "gA1", bf), _dev(gA0, "gA0", bf), _dev(gb1, "gb1"), _dev(gb0, "gb0"),
                                     ctypes.c_int64(g.shape[0]), _stream()), "hs_trunk_mlp_bwd")
+
+    @staticmethod
+    def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik):
+        lib = load_library()
+        _check(lib.hs_trunk_split_fwd(_dev(Y, "Y"), ctypes.c_int64(Y.shape[0] // 4), ctypes.c_int64(n_main), K, _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"),
+                                      _dev(idx, "idx", torch.int64), _dev(grad, "grad"), _dev(y_eik, "y_eik"), _dev(J_eik, "J_eik"), _stream()),
+               "hs_trunk_split_fwd")
+
+    @staticmethod
+    def trunk_split_bwd(g_raw, g_sdf, idx, g_grad, g_yeik, g_Jeik, B, n_main, K, g):
+        lib = load_library()
+        _check(lib.hs_trunk_split_bwd(_dev(g_raw, "g_sdf_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), _dev(g_grad, "g_grad"),
+                                      _dev(g_yeik, "g_y_eik"), _dev(g_Jeik, "g_J_eik"), ctypes.c_int64(B), ctypes.c_int64(n_main), K, g.shape[-1],
+                                      _dev(g, "g", torch.bfloat16), _stream()), "hs_trunk_split_bwd")
 
     @staticmethod
     def softplus_tangent_bwd_h(H, G, gA, gbias):

@@ -140,92 +140,141 @@ def _wgrad_rows(g, x):
     return (g.t() @ x).float()
 
 
-class _fused_trunk(torch.autograd.Function):
-    """x [B,3] (constant), hash table, the three effective weight matrices and biases -> y [B,K] f32, J [B,K,3] f32.
+def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
+    """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save."""
+    ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+    x = x.contiguous()
+    x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+    B, D = x01.shape
+    L = offsets.shape[0] - 1
+    C = embeddings.shape[1]
+    dev, bf = x.device, torch.bfloat16
+    feat = torch.empty(B, L * C, device=dev, dtype=x.dtype)
+    dydx = torch.empty(L, B, D * C, device=dev, dtype=x.dtype)
+    _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
+    jac_scale = 0.5 / divide_factor
+    X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
+    _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
+    F_in, d_out = W0.shape[1], W2.shape[0]
+    KP = 32 * ((d_out + 31) // 32)
+    w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
+                  torch.empty(KP, 256, device=dev, dtype=bf))
+    w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
+    f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
+    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
+                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True)])
+    M = 4 * B
+    H0 = torch.empty(M, 256, device=dev, dtype=bf)
+    H1 = torch.empty(M, 256, device=dev, dtype=bf)
+    Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
+    _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
+                               b2.detach().float().contiguous(), d_out, H0, H1, Y)
+    ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
+    return Y, (x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t)
 
-    forward: hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd (3 layers on the matrix cores, activations never
-    leave the CU between layers; the layer outputs H0, H1 are written once for the backward).
-    backward: library GEMMs for the data/weight gradients, hs_softplus_tangent_bwd_h between them (works from H, so
-    the pre-activations are never stored), then the fused value+Jacobian scatter into the table gradient."""
+
+def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
+    """g: cotangent of Y as a bf16 [4B, KP] image.  Returns the gradients of (embeddings, W0, b0, W1, b1, W2, b2):
+    k_trunk_bwd for the data path, library split-M GEMMs for the weight gradients, the 256->96 input-gradient GEMM, and the
+    fused value+Jacobian scatter into the table gradient."""
+    x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t = saved
+    B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
+    dev, bf = X.device, torch.bfloat16
+    M = 4 * B
+    gA1 = torch.empty(M, 256, device=dev, dtype=bf)
+    gA0 = torch.empty(M, 256, device=dev, dtype=bf)
+    gb1 = torch.zeros(256, device=dev)
+    gb0 = torch.zeros(256, device=dev)
+    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0)
+
+    def table_branch():
+        gX = (gA0 @ w0).view(B, 4, _TRUNK_PITCH)
+        g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
+        g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
+        _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
+        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
+
+    g_emb = target = None
+    if need_table:
+        table = ctx.table
+        inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+        target = table.grad if inplace else torch.zeros_like(embeddings)
+        g_emb = None if inplace else target
+        if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
+            # experiment (off by default, see backend.OVERLAP_SCATTER): scatter on a parallel branch beside the GEMMs below
+            with torch.cuda.stream(_be.fork_side_stream(gA0, w0, x01, offsets, target)):
+                table_branch()
+        else:
+            table_branch()
+    gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
+    gW1 = _wgrad_rows(gA1, H0) if need_w else None
+    gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
+    return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
+
+
+class _fused_trunk(torch.autograd.Function):
+    """x [B,3] (constant), hash table, the three effective weight matrices and biases -> y [B,K] f32, J [B,K,3] f32
+    (k_trunk_fwd / k_trunk_bwd, see _trunk_fwd_core / _trunk_bwd_core)."""
 
     @staticmethod
     def forward(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        x = x.contiguous()
-        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
-        B, D = x01.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        dev, bf = x.device, torch.bfloat16
-        feat = torch.empty(B, L * C, device=dev, dtype=x.dtype)
-        dydx = torch.empty(L, B, D * C, device=dev, dtype=x.dtype)
-        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
-        jac_scale = 0.5 / divide_factor
-        X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
-        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
-        F_in, d_out = W0.shape[1], W2.shape[0]
-        KP = 32 * ((d_out + 31) // 32)
-        w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
-                      torch.empty(KP, 256, device=dev, dtype=bf))
-        w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
-        f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
-                                (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True)])
-        M = 4 * B
-        H0 = torch.empty(M, 256, device=dev, dtype=bf)
-        H1 = torch.empty(M, 256, device=dev, dtype=bf)
-        Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
-        _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
-                                   b2.detach().float().contiguous(), d_out, H0, H1, Y)
-        ctx.save_for_backward(x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t)
-        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
-        Y = Y.view(B, 4, d_out)
+        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
+        ctx.save_for_backward(*saved)
+        Y = Y.view(x.shape[0], 4, -1)
         return Y[:, 0].contiguous(), Y[:, 1:].transpose(1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, gy, gJ):
-        x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t = ctx.saved_tensors
-        B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
-        dev, bf = X.device, torch.bfloat16
-        M = 4 * B
-        KP = w2t.shape[1]
-        g = torch.zeros(B, 4, KP, device=dev, dtype=bf)
+        saved = ctx.saved_tensors
+        B, d_out = ctx.cfg[0], ctx.cfg[-1]
+        KP = saved[-1].shape[1]
+        g = torch.zeros(B, 4, KP, device=saved[3].device, dtype=torch.bfloat16)
         if gy is not None:
             g[:, 0, :d_out] = gy
         if gJ is not None:
             g[:, 1:, :d_out] = gJ.transpose(1, 2)
-        g = g.view(M, KP)
-        need_w = ctx.needs_input_grad[7]
         gb2 = gy.sum(0) if ctx.needs_input_grad[12] and gy is not None else None
-        gA1 = torch.empty(M, 256, device=dev, dtype=bf)
-        gA0 = torch.empty(M, 256, device=dev, dtype=bf)
-        gb1 = torch.zeros(256, device=dev)
-        gb0 = torch.zeros(256, device=dev)
-        _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0)
-        def table_branch():
-            gX = (gA0 @ w0).view(B, 4, _TRUNK_PITCH)
-            g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
-            g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
-            _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
-            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
-
-        g_emb = target = None
-        if ctx.needs_input_grad[1]:
-            table = ctx.table
-            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            g_emb = None if inplace else target
-            if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
-                # input-gradient GEMM + slicing + atomic-bound scatter on a parallel branch; the weight-gradient GEMMs below
-                # (matrix-core-bound) proceed on this stream.  Joined by the optimiser (backend.join_side_stream).
-                with torch.cuda.stream(_be.fork_side_stream(gA0, w0, x01, offsets, target)):
-                    table_branch()
-            else:
-                table_branch()
-        gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
-        gW1 = _wgrad_rows(gA1, H0) if need_w else None
-        gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
+        g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g.view(4 * B, KP), gb2, ctx.needs_input_grad[1], ctx.needs_input_grad[7])
         return None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
+
+
+class _fused_trunk_render(torch.autograd.Function):
+    """The trunk pass of one training iteration: rows [0, n_main) are rendered samples, the rest the Eikonal set.
+    Returns sdf_raw [n_main,K], sdf [n_main,1] (min over objects), idx [n_main,1] (argmin, not differentiable),
+    gradients [n_main,3] (d min-sdf / dx), y_eik [Be,K], J_eik [Be,K,3].
+    Versus _fused_trunk + torch ops: the [B,K,3] Jacobian of the rendered points is never materialised, and the cotangent image
+    of the trunk output is assembled by one kernel instead of autograd's zero-fill / scatter / pad chain (csrc/encode_ops.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
+        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
+        B, K = x.shape[0], W2.shape[0]
+        dev = x.device
+        Be = B - n_main
+        sdf_raw, sdf = torch.empty(n_main, K, device=dev), torch.empty(n_main, 1, device=dev)
+        idx = torch.empty(n_main, 1, device=dev, dtype=torch.int64)
+        grad = torch.empty(n_main, 3, device=dev)
+        y_eik, J_eik = torch.empty(Be, K, device=dev), torch.empty(Be, K, 3, device=dev)
+        _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik)
+        ctx.save_for_backward(*saved, idx)
+        ctx.n_main = n_main
+        ctx.mark_non_differentiable(idx)
+        return sdf_raw, sdf, idx, grad, y_eik, J_eik
+
+    @staticmethod
+    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_Jeik):
+        *saved, idx = ctx.saved_tensors
+        B, d_out = ctx.cfg[0], ctx.cfg[-1]
+        KP = saved[-1].shape[1]
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g = torch.empty(4 * B, KP, device=idx.device, dtype=torch.bfloat16)
+        _be._backend.trunk_split_bwd(c(g_raw), c(g_sdf), idx, c(g_grad), c(g_yeik), c(g_Jeik), B, ctx.n_main, d_out, g)
+        gb2 = None
+        if ctx.needs_input_grad[13]:
+            Sg = _split_rows(B)
+            gb2 = g.view(Sg, B // Sg, 4, KP)[:, :, 0, :d_out].sum(1, dtype=torch.float32).sum(0)
+        g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g, gb2, ctx.needs_input_grad[2], ctx.needs_input_grad[8])
+        return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
 
 
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
@@ -1028,11 +1077,20 @@ class HoloSceneNetwork(nn.Module):
             if self.all_mesh_bbox_dict is not None:
                 raise NotImplementedError("collision-driven Eikonal sampling belongs to Stage 2 (network.py:868-902)")
         n_main = points_flat.shape[0]
-        y_all, J_all = net.sdf_and_jacobian(points_flat if eik is None else torch.cat([points_flat, eik], 0))
-        y_all, J_all = y_all[:, :net.d_out], J_all[:, :net.d_out]
-        sdf_raw, J_main = y_all[:n_main], J_all[:n_main]
-        sdf, idx_min = sdf_raw.min(dim=-1, keepdim=True)
-        gradients = torch.gather(J_main, 1, idx_min.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        x_all = points_flat if eik is None else torch.cat([points_flat, eik], 0)
+        if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
+            enc = net.encoding
+            l0, l1, l2 = net._lins()
+            sdf_raw, sdf, idx_min, gradients, y_eik, J_eik = _fused_trunk_render.apply(
+                x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                net.embedder.multires, float(net.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+        else:
+            y_all, J_all = net.sdf_and_jacobian(x_all)
+            y_all, J_all = y_all[:, :net.d_out], J_all[:, :net.d_out]
+            sdf_raw, J_main = y_all[:n_main], J_all[:n_main]
+            sdf, idx_min = sdf_raw.min(dim=-1, keepdim=True)
+            gradients = torch.gather(J_main, 1, idx_min.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+            y_eik, J_eik = y_all[n_main:], J_all[n_main:]
         if not net.color_grid_feature:
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
@@ -1078,7 +1136,7 @@ class HoloSceneNetwork(nn.Module):
 
         if self.training:
             # replaces gradient() + get_sdf_raw() + get_sdf_vals() on the Eikonal set (network.py:856-863)
-            y, J = y_all[n_main:], J_all[n_main:]
+            y, J = y_eik, J_eik
             min_sdf, idx = y.min(dim=-1, keepdim=True)
             g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
             grad_theta = torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)

@@ -670,3 +670,51 @@ def test_whole_iteration_graph_training_reduces_loss():
     assert all(l == l and abs(l) < 1e6 for l in losses)
     assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5
     assert tr.flat.read_state().step >= 40
+
+
+@pytest.mark.parametrize("d_out,B,n_main", [(32, 4096, 3072), (5, 1000, 1000), (21, 130, 0)])
+def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n_main):
+    """_fused_trunk_render (hs_trunk_split_fwd/_bwd around the MFMA trunk) vs _fused_trunk followed by the slicing / min / gather
+    ops of HoloSceneNetwork.render: same kernels underneath, so outputs agree bit for bit and gradients to bf16-image rounding."""
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    net.set_mlp_precision("bf16")
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+    x = torch.rand(B, 3, device=DEV) * 2.4 - 1.2
+    Be = B - n_main
+    cot = [torch.randn(n_main, d_out, device=DEV), torch.randn(n_main, 1, device=DEV), torch.randn(n_main, 3, device=DEV),
+           torch.randn(Be, d_out, device=DEV), torch.randn(Be, d_out, 3, device=DEV)]
+    params = [net.encoding.embeddings] + [p for l in net._lins() for p in (l.weight_v, l.weight_g, l.bias)]
+    enc = net.encoding
+    l0, l1, l2 = net._lins()
+
+    def args():   # fresh weight-norm nodes per run
+        return (enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), 6, 1.0, l0.weight, l0.bias, l1.weight,
+                l1.bias, l2.weight, l2.bias)
+
+    def ref():
+        y, J = N._fused_trunk.apply(x, *args())
+        sdf_raw, Jm = y[:n_main], J[:n_main]
+        sdf, idx = sdf_raw.min(dim=-1, keepdim=True)
+        grad = torch.gather(Jm, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        return [sdf_raw, sdf, grad, y[n_main:], J[n_main:]], idx
+
+    def new():
+        sdf_raw, sdf, idx, grad, y_e, J_e = N._fused_trunk_render.apply(x, n_main, *args())
+        return [sdf_raw, sdf, grad, y_e, J_e], idx
+
+    res = {}
+    for name, fn in (("ref", ref), ("new", new)):
+        outs, idx = fn()
+        loss = sum((o * c).sum() for o, c in zip(outs, cot))
+        res[name] = ([o.detach() for o in outs], idx, [g.float() for g in torch.autograd.grad(loss, params)])
+    for a, b, n in zip(res["new"][0], res["ref"][0], ("sdf_raw", "sdf", "grad", "y_eik", "J_eik")):
+        assert torch.equal(a, b), n
+    assert torch.equal(res["new"][1], res["ref"][1])
+    for a, b, n in zip(res["new"][2], res["ref"][2], ["table"] + [f"lin{i}.{k}" for i in range(3) for k in ("v", "g", "bias")]):
+        rel = float((a - b).norm() / (b.norm() + 1e-20))
+        assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
