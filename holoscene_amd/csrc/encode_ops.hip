@@ -225,6 +225,38 @@ __global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict
     }
 }
 
+// Every position the iteration's render pass evaluates, in one launch (network.py:805-811, 843-854): the R*N rendered samples
+// o + z d, then the Eikonal set = [uniform points | near-surface points o + z_eik d] followed by the same 2R points jittered by
+// (u - 0.5) * 0.01; plus each position's hash-grid coordinate (x/divide_factor + 1)/2 and the per-sample view directions.
+// Same roundings as the whole-tensor ops it replaces (~20 launches): no contraction, scalar division as multiplication by the
+// fp32 reciprocal.
+__global__ __launch_bounds__(kThreads) void k_render_points(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ z,
+                                                             const float *__restrict__ z_eik, const float *__restrict__ eik_uniform,
+                                                             const float *__restrict__ eik_jitter, int64_t R, int N, float divide_factor,
+                                                             float *__restrict__ x, float *__restrict__ x01, float *__restrict__ dirs) {
+    const int64_t n_main = R * N, n_eik = z_eik ? 4 * R : 0;
+    const int64_t total = (n_main + n_eik) * 3;
+    const float inv_df = __fdiv_rn(1.0f, divide_factor);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = i / 3;
+        const int c = (int)(i - p * 3);
+        float v;
+        if (p < n_main) {
+            const int64_t r = p / N;
+            v = __fadd_rn(o[r * 3 + c], __fmul_rn(z[p], d[r * 3 + c]));
+            dirs[i] = d[r * 3 + c];
+        } else {
+            int64_t e = p - n_main;                 // 0..4R: [uniform R | near R | jittered copies 2R]
+            const bool jit = e >= 2 * R;
+            if (jit) e -= 2 * R;
+            v = e < R ? eik_uniform[e * 3 + c] : __fadd_rn(o[(e - R) * 3 + c], __fmul_rn(z_eik[e - R], d[(e - R) * 3 + c]));
+            if (jit) v = __fadd_rn(v, __fmul_rn(__fsub_rn(eik_jitter[e * 3 + c], 0.5f), 0.01f));
+        }
+        x[i] = v;
+        x01[i] = __fmul_rn(__fadd_rn(__fmul_rn(v, inv_df), 1.0f), 0.5f);
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 int grid_for(int64_t total) {
@@ -310,6 +342,16 @@ int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t
     if (!g || (n_main > 0 && !idx)) return HS_ERR_NULL;
     k_trunk_split_bwd<<<grid_for(B * 4 * KP), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_J_eik, B, n_main, K, KP,
                                                                              (__hip_bfloat16 *)g);
+    return check_launch();
+}
+
+int hs_render_points(const float *cam_loc, const float *ray_dirs, const float *z_vals, const float *z_eik, const float *eik_uniform,
+                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, void *stream) {
+    if (N < 1 || divide_factor == 0.f) return HS_ERR_ARG;
+    if (R == 0) return HS_OK;
+    if (!cam_loc || !ray_dirs || !z_vals || !x || !x01 || !dirs_flat || (z_eik && (!eik_uniform || !eik_jitter))) return HS_ERR_NULL;
+    k_render_points<<<grid_for((R * N + (z_eik ? 4 * R : 0)) * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform,
+                                                                                                      eik_jitter, R, N, divide_factor, x, x01, dirs_flat);
     return check_launch();
 }
 

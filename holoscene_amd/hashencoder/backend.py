@@ -72,7 +72,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
 
 
 def _check(rc, what):
@@ -347,6 +347,14 @@ class _HipBackend:
                                      _dev(gy, "gy", bf), _dev(gA_r1, "gA_r1", bf), _dev(gA_r0, "gA_r0", bf), _dev(g_fv, "g_fv", bf),
                                      _dev(gA_hc, "gA_hc", bf), _dev(d_normals, "d_normals"), _dev(g_featc, "g_featc"), _dev(gbias, "gbias"),
                                      ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance_bwd")
+
+    @staticmethod
+    def render_points(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform, eik_jitter, divide_factor, x, x01, dirs_flat):
+        lib = load_library()
+        R, N = z_vals.shape
+        _check(lib.hs_render_points(_dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"), _dev(z_vals, "z_vals"), _dev(z_eik, "z_eik"),
+                                    _dev(eik_uniform, "eik_uniform"), _dev(eik_jitter, "eik_jitter"), ctypes.c_int64(R), N, ctypes.c_float(divide_factor),
+                                    _dev(x, "x"), _dev(x01, "x01"), _dev(dirs_flat, "dirs_flat"), _stream()), "hs_render_points")
 
     @staticmethod
     def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor, gate=None):

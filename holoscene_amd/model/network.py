@@ -140,11 +140,13 @@ def _wgrad_rows(g, x):
     return (g.t() @ x).float()
 
 
-def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
-    """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save."""
+def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+    """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save.
+    x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points)."""
     ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
     x = x.contiguous()
-    x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+    if x01 is None:
+        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
     B, D = x01.shape
     L = offsets.shape[0] - 1
     C = embeddings.shape[1]
@@ -246,8 +248,8 @@ class _fused_trunk_render(torch.autograd.Function):
     of the trunk output is assembled by one kernel instead of autograd's zero-fill / scatter / pad chain (csrc/encode_ops.hip)."""
 
     @staticmethod
-    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
-        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
+    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
         B, K = x.shape[0], W2.shape[0]
         dev = x.device
         Be = B - n_main
@@ -274,7 +276,7 @@ class _fused_trunk_render(torch.autograd.Function):
             Sg = _split_rows(B)
             gb2 = g.view(Sg, B // Sg, 4, KP)[:, :, 0, :d_out].sum(1, dtype=torch.float32).sum(0)
         g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g, gb2, ctx.needs_input_grad[2], ctx.needs_input_grad[8])
-        return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
+        return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
 
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
@@ -290,11 +292,12 @@ class _fused_appearance(torch.autograd.Function):
     split-M GEMMs for the five weight gradients, scatter into the colour table gradient."""
 
     @staticmethod
-    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2):
+    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         be = _be._backend
         points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
-        x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
+        if x01 is None:
+            x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
         B = points.shape[0]
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
         dev, bf = points.device, torch.bfloat16
@@ -350,7 +353,7 @@ class _fused_appearance(torch.autograd.Function):
             else:
                 be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
             g_emb = None if inplace else target
-        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2)
+        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 
 
 class _render_input(torch.autograd.Function):
@@ -1058,32 +1061,41 @@ class HoloSceneNetwork(nn.Module):
         dev = ray_dirs.device
         num_rays = ray_dirs.shape[0]
         N_samples = z_vals.shape[1]
-        points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-        dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N_samples, -1).reshape(-1, 3)
-
         net = self.implicit_network
+        if self.training and self.all_mesh_bbox_dict is not None:
+            raise NotImplementedError("collision-driven Eikonal sampling belongs to Stage 2 (network.py:868-902)")
+        n_main = num_rays * N_samples
         # Eikonal set (network.py:843-854), drawn up front so that ONE value+Jacobian pass serves the rendered points
         # and the Eikonal points together (half the trunk launches; the GEMMs simply get 4 % more rows)
-        eik = None
+        e0 = jitter = None
         if self.training:
-            if "eik_uniform" in rng:
-                eik = rng["eik_uniform"].to(dev)
-            else:
-                eik = torch.empty(num_rays, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere)
-            near_surface = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-            eik = torch.cat([eik, near_surface], 0)
-            jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand_like(eik)
-            eik = torch.cat([eik, eik + (jitter - 0.5) * 0.01], 0)
-            if self.all_mesh_bbox_dict is not None:
-                raise NotImplementedError("collision-driven Eikonal sampling belongs to Stage 2 (network.py:868-902)")
-        n_main = points_flat.shape[0]
-        x_all = points_flat if eik is None else torch.cat([points_flat, eik], 0)
+            e0 = (rng["eik_uniform"].to(dev) if "eik_uniform" in rng
+                  else torch.empty(num_rays, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere))
+            jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand(2 * num_rays, 3, device=dev)
+        x01_all = None
+        if ray_dirs.is_cuda and COMPOSITE_IMPL == "hip":   # all positions, their grid coordinates and the view directions: one kernel
+            n_all = n_main + (4 * num_rays if self.training else 0)
+            x_all, x01_all = torch.empty(n_all, 3, device=dev), torch.empty(n_all, 3, device=dev)
+            dirs_flat = torch.empty(n_main, 3, device=dev)
+            _be._backend.render_points(cam_loc.contiguous(), ray_dirs.contiguous(), z_vals.contiguous(),
+                                       z_samples_eik.reshape(-1).contiguous() if self.training else None,
+                                       None if e0 is None else e0.contiguous().float(), None if jitter is None else jitter.contiguous().float(),
+                                       float(net.divide_factor), x_all, x01_all, dirs_flat)
+            points_flat = x_all[:n_main]
+        else:
+            points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N_samples, -1).reshape(-1, 3)
+            x_all = points_flat
+            if self.training:
+                near_surface = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+                eik = torch.cat([e0, near_surface], 0)
+                x_all = torch.cat([points_flat, eik, eik + (jitter - 0.5) * 0.01], 0)
         if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
             sdf_raw, sdf, idx_min, gradients, y_eik, J_eik = _fused_trunk_render.apply(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
-                net.embedder.multires, float(net.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+                net.embedder.multires, float(net.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias, x01_all)
         else:
             y_all, J_all = net.sdf_and_jacobian(x_all)
             y_all, J_all = y_all[:, :net.d_out], J_all[:, :net.d_out]
@@ -1097,7 +1109,8 @@ class HoloSceneNetwork(nn.Module):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
             rgb = _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
                                           int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
-                                          mlp[2].bias, rn.lin0.weight, rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias)
+                                          mlp[2].bias, rn.lin0.weight, rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias,
+                                          None if x01_all is None else x01_all[:n_main])
             rgb = rgb.reshape(-1, N_samples, 3)
         else:
             feature_vectors = net._color_features(points_flat)

@@ -182,6 +182,12 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
 int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, float *x, float *x01, int64_t R, int32_t S, float divide_factor,
                   const hsGate *gate /* NULL = none */, void *stream);
 
+/* All positions of the render pass in one launch (model/network.py:805-811, 843-854): x [(R*N + 4R), 3] = the R*N rendered
+ * samples cam_loc + z_vals*ray_dirs, then (training: z_eik != NULL) the Eikonal set [eik_uniform [R,3] | cam_loc + z_eik*ray_dirs]
+ * and its copy jittered by (eik_jitter [2R,3] - 0.5)*0.01;  x01 = (x/divide_factor + 1)/2;  dirs_flat [R*N,3] = ray_dirs per sample. */
+int hs_render_points(const float *cam_loc, const float *ray_dirs, const float *z_vals, const float *z_eik, const float *eik_uniform,
+                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, void *stream);
+
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
  * A, out, G, gA: [B, rows, W], storage type `dtype` = HS_F32 or HS_BF16 (arithmetic is fp32 either way; bias and
