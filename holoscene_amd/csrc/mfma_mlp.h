@@ -80,9 +80,10 @@ __device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *
 }
 
 // One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KC.  wave -> neurons [nq*64,+64), points [ph*64,+64)
+// compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
 template <int AP = HP>
 __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
-                                          int nq, int ph, int lane) {
+                                          int nq, int ph, int lane, bool compute = true) {
     const int nchunks = K / KC;
     ChunkRegs pre = load_chunk(W, ldw, 0);
     store_chunk(Wc, pre);
@@ -92,6 +93,7 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
         if (c + 1 < nchunks) pre = load_chunk(W, ldw, (c + 1) * KC);
 #endif
 #ifndef HS_EXP_NO_MMA
+        if (compute) {
         Frags f0 = load_frags<AP>(Wc, H, 2 * c, nq, ph, lane);
         Frags f1 = load_frags<AP>(Wc, H, 2 * c + 1, nq, ph, lane);   // in flight while f0's MFMAs run
 #pragma unroll
@@ -102,6 +104,7 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.a[nt], f1.b[pt], acc[nt][pt], 0, 0, 0);
+        }
 #endif
         if (c + 1 < nchunks) store_chunk(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
         __syncthreads();

@@ -86,18 +86,28 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
     if (threadIdx.x < HID) { bias[threadIdx.x] = b0[threadIdx.x]; bias[HID + threadIdx.x] = b1[threadIdx.x]; }
     if (threadIdx.x < 64) bias[2 * HID + threadIdx.x] = (int)threadIdx.x < d_out ? b2[threadIdx.x] : 0.f;
     const int64_t ntiles = (B + BM - 1) / BM;
+    // this thread's share of a tile's inputs (4 threads per point: coordinates + 8 of the 32 features), fetched one tile ahead so
+    // that the staging phase below never waits on global memory (it used to expose a full load latency per tile)
+    const int sp = threadIdx.x & (BM - 1), spart = threadIdx.x / BM;   // spart 0..3
+    float xv[3];
+    float4 fv[2];
+    auto fetch = [&](int64_t tile_) {
+        const int64_t gp = tile_ * BM + sp;
+        const bool ok = tile_ < ntiles && gp < B;
+        xv[0] = ok ? x[gp * 3] : 0.f; xv[1] = ok ? x[gp * 3 + 1] : 0.f; xv[2] = ok ? x[gp * 3 + 2] : 0.f;
+        const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * NFEAT + spart * 8);
+        fv[0] = ok ? fp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        fv[1] = ok ? fp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");  // keep the per-tile weight loads inside the loop (hoisted they would pin ~90 VGPRs)
         const int64_t p0 = tile * BM;
-        // ---- input features: H[p][0..K0).  Four threads per point; sin/cos pairs from the hardware v_sin/v_cos units
+        // ---- input features: H[p][0..K0).  sin/cos pairs from the hardware v_sin/v_cos units
         //      (arguments <= 2^5 * 1.75 rad, well inside their range; the bf16 destination keeps 8 bits anyway).
         {
-            const int p = threadIdx.x & (BM - 1), part = threadIdx.x / BM;   // part 0..3
-            const int64_t gp = p0 + p;
-            const bool ok = gp < B;
-            uint16_t *row = H + (size_t)p * HP;
-            float xv[3] = {0.f, 0.f, 0.f};
-            if (ok) { xv[0] = x[gp * 3]; xv[1] = x[gp * 3 + 1]; xv[2] = x[gp * 3 + 2]; }
+            const int part = spart;
+            uint16_t *row = H + (size_t)sp * HP;
             if (part == 0) { row[0] = (uint16_t)f2bf(xv[0]); row[1] = (uint16_t)f2bf(xv[1]); row[2] = (uint16_t)f2bf(xv[2]); }
             if (part < 3) {
 #pragma unroll
@@ -116,14 +126,14 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
 #pragma unroll
                 for (int c = NPE + NFEAT; c < K0; c++) row[c] = 0;
             }
-            const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * NFEAT + part * 8);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const float4 v = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v = fv[i];
                 uint16_t *dst = row + NPE + part * 8 + 4 * i;   // odd column -> 2-byte stores
                 dst[0] = (uint16_t)f2bf(v.x); dst[1] = (uint16_t)f2bf(v.y); dst[2] = (uint16_t)f2bf(v.z); dst[3] = (uint16_t)f2bf(v.w);
             }
         }
+        fetch(tile + gridDim.x);   // in flight under the three layers of this tile
         __syncthreads();
         f32x16 acc[2][2];
         zero_acc(acc);
@@ -357,7 +367,8 @@ template <int KP>  // padded d_out: 32 or 64
 __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restrict__ g, const uint16_t *__restrict__ H1, const uint16_t *__restrict__ H0,
                                                          const uint16_t *__restrict__ W2t, const uint16_t *__restrict__ W1t,
                                                          uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
-                                                         float *__restrict__ gb0, int64_t M) {
+                                                         float *__restrict__ gb0, const uint16_t *__restrict__ W0t, uint16_t *__restrict__ gX,
+                                                         int64_t M) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
@@ -394,6 +405,36 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         __syncthreads();
         store_tile(H, gA0, r0, M);
         sum0 += tile_colsum<4>(H);
+        if (W0t) {
+            // ---- cotangent of the trunk input: gX = gA0 . W0 (K0 = 96 columns; W0t = W0^T zero-padded to 256 rows).  Only the
+            //      waves owning neurons < 96 multiply; the others keep streaming weight chunks.  Saves the library GEMM's
+            //      second read of gA0 (214 MB at M = 417 792).
+            zero_acc(acc);
+            layer_mma(W0t, HID, HID, H, Wc, acc, nq, ph, lane, nq < 2);
+            if (nq < 2) {
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    if (nq * 64 + nt * 32 >= K0) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int n0 = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5);
+#pragma unroll
+                        for (int pt = 0; pt < 2; pt++) {
+                            const int p = ph * 64 + pt * 32 + (lane & 31);
+                            uint2 pk;
+                            pk.x = pack_bf16(acc[nt][pt][q * 4 + 0], acc[nt][pt][q * 4 + 1]);
+                            pk.y = pack_bf16(acc[nt][pt][q * 4 + 2], acc[nt][pt][q * 4 + 3]);
+                            *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {
+                const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
+                if (r0 + row < M) *reinterpret_cast<uint4 *>(gX + (size_t)(r0 + row) * K0 + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+            }
+        }
         __syncthreads();
     }
     if (threadIdx.x < HID) {
@@ -455,10 +496,10 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
 }
 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
-                     float *gb1, float *gb0, int64_t M, void *stream) {
+                     float *gb1, float *gb0, const void *W0t, void *gX, int64_t M, void *stream) {
     if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
-    if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0) return HS_ERR_NULL;
+    if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0 || (W0t && !gX)) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
     const int64_t ntiles = (M + BM - 1) / BM;
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
@@ -467,12 +508,12 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, (uint16_t *)gX, M);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, (uint16_t *)gX, M);
     }
     return check_launch();
 }

@@ -162,9 +162,10 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
                   torch.empty(KP, 256, device=dev, dtype=bf))
     w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
+    w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
     f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
     _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
-                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True)])
+                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
     M = 4 * B
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
@@ -172,14 +173,14 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
                                b2.detach().float().contiguous(), d_out, H0, H1, Y)
     ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
-    return Y, (x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t)
+    return Y, (x01, embeddings, offsets, X, H0, H1, w0t, w1t, w2t)
 
 
 def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     """g: cotangent of Y as a bf16 [4B, KP] image.  Returns the gradients of (embeddings, W0, b0, W1, b1, W2, b2):
     k_trunk_bwd for the data path, library split-M GEMMs for the weight gradients, the 256->96 input-gradient GEMM, and the
     fused value+Jacobian scatter into the table gradient."""
-    x01, embeddings, offsets, X, H0, H1, w0, w1t, w2t = saved
+    x01, embeddings, offsets, X, H0, H1, w0t, w1t, w2t = saved
     B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
     dev, bf = X.device, torch.bfloat16
     M = 4 * B
@@ -187,10 +188,10 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     gA0 = torch.empty(M, 256, device=dev, dtype=bf)
     gb1 = torch.zeros(256, device=dev)
     gb0 = torch.zeros(256, device=dev)
-    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0)
+    gX = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf) if need_table else None
+    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, gX)
 
     def table_branch():
-        gX = (gA0 @ w0).view(B, 4, _TRUNK_PITCH)
         g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
         g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
         _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
@@ -204,7 +205,7 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
         g_emb = None if inplace else target
         if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
             # experiment (off by default, see backend.OVERLAP_SCATTER): scatter on a parallel branch beside the GEMMs below
-            with torch.cuda.stream(_be.fork_side_stream(gA0, w0, x01, offsets, target)):
+            with torch.cuda.stream(_be.fork_side_stream(gX, x01, offsets, target)):
                 table_branch()
         else:
             table_branch()
