@@ -367,8 +367,8 @@ template <int KP>  // padded d_out: 32 or 64
 __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restrict__ g, const uint16_t *__restrict__ H1, const uint16_t *__restrict__ H0,
                                                          const uint16_t *__restrict__ W2t, const uint16_t *__restrict__ W1t,
                                                          uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
-                                                         float *__restrict__ gb0, const uint16_t *__restrict__ W0t, uint16_t *__restrict__ gX,
-                                                         int64_t M) {
+                                                         float *__restrict__ gb0, const uint16_t *__restrict__ W0t, float *__restrict__ g_feat,
+                                                         float *__restrict__ g_dydx, int L, int C, float jac_scale, int64_t M) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
@@ -430,9 +430,20 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                 }
             }
             __syncthreads();
-            for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {
-                const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
-                if (r0 + row < M) *reinterpret_cast<uint4 *>(gX + (size_t)(r0 + row) * K0 + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+            // the hash-feature columns of that tile ARE the cotangents the table scatter consumes (hs_trunk_input_bwd's slicing):
+            // value rows -> g_feat [B, L*C]; tangent row d -> g_dydx [L, B, 3*C] scaled by d(x01)/dx.  Coalesced fp32 runs.
+            const int64_t Bp = M >> 2, pb = r0 >> 2;     // points in total / first point of this tile (BM/4 points per tile)
+            const int LC = L * C;
+            for (int idx = threadIdx.x; idx < (BM / 4) * LC; idx += kThreads) {
+                const int pt = idx / LC, f = idx - pt * LC;
+                if (pb + pt < Bp) g_feat[(size_t)(pb + pt) * LC + f] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + f] << 16);
+            }
+            const int run = (BM / 4) * 3 * C;
+            for (int idx = threadIdx.x; idx < L * run; idx += kThreads) {
+                const int l = idx / run, rem = idx - l * run, pt = rem / (3 * C), dc = rem - pt * (3 * C), d = dc / C, c = dc - d * C;
+                if (pb + pt < Bp)
+                    g_dydx[((size_t)l * Bp + pb + pt) * (3 * C) + dc] =
+                        jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * C + c] << 16);
             }
         }
         __syncthreads();
@@ -496,10 +507,12 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
 }
 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
-                     float *gb1, float *gb0, const void *W0t, void *gX, int64_t M, void *stream) {
+                     float *gb1, float *gb0, const void *W0t, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale, int64_t M,
+                     void *stream) {
     if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
-    if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0 || (W0t && !gX)) return HS_ERR_NULL;
+    if (W0t && (L < 1 || C < 1 || L * C != NFEAT)) return HS_ERR_ARG;
+    if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0 || (W0t && (!g_feat || !g_dydx))) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
     const int64_t ntiles = (M + BM - 1) / BM;
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
@@ -508,12 +521,12 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, (uint16_t *)gX, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, (uint16_t *)gX, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M);
     }
     return check_launch();
 }

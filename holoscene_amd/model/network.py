@@ -188,13 +188,13 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     gA0 = torch.empty(M, 256, device=dev, dtype=bf)
     gb1 = torch.zeros(256, device=dev)
     gb0 = torch.zeros(256, device=dev)
-    gX = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf) if need_table else None
-    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, gX)
-
-    def table_branch():
+    g_feat = g_dydx = None
+    if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
         g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
         g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
-        _be._backend.trunk_input_bwd(gX, g_feat, g_dydx, nfreq, L, C, jac_scale)
+    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale)
+
+    def table_branch():
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
 
     g_emb = target = None
@@ -205,7 +205,7 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
         g_emb = None if inplace else target
         if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
             # experiment (off by default, see backend.OVERLAP_SCATTER): scatter on a parallel branch beside the GEMMs below
-            with torch.cuda.stream(_be.fork_side_stream(gX, x01, offsets, target)):
+            with torch.cuda.stream(_be.fork_side_stream(g_feat, g_dydx, x01, offsets, target)):
                 table_branch()
         else:
             table_branch()

@@ -265,10 +265,13 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
  *   W2t [256, g_pitch] = W2^T (zero-padded), W1t [256, 256] = W1^T, both bf16
  *   gA1, gA0 [M, 256] bf16: cotangents of the two hidden pre-activations (feed the weight-gradient GEMMs and, for gA0,
  *   the input-gradient GEMM);  gb1, gb0 [256] fp32 (+=): bias gradients (may be NULL).
- *   W0t [256, 256] bf16 = W0^T (rows = the 96 padded input columns, zero beyond): if given, gX [M, 96] bf16 = gA0 . W0, the
- *   cotangent of hs_trunk_input_fwd's output, is produced in the same pass. */
+ *   W0t [256, 256] bf16 = W0^T (rows = the 96 padded input columns, zero beyond): if given, the cotangent gA0 . W0 of
+ *   hs_trunk_input_fwd's output is formed in the same pass and its hash-feature part is written in the form the table
+ *   scatter reads (what hs_trunk_input_bwd would produce): g_feat [M/4, L*C] fp32 from the value rows, g_dydx [L, M/4, 3*C]
+ *   fp32 = jac_scale * the tangent rows.  Needs L*C == 32. */
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
-                     float *gb1, float *gb0, const void *W0t /* NULL = skip */, void *gX, int64_t M, void *stream);
+                     float *gb1, float *gb0, const void *W0t /* NULL = skip */, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale,
+                     int64_t M, void *stream);
 
 /* Consumers of hs_trunk_mlp_fwd's Y [4*B, K] and producers of its cotangent (K <= 64).  Points b < n_main are rendered
  * samples: sdf_raw [n_main,K] = value rows, sdf [n_main] = min_k, idx [n_main] = argmin (lowest index among equals),

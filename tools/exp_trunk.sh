@@ -12,7 +12,7 @@ dev = 'cuda'
 bf = torch.bfloat16
 X = (torch.randn(M, 96, device=dev) * 0.3).to(bf)
 w0 = (torch.randn(256, 96, device=dev) * 0.05).to(bf); w1 = (torch.randn(256, 256, device=dev) * 0.05).to(bf); w2 = (torch.randn(32, 256, device=dev) * 0.05).to(bf)
-w2t = w2.t().contiguous(); w1t = w1.t().contiguous(); w0t = torch.zeros(256, 256, device=dev, dtype=bf); w0t[:96] = w0.t(); gX = torch.empty(M, 96, device=dev, dtype=bf)
+w2t = w2.t().contiguous(); w1t = w1.t().contiguous(); w0t = torch.zeros(256, 256, device=dev, dtype=bf); w0t[:96] = w0.t(); gfe = torch.empty(M // 4, 32, device=dev); gdy = torch.empty(16, M // 4, 6, device=dev)
 b0 = torch.zeros(256, device=dev); b1 = torch.zeros(256, device=dev); b2 = torch.zeros(32, device=dev)
 H0 = torch.empty(M, 256, device=dev, dtype=bf); H1 = torch.empty(M, 256, device=dev, dtype=bf); Y = torch.empty(M, 32, device=dev)
 g = (torch.randn(M, 32, device=dev)).to(bf); gA1 = torch.empty_like(H0); gA0 = torch.empty_like(H0); gb1 = torch.zeros(256, device=dev); gb0 = torch.zeros(256, device=dev)
@@ -20,7 +20,7 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 def fwd():
     lib.hs_trunk_mlp_fwd(p(X), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, p(H0), p(H1), p(Y), ctypes.c_int64(M), None)
 def bwd():
-    lib.hs_trunk_mlp_bwd(p(g), 32, p(H1), p(H0), p(w2t), p(w1t), p(gA1), p(gA0), p(gb1), p(gb0), p(w0t), p(gX), ctypes.c_int64(M), None)
+    lib.hs_trunk_mlp_bwd(p(g), 32, p(H1), p(H0), p(w2t), p(w1t), p(gA1), p(gA0), p(gb1), p(gb0), p(w0t), p(gfe), p(gdy), 16, 2, ctypes.c_float(0.5), ctypes.c_int64(M), None)
 def t(fn):
     for _ in range(3): fn()
     torch.cuda.synchronize()
