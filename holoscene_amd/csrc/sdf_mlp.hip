@@ -249,7 +249,9 @@ template <int NOUT_TILES>
 __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restrict__ X, const uint16_t *__restrict__ W0, const float *__restrict__ b0,
                                                          const uint16_t *__restrict__ W1, const float *__restrict__ b1,
                                                          const uint16_t *__restrict__ W2, const float *__restrict__ b2, int d_out,
-                                                         uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y, int64_t M) {
+                                                         uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y, int64_t M,
+                                                         const float *__restrict__ xs, const float *__restrict__ feat, const float *__restrict__ dydx,
+                                                         uint16_t *__restrict__ Xout, int L, int C, float jac_scale) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
@@ -262,13 +264,49 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
         const int64_t r0 = tile * BM;
-        for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {
-            const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (r0 + row < M) v = *reinterpret_cast<const uint4 *>(X + (size_t)(r0 + row) * K0 + seg * 8);
-            *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+        if (X) {
+            for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {
+                const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (r0 + row < M) v = *reinterpret_cast<const uint4 *>(X + (size_t)(r0 + row) * K0 + seg * 8);
+                *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+            }
+            __syncthreads();
+        } else {
+            // ---- build the 4-row input in place (what hs_trunk_input_fwd writes): value row [x, sin/cos(2^k x), features],
+            //      tangent row d its derivative w.r.t. x_d (unit vector | +-2^k cos/sin on component d | dy_dx * d(x01)/dx)
+            const int64_t Bp = M >> 2, pb = r0 >> 2;
+            for (int idx = threadIdx.x; idx < (BM / 4) * K0; idx += kThreads) {
+                const int pt = idx / K0, c = idx - pt * K0;
+                const int64_t b = pb + pt;
+                float v0 = 0.f, t[3] = {0.f, 0.f, 0.f};
+                if (b < Bp && c < NPE + NFEAT) {
+                    if (c < 3) {
+                        v0 = xs[b * 3 + c];
+                        t[c] = 1.f;
+                    } else if (c < NPE) {
+                        const int k = (c - 3) / 6, r = (c - 3) - 6 * k, d = r % 3;
+                        const float f = (float)(1 << k);
+                        float sn, cs;
+                        __sincosf(xs[b * 3 + d] * f, &sn, &cs);
+                        if (r < 3) { v0 = sn; t[d] = f * cs; }
+                        else { v0 = cs; t[d] = -f * sn; }
+                    } else {
+                        const int lc = c - NPE, l = lc / C, ch = lc - l * C;
+                        v0 = feat[b * NFEAT + lc];
+                        const float *j = dydx + ((int64_t)l * Bp + b) * 3 * C + ch;
+                        t[0] = j[0] * jac_scale; t[1] = j[C] * jac_scale; t[2] = j[2 * C] * jac_scale;
+                    }
+                }
+                uint16_t *col = H + (size_t)(4 * pt) * HP + c;
+                col[0] = (uint16_t)f2bf(v0); col[HP] = (uint16_t)f2bf(t[0]); col[2 * HP] = (uint16_t)f2bf(t[1]); col[3 * HP] = (uint16_t)f2bf(t[2]);
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < BM * (K0 / 8); idx += kThreads) {   // kept for the weight gradient of layer 0
+                const int row = idx / (K0 / 8), seg = idx - row * (K0 / 8);
+                if (r0 + row < M) *reinterpret_cast<uint4 *>(Xout + (size_t)(r0 + row) * K0 + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+            }
         }
-        __syncthreads();
         f32x16 acc[2][2];
         zero_acc(acc);
         layer_mma(W0, K0, K0, H, Wc, acc, nq, ph, lane);
@@ -484,10 +522,12 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
 }
 
 int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2, const float *b2,
-                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, void *stream) {
+                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, const float *x, const float *feat, const float *dydx, void *Xout, int32_t L,
+                     int32_t C, float jac_scale, void *stream) {
     if (d_out < 1 || d_out > 64 || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
-    if (!X || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !H0 || !H1 || !Y) return HS_ERR_NULL;
+    if (!X && (L < 1 || C < 1 || L * C != NFEAT)) return HS_ERR_ARG;
+    if ((!X && (!x || !feat || !dydx || !Xout)) || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !H0 || !H1 || !Y) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
     const int64_t ntiles = (M + BM - 1) / BM;
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
@@ -496,12 +536,12 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_fwd<1><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
-                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M);
+                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M, x, feat, dydx, (uint16_t *)Xout, L, C, jac_scale);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_fwd<2><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
-                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M);
+                                                     d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M, x, feat, dydx, (uint16_t *)Xout, L, C, jac_scale);
     }
     return check_launch();
 }

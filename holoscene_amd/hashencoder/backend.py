@@ -364,11 +364,12 @@ class _HipBackend:
                "hs_ray_points")
 
     @staticmethod
-    def trunk_mlp_fwd(X, W0, b0, W1, b1, W2, b2, d_out, H0, H1, Y):
+    def trunk_mlp_fwd(X, W0, b0, W1, b1, W2, b2, d_out, H0, H1, Y, x=None, feat=None, dydx=None, Xout=None, L=0, C=0, jac_scale=0.0):
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_trunk_mlp_fwd(_dev(X, "X", bf), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"), _dev(W2, "W2", bf),
                                     _dev(b2, "b2"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y"), ctypes.c_int64(Y.shape[0]),
+                                    _dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(Xout, "Xout", bf), L, C, ctypes.c_float(jac_scale),
                                     _stream()), "hs_trunk_mlp_fwd")
 
     @staticmethod

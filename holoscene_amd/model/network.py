@@ -129,6 +129,9 @@ class _trunk_input(torch.autograd.Function):
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
 TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+# 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
+# 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
+TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") != "0"
 
 
 def _wgrad_rows(g, x):
@@ -156,7 +159,9 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
     jac_scale = 0.5 / divide_factor
     X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
-    _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
+    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L * C == 32 and D == 3   # k_trunk_fwd assembles its input rows itself
+    if not build_in_kernel:
+        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
     F_in, d_out = W0.shape[1], W2.shape[0]
     KP = 32 * ((d_out + 31) // 32)
     w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
@@ -170,8 +175,11 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
     Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
-    _be._backend.trunk_mlp_fwd(X, w0, b0.detach().float().contiguous(), w1, b1.detach().float().contiguous(), w2,
-                               b2.detach().float().contiguous(), d_out, H0, H1, Y)
+    bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
+    if build_in_kernel:
+        _be._backend.trunk_mlp_fwd(None, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y, x.float(), feat, dydx, X, L, C, jac_scale)
+    else:
+        _be._backend.trunk_mlp_fwd(X, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y)
     ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
     return Y, (x01, embeddings, offsets, X, H0, H1, w0t, w1t, w2t)
 

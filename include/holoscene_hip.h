@@ -256,9 +256,12 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
  *   X  [M, 96] bf16: hs_trunk_input_fwd output with pitch 96 (M = 4 * points, M % 4 == 0)
  *   W0 [256, 96], W1 [256, 256], W2 [32*ceil(d_out/32), 256] bf16 (zero-padded), biases fp32
  *   H0, H1 [M, 256] bf16: layer outputs kept for the backward pass (value rows softplus100(v), tangent rows
- *   sigmoid(100 v) * pre-activation);   Y [M, d_out] fp32 (b2 added on value rows only). */
+ *   sigmoid(100 v) * pre-activation);   Y [M, d_out] fp32 (b2 added on value rows only).
+ *   X == NULL: the input rows are built inside the kernel from x [M/4,3], feat [M/4, L*C] and dydx [L, M/4, 3*C] (exactly
+ *   hs_trunk_input_fwd with nfreq = 6, L*C = 32) and written to Xout [M, 96] for the weight gradient. */
 int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2, const float *b2,
-                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, void *stream);
+                     int32_t d_out, void *H0, void *H1, float *Y, int64_t M, const float *x, const float *feat, const float *dydx, void *Xout, int32_t L,
+                     int32_t C, float jac_scale, void *stream);
 
 /* Backward data path of hs_trunk_mlp_fwd in one kernel.
  *   g [M, g_pitch] bf16: cotangent of Y, zero-padded to g_pitch = 32 or 64 columns
