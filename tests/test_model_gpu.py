@@ -490,10 +490,16 @@ def test_fused_mfma_training_trunk_vs_gemm_path(d_out, B, monkeypatch):
     gem = run("bf16", "gemm")
     assert net._fused_trunk_supported(x)
     got = run("bf16", "mfma")
+    monkeypatch.setattr(N, "TRUNK_INPUT_IN_KERNEL", True)     # the kernel assembling its own input rows: same numbers up to the
+    got_in = run("bf16", "mfma")                               # hardware vs libm sin/cos before the bf16 rounding
+    monkeypatch.setattr(N, "TRUNK_INPUT_IN_KERNEL", False)
+
     def errs(a, b):
         return float((a - b).abs().max()), float(b.abs().max()), float((a - b).norm() / (b.norm() + 1e-20))
 
     flat = lambda r: [r[0], r[1]] + r[2]  # noqa: E731
+    for a, b, n in zip(flat(got_in), flat(got), ["y", "J"] + names):
+        assert errs(a, b)[2] < 5e-3, ("in-kernel input", n, errs(a, b))
     for a, g, b, n in zip(flat(got), flat(gem), flat(ref), ["y", "J"] + names):
         err, scale, rel = errs(a, b)
         gerr, _, grel = errs(g, b)
