@@ -272,6 +272,139 @@ __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const Level
     }
 }
 
+// ------------------------------------------------------------------------------------ binned scatter (hashed levels)
+// Random global float atomics retire at one lane-operation per clock per XCD (~21 G/s for the chip) whatever their addresses
+// (tools/exp/atomic_xcd.hip); a hashed level gives the wave-merge above nothing to merge, so a dense backward pass spends
+// ~1 ms per table issuing 27 M of them.  Scattered plain STORES run 4x faster and LDS atomics 9x, hence two phases:
+//   1. (in the scatter kernels) every non-zero corner contribution becomes a 4+4C-byte record {cell within bin, values},
+//      appended to the bin (1/128 of the level's table) its cell falls in: ranks inside the workgroup by LDS atomics, one
+//      global atomic per (workgroup, touched bin) to reserve space;
+//   2. k_hash_bin_reduce: one workgroup per (level, bin) accumulates its records in LDS (32 KB = 4 096 cells x 2 floats at
+//      T = 2^19) and adds the result to the table with plain coalesced read-modify-writes -- it owns those cells.
+// Dense (coarse) levels keep the wave-merged atomic path, which already removes most of their traffic.  Records that do not
+// fit the bin's capacity fall back to atomics.
+constexpr uint32_t kBins = HS_SCATTER_BINS;
+constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4 096 cells x 2 floats; five workgroups per CU hide each other's latency
+
+template <int C>
+struct BinRecord { uint32_t cell; float v[C]; };
+
+__device__ __forceinline__ bool binned_level(const LevelInfo &li, int C, const void *ws) {
+    return ws != nullptr && li.hashed && (li.table & (li.table - 1u)) == 0u && li.table >= 64u * kBins &&
+           (size_t)(li.table / kBins) * C * sizeof(float) <= kReduceLds;
+}
+
+// all threads of the workgroup call this (level is workgroup-uniform)
+template <int D, int C>
+__device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restrict__ gg, const LevelInfo &li, uint32_t level, const uint32_t g[D],
+                                         const float cache[(1 << D) * C], bool valid) {
+    __shared__ uint32_t hist[kBins], base[kBins];
+    uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
+    BinRecord<C> *records = reinterpret_cast<BinRecord<C> *>(reinterpret_cast<char *>(lay.scatter_ws) + HS_MAX_LEVELS * kBins * sizeof(uint32_t));
+    const uint32_t per_bin = li.table / kBins;
+    if (threadIdx.x < kBins) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t cell[1 << D], rank[1 << D];
+    bool nz[1 << D];
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        uint32_t gl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) gl[d] = g[d] + ((corner >> d) & 1);
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < C; c++) any |= cache[corner * C + c] != 0.f;
+        nz[corner] = valid && any;
+        cell[corner] = nz[corner] ? cell_index<D>(li, gl) : 0u;
+        rank[corner] = nz[corner] ? atomicAdd(&hist[cell[corner] / per_bin], 1u) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins && hist[threadIdx.x] != 0u) base[threadIdx.x] = atomicAdd(&counts[level * kBins + threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); corner++) {
+        if (!nz[corner]) continue;
+        const uint32_t bin = cell[corner] / per_bin, pos = base[bin] + rank[corner];
+        if (pos < lay.scatter_cap) {
+            BinRecord<C> r;
+            r.cell = cell[corner] - bin * per_bin;
+#pragma unroll
+            for (int c = 0; c < C; c++) r.v[c] = cache[corner * C + c];
+            records[((size_t)level * kBins + bin) * lay.scatter_cap + pos] = r;
+        } else {   // bin full: straight to the table
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float v = cache[corner * C + c];
+                if (v != 0.f) unsafeAtomicAdd(gg + (size_t)cell[corner] * C + c, v);
+            }
+        }
+    }
+}
+
+// (a kernel, not hipMemsetAsync: a memset node inside a captured graph cost ~0.5 ms per replay on this stack)
+__global__ void k_zero_u32(uint32_t *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+template <int D, int C>
+__global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
+                                                          hsHashLayout lay) {
+    extern __shared__ float acc[];
+    const uint32_t level = blockIdx.y, bin = blockIdx.x;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    if (!binned_level(li, C, lay.scatter_ws)) return;
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(lay.scatter_ws);
+    const BinRecord<C> *records = reinterpret_cast<const BinRecord<C> *>(reinterpret_cast<const char *>(lay.scatter_ws) +
+                                                                          HS_MAX_LEVELS * kBins * sizeof(uint32_t)) +
+                                  ((size_t)level * kBins + bin) * lay.scatter_cap;
+    const uint32_t n = min(counts[level * kBins + bin], lay.scatter_cap);
+    if (n == 0u) return;
+    const uint32_t per_bin = li.table / kBins;
+    const uint32_t nvec = per_bin * C / 4;                       // per_bin >= 64: a whole number of float4
+    float4 *acc4 = reinterpret_cast<float4 *>(acc);
+    for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // records: independent loads, four in flight per thread before the first LDS atomic
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * blockDim.x < n; i += 4 * blockDim.x) {
+        BinRecord<C> r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = records[i + k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < C; c++) atomicAdd(&acc[r[k].cell * C + c], r[k].v[c]);
+    }
+    for (; i < n; i += blockDim.x) {
+        const BinRecord<C> r = records[i];
+#pragma unroll
+        for (int c = 0; c < C; c++) atomicAdd(&acc[r.cell * C + c], r.v[c]);
+    }
+    __syncthreads();
+    // this workgroup owns the bin's cells: plain 16-byte read-modify-writes, all loads of a thread issued before its stores
+    float4 *dst = reinterpret_cast<float4 *>(gemb + ((size_t)li.offset + (size_t)bin * per_bin) * C);
+    constexpr int kV = 4;
+    for (uint32_t j0 = threadIdx.x; j0 < nvec; j0 += kV * blockDim.x) {
+        float4 a[kV], t[kV];
+        bool any[kV];
+#pragma unroll
+        for (int k = 0; k < kV; k++) {
+            const uint32_t j = j0 + k * blockDim.x;
+            a[k] = j < nvec ? acc4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            any[k] = a[k].x != 0.f || a[k].y != 0.f || a[k].z != 0.f || a[k].w != 0.f;
+            if (any[k]) t[k] = dst[j];
+        }
+#pragma unroll
+        for (int k = 0; k < kV; k++) {
+            if (!any[k]) continue;
+            const uint32_t j = j0 + k * blockDim.x;
+            t[k].x += a[k].x; t[k].y += a[k].y; t[k].z += a[k].z; t[k].w += a[k].w;
+            dst[j] = t[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ first backward: scatter
 template <int D, int C>
 __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__restrict__ grad, const float *__restrict__ x,
@@ -304,7 +437,8 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
 #pragma unroll
         for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
-    scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
+    if (binned_level(li, C, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
+    else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 
 // ------------------------------------------------------------------------------------ first backward: d/dx
@@ -459,7 +593,8 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             }
         }
     }
-    scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
+    if (binned_level(li, C, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
+    else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -478,6 +613,8 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.schedule = 0;
     lay.gate.a = nullptr;
     lay.gate.b = nullptr;
+    lay.scatter_ws = nullptr;
+    lay.scatter_cap = 0;
     return lay;
 }
 
@@ -541,9 +678,12 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
     hipStream_t st = (hipStream_t)stream;
     if (grad_embeddings) {
         const LevelScales sc = make_scales(L, S, H);
+        if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
         dispatch_dc(D, C, [&](auto d, auto c) {
             k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
                 grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+            if (lay.scatter_ws)
+                k_hash_bin_reduce<decltype(d)::value, decltype(c)::value><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
         });
     }
     if (grad_inputs)
@@ -581,11 +721,22 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);
     hipStream_t st = (hipStream_t)stream;
+    if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
     dispatch_dc(D, C, [&](auto d, auto c) {
         k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
             g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+        if (lay.scatter_ws)
+            k_hash_bin_reduce<decltype(d)::value, decltype(c)::value><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
     });
     return check_launch();
+}
+
+int64_t hs_hash_scatter_ws_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t *cap_out) {
+    if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    const uint64_t per_level = (uint64_t)B << D;                           // corner contributions of one level
+    const uint32_t cap = (uint32_t)(per_level / kBins * 3 / 2 + 1024);     // hashed cells are uniform over the bins: 50 % head room
+    if (cap_out) *cap_out = cap;
+    return (int64_t)(HS_MAX_LEVELS * kBins * sizeof(uint32_t)) + (int64_t)L * kBins * (int64_t)cap * (int64_t)(4 + 4 * C);
 }
 
 // ---- reference-compatible entry points (hashencoder/src/bindings.cpp:5-9)

@@ -27,7 +27,8 @@ class hsGate(ctypes.Structure):
 
 class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
-                ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate)]
+                ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
+                ("scatter_cap", ctypes.c_uint32)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -72,7 +73,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
 
 
 def _check(rc, what):
@@ -97,6 +98,8 @@ def _stream():
 
 
 SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
+# Scatter the hashed levels through per-bin record lists + an LDS reduction instead of global atomics (csrc/hash_encode.hip)
+SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
 
 # When True and a table already has a `.grad` buffer attached (flat gradient storage, training/flat.py), the
 # scatter kernels accumulate straight into it and the autograd Functions return no table gradient -- this removes
@@ -168,8 +171,25 @@ class _HipBackend:
 
     # ---- strided / selective variants (include/holoscene_hip.h section 2); point-major features, level-major dy_dx
     @staticmethod
-    def _layout(B, D, C, L, gate=None):
-        return hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate))
+    def _layout(B, D, C, L, gate=None, ws=None):
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0)
+        if ws is not None:
+            buf, cap = ws
+            lay.scatter_ws, lay.scatter_cap = _dev(buf, "scatter_ws", torch.uint8).value, cap
+        return lay
+
+    @staticmethod
+    def scatter_workspace(B, D, C, L, device):
+        """(uint8 buffer, per-bin capacity) for the binned scatter of hs_hash_bwd / hs_hash_bwd_jac, or None when disabled."""
+        if not SCATTER_BINS:
+            return None
+        lib = load_library()
+        lib.hs_hash_scatter_ws_bytes.restype = ctypes.c_int64
+        cap = ctypes.c_uint32(0)
+        n = lib.hs_hash_scatter_ws_bytes(B, D, C, L, ctypes.byref(cap))
+        if n < 0:
+            raise RuntimeError(f"hs_hash_scatter_ws_bytes: {n}")
+        return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
 
     @classmethod
     def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None):
@@ -180,9 +200,9 @@ class _HipBackend:
                                _stream()), "hs_hash_fwd")
 
     @classmethod
-    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs):
+    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L)
+        lay = cls._layout(B, D, C, L, ws=ws)
         _check(lib.hs_hash_bwd(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
                                _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
                                _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay), _stream()), "hs_hash_bwd")
@@ -197,9 +217,9 @@ class _HipBackend:
                                 _stream()), "hs_hash_bwd2")
 
     @classmethod
-    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H):
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L)
+        lay = cls._layout(B, D, C, L, ws=ws)
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")

@@ -129,6 +129,7 @@ class _trunk_input(torch.autograd.Function):
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
 TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+_BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
 # 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
 # 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
 TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") != "0"
@@ -203,7 +204,8 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale)
 
     def table_branch():
-        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres)
+        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
+                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None)
 
     g_emb = target = None
     if need_table:
@@ -360,7 +362,8 @@ class _fused_appearance(torch.autograd.Function):
                 with torch.cuda.stream(_be.fork_side_stream(g_featc, x01, offsets, target)):
                     be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
             else:
-                be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
+                be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
+                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None)
             g_emb = None if inplace else target
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 

@@ -103,7 +103,13 @@ typedef struct hsHashLayout {
     int64_t dydx_point_stride;
     int32_t schedule;
     hsGate gate;               /* honoured by hs_hash_fwd only */
+    void *scatter_ws;          /* NULL, or work space of hs_hash_scatter_ws_bytes() bytes: hs_hash_bwd / hs_hash_bwd_jac then scatter */
+    uint32_t scatter_cap;      /* the hashed levels through per-bin record lists + an LDS reduction instead of global atomics     */
 } hsHashLayout;
+
+/* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */
+#define HS_SCATTER_BINS 128
+int64_t hs_hash_scatter_ws_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t *cap_out);
 
 int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,
                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
