@@ -184,40 +184,50 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.rays * world * args.steps / elapsed
 
-    # ---- roofline of the dominant hand-written kernel: k_hash_bwd_jac, the fused value+Jacobian scatter into the
-    # geometry-grid gradient (largest single kernel of the iteration in profiles/).  Kernels inside a replayed HIP
-    # graph cannot be bracketed by events, so the same iteration is run eagerly a few times right after the timed
-    # region and every launch of the kernel is timed with HIP events on the launching stream.
-    # Algorithmic bytes per point (SURVEY 8d, G = L*8*C*4 = 1024 B): read-modify-write of the 8 corner entries on all
-    # levels = 2G, plus the cotangents g_feat (L*C*4 = 128 B), g_dydx (L*3*C*4 = 384 B) and the coordinates (12 B).
+    # ---- roofline of the dominant hand-written kernel on the hash side: k_hash_fwd<3,2,false>, the gather of the sampler's SDF
+    # sweeps (5 launches of R*S points per iteration: the largest hash-grid consumer once the scatter is binned / zero-skipped).
+    # Kernels inside a replayed HIP graph cannot be bracketed by events, so the same iteration is run eagerly a few times right
+    # after the timed region and every launch is timed with HIP events on the launching stream.
+    # Algorithmic bytes per point: gather G = L*8*C*4 = 1024 B + coordinates 12 B + features out L*C*4 = 128 B.
     L, C = 16, 2
     G = L * 8 * C * 4
-    bytes_per_point = 2 * G + L * C * 4 + L * 3 * C * 4 + 12
-    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2) + 4 * args.rays   # rendered points + Eikonal set, one launch
+    bytes_per_point = G + 12 + L * C * 4
+    n_sweep = args.rays * args.samples
+    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2) + 4 * args.rays   # rendered points + Eikonal set (scatter launch)
+    scatter_bytes_per_point = 2 * G + L * C * 4 + L * 3 * C * 4 + 12
     tr.use_graph = False
-    with KernelTimer(backend._HipBackend, "bwd_jac", size_arg=5) as kt, KernelTimer(backend._HipBackend, "sdf_mlp_fwd", size_arg=0) as km:
+    with KernelTimer(backend._HipBackend, "fwd", size_arg=4) as kf, KernelTimer(backend._HipBackend, "bwd_jac", size_arg=5) as kt, \
+            KernelTimer(backend._HipBackend, "sdf_mlp_fwd", size_arg=0) as km:
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        kt.enabled = km.enabled = True
+        kf.enabled = kt.enabled = km.enabled = True
         for _ in range(args.roofline_steps):
             step()
         torch.cuda.synchronize()
-        kt.enabled = km.enabled = False
-        ms = [t for t, b in zip(*kt.summary()) if b == n_main]
+        kf.enabled = kt.enabled = km.enabled = False
+        ms = [t for t, b in zip(*kf.summary()) if b == n_sweep]
+        sc_ms = [t for t, b in zip(*kt.summary()) if b == n_main]
         mfma_ms = km.summary()[0]
         mfma_pts = [int(x_.shape[0]) for x_ in km.summary()[1]]
     total_ms = sum(ms)
-    achieved = bytes_per_point * n_main * len(ms) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    achieved = bytes_per_point * n_sweep * len(ms) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
     if os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (corrected as the microarch guide says)
-        traffic = json.load(open(pmc_file)).get("k_hash_bwd_jac_main_launch_bytes")
-    roofline = {"kernel": "k_hash_bwd_jac<3,2> (fused value+Jacobian scatter, geometry grid; rendered points + Eikonal set)", "bound": "hbm",
+        traffic = json.load(open(pmc_file)).get("k_hash_fwd_sweep_launch_bytes")
+    roofline = {"kernel": "k_hash_fwd<3,2,false> (hash-grid gather of one sampler SDF sweep: rays x samples points, geometry grid)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": len(ms), "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2),
-                "algorithmic_bytes_per_launch": bytes_per_point * n_main,
-                "note": "float-atomic scatter: bounded by the global atomic issue rate (1 lane-op/clk/XCD = ~21 G/s measured, tools/exp/atomic_xcd.hip), not by HBM bandwidth; exactly-zero contributions are skipped but counted as algorithmic bytes"}
+                "algorithmic_bytes_per_launch": bytes_per_point * n_sweep,
+                "note": "random 8-byte gathers: the 48.8 MB table is resident in the 256 MB memory-side cache, so the bound is the L2/fabric "
+                        "gather rate, not the HBM pins; the first sweep of an iteration runs cold (right after Adam streamed 0.7 GB)"}
+    if sc_ms:   # the scatter side: zero + record binning / wave-merged atomics + per-bin LDS reduction, timed as one operation
+        roofline["scatter_op"] = {"op": "hs_hash_bwd_jac (k_hash_bwd_jac + k_hash_bin_reduce; rendered points + Eikonal set)",
+                                  "avg_us": round(sum(sc_ms) / len(sc_ms) * 1e3, 2), "calls": len(sc_ms),
+                                  "algorithmic_bytes_per_call": scatter_bytes_per_point * n_main,
+                                  "achieved_GBs": round(scatter_bytes_per_point * n_main * len(sc_ms) / (sum(sc_ms) * 1e-3) / 1e9, 1),
+                                  "note": "exactly-zero contributions are skipped but counted as algorithmic bytes"}
     if mfma_ms:  # the matrix-core kernel of the path (sampler SDF sweeps), for the MFMA side of the roofline
         flops = sum(p * 2 * (96 * 256 + 256 * 256 + 256 * 32) for p in mfma_pts)
         roofline["mfma_kernel"] = {"kernel": "k_sdf_mlp<1> (bf16 MFMA fused SDF trunk)", "achieved": round(flops / (sum(mfma_ms) * 1e-3) / 1e12, 1),
