@@ -54,6 +54,17 @@ __device__ __forceinline__ float laplace_sigma(float s, float beta) {
     return (1.f / beta) * (0.5f + 0.5f * sgn * expm1f(-fabsf(s) / beta));
 }
 
+// The line search evaluates the bound 11 times per ray and round; with libm expf/expm1f (15-20 instructions each, four per
+// section) the update kernel is ALU-bound.  Hardware exponentials (v_exp_f32, 1-2 ulp) change the bound by ~1e-6 relative: a
+// bisection decision flips only if the bound lies that close to eps.  The draw kernels keep libm: they place the samples.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float laplace_sigma_fast(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    const float x = -fabsf(s) / beta;
+    const float em1 = x > -1e-3f ? x + 0.5f * x * x : __expf(x) - 1.f;   // expm1 near 0 by its series
+    return (1.f / beta) * (0.5f + 0.5f * sgn * em1);
+}
+
 // sections [lo, hi) handled by this lane
 __device__ __forceinline__ void lane_chunk(int n, int lane, int &lo, int &hi) {
     const int ch = (n + kWave - 1) / kWave;
@@ -102,8 +113,8 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
     chunk_of(n, tid, kUpd, lo, hi);
     float fsum = 0.f, esum = 0.f;
     for (int i = lo; i < hi; i++) {
-        const float f_i = dists[i] * laplace_sigma(sdf[i], beta);
-        const float e_i = expf(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
+        const float f_i = dists[i] * laplace_sigma_fast(sdf[i], beta);
+        const float e_i = fast_exp(-dstar[i] / beta) * (dists[i] * dists[i]) / (4.f * beta * beta);
         fe[i] = f_i; ee[i] = e_i;
         fsum += f_i; esum += e_i;
     }
@@ -112,7 +123,7 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
     float best = -INFINITY;
     for (int i = lo; i < hi; i++) {
         e += ee[i];
-        const float b = (fminf(expf(e), 1.0e6f) - 1.0f) * expf(-f);
+        const float b = (fminf(fast_exp(e), 1.0e6f) - 1.0f) * fast_exp(-f);
         best = fmaxf(best, b);
         f += fe[i];
     }
