@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
                                                        const float *__restrict__ b0, const uint16_t *__restrict__ W1,
                                                        const float *__restrict__ b1, const uint16_t *__restrict__ W2,
                                                        const float *__restrict__ b2, int d_out, int select, float *__restrict__ out_min,
-                                                       float *__restrict__ out_raw, int64_t B, hsGate gate) {
+                                                       float *__restrict__ out_raw, int64_t B, hsGate gate, int feat_level_major) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
     uint16_t *H = lds;                                  // [BM][HP]
@@ -95,9 +95,17 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
         const int64_t gp = tile_ * BM + sp;
         const bool ok = tile_ < ntiles && gp < B;
         xv[0] = ok ? x[gp * 3] : 0.f; xv[1] = ok ? x[gp * 3 + 1] : 0.f; xv[2] = ok ? x[gp * 3 + 2] : 0.f;
-        const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * NFEAT + spart * 8);
-        fv[0] = ok ? fp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        fv[1] = ok ? fp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (feat_level_major) {   // feat [16, B, 2]: what the hash kernel writes fully coalesced (8 bytes per lane, lanes = points)
+            const float2 *fl = reinterpret_cast<const float2 *>(feat) + (size_t)(spart * 4) * B + (ok ? gp : 0);
+            const float2 z2 = make_float2(0.f, 0.f);
+            const float2 a = ok ? fl[0] : z2, b = ok ? fl[B] : z2, c = ok ? fl[2 * B] : z2, e = ok ? fl[3 * B] : z2;
+            fv[0] = make_float4(a.x, a.y, b.x, b.y);
+            fv[1] = make_float4(c.x, c.y, e.x, e.y);
+        } else {
+            const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * NFEAT + spart * 8);
+            fv[0] = ok ? fp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            fv[1] = ok ? fp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -499,7 +507,8 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 extern "C" {
 
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate, void *stream) {
+                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
+                   void *stream) {
     if (d_out < 1 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!x || !feat || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out_min) return HS_ERR_NULL;
@@ -511,12 +520,12 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_sdf_mlp<1><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
-                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr});
+                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
-                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr});
+                                                   out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     }
     return check_launch();
 }

@@ -171,8 +171,10 @@ class _HipBackend:
 
     # ---- strided / selective variants (include/holoscene_hip.h section 2); point-major features, level-major dy_dx
     @staticmethod
-    def _layout(B, D, C, L, gate=None, ws=None):
+    def _layout(B, D, C, L, gate=None, ws=None, level_major=False):
         lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0)
+        if level_major:      # features [L, B, C]: consecutive lanes (points) write consecutive 4C-byte entries
+            lay.level_stride, lay.point_stride = B * C, C
         if ws is not None:
             buf, cap = ws
             lay.scatter_ws, lay.scatter_cap = _dev(buf, "scatter_ws", torch.uint8).value, cap
@@ -192,9 +194,9 @@ class _HipBackend:
         return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
 
     @classmethod
-    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None):
+    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, gate)
+        lay = cls._layout(B, D, C, L, gate, level_major=level_major)
         _check(lib.hs_hash_fwd(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
                                _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), ctypes.byref(lay),
                                _stream()), "hs_hash_fwd")
@@ -328,12 +330,12 @@ class _HipBackend:
 
     # ---- fused SDF-trunk inference (include/holoscene_hip.h section 7)
     @staticmethod
-    def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw, gate=None):
+    def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw, gate=None, feat_level_major=False):
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
                                   _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
-                                  ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), _stream()), "hs_sdf_mlp_fwd")
+                                  ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp_fwd")
 
     @staticmethod
     def pack_bf16(jobs):

@@ -734,13 +734,16 @@ class ObjectImplicitNetworkGrid(nn.Module):
         be.ray_points(cam_loc.contiguous(), ray_dirs.contiguous(), z.contiguous(), x, x01, float(self.divide_factor), gate=gate)
         enc = self.encoding
         L, C = enc.num_levels, enc.level_dim
-        feat = torch.empty(R * S, L * C, device=dev)
+        # level-major features [L, R*S, C]: the gather kernel's stores become fully coalesced (point-major 8-byte pieces at a
+        # 128-byte stride were written 4x, PMC WRITE_SIZE 66 MB for 17 MB), and the MFMA kernel reads 8-byte runs per level
+        lm = L == 16 and C == 2
+        feat = torch.empty((L, R * S, C) if lm else (R * S, L * C), device=dev)
         be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
-               gate=gate)
+               gate=gate, level_major=lm)
         d_out = self._lins()[2].out_features
         out = torch.empty(R, S, device=dev)
         w0, b0, w1, b1, w2, b2 = self._packed_weights()
-        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, None, gate=gate)
+        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, None, gate=gate, feat_level_major=lm)
         return out
 
     def sdf_and_jacobian(self, x):

@@ -255,7 +255,8 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
  *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
  *   out_min [B] = min_k y_k (select < 0) or y_select; out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate /* NULL = none */, void *stream);
+                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate /* NULL = none */,
+                   int32_t feat_level_major /* 0: feat [B,32]; 1: feat [16,B,2] (level-major, as hs_hash_fwd writes fully coalesced) */, void *stream);
 
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
  * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).
