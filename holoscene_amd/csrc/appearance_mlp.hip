@@ -155,14 +155,15 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
                 uint16_t *prow = P + (size_t)p * PP;
 #pragma unroll
                 for (int c = 3 * NPE1; c < PW; c++) prow[c] = 0;
-                const float4 *fp = reinterpret_cast<const float4 *>(featc + (ok ? gp : 0) * NFC);
+                // featc is level-major [16, B, 2] (the hash kernel's coalesced store order): 8 bytes per level, consecutive points adjacent
+                const float2 *fl = reinterpret_cast<const float2 *>(featc) + (ok ? gp : 0);
                 uint16_t *hrow = H + (size_t)p * HP;
 #pragma unroll
                 for (int i = 0; i < NFC / 4; i++) {
-                    const float4 f = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float2 a = ok ? fl[(size_t)(2 * i) * B] : make_float2(0.f, 0.f), b = ok ? fl[(size_t)(2 * i + 1) * B] : make_float2(0.f, 0.f);
                     uint2 pk;
-                    pk.x = pack_bf16(f.x, f.y);
-                    pk.y = pack_bf16(f.z, f.w);
+                    pk.x = pack_bf16(a.x, a.y);
+                    pk.y = pack_bf16(b.x, b.y);
                     *reinterpret_cast<uint2 *>(hrow + 4 * i) = pk;
                 }
             }
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
             for (int i = 0; i < 16; i++) srow[(i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)] = y[i];
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < BM * NFC; idx += kThreads) {   // coalesced fp32 rows for the hash scatter
-            const int row = idx >> 5, c = idx & 31;
-            if (p0 + row < B) g_featc[(size_t)(p0 + row) * NFC + c] = S[(size_t)row * SP + c];
+        for (int idx = threadIdx.x; idx < BM * NFC; idx += kThreads) {   // level-major [16, B, 2] fp32: coalesced runs for the hash scatter
+            const int l = idx / (BM * 2), rem = idx - l * (BM * 2), row = rem >> 1, ch = rem & 1;
+            if (p0 + row < B) g_featc[((size_t)l * B + p0 + row) * 2 + ch] = S[(size_t)row * SP + l * 2 + ch];
         }
         __syncthreads();
     }

@@ -477,12 +477,13 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             }
             __syncthreads();
             // the hash-feature columns of that tile ARE the cotangents the table scatter consumes (hs_trunk_input_bwd's slicing):
-            // value rows -> g_feat [B, L*C]; tangent row d -> g_dydx [L, B, 3*C] scaled by d(x01)/dx.  Coalesced fp32 runs.
+            // value rows -> g_feat [L, B, C] (level-major); tangent row d -> g_dydx [L, B, 3*C] scaled by d(x01)/dx.  Coalesced fp32 runs.
             const int64_t Bp = M >> 2, pb = r0 >> 2;     // points in total / first point of this tile (BM/4 points per tile)
             const int LC = L * C;
-            for (int idx = threadIdx.x; idx < (BM / 4) * LC; idx += kThreads) {
-                const int pt = idx / LC, f = idx - pt * LC;
-                if (pb + pt < Bp) g_feat[(size_t)(pb + pt) * LC + f] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + f] << 16);
+            for (int idx = threadIdx.x; idx < (BM / 4) * LC; idx += kThreads) {   // level-major [L, B, C]
+                const int l = idx / ((BM / 4) * C), rem = idx - l * ((BM / 4) * C), pt = rem / C, c = rem - pt * C;
+                if (pb + pt < Bp)
+                    g_feat[((size_t)l * Bp + pb + pt) * C + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * C + c] << 16);
             }
             const int run = (BM / 4) * 3 * C;
             for (int idx = threadIdx.x; idx < L * run; idx += kThreads) {

@@ -202,9 +202,9 @@ class _HipBackend:
                                _stream()), "hs_hash_fwd")
 
     @classmethod
-    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None):
+    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, ws=ws)
+        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major)
         _check(lib.hs_hash_bwd(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
                                _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
                                _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay), _stream()), "hs_hash_bwd")
@@ -219,9 +219,9 @@ class _HipBackend:
                                 _stream()), "hs_hash_bwd2")
 
     @classmethod
-    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None):
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, ws=ws)
+        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major)
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")
@@ -357,7 +357,7 @@ class _HipBackend:
         _check(lib.hs_appearance_fwd(_dev(featc, "featc"), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
                                      *[_dev(W[k], k, bf) for k in ("Wc0", "Wc1", "Wr0f", "Wr0p", "Wr1", "Wr2")],
                                      *[_dev(b, "bias") for b in biases], _dev(xin, "xin", bf), _dev(hc, "hc", bf), _dev(fv, "fv", bf),
-                                     _dev(r0, "r0", bf), _dev(r1, "r1", bf), _dev(rgb, "rgb"), ctypes.c_int64(featc.shape[0]), _stream()),
+                                     _dev(r0, "r0", bf), _dev(r1, "r1", bf), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]), _stream()),
                "hs_appearance_fwd")
 
     @staticmethod

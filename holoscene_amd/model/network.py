@@ -199,13 +199,13 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     gb0 = torch.zeros(256, device=dev)
     g_feat = g_dydx = None
     if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
-        g_feat = torch.empty(B, L * C, device=dev, dtype=torch.float32)
+        g_feat = torch.empty(L, B, C, device=dev, dtype=torch.float32)     # level-major: coalesced for both writer and scatter
         g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
     _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale)
 
     def table_branch():
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
-                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None)
+                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
 
     g_emb = target = None
     if need_table:
@@ -312,8 +312,8 @@ class _fused_appearance(torch.autograd.Function):
         B = points.shape[0]
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
         dev, bf = points.device, torch.bfloat16
-        featc = torch.empty(B, L * C, device=dev)
-        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None)
+        featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for k_appear_fwd
+        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
         new = lambda r, c: torch.empty(r, c, device=dev, dtype=bf)  # noqa: E731
         W = {"Wc0": new(256, 32), "Wc1": new(256, 256), "Wr0f": new(256, 256), "Wr0p": new(256, 96), "Wr1": new(256, 256), "Wr2": new(32, 256),
              "Wr2t": new(256, 32), "Wr1t": new(256, 256), "Wr0ft": new(256, 256), "Wr0nt": new(32, 256), "Wc1t": new(256, 256), "Wc0t": new(32, 256)}
@@ -339,7 +339,7 @@ class _fused_appearance(torch.autograd.Function):
         new = lambda c: torch.empty(B, c, device=dev, dtype=bf)  # noqa: E731
         gy, gA_r1, gA_r0, g_fv, gA_hc = new(32), new(256), new(256), new(256), new(256)
         d_normals = torch.empty(B, 3, device=dev)
-        g_featc = torch.empty(B, L * C, device=dev)
+        g_featc = torch.empty(L, B, C, device=dev)
         gb = torch.zeros(4, 256, device=dev)
         W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
         be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb)
@@ -360,10 +360,10 @@ class _fused_appearance(torch.autograd.Function):
             target = table.grad if inplace else torch.zeros_like(embeddings)
             if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):   # the scatter is atomic-issue-bound: let the trunk's matrix-core backward run beside it
                 with torch.cuda.stream(_be.fork_side_stream(g_featc, x01, offsets, target)):
-                    be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None)
+                    be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None, level_major=True)
             else:
                 be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None)
+                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
             g_emb = None if inplace else target
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 
@@ -959,7 +959,8 @@ class HoloSceneNetwork(nn.Module):
         if not (x.is_cuda and net.mlp_bf16 and rn.mlp_bf16 and net.color_grid_feature and rn.mode == "idr" and rn.num_layers == 4):
             return False
         mlp = net.color_grid_feature_map_mlp
-        return (rn.multires_view == 4 and rn.multires_point == 4 and rn.multires_normal == 4 and net.color_grid_feature_dim == 32
+        enc = net.color_encoding
+        return (rn.multires_view == 4 and rn.multires_point == 4 and rn.multires_normal == 4 and enc.num_levels == 16 and enc.level_dim == 2
                 and tuple(mlp[0].weight.shape) == (256, 32) and tuple(mlp[2].weight.shape) == (256, 256)
                 and tuple(rn.lin0.weight_v.shape) == (256, 337) and tuple(rn.lin1.weight_v.shape) == (256, 256)
                 and tuple(rn.lin2.weight_v.shape) == (3, 256))

@@ -277,7 +277,7 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
  *   the input-gradient GEMM);  gb1, gb0 [256] fp32 (+=): bias gradients (may be NULL).
  *   W0t [256, 256] bf16 = W0^T (rows = the 96 padded input columns, zero beyond): if given, the cotangent gA0 . W0 of
  *   hs_trunk_input_fwd's output is formed in the same pass and its hash-feature part is written in the form the table
- *   scatter reads (what hs_trunk_input_bwd would produce): g_feat [M/4, L*C] fp32 from the value rows, g_dydx [L, M/4, 3*C]
+ *   scatter reads: g_feat [L, M/4, C] fp32 (LEVEL-major) from the value rows, g_dydx [L, M/4, 3*C]
  *   fp32 = jac_scale * the tangent rows.  Needs L*C == 32. */
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t /* NULL = skip */, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale,
@@ -297,7 +297,8 @@ int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t
  * Replaces, per rendered point: color_grid_feature_map_mlp (model/network.py:99-101, 186-188), the posenc + concat of
  * RenderingNetwork.forward (:586-596) and its three weight-normalised Linear layers + ReLU + sigmoid (:598-612), and
  * their autograd backward.  bf16 operands, fp32 accumulation.  B points.
- *   featc [B,32] fp32 colour hash features; points, dirs, normals [B,3] fp32
+ *   featc [16,B,2] fp32 colour hash features, LEVEL-major (hs_hash_fwd with level_stride = 2B, point_stride = 2: its coalesced
+ *   store order); points, dirs, normals [B,3] fp32
  *   Wc0 [256,32], Wc1 [256,256]: colour MLP;  W_R0 [256,337] split into Wr0p [256,96] (columns 0..80 = encoded point |
  *   view dir | normal, zero-padded) and Wr0f [256,256] (columns 81..336 = feature vector);  Wr1 [256,256];  Wr2 [32,256]
  *   (rows 0..2 used).  All bf16 row-major (hs_pack_bf16 builds them); biases fp32 (br2: 3 values).
@@ -310,7 +311,7 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
 /* Backward data path.  Transposed bf16 weights: Wr2t [256,32], Wr1t [256,256], Wr0ft [256,256] (= Wr0f^T), Wr0nt [32,256]
  * (rows j < 27 = column 54+j of W_R0: the encoded-normal inputs), Wc1t [256,256], Wc0t [32,256].
  * Outputs: gy [B,32] bf16 (cotangent of the pre-sigmoid outputs, columns 0..2), gA_r1, gA_r0, g_fv, gA_hc [B,256] bf16
- * (pre-activation cotangents; g_fv = cotangent of the feature vector), d_normals [B,3], g_featc [B,32] fp32,
+ * (pre-activation cotangents; g_fv = cotangent of the feature vector), d_normals [B,3], g_featc [16,B,2] fp32 (level-major),
  * gbias [4,256] fp32 (+=; rows: br1, br0, bc1, bc0; may be NULL). */
 int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
                       const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
