@@ -176,6 +176,10 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
             // lane holds, for point prow, neurons t*32 + (i&3) + 8*(i>>2) + 4*(lane>>5)
             const int64_t gp = p0 + prow;
             float best = INFINITY;
+            // raw outputs: parked in this point's own (now dead) activation row -- each wave reads only its 32 rows of H, and its
+            // LDS operations retire in order -- and stored coalesced by the whole workgroup below (lane-wise 4-byte stores at a
+            // d_out*4-byte stride made the raw sweep 4.5x slower than the min sweep)
+            float *park = reinterpret_cast<float *>(H + (size_t)prow * HP);
 #pragma unroll
             for (int t = 0; t < NOUT_TILES; t++)
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
                     const int n = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                     if (n < d_out) {
                         const float v = y[t][i] + bias[2 * HID + n];
-                        if (out_raw && gp < B) out_raw[gp * d_out + n] = v;
+                        if (out_raw) park[n] = v;
                         if (select < 0) best = fminf(best, v);
                         else if (n == select) best = v;
                     }
@@ -191,6 +195,13 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
             const float other = __shfl_xor(best, 32);
             best = fminf(best, other);  // for `select`, exactly one half holds the value, the other +inf
             if (lane < 32 && gp < B) out_min[gp] = best;
+        }
+        if (out_raw) {
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < BM * d_out; idx += kThreads) {
+                const int row = idx / d_out, n = idx - row * d_out;
+                if (p0 + row < B) out_raw[(p0 + row) * d_out + n] = reinterpret_cast<const float *>(H + (size_t)row * HP)[n];
+            }
         }
         __syncthreads();  // H and the chunk area are rewritten by the next tile
     }

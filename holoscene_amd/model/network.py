@@ -712,14 +712,21 @@ class ObjectImplicitNetworkGrid(nn.Module):
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
         """min_k sdf_k (or sdf_select) [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
-        x = x.contiguous()
-        feat = self.encoding(x / self.divide_factor)
+        x = x.contiguous().float()
         B = x.shape[0]
+        enc = self.encoding
+        L, C = enc.num_levels, enc.level_dim
+        lm = L == 16 and C == 2        # level-major features: coalesced stores in the gather kernel (see sdf_along_rays)
+        x01 = ((x / self.divide_factor + 1.0) / 2.0).contiguous()
+        feat = torch.empty((L, B, C) if lm else (B, L * C), device=x.device)
+        be = _be._backend
+        be.fwd(x01, enc.embeddings, enc.offsets, feat, B, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+               level_major=lm)
         d_out = self._lins()[2].out_features
         out = torch.empty(B, 1, device=x.device)
         raw = torch.empty(B, d_out, device=x.device) if want_raw else None
         w0, b0, w1, b1, w2, b2 = self._packed_weights()
-        _be._backend.sdf_mlp_fwd(x, feat.contiguous(), w0, b0, w1, b1, w2, b2, d_out, select, out, raw)
+        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, raw, feat_level_major=lm)
         return out, raw
 
     def sdf_along_rays(self, cam_loc, ray_dirs, z, select=-1, gate=None):
