@@ -228,9 +228,9 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
 // Lanes whose base cell equals their predecessor's form a run; a segmented inclusive scan (wave shuffles)
 // sums the 2^D*C corner contributions over each run and only the run's last lane issues atomics.
 // All 64 lanes must call this (inactive lanes pass valid=false).
+// Returns whether this lane ends a run (and now holds the run's sums in `cache`).
 template <int D, int C>
-__device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const LevelInfo &li, const uint32_t g[D], float cache[(1 << D) * C],
-                                             bool valid) {
+__device__ __forceinline__ bool wave_merge(const uint32_t g[D], float cache[(1 << D) * C], bool valid) {
     const int lane = threadIdx.x & 63;
     bool same_prev = valid && lane > 0;
 #pragma unroll
@@ -254,7 +254,13 @@ __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const Level
         }
         tail = valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
     }
-    if (!tail) return;
+    return tail;
+}
+
+template <int D, int C>
+__device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const LevelInfo &li, const uint32_t g[D], float cache[(1 << D) * C],
+                                             bool valid) {
+    if (!wave_merge<D, C>(g, cache, valid)) return;
 #pragma unroll
     for (int corner = 0; corner < (1 << D); corner++) {
         uint32_t gl[D];
@@ -297,8 +303,11 @@ __device__ __forceinline__ bool binned_level(const LevelInfo &li, int C, const v
 // all threads of the workgroup call this (level is workgroup-uniform)
 template <int D, int C>
 __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restrict__ gg, const LevelInfo &li, uint32_t level, const uint32_t g[D],
-                                         const float cache[(1 << D) * C], bool valid) {
+                                         float cache[(1 << D) * C], bool valid) {
     __shared__ uint32_t hist[kBins], base[kBins];
+    // samples of a ray crowd around the surface: even on the finest level consecutive lanes often share a cell, so runs are
+    // merged in the wave first and only their last lane emits records (632 k -> far fewer per level in the benchmark state)
+    valid = wave_merge<D, C>(g, cache, valid);
     uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
     BinRecord<C> *records = reinterpret_cast<BinRecord<C> *>(reinterpret_cast<char *>(lay.scatter_ws) + HS_MAX_LEVELS * kBins * sizeof(uint32_t));
     const uint32_t per_bin = li.table / kBins;
