@@ -170,31 +170,37 @@ __global__ __launch_bounds__(kThreads) void k_ray_points(const float *__restrict
 // materialisation + min + gather (forward) and the zero-fill / scatter / slice-pad kernels autograd runs for them (backward).
 __global__ __launch_bounds__(256) void k_trunk_split_fwd(const float *__restrict__ Y, int64_t B, int64_t n_main, int K, float *__restrict__ sdf_raw,
                                                           float *__restrict__ sdf, int64_t *__restrict__ idx, float *__restrict__ grad,
-                                                          float *__restrict__ y_eik, float *__restrict__ J_eik) {
+                                                          float *__restrict__ y_eik, float *__restrict__ min_eik, float *__restrict__ gtheta) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t Be = B - n_main;
     for (int64_t b = wave0; b < B; b += nwaves) {
         const float *y = Y + b * 4 * K;
         const float v = lane < K ? y[lane] : INFINITY;
-        if (b < n_main) {
-            float best = v;
-            int bi = lane;
+        float best = v;
+        int bi = lane;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {   // minimum, lowest index among equals
-                const float ov = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bi, off);
-                if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-            }
+        for (int off = 32; off > 0; off >>= 1) {   // minimum, lowest index among equals
+            const float ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) idx[b] = bi;
+        if (b < n_main) {
             if (lane < K) sdf_raw[b * K + lane] = v;
-            if (lane == 0) { sdf[b] = best; idx[b] = bi; }
+            if (lane == 0) sdf[b] = best;
             if (lane < 3) grad[b * 3 + lane] = y[(1 + lane) * K + bi];
         } else {
+            // Eikonal point e: per-object SDFs, their minimum, and the stacked gradient rows the reference builds with K+1
+            // autograd passes (network.py:212-254): row k*Be + e = d sdf_k/dx, row K*Be + e = d min_k sdf_k/dx
             const int64_t e = b - n_main;
+            if (lane == 0) min_eik[e] = best;
             if (lane < K) {
                 y_eik[e * K + lane] = v;
 #pragma unroll
-                for (int d = 0; d < 3; d++) J_eik[(e * K + lane) * 3 + d] = y[(1 + d) * K + lane];
+                for (int d = 0; d < 3; d++) gtheta[((int64_t)lane * Be + e) * 3 + d] = y[(1 + d) * K + lane];
             }
+            if (lane < 3) gtheta[((int64_t)K * Be + e) * 3 + lane] = y[(1 + lane) * K + bi];
         }
     }
 }
@@ -202,23 +208,23 @@ __global__ __launch_bounds__(256) void k_trunk_split_fwd(const float *__restrict
 // cotangent of Y as the bf16 [4*B, KP] image k_trunk_bwd reads (columns >= K zero); any input may be NULL (= zero)
 __global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx,
                                                           const float *__restrict__ g_grad, const float *__restrict__ g_yeik,
-                                                          const float *__restrict__ g_Jeik, int64_t B, int64_t n_main, int K, int KP,
-                                                          __hip_bfloat16 *__restrict__ g) {
-    const int64_t total = B * 4 * KP;
+                                                          const float *__restrict__ g_mineik, const float *__restrict__ g_theta, int64_t B,
+                                                          int64_t n_main, int K, int KP, __hip_bfloat16 *__restrict__ g) {
+    const int64_t total = B * 4 * KP, Be = B - n_main;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i % KP);
         const int64_t row = i / KP, b = row >> 2;
         const int r = (int)(row & 3);
         float v = 0.f;
         if (k < K) {
+            const bool hit = k == (int)idx[b];
             if (b < n_main) {
-                const bool hit = k == (int)idx[b];
                 if (r == 0) v = (g_raw ? g_raw[b * K + k] : 0.f) + (hit && g_sdf ? g_sdf[b] : 0.f);
                 else if (hit && g_grad) v = g_grad[b * 3 + (r - 1)];
             } else {
                 const int64_t e = b - n_main;
-                if (r == 0) v = g_yeik ? g_yeik[e * K + k] : 0.f;
-                else v = g_Jeik ? g_Jeik[(e * K + k) * 3 + (r - 1)] : 0.f;
+                if (r == 0) v = (g_yeik ? g_yeik[e * K + k] : 0.f) + (hit && g_mineik ? g_mineik[e] : 0.f);
+                else if (g_theta) v = g_theta[((int64_t)k * Be + e) * 3 + (r - 1)] + (hit ? g_theta[((int64_t)K * Be + e) * 3 + (r - 1)] : 0.f);
             }
         }
         g[i] = __float2bfloat16(v);
@@ -326,21 +332,21 @@ int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, f
 }
 
 int hs_trunk_split_fwd(const float *Y, int64_t B, int64_t n_main, int32_t K, float *sdf_raw, float *sdf, int64_t *idx, float *grad, float *y_eik,
-                       float *J_eik, void *stream) {
+                       float *min_eik, float *grad_theta, void *stream) {
     if (K < 1 || K > 64 || n_main < 0 || n_main > B) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
-    if (!Y || (n_main > 0 && (!sdf_raw || !sdf || !idx || !grad)) || (n_main < B && (!y_eik || !J_eik))) return HS_ERR_NULL;
+    if (!Y || !idx || (n_main > 0 && (!sdf_raw || !sdf || !grad)) || (n_main < B && (!y_eik || !min_eik || !grad_theta))) return HS_ERR_NULL;
     const int64_t want = (B + 3) / 4;
-    k_trunk_split_fwd<<<(int)(want < 8192 ? want : 8192), 256, 0, (hipStream_t)stream>>>(Y, B, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik);
+    k_trunk_split_fwd<<<(int)(want < 8192 ? want : 8192), 256, 0, (hipStream_t)stream>>>(Y, B, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta);
     return check_launch();
 }
 
-int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t *idx, const float *g_grad, const float *g_y_eik, const float *g_J_eik,
-                       int64_t B, int64_t n_main, int32_t K, int32_t KP, void *g, void *stream) {
+int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t *idx, const float *g_grad, const float *g_y_eik,
+                       const float *g_min_eik, const float *g_grad_theta, int64_t B, int64_t n_main, int32_t K, int32_t KP, void *g, void *stream) {
     if (K < 1 || K > KP || n_main < 0 || n_main > B) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
-    if (!g || (n_main > 0 && !idx)) return HS_ERR_NULL;
-    k_trunk_split_bwd<<<grid_for(B * 4 * KP), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_J_eik, B, n_main, K, KP,
+    if (!g || !idx) return HS_ERR_NULL;
+    k_trunk_split_bwd<<<grid_for(B * 4 * KP), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_min_eik, g_grad_theta, B, n_main, K, KP,
                                                                              (__hip_bfloat16 *)g);
     return check_launch();
 }

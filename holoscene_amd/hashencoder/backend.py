@@ -404,18 +404,18 @@ class _HipBackend:
                                     ctypes.c_int64(g.shape[0]), _stream()), "hs_trunk_mlp_bwd")
 
     @staticmethod
-    def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik):
+    def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta):
         lib = load_library()
         _check(lib.hs_trunk_split_fwd(_dev(Y, "Y"), ctypes.c_int64(Y.shape[0] // 4), ctypes.c_int64(n_main), K, _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"),
-                                      _dev(idx, "idx", torch.int64), _dev(grad, "grad"), _dev(y_eik, "y_eik"), _dev(J_eik, "J_eik"), _stream()),
-               "hs_trunk_split_fwd")
+                                      _dev(idx, "idx", torch.int64), _dev(grad, "grad"), _dev(y_eik, "y_eik"), _dev(min_eik, "min_eik"),
+                                      _dev(grad_theta, "grad_theta"), _stream()), "hs_trunk_split_fwd")
 
     @staticmethod
-    def trunk_split_bwd(g_raw, g_sdf, idx, g_grad, g_yeik, g_Jeik, B, n_main, K, g):
+    def trunk_split_bwd(g_raw, g_sdf, idx, g_grad, g_yeik, g_mineik, g_theta, B, n_main, K, g):
         lib = load_library()
         _check(lib.hs_trunk_split_bwd(_dev(g_raw, "g_sdf_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), _dev(g_grad, "g_grad"),
-                                      _dev(g_yeik, "g_y_eik"), _dev(g_Jeik, "g_J_eik"), ctypes.c_int64(B), ctypes.c_int64(n_main), K, g.shape[-1],
-                                      _dev(g, "g", torch.bfloat16), _stream()), "hs_trunk_split_bwd")
+                                      _dev(g_yeik, "g_y_eik"), _dev(g_mineik, "g_min_eik"), _dev(g_theta, "g_grad_theta"), ctypes.c_int64(B),
+                                      ctypes.c_int64(n_main), K, g.shape[-1], _dev(g, "g", torch.bfloat16), _stream()), "hs_trunk_split_bwd")
 
     @staticmethod
     def softplus_tangent_bwd_h(H, G, gA, gbias):

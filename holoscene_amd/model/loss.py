@@ -33,11 +33,20 @@ class _fused_core_loss(torch.autograd.Function):
         dev = rgb.device
         R = rgb.shape[0]
         c = lambda t: t.detach().contiguous().float()  # noqa: E731
-        rgb_, depth_, nmap_, opac_, g1_, g2_ = c(rgb), c(depth).reshape(-1), c(nmap), c(opac), c(g1), c(g2)
+        rgb_, depth_, nmap_, opac_ = c(rgb), c(depth).reshape(-1), c(nmap), c(opac)
+        ctx.stacked = g2 is None
+        if ctx.stacked:     # g1 = ALL stacked gradient rows (render's "grad_theta_all"): the halves are views, and so are their cotangents
+            g_all = c(g1)
+            half = g_all.shape[0] // 2
+            g1_, g2_ = g_all[:half], g_all[half:]
+            d_all = torch.empty_like(g_all)
+            d_g1, d_g2 = d_all[:half], d_all[half:]
+        else:
+            g1_, g2_ = c(g1), c(g2)
+            d_g1, d_g2 = torch.empty_like(g1_), torch.empty_like(g2_)
         out5 = torch.empty(5, device=dev)
         acc2 = torch.zeros(2, device=dev)
         g_rgb, g_depth, g_nmap, g_opac = torch.empty_like(rgb_), torch.empty_like(depth_), torch.empty_like(nmap_), torch.empty_like(opac_)
-        d_g1, d_g2 = torch.empty_like(g1_), torch.empty_like(g2_)
         be = _be._backend
         be.loss_rays(rgb_, c(rgb_gt).reshape(-1, 3), depth_, c(depth_gt).reshape(-1), nmap_, c(n_gt).reshape(-1, 3), c(gt_mask).reshape(-1),
                      c(sdf), opac_, segs.reshape(-1).long().contiguous(), (w_rgb, w_depth, w_l1, w_cos, w_opac), out5, g_rgb, g_depth, g_nmap, g_opac)
@@ -47,13 +56,19 @@ class _fused_core_loss(torch.autograd.Function):
         wvec = _WEIGHT_CACHE.get(key)
         if wvec is None:   # built once (during the eager warm-up), so that graph capture never sees a host->device copy
             wvec = _WEIGHT_CACHE[key] = torch.tensor(key[1], device=dev)
-        ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_g1, d_g2)
+        if ctx.stacked:
+            ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_all)
+        else:
+            ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_g1, d_g2)
         ctx.mark_non_differentiable(terms)
         return (terms * wvec).sum(), terms
 
     @staticmethod
     def backward(ctx, g, _g_terms):
-        return tuple(t * g for t in ctx.saved_tensors) + (None,) * 7
+        grads = tuple(t * g for t in ctx.saved_tensors)
+        if ctx.stacked:
+            grads = grads + (None,)
+        return grads + (None,) * 7
 
 
 def compute_scale_and_shift_batch(prediction, target):
@@ -198,8 +213,10 @@ class HoloSceneLoss(MonoSDFLoss):
         self.step += 1
         weights = (1.0, decay * self.depth_weight, decay * self.normal_l1_weight, decay * self.normal_cos_weight,
                    self.semantic_weight, self.eikonal_weight, self.smooth_weight)
+        stacked = model_outputs.get("grad_theta_all")
         total, t = _fused_core_loss.apply(model_outputs["rgb_values"], model_outputs["depth_values"], model_outputs["normal_map"],
-                                          model_outputs["object_opacity"], model_outputs["grad_theta"], model_outputs["grad_theta_nei"],
+                                          model_outputs["object_opacity"], model_outputs["grad_theta"] if stacked is None else stacked,
+                                          model_outputs["grad_theta_nei"] if stacked is None else None,
                                           model_outputs["sdf"], ground_truth["rgb"], ground_truth["depth"], ground_truth["normal"],
                                           ground_truth["mask"], ground_truth["segs"], weights)
         return {"loss": total, "rgb_loss": t[0], "depth_loss": t[1], "normal_l1": t[2], "normal_cos": t[3], "eikonal_loss": t[5],

@@ -253,10 +253,12 @@ class _fused_trunk(torch.autograd.Function):
 
 class _fused_trunk_render(torch.autograd.Function):
     """The trunk pass of one training iteration: rows [0, n_main) are rendered samples, the rest the Eikonal set.
-    Returns sdf_raw [n_main,K], sdf [n_main,1] (min over objects), idx [n_main,1] (argmin, not differentiable),
-    gradients [n_main,3] (d min-sdf / dx), y_eik [Be,K], J_eik [Be,K,3].
-    Versus _fused_trunk + torch ops: the [B,K,3] Jacobian of the rendered points is never materialised, and the cotangent image
-    of the trunk output is assembled by one kernel instead of autograd's zero-fill / scatter / pad chain (csrc/encode_ops.hip)."""
+    Returns sdf_raw [n_main,K], sdf [n_main,1] (min over objects), idx [B,1] (argmin, not differentiable),
+    gradients [n_main,3] (d min-sdf / dx), and for the Eikonal points y_eik [Be,K], min_eik [Be,1] and grad_theta
+    [(K+1)*Be, 3] -- the stacked rows of ObjectImplicitNetworkGrid.gradient (network.py:212-254).
+    Versus _fused_trunk + torch ops: no [B,K,3] Jacobian for the rendered points, no min/gather/transpose/cat chain for the
+    Eikonal set, and the cotangent image of the trunk output is assembled by one kernel instead of autograd's zero-fill /
+    scatter / pad chain (csrc/encode_ops.hip)."""
 
     @staticmethod
     def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
@@ -265,23 +267,23 @@ class _fused_trunk_render(torch.autograd.Function):
         dev = x.device
         Be = B - n_main
         sdf_raw, sdf = torch.empty(n_main, K, device=dev), torch.empty(n_main, 1, device=dev)
-        idx = torch.empty(n_main, 1, device=dev, dtype=torch.int64)
+        idx = torch.empty(B, 1, device=dev, dtype=torch.int64)
         grad = torch.empty(n_main, 3, device=dev)
-        y_eik, J_eik = torch.empty(Be, K, device=dev), torch.empty(Be, K, 3, device=dev)
-        _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, J_eik)
+        y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
+        _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta)
         ctx.save_for_backward(*saved, idx)
         ctx.n_main = n_main
         ctx.mark_non_differentiable(idx)
-        return sdf_raw, sdf, idx, grad, y_eik, J_eik
+        return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
 
     @staticmethod
-    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_Jeik):
+    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_mineik, g_theta):
         *saved, idx = ctx.saved_tensors
         B, d_out = ctx.cfg[0], ctx.cfg[-1]
         KP = saved[-1].shape[1]
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         g = torch.empty(4 * B, KP, device=idx.device, dtype=torch.bfloat16)
-        _be._backend.trunk_split_bwd(c(g_raw), c(g_sdf), idx, c(g_grad), c(g_yeik), c(g_Jeik), B, ctx.n_main, d_out, g)
+        _be._backend.trunk_split_bwd(c(g_raw), c(g_sdf), idx, c(g_grad), c(g_yeik), c(g_mineik), c(g_theta), B, ctx.n_main, d_out, g)
         gb2 = None
         if ctx.needs_input_grad[13]:
             Sg = _split_rows(B)
@@ -1116,7 +1118,7 @@ class HoloSceneNetwork(nn.Module):
         if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
-            sdf_raw, sdf, idx_min, gradients, y_eik, J_eik = _fused_trunk_render.apply(
+            sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = _fused_trunk_render.apply(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias, x01_all)
         else:
@@ -1126,6 +1128,7 @@ class HoloSceneNetwork(nn.Module):
             sdf, idx_min = sdf_raw.min(dim=-1, keepdim=True)
             gradients = torch.gather(J_main, 1, idx_min.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
             y_eik, J_eik = y_all[n_main:], J_all[n_main:]
+            min_eik = gtheta = None
         if not net.color_grid_feature:
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
@@ -1172,10 +1175,14 @@ class HoloSceneNetwork(nn.Module):
 
         if self.training:
             # replaces gradient() + get_sdf_raw() + get_sdf_vals() on the Eikonal set (network.py:856-863)
-            y, J = y_eik, J_eik
-            min_sdf, idx = y.min(dim=-1, keepdim=True)
-            g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
-            grad_theta = torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
+            if gtheta is not None:      # already stacked by the split kernel
+                y, min_sdf, grad_theta = y_eik, min_eik, gtheta
+                output["grad_theta_all"] = grad_theta    # (the fused objective takes the two halves from this one tensor)
+            else:
+                y, J = y_eik, J_eik
+                min_sdf, idx = y.min(dim=-1, keepdim=True)
+                g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+                grad_theta = torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
             output["sample_sdf"] = y
             output["sample_minsdf"] = min_sdf
             half = grad_theta.shape[0] // 2  # quirk Q2: halves of the stacked rows, not original/jittered

@@ -283,15 +283,17 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
                      float *gb1, float *gb0, const void *W0t /* NULL = skip */, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale,
                      int64_t M, void *stream);
 
-/* Consumers of hs_trunk_mlp_fwd's Y [4*B, K] and producers of its cotangent (K <= 64).  Points b < n_main are rendered
- * samples: sdf_raw [n_main,K] = value rows, sdf [n_main] = min_k, idx [n_main] = argmin (lowest index among equals),
- * grad [n_main,3] = the Jacobian row of the minimum (model/network.py:289-299).  Points b >= n_main are the Eikonal set:
- * y_eik [B-n_main,K], J_eik [B-n_main,K,3] (network.py:856-866).  hs_trunk_split_bwd assembles the bf16 [4*B, KP] cotangent
- * image hs_trunk_mlp_bwd reads from the cotangents of those outputs (any may be NULL = zero). */
+/* Consumers of hs_trunk_mlp_fwd's Y [4*B, K] and producers of its cotangent (K <= 64).  idx [B] = argmin_k of the value row
+ * (lowest index among equals).  Points b < n_main are rendered samples: sdf_raw [n_main,K] = value rows, sdf [n_main] = min_k,
+ * grad [n_main,3] = the Jacobian row of the minimum (model/network.py:289-299).  Points b >= n_main are the Eikonal set
+ * (Be = B - n_main points): y_eik [Be,K], min_eik [Be], grad_theta [(K+1)*Be, 3] = the stacked gradient rows of
+ * ObjectImplicitNetworkGrid.gradient (network.py:212-254: row k*Be+e = d sdf_k/dx, row K*Be+e = d min sdf/dx).
+ * hs_trunk_split_bwd assembles the bf16 [4*B, KP] cotangent image hs_trunk_mlp_bwd reads from the cotangents of those outputs
+ * (any may be NULL = zero). */
 int hs_trunk_split_fwd(const float *Y, int64_t B, int64_t n_main, int32_t K, float *sdf_raw, float *sdf, int64_t *idx, float *grad, float *y_eik,
-                       float *J_eik, void *stream);
-int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t *idx, const float *g_grad, const float *g_y_eik, const float *g_J_eik,
-                       int64_t B, int64_t n_main, int32_t K, int32_t KP, void *g, void *stream);
+                       float *min_eik, float *grad_theta, void *stream);
+int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t *idx, const float *g_grad, const float *g_y_eik,
+                       const float *g_min_eik, const float *g_grad_theta, int64_t B, int64_t n_main, int32_t K, int32_t KP, void *g, void *stream);
 
 /* ------------------------------------------------------------------ 7b. fused colour branch of a rendered sample
  * Replaces, per rendered point: color_grid_feature_map_mlp (model/network.py:99-101, 186-188), the posenc + concat of

@@ -693,7 +693,7 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
     x = torch.rand(B, 3, device=DEV) * 2.4 - 1.2
     Be = B - n_main
     cot = [torch.randn(n_main, d_out, device=DEV), torch.randn(n_main, 1, device=DEV), torch.randn(n_main, 3, device=DEV),
-           torch.randn(Be, d_out, device=DEV), torch.randn(Be, d_out, 3, device=DEV)]
+           torch.randn(Be, d_out, device=DEV), torch.randn(Be, 1, device=DEV), torch.randn((d_out + 1) * Be, 3, device=DEV)]
     params = [net.encoding.embeddings] + [p for l in net._lins() for p in (l.weight_v, l.weight_g, l.bias)]
     enc = net.encoding
     l0, l1, l2 = net._lins()
@@ -707,18 +707,22 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
         sdf_raw, Jm = y[:n_main], J[:n_main]
         sdf, idx = sdf_raw.min(dim=-1, keepdim=True)
         grad = torch.gather(Jm, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
-        return [sdf_raw, sdf, grad, y[n_main:], J[n_main:]], idx
+        ye, Je = y[n_main:], J[n_main:]          # the Eikonal block of HoloSceneNetwork.render / ObjectImplicitNetworkGrid.gradient
+        min_e, idx_e = ye.min(dim=-1, keepdim=True)
+        g_min = torch.gather(Je, 1, idx_e.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        gtheta = torch.cat([Je.transpose(0, 1).reshape(-1, 3), g_min], 0)
+        return [sdf_raw, sdf, grad, ye, min_e, gtheta], torch.cat([idx, idx_e], 0)
 
     def new():
-        sdf_raw, sdf, idx, grad, y_e, J_e = N._fused_trunk_render.apply(x, n_main, *args())
-        return [sdf_raw, sdf, grad, y_e, J_e], idx
+        sdf_raw, sdf, idx, grad, y_e, min_e, gtheta = N._fused_trunk_render.apply(x, n_main, *args())
+        return [sdf_raw, sdf, grad, y_e, min_e, gtheta], idx
 
     res = {}
     for name, fn in (("ref", ref), ("new", new)):
         outs, idx = fn()
         loss = sum((o * c).sum() for o, c in zip(outs, cot))
         res[name] = ([o.detach() for o in outs], idx, [g.float() for g in torch.autograd.grad(loss, params)])
-    for a, b, n in zip(res["new"][0], res["ref"][0], ("sdf_raw", "sdf", "grad", "y_eik", "J_eik")):
+    for a, b, n in zip(res["new"][0], res["ref"][0], ("sdf_raw", "sdf", "grad", "y_eik", "min_eik", "grad_theta")):
         assert torch.equal(a, b), n
     assert torch.equal(res["new"][1], res["ref"][1])
     for a, b, n in zip(res["new"][2], res["ref"][2], ["table"] + [f"lin{i}.{k}" for i in range(3) for k in ("v", "g", "bias")]):
