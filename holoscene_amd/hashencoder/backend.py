@@ -37,6 +37,10 @@ class hsPackJob(ctypes.Structure):
                 ("transpose", ctypes.c_int32)]
 
 
+class hsSumJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32)]
+
+
 ABI_VERSION = 2
 
 
@@ -73,7 +77,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices"]
 
 
 def _check(rc, what):
@@ -348,6 +352,19 @@ class _HipBackend:
             a.ld, a.row0, a.col0, a.rows, a.cols = src.shape[1], row0, col0, rows, cols
             a.dst_rows, a.dst_cols, a.transpose = dst.shape[0], dst.shape[1], int(tr)
         _check(lib.hs_pack_bf16(arr, len(jobs), _stream()), "hs_pack_bf16")
+
+    @staticmethod
+    def sum_slices(partials):
+        """partials: list of bf16 tensors [S, ...]; returns the fp32 sums over dim 0, all in one launch."""
+        lib = load_library()
+        arr = (hsSumJob * len(partials))()
+        outs = []
+        for a, t in zip(arr, partials):
+            out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
+            a.src, a.dst, a.n, a.slices = _dev(t, "partials", torch.bfloat16).value, _dev(out, "out").value, out.numel(), t.shape[0]
+            outs.append(out)
+        _check(lib.hs_sum_slices(arr, len(partials), _stream()), "hs_sum_slices")
+        return outs
 
     @staticmethod
     def appearance_fwd(featc, points, dirs, normals, W, biases, xin, hc, fv, r0, r1, rgb):

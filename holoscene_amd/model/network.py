@@ -144,6 +144,22 @@ def _wgrad_rows(g, x):
     return (g.t() @ x).float()
 
 
+def _wgrad_rows_many(pairs):
+    """[_wgrad_rows(g, x) for g, x in pairs] with the slice sums of all of them in ONE launch (hs_sum_slices)."""
+    parts, direct = [], {}
+    for i, (g, x) in enumerate(pairs):
+        M = x.shape[0]
+        S = _split_rows(M)
+        if S > 1 and g.dtype == torch.bfloat16 and g.is_cuda and (g.shape[1] * x.shape[1]) % 4 == 0:
+            parts.append((i, torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1))))
+        else:
+            direct[i] = _wgrad_rows(g, x)
+    sums = _be._backend.sum_slices([p for _, p in parts]) if parts else []
+    for (i, _), s_ in zip(parts, sums):
+        direct[i] = s_
+    return [direct[i] for i in range(len(pairs))]
+
+
 def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
     """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save.
     x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points)."""
@@ -219,9 +235,10 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
                 table_branch()
         else:
             table_branch()
-    gW2 = _wgrad_rows(g, H1)[:d_out] if need_w else None
-    gW1 = _wgrad_rows(gA1, H0) if need_w else None
-    gW0 = _wgrad_rows(gA0, X.view(M, _TRUNK_PITCH))[:, :F_in] if need_w else None
+    gW2 = gW1 = gW0 = None
+    if need_w:
+        gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))])
+        gW2, gW0 = gW2[:d_out], gW0[:, :F_in]
     return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
 
 
@@ -348,13 +365,12 @@ class _fused_appearance(torch.autograd.Function):
         need_w = ctx.needs_input_grad[8]
         gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbr2 = None
         if need_w:
-            gWr2 = _wgrad_rows(gy, r1)[:3]
+            w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many([(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)])
+            gWr2 = w_r2[:3]
             Sg = _split_rows(B)
             gbr2 = gy.view(Sg, B // Sg, 32).sum(1, dtype=torch.float32).sum(0)[:3]
-            gWr1 = _wgrad_rows(gA_r1, r0)
-            gWr0 = torch.cat([_wgrad_rows(gA_r0, xin)[:, 32:113], _wgrad_rows(gA_r0, fv)], 1)
-            gWc1 = _wgrad_rows(g_fv, hc)
-            gWc0 = _wgrad_rows(gA_hc, xin)[:, :32]
+            gWr0 = torch.cat([w_r0x[:, 32:113], w_r0f], 1)
+            gWc0 = w_c0[:, :32]
         g_emb = None
         if ctx.needs_input_grad[3]:
             table = ctx.table

@@ -333,6 +333,16 @@ typedef struct hsPackJob {
 } hsPackJob;
 int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream);
 
+/* dst[i] = sum_s src[s*n + i] (src bf16 [slices, n], dst fp32 [n], n % 4 == 0) for up to HS_PACK_MAX_JOBS matrices in one launch:
+ * the final reduction of the split-M weight-gradient GEMMs. */
+typedef struct hsSumJob {
+    const void *src;
+    float *dst;
+    int64_t n;
+    int32_t slices;
+} hsSumJob;
+int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
