@@ -378,6 +378,44 @@ __global__ __launch_bounds__(256) void k_sum_slices(SumJobs jobs) {
     }
 }
 
+// Weight normalisation W = g * v / ||v||_row (nn.utils.weight_norm, dim 0; model/network.py:158-159) and its backward for
+// several layers in one launch each: one wave per output row.
+struct WnJobs { hsWnJob j[HS_PACK_MAX_JOBS]; int32_t row_end[HS_PACK_MAX_JOBS]; int32_t n; };
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_weight_norm(WnJobs jobs) {
+    const int row_g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int j = 0;
+    while (j < jobs.n && row_g >= jobs.row_end[j]) j++;
+    if (j >= jobs.n) return;
+    const hsWnJob jb = jobs.j[j];
+    const int row = row_g - (j ? jobs.row_end[j - 1] : 0);
+    const float *v = jb.v + (size_t)row * jb.cols;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < jb.cols; c += 64) {
+        const float x = v[c];
+        ss += x * x;
+        if (BWD) dot += jb.gW[(size_t)row * jb.cols + c] * x;
+    }
+    const float norm = sqrtf(wave_sum64(ss));
+    const float g = jb.g[row];
+    if (!BWD) {
+        const float sc = g / norm;
+        for (int c = lane; c < jb.cols; c += 64) jb.W[(size_t)row * jb.cols + c] = v[c] * sc;
+    } else {
+        dot = wave_sum64(dot);
+        const float sc = g / norm, back = dot / (norm * norm);
+        for (int c = lane; c < jb.cols; c += 64) jb.gv[(size_t)row * jb.cols + c] = sc * (jb.gW[(size_t)row * jb.cols + c] - v[c] * back);
+        if (lane == 0) jb.gg[row] = dot / norm;
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 constexpr size_t kLdsFwd = ((size_t)BM * HP + 2 * (size_t)HID * WP + (size_t)BM * PP) * sizeof(uint16_t) + (4 * HID + 4) * sizeof(float);
@@ -454,6 +492,25 @@ int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream) {
     }
     const int64_t want = (max_n / 4 + 255) / 256;
     k_sum_slices<<<dim3((unsigned)(want < 256 ? want : 256), n_jobs), 256, 0, (hipStream_t)stream>>>(sj);
+    return check_launch();
+}
+
+int hs_weight_norm(const hsWnJob *jobs, int32_t n_jobs, int32_t backward, void *stream) {
+    if (n_jobs < 0 || n_jobs > HS_PACK_MAX_JOBS) return HS_ERR_ARG;
+    if (n_jobs == 0) return HS_OK;
+    if (!jobs) return HS_ERR_NULL;
+    WnJobs wj;
+    int total = 0;
+    for (int i = 0; i < n_jobs; i++) {
+        wj.j[i] = jobs[i];
+        if (!jobs[i].v || !jobs[i].g || (backward ? (!jobs[i].gW || !jobs[i].gv || !jobs[i].gg) : !jobs[i].W)) return HS_ERR_NULL;
+        if (jobs[i].rows < 1 || jobs[i].cols < 1) return HS_ERR_ARG;
+        total += jobs[i].rows;
+        wj.row_end[i] = total;
+    }
+    wj.n = n_jobs;
+    if (backward) k_weight_norm<true><<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(wj);
+    else k_weight_norm<false><<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(wj);
     return check_launch();
 }
 

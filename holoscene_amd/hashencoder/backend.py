@@ -41,6 +41,11 @@ class hsSumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32)]
 
 
+class hsWnJob(ctypes.Structure):
+    _fields_ = [("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("gW", ctypes.c_void_p), ("W", ctypes.c_void_p), ("gv", ctypes.c_void_p),
+                ("gg", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+
+
 ABI_VERSION = 2
 
 
@@ -77,7 +82,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
 
 
 def _check(rc, what):
@@ -352,6 +357,32 @@ class _HipBackend:
             a.ld, a.row0, a.col0, a.rows, a.cols = src.shape[1], row0, col0, rows, cols
             a.dst_rows, a.dst_cols, a.transpose = dst.shape[0], dst.shape[1], int(tr)
         _check(lib.hs_pack_bf16(arr, len(jobs), _stream()), "hs_pack_bf16")
+
+    @staticmethod
+    def weight_norm_fwd(vs, gs):
+        """[g * v / ||v||_row for v, g in zip(vs, gs)] in one launch (fp32)."""
+        lib = load_library()
+        arr = (hsWnJob * len(vs))()
+        outs = []
+        for a, v, g in zip(arr, vs, gs):
+            W = torch.empty_like(v)
+            a.v, a.g, a.W, a.rows, a.cols = _dev(v, "v").value, _dev(g, "g").value, _dev(W, "W").value, v.shape[0], v.shape[1]
+            outs.append(W)
+        _check(lib.hs_weight_norm(arr, len(vs), 0, _stream()), "hs_weight_norm")
+        return outs
+
+    @staticmethod
+    def weight_norm_bwd(vs, gs, gWs):
+        lib = load_library()
+        arr = (hsWnJob * len(vs))()
+        outs = []
+        for a, v, g, gW in zip(arr, vs, gs, gWs):
+            gv, gg = torch.empty_like(v), torch.empty_like(g)
+            a.v, a.g, a.gW = _dev(v, "v").value, _dev(g, "g").value, _dev(gW, "gW").value
+            a.gv, a.gg, a.rows, a.cols = _dev(gv, "gv").value, _dev(gg, "gg").value, v.shape[0], v.shape[1]
+            outs += [gv, gg]
+        _check(lib.hs_weight_norm(arr, len(vs), 1, _stream()), "hs_weight_norm")
+        return outs
 
     @staticmethod
     def sum_slices(partials):

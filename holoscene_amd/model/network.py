@@ -547,6 +547,33 @@ class WNLinear(nn.Module):
         return linear_rows(x, self.weight, self.bias, self.bf16)
 
 
+class _weight_norm_many(torch.autograd.Function):
+    """(v0, g0, v1, g1, ...) -> (W0, W1, ...), W = g * v / ||v||_row: all layers of a network in one launch each way
+    (csrc/appearance_mlp.hip: k_weight_norm) instead of one torch._weight_norm kernel per layer and direction."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        vs = [t.detach().float().contiguous() for t in vg[0::2]]
+        gs = [t.detach().float().contiguous() for t in vg[1::2]]
+        ctx.save_for_backward(*vs, *gs)
+        ctx.n = len(vs)
+        return tuple(_be._backend.weight_norm_fwd(vs, gs))
+
+    @staticmethod
+    def backward(ctx, *gWs):
+        vs, gs = ctx.saved_tensors[:ctx.n], ctx.saved_tensors[ctx.n:]
+        gWs = [torch.zeros_like(v) if gW is None else gW.contiguous().float() for v, gW in zip(vs, gWs)]
+        out = _be._backend.weight_norm_bwd(list(vs), list(gs), gWs)
+        return tuple(o.view_as(p) for o, p in zip(out, [t for pair in zip(vs, gs) for t in pair]))
+
+
+def effective_weights(lins):
+    """Weight-normalised matrices of a list of WNLinear layers (one fused launch on the GPU)."""
+    if lins[0].weight_v.is_cuda:
+        return _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
+    return tuple(l.weight for l in lins)
+
+
 class _softplus_tangent(torch.autograd.Function):
     """[B,rows,W] pre-activations (row 0 = value, rest = tangents) + bias -> activations, one fused pass
     each way (csrc/mlp_ops.hip)."""
@@ -717,7 +744,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         n2 = 32 * ((l2.out_features + 31) // 32)
         w0, w1, w2 = torch.empty(256, 96, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf), torch.empty(n2, 256, device=dev, dtype=bf)
         with torch.no_grad():
-            f0, f1, f2 = l0.weight.float().contiguous(), l1.weight.float().contiguous(), l2.weight.float().contiguous()
+            f0, f1, f2 = effective_weights([l0, l1, l2])
         _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False), (f1, w1, 0, 0, 256, 256, False),
                                 (f2, w2, 0, 0, l2.out_features, 256, False)])
         self._packed_cache = (w0, l0.bias.detach().float().contiguous(), w1, l1.bias.detach().float().contiguous(), w2,
@@ -1134,9 +1161,10 @@ class HoloSceneNetwork(nn.Module):
         if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
+            W0, W1, W2 = effective_weights([l0, l1, l2])
             sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = _fused_trunk_render.apply(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
-                net.embedder.multires, float(net.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias, x01_all)
+                net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
         else:
             y_all, J_all = net.sdf_and_jacobian(x_all)
             y_all, J_all = y_all[:, :net.d_out], J_all[:, :net.d_out]
@@ -1149,9 +1177,10 @@ class HoloSceneNetwork(nn.Module):
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
+            R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
             rgb = _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
                                           int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
-                                          mlp[2].bias, rn.lin0.weight, rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias,
+                                          mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias, R2, rn.lin2.bias,
                                           None if x01_all is None else x01_all[:n_main])
             rgb = rgb.reshape(-1, N_samples, 3)
         else:

@@ -343,6 +343,16 @@ typedef struct hsSumJob {
 } hsSumJob;
 int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream);
 
+/* Weight normalisation of several layers in one launch (nn.utils.weight_norm with dim = 0, model/network.py:158-159):
+ * forward  W[r,:] = g[r] * v[r,:] / ||v[r,:]||;   backward (gW given)  gg[r] = <gW[r,:], v[r,:]> / ||v[r,:]||,
+ * gv[r,:] = g[r]/||v[r,:]|| * (gW[r,:] - v[r,:] * <gW[r,:], v[r,:]> / ||v[r,:]||^2).  All fp32, row-major [rows, cols]. */
+typedef struct hsWnJob {
+    const float *v, *g, *gW;
+    float *W, *gv, *gg;
+    int32_t rows, cols;
+} hsWnJob;
+int hs_weight_norm(const hsWnJob *jobs, int32_t n_jobs, int32_t backward, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation

@@ -728,3 +728,22 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
     for a, b, n in zip(res["new"][2], res["ref"][2], ["table"] + [f"lin{i}.{k}" for i in range(3) for k in ("v", "g", "bias")]):
         rel = float((a - b).norm() / (b.norm() + 1e-20))
         assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
+
+
+def test_batched_weight_norm_vs_torch():
+    """hs_weight_norm (all layers of a network in one launch per direction) vs torch._weight_norm and its autograd backward."""
+    from holoscene_amd.model import network as N
+    torch.manual_seed(3)
+    shapes = [(256, 71), (256, 256), (32, 256), (3, 256), (256, 337)]
+    vs = [torch.randn(*s, device=DEV, requires_grad=True) for s in shapes]
+    gs = [(torch.rand(s[0], 1, device=DEV) + 0.5).requires_grad_(True) for s in shapes]
+    cots = [torch.randn(*s, device=DEV) for s in shapes]
+    Ws = N._weight_norm_many.apply(*[t for pair in zip(vs, gs) for t in pair])
+    got = torch.autograd.grad(sum((W * c).sum() for W, c in zip(Ws, cots)), vs + gs)
+    ref_W = [torch._weight_norm(v, g, 0) for v, g in zip(vs, gs)]
+    ref = torch.autograd.grad(sum((W * c).sum() for W, c in zip(ref_W, cots)), vs + gs)
+    for a, b in zip(Ws, ref_W):
+        close(a, b, 1e-6, 1e-7, "W")
+    for a, b, n in zip(got, ref, ["gv"] * 5 + ["gg"] * 5):
+        assert a.shape == b.shape
+        close(a, b, 2e-5, 1e-5 * float(b.abs().max()), n)
