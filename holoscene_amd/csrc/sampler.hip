@@ -339,14 +339,14 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
 __global__ __launch_bounds__(kWave) void k_sampler_final(const float *__restrict__ z_samples, int n_s, const float *__restrict__ z_in, int ld,
                                                           const int64_t *__restrict__ pick, int n_extra, float near, float far,
                                                           const int64_t *__restrict__ eik_idx, float *__restrict__ z_out, float *__restrict__ z_eik,
-                                                          int R) {
+                                                          int R, const float *__restrict__ near_r, const float *__restrict__ far_r) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     const int n = n_s + 2 + n_extra;
     float *v = lds, *sorted = lds + n;
     for (int i = lane; i < n_s; i += kWave) v[i] = z_samples[(size_t)r * n_s + i];
-    if (lane == 0) { v[n_s] = near; v[n_s + 1] = far; }
+    if (lane == 0) { v[n_s] = near_r ? near_r[r] : near; v[n_s + 1] = far_r ? far_r[r] : far; }   // per-ray bounds: get_z_vals_near_far
     for (int i = lane; i < n_extra; i += kWave) v[n_s + 2 + i] = z_in[(size_t)r * ld + pick[i]];
     __syncthreads();
     for (int i = lane; i < n; i += kWave) {  // rank sort (n ~ 100)
@@ -474,13 +474,13 @@ int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, in
 }
 
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
-                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream) {
+                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, const float *near_rays, const float *far_rays, void *stream) {
     if (R <= 0) return HS_OK;
     if (!z_samples || !z || !z_out || (n_extra > 0 && !pick) || (z_eik && !eik_idx)) return HS_ERR_NULL;
     const int n = n_s + 2 + n_extra;
     if (n > 4096) return HS_ERR_ARG;
     k_sampler_final<<<dim3(R), dim3(kWave), 2 * n * sizeof(float), (hipStream_t)stream>>>(z_samples, n_s, z, ld, pick, n_extra, near, far, eik_idx,
-                                                                                          z_out, z_eik, R);
+                                                                                          z_out, z_eik, R, near_rays, far_rays);
     return check_launch();
 }
 

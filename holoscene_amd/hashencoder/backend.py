@@ -266,13 +266,13 @@ class _HipBackend:
         _check(lib.hs_sampler_pick(_dev(ctl, "ctl"), _dev(u, "u"), n_extra, _dev(pick, "pick", torch.int64), _stream()), "hs_sampler_pick")
 
     @staticmethod
-    def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik):
+    def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik, near_rays=None, far_rays=None):
         lib = load_library()
         R, ld = z.shape
         n_extra = 0 if pick is None else pick.numel()
         _check(lib.hs_sampler_final(_dev(z_samples, "z_samples"), z_samples.shape[1], _dev(z, "z"), ld, _dev(pick, "pick", torch.int64), n_extra,
                                     ctypes.c_float(near), ctypes.c_float(far), _dev(eik_idx, "eik_idx", torch.int64), _dev(z_out, "z_out"),
-                                    _dev(z_eik, "z_eik"), R, _stream()), "hs_sampler_final")
+                                    _dev(z_eik, "z_eik"), R, _dev(near_rays, "near_rays"), _dev(far_rays, "far_rays"), _stream()), "hs_sampler_final")
 
     @staticmethod
     def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init):

@@ -192,7 +192,24 @@ class ErrorBoundSampler(RaySampler):
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
         return self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng or {})
 
-    def _get_z_vals_hip(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None):
+    @torch.no_grad()
+    def get_z_vals_near_far(self, ray_dirs, cam_loc, model, near, far, idx=None, rng=None):
+        """Algorithm 1 between caller-supplied bounds (scalars or per-ray [R,1] tensors): the Stage-2/3 entry point
+        (ray_sampler.py:290-447; callers network.py:1321, 1472, 1751).  Differs from get_z_vals only in the first uniform samples
+        (ray_sampler.py:85-102) and in the near / far samples appended at the end (:434-436 commented out there)."""
+        rng = rng or {}
+        dev = ray_dirs.device
+        z0, near_t, far_t = self.uniform_sampler.get_z_vals_near_far(ray_dirs, cam_loc, model, near, far, t_rand=rng.get("t_rand"))
+        d0 = z0[:, 1:] - z0[:, :-1]
+        beta_init = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
+        bounds = (near_t.reshape(-1).contiguous().float(), far_t.reshape(-1).contiguous().float())
+        if SAMPLER_IMPL == "hip":
+            return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng, z0.contiguous(), beta_init, bounds=bounds)
+        if SAMPLER_IMPL != "torch":
+            raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
+        return self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng, z0=z0, bounds=bounds)
+
+    def _get_z_vals_hip(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, bounds=None):
         """Algorithm 1 with the per-ray arithmetic in three fused kernels per round (update / draw / final).
         Per round: 1 SDF sweep, 2 kernel launches, one 4-byte device->host read for the convergence test."""
         if not ray_dirs.is_cuda:
@@ -307,7 +324,8 @@ class ErrorBoundSampler(RaySampler):
             eik = torch.randint(n_out, (R,), device=dev)
         z_out = torch.empty(R, n_out, device=dev)
         z_eik = torch.empty(R, 1, device=dev)
-        be.sampler_final(samples, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
+        be.sampler_final(samples, z, pick, float(self.near), float(self.far), eik, z_out, z_eik,
+                         near_rays=None if bounds is None else bounds[0], far_rays=None if bounds is None else bounds[1])
         if hasattr(model.implicit_network, "invalidate_packed_weights"):
             model.implicit_network.invalidate_packed_weights()   # the images belong to this parameter state only
         return z_out, z_eik
@@ -377,11 +395,14 @@ class ErrorBoundSampler(RaySampler):
         self._rounds = ci[3:4]
         return z_out, z_eik
 
-    def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng):
+    def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng, z0=None, bounds=None):
         dev = ray_dirs.device
         R = ray_dirs.shape[0]
         beta0 = model.density.get_beta().detach()
-        z_vals, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+        if z0 is None:
+            z_vals, _, _ = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand"))
+        else:
+            z_vals = z0
         samples, order, sdf = z_vals, None, None
         dists = z_vals[:, 1:] - z_vals[:, :-1]
         # Lemma 2: beta that certainly satisfies the bound (fp32 log as the reference, :138-140)
@@ -434,8 +455,8 @@ class ErrorBoundSampler(RaySampler):
                 z_vals, order = torch.sort(torch.cat([z_vals, samples], -1), -1)
         self.last_rounds = rounds
         z_samples = samples
-        near = torch.full((R, 1), float(self.near), device=dev)
-        far = torch.full((R, 1), float(self.far), device=dev)
+        near = torch.full((R, 1), float(self.near), device=dev) if bounds is None else bounds[0].reshape(R, 1)
+        far = torch.full((R, 1), float(self.far), device=dev) if bounds is None else bounds[1].reshape(R, 1)
         if self.N_samples_extra > 0:
             if model.training:
                 perm = rng["perm"] if "perm" in rng else torch.randperm(z_vals.shape[1])

@@ -173,7 +173,9 @@ int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, in
 /* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
  * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
-                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, void *stream);
+                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R,
+                     const float *near_rays, const float *far_rays /* [R] per-ray bounds overriding near / far (ray_sampler.py:290-447), or NULL */,
+                     void *stream);
 
 /* Camera rays + first (uniform, stratified) depths + Lemma-2 beta in one launch (utils/rend_util.py:56-125 twice incl. the
  * 2x-offset depth-scale rays, model/ray_sampler.py:48-83 and :136-140).  uv [R,2] pixels; ray_offset [R,2] or NULL; pose,

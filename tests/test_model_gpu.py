@@ -747,3 +747,40 @@ def test_batched_weight_norm_vs_torch():
     for a, b, n in zip(got, ref, ["gv"] * 5 + ["gg"] * 5):
         assert a.shape == b.shape
         close(a, b, 2e-5, 1e-5 * float(b.abs().max()), n)
+
+
+@pytest.mark.parametrize("idx", [None, 1, [0, 1]])
+@pytest.mark.parametrize("per_ray", [False, True])
+def test_sampler_between_supplied_bounds(idx, per_ray, monkeypatch):
+    """ErrorBoundSampler.get_z_vals_near_far (reference ray_sampler.py:290-447): fused kernels vs the whole-tensor
+    formulation on identical draws, scalar and per-ray bounds, scene / single-object / object-subset SDF queries."""
+    from holoscene_amd.model import ray_sampler as RS
+    rec = load("sampler_2")
+    model = build_model(rec, DEV).train()
+    ins = _dev(section(rec, "in."))
+    R = ins["ray_dirs"].shape[0]
+    g = torch.Generator().manual_seed(4)
+    if per_ray:
+        near = (torch.rand(R, 1, generator=g) * 0.3).to(DEV)
+        far = (1.0 + torch.rand(R, 1, generator=g) * 1.5).to(DEV)
+    else:
+        near, far = 0.1, 2.2
+    sm = model.ray_sampler
+    n_out = sm.N_samples + 2 + sm.N_samples_extra
+    rng = {"t_rand": torch.rand(R, sm.N_samples_eval, generator=g).to(DEV), "u_final": torch.rand(R, sm.N_samples, generator=g).to(DEV),
+           "eik_idx": torch.randint(n_out, (R,), generator=g).to(DEV)}
+    res = {}
+    for impl in ("hip", "torch"):
+        monkeypatch.setattr(RS, "SAMPLER_IMPL", impl)
+        z, z_eik = sm.get_z_vals_near_far(ins["ray_dirs"], ins["cam_loc"], model, near, far, idx=idx,
+                                          rng=dict(rng, perm=torch.arange(sm.N_samples_eval * sm.max_total_iters)))
+        res[impl] = (z, z_eik, sm.last_rounds)
+    z, z_eik, _ = res["hip"]
+    assert z.shape == (R, n_out) and bool((z[:, 1:] >= z[:, :-1]).all())
+    lo = near if per_ray else torch.full((R, 1), near, device=DEV)
+    hi = far if per_ray else torch.full((R, 1), far, device=DEV)
+    assert bool((z >= lo - 1e-6).all()) and bool((z <= hi + 1e-6).all())
+    assert torch.equal(z[:, :1], lo) and torch.equal(z[:, -1:], hi)          # the bounds themselves are samples (:261-263)
+    assert res["hip"][2] == res["torch"][2]
+    z_close(z, res["torch"][0], frac_loose=0.05)
+    assert torch.equal(z_eik, torch.gather(z, 1, rng["eik_idx"][:, None]))
