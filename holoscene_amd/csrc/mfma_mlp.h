@@ -25,8 +25,12 @@ constexpr int kRowWaves = BM / 32;  // waves that take part in a narrow (<= 32 o
 constexpr int kGridCap = 256 * (128 / BM);
 constexpr int HID = 256;          // hidden width
 constexpr int HP = HID + 8;       // activation row pitch (bf16)
-constexpr int KC = 32;            // weight chunk depth
-constexpr int WP = KC + 8;        // weight chunk row pitch (bf16)
+#ifndef HS_MLP_KC
+#define HS_MLP_KC 32
+#endif
+constexpr int KC = HS_MLP_KC;     // (largest) weight chunk depth: sizes the two chunk buffers.  64 halves the number of barrier rounds per
+                                  // 256-deep layer; kernels that need the LDS for something else stay at 32
+constexpr int WP = KC + 8;        // row pitch (bf16) of a KC-deep chunk; buffers are HID * WP apart whatever depth a layer streams with
 constexpr int K0 = 96;            // padded input width (71 -> 96)
 
 __device__ __forceinline__ uint32_t f2bf(float f) {  // round-to-nearest-even; inputs are finite here
@@ -42,71 +46,78 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // one v_cvt_
     return *reinterpret_cast<const uint32_t *>(&r);
 }
 
-// rows [0,256) x cols [k0, k0+KC) of a row-major [256][ldw] bf16 matrix = 16 KB, spread over the workgroup
+// rows [0,256) x cols [k0, k0+KCH) of a row-major [256][ldw] bf16 matrix, spread over the workgroup
 constexpr int kChunkTPR = kThreads / HID;            // threads per weight row: 2 (512 threads) or 1 (256 threads)
-constexpr int kChunkVec = KC / 8 / kChunkTPR;        // 16-byte vectors per thread: 2 or 4
-struct ChunkRegs { uint4 v[kChunkVec]; };
+template <int KCH> struct ChunkRegs { uint4 v[KCH / 8 / kChunkTPR]; };
 
-__device__ __forceinline__ ChunkRegs load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
-    ChunkRegs r;
+template <int KCH>
+__device__ __forceinline__ ChunkRegs<KCH> load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
+    ChunkRegs<KCH> r;
+    constexpr int NV = KCH / 8 / kChunkTPR;
     const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
-    const uint16_t *src = W + (size_t)row * ldw + k0 + part * (8 * kChunkVec);
+    const uint16_t *src = W + (size_t)row * ldw + k0 + part * (8 * NV);
 #pragma unroll
-    for (int i = 0; i < kChunkVec; i++) r.v[i] = *reinterpret_cast<const uint4 *>(src + 8 * i);
+    for (int i = 0; i < NV; i++) r.v[i] = *reinterpret_cast<const uint4 *>(src + 8 * i);
     return r;
 }
 
-__device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs &r) {
+template <int KCH>
+__device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs<KCH> &r) {
+    constexpr int NV = KCH / 8 / kChunkTPR;
     const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
-    uint16_t *dst = Wc + (size_t)row * WP + part * (8 * kChunkVec);
+    uint16_t *dst = Wc + (size_t)row * (KCH + 8) + part * (8 * NV);
 #pragma unroll
-    for (int i = 0; i < kChunkVec; i++) *reinterpret_cast<uint4 *>(dst + 8 * i) = r.v[i];
+    for (int i = 0; i < NV; i++) *reinterpret_cast<uint4 *>(dst + 8 * i) = r.v[i];
 }
 
 struct Frags { bf16x8 a[2], b[2]; };
 
-// operand fragments of k-step `s` (16 wide): weights from the chunk buffer, activations from H (row pitch AP)
-template <int AP = HP>
+// operand fragments of k-step `s` (16 wide) of a layer streamed in KCH-deep chunks: weights from the chunk buffer, activations
+// from H (row pitch AP)
+template <int AP, int KCH>
 __device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *H, int s, int nq, int ph, int lane) {
     Frags f;
-    const uint16_t *wbuf = Wc + (size_t)((s >> 1) & 1) * HID * WP + (s & 1) * 16 + (lane >> 5) * 8;
+    constexpr int KS = KCH / 16;
+    const uint16_t *wbuf = Wc + (size_t)((s / KS) & 1) * HID * WP + (s % KS) * 16 + (lane >> 5) * 8;
     const uint16_t *hrow = H + s * 16 + (lane >> 5) * 8;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        f.a[i] = *reinterpret_cast<const bf16x8 *>(wbuf + (size_t)(nq * 64 + i * 32 + (lane & 31)) * WP);
+        f.a[i] = *reinterpret_cast<const bf16x8 *>(wbuf + (size_t)(nq * 64 + i * 32 + (lane & 31)) * (KCH + 8));
         f.b[i] = *reinterpret_cast<const bf16x8 *>(hrow + (size_t)(ph * 64 + i * 32 + (lane & 31)) * AP);
     }
     return f;
 }
 
-// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KC.  wave -> neurons [nq*64,+64), points [ph*64,+64)
+// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KCH.  wave -> neurons [nq*64,+64), points [ph*64,+64)
 // compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
-template <int AP = HP>
+template <int AP = HP, int KCH = KC>
 __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
                                           int nq, int ph, int lane, bool compute = true) {
-    const int nchunks = K / KC;
-    ChunkRegs pre = load_chunk(W, ldw, 0);
-    store_chunk(Wc, pre);
+    constexpr int KS = KCH / 16;
+    const int nchunks = K / KCH;
+    ChunkRegs<KCH> pre = load_chunk<KCH>(W, ldw, 0);
+    store_chunk<KCH>(Wc, pre);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
 #ifndef HS_EXP_NO_WLOAD
-        if (c + 1 < nchunks) pre = load_chunk(W, ldw, (c + 1) * KC);
+        if (c + 1 < nchunks) pre = load_chunk<KCH>(W, ldw, (c + 1) * KCH);
 #endif
 #ifndef HS_EXP_NO_MMA
         if (compute) {
-        Frags f0 = load_frags<AP>(Wc, H, 2 * c, nq, ph, lane);
-        Frags f1 = load_frags<AP>(Wc, H, 2 * c + 1, nq, ph, lane);   // in flight while f0's MFMAs run
+            Frags f[2];
+            f[0] = load_frags<AP, KCH>(Wc, H, c * KS, nq, ph, lane);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+            for (int kk = 0; kk < KS; kk++) {
+                if (kk + 1 < KS) f[(kk + 1) & 1] = load_frags<AP, KCH>(Wc, H, c * KS + kk + 1, nq, ph, lane);   // in flight under this step's MFMAs
+                const Frags &g = f[kk & 1];
 #pragma unroll
-            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a[nt], f0.b[pt], acc[nt][pt], 0, 0, 0);
+                for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.a[nt], f1.b[pt], acc[nt][pt], 0, 0, 0);
+                    for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.a[nt], g.b[pt], acc[nt][pt], 0, 0, 0);
+            }
         }
 #endif
-        if (c + 1 < nchunks) store_chunk(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
+        if (c + 1 < nchunks) store_chunk<KCH>(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
         __syncthreads();
     }
 }

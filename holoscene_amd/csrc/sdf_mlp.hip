@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#define HS_MLP_KC 64   // 256-deep layers stream their weights in 64-deep chunks (half the barrier rounds); LDS: 66 + 72 KB
 #include "mfma_mlp.h"
 
 namespace {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
         __syncthreads();
         f32x16 acc[2][2];
         zero_acc(acc);
-        layer_mma(W0, K0, K0, H, Wc, acc, nq, ph, lane);
+        layer_mma<HP, 32>(W0, K0, K0, H, Wc, acc, nq, ph, lane);
         epilogue_softplus(bias, H, acc, nq, ph, lane);
         __syncthreads();
         zero_acc(acc);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
         }
         f32x16 acc[2][2];
         zero_acc(acc);
-        layer_mma(W0, K0, K0, H, Wc, acc, nq, ph, lane);
+        layer_mma<HP, 32>(W0, K0, K0, H, Wc, acc, nq, ph, lane);
         epilogue_tangent(bias, H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, H0, r0, M);   // reads of H; the next epilogue's writes sit behind layer_mma's barriers
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         f32x16 acc[2][2];
         TileRegs hr = load_tile_regs(H1, r0, M);   // in flight under the matrix product
         zero_acc(acc);
-        layer_mma(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
+        layer_mma<HP, 32>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
         __syncthreads();
         epilogue_bwd(H, acc, nq, ph, lane);
