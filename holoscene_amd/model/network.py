@@ -248,6 +248,7 @@ class _fused_trunk(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
+        ctx.set_materialize_grads(False)
         Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
         ctx.save_for_backward(*saved)
         Y = Y.view(x.shape[0], 4, -1)
@@ -279,6 +280,7 @@ class _fused_trunk_render(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+        ctx.set_materialize_grads(False)    # unused outputs reach backward as None (the kernels take NULL), not as zero-filled tensors
         Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
         B, K = x.shape[0], W2.shape[0]
         dev = x.device
@@ -483,6 +485,7 @@ class _composite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, sdf, raw, rgb, g, beta, depth_scale, sem_scale):
+        ctx.set_materialize_grads(False)
         z, sdf, raw, rgb, g = z.contiguous(), sdf.contiguous(), raw.contiguous(), rgb.contiguous(), g.contiguous()
         depth_scale = depth_scale.contiguous()
         beta1 = beta.detach().reshape(1).contiguous()
@@ -553,6 +556,7 @@ class _weight_norm_many(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *vg):
+        ctx.set_materialize_grads(False)
         vs = [t.detach().float().contiguous() for t in vg[0::2]]
         gs = [t.detach().float().contiguous() for t in vg[1::2]]
         ctx.save_for_backward(*vs, *gs)
