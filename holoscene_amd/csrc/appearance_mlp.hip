@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
     float *S = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);   // [BM][SP] fp32 scratch for the narrow products
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = wave & 3, ph = wave >> 2;
-    float s_r1 = 0.f, s_r0 = 0.f, s_c1 = 0.f, s_c0 = 0.f;
+    float s_r1 = 0.f, s_r0 = 0.f, s_c1 = 0.f, s_c0 = 0.f, s_y = 0.f;
     const int64_t ntiles = (B + BM - 1) / BM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
@@ -250,6 +250,11 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
             if (gp < B) *reinterpret_cast<uint4 *>(gy + (size_t)gp * 32 + seg * 8) = v;
         }
         __syncthreads();
+        {   // output-layer bias gradient: column sums of the 3 live columns (thread = column x row group)
+            const int col = threadIdx.x & 3, rg = threadIdx.x >> 2;
+            if (col < 3)
+                for (int r = rg; r < BM; r += kThreads / 4) s_y += __uint_as_float((uint32_t)H[(size_t)r * HP + col] << 16);
+        }
         f32x16 acc[2][2];
         TileRegs hr = load_tile_regs(r1, p0, B);
         zero_acc(acc);
@@ -330,6 +335,17 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         unsafeAtomicAdd(gb + HID + threadIdx.x, s_r0);
         unsafeAtomicAdd(gb + 2 * HID + threadIdx.x, s_c1);
         unsafeAtomicAdd(gb + 3 * HID + threadIdx.x, s_c0);
+    }
+    if (gb) {   // workgroup reduction before the (same-address) atomics
+        float *red = reinterpret_cast<float *>(lds);
+        __syncthreads();
+        red[threadIdx.x] = s_y;
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float t = 0.f;
+            for (int i = threadIdx.x; i < kThreads; i += 4) t += red[i];
+            unsafeAtomicAdd(gb + 4 * HID + threadIdx.x, t);
+        }
     }
 }
 

@@ -426,13 +426,14 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                                                          const uint16_t *__restrict__ W2t, const uint16_t *__restrict__ W1t,
                                                          uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
                                                          float *__restrict__ gb0, const uint16_t *__restrict__ W0t, float *__restrict__ g_feat,
-                                                         float *__restrict__ g_dydx, int L, int C, float jac_scale, int64_t M) {
+                                                         float *__restrict__ g_dydx, int L, int C, float jac_scale, int64_t M,
+                                                         float *__restrict__ gb2) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = wave & 3, ph = wave >> 2;
-    float sum1 = 0.f, sum0 = 0.f;
+    float sum1 = 0.f, sum0 = 0.f, sum2 = 0.f;
     const int64_t ntiles = (M + BM - 1) / BM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
         }
         __syncthreads();
+        if (gb2) {   // last layer's bias gradient: column sums of the VALUE rows of the output cotangent (thread = column x row group)
+            const int col = threadIdx.x % KP, rg = threadIdx.x / KP;
+            for (int r = 4 * rg; r < BM; r += 4 * (kThreads / KP)) sum2 += __uint_as_float((uint32_t)H[(size_t)r * HP + col] << 16);
+        }
         f32x16 acc[2][2];
         TileRegs hr = load_tile_regs(H1, r0, M);   // in flight under the matrix product
         zero_acc(acc);
@@ -511,6 +516,17 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         if (gb1) unsafeAtomicAdd(gb1 + threadIdx.x, sum1);
         if (gb0) unsafeAtomicAdd(gb0 + threadIdx.x, sum0);
     }
+    if (gb2) {   // workgroup reduction first: 256 workgroups x 512 same-address atomics would serialise for ~0.2 ms
+        float *red = reinterpret_cast<float *>(lds);
+        __syncthreads();
+        red[threadIdx.x] = sum2;
+        __syncthreads();
+        if (threadIdx.x < KP) {
+            float t = 0.f;
+            for (int i = threadIdx.x; i < kThreads; i += KP) t += red[i];
+            unsafeAtomicAdd(gb2 + threadIdx.x, t);
+        }
+    }
 }
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
@@ -570,7 +586,7 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale, int64_t M,
-                     void *stream) {
+                     float *gb2, void *stream) {
     if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
     if (W0t && (L < 1 || C < 1 || L * C != NFEAT)) return HS_ERR_ARG;
@@ -583,12 +599,12 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2);
     }
     return check_launch();
 }

@@ -443,13 +443,13 @@ class _HipBackend:
                                     _stream()), "hs_trunk_mlp_fwd")
 
     @staticmethod
-    def trunk_mlp_bwd(g, H1, H0, W2t, W1t, gA1, gA0, gb1, gb0, W0t=None, g_feat=None, g_dydx=None, L=0, C=0, jac_scale=0.0):
+    def trunk_mlp_bwd(g, H1, H0, W2t, W1t, gA1, gA0, gb1, gb0, W0t=None, g_feat=None, g_dydx=None, L=0, C=0, jac_scale=0.0, gb2=None):
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_trunk_mlp_bwd(_dev(g, "g", bf), g.shape[-1], _dev(H1, "H1", bf), _dev(H0, "H0", bf), _dev(W2t, "W2t", bf),
                                     _dev(W1t, "W1t", bf), _dev(gA1, "gA1", bf), _dev(gA0, "gA0", bf), _dev(gb1, "gb1"), _dev(gb0, "gb0"),
                                     _dev(W0t, "W0t", bf), _dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), L, C, ctypes.c_float(jac_scale),
-                                    ctypes.c_int64(g.shape[0]), _stream()), "hs_trunk_mlp_bwd")
+                                    ctypes.c_int64(g.shape[0]), _dev(gb2, "gb2"), _stream()), "hs_trunk_mlp_bwd")
 
     @staticmethod
     def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta):

@@ -129,6 +129,7 @@ class _trunk_input(torch.autograd.Function):
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
 TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+_FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
 _BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
 # 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
 # 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
@@ -211,13 +212,17 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     M = 4 * B
     gA1 = torch.empty(M, 256, device=dev, dtype=bf)
     gA0 = torch.empty(M, 256, device=dev, dtype=bf)
-    gb1 = torch.zeros(256, device=dev)
-    gb0 = torch.zeros(256, device=dev)
+    KP = g.shape[1]
+    gbz = torch.zeros(2 * 256 + KP, device=dev)      # one zero-fill for the three bias-gradient accumulators
+    gb1, gb0, gb2k = gbz[:256], gbz[256:512], gbz[512:]
     g_feat = g_dydx = None
     if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
         g_feat = torch.empty(L, B, C, device=dev, dtype=torch.float32)     # level-major: coalesced for both writer and scatter
         g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
-    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale)
+    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale,
+                               gb2=gb2k if gb2 is _FROM_KERNEL else None)
+    if gb2 is _FROM_KERNEL:
+        gb2 = gb2k[:d_out]
 
     def table_branch():
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
@@ -303,10 +308,7 @@ class _fused_trunk_render(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         g = torch.empty(4 * B, KP, device=idx.device, dtype=torch.bfloat16)
         _be._backend.trunk_split_bwd(c(g_raw), c(g_sdf), idx, c(g_grad), c(g_yeik), c(g_mineik), c(g_theta), B, ctx.n_main, d_out, g)
-        gb2 = None
-        if ctx.needs_input_grad[13]:
-            Sg = _split_rows(B)
-            gb2 = g.view(Sg, B // Sg, 4, KP)[:, :, 0, :d_out].sum(1, dtype=torch.float32).sum(0)
+        gb2 = _FROM_KERNEL if ctx.needs_input_grad[13] else None
         g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g, gb2, ctx.needs_input_grad[2], ctx.needs_input_grad[8])
         return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
@@ -361,7 +363,7 @@ class _fused_appearance(torch.autograd.Function):
         gy, gA_r1, gA_r0, g_fv, gA_hc = new(32), new(256), new(256), new(256), new(256)
         d_normals = torch.empty(B, 3, device=dev)
         g_featc = torch.empty(L, B, C, device=dev)
-        gb = torch.zeros(4, 256, device=dev)
+        gb = torch.zeros(5, 256, device=dev)
         W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
         be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb)
         need_w = ctx.needs_input_grad[8]
@@ -369,8 +371,7 @@ class _fused_appearance(torch.autograd.Function):
         if need_w:
             w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many([(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)])
             gWr2 = w_r2[:3]
-            Sg = _split_rows(B)
-            gbr2 = gy.view(Sg, B // Sg, 32).sum(1, dtype=torch.float32).sum(0)[:3]
+            gbr2 = gb[4, :3]
             gWr0 = torch.cat([w_r0x[:, 32:113], w_r0f], 1)
             gWc0 = w_c0[:, :32]
         g_emb = None

@@ -283,7 +283,8 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
  *   fp32 = jac_scale * the tangent rows.  Needs L*C == 32. */
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t /* NULL = skip */, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale,
-                     int64_t M, void *stream);
+                     int64_t M, float *gb2 /* [g_pitch] fp32 (+=): column sums of g's value rows = last layer's bias gradient, or NULL */,
+                     void *stream);
 
 /* Consumers of hs_trunk_mlp_fwd's Y [4*B, K] and producers of its cotangent (K <= 64).  idx [B] = argmin_k of the value row
  * (lowest index among equals).  Points b < n_main are rendered samples: sdf_raw [n_main,K] = value rows, sdf [n_main] = min_k,
@@ -316,7 +317,7 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
  * (rows j < 27 = column 54+j of W_R0: the encoded-normal inputs), Wc1t [256,256], Wc0t [32,256].
  * Outputs: gy [B,32] bf16 (cotangent of the pre-sigmoid outputs, columns 0..2), gA_r1, gA_r0, g_fv, gA_hc [B,256] bf16
  * (pre-activation cotangents; g_fv = cotangent of the feature vector), d_normals [B,3], g_featc [16,B,2] fp32 (level-major),
- * gbias [4,256] fp32 (+=; rows: br1, br0, bc1, bc0; may be NULL). */
+ * gbias [5,256] fp32 (+=; rows: br1, br0, bc1, bc0, br2 (3 values); may be NULL). */
 int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
                       const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
                       void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, void *stream);

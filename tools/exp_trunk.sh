@@ -20,7 +20,7 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 def fwd():
     lib.hs_trunk_mlp_fwd(p(X), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, p(H0), p(H1), p(Y), ctypes.c_int64(M), None, None, None, None, 0, 0, ctypes.c_float(0.0), None)
 def bwd():
-    lib.hs_trunk_mlp_bwd(p(g), 32, p(H1), p(H0), p(w2t), p(w1t), p(gA1), p(gA0), p(gb1), p(gb0), p(w0t), p(gfe), p(gdy), 16, 2, ctypes.c_float(0.5), ctypes.c_int64(M), None)
+    lib.hs_trunk_mlp_bwd(p(g), 32, p(H1), p(H0), p(w2t), p(w1t), p(gA1), p(gA0), p(gb1), p(gb0), p(w0t), p(gfe), p(gdy), 16, 2, ctypes.c_float(0.5), ctypes.c_int64(M), None, None)
 def t(fn):
     for _ in range(3): fn()
     torch.cuda.synchronize()
