@@ -271,7 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
         gbeta += gsig * ls.db;
     }
     const float gb = block_sum<BLOCK>(act ? gbeta : 0.f, scratch);
-    if (i == 0 && d_beta) unsafeAtomicAdd(d_beta, gb);
+    if (i == 0 && d_beta) d_beta[r] = gb;   // per-ray partial; the caller sums
 }
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     }
     if (lane == 0) {
         beta_io[r] = hi;
-        atomic_max_float(beta_max, hi);
+        // only rays still above beta0 can make the round's test (max beta > beta0, ray_sampler.py:204) true; the others skip the
+        // same-address atomic (1 024 of them per launch serialise in the L2)
+        if (hi > beta0) atomic_max_float(beta_max, hi);
     }
 }
 

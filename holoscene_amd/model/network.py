@@ -516,10 +516,10 @@ class _composite(torch.autograd.Function):
         d_raw = torch.empty_like(raw)
         d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[3] else None
         d_g = torch.empty_like(g) if ctx.needs_input_grad[4] else None
-        d_beta = torch.zeros(1, device=z.device) if ctx.needs_input_grad[5] else None
+        d_beta = torch.empty(z.shape[0], device=z.device) if ctx.needs_input_grad[5] else None   # per-ray partials
         _be._backend.composite_bwd(z, sdf, raw, rgb, g, beta1, depth_scale, ctx.sem_scale, c(g_w), c(g_rgb), c(g_depth), c(g_normal), c(g_sem),
                                    c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta)
-        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.reshape(ctx.beta_shape)), None, None
+        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None
 
 
 def default_mlp_precision():

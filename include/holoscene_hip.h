@@ -144,7 +144,8 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
  *   z/sdf [R, ld]: in = sorted sample set of m_old entries per ray, out = merged set of m_old+s_new
  *   (samples/new_sdf [R, s_new] ascending per ray); beta [R]: in = current upper bound, out = the
  *   smallest beta within eps found by `beta_iters` bisection steps from *beta0 (device scalar);
- *   *beta_max = max(*beta_max, beta_r) via atomics (zero it before the call). */
+ *   *beta_max = max(*beta_max, beta_r over the rays with beta_r > *beta0) via atomics (zero it before the call): it exceeds *beta0
+ *   exactly when some ray is unconverged, which is all Algorithm 1 asks of it. */
 int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
                       float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate /* NULL = none */,
                       const int32_t *m_dev /* NULL, or device count overriding m_old (hsSamplerCtl.m) */, void *stream);
@@ -239,7 +240,8 @@ int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, in
  * forward writes weights [R,N], transmittance [R,N] (may be NULL), rgb_out [R,3], depth_out [R] (already multiplied by
  * depth_scale), normal_out [R,3] (world frame, un-rotated), sem_out [R,K], opac_out [R,K].  N <= 256, N*(8+2K) floats <= 64 KB.
  * backward takes the cotangents of those outputs (any may be NULL = zero) and writes d_sdf [R*N], d_raw [R*N,K],
- * d_rgb [R*N,3] (may be NULL), d_g [R*N,3] (may be NULL), and ACCUMULATES d_beta (device scalar, may be NULL). */
+ * d_rgb [R*N,3] (may be NULL), d_g [R*N,3] (may be NULL), and d_beta [R] (may be NULL): PER-RAY partial derivatives w.r.t. beta,
+ * to be summed by the caller (one same-address atomic per ray serialised in the L2). */
 int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
                      const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, float *weights, float *transmittance,
                      float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, void *stream);
