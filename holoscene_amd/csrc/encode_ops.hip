@@ -210,24 +210,43 @@ __global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict
                                                           const float *__restrict__ g_grad, const float *__restrict__ g_yeik,
                                                           const float *__restrict__ g_mineik, const float *__restrict__ g_theta, int64_t B,
                                                           int64_t n_main, int K, int KP, __hip_bfloat16 *__restrict__ g) {
-    const int64_t total = B * 4 * KP, Be = B - n_main;
+    // one thread = 8 consecutive columns of one row (one 16-byte store); KP is a multiple of 32
+    const int groups = KP >> 3;
+    const int64_t total = B * 4 * groups, Be = B - n_main;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i % KP);
-        const int64_t row = i / KP, b = row >> 2;
+        const int k0 = (int)(i % groups) * 8;
+        const int64_t row = i / groups, b = row >> 2;
         const int r = (int)(row & 3);
-        float v = 0.f;
-        if (k < K) {
-            const bool hit = k == (int)idx[b];
-            if (b < n_main) {
-                if (r == 0) v = (g_raw ? g_raw[b * K + k] : 0.f) + (hit && g_sdf ? g_sdf[b] : 0.f);
-                else if (hit && g_grad) v = g_grad[b * 3 + (r - 1)];
-            } else {
-                const int64_t e = b - n_main;
-                if (r == 0) v = (g_yeik ? g_yeik[e * K + k] : 0.f) + (hit && g_mineik ? g_mineik[e] : 0.f);
-                else if (g_theta) v = g_theta[((int64_t)k * Be + e) * 3 + (r - 1)] + (hit ? g_theta[((int64_t)K * Be + e) * 3 + (r - 1)] : 0.f);
+        const int hit_k = (int)idx[b];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j;
+            float x = 0.f;
+            if (k < K) {
+                const bool hit = k == hit_k;
+                if (b < n_main) {
+                    if (r == 0) x = (g_raw ? g_raw[b * K + k] : 0.f) + (hit && g_sdf ? g_sdf[b] : 0.f);
+                    else if (hit && g_grad) x = g_grad[b * 3 + (r - 1)];
+                } else {
+                    const int64_t e = b - n_main;
+                    if (r == 0) x = (g_yeik ? g_yeik[e * K + k] : 0.f) + (hit && g_mineik ? g_mineik[e] : 0.f);
+                    else if (g_theta) x = g_theta[((int64_t)k * Be + e) * 3 + (r - 1)] + (hit ? g_theta[((int64_t)K * Be + e) * 3 + (r - 1)] : 0.f);
+                }
             }
+            v[j] = x;
         }
-        g[i] = __float2bfloat16(v);
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        uint4 out;
+        uint32_t *o = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f2 p = {v[2 * j], v[2 * j + 1]};
+            const bf2 q = __builtin_convertvector(p, bf2);
+            o[j] = *reinterpret_cast<const uint32_t *>(&q);
+        }
+        *reinterpret_cast<uint4 *>(g + row * KP + k0) = out;
     }
 }
 
@@ -346,7 +365,8 @@ int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t
     if (K < 1 || K > KP || n_main < 0 || n_main > B) return HS_ERR_ARG;
     if (B == 0) return HS_OK;
     if (!g || !idx) return HS_ERR_NULL;
-    k_trunk_split_bwd<<<grid_for(B * 4 * KP), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_min_eik, g_grad_theta, B, n_main, K, KP,
+    if (KP & 31) return HS_ERR_ARG;
+    k_trunk_split_bwd<<<grid_for(B * 4 * (KP / 8)), 256, 0, (hipStream_t)stream>>>(g_sdf_raw, g_sdf, idx, g_grad, g_y_eik, g_min_eik, g_grad_theta, B, n_main, K, KP,
                                                                              (__hip_bfloat16 *)g);
     return check_launch();
 }
