@@ -170,6 +170,43 @@ def test_full_size_properties():
     assert abs((enc.embeddings.double() * g2.double()).sum() - (gx.double() * v.double()).sum()) <= 1e-4 * abs((gx.double() * v.double()).sum())
 
 
+def test_full_size_binned_scatter_properties():
+    """Binned scatter at BASELINE config-2 size (stock grid, 100 352 ray-ordered points + level-major cotangents): the adjoint
+    identity <enc(x), g> == <E, dE> that ties it to the forward kernel, equality with the atomic path, and accumulation on top
+    of existing content -- size-independent properties, no oracle involved."""
+    from holoscene_amd.hashencoder import HashEncoder
+    torch.manual_seed(1)
+    enc = HashEncoder(desired_resolution=2048).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    be = _be()
+    R, N = 1024, 98
+    o = torch.rand(R, 1, 3, device="cuda") * 0.2 + 0.4
+    d = torch.nn.functional.normalize(torch.randn(R, 1, 3, device="cuda"), dim=-1)
+    z = torch.sort(torch.rand(R, N, 1, device="cuda") ** 3 * 0.5, 1)[0]        # crowded near the origin of each ray, like real samples
+    x = (o + z * d).reshape(-1, 3).clamp(0, 1).contiguous()
+    B, L, C = x.shape[0], 16, 2
+    S, H = float(np.log2(enc.per_level_scale)), int(enc.base_resolution)
+    feat = torch.empty(L, B, C, device="cuda")
+    be.fwd(x, enc.embeddings, enc.offsets, feat, B, 3, C, L, S, H, None, level_major=True)
+    g = torch.randn(L, B, C, device="cuda")
+    g[:, ::5] = 0
+    ws = be.scatter_workspace(B, 3, C, L, "cuda")
+    prior = torch.randn_like(enc.embeddings)
+    ge = prior.clone()
+    be.bwd(g, x, enc.offsets, ge, B, 3, C, L, S, H, None, None, ws=ws, level_major=True)
+    ge_atomic = prior.clone()
+    be.bwd(g, x, enc.offsets, ge_atomic, B, 3, C, L, S, H, None, None, level_major=True)
+    dE = (ge - prior).double()
+    lhs = (feat.double() * g.double()).sum()
+    rhs = (enc.embeddings.double() * dE).sum()
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+    assert (ge - ge_atomic).abs().max() <= 2e-6 * np.sqrt(B) * float(dE.abs().max())
+    counts = ws[0][:32 * 128 * 4].view(torch.int32).view(32, 128)[:L]
+    assert int(counts[:5].sum()) == 0 and int(counts[5:].sum()) > 0          # dense levels 0-4 stay on the atomic path
+    assert int(counts.sum()) < 0.8 * 11 * B * 8                               # the wave merge removed records of crowded samples
+
+
 def test_scatter_with_ray_ordered_points_vs_oracle():
     """Consecutive lanes in the same cell exercise the wave-merged scatter (runs of every length,
     runs crossing wave boundaries, OOB lanes splitting runs, a ragged last block)."""
