@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_pack_bf16(PackJobs jobs) {
         const int r = i / jb.dst_cols, c = i - r * jb.dst_cols;
         float v = 0.f;
         if (r < jb.rows && c < jb.cols)
-            v = jb.transpose ? jb.src[(size_t)(jb.row0 + c) * jb.ld + jb.col0 + r] : jb.src[(size_t)(jb.row0 + r) * jb.ld + jb.col0 + c];
+            v = jb.scale * (jb.transpose ? jb.src[(size_t)(jb.row0 + c) * jb.ld + jb.col0 + r] : jb.src[(size_t)(jb.row0 + r) * jb.ld + jb.col0 + c]);
         dst[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
     }
 }

@@ -36,18 +36,20 @@ namespace {
 constexpr int NPE = 39;           // 3 + 6*6 positional-encoding values
 constexpr int NFEAT = 32;
 
-__device__ __forceinline__ float softplus100(float v) {  // branch-free Softplus(beta=100, threshold=20)
+// Softplus(beta=100) in the SCALED domain the inference kernel works in.  With t = 100*log2(e) * v:
+//   softplus100(v) = ln2/100 * log2(1 + 2^t)
+// The factor 100*log2(e) is folded into W0 and the biases (W1 then needs none: its input carries 100/ln2, its output wants
+// 100*log2(e), and the two cancel), ln2/100 into W2 -- all at weight-packing time -- so an element costs
+// bias-add, v_exp_f32, add, v_log_f32 and one select instead of also three multiplies and a min.  Above t = 30 log2(1 + 2^t) == t in fp32
+// (PyTorch's linear branch starts at 100 v = 20, i.e. t = 28.9, where the two differ by 3e-9 relative).
+constexpr float kActScale = 100.f * 1.44269504f;    // applied to W0, b0, b1 (hs_sdf_mlp_fwd scales the biases itself)
+__device__ __forceinline__ float softplus_scaled(float t) {
 #ifdef HS_EXP_NO_EPILOGUE
-    return v;
+    return t;
 #endif
-    // raw v_exp_f32 / v_log_f32 (base 2): the log argument is in [1, 1+e^20], so the denormal-scaling wrapper that
-    // __logf carries (cmp + cndmask + ldexp per value) is dead weight here
-    const float t = v * 100.f;
-    const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f) * 1.44269504f);
-    const float sp = __builtin_amdgcn_logf(1.f + e) * (0.69314718f * 0.01f);
-    return t > 20.f ? v : sp;
+    const float l = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(fminf(t, 64.f)));
+    return t > 30.f ? t : l;
 }
-
 
 // bias + softplus + bf16 pack, written back into the activation tile (all waves have passed the barrier that ends layer_mma)
 __device__ __forceinline__ void epilogue_softplus(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
@@ -60,8 +62,8 @@ __device__ __forceinline__ void epilogue_softplus(const float *bias_lds, uint16_
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
                 const int p = ph * 64 + pt * 32 + (lane & 31);
-                const float v0 = softplus100(acc[nt][pt][q * 4 + 0] + bi.x), v1 = softplus100(acc[nt][pt][q * 4 + 1] + bi.y);
-                const float v2 = softplus100(acc[nt][pt][q * 4 + 2] + bi.z), v3 = softplus100(acc[nt][pt][q * 4 + 3] + bi.w);
+                const float v0 = softplus_scaled(acc[nt][pt][q * 4 + 0] + bi.x), v1 = softplus_scaled(acc[nt][pt][q * 4 + 1] + bi.y);
+                const float v2 = softplus_scaled(acc[nt][pt][q * 4 + 2] + bi.z), v3 = softplus_scaled(acc[nt][pt][q * 4 + 3] + bi.w);
                 uint2 pk;
                 pk.x = pack_bf16(v0, v1);
                 pk.y = pack_bf16(v2, v3);
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
     float *bias = reinterpret_cast<float *>(Wc + 2 * (size_t)HID * WP);   // b0[256] b1[256] b2[64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = wave & 3, ph = wave >> 2;
-    if (threadIdx.x < HID) { bias[threadIdx.x] = b0[threadIdx.x]; bias[HID + threadIdx.x] = b1[threadIdx.x]; }
+    if (threadIdx.x < HID) { bias[threadIdx.x] = b0[threadIdx.x] * kActScale; bias[HID + threadIdx.x] = b1[threadIdx.x] * kActScale; }   // scaled domain
     if (threadIdx.x < 64) bias[2 * HID + threadIdx.x] = (int)threadIdx.x < d_out ? b2[threadIdx.x] : 0.f;
     const int64_t ntiles = (B + BM - 1) / BM;
     // this thread's share of a tile's inputs (4 threads per point: coordinates + 8 of the 32 features), fetched one tile ahead so

@@ -34,7 +34,7 @@ class hsHashLayout(ctypes.Structure):
 class hsPackJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ld", ctypes.c_int32), ("row0", ctypes.c_int32), ("col0", ctypes.c_int32),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("dst_rows", ctypes.c_int32), ("dst_cols", ctypes.c_int32),
-                ("transpose", ctypes.c_int32)]
+                ("transpose", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
 class hsSumJob(ctypes.Structure):
@@ -348,11 +348,13 @@ class _HipBackend:
 
     @staticmethod
     def pack_bf16(jobs):
-        """jobs: list of (src fp32 2-D tensor, dst bf16 2-D tensor, row0, col0, rows, cols, transpose); rows/cols = valid extent
-        in destination orientation, the rest of dst is zero-filled."""
+        """jobs: list of (src fp32 2-D tensor, dst bf16 2-D tensor, row0, col0, rows, cols, transpose[, scale]); rows/cols = valid
+        extent in destination orientation, the rest of dst is zero-filled."""
         lib = load_library()
         arr = (hsPackJob * len(jobs))()
-        for a, (src, dst, row0, col0, rows, cols, tr) in zip(arr, jobs):
+        for a, job in zip(arr, jobs):
+            src, dst, row0, col0, rows, cols, tr = job[:7]
+            a.scale = float(job[7]) if len(job) > 7 else 1.0
             a.src, a.dst = _dev(src, "src").value, _dev(dst, "dst", torch.bfloat16).value
             a.ld, a.row0, a.col0, a.rows, a.cols = src.shape[1], row0, col0, rows, cols
             a.dst_rows, a.dst_cols, a.transpose = dst.shape[0], dst.shape[1], int(tr)

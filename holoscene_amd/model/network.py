@@ -750,8 +750,11 @@ class ObjectImplicitNetworkGrid(nn.Module):
         w0, w1, w2 = torch.empty(256, 96, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf), torch.empty(n2, 256, device=dev, dtype=bf)
         with torch.no_grad():
             f0, f1, f2 = effective_weights([l0, l1, l2])
-        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False), (f1, w1, 0, 0, 256, 256, False),
-                                (f2, w2, 0, 0, l2.out_features, 256, False)])
+        # k_sdf_mlp works in the scaled activation domain t = 100*log2(e)*v (csrc/sdf_mlp.hip, softplus_scaled): the factor goes into
+        # W0 (the kernel scales the biases), its inverse ln2/100 into W2; W1 needs none
+        act = 100.0 * 1.4426950408889634
+        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False, act), (f1, w1, 0, 0, 256, 256, False),
+                                (f2, w2, 0, 0, l2.out_features, 256, False, 1.0 / act)])
         self._packed_cache = (w0, l0.bias.detach().float().contiguous(), w1, l1.bias.detach().float().contiguous(), w2,
                               l2.bias.detach().float().contiguous())
         return self._packed_cache

@@ -255,7 +255,9 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
  * SDF branch of ObjectImplicitNetworkGrid.forward (model/network.py:169-210) for no-grad queries (the sampler's
  * sweeps, get_sdf_vals / get_object_sdf_vals :305-318), bf16 operands / fp32 accumulation:
  *   x [B,3] f32, feat [B,32] f32 (hash features) -> posenc(6) ++ feat (71, zero-padded to 96) -> 256 -> 256 -> d_out.
- *   W0 [256,96] bf16 (columns >= 71 zero), W1 [256,256] bf16, W2 [32*ceil(d_out/32), 256] bf16 (rows >= d_out zero),
+ *   W0 [256,96] bf16 (columns >= 71 zero) PRE-MULTIPLIED by 100*log2(e), W1 [256,256] bf16 as is, W2 [32*ceil(d_out/32), 256]
+ *   bf16 (rows >= d_out zero) PRE-MULTIPLIED by ln2/100 -- the kernel evaluates Softplus(beta=100) as log2(1 + 2^t) on
+ *   t = 100*log2(e)*v (hs_pack_bf16's per-job `scale` does this); the biases are passed unscaled,
  *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
  *   out_min [B] = min_k y_k (select < 0) or y_select; out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
@@ -335,6 +337,7 @@ typedef struct hsPackJob {
     int32_t rows, cols;         /* valid extent, in destination orientation */
     int32_t dst_rows, dst_cols;
     int32_t transpose;
+    float scale;                /* every element is multiplied by this before the bf16 rounding */
 } hsPackJob;
 int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream);
 
