@@ -784,3 +784,28 @@ def test_sampler_between_supplied_bounds(idx, per_ray, monkeypatch):
     assert res["hip"][2] == res["torch"][2]
     z_close(z, res["torch"][0], frac_loose=0.05)
     assert torch.equal(z_eik, torch.gather(z, 1, rng["eik_idx"][:, None]))
+
+
+def test_eval_mode_forward_through_fused_paths():
+    """model.eval(): no Eikonal set (the split kernel sees n_main == B), linspace draws in the sampler, no ray jitter -- bf16 fused
+    path vs fp32 path on the same parameters."""
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        tr = Stage1Trainer(stock_conf(num_rays=256, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=0.05, mlp_precision=prec),
+                           device=DEV, optimizer="torch")
+        benchmark_model_state(tr.model, 0.05)
+        scene = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, ring=4, device=DEV)
+        _, mi, _ = scene.next_batch()
+        tr.model.eval()
+        with torch.no_grad():
+            outs[prec] = tr.model(mi, torch.tensor([0]), iter_step=3)
+    a, b = outs["fp32"], outs["bf16"]
+    assert "grad_theta" not in b and b["rgb_values"].shape == (256, 3)
+    z = b["z_vals"]
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    # (the two runs place their samples from SDF queries of different precision, so single rays can differ visibly; the means may not)
+    for k, tol in (("rgb_values", 2e-2), ("depth_values", 5e-2), ("normal_map", 5e-2)):
+        d = (a[k] - b[k]).abs()
+        assert float(d.mean()) < 0.2 * tol and float(d.max()) < 5 * tol, (k, float(d.mean()), float(d.max()))
