@@ -30,6 +30,27 @@ __device__ __forceinline__ float lap_sigma(float s, float beta) {
     return (1.f / beta) * (0.5f + 0.5f * sgn * expm1f(-fabsf(s) / beta));
 }
 
+// Hardware-exponential variants for the per-object loops (K = 32 objects per sample: 3 libm calls each made the kernels
+// ALU-bound).  v_exp_f32 is 1-2 ulp; expm1 near zero comes from its series so that small |s|/beta keep their relative accuracy.
+__device__ __forceinline__ float fast_expm1(float x) { return x > -1e-3f ? x + 0.5f * x * x : __expf(x) - 1.f; }   // x <= 0
+
+__device__ __forceinline__ float lap_sigma_fast(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.f / beta) * (0.5f + 0.5f * sgn * fast_expm1(-fabsf(s) / beta));
+}
+
+__device__ __forceinline__ Lap lap_full_fast(float s, float beta) {
+    const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    const float a = fabsf(s), ib = 1.f / beta;
+    const float em1 = fast_expm1(-a * ib), e = em1 + 1.f;
+    const float psi = 0.5f + 0.5f * sgn * em1;
+    Lap r;
+    r.sigma = ib * psi;
+    r.ds = -0.5f * sgn * sgn * e * ib * ib;
+    r.db = -psi * ib * ib + ib * (0.5f * sgn * e * a * ib * ib);
+    return r;
+}
+
 __device__ __forceinline__ Lap lap_full(float s, float beta) {
     const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
     const float a = fabsf(s), ib = 1.f / beta;
@@ -163,8 +184,8 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
         const float *rw = raw + p * K;
         for (int k = 0; k < K; k++) {
             const float s = rw[k];
-            c[8 + k] = w * sem_scale / (1.f + expf(sem_scale * s));           // s*sigmoid(-s*raw)
-            c[8 + K + k] = (1.f - expf(-d * lap_sigma(s, beta))) * T;
+            c[8 + k] = w * sem_scale / (1.f + __expf(sem_scale * s));           // s*sigmoid(-s*raw)
+            c[8 + K + k] = (1.f - __expf(-d * lap_sigma_fast(s, beta))) * T;
         }
     }
     __syncthreads();
@@ -249,11 +270,11 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
         float *dr = d_raw + p * K;
         for (int k = 0; k < K; k++) {
             const float s = rw[k];
-            const float ex = expf(sem_scale * s);
+            const float ex = __expf(sem_scale * s);
             const float sem = sem_scale / (1.f + ex);
             gw += gs[k] * sem;
-            const Lap lk = lap_full(s, beta);
-            const float ek = expf(-d * lk.sigma);
+            const Lap lk = lap_full_fast(s, beta);
+            const float ek = __expf(-d * lk.sigma);
             gT_obj += go[k] * (1.f - ek);
             const float gsig = go[k] * T * d * ek;                    // dL/dsigma_ik
             // d sem/d raw = -s^2 * sigmoid(-s raw) * (1 - sigmoid(-s raw)) = -sem * s*ex/(1+ex)
