@@ -57,7 +57,8 @@ __global__ __launch_bounds__(kThreads) void k_trunk_input_fwd(const float *__res
             const int k = (c - 3) / 6, r = (c - 3) - 6 * k, d = r % 3;
             const float f = (float)(1 << k), a = x[b * 3 + d] * f;
             float sn, cs;
-            sincosf(a, &sn, &cs);
+            if (sizeof(T) == 2) __sincosf(a, &sn, &cs);   // bf16 destination: the hardware v_sin/v_cos units are exact to more bits than it keeps
+            else sincosf(a, &sn, &cs);
             if (r < 3) { v0 = sn; t[d] = f * cs; }
             else { v0 = cs; t[d] = -f * sn; }
         } else {
