@@ -255,12 +255,39 @@ __global__ void k_sampler_pick(const hsSamplerCtl *__restrict__ ctl, const float
 
 // ------------------------------------------------------------------------------------ draw
 // mode 0: pdf ~ error-bound opacity (+tiny); mode 1: pdf ~ rendering weights (+1e-5).  u: explicit [R,n_out] or NULL = linspace(0,1,n_out)
+// Optional fused duties of a draw launch in the device-controlled loop (hs_sampler_draw_step):
+//  * the loop-control step that used to be its own 1-thread launch: every workgroup derives the post-round state from ctl_in
+//    (read-only here) + the round's beta_max, workgroup 0 publishes it to ctl_out (a different slot: no intra-launch race);
+//  * the positions of the drawn depths (k_ray_points' arithmetic, same roundings) for the next SDF sweep.
+struct DrawExt {
+    const hsSamplerCtl *ctl_in;
+    hsSamplerCtl *ctl_out;
+    const float *beta_max, *beta0;
+    int s_new, max_rounds;
+    const float *o, *d;
+    float *x, *x01;
+    float divide_factor;
+};
+
 __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
                                                          const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
-                                                         int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev) {
+                                                         int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev,
+                                                         DrawExt ext) {
     extern __shared__ float lds[];
-    if (gate_closed(gate)) return;
-    if (m_dev) m = *m_dev;
+    if (ext.ctl_in) {
+        hsSamplerCtl c = *ext.ctl_in;
+        if (c.running > c.half) {   // k_sampler_step
+            c.m += ext.s_new;
+            c.rounds += 1;
+            if (!(*ext.beta_max > *ext.beta0) || c.rounds >= ext.max_rounds) c.running = 0.f;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ext.ctl_out = c;
+        if (mode == 0 && !(c.running > c.half)) return;
+        m = c.m;
+    } else {
+        if (gate_closed(gate)) return;
+        if (m_dev) m = *m_dev;
+    }
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
@@ -332,7 +359,18 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
         const float c0 = cdf[below], c1 = cdf[above], b0 = z[below], b1 = z[above];
         float den = c1 - c0;
         if (den < 1e-5f) den = 1.f;
-        out[(size_t)r * n_out + j] = b0 + (u - c0) / den * (b1 - b0);
+        const float zj = b0 + (u - c0) / den * (b1 - b0);
+        out[(size_t)r * n_out + j] = zj;
+        if (ext.x) {
+            const float inv_df = __fdiv_rn(1.0f, ext.divide_factor);
+            const size_t p = ((size_t)r * n_out + j) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v = __fadd_rn(ext.o[r * 3 + c], __fmul_rn(zj, ext.d[r * 3 + c]));
+                ext.x[p + c] = v;
+                ext.x01[p + c] = __fmul_rn(__fadd_rn(__fmul_rn(v, inv_df), 1.0f), 0.5f);
+            }
+        }
     }
 }
 
@@ -371,7 +409,8 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
                                                       const float *__restrict__ intr, const float *__restrict__ t_rand, int S, float near,
                                                       float far_cap, float bound, float eps, float *__restrict__ ray_dirs,
                                                       float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
-                                                      float *__restrict__ beta_init, int R) {
+                                                      float *__restrict__ beta_init, int R, float divide_factor, float *__restrict__ x,
+                                                      float *__restrict__ x01) {
     extern __shared__ float lds[];  // [S] stratified depths of this ray
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
@@ -426,6 +465,16 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
         }
         lds[i] = val;
         z0[(size_t)r * S + i] = val;
+        if (x) {   // positions of the first sweep (k_ray_points' arithmetic, same roundings)
+            const float inv_df = __fdiv_rn(1.0f, divide_factor);
+            const size_t p = ((size_t)r * S + i) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v = __fadd_rn(o[c], __fmul_rn(val, d[c]));
+                x[p + c] = v;
+                x01[p + c] = __fmul_rn(__fadd_rn(__fmul_rn(v, inv_df), 1.0f), 0.5f);
+            }
+        }
     }
     __syncthreads();
     float acc = 0.f;
@@ -458,7 +507,22 @@ int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, con
     if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
     if (m_dev) m = ld;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev);
+    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev, DrawExt{});
+    return check_launch();
+}
+
+int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const float *beta, int32_t mode, float add_tiny, const float *u, int32_t n_out,
+                         float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0,
+                         int32_t s_new, int32_t max_rounds, const float *cam_loc, const float *ray_dirs, float divide_factor, float *x, float *x01,
+                         void *stream) {
+    if (R <= 0 || n_out <= 0) return HS_OK;
+    if (!z || !sdf || !beta || !out || !ctl_in || !ctl_out || !beta_max || !beta0) return HS_ERR_NULL;
+    if (ctl_in == ctl_out) return HS_ERR_ARG;
+    if (x && (!x01 || !cam_loc || !ray_dirs || divide_factor == 0.f)) return HS_ERR_NULL;
+    if (ld < 2 || ld > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
+    const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, cam_loc, ray_dirs, x, x01, divide_factor};
+    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * ld * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R,
+                                                                                          hsGate{nullptr, nullptr}, nullptr, ext);
     return check_launch();
 }
 
@@ -488,12 +552,13 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 void *stream) {
+                 float divide_factor, float *x, float *x01, void *stream) {
     if (R <= 0) return HS_OK;
     if (S < 2 || S > 4096) return HS_ERR_ARG;
     if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
+    if (x && (!x01 || divide_factor == 0.f)) return HS_ERR_ARG;
     k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
-                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R);
+                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01);
     return check_launch();
 }
 

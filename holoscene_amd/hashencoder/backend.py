@@ -46,7 +46,7 @@ class hsWnJob(ctypes.Structure):
                 ("gg", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _gate(gate):
@@ -82,7 +82,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
 
 
 def _check(rc, what):
@@ -254,6 +254,17 @@ class _HipBackend:
                                    _stream()), "hs_sampler_draw")
 
     @staticmethod
+    def sampler_draw_step(z, sdf, beta, mode, add_tiny, u, n_out, out, ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds,
+                          cam_loc=None, ray_dirs=None, divide_factor=1.0, x=None, x01=None):
+        """ctl_in / ctl_out: two different float32[4] hsSamplerCtl slots (see sampler_step)."""
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_draw_step(_dev(z, "z"), _dev(sdf, "sdf"), ld, _dev(beta, "beta"), mode, ctypes.c_float(add_tiny), _dev(u, "u"), n_out,
+                                        _dev(out, "out"), R, _dev(ctl_in, "ctl_in"), _dev(ctl_out, "ctl_out"), _dev(beta_max, "beta_max"),
+                                        _dev(beta0, "beta0"), s_new, max_rounds, _dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"),
+                                        ctypes.c_float(divide_factor), _dev(x, "x"), _dev(x01, "x01"), _stream()), "hs_sampler_draw_step")
+
+    @staticmethod
     def sampler_step(ctl, beta_max, beta0, s_new, max_rounds):
         """ctl: float32[4] device tensor holding an hsSamplerCtl {running, half, m (int32 bits), rounds (int32 bits)}."""
         lib = load_library()
@@ -275,12 +286,14 @@ class _HipBackend:
                                     _dev(z_eik, "z_eik"), R, _dev(near_rays, "near_rays"), _dev(far_rays, "far_rays"), _stream()), "hs_sampler_final")
 
     @staticmethod
-    def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init):
+    def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init,
+                  divide_factor=1.0, x=None, x01=None):
         lib = load_library()
         _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
                                 _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
                                 ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
-                                _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], _stream()), "hs_ray_setup")
+                                _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], ctypes.c_float(divide_factor), _dev(x, "x"),
+                                _dev(x01, "x01"), _stream()), "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
     @staticmethod

@@ -790,8 +790,14 @@ class ObjectImplicitNetworkGrid(nn.Module):
         dev = z.device
         x = torch.empty(R * S, 3, device=dev)
         x01 = torch.empty(R * S, 3, device=dev)
+        _be._backend.ray_points(cam_loc.contiguous(), ray_dirs.contiguous(), z.contiguous(), x, x01, float(self.divide_factor), gate=gate)
+        return self.sdf_at_points(x, x01, R, S, select, gate=gate)
+
+    def sdf_at_points(self, x, x01, R, S, select=-1, gate=None):
+        """sdf_along_rays after its positions launch: x [R*S,3] world positions, x01 their hash-grid coordinates (as hs_ray_points,
+        hs_ray_setup or hs_sampler_draw_step wrote them) -> [R,S]."""
+        dev = x.device
         be = _be._backend
-        be.ray_points(cam_loc.contiguous(), ray_dirs.contiguous(), z.contiguous(), x, x01, float(self.divide_factor), gate=gate)
         enc = self.encoding
         L, C = enc.num_levels, enc.level_dim
         # level-major features [L, R*S, C]: the gather kernel's stores become fully coalesced (point-major 8-byte pieces at a
@@ -1078,17 +1084,18 @@ class HoloSceneNetwork(nn.Module):
             t_rand = torch.rand(R, S, device=dev)
         out = {"ray_dirs": torch.empty(R, 3, device=dev), "cam_loc": torch.empty(R, 3, device=dev), "depth_scale": torch.empty(R, 1, device=dev),
                "z0": torch.empty(R, S, device=dev), "beta_init": torch.empty(R, device=dev),
+               "x0": torch.empty(R * S, 3, device=dev), "x0_grid": torch.empty(R * S, 3, device=dev),   # positions of z0: the sampler's first sweep
                "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
         _be._backend.ray_setup(uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
                                pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
                                None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
                                float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
-                               out["depth_scale"], out["z0"], out["beta_init"])
+                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"])
         return out
 
     def sample(self, rays, rng=None, idx=None):
         return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng, z0=rays.get("z0"),
-                                           beta_init=rays.get("beta_init"))
+                                           beta_init=rays.get("beta_init"), x0=(rays["x0"], rays["x0_grid"]) if "x0" in rays else None)
 
     def wants_background(self, iter_step):
         return bool(self.use_bg_reg and iter_step % self.render_bg_iter == 0)
@@ -1116,8 +1123,9 @@ class HoloSceneNetwork(nn.Module):
             bg = {"ray_dirs": ray_dirs0.reshape(-1, 3).contiguous(),
                   "cam_loc": cam_loc0.unsqueeze(1).repeat(1, n0, 1).reshape(-1, 3).contiguous(),
                   "depth_scale": tmp0[0, :, 2:].contiguous()}
+        x0 = (bg.pop("x0"), bg.pop("x0_grid")) if "x0" in bg else None
         bg["z_vals"], _ = self.ray_sampler.get_z_vals(bg["ray_dirs"], bg["cam_loc"], self, idx=0, rng=rng.get("bg"), z0=bg.pop("z0", None),
-                                                      beta_init=bg.pop("beta_init", None))
+                                                      beta_init=bg.pop("beta_init", None), x0=x0)
         bg.pop("rot", None)
         return bg
 

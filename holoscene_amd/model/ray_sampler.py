@@ -181,12 +181,12 @@ class ErrorBoundSampler(RaySampler):
         return net.get_multi_object_sdf_vals(points, idx)
 
     @torch.no_grad()
-    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None, z0=None, beta_init=None):
-        """z0 / beta_init: optionally the first uniform depths and Lemma-2 beta already produced by the fused ray-setup
-        kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference."""
+    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None, z0=None, beta_init=None, x0=None):
+        """z0 / beta_init (/ x0 = positions (x, x01) of z0): optionally the first uniform depths and Lemma-2 beta already produced
+        by the fused ray-setup kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference."""
         if SAMPLER_IMPL == "hip":
             if ray_dirs.is_cuda and self.device_control_ok(model, idx):
-                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
+                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init, x0)
             return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
         if SAMPLER_IMPL != "torch":
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
@@ -331,7 +331,7 @@ class ErrorBoundSampler(RaySampler):
         return z_out, z_eik
 
 
-    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None):
+    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, x0=None):
         """Algorithm 1 with device-side loop control: max_total_iters unrolled rounds of gated kernels, zero host syncs."""
         be = _be._backend
         dev = ray_dirs.device
@@ -347,32 +347,45 @@ class ErrorBoundSampler(RaySampler):
             beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
         else:
             beta = beta_init.clone()
-        if self._ctl_init is None or self._ctl_init.device != dev:
-            self._ctl_init = torch.tensor([1.0, 0.5, 0.0, 0.0], device=dev)     # hsSamplerCtl {running, half, m = 0, rounds = 0}
+        nr = self.max_total_iters
+        if self._ctl_init is None or self._ctl_init.device != dev or self._ctl_init.shape[0] != nr + 1:
+            init = torch.zeros(nr + 1, 4)
+            init[0] = torch.tensor([1.0, 0.5, 0.0, 0.0])     # hsSamplerCtl {running, half, m = 0, rounds = 0}; slot r+1 = state after round r
+            self._ctl_init = init.to(dev)
         ctl = self._ctl_init.clone()
         ci = ctl.view(torch.int32)
-        m_dev, gate = ci[2:3], (ctl[0:1], ctl[1:2])
         z = torch.empty(R, ld, device=dev)
         sdf = torch.empty(R, ld, device=dev)
-        beta_max_all = torch.zeros(self.max_total_iters, device=dev)
+        beta_max_all = torch.zeros(nr, device=dev)
         cam = (cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc).contiguous()
         dirs = ray_dirs.contiguous()
         sel = -1 if idx is None else idx
         samples = z0.contiguous()
-        for r in range(self.max_total_iters):
-            new_sdf = net.sdf_along_rays(cam, dirs, samples, sel, gate=gate)
+        df = float(net.divide_factor)
+        if x0 is None:
+            x, x01 = torch.empty(R * S, 3, device=dev), torch.empty(R * S, 3, device=dev)
+            be.ray_points(cam, dirs, samples, x, x01, df)
+        else:
+            x, x01 = x0
+        # per round: hash gather, fused trunk, update, then ONE launch that steps the loop control, draws the next depths and
+        # writes their positions (csrc/sampler.hip: hs_sampler_draw_step); every kernel of round r is gated on slot r
+        for r in range(nr):
+            gate, m_dev = (ctl[r, 0:1], ctl[r, 1:2]), ci[r, 2:3]
+            new_sdf = net.sdf_at_points(x, x01, R, S, sel, gate=gate)
             be.sampler_update(z, sdf, 0, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1], gate=gate,
                               m_dev=m_dev)
-            be.sampler_step(ctl, beta_max_all[r:r + 1], beta0, S, self.max_total_iters)
-            if r + 1 < self.max_total_iters:
+            if r + 1 < nr:
                 samples = torch.empty(R, S, device=dev)
-                be.sampler_draw(z, sdf, 0, beta, 0, float(self.add_tiny), None, S, samples, gate=gate, m_dev=m_dev)
+                x, x01 = torch.empty(R * S, 3, device=dev), torch.empty(R * S, 3, device=dev)
+                be.sampler_draw_step(z, sdf, beta, 0, float(self.add_tiny), None, S, samples, ctl[r], ctl[r + 1], beta_max_all[r:r + 1], beta0, S, nr,
+                                     cam, dirs, df, x, x01)
         n = self.N_samples
         u = None
         if model.training:
             u = (rng["u_final"].to(dev) if "u_final" in rng else _rand((R, n), dev, self.cpu_rng)).contiguous()
         final = torch.empty(R, n, device=dev)
-        be.sampler_draw(z, sdf, 0, beta, 1, float(self.add_tiny), u, n, final, m_dev=m_dev)
+        be.sampler_draw_step(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[nr - 1], ctl[nr], beta_max_all[nr - 1:nr], beta0, S, nr)
+        ctl_end = ctl[nr]
         pick = None
         if self.N_samples_extra > 0:
             if "perm" in rng:   # explicit permutation of the (then host-known) merged set: parity tests
@@ -380,7 +393,7 @@ class ErrorBoundSampler(RaySampler):
             else:
                 pick = torch.empty(self.N_samples_extra, device=dev, dtype=torch.int64)
                 up = _rand((self.N_samples_extra,), dev, self.cpu_rng) if model.training else None
-                be.sampler_pick(ctl, up, self.N_samples_extra, pick)
+                be.sampler_pick(ctl_end, up, self.N_samples_extra, pick)
         n_out = n + 2 + self.N_samples_extra
         if "eik_idx" in rng:
             eik = rng["eik_idx"].to(dev).long().contiguous()
@@ -392,7 +405,7 @@ class ErrorBoundSampler(RaySampler):
         z_eik = torch.empty(R, 1, device=dev)
         be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
         net.invalidate_packed_weights()
-        self._rounds = ci[3:4]
+        self._rounds = ci[nr, 3:4]
         return z_out, z_eik
 
     def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng, z0=None, bounds=None):

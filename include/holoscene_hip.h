@@ -171,6 +171,16 @@ typedef struct hsSamplerCtl {
 int hs_sampler_step(hsSamplerCtl *ctl, const float *beta_max, const float *beta0, int32_t s_new, int32_t max_rounds, void *stream);
 int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, int64_t *pick, void *stream);
 
+/* hs_sampler_draw + hs_sampler_step (+ hs_ray_points) in one launch, for the device-controlled loop with one hsSamplerCtl slot
+ * per round: every workgroup derives the state after the round just updated from *ctl_in and *beta_max (hs_sampler_step's
+ * rule), workgroup 0 writes it to *ctl_out (ctl_out != ctl_in), and the draw runs on that state: mode 0 returns at once when
+ * the loop has stopped, mode 1 (the final draw) always runs, both with m = ctl_out->m.  z / sdf rows hold ld entries.
+ * x != NULL: also the positions of the drawn depths, x / x01 [R*n_out,3] as hs_ray_points writes them. */
+int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const float *beta, int32_t mode, float add_tiny, const float *u, int32_t n_out,
+                         float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0,
+                         int32_t s_new, int32_t max_rounds, const float *cam_loc, const float *ray_dirs, float divide_factor,
+                         float *x /* or NULL */, float *x01, void *stream);
+
 /* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
  * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
@@ -181,10 +191,11 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 /* Camera rays + first (uniform, stratified) depths + Lemma-2 beta in one launch (utils/rend_util.py:56-125 twice incl. the
  * 2x-offset depth-scale rays, model/ray_sampler.py:48-83 and :136-140).  uv [R,2] pixels; ray_offset [R,2] or NULL; pose,
  * intrinsics: DEVICE 4x4 row-major; t_rand [R,S] or NULL (= no stratified jitter, eval mode).
- * Outputs: ray_dirs [R,3], cam_loc [R,3], depth_scale [R], z0 [R,S], beta_init [R]. */
+ * Outputs: ray_dirs [R,3], cam_loc [R,3], depth_scale [R], z0 [R,S], beta_init [R]; when x != NULL also the positions of
+ * the first SDF sweep, x / x01 [R*S,3] exactly as hs_ray_points(cam_loc, ray_dirs, z0, ..., divide_factor) would write them. */
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 void *stream);
+                 float divide_factor, float *x /* or NULL */, float *x01, void *stream);
 
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */

@@ -460,6 +460,11 @@ def test_fused_ray_setup_vs_torch_formulation(train):
     d0 = z_ref[:, 1:] - z_ref[:, :-1]
     beta_ref = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(model.ray_sampler.eps + 1.0)))) * (d0 ** 2).sum(-1))
     close(fused["beta_init"], beta_ref, 1e-5, 1e-7, "beta_init")
+    # positions of the first sweep: bit-identical to the separate positions launch on the kernel's own rays / depths
+    from holoscene_amd.hashencoder import backend
+    x, x01 = torch.empty(R * S, 3, device=DEV), torch.empty(R * S, 3, device=DEV)
+    backend._backend.ray_points(fused["cam_loc"], fused["ray_dirs"], fused["z0"], x, x01, float(model.implicit_network.divide_factor))
+    assert torch.equal(fused["x0"], x) and torch.equal(fused["x0_grid"], x01)
 
 
 @pytest.mark.parametrize("d_out,B", [(32, 25088), (5, 1000), (21, 37)])
@@ -574,6 +579,49 @@ def test_device_side_extra_sample_pick():
         assert p == arr[:n]
         be.sampler_pick(ctl, None, n, pick)
         assert torch.equal(pick.cpu(), torch.linspace(0, m - 1, n).long())
+
+
+def test_fused_draw_step_equals_separate_launches():
+    """hs_sampler_draw_step (loop-control step + draw + positions in one launch) vs hs_sampler_step, hs_sampler_draw and
+    hs_ray_points run one after the other: identical control state, depths and positions -- for a round that continues, one that
+    converged (mode 0 must leave its outputs untouched, mode 1 must still draw) and one that exhausted the round budget."""
+    from holoscene_amd.hashencoder import backend
+    be = backend._backend
+    torch.manual_seed(3)
+    R, S, nr, df = 64, 16, 4, 1.5
+    ld = S * nr
+    for m_old, bmax, rounds_before in ((16, 0.2, 0), (32, 0.01, 1), (48, 0.2, 3)):
+        m_new = m_old + S
+        z = torch.sort(torch.rand(R, ld, device=DEV) * 3 + 0.1, dim=1).values.contiguous()
+        sdf = torch.randn(R, ld, device=DEV) * 0.3
+        beta = torch.rand(R, device=DEV) * 0.1 + 0.02
+        beta0 = torch.tensor([0.05], device=DEV)
+        beta_max = torch.tensor([bmax], device=DEV)
+        cam, dirs = torch.randn(R, 3, device=DEV), torch.nn.functional.normalize(torch.randn(R, 3, device=DEV), dim=-1)
+        for mode, n_out in ((0, S), (1, 24)):
+            u = torch.rand(R, n_out, device=DEV) if mode == 1 else None
+            ctl = torch.tensor([1.0, 0.5, 0.0, 0.0], device=DEV)
+            ctl.view(torch.int32)[2], ctl.view(torch.int32)[3] = m_old, rounds_before
+            # separate launches
+            c1 = ctl.clone()
+            be.sampler_step(c1, beta_max, beta0, S, nr)
+            running = bool(c1[0] > c1[1])
+            assert running == (bmax > 0.05 and rounds_before + 1 < nr)
+            out1 = torch.full((R, n_out), -7.0, device=DEV)
+            x1, x011 = torch.full((R * n_out, 3), -7.0, device=DEV), torch.full((R * n_out, 3), -7.0, device=DEV)
+            gate = (c1[0:1], c1[1:2]) if mode == 0 else None
+            be.sampler_draw(z, sdf, 0, beta, mode, 1e-4, u, n_out, out1, gate=gate, m_dev=c1.view(torch.int32)[2:3])
+            if mode == 1 or running:
+                be.ray_points(cam, dirs, out1, x1, x011, df)
+            # fused
+            c_out = torch.zeros(4, device=DEV)
+            out2 = torch.full((R, n_out), -7.0, device=DEV)
+            x2, x012 = torch.full((R * n_out, 3), -7.0, device=DEV), torch.full((R * n_out, 3), -7.0, device=DEV)
+            be.sampler_draw_step(z, sdf, beta, mode, 1e-4, u, n_out, out2, ctl, c_out, beta_max, beta0, S, nr, cam, dirs, df, x2, x012)
+            assert torch.equal(c_out.view(torch.int32), c1.view(torch.int32))
+            assert int(c_out.view(torch.int32)[2]) == m_new
+            assert torch.equal(out1, out2) and torch.equal(x1, x2) and torch.equal(x011, x012)
+            assert (out2 != -7.0).all() == (mode == 1 or running)
 
 
 @pytest.mark.parametrize("B", [25088, 1000, 37])
