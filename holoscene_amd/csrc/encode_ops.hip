@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict
 __global__ __launch_bounds__(kThreads) void k_render_points(const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ z,
                                                              const float *__restrict__ z_eik, const float *__restrict__ eik_uniform,
                                                              const float *__restrict__ eik_jitter, int64_t R, int N, float divide_factor,
-                                                             float *__restrict__ x, float *__restrict__ x01, float *__restrict__ dirs) {
+                                                             float *__restrict__ x, float *__restrict__ x01, float *__restrict__ dirs, float eik_scale,
+                                                             float eik_shift) {
     const int64_t n_main = R * N, n_eik = z_eik ? 4 * R : 0;
     const int64_t total = (n_main + n_eik) * 3;
     const float inv_df = __fdiv_rn(1.0f, divide_factor);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_render_points(const float *__restr
             int64_t e = p - n_main;                 // 0..4R: [uniform R | near R | jittered copies 2R]
             const bool jit = e >= 2 * R;
             if (jit) e -= 2 * R;
-            v = e < R ? eik_uniform[e * 3 + c] : __fadd_rn(o[(e - R) * 3 + c], __fmul_rn(z_eik[e - R], d[(e - R) * 3 + c]));
+            v = e < R ? __fadd_rn(__fmul_rn(eik_uniform[e * 3 + c], eik_scale), eik_shift) : __fadd_rn(o[(e - R) * 3 + c], __fmul_rn(z_eik[e - R], d[(e - R) * 3 + c]));
             if (jit) v = __fadd_rn(v, __fmul_rn(__fsub_rn(eik_jitter[e * 3 + c], 0.5f), 0.01f));
         }
         x[i] = v;
@@ -373,12 +374,13 @@ int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t
 }
 
 int hs_render_points(const float *cam_loc, const float *ray_dirs, const float *z_vals, const float *z_eik, const float *eik_uniform,
-                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, void *stream) {
+                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, float eik_scale,
+                     float eik_shift, void *stream) {
     if (N < 1 || divide_factor == 0.f) return HS_ERR_ARG;
     if (R == 0) return HS_OK;
     if (!cam_loc || !ray_dirs || !z_vals || !x || !x01 || !dirs_flat || (z_eik && (!eik_uniform || !eik_jitter))) return HS_ERR_NULL;
     k_render_points<<<grid_for((R * N + (z_eik ? 4 * R : 0)) * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform,
-                                                                                                      eik_jitter, R, N, divide_factor, x, x01, dirs_flat);
+                                                                                                      eik_jitter, R, N, divide_factor, x, x01, dirs_flat, eik_scale, eik_shift);
     return check_launch();
 }
 

@@ -52,9 +52,11 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 // (1 024 threads striding 392-byte rows on ONE CU: 100 us); here they are coalesced wave reads spread over the chip.
 __global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
                                                          const float *__restrict__ gt_mask, int R, int N, int K, float w_opac,
-                                                         float *__restrict__ fg, float *__restrict__ bce, float *__restrict__ g_opac) {
+                                                         float *__restrict__ fg, float *__restrict__ bce, float *__restrict__ g_opac,
+                                                         float *__restrict__ zero2) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0.f;   // k_loss_eikonal's accumulators (launched after this kernel)
     if (r >= R) return;
     bool pos = false, neg = false;
     for (int i = lane; i < N; i += 64) {
@@ -80,13 +82,15 @@ __global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict_
     }
 }
 
-// out[0..4] = rgb, depth, normal_l1, normal_cos, opacity losses (unweighted)
+// out[0..4] = rgb, depth, normal_l1, normal_cos, opacity losses (unweighted).  acc2 != NULL (hs_loss_stage1: k_loss_eikonal has
+// run): also out[5..6] = eikonal, smooth (= acc2 / H) and out[7] = the weighted total of all seven terms.
 __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ rgb, const float *__restrict__ rgb_gt, const float *__restrict__ depth,
                                                       const float *__restrict__ depth_gt, const float *__restrict__ nmap,
                                                       const float *__restrict__ n_gt, const float *__restrict__ fg,
                                                       const float *__restrict__ bce, int R, int K, float w_rgb, float w_depth,
                                                       float w_l1, float w_cos, float *__restrict__ out, float *__restrict__ g_rgb,
-                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap) {
+                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap, const float *__restrict__ acc2, float invH,
+                                                      float w_opac, float w_eik, float w_smooth) {
     __shared__ float scratch[kBlock / 64];
     const float invR = 1.f / (float)R;
     // ---- pass 1: rgb, normals, opacity (ray-local), and the five sums of the depth least-squares system
@@ -159,7 +163,14 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
         const float dq = ((2.f * p * E - D - Bs * tt) - q * ddet) / det;
         g_depth[r] = w_depth * 2.f * invR * (c * res * w + S1 * dw + S0 * dq);
     }
-    if (threadIdx.x == 0) { out[0] = Lrgb; out[1] = Ld; out[2] = Ll1; out[3] = Lcos; out[4] = Lop; }
+    if (threadIdx.x == 0) {
+        out[0] = Lrgb; out[1] = Ld; out[2] = Ll1; out[3] = Lcos; out[4] = Lop;
+        if (acc2) {
+            const float Le = acc2[0] * invH, Ls = acc2[1] * invH;
+            out[5] = Le; out[6] = Ls;
+            out[7] = w_rgb * Lrgb + w_depth * Ld + w_l1 * Ll1 + w_cos * Lcos + w_opac * Lop + w_eik * Le + w_smooth * Ls;
+        }
+    }
 }
 
 // n = g/(|g|+eps): returns n, and `back` maps a cotangent of n to a cotangent of g
@@ -228,9 +239,27 @@ int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, cons
     if (!rgb || !rgb_gt || !depth || !depth_gt || !normal_map || !normal_gt || !gt_mask || !sdf || !opacity || !segs || !out5 || !g_rgb || !g_depth ||
         !g_normal_map || !g_opacity || !scratch)
         return HS_ERR_NULL;
-    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w_opac, scratch, scratch + R, g_opacity);
+    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w_opac, scratch, scratch + R, g_opacity, nullptr);
     k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, scratch, scratch + R, R, K, w_rgb, w_depth, w_l1,
-                                                        w_cos, out5, g_rgb, g_depth, g_normal_map);
+                                                        w_cos, out5, g_rgb, g_depth, g_normal_map, nullptr, 0.f, 0.f, 0.f, 0.f);
+    return check_launch();
+}
+
+int hs_loss_stage1(const float *rgb, const float *rgb_gt, const float *depth, const float *depth_gt, const float *normal_map, const float *normal_gt,
+                   const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, const float *g1,
+                   const float *g2, int64_t H, const float *weights7, float *out8, float *g_rgb, float *g_depth, float *g_normal_map, float *g_opacity,
+                   float *d_g1, float *d_g2, float *scratch, void *stream) {
+    if (R < 1 || N < 1 || K < 1 || H < 1) return HS_ERR_ARG;
+    if (!rgb || !rgb_gt || !depth || !depth_gt || !normal_map || !normal_gt || !gt_mask || !sdf || !opacity || !segs || !g1 || !g2 || !weights7 || !out8 ||
+        !g_rgb || !g_depth || !g_normal_map || !g_opacity || !d_g1 || !d_g2 || !scratch)
+        return HS_ERR_NULL;
+    const float *w = weights7;   // rgb, depth, normal_l1, normal_cos, opacity, eikonal, smooth
+    float *acc2 = scratch + 2 * (size_t)R;
+    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w[4], scratch, scratch + R, g_opacity, acc2);
+    const int64_t want = (H + 255) / 256;
+    k_loss_eikonal<<<(int)(want < 2048 ? want : 2048), 256, 0, (hipStream_t)stream>>>(g1, g2, H, w[5], w[6], acc2, d_g1, d_g2);
+    k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, scratch, scratch + R, R, K, w[0], w[1], w[2], w[3],
+                                                        out8, g_rgb, g_depth, g_normal_map, acc2, 1.f / (float)H, w[4], w[5], w[6]);
     return check_launch();
 }
 

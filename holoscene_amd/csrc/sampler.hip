@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
 __global__ __launch_bounds__(kWave) void k_sampler_final(const float *__restrict__ z_samples, int n_s, const float *__restrict__ z_in, int ld,
                                                           const int64_t *__restrict__ pick, int n_extra, float near, float far,
                                                           const int64_t *__restrict__ eik_idx, float *__restrict__ z_out, float *__restrict__ z_eik,
-                                                          int R, const float *__restrict__ near_r, const float *__restrict__ far_r) {
+                                                          int R, const float *__restrict__ near_r, const float *__restrict__ far_r, const float *__restrict__ eik_u) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kWave) void k_sampler_final(const float *__restrict
     }
     __syncthreads();
     for (int i = lane; i < n; i += kWave) z_out[(size_t)r * n + i] = sorted[i];
-    if (lane == 0 && z_eik) z_eik[r] = sorted[eik_idx[r]];
+    if (lane == 0 && z_eik) z_eik[r] = sorted[eik_u ? min((int)(eik_u[r] * (float)n), n - 1) : (int)eik_idx[r]];
 }
 
 
@@ -410,12 +410,12 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
                                                       float far_cap, float bound, float eps, float *__restrict__ ray_dirs,
                                                       float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
                                                       float *__restrict__ beta_init, int R, float divide_factor, float *__restrict__ x,
-                                                      float *__restrict__ x01) {
+                                                      float *__restrict__ x01, float offset_shift) {
     extern __shared__ float lds[];  // [S] stratified depths of this ray
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     const float fx = intr[0], sk = intr[1], cx = intr[2], fy = intr[5], cy = intr[6];
-    const float ox = offset ? offset[2 * r] : 0.f, oy = offset ? offset[2 * r + 1] : 0.f;
+    const float ox = offset ? offset[2 * r] + offset_shift : 0.f, oy = offset ? offset[2 * r + 1] + offset_shift : 0.f;
     const float u = uv[2 * r], v = uv[2 * r + 1];
     // lift (rend_util.py:112-125) at depth 1, then camera-to-world
     const float x1 = u + ox, y1 = v + oy;
@@ -540,25 +540,26 @@ int hs_sampler_pick(const hsSamplerCtl *ctl, const float *u, int32_t n_extra, in
 }
 
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
-                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, const float *near_rays, const float *far_rays, void *stream) {
+                     const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R, const float *near_rays, const float *far_rays, const float *eik_u,
+                     void *stream) {
     if (R <= 0) return HS_OK;
-    if (!z_samples || !z || !z_out || (n_extra > 0 && !pick) || (z_eik && !eik_idx)) return HS_ERR_NULL;
+    if (!z_samples || !z || !z_out || (n_extra > 0 && !pick) || (z_eik && !eik_idx && !eik_u)) return HS_ERR_NULL;
     const int n = n_s + 2 + n_extra;
     if (n > 4096) return HS_ERR_ARG;
     k_sampler_final<<<dim3(R), dim3(kWave), 2 * n * sizeof(float), (hipStream_t)stream>>>(z_samples, n_s, z, ld, pick, n_extra, near, far, eik_idx,
-                                                                                          z_out, z_eik, R, near_rays, far_rays);
+                                                                                          z_out, z_eik, R, near_rays, far_rays, eik_u);
     return check_launch();
 }
 
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 float divide_factor, float *x, float *x01, void *stream) {
+                 float divide_factor, float *x, float *x01, float offset_shift, void *stream) {
     if (R <= 0) return HS_OK;
     if (S < 2 || S > 4096) return HS_ERR_ARG;
     if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
     if (x && (!x01 || divide_factor == 0.f)) return HS_ERR_ARG;
     k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
-                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01);
+                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift);
     return check_launch();
 }
 

@@ -82,7 +82,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
 
 
 def _check(rc, what):
@@ -277,23 +277,24 @@ class _HipBackend:
         _check(lib.hs_sampler_pick(_dev(ctl, "ctl"), _dev(u, "u"), n_extra, _dev(pick, "pick", torch.int64), _stream()), "hs_sampler_pick")
 
     @staticmethod
-    def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik, near_rays=None, far_rays=None):
+    def sampler_final(z_samples, z, pick, near, far, eik_idx, z_out, z_eik, near_rays=None, far_rays=None, eik_u=None):
         lib = load_library()
         R, ld = z.shape
         n_extra = 0 if pick is None else pick.numel()
         _check(lib.hs_sampler_final(_dev(z_samples, "z_samples"), z_samples.shape[1], _dev(z, "z"), ld, _dev(pick, "pick", torch.int64), n_extra,
                                     ctypes.c_float(near), ctypes.c_float(far), _dev(eik_idx, "eik_idx", torch.int64), _dev(z_out, "z_out"),
-                                    _dev(z_eik, "z_eik"), R, _dev(near_rays, "near_rays"), _dev(far_rays, "far_rays"), _stream()), "hs_sampler_final")
+                                    _dev(z_eik, "z_eik"), R, _dev(near_rays, "near_rays"), _dev(far_rays, "far_rays"), _dev(eik_u, "eik_u"), _stream()),
+               "hs_sampler_final")
 
     @staticmethod
     def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init,
-                  divide_factor=1.0, x=None, x01=None):
+                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0):
         lib = load_library()
         _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
                                 _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
                                 ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
                                 _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], ctypes.c_float(divide_factor), _dev(x, "x"),
-                                _dev(x01, "x01"), _stream()), "hs_ray_setup")
+                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _stream()), "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
     @staticmethod
@@ -434,12 +435,13 @@ class _HipBackend:
                                      ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance_bwd")
 
     @staticmethod
-    def render_points(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform, eik_jitter, divide_factor, x, x01, dirs_flat):
+    def render_points(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform, eik_jitter, divide_factor, x, x01, dirs_flat, eik_scale=1.0, eik_shift=0.0):
         lib = load_library()
         R, N = z_vals.shape
         _check(lib.hs_render_points(_dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"), _dev(z_vals, "z_vals"), _dev(z_eik, "z_eik"),
                                     _dev(eik_uniform, "eik_uniform"), _dev(eik_jitter, "eik_jitter"), ctypes.c_int64(R), N, ctypes.c_float(divide_factor),
-                                    _dev(x, "x"), _dev(x01, "x01"), _dev(dirs_flat, "dirs_flat"), _stream()), "hs_render_points")
+                                    _dev(x, "x"), _dev(x01, "x01"), _dev(dirs_flat, "dirs_flat"), ctypes.c_float(eik_scale), ctypes.c_float(eik_shift),
+                                    _stream()), "hs_render_points")
 
     @staticmethod
     def ray_points(cam_loc, ray_dirs, z, x, x01, divide_factor, gate=None):
@@ -530,6 +532,20 @@ class _HipBackend:
                                 _dev(n_gt, "normal_gt"), _dev(gt_mask, "gt_mask"), _dev(sdf, "sdf"), _dev(opac, "opacity"),
                                 _dev(segs, "segs", torch.int64), R, N, K, *w, _dev(out5, "out5"), _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"),
                                 _dev(g_nmap, "g_normal_map"), _dev(g_opac, "g_opacity"), _dev(scratch, "scratch"), _stream()), "hs_loss_rays")
+
+    @staticmethod
+    def loss_stage1(rgb, rgb_gt, depth, depth_gt, nmap, n_gt, gt_mask, sdf, opac, segs, g1, g2, weights7, out8, g_rgb, g_depth, g_nmap, g_opac, d_g1, d_g2):
+        lib = load_library()
+        R, N = sdf.shape
+        K = opac.shape[1]
+        w = (ctypes.c_float * 7)(*[float(x) for x in weights7])
+        scratch = torch.empty(2 * R + 2, device=rgb.device)
+        _check(lib.hs_loss_stage1(_dev(rgb, "rgb"), _dev(rgb_gt, "rgb_gt"), _dev(depth, "depth"), _dev(depth_gt, "depth_gt"), _dev(nmap, "normal_map"),
+                                  _dev(n_gt, "normal_gt"), _dev(gt_mask, "gt_mask"), _dev(sdf, "sdf"), _dev(opac, "opacity"),
+                                  _dev(segs, "segs", torch.int64), R, N, K, _dev(g1, "g1"), _dev(g2, "g2"), ctypes.c_int64(g1.shape[0]), w,
+                                  _dev(out8, "out8"), _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_nmap, "g_normal_map"),
+                                  _dev(g_opac, "g_opacity"), _dev(d_g1, "d_g1"), _dev(d_g2, "d_g2"), _dev(scratch, "scratch"), _stream()),
+               "hs_loss_stage1")
 
     @staticmethod
     def loss_eikonal(g1, g2, w_eik, w_smooth, acc2, d_g1, d_g2):

@@ -1,4 +1,6 @@
 """Laplace-CDF density of VolSDF (reference: model/density.py:5-30)."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -28,5 +30,19 @@ class LaplaceDensity(Density):
             beta = self.get_beta()
         return laplace_density(sdf, beta)
 
+    _shared = None
+
     def get_beta(self):
+        if self._shared is not None:
+            return self._shared
         return self.beta.abs() + self.beta_min
+
+    @contextlib.contextmanager
+    def shared_beta(self):
+        """Within the block every get_beta() returns ONE tensor evaluated on entry (with its autograd history): an iteration asks
+        for beta in the sampler, the background sampler and the renderer, and the parameter cannot change in between."""
+        self._shared = self.beta.abs() + self.beta_min
+        try:
+            yield self._shared
+        finally:
+            self._shared = None

@@ -20,7 +20,15 @@ from ..utils.conf import get_class
 LOSS_IMPL = os.environ.get("HOLOSCENE_LOSS_IMPL", "hip")
 
 
-_WEIGHT_CACHE = {}
+_ZERO = {}
+
+
+def _zero_scalar(dev):
+    """A shared 0-d zero per device for the terms that are switched off (never written to): no fill launch per iteration."""
+    z = _ZERO.get(str(dev))
+    if z is None:
+        z = _ZERO[str(dev)] = torch.zeros((), device=dev)
+    return z
 
 
 class _fused_core_loss(torch.autograd.Function):
@@ -44,28 +52,21 @@ class _fused_core_loss(torch.autograd.Function):
         else:
             g1_, g2_ = c(g1), c(g2)
             d_g1, d_g2 = torch.empty_like(g1_), torch.empty_like(g2_)
-        out5 = torch.empty(5, device=dev)
-        acc2 = torch.zeros(2, device=dev)
+        out8 = torch.empty(8, device=dev)   # the seven unweighted terms (rgb, depth, n_l1, n_cos, opacity, eikonal, smooth) + weighted total
         g_rgb, g_depth, g_nmap, g_opac = torch.empty_like(rgb_), torch.empty_like(depth_), torch.empty_like(nmap_), torch.empty_like(opac_)
-        be = _be._backend
-        be.loss_rays(rgb_, c(rgb_gt).reshape(-1, 3), depth_, c(depth_gt).reshape(-1), nmap_, c(n_gt).reshape(-1, 3), c(gt_mask).reshape(-1),
-                     c(sdf), opac_, segs.reshape(-1).long().contiguous(), (w_rgb, w_depth, w_l1, w_cos, w_opac), out5, g_rgb, g_depth, g_nmap, g_opac)
-        be.loss_eikonal(g1_, g2_, w_eik, w_smooth, acc2, d_g1, d_g2)
-        terms = torch.cat([out5, acc2 / g1_.shape[0]])   # rgb, depth, n_l1, n_cos, opacity, eikonal, smooth
-        key = (str(dev), tuple(float(x) for x in weights))
-        wvec = _WEIGHT_CACHE.get(key)
-        if wvec is None:   # built once (during the eager warm-up), so that graph capture never sees a host->device copy
-            wvec = _WEIGHT_CACHE[key] = torch.tensor(key[1], device=dev)
+        _be._backend.loss_stage1(rgb_, c(rgb_gt).reshape(-1, 3), depth_, c(depth_gt).reshape(-1), nmap_, c(n_gt).reshape(-1, 3), c(gt_mask).reshape(-1),
+                                 c(sdf), opac_, segs.reshape(-1).long().contiguous(), g1_, g2_, weights, out8, g_rgb, g_depth, g_nmap, g_opac, d_g1, d_g2)
+        terms, total = out8[:7], out8[7]
         if ctx.stacked:
             ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_all)
         else:
             ctx.save_for_backward(g_rgb, g_depth.reshape(depth.shape), g_nmap, g_opac, d_g1, d_g2)
         ctx.mark_non_differentiable(terms)
-        return (terms * wvec).sum(), terms
+        return total, terms
 
     @staticmethod
     def backward(ctx, g, _g_terms):
-        grads = tuple(t * g for t in ctx.saved_tensors)
+        grads = tuple(torch._foreach_mul(list(ctx.saved_tensors), g))   # one launch for all cotangents
         if ctx.stacked:
             grads = grads + (None,)
         return grads + (None,) * 7
@@ -232,7 +233,7 @@ class HoloSceneLoss(MonoSDFLoss):
         else:
             output, fused_semantic = super().forward(model_outputs, ground_truth), None
         dev = output["loss"].device
-        zero = torch.zeros((), device=dev)
+        zero = _zero_scalar(dev)
         if fused_semantic is not None:
             semantic_loss = fused_semantic
         elif "semantic_values" in model_outputs and not self.use_obj_opacity:
@@ -264,5 +265,8 @@ class HoloSceneLoss(MonoSDFLoss):
         output["background_reg_loss"] = background_reg_loss
         if fused_semantic is None:   # (the fused core already contains semantic_weight * semantic_loss)
             output["loss"] = output["loss"] + self.semantic_weight * semantic_loss
-        output["loss"] = output["loss"] + self.reg_vio_weight * sample_sdf_loss + self.bg_reg_weight * background_reg_loss
+        if sample_sdf_loss is not zero:     # switched-off terms add nothing: skip their launches
+            output["loss"] = output["loss"] + self.reg_vio_weight * sample_sdf_loss
+        if background_reg_loss is not zero:
+            output["loss"] = output["loss"] + self.bg_reg_weight * background_reg_loss
         return output

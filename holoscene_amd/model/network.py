@@ -1049,17 +1049,41 @@ class HoloSceneNetwork(nn.Module):
     # forward() = prepare_rays -> sample -> (prepare_background) -> render.  The stages exist so the trainer can
     # run the data-dependent part (rays + Algorithm-1 sampler, which needs a host decision per round) eagerly and
     # replay everything after it -- render, loss, backward, Adam -- as one captured HIP graph.
+    def draw_uniforms(self, num_rays, device):
+        """Every U[0,1) draw of one training iteration from ONE generator launch (the reference draws them where it needs them:
+        network.py:773 ray offsets, ray_sampler.py:77 stratified jitter, :238 inverse-CDF draws, :269 extra samples, :279
+        Eikonal pick, network.py:846-853 Eikonal points): an `rng` dict for prepare_rays / sample / render whose *_u entries are
+        raw draws that the consuming kernels shift / scale / quantise themselves."""
+        sm = self.ray_sampler
+        R = num_rays
+        sizes = {"ray_offset_u": (1, R, 2), "t_rand": (R, sm.N_samples_eval), "u_final": (R, sm.N_samples), "u_pick": (max(sm.N_samples_extra, 1),),
+                 "eik_u": (R,), "eik_uniform_u": (R, 3), "eik_jitter": (2 * R, 3)}
+        total = sum(int(np.prod(v)) for v in sizes.values())
+        pool = torch.rand(total, device=device)
+        rng, off = {}, 0
+        for k, shp in sizes.items():
+            n = int(np.prod(shp))
+            rng[k] = pool[off:off + n].view(shp)
+            off += n
+        return rng
+
     def prepare_rays(self, input, rng=None):
         rng = rng or {}
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         dev = uv.device
-        if self.training:
-            ray_offset = rng["ray_offset"] if "ray_offset" in rng else torch.rand_like(uv) - 0.5
-        else:
-            ray_offset = None
         from . import ray_sampler as _rs
-        if _rs.SAMPLER_IMPL == "hip" and uv.is_cuda and pose.shape[1] != 7 and uv.shape[0] == 1:
-            return self._setup_rays_fused(uv, ray_offset, pose, intrinsics, rng.get("t_rand"))
+        fused = _rs.SAMPLER_IMPL == "hip" and uv.is_cuda and pose.shape[1] != 7 and uv.shape[0] == 1
+        shift = 0.0
+        if not self.training:
+            ray_offset = None
+        elif "ray_offset" in rng:
+            ray_offset = rng["ray_offset"]
+        elif "ray_offset_u" in rng and fused:
+            ray_offset, shift = rng["ray_offset_u"], -0.5     # the kernel subtracts the 0.5
+        else:
+            ray_offset = (rng["ray_offset_u"] if "ray_offset_u" in rng else torch.rand_like(uv)) - 0.5
+        if fused:
+            return self._setup_rays_fused(uv, ray_offset, pose, intrinsics, rng.get("t_rand"), offset_shift=shift)
         if self.training:
             ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics, ray_offset=ray_offset)
             # quirk Q1: the reference's first call shifted uv in place, so its depth-scale rays carry 2x the offset
@@ -1073,7 +1097,7 @@ class HoloSceneNetwork(nn.Module):
                 "depth_scale": ray_dirs_tmp[0, :, 2:].contiguous(),
                 "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
 
-    def _setup_rays_fused(self, uv, ray_offset, pose, intrinsics, t_rand=None):
+    def _setup_rays_fused(self, uv, ray_offset, pose, intrinsics, t_rand=None, offset_shift=0.0):
         """Rays, depth scale, the sampler's first (stratified uniform) depths and its Lemma-2 beta from one kernel
         (csrc/sampler.hip: k_ray_setup)."""
         dev = uv.device
@@ -1090,7 +1114,7 @@ class HoloSceneNetwork(nn.Module):
                                pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
                                None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
                                float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
-                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"])
+                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift)
         return out
 
     def sample(self, rays, rng=None, idx=None):
@@ -1152,19 +1176,30 @@ class HoloSceneNetwork(nn.Module):
         # Eikonal set (network.py:843-854), drawn up front so that ONE value+Jacobian pass serves the rendered points
         # and the Eikonal points together (half the trunk launches; the GEMMs simply get 4 % more rows)
         e0 = jitter = None
+        eik_scale, eik_shift = 1.0, 0.0
+        fused_points = ray_dirs.is_cuda and COMPOSITE_IMPL == "hip"
         if self.training:
-            e0 = (rng["eik_uniform"].to(dev) if "eik_uniform" in rng
-                  else torch.empty(num_rays, 3, device=dev).uniform_(-self.scene_bounding_sphere, self.scene_bounding_sphere))
+            b = float(self.scene_bounding_sphere)
+            if "eik_uniform" in rng:
+                e0 = rng["eik_uniform"].to(dev)
+            elif "eik_uniform_u" in rng:     # raw U[0,1): uniform_(-b, b) = u * 2b - b, applied by the positions kernel when there is one
+                e0 = rng["eik_uniform_u"]
+                if fused_points:
+                    eik_scale, eik_shift = 2.0 * b, -b
+                else:
+                    e0 = e0 * (2.0 * b) - b
+            else:
+                e0 = torch.empty(num_rays, 3, device=dev).uniform_(-b, b)
             jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand(2 * num_rays, 3, device=dev)
         x01_all = None
-        if ray_dirs.is_cuda and COMPOSITE_IMPL == "hip":   # all positions, their grid coordinates and the view directions: one kernel
+        if fused_points:   # all positions, their grid coordinates and the view directions: one kernel
             n_all = n_main + (4 * num_rays if self.training else 0)
             x_all, x01_all = torch.empty(n_all, 3, device=dev), torch.empty(n_all, 3, device=dev)
             dirs_flat = torch.empty(n_main, 3, device=dev)
             _be._backend.render_points(cam_loc.contiguous(), ray_dirs.contiguous(), z_vals.contiguous(),
                                        z_samples_eik.reshape(-1).contiguous() if self.training else None,
                                        None if e0 is None else e0.contiguous().float(), None if jitter is None else jitter.contiguous().float(),
-                                       float(net.divide_factor), x_all, x01_all, dirs_flat)
+                                       float(net.divide_factor), x_all, x01_all, dirs_flat, eik_scale, eik_shift)
             points_flat = x_all[:n_main]
         else:
             points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)

@@ -348,15 +348,15 @@ class ErrorBoundSampler(RaySampler):
         else:
             beta = beta_init.clone()
         nr = self.max_total_iters
-        if self._ctl_init is None or self._ctl_init.device != dev or self._ctl_init.shape[0] != nr + 1:
-            init = torch.zeros(nr + 1, 4)
-            init[0] = torch.tensor([1.0, 0.5, 0.0, 0.0])     # hsSamplerCtl {running, half, m = 0, rounds = 0}; slot r+1 = state after round r
+        if self._ctl_init is None or self._ctl_init.device != dev or self._ctl_init.numel() != (nr + 1) * 4 + nr:
+            init = torch.zeros((nr + 1) * 4 + nr)            # [nr+1] hsSamplerCtl slots (slot r+1 = state after round r) | [nr] per-round max beta
+            init[:4] = torch.tensor([1.0, 0.5, 0.0, 0.0])     # slot 0: {running, half, m = 0, rounds = 0}
             self._ctl_init = init.to(dev)
-        ctl = self._ctl_init.clone()
+        state = self._ctl_init.clone()                        # one copy initialises the control slots and zeroes the max-beta cells
+        ctl, beta_max_all = state[:(nr + 1) * 4].view(nr + 1, 4), state[(nr + 1) * 4:]
         ci = ctl.view(torch.int32)
         z = torch.empty(R, ld, device=dev)
         sdf = torch.empty(R, ld, device=dev)
-        beta_max_all = torch.zeros(nr, device=dev)
         cam = (cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc).contiguous()
         dirs = ray_dirs.contiguous()
         sel = -1 if idx is None else idx
@@ -392,18 +392,23 @@ class ErrorBoundSampler(RaySampler):
                 pick = rng["perm"][: self.N_samples_extra].to(dev).long().contiguous()
             else:
                 pick = torch.empty(self.N_samples_extra, device=dev, dtype=torch.int64)
-                up = _rand((self.N_samples_extra,), dev, self.cpu_rng) if model.training else None
+                up = None
+                if model.training:
+                    up = rng["u_pick"][: self.N_samples_extra].contiguous() if "u_pick" in rng else _rand((self.N_samples_extra,), dev, self.cpu_rng)
                 be.sampler_pick(ctl_end, up, self.N_samples_extra, pick)
         n_out = n + 2 + self.N_samples_extra
+        eik_u = None
         if "eik_idx" in rng:
             eik = rng["eik_idx"].to(dev).long().contiguous()
+        elif "eik_u" in rng:      # raw U[0,1) draws: the kernel quantises them to [0, n_out)
+            eik, eik_u = None, rng["eik_u"].contiguous()
         elif self.cpu_rng:
             eik = torch.randint(n_out, (R,)).to(dev)
         else:
             eik = torch.randint(n_out, (R,), device=dev)
         z_out = torch.empty(R, n_out, device=dev)
         z_eik = torch.empty(R, 1, device=dev)
-        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik)
+        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u)
         net.invalidate_packed_weights()
         self._rounds = ci[nr, 3:4]
         return z_out, z_eik

@@ -83,6 +83,10 @@ class Stage1Trainer:
             raise ValueError(optimizer)
         if graph and self.flat is None:
             raise ValueError("graph=True needs optimizer='flat'")
+        if graph and getattr(self.loss, "end_step", -1) > 0:
+            # loss.end_step > 0 makes the depth / normal weights a host-side function of the step (loss.py:322-323): a captured
+            # graph would freeze them at their capture-time value.  No stock conf sets it; run those eagerly rather than wrongly.
+            raise ValueError("graph=True cannot be combined with loss.end_step > 0 (per-step host-side loss weights); use graph=False")
         self.use_graph = graph
         self.freeze_parameters = freeze_parameters  # tests: compute gradients but skip the update
         self.zero1 = zero1 and world_size > 1
@@ -144,13 +148,15 @@ class Stage1Trainer:
     def _full_body(self, st, with_bg, call_reg):
         model = self.model
         self.flat.zero_grad()
-        with torch.no_grad():
-            rays = model.prepare_rays(st["input"])
-            z_vals, z_eik = model.sample(rays)
-            rounds = model.ray_sampler._rounds
-            bg = model.prepare_background(st["input"]) if with_bg else None
-            model.ray_sampler._rounds = rounds      # report the main pass, not the background patch
-        out = model.render(rays, z_vals, z_eik, None, bg=bg)
+        with model.density.shared_beta():   # entered with grad enabled: the renderer differentiates through it, the samplers detach it
+            with torch.no_grad():
+                rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
+                rays = model.prepare_rays(st["input"], rng)
+                z_vals, z_eik = model.sample(rays, rng)
+                rounds = model.ray_sampler._rounds
+                bg = model.prepare_background(st["input"]) if with_bg else None
+                model.ray_sampler._rounds = rounds      # report the main pass, not the background patch
+            out = model.render(rays, z_vals, z_eik, None, rng=rng, bg=bg)
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         loss_out["loss"].backward()

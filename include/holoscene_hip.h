@@ -186,7 +186,7 @@ int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const flo
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
                      const int64_t *eik_idx, float *z_out, float *z_eik, int32_t R,
                      const float *near_rays, const float *far_rays /* [R] per-ray bounds overriding near / far (ray_sampler.py:290-447), or NULL */,
-                     void *stream);
+                     const float *eik_u /* NULL, or [R] U[0,1) draws replacing eik_idx: index = min(int(u * n), n - 1) */, void *stream);
 
 /* Camera rays + first (uniform, stratified) depths + Lemma-2 beta in one launch (utils/rend_util.py:56-125 twice incl. the
  * 2x-offset depth-scale rays, model/ray_sampler.py:48-83 and :136-140).  uv [R,2] pixels; ray_offset [R,2] or NULL; pose,
@@ -195,7 +195,8 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
  * the first SDF sweep, x / x01 [R*S,3] exactly as hs_ray_points(cam_loc, ray_dirs, z0, ..., divide_factor) would write them. */
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 float divide_factor, float *x /* or NULL */, float *x01, void *stream);
+                 float divide_factor, float *x /* or NULL */, float *x01,
+                 float offset_shift /* added to ray_offset: 0, or -0.5 when ray_offset holds raw U[0,1) draws */, void *stream);
 
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
@@ -204,9 +205,11 @@ int hs_ray_points(const float *cam_loc, const float *ray_dirs, const float *z, f
 
 /* All positions of the render pass in one launch (model/network.py:805-811, 843-854): x [(R*N + 4R), 3] = the R*N rendered
  * samples cam_loc + z_vals*ray_dirs, then (training: z_eik != NULL) the Eikonal set [eik_uniform [R,3] | cam_loc + z_eik*ray_dirs]
- * and its copy jittered by (eik_jitter [2R,3] - 0.5)*0.01;  x01 = (x/divide_factor + 1)/2;  dirs_flat [R*N,3] = ray_dirs per sample. */
+ * and its copy jittered by (eik_jitter [2R,3] - 0.5)*0.01;  x01 = (x/divide_factor + 1)/2;  dirs_flat [R*N,3] = ray_dirs per sample.
+ * eik_uniform is used as eik_uniform * eik_scale + eik_shift (1, 0: values already in the bounding box; 2b, -b: raw U[0,1) draws). */
 int hs_render_points(const float *cam_loc, const float *ray_dirs, const float *z_vals, const float *z_eik, const float *eik_uniform,
-                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, void *stream);
+                     const float *eik_jitter, int64_t R, int32_t N, float divide_factor, float *x, float *x01, float *dirs_flat, float eik_scale,
+                     float eik_shift, void *stream);
 
 /* ------------------------------------------------------------------ 4. value+Jacobian trunk, elementwise stages
  *
@@ -408,6 +411,13 @@ int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, cons
                  float w_depth, float w_l1, float w_cos, float w_opac, float *out5, float *g_rgb, float *g_depth, float *g_normal_map,
                  float *g_opacity, float *scratch /* [2R] work space */, void *stream);
 int hs_loss_eikonal(const float *g1, const float *g2, int64_t H, float w_eik, float w_smooth, float *acc2, float *d_g1, float *d_g2, void *stream);
+/* Both of the above plus the weighted total (loss.py:325-334, 655-657) as three launches with no host-side glue:
+ * weights7 (HOST array) = weights of {rgb, depth, normal_l1, normal_cos, opacity, eikonal, smooth};
+ * out8 = the seven unweighted terms in that order, then sum_i weights7[i] * term_i.  scratch [2R + 2] (needs no initialisation). */
+int hs_loss_stage1(const float *rgb, const float *rgb_gt, const float *depth, const float *depth_gt, const float *normal_map, const float *normal_gt,
+                   const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, const float *g1,
+                   const float *g2, int64_t H, const float *weights7, float *out8, float *g_rgb, float *g_depth, float *g_normal_map, float *g_opacity,
+                   float *d_g1, float *d_g2, float *scratch, void *stream);
 
 #ifdef __cplusplus
 }

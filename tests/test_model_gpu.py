@@ -683,6 +683,36 @@ def _full_graph_trainer(beta, freeze, rays=256):
     return tr, SyntheticScene(rays, 4, img_res=(64, 64), num_frames=3, ring=4, device=DEV)
 
 
+def test_pooled_uniform_draws_equal_explicit_draws():
+    """HoloSceneNetwork.draw_uniforms hands raw U[0,1) slices of one generator launch to the kernels, which shift / scale / quantise
+    them themselves (hs_ray_setup offset_shift, hs_sampler_final eik_u, hs_render_points eik_scale/shift).  The same iteration fed
+    with the host-side conversions of those draws through the explicit-draw keys must give identical rays, depths and outputs."""
+    tr, scene = _full_graph_trainer(0.01, True)
+    model = tr.model.train()
+    _, ins, _ = scene.next_batch()
+    R = ins["uv"].shape[1]
+    torch.manual_seed(11)
+    pooled = model.draw_uniforms(R, DEV)
+    n_out = model.ray_sampler.N_samples + 2 + model.ray_sampler.N_samples_extra
+    b = float(model.scene_bounding_sphere)
+    explicit = {"ray_offset": pooled["ray_offset_u"] - 0.5, "t_rand": pooled["t_rand"], "u_final": pooled["u_final"], "u_pick": pooled["u_pick"],
+                "eik_idx": (pooled["eik_u"] * n_out).long().clamp(max=n_out - 1), "eik_uniform": pooled["eik_uniform_u"] * (2.0 * b) - b,
+                "eik_jitter": pooled["eik_jitter"]}
+    res = []
+    for rng in (pooled, explicit):
+        with torch.no_grad():
+            rays = model.prepare_rays(ins, rng)
+            z, z_eik = model.sample(rays, rng)
+        out = model.render(rays, z, z_eik, None, rng=rng)
+        res.append((rays, z, z_eik, out))
+    (ra, za, ea, oa), (rb, zb, eb, ob) = res
+    for k in ("ray_dirs", "cam_loc", "depth_scale", "z0", "beta_init"):
+        assert torch.equal(ra[k], rb[k]), k
+    assert torch.equal(za, zb) and torch.equal(ea, eb)
+    for k in ("rgb_values", "depth_values", "normal_map", "grad_theta", "grad_theta_nei"):
+        assert torch.equal(oa[k], ob[k]), k
+
+
 @pytest.mark.parametrize("beta", [0.05, 0.002])
 def test_whole_iteration_graph_matches_eager_execution(beta):
     """Rays + device-controlled sampler + render + loss + backward captured as ONE graph vs the eager execution of the same
