@@ -158,8 +158,7 @@ def main():
     rounds_seen = []
 
     def step():
-        idx, mi, gt = scene.next_batch()
-        tr.train_step(idx, mi, gt)
+        tr.train_step_resident(scene)    # batch gathered from the HBM-resident frames straight into the graph's input block
         r_ = tr.model.ray_sampler._rounds       # int, or a device tensor (device-controlled sampler): no sync inside the loop
         rounds_seen.append(r_.clone() if torch.is_tensor(r_) else r_)
 
@@ -251,8 +250,7 @@ def main():
             if i == 8:
                 barrier()
                 t0 = time.perf_counter()
-            idx, mi, gt = scene.next_batch()
-            tr2.train_step(idx, mi, gt)
+            tr2.train_step_resident(scene)
             r_ = tr2.model.ray_sampler._rounds
             r2.append(r_.clone() if torch.is_tensor(r_) else r_)
         barrier()

@@ -284,6 +284,24 @@ __global__ __launch_bounds__(kThreads) void k_render_points(const float *__restr
     }
 }
 
+// ---- batch assembly from device-resident images: dst[i, :] = src[idx[i], :] for several arrays in one launch (the pixel gather of
+// a training batch -- uv, colour, depth, normal, label rows of the sampled pixels, datasets/scene_dataset.py:143-167 does it with
+// fancy indexing on the host -- written straight into the captured graph's static input block).  Rows are copied in 4-byte words.
+struct GatherJobs { hsGatherJob j[HS_GATHER_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_gather_rows(GatherJobs jobs) {
+    const hsGatherJob jb = jobs.j[blockIdx.y];
+    const int words = jb.row_bytes >> 2;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(jb.src);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(jb.dst);
+    const int64_t total = jb.n * words;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / words;
+        const int w = (int)(i - r * words);
+        dst[i] = src[jb.idx[r] * words + w];
+    }
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 int grid_for(int64_t total) {
@@ -381,6 +399,26 @@ int hs_render_points(const float *cam_loc, const float *ray_dirs, const float *z
     if (!cam_loc || !ray_dirs || !z_vals || !x || !x01 || !dirs_flat || (z_eik && (!eik_uniform || !eik_jitter))) return HS_ERR_NULL;
     k_render_points<<<grid_for((R * N + (z_eik ? 4 * R : 0)) * 3), kThreads, 0, (hipStream_t)stream>>>(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform,
                                                                                                       eik_jitter, R, N, divide_factor, x, x01, dirs_flat, eik_scale, eik_shift);
+    return check_launch();
+}
+
+int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream) {
+    if (n_jobs < 0 || n_jobs > HS_GATHER_MAX_JOBS) return HS_ERR_ARG;
+    if (n_jobs == 0) return HS_OK;
+    if (!jobs) return HS_ERR_NULL;
+    GatherJobs gj;
+    int64_t most = 0;
+    for (int i = 0; i < n_jobs; i++) {
+        const hsGatherJob &j = jobs[i];
+        if (j.n < 0 || j.row_bytes <= 0 || (j.row_bytes & 3)) return HS_ERR_ARG;
+        if (j.n > 0 && (!j.src || !j.dst || !j.idx)) return HS_ERR_NULL;
+        gj.j[i] = j;
+        const int64_t t = j.n * (j.row_bytes >> 2);
+        most = t > most ? t : most;
+    }
+    if (most == 0) return HS_OK;
+    const int64_t want = (most + 255) / 256;
+    k_gather_rows<<<dim3((unsigned)(want < 64 ? want : 64), n_jobs), 256, 0, (hipStream_t)stream>>>(gj);
     return check_launch();
 }
 

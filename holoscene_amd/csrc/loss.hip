@@ -225,6 +225,62 @@ __global__ __launch_bounds__(256) void k_loss_eikonal(const float *__restrict__ 
     if (threadIdx.x == 0) unsafeAtomicAdd(acc + 1, scratch[0] + scratch[1] + scratch[2] + scratch[3]);
 }
 
+// Background-surface smoothness (model/loss.py:519-547 compute_grad_error on the depth and on the three normal channels of the
+// side x side background patch, :549-557): 4 scales (stride 1, 2, 4, 8), masked absolute first differences along x and y,
+// each scale divided by its number of masked pixels.  The reference evaluates this with ~190 small tensor ops and autograd
+// replays ~220 more; the patch has 1 024 pixels, so one workgroup computes the value and the analytic gradient: thread = pixel,
+// every pixel sums the pairs it belongs to (left / right / up / down neighbour at each scale), no atomics.
+//   labels != 0 marks the pixels where something occludes the background (:652-654).
+__global__ __launch_bounds__(kBlock) void k_bg_smooth(const float *__restrict__ depth, const float *__restrict__ normal, const int64_t *__restrict__ labels,
+                                                      int side, float *__restrict__ out, float *__restrict__ g_depth, float *__restrict__ g_normal) {
+    __shared__ float scratch[kBlock / 64];
+    __shared__ float val[4][kBlock];   // masked values v = m * x per channel (depth, nx, ny, nz)
+    __shared__ float msk[kBlock];
+    const int P = side * side, p = threadIdx.x;
+    const bool live = p < P;
+    const int y = live ? p / side : 0, x = live ? p - y * side : 0;
+    const float m = live && labels[p] != 0 ? 1.f : 0.f;
+    msk[p] = m;
+    val[0][p] = live ? m * depth[p] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) val[c + 1][p] = live ? m * normal[3 * p + c] : 0.f;
+    __syncthreads();
+    float total_d = 0.f, total_n = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 4; s++) {
+        const int step = 1 << s;
+        const bool on = live && (y % step == 0) && (x % step == 0);
+        const float div = block_sum(on ? m : 0.f, scratch);
+        float sum_d = 0.f, sum_n = 0.f;
+        if (on) {
+            const float inv = div > 0.f ? 1.f / fmaxf(div, 1.f) : 0.f;
+            // neighbours at this scale: (dx, dy) in {(+step,0), (0,+step)} own the pair's value; all four feed this pixel's gradient
+            const int nx[4] = {x + step, x, x - step, x}, ny[4] = {y, y + step, y, y - step};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (nx[k] < 0 || ny[k] < 0 || nx[k] >= side || ny[k] >= side) continue;
+                const int q = ny[k] * side + nx[k];
+                const float pw = m * msk[q];
+                if (pw == 0.f) continue;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float d = k < 2 ? val[c][q] - val[c][p] : val[c][p] - val[c][q];   // later element minus earlier element
+                    if (k < 2) { if (c == 0) sum_d += pw * fabsf(d); else sum_n += pw * fabsf(d); }
+                    const float sg = sgn(d) * pw * m * inv;       // d v_p / d x_p = m
+                    g[c] += k < 2 ? -sg : sg;
+                }
+            }
+        }
+        const float Sd = block_sum(sum_d, scratch), Sn = block_sum(sum_n, scratch);
+        if (div > 0.f) { total_d += Sd / fmaxf(div, 1.f); total_n += Sn / fmaxf(div, 1.f); }
+    }
+    if (live) {
+        g_depth[p] = g[0];
+#pragma unroll
+        for (int c = 0; c < 3; c++) g_normal[3 * p + c] = g[c + 1];
+    }
+    if (p == 0) out[0] = total_d + total_n;
+}
+
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 }  // namespace
@@ -269,6 +325,14 @@ int hs_loss_eikonal(const float *g1, const float *g2, int64_t H, float w_eik, fl
     const int64_t want = (H + 255) / 256;
     const int grid = (int)(want < 2048 ? want : 2048);
     k_loss_eikonal<<<grid, 256, 0, (hipStream_t)stream>>>(g1, g2, H, w_eik, w_smooth, acc2, d_g1, d_g2);
+    return check_launch();
+}
+
+int hs_bg_smooth_loss(const float *depth, const float *normal, const int64_t *labels, int32_t side, float *out, float *g_depth, float *g_normal,
+                      void *stream) {
+    if (side < 1 || side * side > kBlock) return HS_ERR_ARG;
+    if (!depth || !normal || !labels || !out || !g_depth || !g_normal) return HS_ERR_NULL;
+    k_bg_smooth<<<1, kBlock, 0, (hipStream_t)stream>>>(depth, normal, labels, side, out, g_depth, g_normal);
     return check_launch();
 }
 

@@ -46,6 +46,10 @@ class hsWnJob(ctypes.Structure):
                 ("gg", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
 
 
+class hsGatherJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
+
+
 ABI_VERSION = 3
 
 
@@ -82,7 +86,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
 
 
 def _check(rc, what):
@@ -401,6 +405,27 @@ class _HipBackend:
         return outs
 
     @staticmethod
+    def gather_plan(jobs):
+        """jobs: list of (src [rows, ...], dst [n, ...], idx int64 [n]) device tensors -> a reusable launch description of
+        dst[i] = src[idx[i]] for all of them (hs_gather_rows).  The plan keeps the tensors alive; run it with gather_rows(plan)."""
+        arr = (hsGatherJob * len(jobs))()
+        for a, (src, dst, idx) in zip(arr, jobs):
+            if not (src.is_cuda and dst.is_cuda and idx.is_cuda and src.is_contiguous() and dst.is_contiguous() and idx.is_contiguous()):
+                raise RuntimeError("gather_plan: contiguous CUDA tensors expected")
+            if idx.dtype != torch.int64 or src.dtype != dst.dtype:
+                raise RuntimeError("gather_plan: idx must be int64 and src / dst of one dtype")
+            row = (src.numel() // src.shape[0]) * src.element_size()
+            if dst.numel() * dst.element_size() != idx.numel() * row or row % 4:
+                raise RuntimeError("gather_plan: dst must hold idx.numel() rows of src's row size (a multiple of 4 bytes)")
+            a.src, a.dst, a.idx, a.n, a.row_bytes = src.data_ptr(), dst.data_ptr(), idx.data_ptr(), idx.numel(), row
+        return (arr, len(jobs), jobs)
+
+    @staticmethod
+    def gather_rows(plan):
+        lib = load_library()
+        _check(lib.hs_gather_rows(plan[0], plan[1], _stream()), "hs_gather_rows")
+
+    @staticmethod
     def sum_slices(partials):
         """partials: list of bf16 tensors [S, ...]; returns the fp32 sums over dim 0, all in one launch."""
         lib = load_library()
@@ -546,6 +571,12 @@ class _HipBackend:
                                   _dev(out8, "out8"), _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_nmap, "g_normal_map"),
                                   _dev(g_opac, "g_opacity"), _dev(d_g1, "d_g1"), _dev(d_g2, "d_g2"), _dev(scratch, "scratch"), _stream()),
                "hs_loss_stage1")
+
+    @staticmethod
+    def bg_smooth_loss(depth, normal, labels, side, out, g_depth, g_normal):
+        lib = load_library()
+        _check(lib.hs_bg_smooth_loss(_dev(depth, "depth"), _dev(normal, "normal"), _dev(labels, "labels", torch.int64), side, _dev(out, "out"),
+                                     _dev(g_depth, "g_depth"), _dev(g_normal, "g_normal"), _stream()), "hs_bg_smooth_loss")
 
     @staticmethod
     def loss_eikonal(g1, g2, w_eik, w_smooth, acc2, d_g1, d_g2):

@@ -72,6 +72,25 @@ class _fused_core_loss(torch.autograd.Function):
         return grads + (None,) * 7
 
 
+class _fused_bg_smooth(torch.autograd.Function):
+    """HoloSceneLoss.get_bg_render_loss in one launch (csrc/loss.hip: k_bg_smooth): value and analytic gradient."""
+
+    @staticmethod
+    def forward(ctx, bg_depth, bg_normal, labels, side):
+        d = bg_depth.detach().reshape(-1).contiguous().float()
+        n = bg_normal.detach().reshape(-1, 3).contiguous().float()
+        out = torch.empty(1, device=d.device)
+        g_d, g_n = torch.empty_like(d), torch.empty_like(n)
+        _be._backend.bg_smooth_loss(d, n, labels.reshape(-1).long().contiguous(), side, out, g_d, g_n)
+        ctx.save_for_backward(g_d.reshape(bg_depth.shape), g_n.reshape(bg_normal.shape))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_d, g_n = torch._foreach_mul(list(ctx.saved_tensors), g)
+        return g_d, g_n, None, None
+
+
 def compute_scale_and_shift_batch(prediction, target):
     """Least-squares (scale, shift) aligning prediction [B,N] to target [B,N] (loss.py:181-193)."""
     ones = torch.ones_like(prediction)
@@ -202,7 +221,10 @@ class HoloSceneLoss(MonoSDFLoss):
             total = total + torch.where(divisor > 0, (gx.sum() + gy.sum()) / divisor.clamp(min=1), torch.zeros_like(total))
         return total
 
-    def get_bg_render_loss(self, bg_depth, bg_normal, mask):
+    def get_bg_render_loss(self, bg_depth, bg_normal, mask, labels=None):
+        """labels: the integer map the mask came from (mask = labels != 0); given on CUDA, the fused kernel is used."""
+        if labels is not None and LOSS_IMPL == "hip" and bg_depth.is_cuda:
+            return _fused_bg_smooth.apply(bg_depth, bg_normal, labels, 32)
         bg_depth = bg_depth.reshape(1, 32, 32)
         bg_normal = bg_normal.reshape(32, 32, 3).permute(2, 0, 1)
         mask = mask.reshape(1, 32, 32)
@@ -249,11 +271,14 @@ class HoloSceneLoss(MonoSDFLoss):
         else:
             sample_sdf_loss = zero
         if "bg_depth_values" in model_outputs:
-            if "bg_mask" in model_outputs:
-                bg_mask = (model_outputs["bg_mask"] != 0).int()  # smooth only where something occludes the background
+            labels = model_outputs["bg_mask"] if "bg_mask" in model_outputs else ground_truth["segs"].to(dev)
+            if LOSS_IMPL == "hip" and labels.is_cuda:
+                bg_mask = None                                   # the fused kernel tests labels != 0 itself
+            elif "bg_mask" in model_outputs:
+                bg_mask = (labels != 0).int()  # smooth only where something occludes the background
             else:
-                bg_mask = (ground_truth["segs"] != 0).to(dev)
-            background_reg_loss = self.get_bg_render_loss(model_outputs["bg_depth_values"], model_outputs["bg_normal_map"], bg_mask)
+                bg_mask = labels != 0
+            background_reg_loss = self.get_bg_render_loss(model_outputs["bg_depth_values"], model_outputs["bg_normal_map"], bg_mask, labels=labels)
         else:
             background_reg_loss = zero
         if "rgb_offset" in model_outputs:

@@ -51,6 +51,8 @@ class SyntheticScene:
         self._ring = [self._draw(g) for _ in range(ring)]
         self._ring_dev = [(f, idx.to(self.device)) for f, idx in self._ring]
         self._cursor = 0
+        self._plans, self._const_done = {}, set()
+        self._frame_idx = [torch.tensor([f], dtype=torch.int64).to(self.device) for f, _ in self._ring]   # made here: no host->device copy (= sync) per step
 
     def _draw(self, g):
         """One (frame, pixel-index) batch, ns_dataset.py:383, 409-430."""
@@ -74,3 +76,24 @@ class SyntheticScene:
         gt = {"rgb": self.rgb[frame][idx][None], "depth": self.depth[frame][idx][None], "normal": self.normal[frame][idx][None],
               "mask": torch.ones(1, idx.numel(), 1, device=self.device), "segs": self.segs[idx][None]}
         return torch.tensor([frame]), model_input, gt
+
+    def write_batch(self, dst_input, dst_gt):
+        """next_batch() written straight into existing buffers (the training graph's static input block) by ONE gather launch
+        (csrc/encode_ops.hip: hs_gather_rows) instead of six indexing launches plus the copies into the block.  Same ring, same
+        cursor: interleaving next_batch() and write_batch() walks the same sequence of batches."""
+        from ..hashencoder import backend as _be
+        slot = self._cursor % len(self._ring_dev)
+        self._cursor += 1
+        tag = dst_input["uv"].data_ptr()
+        plan = self._plans.get((slot, tag))
+        if plan is None:
+            frame, idx = self._ring_dev[slot]
+            fidx = self._frame_idx[slot]
+            plan = self._plans[(slot, tag)] = _be._backend.gather_plan([
+                (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
+                (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
+        if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
+            dst_input["intrinsics"].copy_(self.intrinsics)
+            dst_gt["mask"].fill_(1.0)
+            self._const_done.add(tag)
+        _be._backend.gather_rows(plan)

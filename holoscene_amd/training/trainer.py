@@ -196,6 +196,24 @@ class Stage1Trainer:
         self.iter_step += 1
         return entry["out"], entry["loss"]
 
+    def train_step_resident(self, dataset):
+        """One iteration on a device-resident dataset (anything with next_batch() -> (indices, model_input, ground_truth) and
+        write_batch(dst_input, dst_gt)): once the whole-iteration graph of the variant exists, the batch is gathered straight into
+        its static input block -- no intermediate batch tensors, no copies -- and the graph is replayed."""
+        if self.use_graph and hasattr(dataset, "write_batch") and self._full_graph_ok():
+            with_bg = self.model.wants_background(self.iter_step)
+            entry = self._graphs.get(("full", with_bg, self.iter_step >= self.add_objectvio_iter))
+            if entry is not None:
+                self.model.train()
+                dataset.write_batch(entry["static"]["input"], entry["static"]["gt"])
+                entry["graph"].replay()
+                self.model.ray_sampler._rounds = entry["rounds"]
+                if self.world_size > 1:
+                    dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+                self.iter_step += 1
+                return entry["out"], entry["loss"]
+        return self.train_step(*dataset.next_batch())
+
     def _capture(self, key, fresh):
         """fresh: dict of live tensors with the shapes of this variant; becomes the static input block."""
         with_bg, call_reg = key

@@ -375,6 +375,19 @@ typedef struct hsWnJob {
 } hsWnJob;
 int hs_weight_norm(const hsWnJob *jobs, int32_t n_jobs, int32_t backward, void *stream);
 
+/* Batch assembly from device-resident arrays: dst[i, :] = src[idx[i], :], rows of row_bytes (a multiple of 4) bytes, for up to
+ * HS_GATHER_MAX_JOBS arrays in one launch -- the sampled-pixel gather of a training batch (datasets/scene_dataset.py:143-167:
+ * uv / rgb / depth / normal / label rows at sampling_idx) written straight into the training graph's static input block. */
+#define HS_GATHER_MAX_JOBS 12
+typedef struct hsGatherJob {
+    const void *src;
+    void *dst;
+    const int64_t *idx;   /* [n] row indices into src */
+    int64_t n;
+    int32_t row_bytes;
+} hsGatherJob;
+int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
@@ -418,6 +431,12 @@ int hs_loss_stage1(const float *rgb, const float *rgb_gt, const float *depth, co
                    const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, const float *g1,
                    const float *g2, int64_t H, const float *weights7, float *out8, float *g_rgb, float *g_depth, float *g_normal_map, float *g_opacity,
                    float *d_g1, float *d_g2, float *scratch, void *stream);
+
+/* Background-surface smoothness of the side x side (side <= 32) background patch (model/loss.py:519-557, 652-657):
+ * compute_grad_error(depth) + compute_grad_error(normal), 4 scales of masked absolute first differences, mask = labels != 0.
+ * depth [P], normal [P,3] (pixel-major), labels int64 [P], P = side^2.  out[0] = the loss, g_depth / g_normal = its gradient. */
+int hs_bg_smooth_loss(const float *depth, const float *normal, const int64_t *labels, int32_t side, float *out, float *g_depth, float *g_normal,
+                      void *stream);
 
 #ifdef __cplusplus
 }
