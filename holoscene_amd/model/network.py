@@ -316,6 +316,9 @@ class _fused_trunk_render(torch.autograd.Function):
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
 # bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
 APPEARANCE_IMPL = os.environ.get("HOLOSCENE_APPEARANCE_IMPL", "mfma")
+# background-surface pass of render(): "hip" = the main pass's fused kernels (trunk + split, compositing) when their shapes are
+# supported; "torch" = the whole-tensor formulation (always used otherwise)
+BG_IMPL = os.environ.get("HOLOSCENE_BG_IMPL", "hip")
 
 
 class _fused_appearance(torch.autograd.Function):
@@ -1209,10 +1212,11 @@ class HoloSceneNetwork(nn.Module):
                 near_surface = (cam_loc.unsqueeze(1) + z_samples_eik.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
                 eik = torch.cat([e0, near_surface], 0)
                 x_all = torch.cat([points_flat, eik, eik + (jitter - 0.5) * 0.01], 0)
+        trunk_W = None
         if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
-            W0, W1, W2 = effective_weights([l0, l1, l2])
+            trunk_W = W0, W1, W2 = effective_weights([l0, l1, l2])
             sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = _fused_trunk_render.apply(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
@@ -1290,14 +1294,37 @@ class HoloSceneNetwork(nn.Module):
         if bg is not None:  # background-surface pass (network.py:943-968)
             bg_z, ray_dirs0, cam_loc0 = bg["z_vals"], bg["ray_dirs"], bg["cam_loc"]
             n_bg = bg_z.shape[1]
-            bg_points = (cam_loc0.unsqueeze(1) + bg_z.unsqueeze(2) * ray_dirs0.unsqueeze(1)).reshape(-1, 3)
-            scene_sdf, _, bg_gradients, scene_semantic, bg_sdf = self.implicit_network.get_specific_outputs(bg_points, 0)
-            bg_weight, _, _ = self.volume_rendering(bg_z, bg_sdf)
-            scene_weight, _, _ = self.volume_rendering(bg_z, scene_sdf)  # semantics use the scene SDF
-            bg_semantic = torch.sum(scene_weight.unsqueeze(-1) * scene_semantic.reshape(-1, n_bg, self.num_semantic), 1)
-            output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
-            output["bg_depth_values"] = bg["depth_scale"] * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
-            bg_normals = (bg_gradients / (bg_gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, n_bg, 3)
-            bg_normal_map = torch.sum(bg_weight.unsqueeze(-1) * bg_normals, 1)
+            fused_bg = (BG_IMPL == "hip" and fused_points and COMPOSITE_IMPL == "hip" and TRUNK_IMPL == "mfma"
+                        and net._fused_trunk_supported(bg_z) and net._lins()[2].out_features == net.d_out)
+            if fused_bg:
+                # the same kernels as the main pass: positions, value+Jacobian trunk + split (no Eikonal rows), compositing -- once
+                # with the scene SDF for the label map (forward only), once with object 0's SDF for depth and normals
+                B0 = bg_z.numel()
+                xb, xb01 = torch.empty(B0, 3, device=dev), torch.empty(B0, 3, device=dev)
+                _be._backend.ray_points(cam_loc0.contiguous(), ray_dirs0.contiguous(), bg_z.contiguous(), xb, xb01, float(net.divide_factor))
+                enc = net.encoding
+                l0, l1, l2 = net._lins()
+                W0, W1, W2 = trunk_W if trunk_W is not None else effective_weights([l0, l1, l2])   # the main pass's normalised weights
+                raw_b, sdf_b, _, grad_b, _, _, _ = _fused_trunk_render.apply(
+                    xb, B0, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                    net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, xb01)
+                beta, unused_rgb = self.density.get_beta(), grad_b.detach()     # (the colour slot of the kernel is not needed here)
+                with torch.no_grad():
+                    bg_semantic = _composite.apply(bg_z, sdf_b, raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid)[5]
+                output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
+                comp = _composite.apply(bg_z, raw_b[:, 0:1], raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid)
+                output["bg_depth_values"], bg_normal_map = comp[3], comp[4]
+            elif BG_IMPL not in ("hip", "torch"):
+                raise RuntimeError(f"unknown HOLOSCENE_BG_IMPL={BG_IMPL!r}")
+            else:
+                bg_points = (cam_loc0.unsqueeze(1) + bg_z.unsqueeze(2) * ray_dirs0.unsqueeze(1)).reshape(-1, 3)
+                scene_sdf, _, bg_gradients, scene_semantic, bg_sdf = self.implicit_network.get_specific_outputs(bg_points, 0)
+                bg_weight, _, _ = self.volume_rendering(bg_z, bg_sdf)
+                scene_weight, _, _ = self.volume_rendering(bg_z, scene_sdf)  # semantics use the scene SDF
+                bg_semantic = torch.sum(scene_weight.unsqueeze(-1) * scene_semantic.reshape(-1, n_bg, self.num_semantic), 1)
+                output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
+                output["bg_depth_values"] = bg["depth_scale"] * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
+                bg_normals = (bg_gradients / (bg_gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, n_bg, 3)
+                bg_normal_map = torch.sum(bg_weight.unsqueeze(-1) * bg_normals, 1)
             output["bg_normal_map"] = (rot @ bg_normal_map.permute(1, 0)).permute(1, 0).contiguous()
         return output

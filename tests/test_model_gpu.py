@@ -709,6 +709,40 @@ def test_fused_background_smoothness_vs_torch_formulation(density, monkeypatch):
             close(g_h, g_t, 1e-5, 1e-7, name)
 
 
+def test_fused_background_pass_vs_torch_formulation(monkeypatch):
+    """render()'s background-surface pass through the main pass's kernels (trunk + split, compositing twice) vs the whole-tensor
+    formulation on the same bf16 trunk: label map, depth and normal map of the 32x32 patch, and the gradient of a scalar of them
+    with respect to the geometry hash table and the trunk weights."""
+    from holoscene_amd.model import network as N
+    tr, scene = _full_graph_trainer(0.01, True)
+    model = tr.model.train()
+    _, ins, _ = scene.next_batch()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        rng = model.draw_uniforms(ins["uv"].shape[1], DEV)
+        rays = model.prepare_rays(ins, rng)
+        z, z_eik = model.sample(rays, rng)
+        bg = model.prepare_background(ins)
+    params = [model.implicit_network.encoding.embeddings] + [p for l in model.implicit_network._lins() for p in l.parameters()] + [model.density.beta]
+    cot_d, cot_n = torch.randn(1024, 1, device=DEV), torch.randn(1024, 3, device=DEV)
+    res = {}
+    for impl in ("torch", "hip"):
+        monkeypatch.setattr(N, "BG_IMPL", impl)
+        out = model.render(rays, z, z_eik, None, rng=rng, bg=dict(bg))
+        val = (out["bg_depth_values"] * cot_d).sum() + (out["bg_normal_map"] * cot_n).sum()
+        grads = torch.autograd.grad(val, params, allow_unused=True)
+        res[impl] = (out["bg_mask"], out["bg_depth_values"].detach(), out["bg_normal_map"].detach(), grads)
+    a, b = res["hip"], res["torch"]
+    assert float((a[0] != b[0]).float().mean()) <= 0.01          # argmax labels: ties aside, identical
+    close(a[1], b[1], 1e-4, 1e-5, "bg depth")
+    close(a[2], b[2], 1e-4, 1e-5, "bg normal map")
+    for ga, gb, p in zip(a[3], b[3], params):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            rel = float((ga - gb).norm() / gb.norm().clamp(min=1e-20))
+            assert rel < 2e-2, (tuple(p.shape), rel)       # bf16 cotangent images on both sides (split kernel vs autograd chain)
+
+
 def test_resident_batch_gather_equals_indexed_batches():
     """SyntheticScene.write_batch (one hs_gather_rows launch into existing buffers) vs next_batch (torch fancy indexing) on two
     identically seeded scenes, and a trainer stepping through train_step_resident vs train_step on the same batches."""
