@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
                                                           const float *__restrict__ depth_scale, float sem_scale, int N, int K,
                                                           float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ rgb_out,
                                                           float *__restrict__ depth_out, float *__restrict__ normal_out, float *__restrict__ sem_out,
-                                                          float *__restrict__ opac_out) {
+                                                          float *__restrict__ opac_out, const float *__restrict__ rot) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, i = threadIdx.x;
     const int C = 8 + 2 * K;
@@ -191,13 +191,19 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
     __syncthreads();
     for (int j = i; j < C; j += BLOCK) {  // column sums -> outputs
         if (j == 4) continue;            // folded into the depth column
-        float acc = 0.f, acc_w = 0.f;
+        if (rot && (j == 6 || j == 7)) continue;   // the thread of column 5 sums all three normal components and rotates them
+        float acc = 0.f, acc_w = 0.f, acc1 = 0.f, acc2 = 0.f;
         for (int n = 0; n < N; n++) {
             acc += contrib[(size_t)n * C + j];
             if (j == 3) acc_w += contrib[(size_t)n * C + 4];
+            if (rot && j == 5) { acc1 += contrib[(size_t)n * C + 6]; acc2 += contrib[(size_t)n * C + 7]; }
         }
         if (j < 3) rgb_out[3 * r + j] = acc;
         else if (j == 3) depth_out[r] = depth_scale[r] * (acc / (acc_w + 1e-8f));
+        else if (rot && j == 5) {     // world -> camera frame (network.py:917-918: rot @ normal_map^T)
+#pragma unroll
+            for (int a = 0; a < 3; a++) normal_out[3 * r + a] = rot[3 * a] * acc + rot[3 * a + 1] * acc1 + rot[3 * a + 2] * acc2;
+        }
         else if (j < 8) normal_out[3 * r + (j - 5)] = acc;
         else if (j < 8 + K) sem_out[(size_t)r * K + (j - 8)] = acc;
         else opac_out[(size_t)r * K + (j - 8 - K)] = acc;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
                                                           const float *__restrict__ g_depth, const float *__restrict__ g_normal,
                                                           const float *__restrict__ g_sem, const float *__restrict__ g_opac,
                                                           float *__restrict__ d_sdf, float *__restrict__ d_raw, float *__restrict__ d_rgb,
-                                                          float *__restrict__ d_g, float *__restrict__ d_beta) {
+                                                          float *__restrict__ d_g, float *__restrict__ d_beta, const float *__restrict__ rot) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, i = threadIdx.x;
     float *scratch = lds;          // [4]
@@ -256,7 +262,13 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
         gx = g[3 * p]; gy = g[3 * p + 1]; gz = g[3 * p + 2];
         rn = sqrtf(gx * gx + gy * gy + gz * gz);
         const float inv = 1.f / (rn + 1e-6f);
-        const float n0 = g_normal ? g_normal[3 * r] : 0.f, n1 = g_normal ? g_normal[3 * r + 1] : 0.f, n2 = g_normal ? g_normal[3 * r + 2] : 0.f;
+        float n0 = g_normal ? g_normal[3 * r] : 0.f, n1 = g_normal ? g_normal[3 * r + 1] : 0.f, n2 = g_normal ? g_normal[3 * r + 2] : 0.f;
+        if (rot) {   // cotangent of the camera-frame normal -> world frame: rot^T
+            const float c0 = n0, c1 = n1, c2_ = n2;
+            n0 = rot[0] * c0 + rot[3] * c1 + rot[6] * c2_;
+            n1 = rot[1] * c0 + rot[4] * c1 + rot[7] * c2_;
+            n2 = rot[2] * c0 + rot[5] * c1 + rot[8] * c2_;
+        }
         gw += (n0 * gx + n1 * gy + n2 * gz) * inv;
         if (d_g) {  // n = g/(|g|+eps): dn/dg = I/(r+eps) - g g^T / (r (r+eps)^2)
             const float dot = (n0 * gx + n1 * gy + n2 * gz) * w;
@@ -303,7 +315,7 @@ extern "C" {
 
 int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
                      const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, float *weights, float *transmittance,
-                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, void *stream) {
+                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, const float *rot, void *stream) {
     if (R <= 0) return HS_OK;
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !weights || !rgb_out || !depth_out || !normal_out || !sem_out || !opac_out)
@@ -311,24 +323,24 @@ int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const f
     const size_t lds = (4 + (size_t)N * (8 + 2 * K)) * sizeof(float);
     if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix must fit the default dynamic-LDS window
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) k_composite_fwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
-    else if (N <= 128) k_composite_fwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
-    else k_composite_fwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out);
+    if (N <= 64) k_composite_fwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
+    else if (N <= 128) k_composite_fwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
+    else k_composite_fwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
     return check_launch();
 }
 
 int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
                      const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, const float *g_weights, const float *g_rgb_out,
                      const float *g_depth, const float *g_normal, const float *g_sem, const float *g_opac, float *d_sdf, float *d_raw,
-                     float *d_rgb, float *d_g, float *d_beta, void *stream) {
+                     float *d_rgb, float *d_g, float *d_beta, const float *rot, void *stream) {
     if (R <= 0) return HS_OK;
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !d_sdf || !d_raw) return HS_ERR_NULL;
     const size_t lds = (4 + 2 * (size_t)K) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) k_composite_bwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
-    else if (N <= 128) k_composite_bwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
-    else k_composite_bwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta);
+    if (N <= 64) k_composite_bwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
+    else if (N <= 128) k_composite_bwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
+    else k_composite_bwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
     return check_launch();
 }
 

@@ -410,10 +410,11 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
                                                       float far_cap, float bound, float eps, float *__restrict__ ray_dirs,
                                                       float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
                                                       float *__restrict__ beta_init, int R, float divide_factor, float *__restrict__ x,
-                                                      float *__restrict__ x01, float offset_shift) {
+                                                      float *__restrict__ x01, float offset_shift, float *__restrict__ rot_out) {
     extern __shared__ float lds[];  // [S] stratified depths of this ray
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
+    if (rot_out && r == 0 && lane < 9) rot_out[lane] = pose[4 * (lane % 3) + lane / 3];   // world -> camera: transpose of the pose rotation
     const float fx = intr[0], sk = intr[1], cx = intr[2], fy = intr[5], cy = intr[6];
     const float ox = offset ? offset[2 * r] + offset_shift : 0.f, oy = offset ? offset[2 * r + 1] + offset_shift : 0.f;
     const float u = uv[2 * r], v = uv[2 * r + 1];
@@ -553,13 +554,13 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 float divide_factor, float *x, float *x01, float offset_shift, void *stream) {
+                 float divide_factor, float *x, float *x01, float offset_shift, float *rot_out, void *stream) {
     if (R <= 0) return HS_OK;
     if (S < 2 || S > 4096) return HS_ERR_ARG;
     if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
     if (x && (!x01 || divide_factor == 0.f)) return HS_ERR_ARG;
     k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
-                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift);
+                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift, rot_out);
     return check_launch();
 }
 

@@ -292,13 +292,13 @@ class _HipBackend:
 
     @staticmethod
     def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init,
-                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0):
+                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0, rot_out=None):
         lib = load_library()
         _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
                                 _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
                                 ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
                                 _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], ctypes.c_float(divide_factor), _dev(x, "x"),
-                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _stream()), "hs_ray_setup")
+                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _dev(rot_out, "rot_out"), _stream()), "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
     @staticmethod
@@ -333,19 +333,19 @@ class _HipBackend:
 
     # ---- fused compositing (include/holoscene_hip.h section 6)
     @staticmethod
-    def composite_fwd(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out):
+    def composite_fwd(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out, rot=None):
         lib = load_library()
         R, N = z.shape
         K = raw.shape[-1]
         _check(lib.hs_composite_fwd(_dev(z, "z"), _dev(sdf, "sdf"), _dev(raw, "raw"), _dev(rgb, "rgb"), _dev(g, "g"), _dev(beta, "beta"),
                                     _dev(depth_scale, "depth_scale"), ctypes.c_float(sem_scale), R, N, K, _dev(weights, "weights"),
                                     _dev(trans, "trans"), _dev(rgb_out, "rgb_out"), _dev(depth_out, "depth_out"),
-                                    _dev(normal_out, "normal_out"), _dev(sem_out, "sem_out"), _dev(opac_out, "opac_out"), _stream()),
+                                    _dev(normal_out, "normal_out"), _dev(sem_out, "sem_out"), _dev(opac_out, "opac_out"), _dev(rot, "rot"), _stream()),
                "hs_composite_fwd")
 
     @staticmethod
     def composite_bwd(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, g_w, g_rgb, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb,
-                      d_g, d_beta):
+                      d_g, d_beta, rot=None):
         lib = load_library()
         R, N = z.shape
         K = raw.shape[-1]
@@ -353,7 +353,7 @@ class _HipBackend:
                                     _dev(depth_scale, "depth_scale"), ctypes.c_float(sem_scale), R, N, K, _dev(g_w, "g_w"),
                                     _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_normal, "g_normal"), _dev(g_sem, "g_sem"),
                                     _dev(g_opac, "g_opac"), _dev(d_sdf, "d_sdf"), _dev(d_raw, "d_raw"), _dev(d_rgb, "d_rgb"),
-                                    _dev(d_g, "d_g"), _dev(d_beta, "d_beta"), _stream()), "hs_composite_bwd")
+                                    _dev(d_g, "d_g"), _dev(d_beta, "d_beta"), _dev(rot, "rot"), _stream()), "hs_composite_bwd")
 
     # ---- fused SDF-trunk inference (include/holoscene_hip.h section 7)
     @staticmethod

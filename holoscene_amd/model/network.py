@@ -17,6 +17,7 @@ kernels want:
     evaluates and discards (network.py:177-179, 305-311).
   * no per-iteration device->host syncs besides the sampler's convergence test.
 """
+import contextlib
 import math
 import os
 
@@ -488,8 +489,10 @@ class _composite(torch.autograd.Function):
     (un-rotated), semantic_values, object_opacity -- one kernel forward, one backward."""
 
     @staticmethod
-    def forward(ctx, z, sdf, raw, rgb, g, beta, depth_scale, sem_scale):
+    def forward(ctx, z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, rot=None):
+        """rot: optional [3,3] world-to-camera rotation; the normal output is then the camera-frame normal map (network.py:917-918)."""
         ctx.set_materialize_grads(False)
+        ctx.rot = None if rot is None else rot.detach().contiguous().float()
         z, sdf, raw, rgb, g = z.contiguous(), sdf.contiguous(), raw.contiguous(), rgb.contiguous(), g.contiguous()
         depth_scale = depth_scale.contiguous()
         beta1 = beta.detach().reshape(1).contiguous()
@@ -504,7 +507,7 @@ class _composite(torch.autograd.Function):
         sem_out = torch.empty(R, K, device=dev)
         opac_out = torch.empty(R, K, device=dev)
         _be._backend.composite_fwd(z, sdf, raw, rgb, g, beta1, depth_scale, float(sem_scale), weights, trans, rgb_out, depth_out, normal_out,
-                                   sem_out, opac_out)
+                                   sem_out, opac_out, rot=ctx.rot)
         ctx.save_for_backward(z, sdf, raw, rgb, g, beta1, depth_scale)
         ctx.sem_scale = float(sem_scale)
         ctx.beta_shape = beta.shape
@@ -521,8 +524,8 @@ class _composite(torch.autograd.Function):
         d_g = torch.empty_like(g) if ctx.needs_input_grad[4] else None
         d_beta = torch.empty(z.shape[0], device=z.device) if ctx.needs_input_grad[5] else None   # per-ray partials
         _be._backend.composite_bwd(z, sdf, raw, rgb, g, beta1, depth_scale, ctx.sem_scale, c(g_w), c(g_rgb), c(g_depth), c(g_normal), c(g_sem),
-                                   c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta)
-        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None
+                                   c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta, rot=ctx.rot)
+        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None, None
 
 
 def default_mlp_precision():
@@ -575,8 +578,30 @@ class _weight_norm_many(torch.autograd.Function):
         return tuple(o.view_as(p) for o, p in zip(out, [t for pair in zip(vs, gs) for t in pair]))
 
 
+_SHARED_W = None
+
+
+@contextlib.contextmanager
+def shared_effective_weights(lins):
+    """Within the block effective_weights() of any subset of `lins` returns tensors normalised ONCE on entry (one launch for all
+    layers, and one for all their gradients on the way back): a training iteration asks for the trunk's matrices in the
+    sampler, the renderer and the background pass, and for the rendering network's in the renderer; the parameters cannot
+    change in between.  Enter with grad enabled when the block differentiates through the weights."""
+    global _SHARED_W
+    lins = [l for l in lins if isinstance(l, WNLinear) and l.weight_v.is_cuda]
+    if lins:
+        Ws = _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
+        _SHARED_W = {id(l): W for l, W in zip(lins, Ws)}
+    try:
+        yield
+    finally:
+        _SHARED_W = None
+
+
 def effective_weights(lins):
     """Weight-normalised matrices of a list of WNLinear layers (one fused launch on the GPU)."""
+    if _SHARED_W is not None and all(id(l) in _SHARED_W for l in lins):
+        return tuple(_SHARED_W[id(l)] for l in lins)
     if lins[0].weight_v.is_cuda:
         return _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
     return tuple(l.weight for l in lins)
@@ -1052,6 +1077,12 @@ class HoloSceneNetwork(nn.Module):
     # forward() = prepare_rays -> sample -> (prepare_background) -> render.  The stages exist so the trainer can
     # run the data-dependent part (rays + Algorithm-1 sampler, which needs a host decision per round) eagerly and
     # replay everything after it -- render, loss, backward, Adam -- as one captured HIP graph.
+    def weight_norm_layers(self):
+        """Every weight-normalised layer a Stage-1 iteration evaluates (for shared_effective_weights)."""
+        rn = self.rendering_network
+        return list(self.implicit_network._lins()) + [l for l in (getattr(rn, "lin0", None), getattr(rn, "lin1", None), getattr(rn, "lin2", None))
+                                                       if l is not None]
+
     def draw_uniforms(self, num_rays, device):
         """Every U[0,1) draw of one training iteration from ONE generator launch (the reference draws them where it needs them:
         network.py:773 ray offsets, ray_sampler.py:77 stratified jitter, :238 inverse-CDF draws, :269 extra samples, :279
@@ -1112,12 +1143,12 @@ class HoloSceneNetwork(nn.Module):
         out = {"ray_dirs": torch.empty(R, 3, device=dev), "cam_loc": torch.empty(R, 3, device=dev), "depth_scale": torch.empty(R, 1, device=dev),
                "z0": torch.empty(R, S, device=dev), "beta_init": torch.empty(R, device=dev),
                "x0": torch.empty(R * S, 3, device=dev), "x0_grid": torch.empty(R * S, 3, device=dev),   # positions of z0: the sampler's first sweep
-               "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
+               "rot": torch.empty(3, 3, device=dev)}          # pose[0, :3, :3]^T, written by the kernel
         _be._backend.ray_setup(uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
                                pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
                                None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
                                float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
-                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift)
+                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift, out["rot"])
         return out
 
     def sample(self, rays, rng=None, idx=None):
@@ -1245,8 +1276,9 @@ class HoloSceneNetwork(nn.Module):
             if not z_vals.is_cuda:
                 raise RuntimeError("fused compositing needs CUDA tensors (set HOLOSCENE_COMPOSITE_IMPL=torch explicitly for the "
                                    "whole-tensor formulation)")
-            weights, _, rgb_values, depth_values, normal_world, semantic_values, object_opacity = _composite.apply(
-                z_vals, sdf, sdf_raw, rgb.reshape(-1, 3), gradients, self.density.get_beta(), depth_scale, self.implicit_network.sigmoid)
+            weights, _, rgb_values, depth_values, normal_cam, semantic_values, object_opacity = _composite.apply(
+                z_vals, sdf, sdf_raw, rgb.reshape(-1, 3), gradients, self.density.get_beta(), depth_scale, self.implicit_network.sigmoid, rot)
+            normal_world = None     # the kernel rotated the normal map into the camera frame
         elif COMPOSITE_IMPL == "torch":
             semantic = (net.sigmoid * torch.sigmoid(-net.sigmoid * sdf_raw)).reshape(-1, N_samples, self.num_semantic)
             weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
@@ -1268,11 +1300,11 @@ class HoloSceneNetwork(nn.Module):
             "rgb_values": rgb_values,
             "depth_values": depth_values,
             "z_vals": z_vals,
-            "depth_vals": z_vals * depth_scale,
             "sdf": sdf.reshape(z_vals.shape),
             "weights": weights,
         }
 
+        output["depth_vals"] = z_vals * depth_scale
         if self.training:
             # replaces gradient() + get_sdf_raw() + get_sdf_vals() on the Eikonal set (network.py:856-863)
             if gtheta is not None:      # already stacked by the split kernel
@@ -1289,7 +1321,7 @@ class HoloSceneNetwork(nn.Module):
             output["grad_theta"] = grad_theta[:half]
             output["grad_theta_nei"] = grad_theta[half:]
 
-        output["normal_map"] = (rot @ normal_world.permute(1, 0)).permute(1, 0).contiguous()
+        output["normal_map"] = normal_cam if normal_world is None else (rot @ normal_world.permute(1, 0)).permute(1, 0).contiguous()
 
         if bg is not None:  # background-surface pass (network.py:943-968)
             bg_z, ray_dirs0, cam_loc0 = bg["z_vals"], bg["ray_dirs"], bg["cam_loc"]
@@ -1312,8 +1344,8 @@ class HoloSceneNetwork(nn.Module):
                 with torch.no_grad():
                     bg_semantic = _composite.apply(bg_z, sdf_b, raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid)[5]
                 output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
-                comp = _composite.apply(bg_z, raw_b[:, 0:1], raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid)
-                output["bg_depth_values"], bg_normal_map = comp[3], comp[4]
+                comp = _composite.apply(bg_z, raw_b[:, 0:1], raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid, rot)
+                output["bg_depth_values"], output["bg_normal_map"] = comp[3], comp[4]      # (camera frame: rotated by the kernel)
             elif BG_IMPL not in ("hip", "torch"):
                 raise RuntimeError(f"unknown HOLOSCENE_BG_IMPL={BG_IMPL!r}")
             else:
@@ -1326,5 +1358,5 @@ class HoloSceneNetwork(nn.Module):
                 output["bg_depth_values"] = bg["depth_scale"] * (torch.sum(bg_weight * bg_z, 1, keepdims=True) / (bg_weight.sum(dim=1, keepdims=True) + 1e-8))
                 bg_normals = (bg_gradients / (bg_gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, n_bg, 3)
                 bg_normal_map = torch.sum(bg_weight.unsqueeze(-1) * bg_normals, 1)
-            output["bg_normal_map"] = (rot @ bg_normal_map.permute(1, 0)).permute(1, 0).contiguous()
+                output["bg_normal_map"] = (rot @ bg_normal_map.permute(1, 0)).permute(1, 0).contiguous()
         return output

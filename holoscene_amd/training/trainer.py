@@ -7,6 +7,7 @@ print, holoscene_train.py:366-372); scalars are returned as device tensors.
 import torch
 
 from ..model.loss import HoloSceneLoss
+from ..model import network as _net
 from ..model.network import HoloSceneNetwork
 from ..utils.conf import Conf
 from . import distributed as dist_util
@@ -148,7 +149,8 @@ class Stage1Trainer:
     def _full_body(self, st, with_bg, call_reg):
         model = self.model
         self.flat.zero_grad()
-        with model.density.shared_beta():   # entered with grad enabled: the renderer differentiates through it, the samplers detach it
+        # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
+        with model.density.shared_beta(), _net.shared_effective_weights(model.weight_norm_layers()):
             with torch.no_grad():
                 rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
                 rays = model.prepare_rays(st["input"], rng)

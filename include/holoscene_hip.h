@@ -196,7 +196,8 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
                  float divide_factor, float *x /* or NULL */, float *x01,
-                 float offset_shift /* added to ray_offset: 0, or -0.5 when ray_offset holds raw U[0,1) draws */, void *stream);
+                 float offset_shift /* added to ray_offset: 0, or -0.5 when ray_offset holds raw U[0,1) draws */,
+                 float *rot_out /* NULL, or [3,3]: the world-to-camera rotation pose[:3,:3]^T (network.py:917) */, void *stream);
 
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
@@ -252,17 +253,20 @@ int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, in
  *   z [R,N]; sdf [R*N] (scene min-SDF); raw [R*N,K] per-object SDFs; rgb [R*N,3]; g [R*N,3] (d sdf/dx);
  *   beta: device scalar; depth_scale [R]; sem_scale = implicit_network.sigmoid.
  * forward writes weights [R,N], transmittance [R,N] (may be NULL), rgb_out [R,3], depth_out [R] (already multiplied by
- * depth_scale), normal_out [R,3] (world frame, un-rotated), sem_out [R,K], opac_out [R,K].  N <= 256, N*(8+2K) floats <= 64 KB.
+ * depth_scale), normal_out [R,3] (world frame; with rot != NULL -- a DEVICE row-major 3x3 world-to-camera rotation -- the camera-frame
+ * normal map rot . n of network.py:917-918, and backward then expects the cotangent of THAT), sem_out [R,K], opac_out [R,K].
+ * N <= 256, N*(8+2K) floats <= 64 KB.
  * backward takes the cotangents of those outputs (any may be NULL = zero) and writes d_sdf [R*N], d_raw [R*N,K],
  * d_rgb [R*N,3] (may be NULL), d_g [R*N,3] (may be NULL), and d_beta [R] (may be NULL): PER-RAY partial derivatives w.r.t. beta,
  * to be summed by the caller (one same-address atomic per ray serialised in the L2). */
 int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
                      const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, float *weights, float *transmittance,
-                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, void *stream);
+                     float *rgb_out, float *depth_out, float *normal_out, float *sem_out, float *opac_out, const float *rot /* or NULL */,
+                     void *stream);
 int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const float *rgb, const float *g, const float *beta,
                      const float *depth_scale, float sem_scale, int32_t R, int32_t N, int32_t K, const float *g_weights, const float *g_rgb_out,
                      const float *g_depth, const float *g_normal, const float *g_sem, const float *g_opac, float *d_sdf, float *d_raw,
-                     float *d_rgb, float *d_g, float *d_beta, void *stream);
+                     float *d_rgb, float *d_g, float *d_beta, const float *rot /* or NULL */, void *stream);
 
 /* ------------------------------------------------------------------ 7. fused SDF-trunk inference on the matrix cores
  *
