@@ -21,6 +21,17 @@ LOSS_IMPL = os.environ.get("HOLOSCENE_LOSS_IMPL", "hip")
 
 
 _ZERO = {}
+_ONE = {}
+
+
+def unit_cotangent(dev):
+    """The shared 0-d tensor 1.0 of a device.  `loss.backward(gradient=unit_cotangent(dev))` lets the fused objective recognise the
+    plain d loss / d loss = 1 root by its storage and hand out its stored gradients as they are (no fill for the root, no multiply by
+    one); any other cotangent takes the general path.  Never written to."""
+    o = _ONE.get(str(dev))
+    if o is None:
+        o = _ONE[str(dev)] = torch.ones((), device=dev)
+    return o
 
 
 def _zero_scalar(dev):
@@ -66,7 +77,11 @@ class _fused_core_loss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_terms):
-        grads = tuple(torch._foreach_mul(list(ctx.saved_tensors), g))   # one launch for all cotangents
+        one = _ONE.get(str(g.device))
+        if one is not None and g.data_ptr() == one.data_ptr():    # the root cotangent 1.0 (unit_cotangent): the stored gradients are the answer
+            grads = tuple(ctx.saved_tensors)
+        else:
+            grads = tuple(torch._foreach_mul(list(ctx.saved_tensors), g))   # one launch for all cotangents
         if ctx.stacked:
             grads = grads + (None,)
         return grads + (None,) * 7

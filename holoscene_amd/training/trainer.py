@@ -6,7 +6,7 @@ print, holoscene_train.py:366-372); scalars are returned as device tensors.
 """
 import torch
 
-from ..model.loss import HoloSceneLoss
+from ..model.loss import HoloSceneLoss, unit_cotangent
 from ..model import network as _net
 from ..model.network import HoloSceneNetwork
 from ..utils.conf import Conf
@@ -133,7 +133,7 @@ class Stage1Trainer:
         out = self.model.render(st["rays"], st["z_vals"], st["z_eik"], None, bg=bg)
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
-        loss_out["loss"].backward()
+        loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
         if self.world_size == 1 and not self.freeze_parameters:
             self.flat.step()
@@ -161,7 +161,7 @@ class Stage1Trainer:
             out = model.render(rays, z_vals, z_eik, None, rng=rng, bg=bg)
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
-        loss_out["loss"].backward()
+        loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
         if self.world_size == 1 and not self.freeze_parameters:
             self.flat.step()
