@@ -919,6 +919,48 @@ class ObjectImplicitNetworkGrid(nn.Module):
         semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
         return sdf, feature_vectors, gradients, semantic, sdf_raw[:, idx]
 
+    # ---- object-subset variants used by the Stage-2/3 entry points of HoloSceneNetwork (network.py:359-459).  One value+Jacobian
+    # pass gives every per-object SDF and gradient; a variant only chooses which columns the minimum runs over.
+    def _subset_min(self, sdf_raw, J, cols):
+        """min over the object columns `cols` (None = all): value [B,1], the gradient of that minimum [B,3]."""
+        y = sdf_raw if cols is None else sdf_raw[:, cols]
+        Jc = J if cols is None else J[:, cols]
+        sdf, k = y.min(dim=-1, keepdim=True)
+        return sdf, torch.gather(Jc, 1, k.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+
+    def _value_jacobian_features(self, x):
+        y, J = self.sdf_and_jacobian(x)
+        if self.color_grid_feature:
+            return y, J, self._color_features(x)
+        return y[:, :self.d_out], J[:, :self.d_out], y[:, self.d_out:]
+
+    def get_multi_specific_outputs(self, x, idxs):
+        """Scene SDF / gradient / semantics over ALL objects + the minimum over the objects `idxs` (network.py:359-385)."""
+        sdf_raw, J, fv = self._value_jacobian_features(x)
+        sdf, gradients = self._subset_min(sdf_raw, J, None)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
+        return sdf, fv, gradients, semantic, sdf_raw[:, idxs].min(dim=-1, keepdim=True)[0]
+
+    def get_only_multi_specific_outputs(self, x, idxs):
+        """Everything restricted to the objects `idxs` (network.py:387-406)."""
+        sdf_raw, J, fv = self._value_jacobian_features(x)
+        sdf, gradients = self._subset_min(sdf_raw, J, idxs)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw[:, idxs])
+        return sdf, fv, gradients, semantic
+
+    def get_multi_specific_outputs_subset_objs(self, x, idxs, subset_idxs):
+        """SDF / gradient / semantics over `subset_idxs` + the minimum over `idxs` (network.py:408-435)."""
+        sdf_raw, J, fv = self._value_jacobian_features(x)
+        sdf, gradients = self._subset_min(sdf_raw, J, subset_idxs)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw[:, subset_idxs])
+        return sdf, fv, gradients, semantic, sdf_raw[:, idxs].min(dim=-1, keepdim=True)[0]
+
+    def get_specific_outputs_nm(self, x, idx):
+        """One object's own SDF and gradient, no minimum (network.py:437-458); semantics over all objects."""
+        sdf_raw, J, fv = self._value_jacobian_features(x)
+        semantic = self.sigmoid * torch.sigmoid(-self.sigmoid * sdf_raw)
+        return sdf_raw[:, idx], fv, J[:, idx], semantic
+
     def get_sdf_raw(self, x):
         if self.color_grid_feature and self._fused_sdf_supported(x):
             return self._sdf_fused(x, want_raw=True)[1]
@@ -1072,6 +1114,179 @@ class HoloSceneNetwork(nn.Module):
     def occlusion_opacity(self, z_vals, transmittance, dists, sdf_raw):
         obj_density = self.density(sdf_raw).transpose(0, 1).reshape(-1, dists.shape[0], dists.shape[1])  # [K, R, N]
         return (1 - torch.exp(-dists * obj_density)) * transmittance
+
+    # ---------------------------------------------------------------- Stage-2/3 entry points
+    # network.py:1016-1801 is sixteen near-copies of one routine: sample the rays against an object subset, evaluate value +
+    # gradient + colour at the samples, composite with the weights of one SDF (`weights`) and of another (`bg_weights`).
+    # _render_object_rays is that routine; the public methods below keep the reference's names, signatures and return values
+    # (plus an optional `rng=` dict of injected draws, as everywhere in this package).
+    def _render_object_rays(self, cam_loc, ray_dirs, rot, depth_scale, kind, obj_idxs, subset=None, near_far=None, sem_bg_weights=False,
+                            detach_rgb=False, nf_outputs=False, indices=0, rng=None):
+        """kind: "multi" = scene outputs + min over obj_idxs (get_multi_specific_outputs), "only" = everything restricted to
+        obj_idxs, "subset" = outputs over `subset` + min over obj_idxs."""
+        sm, net = self.ray_sampler, self.implicit_network
+        if near_far is None:
+            z_vals, _ = sm.get_z_vals(ray_dirs, cam_loc, self, idx=obj_idxs, rng=rng)
+        else:
+            z_vals, _ = sm.get_z_vals_near_far(ray_dirs, cam_loc, self, near_far[0], near_far[1], idx=obj_idxs, rng=rng)
+        N = z_vals.shape[1]
+        points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+        dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N, -1).reshape(-1, 3)
+        if kind == "multi":
+            sdf, fv, gradients, semantic, sdf_obj = net.get_multi_specific_outputs(points_flat, obj_idxs)
+        elif kind == "only":
+            sdf, fv, gradients, semantic = net.get_only_multi_specific_outputs(points_flat, obj_idxs)
+            sdf_obj = None
+        elif kind == "subset":
+            sdf, fv, gradients, semantic, sdf_obj = net.get_multi_specific_outputs_subset_objs(points_flat, obj_idxs, subset)
+        else:
+            raise ValueError(kind)
+        rgb = self.rendering_network(points_flat, gradients.detach() if detach_rgb else gradients, dirs_flat, fv, indices).reshape(-1, N, 3)
+        semantic = semantic.reshape(-1, N, semantic.shape[-1])
+        weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
+        if kind == "only":
+            w_out = weights
+            opacity_key, opacity = "object_opacity", self.occlusion_opacity(z_vals, transmittance, dists, sdf).sum(-1).transpose(0, 1)
+        else:
+            w_out, _, _ = self.volume_rendering(z_vals, sdf_obj)
+            if kind == "multi":
+                opacity_key, opacity = "object_opacity", self.occlusion_opacity(z_vals, transmittance, dists, sdf_obj).sum(-1).transpose(0, 1)
+            elif nf_outputs:
+                opacity_key, opacity = "opacity", torch.sum(w_out, dim=-1).reshape(-1)
+            else:
+                opacity_key, opacity = "opacity", self.occlusion_opacity(z_vals, transmittance, dists, sdf).sum(-1).transpose(0, 1)
+        rgb_values = torch.sum((w_out.detach() if detach_rgb else w_out).unsqueeze(-1) * rgb, 1)
+        semantic_values = torch.sum((w_out if sem_bg_weights else weights).unsqueeze(-1) * semantic, 1)
+        depth_values = torch.sum(w_out * z_vals, 1, keepdims=True)
+        if not nf_outputs:
+            depth_values = depth_values / (w_out.sum(dim=1, keepdims=True) + 1e-8)
+        output = {"rgb": rgb, "semantic_values": semantic_values, opacity_key: opacity, "rgb_values": rgb_values,
+                  "depth_values": depth_scale * depth_values, "z_vals": z_vals, "depth_vals": z_vals * depth_scale,
+                  "sdf": sdf.reshape(z_vals.shape), "weights": weights}
+        if kind != "only":
+            output["bg_weights"] = w_out
+        normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N, 3)
+        normal_map = torch.sum(w_out.unsqueeze(-1) * normals, 1)
+        output["normal_map"] = (rot @ normal_map.permute(1, 0)).permute(1, 0).contiguous()
+        return output
+
+    @staticmethod
+    def _world_rays(ray_origins, ray_dirs, pose):
+        """Rays given in world space (network.py:1095-1104): normalised directions, world->camera rotation, z of the camera-frame
+        direction as the depth scale."""
+        cam_loc = ray_origins.reshape(-1, 3)
+        ray_dirs = F.normalize(ray_dirs.reshape(-1, 3), dim=-1)
+        rot = pose[..., :3, :3].reshape(3, 3).permute(1, 0).contiguous()
+        depth_scale = (rot @ ray_dirs.permute(1, 0)).permute(1, 0)[:, 2:]
+        return cam_loc, ray_dirs, rot, depth_scale
+
+    def forward_multi_obj(self, input, indices, obj_idxs, iter_step=-1, rng=None):
+        """network.py:1016-1090: pixel rays of one frame rendered against the objects `obj_idxs`."""
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+        ray_dirs_tmp, _ = rend_util.get_camera_params(uv, torch.eye(4, device=pose.device)[None], intrinsics)
+        num_pixels = ray_dirs.shape[1]
+        cam_loc = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
+        rot = pose[0, :3, :3].permute(1, 0).contiguous()
+        return self._render_object_rays(cam_loc, ray_dirs.reshape(-1, 3), rot, ray_dirs_tmp[0, :, 2:], "multi", obj_idxs, indices=indices, rng=rng)
+
+    def forward_multi_obj_rays(self, ray_origins, ray_dirs, pose, obj_idxs, iter_step=-1, sem_bg_weights=False, rng=None):
+        """network.py:1092-1164."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "multi", obj_idxs, sem_bg_weights=sem_bg_weights, rng=rng)
+
+    def forward_only_multi_obj_rays(self, ray_origins, ray_dirs, pose, obj_idxs, iter_step=-1, rng=None):
+        """network.py:1166-1233."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "only", obj_idxs, rng=rng)
+
+    def forward_multi_obj_rays_subset_all_sdf(self, ray_origins, ray_dirs, pose, obj_idxs, subset_obj_idxs, iter_step=-1, rng=None):
+        """network.py:1235-1305."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "subset", obj_idxs, subset=subset_obj_idxs, rng=rng)
+
+    def forward_multi_obj_rays_subset_all_sdf_near_far(self, ray_origins, ray_dirs, pose, obj_idxs, subset_obj_idxs, near, far, iter_step=-1,
+                                                       rng=None):
+        """network.py:1307-1382 (un-normalised depth sum; 'opacity' = sum of the object weights)."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "subset", obj_idxs, subset=subset_obj_idxs,
+                                        near_far=(near, far), nf_outputs=True, rng=rng)
+
+    def forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry(self, ray_origins, ray_dirs, pose, obj_idxs, subset_obj_idxs, iter_step=-1,
+                                                                      rng=None):
+        """network.py:1384-1456: the colour term sees detached normals and detached object weights."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "subset", obj_idxs, subset=subset_obj_idxs,
+                                        detach_rgb=True, rng=rng)
+
+    def forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry_near_far(self, ray_origins, ray_dirs, pose, obj_idxs, subset_obj_idxs, near,
+                                                                               far, iter_step=-1, rng=None):
+        """network.py:1458-1530."""
+        return self._render_object_rays(*self._world_rays(ray_origins, ray_dirs, pose), "subset", obj_idxs, subset=subset_obj_idxs,
+                                        near_far=(near, far), detach_rgb=True, rng=rng)
+
+    def _colors_along_rays(self, points, rays, obj=None, near_far=None, nm=False, rng=None):
+        """Shared body of the get_colors_* family (network.py:1532-1800): rays leaving `points` along `rays`, composited with the
+        weights of the scene SDF (obj None), of one object's own SDF (nm: get_specific_outputs_nm) or of the min over [obj]."""
+        cam_loc = points.reshape(-1, 3)
+        ray_dirs = F.normalize(rays.reshape(-1, 3), dim=-1)
+        sm, net = self.ray_sampler, self.implicit_network
+        idx = None if obj is None else (obj if nm else [obj])
+        if near_far is None:
+            z_vals, _ = sm.get_z_vals(ray_dirs, cam_loc, self, idx=idx, rng=rng)
+        else:
+            z_vals, _ = sm.get_z_vals_near_far(ray_dirs, cam_loc, self, near_far[0], near_far[1], idx=idx, rng=rng)
+        N = z_vals.shape[1]
+        points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+        dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N, -1).reshape(-1, 3)
+        if obj is None:
+            sdf, fv, gradients, semantic, _ = net.get_outputs(points_flat, beta=None)
+        elif nm:
+            sdf, fv, gradients, semantic = net.get_specific_outputs_nm(points_flat, obj)
+        else:
+            sdf, fv, gradients, semantic, _ = net.get_multi_specific_outputs_subset_objs(points_flat, [obj], [obj])
+        rgb = self.rendering_network(points_flat, gradients, dirs_flat, fv, 0).reshape(-1, N, 3)
+        weights, _, _ = self.volume_rendering(z_vals, sdf)
+        return z_vals, weights, torch.sum(weights.unsqueeze(-1) * rgb, 1).reshape(-1, 3), gradients, semantic
+
+    def _normal_map_of(self, weights, gradients, pose):
+        N = weights.shape[1]
+        normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N, 3)
+        rot = pose.reshape(-1, 4)[:3, :3].permute(1, 0).contiguous()
+        return (rot @ torch.sum(weights.unsqueeze(-1) * normals, 1).permute(1, 0)).permute(1, 0).contiguous()
+
+    def get_colors_normals_from_point_rays(self, points, rays, pose, rng=None):
+        """network.py:1532-1569."""
+        _, weights, rgb_values, gradients, _ = self._colors_along_rays(points, rays, rng=rng)
+        return rgb_values, self._normal_map_of(weights, gradients, pose)
+
+    def get_colors_normals_from_point_rays_obj(self, points, rays, pose, obj_idx, rng=None):
+        """network.py:1571-1612: one object's own SDF; also the arg-max label of the composited semantics."""
+        _, weights, rgb_values, gradients, semantic = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
+        sem = torch.sum(weights.unsqueeze(-1) * semantic.reshape(-1, weights.shape[1], self.num_semantic), 1)
+        return rgb_values, self._normal_map_of(weights, gradients, pose), torch.argmax(sem, dim=-1)
+
+    def get_colors_normals_from_point_rays_obj_f(self, points, rays, pose, obj_idx, rng=None):
+        """network.py:1614-1654: as above, the composited semantics themselves."""
+        _, weights, rgb_values, gradients, semantic = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
+        sem = torch.sum(weights.unsqueeze(-1) * semantic.reshape(-1, weights.shape[1], self.num_semantic), 1)
+        return rgb_values, self._normal_map_of(weights, gradients, pose), sem
+
+    def get_colors_from_point_rays(self, points, rays, rng=None):
+        """network.py:1656-1683."""
+        return self._colors_along_rays(points, rays, rng=rng)[2]
+
+    def get_colors_from_point_rays_obj(self, points, rays, obj_i, rng=None):
+        """network.py:1685-1712."""
+        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[2]
+
+    def get_colors_from_point_rays_obj_offset(self, points, rays, obj_i, rng=None):
+        """network.py:1714-1741 (identical to get_colors_from_point_rays_obj in the reference)."""
+        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[2]
+
+    def get_colors_from_point_rays_obj_offset_near_far(self, points, rays, obj_i, near, far, rng=None):
+        """network.py:1743-1770."""
+        return self._colors_along_rays(points, rays, obj=obj_i, near_far=(near, far), rng=rng)[2]
+
+    def get_colors_from_point_rays_obj_debug(self, points, rays, obj_i, rng=None):
+        """network.py:1772-1801: colour and the summed weights per ray."""
+        _, weights, rgb_values, _, _ = self._colors_along_rays(points, rays, obj=obj_i, rng=rng)
+        return rgb_values, torch.sum(weights, 1)
 
     # ---------------------------------------------------------------- forward (network.py:778-971), in stages
     # forward() = prepare_rays -> sample -> (prepare_background) -> render.  The stages exist so the trainer can

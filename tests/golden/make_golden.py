@@ -285,6 +285,81 @@ def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  rounds={len(calls)}  z={tuple(z.shape)}")
 
 
+def run_multi_obj(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
+    """Stage-2/3 entry points of HoloSceneNetwork (network.py:1016-1801): every member of the
+    forward_multi_obj* / get_colors_* family on one small model, with the draws each call made and everything it returned."""
+    torch.manual_seed(seed)
+    conf = small_conf(K, S, beta)
+    model = Net(conf=conf, graph_node_dict=None, num_images=4)
+    model.train(train)
+    perturb(model, seed + 1, scale=1e-3, emb_scale=1e-3)
+    g = torch.Generator().manual_seed(seed + 3)
+    with torch.no_grad():   # geometric init makes all K objects the SAME function (every min a K-way tie): give each its own shape
+        l2 = model.implicit_network.lin2
+        l2.weight_v[:K] += 0.05 * torch.randn(K, l2.weight_v.shape[1], generator=g) * l2.weight_v[:K].abs().mean()
+        l2.bias[:K] += 0.15 * torch.randn(K, generator=g)
+    uv, intr, _ = batch(R, K, res, seed + 2)
+    pose = look_at_pose(eye)
+    from utils import rend_util
+    dirs, loc = rend_util.get_camera_params(uv.clone(), pose, intr)
+    d = dirs.reshape(-1, 3) * (0.5 + torch.rand(R, 1, generator=g))      # un-normalised on purpose: the entry points normalise
+    o = loc[:, None].repeat(1, R, 1).reshape(-1, 3) + 0.02 * torch.randn(R, 3, generator=g)
+    objs, subset, one = [1, 3], [0, 1, 3], 2
+    near, far = 0.05, 1.6
+    inp = {"intrinsics": intr, "uv": uv, "pose": pose}
+    m = model
+    calls = {
+        "fmor": lambda: m.forward_multi_obj_rays(o.clone(), d.clone(), pose, objs),
+        "fmor_sembg": lambda: m.forward_multi_obj_rays(o.clone(), d.clone(), pose, objs, sem_bg_weights=True),
+        "only": lambda: m.forward_only_multi_obj_rays(o.clone(), d.clone(), pose, objs),
+        "subset": lambda: m.forward_multi_obj_rays_subset_all_sdf(o.clone(), d.clone(), pose, objs, subset),
+        "subset_nf": lambda: m.forward_multi_obj_rays_subset_all_sdf_near_far(o.clone(), d.clone(), pose, objs, subset, near, far),
+        "detach": lambda: m.forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry(o.clone(), d.clone(), pose, objs, subset),
+        "detach_nf": lambda: m.forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry_near_far(o.clone(), d.clone(), pose, objs, subset,
+                                                                                                      near, far),
+        "fmo": lambda: m.forward_multi_obj({k: v.clone() for k, v in inp.items()}, torch.tensor([0]), objs),
+        "gcn": lambda: m.get_colors_normals_from_point_rays(o.clone(), d.clone(), pose),
+        "gcn_obj": lambda: m.get_colors_normals_from_point_rays_obj(o.clone(), d.clone(), pose, one),
+        "gcn_obj_f": lambda: m.get_colors_normals_from_point_rays_obj_f(o.clone(), d.clone(), pose, one),
+        "gc": lambda: m.get_colors_from_point_rays(o.clone(), d.clone()),
+        "gc_obj": lambda: m.get_colors_from_point_rays_obj(o.clone(), d.clone(), one),
+        "gc_obj_offset": lambda: m.get_colors_from_point_rays_obj_offset(o.clone(), d.clone(), one),
+        "gc_obj_offset_nf": lambda: m.get_colors_from_point_rays_obj_offset_near_far(o.clone(), d.clone(), one, near, far),
+        "gc_obj_debug": lambda: m.get_colors_from_point_rays_obj_debug(o.clone(), d.clone(), one),
+    }
+    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.train": int(train), "meta.res": res, "meta.near": near, "meta.far": far,
+           "meta.objs": np.array(objs), "meta.subset": np.array(subset), "meta.one": one,
+           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+    to_np("state.", model.state_dict(), rec)
+    to_np("in.", dict(ray_origins=o, ray_dirs=d, pose=pose, uv=uv, intrinsics=intr), rec)
+    names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
+    cot = torch.Generator().manual_seed(seed + 4)
+    for key, fn in calls.items():
+        model.zero_grad()
+        with DrawLog() as log:
+            out = fn()
+        assert len(log.draws) == len(names), (key, [k for k, _ in log.draws])
+        for n, (_, v) in zip(names, log.draws):
+            rec[f"{key}.rand.{n}"] = v.numpy()
+        if isinstance(out, dict):
+            outs = {k: v for k, v in out.items() if torch.is_tensor(v)}
+        else:
+            outs = {f"ret{i}": v for i, v in enumerate(out if isinstance(out, tuple) else (out,))}
+        to_np(f"{key}.out.", outs, rec)
+        if key in ("subset", "detach", "fmor"):   # pins what .detach() changes: gradient of a fixed scalar of the colour and depth outputs
+            c_rgb = torch.randn(outs["rgb_values"].shape, generator=cot)
+            c_dep = torch.randn(outs["depth_values"].shape, generator=cot)
+            # depth = sum(w z) / (sum(w) + 1e-8) is ill-conditioned on rays that miss the objects (sum(w) ~ 1e-8: rounding noise
+            # in the weights becomes the whole gradient); those rays get no depth cotangent
+            c_dep = c_dep * (outs["bg_weights"].sum(dim=1, keepdim=True) > 0.05).float()
+            ((outs["rgb_values"] * c_rgb).sum() + (outs["depth_values"] * c_dep).sum()).backward()
+            rec[f"{key}.cot.rgb_values"], rec[f"{key}.cot.depth_values"] = c_rgb.numpy(), c_dep.numpy()
+            to_np(f"{key}.grad.", {k: p.grad for k, p in model.named_parameters() if p.grad is not None}, rec)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  calls={len(calls)}")
+
+
 def run_hash(name, *, L, base, end, logmap, B, seed, D=3, C=2):
     """Hash-kernel vectors straight from the C oracle (the reference kernels are CUDA-only)."""
     g = torch.Generator().manual_seed(seed)
@@ -324,17 +399,31 @@ def run_tables():
 
 
 def main():
+    """No arguments: every fixture.  With arguments: only the fixtures whose name starts with one of them."""
+    want = sys.argv[1:]
+    sel = lambda name: not want or any(name.startswith(w) for w in want)  # noqa: E731
     Net, Loss = _install_reference()
-    run_tables()
-    run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
-    run_hash("hash_mid", L=8, base=16, end=256, logmap=12, B=400, seed=1)
-    run_iteration(Net, Loss, "iter_k3_bg", K=3, S=16, R=40, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=10)
-    run_iteration(Net, Loss, "iter_k5", K=5, S=16, R=40, beta=0.1, eye=(0.0, 0.1, 0.6), iter_step=3, call_reg=False, seed=20)
+    if sel("hash_tables"):
+        run_tables()
+    if sel("hash_small"):
+        run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
+    if sel("hash_mid"):
+        run_hash("hash_mid", L=8, base=16, end=256, logmap=12, B=400, seed=1)
+    if sel("iter_k3_bg"):
+        run_iteration(Net, Loss, "iter_k3_bg", K=3, S=16, R=40, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=10)
+    if sel("iter_k5"):
+        run_iteration(Net, Loss, "iter_k5", K=5, S=16, R=40, beta=0.1, eye=(0.0, 0.1, 0.6), iter_step=3, call_reg=False, seed=20)
     # (S, beta, eye) chosen by a scan so the sampler takes 1, 2, 3, 4 and 5 rounds
     cases = [(32, 0.3, (0.7, 0, 0)), (64, 0.1, (0.7, 0, 0)), (32, 0.1, (0, 0, 0.6)), (64, 0.01, (0, 0, 0.6)), (32, 0.01, (0.7, 0, 0))]
     for i, (S, beta, eye) in enumerate(cases):
-        run_sampler(Net, f"sampler_{i}", K=2, S=S, R=24, beta=beta, eye=eye, seed=1)
-    run_sampler(Net, "sampler_eval", K=2, S=32, R=24, beta=0.1, eye=(0, 0, 0.6), seed=1, train=False)
+        if sel(f"sampler_{i}"):
+            run_sampler(Net, f"sampler_{i}", K=2, S=S, R=24, beta=beta, eye=eye, seed=1)
+    if sel("sampler_eval"):
+        run_sampler(Net, "sampler_eval", K=2, S=32, R=24, beta=0.1, eye=(0, 0, 0.6), seed=1, train=False)
+    if sel("multi_obj_k5_eval"):
+        run_multi_obj(Net, "multi_obj_k5_eval", K=5, S=16, R=16, beta=0.05, eye=(0.7, 0.0, 0.1), seed=31, train=False)
+    if sel("multi_obj_k5") and (not want or "multi_obj_k5" in want or "multi_obj" in want):
+        run_multi_obj(Net, "multi_obj_k5", K=5, S=16, R=24, beta=0.05, eye=(0.0, 0.1, 0.6), seed=30)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,16 @@ def test_iteration(name):
         close(params[k].detach(), v, 1e-4, 2e-5, "adam1." + k)
 
 
+@pytest.mark.parametrize("name", ["multi_obj_k5", "multi_obj_k5_eval"])
+def test_stage23_entry_points(name):
+    """forward_multi_obj* / get_colors_* (network.py:1016-1801) against what the reference returned."""
+    from model_helpers import check_multi_obj
+    rec = load(name)
+    model = build_model(rec)
+    model.train(bool(rec["meta.train"]))
+    check_multi_obj(model, rec)
+
+
 def test_state_dict_keys_match_reference():
     rec = load("iter_k5")
     model = build_model(rec)

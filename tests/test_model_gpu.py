@@ -771,6 +771,17 @@ def test_resident_batch_gather_equals_indexed_batches():
         assert abs(float(l1["loss"]) - float(l2["loss"])) <= 2e-4 * abs(float(l1["loss"])), (i, float(l1["loss"]), float(l2["loss"]))
 
 
+@pytest.mark.parametrize("name", ["multi_obj_k5", "multi_obj_k5_eval"])
+def test_stage23_entry_points(name):
+    """forward_multi_obj* / get_colors_* (network.py:1016-1801) on the HIP path (fused sampler incl. object-list
+    and near/far variants, hash kernels, value+Jacobian trunk) against what the reference returned, draws injected."""
+    from model_helpers import check_multi_obj
+    rec = load(name)
+    model = build_model(rec, DEV)
+    model.train(bool(rec["meta.train"]))
+    check_multi_obj(model, rec, DEV, rtol=2e-3, atol=5e-4, strict=False)
+
+
 def test_pooled_uniform_draws_equal_explicit_draws():
     """HoloSceneNetwork.draw_uniforms hands raw U[0,1) slices of one generator launch to the kernels, which shift / scale / quantise
     them themselves (hs_ray_setup offset_shift, hs_sampler_final eik_u, hs_render_points eik_scale/shift).  The same iteration fed
