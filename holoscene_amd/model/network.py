@@ -928,10 +928,10 @@ class ObjectImplicitNetworkGrid(nn.Module):
         sdf, k = y.min(dim=-1, keepdim=True)
         return sdf, torch.gather(Jc, 1, k.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
 
-    def _value_jacobian_features(self, x):
+    def _value_jacobian_features(self, x, want_features=True):
         y, J = self.sdf_and_jacobian(x)
         if self.color_grid_feature:
-            return y, J, self._color_features(x)
+            return y[:, :self.d_out], J[:, :self.d_out], (self._color_features(x) if want_features else None)
         return y[:, :self.d_out], J[:, :self.d_out], y[:, self.d_out:]
 
     def get_multi_specific_outputs(self, x, idxs):
@@ -977,6 +977,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return self._trunk(x)[:, idx]
 
     def get_multi_object_sdf_vals(self, x, idxs):
+        if self.color_grid_feature and self._fused_sdf_supported(x):    # all K raw SDFs from the fused matrix-core sweep, then the subset minimum
+            return self._sdf_fused(x, want_raw=True)[1][:, idxs].min(dim=-1, keepdim=True)[0]
         return self._trunk(x)[:, idxs].min(dim=-1, keepdim=True)[0]
 
     def get_sdf_vals_and_sdfs(self, x):
@@ -1115,6 +1117,18 @@ class HoloSceneNetwork(nn.Module):
         obj_density = self.density(sdf_raw).transpose(0, 1).reshape(-1, dists.shape[0], dists.shape[1])  # [K, R, N]
         return (1 - torch.exp(-dists * obj_density)) * transmittance
 
+    def _rgb_at(self, points_flat, dirs_flat, gradients, indices=None, x01=None):
+        """Colour of every sample [B,3]: colour hash grid -> feature MLP -> rendering network, through the fused matrix-core kernels
+        (csrc/appearance_mlp.hip) when the shapes are the stock ones in bf16 mode, else library GEMMs."""
+        net = self.implicit_network
+        if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
+            enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
+            R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
+            return _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
+                                           int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
+                                           mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias, R2, rn.lin2.bias, x01)
+        return self.rendering_network(points_flat, gradients, dirs_flat, net._color_features(points_flat), indices)
+
     # ---------------------------------------------------------------- Stage-2/3 entry points (SURVEY 8f rank 1)
     # network.py:1016-1801 is sixteen near-copies of one routine: sample the rays against an object subset, evaluate value +
     # gradient + colour at the samples, composite with the weights of one SDF (`weights`) and of another (`bg_weights`).
@@ -1132,16 +1146,20 @@ class HoloSceneNetwork(nn.Module):
         N = z_vals.shape[1]
         points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
         dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N, -1).reshape(-1, 3)
-        if kind == "multi":
-            sdf, fv, gradients, semantic, sdf_obj = net.get_multi_specific_outputs(points_flat, obj_idxs)
-        elif kind == "only":
-            sdf, fv, gradients, semantic = net.get_only_multi_specific_outputs(points_flat, obj_idxs)
-            sdf_obj = None
-        elif kind == "subset":
-            sdf, fv, gradients, semantic, sdf_obj = net.get_multi_specific_outputs_subset_objs(points_flat, obj_idxs, subset)
-        else:
+        # one value+Jacobian pass; the variants of network.py:359-435 only choose the columns each minimum runs over (the net-level
+        # get_*_outputs methods do the same and also return the colour features; here the colour goes through _rgb_at instead)
+        sdf_raw, J, fv = net._value_jacobian_features(points_flat, want_features=not net.color_grid_feature)
+        cols = {"multi": None, "only": obj_idxs, "subset": subset}[kind]
+        if kind not in ("multi", "only", "subset"):
             raise ValueError(kind)
-        rgb = self.rendering_network(points_flat, gradients.detach() if detach_rgb else gradients, dirs_flat, fv, indices).reshape(-1, N, 3)
+        sdf, gradients = net._subset_min(sdf_raw, J, cols)
+        semantic = net.sigmoid * torch.sigmoid(-net.sigmoid * (sdf_raw if cols is None else sdf_raw[:, cols]))
+        sdf_obj = None if kind == "only" else sdf_raw[:, obj_idxs].min(dim=-1, keepdim=True)[0]
+        g_rgb = gradients.detach() if detach_rgb else gradients
+        if fv is None:
+            rgb = self._rgb_at(points_flat, dirs_flat, g_rgb, indices).reshape(-1, N, 3)
+        else:
+            rgb = self.rendering_network(points_flat, g_rgb, dirs_flat, fv, indices).reshape(-1, N, 3)
         semantic = semantic.reshape(-1, N, semantic.shape[-1])
         weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
         if kind == "only":
@@ -1234,13 +1252,16 @@ class HoloSceneNetwork(nn.Module):
         N = z_vals.shape[1]
         points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
         dirs_flat = ray_dirs.unsqueeze(1).expand(-1, N, -1).reshape(-1, 3)
-        if obj is None:
-            sdf, fv, gradients, semantic, _ = net.get_outputs(points_flat, beta=None)
-        elif nm:
-            sdf, fv, gradients, semantic = net.get_specific_outputs_nm(points_flat, obj)
+        sdf_raw, J, fv = net._value_jacobian_features(points_flat, want_features=not net.color_grid_feature)
+        if nm:        # one object's own SDF and gradient, no minimum (get_specific_outputs_nm)
+            sdf, gradients = sdf_raw[:, obj], J[:, obj]
+        else:         # scene minimum (get_outputs) or the minimum over [obj] (get_multi_specific_outputs_subset_objs)
+            sdf, gradients = net._subset_min(sdf_raw, J, None if obj is None else [obj])
+        semantic = net.sigmoid * torch.sigmoid(-net.sigmoid * (sdf_raw if (obj is None or nm) else sdf_raw[:, [obj]]))
+        if fv is None:
+            rgb = self._rgb_at(points_flat, dirs_flat, gradients, 0).reshape(-1, N, 3)
         else:
-            sdf, fv, gradients, semantic, _ = net.get_multi_specific_outputs_subset_objs(points_flat, [obj], [obj])
-        rgb = self.rendering_network(points_flat, gradients, dirs_flat, fv, 0).reshape(-1, N, 3)
+            rgb = self.rendering_network(points_flat, gradients, dirs_flat, fv, 0).reshape(-1, N, 3)
         weights, _, _ = self.volume_rendering(z_vals, sdf)
         return z_vals, weights, torch.sum(weights.unsqueeze(-1) * rgb, 1).reshape(-1, 3), gradients, semantic
 
@@ -1476,17 +1497,7 @@ class HoloSceneNetwork(nn.Module):
             min_eik = gtheta = None
         if not net.color_grid_feature:
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
-        if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
-            enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
-            R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
-            rgb = _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
-                                          int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
-                                          mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias, R2, rn.lin2.bias,
-                                          None if x01_all is None else x01_all[:n_main])
-            rgb = rgb.reshape(-1, N_samples, 3)
-        else:
-            feature_vectors = net._color_features(points_flat)
-            rgb = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors, indices).reshape(-1, N_samples, 3)
+        rgb = self._rgb_at(points_flat, dirs_flat, gradients, indices, None if x01_all is None else x01_all[:n_main]).reshape(-1, N_samples, 3)
         if COMPOSITE_IMPL == "hip":
             if not z_vals.is_cuda:
                 raise RuntimeError("fused compositing needs CUDA tensors (set HOLOSCENE_COMPOSITE_IMPL=torch explicitly for the "

@@ -782,6 +782,38 @@ def test_stage23_entry_points(name):
     check_multi_obj(model, rec, DEV, rtol=2e-3, atol=5e-4, strict=False)
 
 
+def test_stage23_entry_points_fused_colour_path(monkeypatch):
+    """The Stage-2/3 entry points on the stock-shaped bf16 model: colour through the matrix-core appearance kernels vs through
+    library GEMMs, same depths (the sampler is made to answer with fixed depths), values and table gradients."""
+    from holoscene_amd.model import network as N
+    tr, _ = _full_graph_trainer(0.02, True)
+    model = tr.model.train()
+    R = 256
+    g = torch.Generator().manual_seed(2)
+    o = (torch.randn(R, 3, generator=g) * 0.05 + torch.tensor([0.7, 0.0, 0.0])).to(DEV)
+    d = -o + torch.randn(R, 3, generator=g).to(DEV) * 0.3
+    pose = torch.eye(4, device=DEV)[None]
+    z_fix = torch.sort(torch.rand(R, 40, generator=g) * 1.5 + 0.05, dim=1).values.to(DEV)
+    sm = model.ray_sampler
+    monkeypatch.setattr(sm, "get_z_vals", lambda *a, **k: (z_fix, None))
+    monkeypatch.setattr(sm, "get_z_vals_near_far", lambda *a, **k: (z_fix, None))
+    table = model.implicit_network.color_encoding.embeddings
+    res = {}
+    for impl in ("gemm", "mfma"):
+        monkeypatch.setattr(N, "APPEARANCE_IMPL", impl)
+        outs = [model.forward_multi_obj_rays_subset_all_sdf(o, d, pose, [1, 2], [0, 1, 2]),
+                model.forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry(o, d, pose, [1, 2], [0, 1, 2]),
+                {"rgb_values": model.get_colors_normals_from_point_rays_obj(o, d, pose, 2)[0]}]
+        val = sum(out["rgb_values"].square().sum() for out in outs)
+        tr.flat.zero_grad()          # (the flat optimiser's tables receive their gradient in place, not through autograd's return path)
+        val.backward()
+        res[impl] = ([out["rgb_values"].detach() for out in outs], table.grad.detach().clone())
+    for a, b in zip(res["mfma"][0], res["gemm"][0]):
+        close(a, b, 2e-2, 2e-2, "rgb_values")
+    rel = float((res["mfma"][1] - res["gemm"][1]).norm() / res["gemm"][1].norm())
+    assert rel < 0.1, rel
+
+
 def test_pooled_uniform_draws_equal_explicit_draws():
     """HoloSceneNetwork.draw_uniforms hands raw U[0,1) slices of one generator launch to the kernels, which shift / scale / quantise
     them themselves (hs_ray_setup offset_shift, hs_sampler_final eik_u, hs_render_points eik_scale/shift).  The same iteration fed
