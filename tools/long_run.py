@@ -9,8 +9,7 @@ benchmark_model_state(tr.model, 0.1)
 scene = SyntheticScene(1024, 32, num_frames=8, ring=64, device='cuda')
 t0 = time.time()
 for it in range(n):
-    idx, mi, gt = scene.next_batch()
-    out, lo = tr.train_step(idx, mi, gt)
+    out, lo = tr.train_step_resident(scene)
     if it % 100 == 0 or it == n - 1:
         torch.cuda.synchronize()
         st = tr.flat.read_state()
