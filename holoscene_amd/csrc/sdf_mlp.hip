@@ -77,7 +77,7 @@ template <int NOUT_TILES>  // d_out padded to 32 * NOUT_TILES
 __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0,
                                                        const float *__restrict__ b0, const uint16_t *__restrict__ W1,
                                                        const float *__restrict__ b1, const uint16_t *__restrict__ W2,
-                                                       const float *__restrict__ b2, int d_out, int select, float *__restrict__ out_min,
+                                                       const float *__restrict__ b2, int d_out, int select, uint64_t select_mask, float *__restrict__ out_min,
                                                        float *__restrict__ out_raw, int64_t B, hsGate gate, int feat_level_major) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
@@ -191,8 +191,9 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
                     if (n < d_out) {
                         const float v = y[t][i] + bias[2 * HID + n];
                         if (out_raw) park[n] = v;
-                        if (select < 0) best = fminf(best, v);
-                        else if (n == select) best = v;
+                        // scene minimum (select < 0, no mask), one object (select >= 0), or the minimum over an object subset (mask)
+                        const bool take = select_mask ? ((select_mask >> n) & 1ull) != 0ull : (select < 0 || n == select);
+                        if (take) best = fminf(best, v);
                     }
                 }
             const float other = __shfl_xor(best, 32);
@@ -538,9 +539,11 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 extern "C" {
 
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
+                   const float *b2, int32_t d_out, int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate,
+                   int32_t feat_level_major,
                    void *stream) {
     if (d_out < 1 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
+    if (select_mask && d_out < 64 && (select_mask >> d_out)) return HS_ERR_ARG;   // a bit beyond the last object
     if (B == 0) return HS_OK;
     if (!x || !feat || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out_min) return HS_ERR_NULL;
     const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t) + (2 * HID + 64) * sizeof(float);
@@ -550,12 +553,12 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
     if (d_out <= 32) {
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        k_sdf_mlp<1><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
+        k_sdf_mlp<1><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select, select_mask,
                                                    out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
-        k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select,
+        k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select, select_mask,
                                                    out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     }
     return check_launch();

@@ -358,10 +358,18 @@ class _HipBackend:
     # ---- fused SDF-trunk inference (include/holoscene_hip.h section 7)
     @staticmethod
     def sdf_mlp_fwd(x, feat, W0, b0, W1, b1, W2, b2, d_out, select, out_min, out_raw, gate=None, feat_level_major=False):
+        """select: -1 = min over all objects, k = object k, or a list / tuple of objects = min over that subset."""
         lib = load_library()
         bf = torch.bfloat16
+        mask = 0
+        if isinstance(select, (list, tuple)):
+            if not select or min(select) < 0 or max(select) >= d_out:
+                raise ValueError(f"object subset {select!r} outside [0, {d_out})")
+            for k in select:
+                mask |= 1 << int(k)
+            select = -1
         _check(lib.hs_sdf_mlp_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0, "W0", bf), _dev(b0, "b0"), _dev(W1, "W1", bf), _dev(b1, "b1"),
-                                  _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
+                                  _dev(W2, "W2", bf), _dev(b2, "b2"), d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                   ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp_fwd")
 
     @staticmethod

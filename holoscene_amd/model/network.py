@@ -792,7 +792,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         self._packed_cache = None
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
-        """min_k sdf_k (or sdf_select) [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
+        """min_k sdf_k (select -1), sdf_select (int) or the minimum over an object list [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
         x = x.contiguous().float()
         B = x.shape[0]
         enc = self.encoding
@@ -811,7 +811,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return out, raw
 
     def sdf_along_rays(self, cam_loc, ray_dirs, z, select=-1, gate=None):
-        """Scene SDF (select < 0: min over objects; else that object's) at cam_loc + z*ray_dirs, [R,S] -> [R,S]: the sampler's
+        """Scene SDF (select < 0: min over objects; int: that object's; list: min over those objects) at cam_loc + z*ray_dirs, [R,S] -> [R,S]: the sampler's
         per-round query (ray_sampler.py:151-157) in three launches -- positions, hash encode, fused matrix-core trunk.
         gate: optional device-side launch gate (backend.hsGate) shared by the three kernels."""
         R, S = z.shape
@@ -977,8 +977,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return self._trunk(x)[:, idx]
 
     def get_multi_object_sdf_vals(self, x, idxs):
-        if self.color_grid_feature and self._fused_sdf_supported(x):    # all K raw SDFs from the fused matrix-core sweep, then the subset minimum
-            return self._sdf_fused(x, want_raw=True)[1][:, idxs].min(dim=-1, keepdim=True)[0]
+        if self.color_grid_feature and self._fused_sdf_supported(x):    # the subset minimum inside the fused matrix-core sweep (object bit mask)
+            return self._sdf_fused(x, select=list(idxs))[0]
         return self._trunk(x)[:, idxs].min(dim=-1, keepdim=True)[0]
 
     def get_sdf_vals_and_sdfs(self, x):

@@ -169,7 +169,8 @@ class ErrorBoundSampler(RaySampler):
 
     def device_control_ok(self, model, idx=None):
         net = model.implicit_network
-        return (CONTROL == "device" and SAMPLER_IMPL == "hip" and (idx is None or isinstance(idx, int)) and getattr(net, "color_grid_feature", False)
+        ok_idx = idx is None or isinstance(idx, int) or (isinstance(idx, (list, tuple)) and len(idx) > 0 and all(isinstance(k, int) for k in idx))
+        return (CONTROL == "device" and SAMPLER_IMPL == "hip" and ok_idx and getattr(net, "color_grid_feature", False)
                 and hasattr(net, "_fused_trunk_supported") and net._fused_trunk_supported(net.encoding.embeddings))
 
     def _query_sdf(self, model, points, idx):
@@ -359,7 +360,7 @@ class ErrorBoundSampler(RaySampler):
         sdf = torch.empty(R, ld, device=dev)
         cam = (cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc).contiguous()
         dirs = ray_dirs.contiguous()
-        sel = -1 if idx is None else idx
+        sel = -1 if idx is None else (list(idx) if isinstance(idx, (list, tuple)) else idx)
         samples = z0.contiguous()
         df = float(net.divide_factor)
         if x0 is None:

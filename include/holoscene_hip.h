@@ -277,9 +277,11 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
  *   bf16 (rows >= d_out zero) PRE-MULTIPLIED by ln2/100 -- the kernel evaluates Softplus(beta=100) as log2(1 + 2^t) on
  *   t = 100*log2(e)*v (hs_pack_bf16's per-job `scale` does this); the biases are passed unscaled,
  *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
- *   out_min [B] = min_k y_k (select < 0) or y_select; out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
+ *   out_min [B] = min_k y_k (select < 0) or y_select, or -- select_mask != 0 -- the minimum over the objects whose bit is set
+ *   (get_multi_object_sdf_vals, network.py:320-326); out_raw [B,d_out] optional (NULL = skip).  d_out <= 64. */
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
-                   const float *b2, int32_t d_out, int32_t select, float *out_min, float *out_raw, int64_t B, const hsGate *gate /* NULL = none */,
+                   const float *b2, int32_t d_out, int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B,
+                   const hsGate *gate /* NULL = none */,
                    int32_t feat_level_major /* 0: feat [B,32]; 1: feat [16,B,2] (level-major, as hs_hash_fwd writes fully coalesced) */, void *stream);
 
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus

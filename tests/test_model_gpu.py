@@ -814,6 +814,39 @@ def test_stage23_entry_points_fused_colour_path(monkeypatch):
     assert rel < 0.1, rel
 
 
+@pytest.mark.parametrize("idx", [[1, 2], [3], 2])
+def test_object_subset_sampler_device_vs_host_control(idx, monkeypatch):
+    """Algorithm 1 against an object subset (the Stage-2/3 entry points' sampler call, ray_sampler.py:151-157 with idx = list): the
+    subset minimum is taken inside the fused SDF sweep (object bit mask of hs_sdf_mlp_fwd), so the device-controlled loop applies;
+    it must place exactly the depths the host-controlled loop places, and the masked sweep must equal min over the raw columns."""
+    from holoscene_amd.model import ray_sampler as RS
+    tr, scene = _full_graph_trainer(0.01, True)
+    model = tr.model.train()
+    _, ins, _ = scene.next_batch()
+    with torch.no_grad():
+        rays = model.prepare_rays(ins)
+    net = model.implicit_network
+    pts = torch.rand(5000, 3, device=DEV) * 1.6 - 0.8
+    with torch.no_grad():
+        raw = net.get_sdf_raw(pts)
+        cols = idx if isinstance(idx, list) else [idx]
+        got = net.get_multi_object_sdf_vals(pts, cols)
+    assert torch.equal(got, raw[:, cols].min(dim=-1, keepdim=True)[0])
+    g = torch.Generator().manual_seed(4)
+    R, S, n, ne = rays["ray_dirs"].shape[0], model.ray_sampler.N_samples_eval, model.ray_sampler.N_samples, model.ray_sampler.N_samples_extra
+    res = {}
+    for control in ("host", "device"):
+        monkeypatch.setattr(RS, "CONTROL", control)
+        assert model.ray_sampler.device_control_ok(model, idx) == (control == "device")
+        g.manual_seed(4)
+        rng = {"t_rand": torch.rand(R, S, generator=g).to(DEV), "u_final": torch.rand(R, n, generator=g).to(DEV),
+               "perm": torch.randperm(S * 5, generator=g)[:S].to(DEV), "eik_idx": torch.randint(n + 2 + ne, (R,), generator=g).to(DEV)}
+        z, z_eik = model.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], model, idx=idx, rng=rng)
+        res[control] = (z, z_eik, int(model.ray_sampler.last_rounds))
+    assert res["host"][2] == res["device"][2]
+    assert torch.equal(res["host"][0], res["device"][0]) and torch.equal(res["host"][1], res["device"][1])
+
+
 def test_pooled_uniform_draws_equal_explicit_draws():
     """HoloSceneNetwork.draw_uniforms hands raw U[0,1) slices of one generator launch to the kernels, which shift / scale / quantise
     them themselves (hs_ray_setup offset_shift, hs_sampler_final eik_u, hs_render_points eik_scale/shift).  The same iteration fed

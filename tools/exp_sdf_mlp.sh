@@ -17,7 +17,7 @@ b0 = torch.zeros(256, device=dev); b1 = torch.zeros(256, device=dev); b2 = torch
 out = torch.empty(B, device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 def run():
-    lib.hs_sdf_mlp_fwd(p(x), p(feat), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, -1, p(out), None, ctypes.c_int64(B), None)
+    lib.hs_sdf_mlp_fwd(p(x), p(feat), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, -1, ctypes.c_uint64(0), p(out), None, ctypes.c_int64(B), None)
 for _ in range(3): run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -32,7 +32,7 @@ def t(fn):
 B = 131072
 x = torch.rand(B, 3, device=dev) * 2 - 1; feat = torch.randn(B, 32, device=dev) * 1e-3; out = torch.empty(B, device=dev)
 def sdf():
-    lib.hs_sdf_mlp_fwd(p(x), p(feat), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, -1, p(out), None, ctypes.c_int64(B), None, 0, None)
+    lib.hs_sdf_mlp_fwd(p(x), p(feat), p(w0), p(b0), p(w1), p(b1), p(w2), p(b2), 32, -1, ctypes.c_uint64(0), p(out), None, ctypes.c_int64(B), None, 0, None)
 print("$v fwd", t(fwd), "us  bwd", t(bwd), "us  sdf_mlp", t(sdf), "us")
 PY
 done
