@@ -205,6 +205,8 @@ class ErrorBoundSampler(RaySampler):
         beta_init = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
         bounds = (near_t.reshape(-1).contiguous().float(), far_t.reshape(-1).contiguous().float())
         if SAMPLER_IMPL == "hip":
+            if ray_dirs.is_cuda and self.device_control_ok(model, idx):
+                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng, z0.contiguous(), beta_init, bounds=bounds)
             return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng, z0.contiguous(), beta_init, bounds=bounds)
         if SAMPLER_IMPL != "torch":
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
@@ -332,7 +334,7 @@ class ErrorBoundSampler(RaySampler):
         return z_out, z_eik
 
 
-    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, x0=None):
+    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, x0=None, bounds=None):
         """Algorithm 1 with device-side loop control: max_total_iters unrolled rounds of gated kernels, zero host syncs."""
         be = _be._backend
         dev = ray_dirs.device
@@ -409,7 +411,8 @@ class ErrorBoundSampler(RaySampler):
             eik = torch.randint(n_out, (R,), device=dev)
         z_out = torch.empty(R, n_out, device=dev)
         z_eik = torch.empty(R, 1, device=dev)
-        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u)
+        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u,
+                         near_rays=None if bounds is None else bounds[0], far_rays=None if bounds is None else bounds[1])
         net.invalidate_packed_weights()
         self._rounds = ci[nr, 3:4]
         return z_out, z_eik

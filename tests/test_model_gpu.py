@@ -842,9 +842,14 @@ def test_object_subset_sampler_device_vs_host_control(idx, monkeypatch):
         rng = {"t_rand": torch.rand(R, S, generator=g).to(DEV), "u_final": torch.rand(R, n, generator=g).to(DEV),
                "perm": torch.randperm(S * 5, generator=g)[:S].to(DEV), "eik_idx": torch.randint(n + 2 + ne, (R,), generator=g).to(DEV)}
         z, z_eik = model.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], model, idx=idx, rng=rng)
-        res[control] = (z, z_eik, int(model.ray_sampler.last_rounds))
+        near = (torch.rand(R, 1, generator=g) * 0.2).to(DEV)
+        far = (1.2 + torch.rand(R, 1, generator=g)).to(DEV)
+        zb, zb_eik = model.ray_sampler.get_z_vals_near_far(rays["ray_dirs"], rays["cam_loc"], model, near, far, idx=idx, rng=rng)
+        assert torch.equal(zb[:, :1], near) and torch.equal(zb[:, -1:], far)
+        res[control] = (z, z_eik, int(model.ray_sampler.last_rounds), zb, zb_eik)
     assert res["host"][2] == res["device"][2]
-    assert torch.equal(res["host"][0], res["device"][0]) and torch.equal(res["host"][1], res["device"][1])
+    for i in (0, 1, 3, 4):      # free sampling and sampling between supplied per-ray bounds: identical depths either way
+        assert torch.equal(res["host"][i], res["device"][i]), i
 
 
 def test_pooled_uniform_draws_equal_explicit_draws():
