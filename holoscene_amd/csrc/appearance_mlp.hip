@@ -373,6 +373,19 @@ struct SumJobs { hsSumJob j[HS_PACK_MAX_JOBS]; };
 
 __global__ __launch_bounds__(256) void k_sum_slices(SumJobs jobs) {
     const hsSumJob jb = jobs.j[blockIdx.y];
+    if (jb.src_f32) {   // fp32 slices (n % 4 == 0)
+        const float *sf = reinterpret_cast<const float *>(jb.src);
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < jb.n; i += (int64_t)gridDim.x * 256 * 4) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int s_ = 0; s_ < jb.slices; s_++) {
+                const float4 v = *reinterpret_cast<const float4 *>(sf + (size_t)s_ * jb.n + i);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(jb.dst + i) = a;
+        }
+        return;
+    }
     const uint16_t *src = reinterpret_cast<const uint16_t *>(jb.src);
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < jb.n; i += (int64_t)gridDim.x * 256 * 4) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;

@@ -430,13 +430,24 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                                                          uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
                                                          float *__restrict__ gb0, const uint16_t *__restrict__ W0t, float *__restrict__ g_feat,
                                                          float *__restrict__ g_dydx, int L, int C, float jac_scale, int64_t M,
-                                                         float *__restrict__ gb2) {
+                                                         float *__restrict__ gb2, float *__restrict__ dW2_part) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
+    constexpr int GP = KP + 8;                                   // row pitch of the side copy of the output-cotangent tile
+    uint16_t *Gs = Wc + 2 * (size_t)HID * WP;                     // [BM][GP], only when dW2_part != NULL (the launcher sizes the LDS)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = wave & 3, ph = wave >> 2;
     float sum1 = 0.f, sum0 = 0.f, sum2 = 0.f;
+    // last layer's weight gradient dW2 = g^T . H1 (reduction over the ROWS): both operand tiles sit in LDS once H1 has been staged, so the
+    // wave owning 32 of the 256 columns accumulates its [KP x 32] block over all tiles of the workgroup in registers (16 VGPRs per 32
+    // outputs) instead of a library GEMM re-reading H1 (214 MB) and g.  The fragments run along the rows of row-major tiles, hence 2-byte
+    // LDS reads (8 per operand and k-step): ~3 % more work in this kernel for one GEMM launch (66 us) less.
+    f32x16 accW[KP / 32];
+#pragma unroll
+    for (int mt = 0; mt < KP / 32; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) accW[mt][i] = 0.f;
     const int64_t ntiles = (M + BM - 1) / BM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (r0 + row < M) v = *reinterpret_cast<const uint4 *>(g + (size_t)(r0 + row) * KP + seg * 8);
             *reinterpret_cast<uint4 *>(H + (size_t)row * HP + seg * 8) = v;
+            if (dW2_part) *reinterpret_cast<uint4 *>(Gs + (size_t)row * GP + seg * 8) = v;
         }
         __syncthreads();
         if (gb2) {   // last layer's bias gradient: column sums of the VALUE rows of the output cotangent (thread = column x row group)
@@ -458,6 +470,26 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         layer_mma<HP, 32>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
         __syncthreads();
+        if (dW2_part) {   // H = H1 tile, Gs = g tile: accW[kout][col] += sum_rows g[row][kout] * H1[row][col], this wave's 32 columns
+            const uint16_t *hcol = H + wave * 32 + (lane & 31);
+#pragma unroll 2
+            for (int ks = 0; ks < BM / 16; ks++) {
+                const int rb = ks * 16 + (lane >> 5) * 8;
+                uint32_t bw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bw[j] = (uint32_t)hcol[(size_t)(rb + 2 * j) * HP] | ((uint32_t)hcol[(size_t)(rb + 2 * j + 1) * HP] << 16);
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(bw);
+#pragma unroll
+                for (int mt = 0; mt < KP / 32; mt++) {
+                    const uint16_t *gcol = Gs + mt * 32 + (lane & 31);
+                    uint32_t aw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) aw[j] = (uint32_t)gcol[(size_t)(rb + 2 * j) * GP] | ((uint32_t)gcol[(size_t)(rb + 2 * j + 1) * GP] << 16);
+                    accW[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(aw), bfrag, accW[mt], 0, 0, 0);
+                }
+            }
+            __syncthreads();   // the epilogue below rewrites H in place
+        }
         epilogue_bwd(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, gA1, r0, M);
@@ -514,6 +546,13 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             }
         }
         __syncthreads();
+    }
+    if (dW2_part) {   // this workgroup's slice [KP][256]; lane: column wave*32 + (lane & 31), outputs (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+        float *dst = dW2_part + (size_t)blockIdx.x * KP * HID + wave * 32 + (lane & 31);
+#pragma unroll
+        for (int mt = 0; mt < KP / 32; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) dst[(size_t)(mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * HID] = accW[mt][i];
     }
     if (threadIdx.x < HID) {
         if (gb1) unsafeAtomicAdd(gb1 + threadIdx.x, sum1);
@@ -589,27 +628,32 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
     return check_launch();
 }
 
+int32_t hs_trunk_bwd_parts(int64_t M) {
+    const int64_t ntiles = (M + BM - 1) / BM;
+    return (int32_t)(ntiles < kGridCap ? ntiles : kGridCap);
+}
+
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale, int64_t M,
-                     float *gb2, void *stream) {
+                     float *gb2, float *dW2_part, void *stream) {
     if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
     if (W0t && (L < 1 || C < 1 || L * C != NFEAT)) return HS_ERR_ARG;
     if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0 || (W0t && (!g_feat || !g_dydx))) return HS_ERR_NULL;
-    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uint16_t);
+    const size_t lds = ((size_t)BM * HP + 2 * (size_t)HID * WP + (dW2_part ? (size_t)BM * (g_pitch + 8) : 0)) * sizeof(uint16_t);
     const int64_t ntiles = (M + BM - 1) / BM;
-    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
+    const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);   // == hs_trunk_bwd_parts(M)
     hipStream_t st = (hipStream_t)stream;
     if (g_pitch == 32) {
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part);
     }
     return check_launch();
 }

@@ -38,7 +38,7 @@ class hsPackJob(ctypes.Structure):
 
 
 class hsSumJob(ctypes.Structure):
-    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32)]
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32), ("src_f32", ctypes.c_int32)]
 
 
 class hsWnJob(ctypes.Structure):
@@ -86,7 +86,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
 
 
 def _check(rc, what):
@@ -435,13 +435,16 @@ class _HipBackend:
 
     @staticmethod
     def sum_slices(partials):
-        """partials: list of bf16 tensors [S, ...]; returns the fp32 sums over dim 0, all in one launch."""
+        """partials: list of bf16 or fp32 tensors [S, ...]; returns the fp32 sums over dim 0, all in one launch."""
         lib = load_library()
         arr = (hsSumJob * len(partials))()
         outs = []
         for a, t in zip(arr, partials):
             out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
-            a.src, a.dst, a.n, a.slices = _dev(t, "partials", torch.bfloat16).value, _dev(out, "out").value, out.numel(), t.shape[0]
+            a.src, a.dst, a.n, a.slices = _dev(t, "partials", t.dtype).value, _dev(out, "out").value, out.numel(), t.shape[0]
+            if t.dtype not in (torch.bfloat16, torch.float32):
+                raise RuntimeError("sum_slices: bf16 or fp32 slices expected")
+            a.src_f32 = int(t.dtype == torch.float32)
             outs.append(out)
         _check(lib.hs_sum_slices(arr, len(partials), _stream()), "hs_sum_slices")
         return outs
@@ -493,13 +496,21 @@ class _HipBackend:
                                     _stream()), "hs_trunk_mlp_fwd")
 
     @staticmethod
-    def trunk_mlp_bwd(g, H1, H0, W2t, W1t, gA1, gA0, gb1, gb0, W0t=None, g_feat=None, g_dydx=None, L=0, C=0, jac_scale=0.0, gb2=None):
+    def trunk_bwd_parts(M):
+        return int(load_library().hs_trunk_bwd_parts(ctypes.c_int64(M)))
+
+    @staticmethod
+    def trunk_mlp_bwd(g, H1, H0, W2t, W1t, gA1, gA0, gb1, gb0, W0t=None, g_feat=None, g_dydx=None, L=0, C=0, jac_scale=0.0, gb2=None,
+                      dW2_part=None):
+        """dW2_part: optional fp32 [trunk_bwd_parts(M), g.shape[1], 256] receiving per-workgroup slices of g^T . H1."""
         lib = load_library()
         bf = torch.bfloat16
+        if dW2_part is not None and tuple(dW2_part.shape) != (_HipBackend.trunk_bwd_parts(g.shape[0]), g.shape[-1], 256):
+            raise RuntimeError("trunk_mlp_bwd: dW2_part has the wrong shape")
         _check(lib.hs_trunk_mlp_bwd(_dev(g, "g", bf), g.shape[-1], _dev(H1, "H1", bf), _dev(H0, "H0", bf), _dev(W2t, "W2t", bf),
                                     _dev(W1t, "W1t", bf), _dev(gA1, "gA1", bf), _dev(gA0, "gA0", bf), _dev(gb1, "gb1"), _dev(gb0, "gb0"),
                                     _dev(W0t, "W0t", bf), _dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), L, C, ctypes.c_float(jac_scale),
-                                    ctypes.c_int64(g.shape[0]), _dev(gb2, "gb2"), _stream()), "hs_trunk_mlp_bwd")
+                                    ctypes.c_int64(g.shape[0]), _dev(gb2, "gb2"), _dev(dW2_part, "dW2_part"), _stream()), "hs_trunk_mlp_bwd")
 
     @staticmethod
     def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta):

@@ -130,6 +130,7 @@ class _trunk_input(torch.autograd.Function):
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
 TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+TRUNK_W2_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_W2_IN_KERNEL", "1") == "1"   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
 _FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
 _BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
 # 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
@@ -146,8 +147,9 @@ def _wgrad_rows(g, x):
     return (g.t() @ x).float()
 
 
-def _wgrad_rows_many(pairs):
-    """[_wgrad_rows(g, x) for g, x in pairs] with the slice sums of all of them in ONE launch (hs_sum_slices)."""
+def _wgrad_rows_many(pairs, ready_parts=()):
+    """[_wgrad_rows(g, x) for g, x in pairs] with the slice sums of all of them in ONE launch (hs_sum_slices); `ready_parts` are
+    slice stacks some kernel already produced (k_trunk_bwd's dW2 slices): their sums are appended to the result."""
     parts, direct = [], {}
     for i, (g, x) in enumerate(pairs):
         M = x.shape[0]
@@ -156,10 +158,11 @@ def _wgrad_rows_many(pairs):
             parts.append((i, torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1))))
         else:
             direct[i] = _wgrad_rows(g, x)
-    sums = _be._backend.sum_slices([p for _, p in parts]) if parts else []
+    stacks = [p for _, p in parts] + list(ready_parts)
+    sums = _be._backend.sum_slices(stacks) if stacks else []
     for (i, _), s_ in zip(parts, sums):
         direct[i] = s_
-    return [direct[i] for i in range(len(pairs))]
+    return [direct[i] for i in range(len(pairs))] + sums[len(parts):]
 
 
 def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
@@ -220,8 +223,10 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
         g_feat = torch.empty(L, B, C, device=dev, dtype=torch.float32)     # level-major: coalesced for both writer and scatter
         g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
+    # the last layer's weight gradient g^T . H1 is accumulated by the same kernel (per-workgroup slices, summed with the GEMM partials below)
+    w2_part = torch.empty(_be._backend.trunk_bwd_parts(M), KP, 256, device=dev) if (need_w and TRUNK_W2_IN_KERNEL) else None
     _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale,
-                               gb2=gb2k if gb2 is _FROM_KERNEL else None)
+                               gb2=gb2k if gb2 is _FROM_KERNEL else None, dW2_part=w2_part)
     if gb2 is _FROM_KERNEL:
         gb2 = gb2k[:d_out]
 
@@ -243,7 +248,10 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
             table_branch()
     gW2 = gW1 = gW0 = None
     if need_w:
-        gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))])
+        if w2_part is not None:
+            gW1, gW0, gW2 = _wgrad_rows_many([(gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))], ready_parts=[w2_part])
+        else:
+            gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))])
         gW2, gW0 = gW2[:d_out], gW0[:, :F_in]
     return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
 

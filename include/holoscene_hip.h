@@ -308,7 +308,10 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t /* NULL = skip */, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale,
                      int64_t M, float *gb2 /* [g_pitch] fp32 (+=): column sums of g's value rows = last layer's bias gradient, or NULL */,
+                     float *dW2_part /* NULL, or [hs_trunk_bwd_parts(M), g_pitch, 256] fp32: per-workgroup slices of the last layer's weight
+                                        gradient g^T . H1 (sum them with hs_sum_slices, src_f32 = 1; rows >= d_out are zero) */,
                      void *stream);
+int32_t hs_trunk_bwd_parts(int64_t M);   /* number of slices hs_trunk_mlp_bwd writes into dW2_part */
 
 /* Consumers of hs_trunk_mlp_fwd's Y [4*B, K] and producers of its cotangent (K <= 64).  idx [B] = argmin_k of the value row
  * (lowest index among equals).  Points b < n_main are rendered samples: sdf_raw [n_main,K] = value rows, sdf [n_main] = min_k,
@@ -361,13 +364,14 @@ typedef struct hsPackJob {
 } hsPackJob;
 int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream);
 
-/* dst[i] = sum_s src[s*n + i] (src bf16 [slices, n], dst fp32 [n], n % 4 == 0) for up to HS_PACK_MAX_JOBS matrices in one launch:
+/* dst[i] = sum_s src[s*n + i] (src bf16 or fp32 [slices, n], dst fp32 [n], n % 4 == 0) for up to HS_PACK_MAX_JOBS matrices in one launch:
  * the final reduction of the split-M weight-gradient GEMMs. */
 typedef struct hsSumJob {
     const void *src;
     float *dst;
     int64_t n;
     int32_t slices;
+    int32_t src_f32;   /* 0: src is bf16 (the GEMM partials), 1: src is fp32 (hs_trunk_mlp_bwd's dW2_part) */
 } hsSumJob;
 int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream);
 
