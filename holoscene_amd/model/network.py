@@ -1168,6 +1168,25 @@ class HoloSceneNetwork(nn.Module):
             rgb = self._rgb_at(points_flat, dirs_flat, g_rgb, indices).reshape(-1, N, 3)
         else:
             rgb = self.rendering_network(points_flat, g_rgb, dirs_flat, fv, indices).reshape(-1, N, 3)
+        base = {"rgb": rgb, "z_vals": z_vals, "depth_vals": z_vals * depth_scale, "sdf": sdf.reshape(z_vals.shape)}
+        if COMPOSITE_IMPL == "hip" and z_vals.is_cuda and not nf_outputs and not detach_rgb:
+            # the fused compositing kernel (csrc/composite.hip) once per weight set.  Pass A runs on the SDF the semantics belong to,
+            # with one extra "object" column appended to the per-object SDFs so that its occlusion-aware opacity comes out of the
+            # same launch; pass B runs on the object-subset minimum and delivers colour, depth and the (rotated) normal map.
+            beta, ds, rgb_flat = self.density.get_beta(), depth_scale.contiguous(), rgb.reshape(-1, 3)
+            cols_raw = sdf_raw if cols is None else sdf_raw[:, cols]
+            n_sem = cols_raw.shape[1]
+            extra = sdf if kind in ("only", "subset") else sdf_obj          # whose density the opacity uses (network.py:1131, 1201, 1270)
+            a = _composite.apply(z_vals, sdf, torch.cat([cols_raw, extra], 1), rgb_flat, gradients, beta, ds, net.sigmoid, rot)
+            weights, sem_w, opacity = a[0], a[5][:, :n_sem], a[6][:, n_sem:]
+            if kind == "only":
+                base.update({"semantic_values": sem_w, "object_opacity": opacity, "rgb_values": a[2], "depth_values": a[3], "weights": weights,
+                             "normal_map": a[4]})
+                return base
+            b = _composite.apply(z_vals, sdf_obj, cols_raw if sem_bg_weights else sdf_obj, rgb_flat, gradients, beta, ds, net.sigmoid, rot)
+            base.update({"semantic_values": b[5] if sem_bg_weights else sem_w, ("object_opacity" if kind == "multi" else "opacity"): opacity,
+                         "rgb_values": b[2], "depth_values": b[3], "weights": weights, "bg_weights": b[0], "normal_map": b[4]})
+            return base
         semantic = semantic.reshape(-1, N, semantic.shape[-1])
         weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
         if kind == "only":
@@ -1186,9 +1205,9 @@ class HoloSceneNetwork(nn.Module):
         depth_values = torch.sum(w_out * z_vals, 1, keepdims=True)
         if not nf_outputs:
             depth_values = depth_values / (w_out.sum(dim=1, keepdims=True) + 1e-8)
-        output = {"rgb": rgb, "semantic_values": semantic_values, opacity_key: opacity, "rgb_values": rgb_values,
-                  "depth_values": depth_scale * depth_values, "z_vals": z_vals, "depth_vals": z_vals * depth_scale,
-                  "sdf": sdf.reshape(z_vals.shape), "weights": weights}
+        output = dict(base)
+        output.update({"semantic_values": semantic_values, opacity_key: opacity, "rgb_values": rgb_values,
+                       "depth_values": depth_scale * depth_values, "weights": weights})
         if kind != "only":
             output["bg_weights"] = w_out
         normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N, 3)
