@@ -1267,7 +1267,8 @@ class HoloSceneNetwork(nn.Module):
 
     def _colors_along_rays(self, points, rays, obj=None, near_far=None, nm=False, rng=None):
         """Shared body of the get_colors_* family (network.py:1532-1800): rays leaving `points` along `rays`, composited with the
-        weights of the scene SDF (obj None), of one object's own SDF (nm: get_specific_outputs_nm) or of the min over [obj]."""
+        weights of the scene SDF (obj None), of one object's own SDF (nm: get_specific_outputs_nm) or of the min over [obj].
+        Returns weights [R,N], colour [R,3], world-frame normal map [R,3], composited semantics [R,K']."""
         cam_loc = points.reshape(-1, 3)
         ray_dirs = F.normalize(rays.reshape(-1, 3), dim=-1)
         sm, net = self.ray_sampler, self.implicit_network
@@ -1289,51 +1290,55 @@ class HoloSceneNetwork(nn.Module):
             rgb = self._rgb_at(points_flat, dirs_flat, gradients, 0).reshape(-1, N, 3)
         else:
             rgb = self.rendering_network(points_flat, gradients, dirs_flat, fv, 0).reshape(-1, N, 3)
+        if COMPOSITE_IMPL == "hip" and z_vals.is_cuda:      # one launch: weights, colour, world-frame normal map, composited semantics
+            ones = torch.ones(z_vals.shape[0], 1, device=z_vals.device)
+            raw_cols = sdf_raw if (obj is None or nm) else sdf_raw[:, [obj]]
+            a = _composite.apply(z_vals, sdf.reshape(-1, 1), raw_cols, rgb.reshape(-1, 3), gradients, self.density.get_beta(), ones, net.sigmoid)
+            return a[0], a[2], a[4], a[5]
         weights, _, _ = self.volume_rendering(z_vals, sdf)
-        return z_vals, weights, torch.sum(weights.unsqueeze(-1) * rgb, 1).reshape(-1, 3), gradients, semantic
-
-    def _normal_map_of(self, weights, gradients, pose):
-        N = weights.shape[1]
         normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N, 3)
+        sem = torch.sum(weights.unsqueeze(-1) * semantic.reshape(-1, N, semantic.shape[-1]), 1)
+        return weights, torch.sum(weights.unsqueeze(-1) * rgb, 1).reshape(-1, 3), torch.sum(weights.unsqueeze(-1) * normals, 1), sem
+
+    @staticmethod
+    def _to_camera(normal_world, pose):
         rot = pose.reshape(-1, 4)[:3, :3].permute(1, 0).contiguous()
-        return (rot @ torch.sum(weights.unsqueeze(-1) * normals, 1).permute(1, 0)).permute(1, 0).contiguous()
+        return (rot @ normal_world.permute(1, 0)).permute(1, 0).contiguous()
 
     def get_colors_normals_from_point_rays(self, points, rays, pose, rng=None):
         """network.py:1532-1569."""
-        _, weights, rgb_values, gradients, _ = self._colors_along_rays(points, rays, rng=rng)
-        return rgb_values, self._normal_map_of(weights, gradients, pose)
+        _, rgb_values, normal_world, _ = self._colors_along_rays(points, rays, rng=rng)
+        return rgb_values, self._to_camera(normal_world, pose)
 
     def get_colors_normals_from_point_rays_obj(self, points, rays, pose, obj_idx, rng=None):
         """network.py:1571-1612: one object's own SDF; also the arg-max label of the composited semantics."""
-        _, weights, rgb_values, gradients, semantic = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
-        sem = torch.sum(weights.unsqueeze(-1) * semantic.reshape(-1, weights.shape[1], self.num_semantic), 1)
-        return rgb_values, self._normal_map_of(weights, gradients, pose), torch.argmax(sem, dim=-1)
+        _, rgb_values, normal_world, sem = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
+        return rgb_values, self._to_camera(normal_world, pose), torch.argmax(sem, dim=-1)
 
     def get_colors_normals_from_point_rays_obj_f(self, points, rays, pose, obj_idx, rng=None):
         """network.py:1614-1654: as above, the composited semantics themselves."""
-        _, weights, rgb_values, gradients, semantic = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
-        sem = torch.sum(weights.unsqueeze(-1) * semantic.reshape(-1, weights.shape[1], self.num_semantic), 1)
-        return rgb_values, self._normal_map_of(weights, gradients, pose), sem
+        _, rgb_values, normal_world, sem = self._colors_along_rays(points, rays, obj=obj_idx, nm=True, rng=rng)
+        return rgb_values, self._to_camera(normal_world, pose), sem
 
     def get_colors_from_point_rays(self, points, rays, rng=None):
         """network.py:1656-1683."""
-        return self._colors_along_rays(points, rays, rng=rng)[2]
+        return self._colors_along_rays(points, rays, rng=rng)[1]
 
     def get_colors_from_point_rays_obj(self, points, rays, obj_i, rng=None):
         """network.py:1685-1712."""
-        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[2]
+        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[1]
 
     def get_colors_from_point_rays_obj_offset(self, points, rays, obj_i, rng=None):
         """network.py:1714-1741 (identical to get_colors_from_point_rays_obj in the reference)."""
-        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[2]
+        return self._colors_along_rays(points, rays, obj=obj_i, rng=rng)[1]
 
     def get_colors_from_point_rays_obj_offset_near_far(self, points, rays, obj_i, near, far, rng=None):
         """network.py:1743-1770."""
-        return self._colors_along_rays(points, rays, obj=obj_i, near_far=(near, far), rng=rng)[2]
+        return self._colors_along_rays(points, rays, obj=obj_i, near_far=(near, far), rng=rng)[1]
 
     def get_colors_from_point_rays_obj_debug(self, points, rays, obj_i, rng=None):
         """network.py:1772-1801: colour and the summed weights per ray."""
-        _, weights, rgb_values, _, _ = self._colors_along_rays(points, rays, obj=obj_i, rng=rng)
+        weights, rgb_values, _, _ = self._colors_along_rays(points, rays, obj=obj_i, rng=rng)
         return rgb_values, torch.sum(weights, 1)
 
     # ---------------------------------------------------------------- forward (network.py:778-971), in stages
