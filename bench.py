@@ -274,7 +274,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
-                                   f"full iteration (sampler+render+eikonal+loss+backward+Adam), beta={args.beta}, lr x{args.lr_scale:g}, "
+                                   f"full iteration (pixel-batch gather from HBM-resident frames+sampler+render+eikonal+loss+backward+Adam; every 10th "
+                                   f"iteration also the 32x32 background-patch pass, render_bg_iter=10), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
                        "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(int(r_) for r_ in rounds_seen) / max(1, len(rounds_seen)), 2),
                        "parallelism": f"dp{world}"},
