@@ -360,6 +360,105 @@ def run_multi_obj(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  calls={len(calls)}")
 
 
+def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05):
+    """G3 / G5 of SURVEY 8c: the query methods of ObjectImplicitNetworkGrid (network.py:169-506), RenderingNetwork.forward (:585-614),
+    volume_rendering and occlusion_opacity (:1803-1824) called directly on a small model with perturbed, object-distinct weights."""
+    torch.manual_seed(seed)
+    model = Net(conf=small_conf(K, 16, beta), graph_node_dict=None, num_images=4)
+    model.eval()
+    perturb(model, seed + 1, scale=1e-2, emb_scale=2e-2)
+    g = torch.Generator().manual_seed(seed + 2)
+    with torch.no_grad():
+        l2 = model.implicit_network.lin2
+        l2.weight_v[:K] += 0.05 * torch.randn(K, l2.weight_v.shape[1], generator=g) * l2.weight_v[:K].abs().mean()
+        l2.bias[:K] += 0.15 * torch.randn(K, generator=g)
+    x = torch.rand(B, 3, generator=g) * 2.4 - 1.2            # some points outside the grid's cube (quirk Q4)
+    x[0], x[1] = torch.tensor([1.0, -1.0, 0.5]), torch.tensor([0.0, 0.0, 0.0])   # boundary and centre
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    net = model.implicit_network
+    a, b = 0, K - 1
+    rec = {"meta.K": K, "meta.S": 16, "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32,
+           "meta.a": a, "meta.b": b}
+    to_np("state.", model.state_dict(), rec)
+    to_np("in.", dict(x=x, dirs=dirs), rec)
+
+    def tup(prefix, vals):
+        to_np(prefix, {f"ret{i}": v for i, v in enumerate(vals if isinstance(vals, tuple) else (vals,))}, rec)
+
+    tup("forward.", net.forward(x.clone()))
+    outs = net.get_outputs(x.clone())
+    tup("get_outputs.", outs)
+    tup("gradient.", net.gradient(x.clone()))
+    tup("get_sdf_vals.", net.get_sdf_vals(x.clone()))
+    tup("get_sdf_raw.", net.get_sdf_raw(x.clone()))
+    tup("get_object_sdf_vals.", net.get_object_sdf_vals(x.clone(), b))
+    tup("get_multi_object_sdf_vals.", net.get_multi_object_sdf_vals(x.clone(), [a, b]))
+    tup("get_sdf_vals_and_sdfs.", net.get_sdf_vals_and_sdfs(x.clone()))
+    tup("get_specific_outputs.", net.get_specific_outputs(x.clone(), a))
+    tup("get_shift_sdf_raw.", net.get_shift_sdf_raw(x.clone()))
+    tup("get_outputs_and_indices.", net.get_outputs_and_indices(x.clone()))
+    tup("rendering.", model.rendering_network(x, outs[2].detach(), dirs, outs[1].detach(), torch.tensor([0])))
+    # compositing on its own
+    z = torch.sort(torch.rand(R, N, generator=g) * 2.0 + 0.05, dim=1).values
+    sdf = torch.randn(R * N, 1, generator=g) * 0.2
+    raw = torch.randn(R * N, K, generator=g) * 0.2
+    w, T, dists = model.volume_rendering(z, sdf)
+    to_np("vr.in.", dict(z=z, sdf=sdf, raw=raw), rec)
+    to_np("vr.out.", dict(weights=w, transmittance=T, dists=dists, occlusion=model.occlusion_opacity(z, T, dists, raw)), rec)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_three_steps(Net, Loss, name, *, K, S, R, beta, eye, seed, res=64, steps=3, decay_rate=0.1, decay_steps=20):
+    """G6 / G7 of SURVEY 8c: three consecutive training iterations of the reference -- forward, loss, backward, Adam, ExponentialLR
+    exactly as HoloSceneTrainRunner wires them (holoscene_train.py:156-169, 355-374, 428; decay_steps shortened so that the
+    schedule is visible) -- with the draws of every step, the learning rates after every step and all parameters after steps 1 and 3."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    conf = small_conf(K, S, beta, use_bg_reg=False)
+    model = Net(conf=conf, graph_node_dict=None, num_images=4)
+    model.train()
+    perturb(model, seed + 1)
+    loss_fn = Loss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
+                   normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0,
+                   reg_vio_weight=0.01, bg_reg_weight=0.01, depth_type="marigold")
+    pose = look_at_pose(eye)
+    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.res": res, "meta.steps": steps, "meta.decay_steps": decay_steps,
+           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+    rec["meta.decay_rate"] = np.float64(decay_rate)
+    to_np("state.", model.state_dict(), rec)
+    lr, lr_grid = 5e-4, 5e-4 * 20
+    opt = torch.optim.Adam([
+        {"params": list(model.implicit_network.grid_parameters()), "lr": lr_grid},
+        {"params": list(model.implicit_network.mlp_parameters()) + list(model.rendering_network.parameters()), "lr": lr},
+        {"params": list(model.density.parameters()), "lr": lr}], betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, decay_rate ** (1.0 / decay_steps))
+    lrs = []
+    for step in range(steps):
+        uv, intr, gt = batch(R, K, res, seed + 10 + step)          # a fresh pixel batch per step, as the data loader gives
+        to_np(f"s{step}.in.", dict(uv=uv, pose=pose, intrinsics=intr), rec)
+        to_np(f"s{step}.gt.", gt, rec)
+        opt.zero_grad()
+        with DrawLog() as log:
+            out = model({"intrinsics": intr, "uv": uv.clone(), "pose": pose}, torch.tensor([0]), iter_step=step + 1)
+        out["iter_step"] = step + 1
+        lo = loss_fn(out, gt, call_reg=False)
+        lo["loss"].backward()
+        for k, v in name_draws(log.draws, bg=False).items():
+            rec[f"s{step}.rand.{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+        rec[f"s{step}.loss"] = np.float64(float(lo["loss"]))
+        opt.step()
+        sched.step()
+        lrs.append([g["lr"] for g in opt.param_groups])
+        if step in (0, steps - 1):
+            to_np(f"adam{step + 1}.", dict(model.named_parameters()), rec)
+    rec["lr_after_step"] = np.array(lrs, dtype=np.float64)      # [steps, 3 groups: grid, mlp, density]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  losses={[round(float(rec[f's{i}.loss']), 5) for i in range(steps)]}")
+
+
 def run_hash(name, *, L, base, end, logmap, B, seed, D=3, C=2):
     """Hash-kernel vectors straight from the C oracle (the reference kernels are CUDA-only)."""
     g = torch.Generator().manual_seed(seed)
@@ -420,6 +519,11 @@ def main():
             run_sampler(Net, f"sampler_{i}", K=2, S=S, R=24, beta=beta, eye=eye, seed=1)
     if sel("sampler_eval"):
         run_sampler(Net, "sampler_eval", K=2, S=32, R=24, beta=0.1, eye=(0, 0, 0.6), seed=1, train=False)
+    if sel("steps3_k3"):
+        run_three_steps(Net, Loss, "steps3_k3", K=3, S=16, R=24, beta=0.05, eye=(0.0, 0.1, 0.6), seed=50)
+    for K in (2, 21, 32):
+        if sel(f"net_k{K}"):
+            run_network(Net, f"net_k{K}", K=K, seed=40 + K)
     if sel("multi_obj_k5_eval"):
         run_multi_obj(Net, "multi_obj_k5_eval", K=5, S=16, R=16, beta=0.05, eye=(0.7, 0.0, 0.1), seed=31, train=False)
     if sel("multi_obj_k5") and (not want or "multi_obj_k5" in want or "multi_obj" in want):

@@ -21,7 +21,7 @@ def section(rec, prefix, as_torch=True):
 
 def oracle_cfg(rec, **extra):
     from oracle.stage1_oracle import Cfg
-    m = {k[5:]: int(v) for k, v in rec.items() if k.startswith("meta.")}
+    m = {k[5:]: int(v) for k, v in rec.items() if k.startswith("meta.") and v.ndim == 0}
     beta = float(rec["state.density.beta"])
     S = m["S"]
     return Cfg(feature_vector_size=m["feat"], d_out=m["K"], dims=(m["width"],) * 2, render_dims=(m["width"],) * 2,

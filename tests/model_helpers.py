@@ -148,3 +148,88 @@ def check_multi_obj(model, rec, dev="cpu", rtol=1e-3, atol=2e-4, grad_rtol=5e-3,
                 else:
                     rel = float((g.cpu() - v).norm() / (v.norm() + 1e-12))
                     assert rel < 1e-2, (key, k, rel)
+
+
+def check_network_methods(model, rec, dev="cpu", rtol=1e-4, atol=1e-5):
+    """G3 / G5: every query method of the implicit network, the rendering network and the two compositing helpers
+    against what the reference returned on the same weights and points (tests/golden/net_k*.npz)."""
+    net = model.implicit_network
+    ins = {k: v.to(dev) for k, v in section(rec, "in.").items()}
+    x, dirs = ins["x"], ins["dirs"]
+    a, b = int(rec["meta.a"]), int(rec["meta.b"])
+
+    def cmp(prefix, vals, skip=()):
+        ref = section(rec, prefix + ".")
+        vals = vals if isinstance(vals, tuple) else (vals,)
+        assert len(ref) == len(vals), (prefix, len(ref), len(vals))
+        for i, v in enumerate(vals):
+            if i in skip:
+                continue
+            r = ref[f"ret{i}"]
+            if r.dtype in (torch.int64, torch.int32):
+                assert torch.equal(v.detach().cpu().reshape(r.shape), r), (prefix, i)
+            else:
+                close(v.reshape(r.shape), r, rtol, atol, f"{prefix}[{i}]")
+
+    cmp("forward", net.forward(x.clone()))
+    outs = net.get_outputs(x.clone())
+    cmp("get_outputs", outs)
+    cmp("gradient", net.gradient(x.clone()))
+    cmp("get_sdf_vals", net.get_sdf_vals(x.clone()))
+    cmp("get_sdf_raw", net.get_sdf_raw(x.clone()))
+    cmp("get_object_sdf_vals", net.get_object_sdf_vals(x.clone(), b))
+    cmp("get_multi_object_sdf_vals", net.get_multi_object_sdf_vals(x.clone(), [a, b]))
+    cmp("get_sdf_vals_and_sdfs", net.get_sdf_vals_and_sdfs(x.clone()))
+    cmp("get_specific_outputs", net.get_specific_outputs(x.clone(), a))
+    cmp("get_shift_sdf_raw", net.get_shift_sdf_raw(x.clone()))
+    cmp("get_outputs_and_indices", net.get_outputs_and_indices(x.clone()))
+    ref_out = section(rec, "get_outputs.")
+    cmp("rendering", model.rendering_network(x, ref_out["ret2"].to(dev), dirs, ref_out["ret1"].to(dev), torch.tensor([0])))
+    vin = {k: v.to(dev) for k, v in section(rec, "vr.in.").items()}
+    vref = section(rec, "vr.out.")
+    w, T, dists = model.volume_rendering(vin["z"], vin["sdf"])
+    close(w, vref["weights"], rtol, atol, "vr.weights")
+    close(T, vref["transmittance"], rtol, atol, "vr.transmittance")
+    close(dists, vref["dists"], rtol, atol, "vr.dists")
+    close(model.occlusion_opacity(vin["z"], T, dists, vin["raw"]), vref["occlusion"], rtol, atol, "vr.occlusion")
+
+
+def run_three_steps(model, rec, dev="cpu", flat=False):
+    """G6 / G7: the reference's three consecutive training iterations (tests/golden/steps3_k3.npz) replayed on this
+    build with the draws of every step injected: torch.optim.Adam + ExponentialLR wired as the trainer does (or, flat=True, the
+    fused flat Adam).  Returns the per-step losses, the learning rates after every step and the named parameters after steps 1, 3."""
+    from holoscene_amd.training.optim import build_optimizer, build_scheduler
+    steps, decay_steps, decay_rate = int(rec["meta.steps"]), int(rec["meta.decay_steps"]), float(rec["meta.decay_rate"])
+    loss_fn = build_loss()
+    if flat:
+        from holoscene_amd.training.flat import FlatAdam
+        fl = FlatAdam(model, 5e-4, 20.0, decay_rate, decay_steps)
+    else:
+        opt = build_optimizer(model, lr=5e-4, lr_factor_for_grid=20.0)
+        sched = build_scheduler(opt, decay_rate, decay_steps)
+    losses, lrs, snaps = [], [], {}
+    for step in range(steps):
+        ins = {k: v.to(dev) for k, v in section(rec, f"s{step}.in.").items()}
+        gt = {k: v.to(dev) for k, v in section(rec, f"s{step}.gt.").items()}
+        rng = {k: v.to(dev) for k, v in section(rec, f"s{step}.rand.").items()}
+        if flat:
+            fl.zero_grad()
+        else:
+            opt.zero_grad()
+        out = model(ins, torch.tensor([0]), iter_step=step + 1, rng=rng)
+        out["iter_step"] = step + 1
+        lo = loss_fn(out, gt, call_reg=False)
+        lo["loss"].backward()
+        losses.append(float(lo["loss"].detach()))
+        if flat:
+            fl.gather_grads()
+            fl.step()
+            st = fl.read_state()
+            lrs.append([float(v) * decay_rate ** (1.0 / decay_steps) for v in st.lr])    # the state holds the rates the step used
+        else:
+            opt.step()
+            sched.step()
+            lrs.append([g["lr"] for g in opt.param_groups])
+        if step in (0, steps - 1):
+            snaps[step + 1] = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+    return losses, lrs, snaps

@@ -74,6 +74,33 @@ def test_stage23_entry_points(name):
     check_multi_obj(model, rec)
 
 
+@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32"])
+def test_network_query_methods(name):
+    """G3 / G5 of SURVEY 8c: ObjectImplicitNetworkGrid's query methods, RenderingNetwork.forward, volume_rendering and
+    occlusion_opacity against direct calls of the reference's (K = 2, 21, 32; perturbed, object-distinct weights; points incl.
+    the cube boundary and outside it)."""
+    from model_helpers import check_network_methods
+    rec = load(name)
+    model = build_model(rec).eval()
+    check_network_methods(model, rec)
+
+
+def test_three_training_steps_match_reference():
+    """G6 / G7 of SURVEY 8c: forward, loss, backward, Adam and the ExponentialLR schedule over three consecutive iterations with
+    fresh batches and draws per step: losses, learning rates and every parameter after steps 1 and 3 vs the reference's run."""
+    import numpy as np
+    from model_helpers import run_three_steps
+    rec = load("steps3_k3")
+    model = build_model(rec).train()
+    losses, lrs, snaps = run_three_steps(model, rec)
+    for i, l in enumerate(losses):
+        assert abs(l - float(rec[f"s{i}.loss"])) <= 2e-4 * abs(float(rec[f"s{i}.loss"])), (i, l, float(rec[f"s{i}.loss"]))
+    assert np.allclose(np.array(lrs), rec["lr_after_step"], rtol=1e-12, atol=0)
+    for n_steps in (1, 3):
+        for k, v in section(rec, f"adam{n_steps}.").items():
+            close(snaps[n_steps][k], v, 2e-4, 4e-5 * n_steps, f"adam{n_steps}.{k}")
+
+
 def test_state_dict_keys_match_reference():
     rec = load("iter_k5")
     model = build_model(rec)

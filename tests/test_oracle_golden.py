@@ -96,6 +96,33 @@ def test_sampler_matches_reference(name):
     close(z_eik, rec["out.z_samples_eik"], 1e-5, 1e-5, "z_eik")
 
 
+@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32"])
+def test_network_methods_match_reference(name):
+    """G3 / G5 of SURVEY 8c: the oracle's network, rendering and compositing restatements against direct calls of the reference's
+    ObjectImplicitNetworkGrid / RenderingNetwork / volume_rendering / occlusion_opacity (K = 2, 21, 32)."""
+    rec = load(name)
+    o = Stage1Oracle(oracle_cfg(rec), section(rec, "state."))
+    o.training = False
+    ins = section(rec, "in.")
+    x, dirs = ins["x"], ins["dirs"]
+    b = int(rec["meta.b"])
+    close(o.implicit(x.clone()), rec["forward.ret0"], 1e-5, 1e-6, "forward")
+    outs = o.get_outputs(x.clone())
+    for i, v in enumerate(outs):
+        close(v, rec[f"get_outputs.ret{i}"], 1e-4, 1e-6, f"get_outputs[{i}]")
+    close(o.gradient(x.clone()), rec["gradient.ret0"], 1e-4, 1e-6, "gradient")
+    close(o.sdf_vals(x.clone()), rec["get_sdf_vals.ret0"], 1e-5, 1e-6, "get_sdf_vals")
+    close(o.sdf_raw(x.clone()), rec["get_sdf_raw.ret0"], 1e-5, 1e-6, "get_sdf_raw")
+    close(o.object_sdf_vals(x.clone(), b), rec["get_object_sdf_vals.ret0"], 1e-5, 1e-6, "get_object_sdf_vals")
+    ref = section(rec, "get_outputs.")
+    close(o.rendering(x, ref["ret2"], dirs, ref["ret1"]), rec["rendering.ret0"], 1e-5, 1e-6, "rendering")
+    vin = section(rec, "vr.in.")
+    w, T, dists = o.volume_rendering(vin["z"], vin["sdf"])
+    close(w, rec["vr.out.weights"], 1e-5, 1e-7, "weights")
+    close(T, rec["vr.out.transmittance"], 1e-5, 1e-7, "transmittance")
+    close(o.occlusion_opacity(T, dists, vin["raw"]), rec["vr.out.occlusion"], 1e-5, 1e-7, "occlusion")
+
+
 @pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5"])
 def test_iteration_matches_reference(name):
     rec = load(name)
