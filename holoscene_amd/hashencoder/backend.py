@@ -121,35 +121,6 @@ SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
 ACCUMULATE_INTO_GRAD = False
 
 
-# Experiment switch: run the atomic-issue-bound table scatters of the backward pass on a side stream (a parallel branch of
-# the captured graph) beside the matrix-core-bound weight-gradient GEMMs.  Only valid with ACCUMULATE_INTO_GRAD on tables owned
-# by FlatAdam (the optimiser calls join_side_stream() first).  Measured on MI355X: 4.68 ms/iteration with the branch vs 4.34
-# without (the scatter's waves crowd the GEMMs out of the CUs; two-branch graphs of a gather and the SDF MLP gain only ~13 %,
-# tools/exp_graph_overlap.py) -> off.
-OVERLAP_SCATTER = os.environ.get("HOLOSCENE_OVERLAP_SCATTER", "0") != "0"
-_side = {}
-
-
-def fork_side_stream(*tensors):
-    """A side stream ordered after everything enqueued so far on the current stream; `tensors` (allocated on the current
-    stream, consumed on the side stream) are protected from early reuse."""
-    dev = torch.cuda.current_device()
-    s = _side.get(dev)
-    if s is None:
-        s = _side[dev] = torch.cuda.Stream(device=dev)
-    s.wait_stream(torch.cuda.current_stream())
-    for t in tensors:
-        if t is not None:
-            t.record_stream(s)
-    return s
-
-
-def join_side_stream():
-    s = _side.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
-    if s is not None:
-        torch.cuda.current_stream().wait_stream(s)
-
-
 def point_major_layout(C, L, D):
     """features [B, L*C]; dy_dx [L, B, D*C] (level stride filled in per call)."""
     return dict(level_stride=C, point_stride=L * C, dydx_point_stride=D * C)

@@ -230,22 +230,14 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     if gb2 is _FROM_KERNEL:
         gb2 = gb2k[:d_out]
 
-    def table_branch():
-        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
-                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
-
     g_emb = target = None
     if need_table:
         table = ctx.table
         inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
         target = table.grad if inplace else torch.zeros_like(embeddings)
         g_emb = None if inplace else target
-        if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):
-            # experiment (off by default, see backend.OVERLAP_SCATTER): scatter on a parallel branch beside the GEMMs below
-            with torch.cuda.stream(_be.fork_side_stream(g_feat, g_dydx, x01, offsets, target)):
-                table_branch()
-        else:
-            table_branch()
+        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
+                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
     gW2 = gW1 = gW0 = None
     if need_w:
         if w2_part is not None:
@@ -391,12 +383,8 @@ class _fused_appearance(torch.autograd.Function):
             table = ctx.table
             inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
             target = table.grad if inplace else torch.zeros_like(embeddings)
-            if inplace and _be.OVERLAP_SCATTER and getattr(table, "_hs_flat_owner", False):   # the scatter is atomic-issue-bound: let the trunk's matrix-core backward run beside it
-                with torch.cuda.stream(_be.fork_side_stream(g_featc, x01, offsets, target)):
-                    be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None, level_major=True)
-            else:
-                be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
+            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
+                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
             g_emb = None if inplace else target
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 

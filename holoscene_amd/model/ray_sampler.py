@@ -27,10 +27,6 @@ from .density import laplace_density
 # "torch": the pre-fusion whole-tensor formulation below, kept for A/B timing and for exercising the host
 #          logic on CPU in `-m "not gpu"` tests.  Never selected implicitly.
 SAMPLER_IMPL = os.environ.get("HOLOSCENE_SAMPLER_IMPL", "hip")
-# 1 = enqueue each Algorithm-1 round one ahead of the host's convergence read (device-gated kernels, flag on a side stream).
-# Measured on MI355X (same box, full bench): the sampler phase alone gets 12 % shorter (1.38 -> 1.21 ms at 5 rounds) but the
-# whole iteration does not (5.26 vs 5.28 ms) and a 1-round state pays 0.3 ms for the gated-out launches -> off by default.
-SPECULATE = os.environ.get("HOLOSCENE_SAMPLER_SPECULATE", "0") != "0"
 # "device": Algorithm 1's loop test runs on the GPU (hsSamplerCtl + gated kernels, loop unrolled max_total_iters times): no
 #           host sync at all, so the sampler -- and with it the whole training iteration -- can live inside one HIP graph.
 #           Needs the fused ray-mode SDF query (bf16 MLP mode, stock trunk shape); other configurations use "host".
@@ -236,67 +232,19 @@ class ErrorBoundSampler(RaySampler):
         sdf = torch.empty(R, ld, device=dev)
         beta_max_all = torch.zeros(self.max_total_iters + 1, device=dev)   # one slot per round: no re-zeroing inside the loop
         samples = z0.contiguous()
-        net = model.implicit_network
-        cam = cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc
-        rays_fused = SPECULATE and (idx is None or isinstance(idx, int)) and getattr(net, "color_grid_feature", False) and net._fused_sdf_supported(samples)
-        sel = -1 if idx is None else idx
-        if rays_fused:
-            # Speculative pipeline: round r+1 is enqueued -- gated ON THE DEVICE by round r's convergence flag -- before the
-            # host reads that flag, so the read (the one sync Algorithm 1 needs per round, :204) overlaps device work
-            # instead of leaving the GPU idle for a host round trip per round.
-            # The flag itself travels on a side stream (event after the round's update kernel), otherwise the copy would
-            # queue up behind the speculative kernels and arrive a whole round late.
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=dev)
-                self._flags = torch.empty(self.max_total_iters + 2, pin_memory=True)
-            side, flags = self._side, self._flags
-            main = torch.cuda.current_stream(dev)
-
-            def enqueue_round(r, smp, m_old):
-                gate = None if r == 0 else (beta_max_all[r - 1:r], beta0)
-                new_sdf = net.sdf_along_rays(cam, ray_dirs, smp, sel, gate=gate)
-                be.sampler_update(z, sdf, m_old, smp, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1],
-                                  gate=gate)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    if r == 0:
-                        flags[-1:].copy_(beta0, non_blocking=True)
-                    flags[r:r + 1].copy_(beta_max_all[r:r + 1], non_blocking=True)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                return done
-
-            r, m = 0, samples.shape[1]
-            arrived = enqueue_round(0, samples, 0)
-            while True:
-                can_continue = r + 1 < self.max_total_iters
-                if can_continue:
-                    nxt = torch.empty(R, S, device=dev)
-                    be.sampler_draw(z, sdf, m, beta, 0, float(self.add_tiny), None, S, nxt, gate=(beta_max_all[r:r + 1], beta0))
-                    arrived_next = enqueue_round(r + 1, nxt, m)
-                arrived.synchronize()
-                unconverged = bool(flags[r] > flags[-1])
-                if not (unconverged and can_continue):
-                    break
-                r, m, arrived = r + 1, m + S, arrived_next
-            main.wait_stream(side)   # the pinned slots are rewritten by the next call
-            rounds = r + 1
-        else:
-            m, rounds = 0, 0
-            while True:
-                points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-                new_sdf = self._query_sdf(model, points, idx).reshape(R, -1).contiguous()
-                beta_max = beta_max_all[rounds:rounds + 1]
-                be.sampler_update(z, sdf, m, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max)
-                m += samples.shape[1]
-                rounds += 1
-                unconverged = bool(beta_max > beta0)  # the one host sync Algorithm 1 needs per round
-                if not (unconverged and rounds < self.max_total_iters):
-                    break
-                samples = torch.empty(R, S, device=dev)
-                be.sampler_draw(z, sdf, m, beta, 0, float(self.add_tiny), None, S, samples)
+        m, rounds = 0, 0
+        while True:
+            points = (cam_loc.unsqueeze(1) + samples.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            new_sdf = self._query_sdf(model, points, idx).reshape(R, -1).contiguous()
+            beta_max = beta_max_all[rounds:rounds + 1]
+            be.sampler_update(z, sdf, m, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max)
+            m += samples.shape[1]
+            rounds += 1
+            unconverged = bool(beta_max > beta0)  # the one host sync Algorithm 1 needs per round
+            if not (unconverged and rounds < self.max_total_iters):
+                break
+            samples = torch.empty(R, S, device=dev)
+            be.sampler_draw(z, sdf, m, beta, 0, float(self.add_tiny), None, S, samples)
         n = self.N_samples
         if model.training:
             u = (rng["u_final"].to(dev) if "u_final" in rng else _rand((R, n), dev, self.cpu_rng)).contiguous()

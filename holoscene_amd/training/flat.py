@@ -68,7 +68,6 @@ class FlatAdam:
             p.grad = None
 
     def gather_grads(self):
-        _be.join_side_stream()   # table scatters may still be running on the side branch (backend.OVERLAP_SCATTER)
         src = [p.grad for p, _ in self.small if p.grad is not None]
         dst = [v for p, v in self.small if p.grad is not None]
         if src:
