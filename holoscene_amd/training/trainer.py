@@ -140,6 +140,12 @@ class Stage1Trainer:
         return out, loss_out
 
     # ------------------------------------------------------------------ whole-iteration graph
+    def _capture_mode(self):
+        """With a process group alive, its watchdog thread polls events of in-flight collectives (cudaEventQuery / hipEventQuery) --
+        a call that is illegal for ANY thread while some stream captures in "global" mode and would invalidate the capture.  The
+        captured region itself contains no collective, so thread-local capture checking is the right scope for N > 1."""
+        return "thread_local" if self.world_size > 1 else "global"
+
     def _full_graph_ok(self):
         """Rays, sampler (device-side loop control), render, loss, backward and Adam in ONE graph: possible whenever the sampler
         can run without host syncs (ray_sampler.CONTROL == "device", bf16 fused SDF queries)."""
@@ -183,7 +189,7 @@ class Stage1Trainer:
             cur.wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
                 out, loss_out = self._full_body(st, key[1], key[2])
             entry = {"graph": g, "static": st, "out": out, "loss": loss_out, "rounds": self.model.ray_sampler._rounds}
             self._graphs[key] = entry
@@ -232,7 +238,7 @@ class Stage1Trainer:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
             out, loss_out = self._graph_body(st, with_bg, call_reg)
         entry = {"graph": g, "static": st, "out": out, "loss": loss_out}
         self._graphs[key] = entry
