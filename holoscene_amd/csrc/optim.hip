@@ -44,7 +44,7 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
 
 __global__ __launch_bounds__(kThreads) void k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, int64_t begin, int64_t end, const hsAdamState *__restrict__ st,
-                                                         float beta1, float beta2, float eps, float gscale) {
+                                                         float beta1, float beta2, float eps, float gscale, int64_t g_base, int64_t mv_base) {
     const float bc2_sqrt = st->bc2_sqrt;
     const int64_t e0 = st->group_end[0], e1 = st->group_end[1];
     const float s0 = st->step_size[0], s1 = st->step_size[1], s2 = st->step_size[2];
@@ -55,8 +55,10 @@ __global__ __launch_bounds__(kThreads) void k_adam_flat(float *__restrict__ p, c
     // the iteration: ~50 us), i.e. the cold-table penalty after the 0.7 GB optimiser sweep is reduced, not removed.
     for (int64_t qq = (int64_t)blockIdx.x * kThreads + threadIdx.x; qq < q1 - q0; qq += (int64_t)gridDim.x * kThreads) {
         const int64_t q = q1 - 1 - qq;
-        float4 pp = reinterpret_cast<float4 *>(p)[q], mm = reinterpret_cast<float4 *>(m)[q], vv = reinterpret_cast<float4 *>(v)[q];
-        const float4 gg = reinterpret_cast<const float4 *>(g)[q];
+        // g / m / v may be shard-local buffers whose element 0 is flat element g_base / mv_base (ZeRO-1: 1/N of the moment storage)
+        const int64_t qg = q - (g_base >> 2), qm = q - (mv_base >> 2);
+        float4 pp = reinterpret_cast<float4 *>(p)[q], mm = reinterpret_cast<float4 *>(m)[qm], vv = reinterpret_cast<float4 *>(v)[qm];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[qg];
         const int64_t i = q << 2;
         float ss[4];
 #pragma unroll
@@ -66,8 +68,8 @@ __global__ __launch_bounds__(kThreads) void k_adam_flat(float *__restrict__ p, c
         adam1(pp.z, gg.z, mm.z, vv.z, ss[2], bc2_sqrt, beta1, beta2, eps, gscale);
         adam1(pp.w, gg.w, mm.w, vv.w, ss[3], bc2_sqrt, beta1, beta2, eps, gscale);
         reinterpret_cast<float4 *>(p)[q] = pp;
-        reinterpret_cast<float4 *>(m)[q] = mm;
-        reinterpret_cast<float4 *>(v)[q] = vv;
+        reinterpret_cast<float4 *>(m)[qm] = mm;
+        reinterpret_cast<float4 *>(v)[qm] = vv;
     }
 }
 
@@ -85,14 +87,20 @@ int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, voi
 
 int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, const hsAdamState *state, float beta1, float beta2,
                  float eps, float grad_scale, void *stream) {
+    return hs_adam_flat_shard(p, g, m, v, begin, end, 0, 0, state, beta1, beta2, eps, grad_scale, stream);
+}
+
+int hs_adam_flat_shard(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, int64_t g_base, int64_t mv_base,
+                       const hsAdamState *state, float beta1, float beta2, float eps, float grad_scale, void *stream) {
     if (end <= begin) return HS_OK;
-    if ((begin & 3) || (end & 3)) return HS_ERR_ARG;  // flat buffers are padded to whole 16-byte quads
+    if ((begin & 3) || (end & 3) || (g_base & 3) || (mv_base & 3) || g_base > begin || mv_base > begin || g_base < 0 || mv_base < 0)
+        return HS_ERR_ARG;  // flat buffers are padded to whole 16-byte quads; a shard-local buffer starts at or before `begin`
     if (!p || !g || !m || !v || !state) return HS_ERR_NULL;
     const int64_t quads = (end - begin) >> 2;
     int64_t want = (quads + kThreads - 1) / kThreads;
     if (want < 1) want = 1;
     const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
-    k_adam_flat<<<grid, kThreads, 0, (hipStream_t)stream>>>(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale);
+    k_adam_flat<<<grid, kThreads, 0, (hipStream_t)stream>>>(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale, g_base, mv_base);
     return check_launch();
 }
 

@@ -86,7 +86,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
 
 
 def _check(rc, what):
@@ -114,11 +114,13 @@ SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
 # Scatter the hashed levels through per-bin record lists + an LDS reduction instead of global atomics (csrc/hash_encode.hip)
 SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
 
-# When True and a table already has a `.grad` buffer attached (flat gradient storage, training/flat.py), the
-# scatter kernels accumulate straight into it and the autograd Functions return no table gradient -- this removes
-# the per-call 48.8 MB zero-fill + AccumulateGrad add of the reference (hashgrid.py:75-76).  Off by default so that
-# torch.autograd.grad(..., embeddings) keeps its meaning.
-ACCUMULATE_INTO_GRAD = False
+def accumulates_into_grad(table):
+    """True for a hash table whose gradient lives in flat gradient storage (training/flat.py marks the parameter with
+    `_hs_flat_owner` and keeps its `.grad` view attached): the scatter kernels then accumulate straight into that buffer and
+    the autograd Functions return no table gradient -- this removes the per-call 48.8 MB zero-fill + AccumulateGrad add of
+    the reference (hashgrid.py:75-76).  Per table, not per process: any other model in the same process keeps the plain
+    torch.autograd.grad(..., embeddings) semantics."""
+    return table is not None and getattr(table, "_hs_flat_owner", False) and table.grad is not None
 
 
 def point_major_layout(C, L, D):
@@ -296,11 +298,12 @@ class _HipBackend:
                                 _stream()), "hs_adam_tick")
 
     @staticmethod
-    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale):
+    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale, g_base=0, mv_base=0):
+        """g_base / mv_base: flat index of element 0 of a shard-local gradient / moment buffer (0 = full-length buffers)."""
         lib = load_library()
-        _check(lib.hs_adam_flat(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), ctypes.c_int64(begin), ctypes.c_int64(end),
-                                _dev(state, "state", torch.uint8), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
-                                ctypes.c_float(grad_scale), _stream()), "hs_adam_flat")
+        _check(lib.hs_adam_flat_shard(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), ctypes.c_int64(begin), ctypes.c_int64(end),
+                                      ctypes.c_int64(g_base), ctypes.c_int64(mv_base), _dev(state, "state", torch.uint8), ctypes.c_float(beta1),
+                                      ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(grad_scale), _stream()), "hs_adam_flat_shard")
 
     # ---- fused compositing (include/holoscene_hip.h section 6)
     @staticmethod

@@ -49,7 +49,7 @@ class _hash_encode(Function):
         need_x = ctx.calc_grad_inputs and ctx.needs_input_grad[0]
         need_e = ctx.needs_input_grad[1]
         table = ctx.table
-        if need_e and _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None and not torch.is_grad_enabled():
+        if need_e and _be.accumulates_into_grad(table) and not torch.is_grad_enabled():
             B, D, C, L, S, H = ctx.dims
             gx = torch.empty_like(inputs) if need_x else None
             _be._backend.bwd(grad.contiguous(), inputs, offsets, table.grad, B, D, C, L, S, H, dy_dx, gx)

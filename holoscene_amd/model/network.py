@@ -63,7 +63,7 @@ class _hash_encode_jac(torch.autograd.Function):
         g_emb = g_x = None
         if ctx.needs_input_grad[1]:
             table = ctx.table
-            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
             _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(),
                                  x01, offsets, target, B, D, C, L, S, H)
@@ -119,7 +119,7 @@ class _trunk_input(torch.autograd.Function):
             g_dydx = torch.empty(L, B, D * C, device=G.device, dtype=torch.float32)
             _be._backend.trunk_input_bwd(G.contiguous(), g_feat, g_dydx, nfreq, L, C, jac_scale)
             table = ctx.table
-            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
             _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
             g_emb = None if inplace else target
@@ -233,7 +233,7 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     g_emb = target = None
     if need_table:
         table = ctx.table
-        inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+        inplace = _be.accumulates_into_grad(table)
         target = table.grad if inplace else torch.zeros_like(embeddings)
         g_emb = None if inplace else target
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
@@ -381,7 +381,7 @@ class _fused_appearance(torch.autograd.Function):
         g_emb = None
         if ctx.needs_input_grad[3]:
             table = ctx.table
-            inplace = _be.ACCUMULATE_INTO_GRAD and table is not None and table.grad is not None
+            inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
             be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
                    ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
@@ -1420,7 +1420,9 @@ class HoloSceneNetwork(nn.Module):
         intrinsics, pose = input["intrinsics"], input["pose"]
         dev = pose.device
         patch = 32
-        if "bg_xy0" in rng:
+        if "bg_xy0" in rng and torch.is_tensor(rng["bg_xy0"]) and rng["bg_xy0"].device == dev:
+            xy0 = rng["bg_xy0"].float()       # already on the device (graph capture: no host->device copy here)
+        elif "bg_xy0" in rng:
             xy0 = torch.tensor([int(v) for v in rng["bg_xy0"]], device=dev, dtype=torch.float32)
         else:  # device-side draw of the patch origin: no host read of the intrinsics
             span = (intrinsics[0, :2, 2] * 2.0).floor() - patch + 1

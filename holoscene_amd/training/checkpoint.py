@@ -31,8 +31,11 @@ def optimizer_state_dicts(trainer):
     flat = trainer.flat
     opt, sched = _torch_pair(trainer)
     n = int(flat.read_state().step)
+    # ZeRO-1: every rank holds real moments for its own slice only -> collect the slices first (a collective: every rank of the
+    # job must call this, whichever rank writes the files)
+    full = flat.gather_moments() if getattr(trainer, "zero1", False) else None
     if n > 0:
-        for p, (m, v) in zip(flat.params, flat.moment_views()):
+        for p, (m, v) in zip(flat.params, flat.moment_views(full)):
             opt.state[p] = {"step": torch.tensor(float(n)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
     for grp in opt.param_groups:
         grp["lr"] = grp["initial_lr"] * flat.gamma ** n
@@ -58,20 +61,22 @@ def load_optimizer_state(trainer, optimizer_state_dict, scheduler_state_dict):
     if steps and steps != {n}:
         raise ValueError(f"optimizer steps {sorted(steps)} do not match scheduler.last_epoch = {n}")
     with torch.no_grad():
-        for p, (m, v) in zip(flat.params, flat.moment_views()):
+        full = (torch.zeros(flat.padded, device=flat.flat_p.device), torch.zeros(flat.padded, device=flat.flat_p.device))
+        for p, (m, v) in zip(flat.params, flat.moment_views(full)):
             st = opt.state.get(p)
             if st:
                 m.copy_(st["exp_avg"])
                 v.copy_(st["exp_avg_sq"])
-            else:
-                m.zero_()
-                v.zero_()
+        flat.load_moments(*full)      # with sharded moments (ZeRO-1) every rank keeps its own slice
     flat.set_state(n, [float(g.get("initial_lr", g["lr"] / gamma ** n)) for g in opt.param_groups])
     return n
 
 
-def save_checkpoints(trainer, checkpoints_path, epoch):
+def save_checkpoints(trainer, checkpoints_path, epoch, write=True):
+    """Under data parallelism EVERY rank calls this (the ZeRO-1 moment gather is a collective); pass write=(rank == 0)."""
     opt_sd, sched_sd = optimizer_state_dicts(trainer)
+    if not write:
+        return
     payloads = {MODEL_DIR: {"epoch": epoch, "model_state_dict": trainer.model.state_dict()},
                 OPTIMIZER_DIR: {"epoch": epoch, "optimizer_state_dict": opt_sd},
                 SCHEDULER_DIR: {"epoch": epoch, "scheduler_state_dict": sched_sd}}

@@ -38,24 +38,34 @@ def broadcast_parameters(module, src=0, group=None):
         dist.broadcast(t.data, src=src, group=group)
 
 
+def reduce_scatter_sum(out_shard, full, world_size, rank, group=None):
+    """out_shard <- sum over ranks of full[rank*n:(rank+1)*n].  RCCL: one reduce_scatter_tensor, out of place (a staging slice of
+    1/N of the buffer: no reliance on the backend's in-place aliasing rules).  gloo (CPU tests) has no reduce-scatter: the same
+    sums through one `reduce` per destination rank over that rank's slice -- identical shard arithmetic, so the world-size-2
+    CPU tests cover exactly the indexing the RCCL branch uses."""
+    n = out_shard.numel()
+    if dist.get_backend(group) == "gloo":
+        for r in range(world_size):
+            dist.reduce(full[r * n:(r + 1) * n], dst=r, op=dist.ReduceOp.SUM, group=group)    # only dst's slice is defined afterwards
+        out_shard.copy_(full[rank * n:(rank + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
+
+
 def exchange_and_step_flat(flat, world_size, zero1=True, group=None):
     """Data-parallel step over flat buffers (training/flat.py).
 
-    zero1=True (default): reduce-scatter the flat gradient (each rank receives the SUM of its 1/N slice), run the
-    fused Adam on that slice only (gradient scaled by 1/N inside the kernel), all-gather the updated parameter
-    slices.  Per rank this moves (N-1)/N of the buffer twice -- the same volume as a ring all-reduce -- but cuts the
-    optimiser's HBM traffic and moment storage use by N.  Element-for-element identical to "all-reduce mean, full Adam".
+    zero1=True (default): reduce-scatter the flat gradient (each rank receives the SUM of its 1/N slice in a staging slice), run the
+    fused Adam on that slice only, straight from the staging slice (gradient scaled by 1/N inside the kernel), all-gather the
+    updated parameter slices.  Per rank this moves (N-1)/N of the buffer twice -- the same volume as a ring all-reduce -- and
+    cuts the optimiser's HBM traffic by N; with FlatAdam(shard_moments=True) (what Stage1Trainer builds for zero1) also the moment
+    storage.  Element-for-element identical to "all-reduce mean, full Adam".
     zero1=False: one all-reduce over the flat gradient, full Adam on every rank."""
     if zero1:
         b, e = flat.shard
-        if dist.get_backend(group) == "gloo":   # gloo (CPU tests) has no reduce_scatter: same sums via all_reduce
-            dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
-        else:   # out of place (a staging slice of 1/N of the buffer): no reliance on in-place aliasing rules of the backend
-            if getattr(flat, "_shard_g", None) is None:
-                flat._shard_g = torch.empty(e - b, device=flat.flat_g.device, dtype=flat.flat_g.dtype)
-            dist.reduce_scatter_tensor(flat._shard_g, flat.flat_g, op=dist.ReduceOp.SUM, group=group)
-            flat.flat_g[b:e].copy_(flat._shard_g)
-        flat.step(grad_scale=1.0 / world_size, shard_only=True)
+        shard_g = flat.shard_grad()
+        reduce_scatter_sum(shard_g, flat.flat_g, world_size, flat.rank, group)
+        flat.step(grad_scale=1.0 / world_size, shard_only=True, grad_shard=shard_g)
         dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e].clone(), group=group)
     else:
         dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)

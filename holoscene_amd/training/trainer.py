@@ -58,7 +58,7 @@ class Stage1Trainer:
     """
 
     def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, rank=0, optimizer="flat", graph=False, zero1=True,
-                 freeze_parameters=False):
+                 freeze_parameters=False, inject_draws=False):
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
@@ -72,10 +72,9 @@ class Stage1Trainer:
         self.decay_steps = decay_steps = conf.get_int("train.max_total_iters", default=200000)
         self.flat = None
         if optimizer == "flat":
-            from ..hashencoder import backend
             from .flat import FlatAdam
-            self.flat = FlatAdam(self.model, self.lr, lr_factor, decay_rate, decay_steps, world_size=world_size, rank=rank)
-            backend.ACCUMULATE_INTO_GRAD = True
+            self.flat = FlatAdam(self.model, self.lr, lr_factor, decay_rate, decay_steps, world_size=world_size, rank=rank,
+                                 shard_moments=zero1 and world_size > 1)
             self.optimizer = self.scheduler = None
         elif optimizer == "torch":
             self.optimizer = build_optimizer(self.model, self.lr, lr_factor)
@@ -90,10 +89,15 @@ class Stage1Trainer:
             raise ValueError("graph=True cannot be combined with loss.end_step > 0 (per-step host-side loss weights); use graph=False")
         self.use_graph = graph
         self.freeze_parameters = freeze_parameters  # tests: compute gradients but skip the update
+        self.inject_draws = inject_draws            # tests: explicit random draws live in the graph's static input block
         self.zero1 = zero1 and world_size > 1
         self.add_objectvio_iter = conf.get_int("train.add_objectvio_iter", default=100000)
         self.iter_step = 0
         self._graphs = {}
+        # same seed on every rank -> identical initial parameters; from here on every rank draws from its own stream (frames, ray
+        # jitter, inverse-CDF draws, Eikonal points): identical draws across data-parallel ranks would correlate the sampling noise
+        if world_size > 1:
+            torch.manual_seed(seed + 7919 * (rank + 1))
 
     # ------------------------------------------------------------------ eager path
     def _exchange_and_step(self):
@@ -108,7 +112,15 @@ class Stage1Trainer:
             self.optimizer.step()
             self.scheduler.step()
 
-    def train_step(self, indices, model_input, ground_truth, rng=None):
+    def train_step(self, indices, model_input, ground_truth, rng=None, depths=None):
+        """rng: explicit random draws (HoloSceneNetwork.forward's dict).  With graph=True they are normally a reason to run
+        eagerly; a trainer built with inject_draws=True instead keeps them in the graph's static input block, so the captured
+        whole-iteration graph itself can be driven by the reference's draws (parity tests).  depths: optional
+        {"z_vals", "z_eik"[, "bg_z"]} that replace the sampler's results downstream of it (the sampler still runs)."""
+        if self.use_graph and self.inject_draws:
+            if rng is None or not self._full_graph_ok():
+                raise ValueError("inject_draws=True needs explicit draws and the whole-iteration graph path")
+            return self._train_step_full_graph(model_input, ground_truth, rng=rng, depths=depths)
         if self.use_graph and rng is None:
             return self._train_step_graph(indices, model_input, ground_truth)
         self.model.train()
@@ -158,13 +170,22 @@ class Stage1Trainer:
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         with model.density.shared_beta(), _net.shared_effective_weights(model.weight_norm_layers()):
             with torch.no_grad():
-                rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
+                if "rng" in st:     # injected draws (static tensors the caller overwrites before each replay)
+                    rng = st["rng"]
+                else:
+                    rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
                 rays = model.prepare_rays(st["input"], rng)
                 z_vals, z_eik = model.sample(rays, rng)
                 rounds = model.ray_sampler._rounds
-                bg = model.prepare_background(st["input"]) if with_bg else None
+                bg = model.prepare_background(st["input"], rng if "rng" in st else None) if with_bg else None
                 model.ray_sampler._rounds = rounds      # report the main pass, not the background patch
+                sampled = {"z_vals": z_vals, "z_eik": z_eik, "bg_z": None if bg is None else bg["z_vals"]}
+                if "depths" in st:  # the caller's depths replace the sampler's downstream of it
+                    z_vals, z_eik = st["depths"]["z_vals"], st["depths"]["z_eik"]
+                    if bg is not None and "bg_z" in st["depths"]:
+                        bg["z_vals"] = st["depths"]["bg_z"]
             out = model.render(rays, z_vals, z_eik, None, rng=rng, bg=bg)
+            out["sampled"] = sampled
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
@@ -173,21 +194,64 @@ class Stage1Trainer:
             self.flat.step()
         return out, loss_out
 
-    def _train_step_full_graph(self, model_input, ground_truth):
+    @staticmethod
+    def _flatten_draws(rng, dev, n_extra):
+        """The injected-draw dict as a flat {name: device tensor} block with shapes that do not depend on the realised sampler
+        round count: only the first N_samples_extra entries of a permutation are ever used (ray_sampler.py:269), the patch origin
+        becomes a float pair."""
+        flat = {}
+        for k, v in rng.items():
+            if k == "bg":
+                flat["bg"] = Stage1Trainer._flatten_draws(v, dev, n_extra)
+            elif k == "bg_xy0":
+                flat[k] = torch.as_tensor([float(a) for a in v], dtype=torch.float32).to(dev)
+            elif k == "perm":
+                flat[k] = torch.as_tensor(v)[:n_extra].to(dev).long().contiguous()
+            else:
+                flat[k] = torch.as_tensor(v).to(dev).contiguous()
+        return flat
+
+    @staticmethod
+    def _copy_tree(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict):
+                Stage1Trainer._copy_tree(dst[k], v)
+            else:
+                dst[k].copy_(v)
+
+    def _warm_up(self, body):
+        """Two eager passes of a to-be-captured body on a side stream (allocator, lazy kernel loading).  They run the full body
+        including its Adam node; parameters, moments and the step / learning-rate state are restored afterwards, so warm-up
+        is invisible to training: hsAdamState.step stays equal to iter_step (checkpoint.load_optimizer_state relies on that for
+        the render_bg_iter / add_objectvio_iter gating after a resume)."""
+        flat = self.flat
+        snap = [t.clone() for t in (flat.flat_p, flat.flat_m, flat.flat_v, flat.state)]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        cur.wait_stream(side)
+        for t, s0 in zip((flat.flat_p, flat.flat_m, flat.flat_v, flat.state), snap):
+            t.copy_(s0)
+        self.model.implicit_network.invalidate_packed_weights()
+        torch.cuda.synchronize()
+
+    def _train_step_full_graph(self, model_input, ground_truth, rng=None, depths=None):
         self.model.train()
         with_bg = self.model.wants_background(self.iter_step)
         key = ("full", with_bg, self.iter_step >= self.add_objectvio_iter)
         entry = self._graphs.get(key)
+        if rng is not None:
+            rng = self._flatten_draws(rng, self.device, self.model.ray_sampler.N_samples_extra)
         if entry is None:
             st = {"input": {k: v.clone() for k, v in model_input.items()}, "gt": {k: v.clone() for k, v in ground_truth.items()}}
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):  # warm-up on a side stream (these are real training steps on the current batch)
-                for _ in range(2):
-                    self._full_body(st, key[1], key[2])
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
+            if rng is not None:
+                st["rng"] = rng       # freshly made device tensors: they become the static block
+            if depths is not None:
+                st["depths"] = {k: v.to(self.device).clone() for k, v in depths.items()}
+            self._warm_up(lambda: self._full_body(st, key[1], key[2]))
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
                 out, loss_out = self._full_body(st, key[1], key[2])
@@ -197,6 +261,10 @@ class Stage1Trainer:
         dl = [st["input"][k] for k in model_input] + [st["gt"][k] for k in ground_truth]
         sl = list(model_input.values()) + list(ground_truth.values())
         torch._foreach_copy_(dl, sl)
+        if rng is not None and st["rng"] is not rng:
+            self._copy_tree(st["rng"], rng)
+        if depths is not None:
+            self._copy_tree(st["depths"], {k: v.to(self.device) for k, v in depths.items()})
         entry["graph"].replay()
         self.model.ray_sampler._rounds = entry["rounds"]
         if self.world_size > 1:
@@ -229,14 +297,7 @@ class Stage1Trainer:
               "gt": {k: v.clone() for k, v in fresh["gt"].items()}}
         if with_bg:
             st["bg"] = {k: v.clone() for k, v in fresh["bg"].items()}
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):  # warm-up on a side stream (these are real training steps on the current batch)
-            for _ in range(2):
-                self._graph_body(st, with_bg, call_reg)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
+        self._warm_up(lambda: self._graph_body(st, with_bg, call_reg))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
             out, loss_out = self._graph_body(st, with_bg, call_reg)

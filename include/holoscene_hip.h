@@ -245,6 +245,11 @@ typedef struct hsAdamState {
 int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, void *stream);
 int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, const hsAdamState *state, float beta1, float beta2,
                  float eps, float grad_scale, void *stream);
+/* The same update with shard-local gradient / moment buffers (ZeRO-1 data parallelism, SURVEY 8e -- new, the reference is single-GPU):
+ * p is the full flat buffer; g[0] holds flat element g_base and m[0], v[0] flat element mv_base (multiples of 4, <= begin), so a
+ * rank keeps only its 1/N slice of both moments and steps straight from the reduce-scatter output. */
+int hs_adam_flat_shard(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, int64_t g_base, int64_t mv_base,
+                       const hsAdamState *state, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------ 6. fused volume-rendering composite
  *

@@ -130,6 +130,17 @@ class DrawLog:
         torch.rand, torch.rand_like, torch.randperm, torch.randint, torch.Tensor.uniform_, np.random.randint = self._saved
 
 
+# layer / grid shapes of a fixture.  "tiny" is what every round-1 fixture uses; "stock" has the layer shapes of
+# confs/replica/room_0/replica_room_0.conf (width 256, feature 256, 16 levels, base 16 -> 2048) with a small hash table so the
+# fixture stays small: those are the shapes the fused matrix-core kernels of the product are built for.
+SHAPES = {"tiny": dict(L=4, base=4, end=32, logmap=10, width=64, feat=32),
+          "stock": dict(L=16, base=16, end=2048, logmap=12, width=256, feat=256)}
+
+
+def shape_meta(shape):
+    return {f"meta.{k}": v for k, v in SHAPES[shape].items()}
+
+
 def small_conf(K, S, beta, L=4, base=4, end=32, logmap=10, width=64, feat=32, use_bg_reg=True):
     return Conf(
         feature_vector_size=feat, scene_bounding_sphere=1.0, use_bg_reg=use_bg_reg, render_bg_iter=10,
@@ -206,20 +217,30 @@ def name_draws(draws, bg):
     return named
 
 
-def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, seed, res=64, adam_steps=2):
+def distinct_objects(model, K, g):
+    """geometric init makes all K objects the SAME function (every min a K-way tie): give each its own shape"""
+    with torch.no_grad():
+        l2 = model.implicit_network.lin2
+        l2.weight_v[:K] += 0.05 * torch.randn(K, l2.weight_v.shape[1], generator=g) * l2.weight_v[:K].abs().mean()
+        l2.bias[:K] += 0.15 * torch.randn(K, generator=g)
+
+
+def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, seed, res=64, adam_steps=2, shape="tiny", distinct=False):
     torch.manual_seed(seed)
     np.random.seed(seed)
-    conf = small_conf(K, S, beta)
+    conf = small_conf(K, S, beta, **SHAPES[shape])
     model = Net(conf=conf, graph_node_dict=None, num_images=4)
     model.train()
     perturb(model, seed + 1)
+    if distinct:
+        distinct_objects(model, K, torch.Generator().manual_seed(seed + 5))
     loss_fn = Loss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
                    normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0,
                    reg_vio_weight=0.01, bg_reg_weight=0.01, depth_type="marigold")
     uv, intr, gt = batch(R, K, res, seed + 2)
     pose = look_at_pose(eye)
     rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.iter_step": iter_step, "meta.call_reg": int(call_reg), "meta.res": res,
-           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+           **shape_meta(shape)}
     to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(uv=uv, pose=pose, intrinsics=intr), rec)
     to_np("gt.", gt, rec)
@@ -228,10 +249,15 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
         {"params": list(model.implicit_network.grid_parameters()), "lr": lr_grid},
         {"params": list(model.implicit_network.mlp_parameters()) + list(model.rendering_network.parameters()), "lr": lr},
         {"params": list(model.density.parameters()), "lr": lr}], betas=(0.9, 0.99), eps=1e-15)
+    sweeps = []
+    orig_sdf_vals = model.implicit_network.get_sdf_vals
+    # the sampler's sweeps of the main pass carry S points per ray (the Eikonal set's get_sdf_vals call has 4R points)
+    model.implicit_network.get_sdf_vals = lambda p: (sweeps.append(p.shape[0]), orig_sdf_vals(p))[1]
     for step in range(adam_steps):
         opt.zero_grad()
         with DrawLog() as log:
             out = model({"intrinsics": intr, "uv": uv.clone(), "pose": pose}, torch.tensor([0]), iter_step=iter_step)
+        rec["meta.rounds"] = sum(1 for n in sweeps if n == R * S)
         out["iter_step"] = iter_step
         lo = loss_fn(out, gt, call_reg=call_reg)
         lo["loss"].backward()
@@ -253,9 +279,9 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  loss={float(lo['loss']):.6f}  N={out['z_vals'].shape[1]}")
 
 
-def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
+def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shape="tiny"):
     torch.manual_seed(seed)
-    conf = small_conf(K, S, beta)
+    conf = small_conf(K, S, beta, **SHAPES[shape])
     model = Net(conf=conf, graph_node_dict=None, num_images=4)
     model.train(train)
     perturb(model, seed + 1, scale=1e-3, emb_scale=1e-3)
@@ -271,8 +297,7 @@ def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
     model.implicit_network.get_sdf_vals = lambda p: (calls.append(p.shape[0]), orig(p))[1]
     with DrawLog() as log:
         z, z_eik = model.ray_sampler.get_z_vals(d, o, model)
-    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.train": int(train), "meta.rounds": len(calls),
-           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+    rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.train": int(train), "meta.rounds": len(calls), **shape_meta(shape)}
     to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(ray_dirs=d, cam_loc=o), rec)
     names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
@@ -360,11 +385,11 @@ def run_multi_obj(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  calls={len(calls)}")
 
 
-def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05):
+def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05, shape="tiny"):
     """G3 / G5 of SURVEY 8c: the query methods of ObjectImplicitNetworkGrid (network.py:169-506), RenderingNetwork.forward (:585-614),
     volume_rendering and occlusion_opacity (:1803-1824) called directly on a small model with perturbed, object-distinct weights."""
     torch.manual_seed(seed)
-    model = Net(conf=small_conf(K, 16, beta), graph_node_dict=None, num_images=4)
+    model = Net(conf=small_conf(K, 16, beta, **SHAPES[shape]), graph_node_dict=None, num_images=4)
     model.eval()
     perturb(model, seed + 1, scale=1e-2, emb_scale=2e-2)
     g = torch.Generator().manual_seed(seed + 2)
@@ -377,8 +402,7 @@ def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05):
     dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
     net = model.implicit_network
     a, b = 0, K - 1
-    rec = {"meta.K": K, "meta.S": 16, "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32,
-           "meta.a": a, "meta.b": b}
+    rec = {"meta.K": K, "meta.S": 16, **shape_meta(shape), "meta.a": a, "meta.b": b}
     to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(x=x, dirs=dirs), rec)
 
@@ -398,6 +422,13 @@ def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05):
     tup("get_shift_sdf_raw.", net.get_shift_sdf_raw(x.clone()))
     tup("get_outputs_and_indices.", net.get_outputs_and_indices(x.clone()))
     tup("rendering.", model.rendering_network(x, outs[2].detach(), dirs, outs[1].detach(), torch.tensor([0])))
+    if shape == "stock":   # the dense grid of the mesh extraction (utils/plots.py:1354-1365 get_grid_uniform, :154-177 callers)
+        vres = 10
+        ax = np.linspace(-1.0, 1.0, vres)
+        xx, yy, zz = np.meshgrid(ax, ax, ax, indexing="ij")
+        gp = torch.tensor(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T, dtype=torch.float)
+        rec["meta.vres"] = vres
+        to_np("volume.", dict(points=gp, raw=net.get_sdf_raw(gp), shift=net.get_shift_sdf_raw(gp), min=net.get_sdf_vals(gp)), rec)
     # compositing on its own
     z = torch.sort(torch.rand(R, N, generator=g) * 2.0 + 0.05, dim=1).values
     sdf = torch.randn(R * N, 1, generator=g) * 0.2
@@ -410,22 +441,25 @@ def run_network(Net, name, *, K, seed, B=48, R=6, N=10, beta=0.05):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def run_three_steps(Net, Loss, name, *, K, S, R, beta, eye, seed, res=64, steps=3, decay_rate=0.1, decay_steps=20):
+def run_three_steps(Net, Loss, name, *, K, S, R, beta, eye, seed, res=64, steps=3, decay_rate=0.1, decay_steps=20, shape="tiny",
+                    distinct=False):
     """G6 / G7 of SURVEY 8c: three consecutive training iterations of the reference -- forward, loss, backward, Adam, ExponentialLR
     exactly as HoloSceneTrainRunner wires them (holoscene_train.py:156-169, 355-374, 428; decay_steps shortened so that the
     schedule is visible) -- with the draws of every step, the learning rates after every step and all parameters after steps 1 and 3."""
     torch.manual_seed(seed)
     np.random.seed(seed)
-    conf = small_conf(K, S, beta, use_bg_reg=False)
+    conf = small_conf(K, S, beta, use_bg_reg=False, **SHAPES[shape])
     model = Net(conf=conf, graph_node_dict=None, num_images=4)
     model.train()
     perturb(model, seed + 1)
+    if distinct:
+        distinct_objects(model, K, torch.Generator().manual_seed(seed + 5))
     loss_fn = Loss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
                    normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0,
                    reg_vio_weight=0.01, bg_reg_weight=0.01, depth_type="marigold")
     pose = look_at_pose(eye)
     rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.res": res, "meta.steps": steps, "meta.decay_steps": decay_steps,
-           "meta.L": 4, "meta.base": 4, "meta.end": 32, "meta.logmap": 10, "meta.width": 64, "meta.feat": 32}
+           **shape_meta(shape)}
     rec["meta.decay_rate"] = np.float64(decay_rate)
     to_np("state.", model.state_dict(), rec)
     lr, lr_grid = 5e-4, 5e-4 * 20
@@ -483,6 +517,45 @@ def run_hash(name, *, L, base, end, logmap, B, seed, D=3, C=2):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def stock_hash_table(seed, n_entries, C=2):
+    """The embedding table of a hash_stock_* fixture: 12.2 M floats are regenerated from the seed instead of stored
+    (torch's CPU generator is bit-reproducible; the fixture keeps a checksum and a strided sample to prove it)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    return (torch.rand(n_entries, C, generator=g) * 2 - 1) * 0.5
+
+
+def run_hash_stock(name, *, seed, B=1000, L=16, base=16, end=2048, logmap=19, D=3, C=2):
+    """G1 of SURVEY 8c at the stock grid (16 levels, 2^19, 16 -> 2048): B = 1000 points incl. boundary / out-of-cube ones.  Table regenerated
+    from the seed; the two table gradients are stored sparsely (touched rows only)."""
+    g = torch.Generator().manual_seed(seed)
+    pls = hash_oracle.per_level_scale_for(base, end, L)
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, logmap, D))
+    emb = stock_hash_table(seed, int(offs[-1]), C)
+    x = torch.rand(B, D, generator=g) * 1.2 - 0.1
+    x[:8] = torch.tensor([[0.0] * D, [1.0] * D, [0.5] * D, [1.0, 0.0, 0.5][:D], [0.0, 1.0, 1.0][:D], [0.25] * D, [0.75] * D,
+                          [1.0, 1.0, 0.0][:D]])
+    S, H = float(np.log2(pls)), base
+    out, dydx = hash_oracle.fwd(x, emb, offs, S, H, True)
+    grad = torch.randn(L, B, C, generator=g)
+    gx, gemb = hash_oracle.bwd(grad, x, emb, offs, S, H, True, dydx)
+    ggx = torch.randn(B, D, generator=g)
+    gg, g2 = hash_oracle.bwd2(grad, x, emb, offs, S, H, dydx, ggx)
+
+    def sparse(t):
+        rows = torch.nonzero(t.abs().sum(-1) > 0).reshape(-1)
+        return rows.numpy().astype(np.int64), t[rows].numpy()
+
+    ge_rows, ge_vals = sparse(gemb)
+    g2_rows, g2_vals = sparse(g2)
+    rec = dict(L=L, base=base, end=end, logmap=logmap, seed=seed, S=np.float32(S), x=x.numpy(), offsets=offs.numpy(),
+               emb_checksum=np.float64(emb.double().sum().item()), emb_sample=emb[::65537].numpy().copy(),
+               out=out.numpy(), dydx=dydx.numpy(), grad=grad.numpy(), grad_x=gx.numpy(), grad_emb_rows=ge_rows, grad_emb_vals=ge_vals,
+               ggx=ggx.numpy(), grad_grad=gg.numpy(), grad2_emb_rows=g2_rows, grad2_emb_vals=g2_vals)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  touched rows {len(ge_rows)}")
+
+
 def run_tables():
     """Offsets/per-level-scale tables of the BASELINE configs from the reference's HashEncoder ctor."""
     from hashencoder.hashgrid import HashEncoder
@@ -524,6 +597,25 @@ def main():
     for K in (2, 21, 32):
         if sel(f"net_k{K}"):
             run_network(Net, f"net_k{K}", K=K, seed=40 + K)
+    # ---- stock layer shapes (width 256, feature 256, L=16, 16 -> 2048): what the fused matrix-core kernels are built for
+    if sel("stock_k32_bg"):
+        run_iteration(Net, Loss, "stock_k32_bg", K=32, S=16, R=32, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=110,
+                      shape="stock", distinct=True)
+    if sel("stock_k21"):
+        run_iteration(Net, Loss, "stock_k21", K=21, S=32, R=32, beta=0.05, eye=(0.7, 0.0, 0.1), iter_step=3, call_reg=False, seed=120,
+                      shape="stock", distinct=True)
+    if sel("stock_steps3_k32"):
+        run_three_steps(Net, Loss, "stock_steps3_k32", K=32, S=16, R=24, beta=0.05, eye=(0.0, 0.1, 0.6), seed=150, shape="stock",
+                        distinct=True)
+    for K in (21, 32):
+        if sel(f"stock_net_k{K}"):
+            run_network(Net, f"stock_net_k{K}", K=K, seed=140 + K, B=160, shape="stock")
+    for i, (S, beta, eye) in enumerate([(32, 0.1, (0, 0, 0.6))]):
+        if sel(f"stock_sampler_{i}"):
+            run_sampler(Net, f"stock_sampler_{i}", K=32, S=S, R=24, beta=beta, eye=eye, seed=1, shape="stock")
+    for seed in (0, 1, 2):
+        if sel(f"hash_stock_s{seed}"):
+            run_hash_stock(f"hash_stock_s{seed}", seed=seed)
     if sel("multi_obj_k5_eval"):
         run_multi_obj(Net, "multi_obj_k5_eval", K=5, S=16, R=16, beta=0.05, eye=(0.7, 0.0, 0.1), seed=31, train=False)
     if sel("multi_obj_k5") and (not want or "multi_obj_k5" in want or "multi_obj" in want):

@@ -4,16 +4,12 @@ import os
 
 import torch
 
-from holoscene_amd.hashencoder import backend
 from holoscene_amd.training import checkpoint as ck
 from holoscene_amd.training.trainer import Stage1Trainer, stock_conf
 
 
 def _trainer(optimizer):
-    prev = backend.ACCUMULATE_INTO_GRAD
-    tr = Stage1Trainer(stock_conf(num_rays=16, S=8, d_out=3, num_levels=4, end_size=32, logmap=8, base_size=4), device="cpu", optimizer=optimizer)
-    backend.ACCUMULATE_INTO_GRAD = prev
-    return tr
+    return Stage1Trainer(stock_conf(num_rays=16, S=8, d_out=3, num_levels=4, end_size=32, logmap=8, base_size=4), device="cpu", optimizer=optimizer)
 
 
 def _fake_steps(tr, n, seed=0):

@@ -87,16 +87,17 @@ class _TorchAdamKernels:
         state.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
 
     @staticmethod
-    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale):
+    def adam_flat(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale, g_base=0, mv_base=0):
         from holoscene_amd.hashencoder.backend import hsAdamState
         st = hsAdamState.from_buffer_copy(bytes(state.numpy().tobytes()))
         idx = torch.arange(begin, end)
         step = torch.where(idx < st.group_end[0], torch.tensor(st.step_size[0]),
                            torch.where(idx < st.group_end[1], torch.tensor(st.step_size[1]), torch.tensor(st.step_size[2])))
-        gg = g[begin:end] * grad_scale
-        m[begin:end] += (1 - beta1) * (gg - m[begin:end])
-        v[begin:end] = v[begin:end] * beta2 + (1 - beta2) * gg * gg
-        p[begin:end] -= step * (m[begin:end] / (v[begin:end].sqrt() / st.bc2_sqrt + eps))
+        gs, ms = slice(begin - g_base, end - g_base), slice(begin - mv_base, end - mv_base)   # shard-local buffers (hs_adam_flat_shard)
+        gg = g[gs] * grad_scale
+        m[ms] += (1 - beta1) * (gg - m[ms])
+        v[ms] = v[ms] * beta2 + (1 - beta2) * gg * gg
+        p[begin:end] -= step * (m[ms] / (v[ms].sqrt() / st.bc2_sqrt + eps))
 
 
 class _TinyModel(torch.nn.Module):
@@ -126,7 +127,8 @@ def _flat_worker(rank, world, port, q, zero1):
         setattr(backend._HipBackend, name, staticmethod(getattr(_TorchAdamKernels, name)))
     torch.manual_seed(0)            # identical replicas
     model = _TinyModel()
-    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank)
+    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1)
+    assert flat.flat_m.numel() == (flat.padded // world if zero1 else flat.padded)
     g = torch.Generator().manual_seed(50 + rank)
     hist = []
     for _ in range(2):
@@ -136,7 +138,14 @@ def _flat_worker(rank, world, port, q, zero1):
         flat.flat_g.copy_(local)
         hist.append(local.clone())
         exchange_and_step_flat(flat, world, zero1=zero1)
-    q.put((rank, [h.numpy() for h in hist], flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))
+    # checkpoint export under ZeRO-1: the per-parameter Adam state must be the FULL moments on whichever rank saves
+    from types import SimpleNamespace
+    from holoscene_amd.training import checkpoint as ck
+    tr = SimpleNamespace(flat=flat, model=model, lr=5e-4, lr_factor=20.0, decay_rate=0.1, decay_steps=1000, zero1=zero1, world_size=world)
+    opt_sd, _ = ck.optimizer_state_dicts(tr)
+    moments = [(s_["exp_avg"].numpy().copy(), s_["exp_avg_sq"].numpy().copy(), float(s_["step"])) for s_ in opt_sd["state"].values()]
+    q.put((rank, [h.numpy() for h in hist], flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()},
+           moments))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,7 +168,7 @@ def test_flat_exchange_equals_single_process_mean_gradient(zero1):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, h0, flat0, params0), (_, h1, flat1, _) = res
+    (_, h0, flat0, params0, mom0), (_, h1, flat1, _, mom1) = res
     assert (flat0 == flat1).all(), "replicas diverged"
     # single-process reference with torch.optim.Adam on the same groups
     torch.manual_seed(0)
@@ -178,3 +187,11 @@ def test_flat_exchange_equals_single_process_mean_gradient(zero1):
         sched.step()
     for n, p in ref.named_parameters():
         assert torch.allclose(p.detach(), torch.from_numpy(params0[n]), rtol=1e-5, atol=1e-7), n
+    # the exported optimiser state (either rank's) = single-process Adam's moments for EVERY parameter, not just the saver's shard
+    for mom in (mom0, mom1):
+        assert len(mom) == len(plist)
+        for p, (m, v, step) in zip(plist, mom):
+            st = opt.state[p]
+            assert step == 2.0
+            assert torch.allclose(st["exp_avg"], torch.from_numpy(m).view_as(p), rtol=1e-4, atol=1e-7)
+            assert torch.allclose(st["exp_avg_sq"], torch.from_numpy(v).view_as(p), rtol=1e-4, atol=1e-9)

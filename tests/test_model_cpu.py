@@ -20,7 +20,7 @@ def _oracle_hash(monkeypatch):
     monkeypatch.setattr(loss, "LOSS_IMPL", "torch")
 
 
-@pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])
+@pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval", "stock_sampler_0"])
 def test_sampler(name):
     rec = load(name)
     model = build_model(rec)
@@ -32,7 +32,7 @@ def test_sampler(name):
     assert z_eik.shape == rec["out.z_samples_eik"].shape
 
 
-@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5"])
+@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21"])
 def test_iteration(name):
     rec = load(name)
     model = build_model(rec)
@@ -74,7 +74,7 @@ def test_stage23_entry_points(name):
     check_multi_obj(model, rec)
 
 
-@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32"])
+@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32", "stock_net_k21", "stock_net_k32"])
 def test_network_query_methods(name):
     """G3 / G5 of SURVEY 8c: ObjectImplicitNetworkGrid's query methods, RenderingNetwork.forward, volume_rendering and
     occlusion_opacity against direct calls of the reference's (K = 2, 21, 32; perturbed, object-distinct weights; points incl.

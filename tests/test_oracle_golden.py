@@ -84,7 +84,7 @@ def test_hash_self_consistency():
     assert abs((g2.double() * emb.double()).sum() - val) < 1e-3 * abs(val)      # linear in emb
 
 
-@pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval"])
+@pytest.mark.parametrize("name", [f"sampler_{i}" for i in range(5)] + ["sampler_eval", "stock_sampler_0"])
 def test_sampler_matches_reference(name):
     rec = load(name)
     o = Stage1Oracle(oracle_cfg(rec), section(rec, "state."))
@@ -96,7 +96,7 @@ def test_sampler_matches_reference(name):
     close(z_eik, rec["out.z_samples_eik"], 1e-5, 1e-5, "z_eik")
 
 
-@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32"])
+@pytest.mark.parametrize("name", ["net_k2", "net_k21", "net_k32", "stock_net_k21", "stock_net_k32"])
 def test_network_methods_match_reference(name):
     """G3 / G5 of SURVEY 8c: the oracle's network, rendering and compositing restatements against direct calls of the reference's
     ObjectImplicitNetworkGrid / RenderingNetwork / volume_rendering / occlusion_opacity (K = 2, 21, 32)."""
@@ -123,7 +123,7 @@ def test_network_methods_match_reference(name):
     close(o.occlusion_opacity(T, dists, vin["raw"]), rec["vr.out.occlusion"], 1e-5, 1e-7, "occlusion")
 
 
-@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5"])
+@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21"])
 def test_iteration_matches_reference(name):
     rec = load(name)
     sd = section(rec, "state.")
