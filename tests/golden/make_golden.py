@@ -31,7 +31,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.dirname(HERE))
 from oracle import hash_oracle  # noqa: E402
+from helpers import stock_hash_table  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- import shims
@@ -253,11 +255,23 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
     orig_sdf_vals = model.implicit_network.get_sdf_vals
     # the sampler's sweeps of the main pass carry S points per ray (the Eikonal set's get_sdf_vals call has 4R points)
     model.implicit_network.get_sdf_vals = lambda p: (sweeps.append(p.shape[0]), orig_sdf_vals(p))[1]
+    sampled = []         # what every sampler call returned: [main pass, background patch]
+    orig_get_z = model.ray_sampler.get_z_vals
+
+    def get_z_logged(*a, **k):
+        r = orig_get_z(*a, **k)
+        sampled.append(r)
+        return r
+    model.ray_sampler.get_z_vals = get_z_logged
     for step in range(adam_steps):
         opt.zero_grad()
         with DrawLog() as log:
             out = model({"intrinsics": intr, "uv": uv.clone(), "pose": pose}, torch.tensor([0]), iter_step=iter_step)
         rec["meta.rounds"] = sum(1 for n in sweeps if n == R * S)
+        if step == 0:
+            rec["aux.z_samples_eik"] = sampled[0][1].detach().numpy().copy()
+            if len(sampled) > 1:
+                rec["aux.bg_z_vals"] = sampled[1][0].detach().numpy().copy()
         out["iter_step"] = iter_step
         lo = loss_fn(out, gt, call_reg=call_reg)
         lo["loss"].backward()
@@ -517,13 +531,6 @@ def run_hash(name, *, L, base, end, logmap, B, seed, D=3, C=2):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def stock_hash_table(seed, n_entries, C=2):
-    """The embedding table of a hash_stock_* fixture: 12.2 M floats are regenerated from the seed instead of stored
-    (torch's CPU generator is bit-reproducible; the fixture keeps a checksum and a strided sample to prove it)."""
-    g = torch.Generator().manual_seed(1000 + seed)
-    return (torch.rand(n_entries, C, generator=g) * 2 - 1) * 0.5
-
-
 def run_hash_stock(name, *, seed, B=1000, L=16, base=16, end=2048, logmap=19, D=3, C=2):
     """G1 of SURVEY 8c at the stock grid (16 levels, 2^19, 16 -> 2048): B = 1000 points incl. boundary / out-of-cube ones.  Table regenerated
     from the seed; the two table gradients are stored sparsely (touched rows only)."""
@@ -556,6 +563,20 @@ def run_hash_stock(name, *, seed, B=1000, L=16, base=16, end=2048, logmap=19, D=
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  touched rows {len(ge_rows)}")
 
 
+def run_conf():
+    """The reference's stock Stage-1 configuration file read by the build's own HOCON reader (holoscene_amd/utils/conf.py; pyhocon is
+    not installed here), stored as plain JSON: the file itself cannot travel, its parsed content is data (what
+    ConfigFactory.parse_file hands to the trainer, holoscene_train.py:48)."""
+    import json
+    from holoscene_amd.utils.conf import parse_file
+    out = {}
+    for tag, rel in {"replica_room_0": "confs/replica/room_0/replica_room_0.conf"}.items():
+        out[tag] = parse_file(os.path.join(REF, rel))
+    with open(os.path.join(HERE, "stock_conf_parsed.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("stock_conf_parsed: ok", sorted(out["replica_room_0"].keys()))
+
+
 def run_tables():
     """Offsets/per-level-scale tables of the BASELINE configs from the reference's HashEncoder ctor."""
     from hashencoder.hashgrid import HashEncoder
@@ -577,6 +598,8 @@ def main():
     Net, Loss = _install_reference()
     if sel("hash_tables"):
         run_tables()
+    if sel("stock_conf_parsed"):
+        run_conf()
     if sel("hash_small"):
         run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
     if sel("hash_mid"):

@@ -38,3 +38,25 @@ def rand_dict(rec):
     if "bg_xy0" in out:
         out["bg_xy0"] = tuple(int(v) for v in out["bg_xy0"])
     return out
+
+
+def stock_hash_table(seed, n_entries, C=2):
+    """The embedding table of a hash_stock_s* fixture: its 12.2 M floats are regenerated from the seed instead of stored
+    (torch's CPU generator is bit-reproducible; the fixture keeps a checksum and a strided sample to prove it)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    return (torch.rand(n_entries, C, generator=g) * 2 - 1) * 0.5
+
+
+def load_hash_stock(name):
+    """A hash_stock_s* fixture with its table regenerated and its sparse table gradients densified."""
+    r = load(name)
+    emb = stock_hash_table(int(r["seed"]), int(r["offsets"][-1]))
+    assert abs(float(emb.double().sum()) - float(r["emb_checksum"])) < 1e-9 and np.array_equal(emb[::65537].numpy(), r["emb_sample"]), \
+        "the regenerated table differs from the one the fixture was made with"
+    out = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) and v.ndim > 0 else v) for k, v in r.items()}
+    out["emb"] = emb
+    for k in ("grad_emb", "grad2_emb"):
+        dense = torch.zeros_like(emb)
+        dense[out[k + "_rows"]] = out[k + "_vals"]
+        out[k] = dense
+    return out

@@ -1,0 +1,128 @@
+"""GPU: the data-parallel exchange with the REAL collectives and the real fused Adam kernel.
+
+  * world size 1 on `nccl` (= RCCL): exactly the branch an 8-GPU run takes -- reduce_scatter_tensor into the staging slice,
+    hs_adam_flat_shard on shard-local gradient / moment buffers, all_gather_into_tensor -- on the one GPU this box has;
+  * world size 2 on `nccl` when two devices are visible (skipped otherwise);
+  * world size 2 with both ranks sharing the GPU over `gloo` (RCCL refuses duplicate devices): the shard arithmetic of the HIP
+    kernel (g_base / mv_base offsets) with two real shards.
+Each case is compared with one process applying torch.optim.Adam to the mean of the ranks' gradients.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _TinyModel(torch.nn.Module):
+    """The three optimiser groups of the Stage-1 model (tables | MLPs | beta) at toy sizes."""
+
+    def __init__(self):
+        super().__init__()
+        self.grid = torch.nn.Parameter(torch.randn(50001, 2))
+        self.net = torch.nn.Linear(37, 29)
+        self.beta = torch.nn.Parameter(torch.tensor(0.1))
+        me = self
+
+        class NS:
+            pass
+        self.implicit_network, self.rendering_network, self.density = NS(), NS(), NS()
+        self.implicit_network.grid_parameters = lambda: [me.grid]
+        self.implicit_network.mlp_parameters = lambda: list(me.net.parameters())
+        self.rendering_network.parameters = lambda: []
+        self.density.parameters = lambda: [me.beta]
+
+
+def _worker(rank, world, port, backend, q, zero1, steps, share_gpu):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0 if share_gpu else rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from holoscene_amd.training.distributed import exchange_and_step_flat
+    from holoscene_amd.training.flat import FlatAdam
+    torch.manual_seed(0)
+    model = _TinyModel().to(dev)
+    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1)
+    g = torch.Generator().manual_seed(50 + rank)
+    hist = []
+    for _ in range(steps):
+        flat.zero_grad()
+        local = torch.randn(flat.padded, generator=g)
+        local[flat.numel:] = 0
+        flat.flat_g.copy_(local.to(dev))
+        hist.append(local.clone())
+        exchange_and_step_flat(flat, world, zero1=zero1)
+    torch.cuda.synchronize()
+    full_m, full_v = flat.gather_moments()
+    q.put((rank, [h.numpy() for h in hist], flat.flat_p.cpu().numpy().copy(), full_m.cpu().numpy().copy(), full_v.cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, backend, zero1, share_gpu, steps=3):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, zero1, steps, share_gpu)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    flats = [r[2] for r in res]
+    for f in flats[1:]:
+        assert (f == flats[0]).all(), "replicas diverged"
+    # single process: Adam on the mean of the ranks' gradients
+    torch.manual_seed(0)
+    ref = _TinyModel()
+    opt = torch.optim.Adam([{"params": [ref.grid], "lr": 5e-4 * 20}, {"params": list(ref.net.parameters()), "lr": 5e-4},
+                            {"params": [ref.beta], "lr": 5e-4}], betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.1 ** (1 / 1000))
+    plist = [ref.grid] + list(ref.net.parameters()) + [ref.beta]
+    n = sum(p.numel() for p in plist)
+    for s in range(steps):
+        mean = sum(torch.from_numpy(r[1][s]) for r in res) / world
+        off = 0
+        for p in plist:
+            p.grad = mean[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        opt.step()
+        sched.step()
+    want_p = torch.cat([p.detach().reshape(-1) for p in plist])
+    want_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in plist])
+    want_v = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in plist])
+    assert torch.allclose(torch.from_numpy(flats[0][:n]), want_p, rtol=1e-5, atol=1e-7)
+    for r in res:       # the gathered moments (what a checkpoint exports) are complete on every rank
+        assert torch.allclose(torch.from_numpy(r[3][:n]), want_m, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(torch.from_numpy(r[4][:n]), want_v, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_rccl_exchange_world_size_1(zero1):
+    _run(1, "nccl", zero1, share_gpu=False)
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_rccl_exchange_two_gpus(zero1):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end multi-GPU runs take this branch)")
+    _run(2, "nccl", zero1, share_gpu=False)
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_two_ranks_sharing_the_gpu_over_gloo(zero1):
+    _run(2, "gloo", zero1, share_gpu=True)

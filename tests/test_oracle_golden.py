@@ -46,6 +46,21 @@ def test_hash_regression(name):
     assert torch.equal(gg, torch.from_numpy(r["grad_grad"])) and torch.equal(g2, torch.from_numpy(r["grad2_emb"]))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_hash_regression_stock_grid(seed):
+    """G1 of SURVEY 8c at the stock grid (16 levels, T = 2^19, 16 -> 2048, B = 1000 incl. boundary and out-of-cube points)."""
+    from helpers import load_hash_stock
+    r = load_hash_stock(f"hash_stock_s{seed}")
+    x, emb, offs = r["x"], r["emb"], r["offsets"]
+    S, H = float(r["S"]), int(r["base"])
+    out, dydx = hash_oracle.fwd(x, emb, offs, S, H, True)
+    assert torch.equal(out, r["out"]) and torch.equal(dydx, r["dydx"])
+    gx, gemb = hash_oracle.bwd(r["grad"], x, emb, offs, S, H, True, dydx)
+    assert torch.equal(gx, r["grad_x"]) and torch.equal(gemb, r["grad_emb"])
+    gg, g2 = hash_oracle.bwd2(r["grad"], x, emb, offs, S, H, dydx, r["ggx"])
+    assert torch.equal(gg, r["grad_grad"]) and torch.equal(g2, r["grad2_emb"])
+
+
 def test_hash_self_consistency():
     """dy_dx = d(out)/dx by central differences; bwd = transpose of fwd; bwd2 = d(grad_x . ggx)/d(grad, emb)."""
     r = load("hash_small")
