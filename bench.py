@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=15)
+    p.add_argument("--steps", type=int, default=200)     # median over >= 200 iterations after 20 warm-up
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--rays", type=int, default=1024)
     p.add_argument("--samples", type=int, default=128)
     p.add_argument("--objects", type=int, default=32)
@@ -50,47 +50,159 @@ def parse():
     p.add_argument("--roofline-steps", type=int, default=6, help="eager iterations after the timed region used to time single kernels")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-second-point", action="store_true", help="skip the beta=0.1 (1 sampler round, dense gradients) point of SURVEY 8(d)")
-    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--no-fp32-point", action="store_true", help="skip the fp32 (the reference's own precision) timing reported beside the headline")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget, split between the 1-thread and the all-threads run")
     return p.parse_args()
 
 
-class KernelTimer:
-    """HIP-event timing of one backend entry point, recorded on the stream the kernel is launched on."""
+MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+K_IN = 71              # real input width of the SDF trunk (3 + 36 positional-encoding values + 32 hash features); the kernels pad it to 96
 
-    def __init__(self, backend_cls, name, size_arg=4):
-        self.events, self.points = [], 0
-        self.size_arg = size_arg
-        self._orig = getattr(backend_cls, name)
-        self._raw = backend_cls.__dict__[name]   # the descriptor (staticmethod/classmethod) to put back
-        self._cls, self._name = backend_cls, name
+
+def trunk_flops_per_row(K):
+    """T(K) = 2 (71*256 + 256^2 + 256 K), on the UNPADDED shapes."""
+    return 2 * (K_IN * 256 + 256 * 256 + 256 * K)
+
+
+CF = 2 * (32 * 256 + 256 * 256)                 # colour-feature MLP per point (SURVEY 8d: Cf)
+RN = 2 * (337 * 256 + 256 * 256 + 256 * 3)      # rendering network per point (SURVEY 8d: Rn)
+G_BYTES = 16 * 8 * 2 * 4                        # hash gather per point and grid: L * 8 corners * C * 4 B = 1024
+
+
+def _work_hash_fwd(a, k):
+    B, C, L, D = a[4], a[6], a[7], a[5]
+    dydx = a[10] if len(a) > 10 else k.get("dy_dx")
+    return 0, B * (L * 8 * C * 4 + 4 * D + L * C * 4 + (L * D * C * 4 if dydx is not None else 0))
+
+
+def _work_sdf_mlp(a, k):
+    B, K = a[0].shape[0], a[8]
+    return B * trunk_flops_per_row(K), B * (12 + 128 + 4)
+
+
+def _work_trunk_fwd(a, k):
+    M, K = a[10].shape[0], a[7]
+    return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 96 * 2 + K * 4) + (M // 4) * (12 + 128 + 384)
+
+
+def _work_trunk_bwd(a, k):
+    g = a[0]
+    M, Kp = g.shape[0], g.shape[-1]
+    K = min(Kp, 32) if Kp <= 32 else Kp          # padded pitch; the unpadded K is set by the caller through _K_OBJECTS
+    K = _K_OBJECTS[0] or K
+    flops = M * 2 * (256 * K + 256 * 256 + K_IN * 256) + (M * 2 * K * 256 if k.get("dW2_part") is not None else 0)
+    return flops, M * (Kp * 2 + 4 * 256 * 2) + (M // 4) * (128 + 384)
+
+
+def _work_appear_fwd(a, k):
+    B = a[1].shape[0]
+    return B * (CF + RN), B * (128 + 36 + 2 * (96 + 4 * 256) + 12)
+
+
+def _work_appear_bwd(a, k):
+    B = a[0].shape[0]
+    return B * (CF + RN), B * (12 + 2 * (3 * 256) + 2 * (5 * 256) + 128 + 12)
+
+
+def _work_scatter(a, k):
+    B, C, L = a[5], a[7], a[8]
+    return 0, B * (2 * L * 8 * C * 4 + L * C * 4 + L * 3 * C * 4 + 12)
+
+
+def _work_adam(a, k):
+    return 0, 7 * 4 * (a[5] - a[4])
+
+
+_K_OBJECTS = [0]
+# backend entry point -> (kernel label, work model returning (algorithmic FLOPs, algorithmic bytes) of one call)
+TIMED = {
+    "fwd": ("k_hash_fwd (hash-grid gather)", _work_hash_fwd),
+    "sdf_mlp_fwd": ("k_sdf_mlp (fused bf16 MFMA SDF trunk, sampler sweeps)", _work_sdf_mlp),
+    "trunk_mlp_fwd": ("k_trunk_fwd (value+Jacobian trunk, 4 rows per point)", _work_trunk_fwd),
+    "trunk_mlp_bwd": ("k_trunk_bwd (trunk data-gradient chain + last-layer wgrad)", _work_trunk_bwd),
+    "appearance_fwd": ("k_appear_fwd (colour-feature MLP + rendering network)", _work_appear_fwd),
+    "appearance_bwd": ("k_appear_bwd", _work_appear_bwd),
+    "bwd_jac": ("hs_hash_bwd_jac (table scatter: k_hash_bwd_jac + k_hash_bin_reduce)", _work_scatter),
+    "adam_flat": ("k_adam_flat", _work_adam),
+    "sampler_update": ("k_sampler_update", None),
+    "sampler_draw_step": ("k_sampler_draw (+ loop control + positions)", None),
+    "composite_fwd": ("k_composite_fwd", None),
+    "composite_bwd": ("k_composite_bwd", None),
+}
+
+
+class KernelTimers:
+    """HIP-event timing of backend entry points, recorded on the stream each kernel is launched on (eager launches only: kernels
+    inside a replayed graph cannot be bracketed)."""
+
+    def __init__(self, backend_cls, names):
+        self.cls, self.names = backend_cls, [n for n in names if n in backend_cls.__dict__]
+        self.records = {n: [] for n in self.names}
         self.enabled = False
+        self._raw = {}
 
     def __enter__(self):
-        orig, me = self._orig, self
+        for n in self.names:
+            raw = self.cls.__dict__[n]
+            self._raw[n] = raw
+            orig = getattr(self.cls, n)
+            work = TIMED[n][1]
 
-        def timed(*a, **k):
-            if not me.enabled:
-                return orig(*a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(*a, **k)
-            e.record()
-            me.events.append((s, e, a[me.size_arg]))  # number of points of this launch
-            return r
+            def timed(*a, _orig=orig, _n=n, _work=work, **k):
+                if not self.enabled:
+                    return _orig(*a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _orig(*a, **k)
+                e.record()
+                self.records[_n].append((s, e, _work(a, k) if _work else (0, 0)))
+                return r
 
-        setattr(self._cls, self._name, staticmethod(timed))
+            setattr(self.cls, n, staticmethod(timed))
         return self
 
     def __exit__(self, *exc):
-        setattr(self._cls, self._name, self._raw)
+        for n, raw in self._raw.items():
+            setattr(self.cls, n, raw)
 
-    def summary(self):
-        ms = [s.elapsed_time(e) for s, e, _ in self.events]
-        pts = [b for _, _, b in self.events]
-        return ms, pts
+    def summary(self, iterations):
+        out = []
+        for n in self.names:
+            rec = self.records[n]
+            if not rec:
+                continue
+            us = [s.elapsed_time(e) * 1e3 for s, e, _ in rec]
+            flops, nbytes = sum(w[0] for _, _, w in rec), sum(w[1] for _, _, w in rec)
+            tot = sum(us)
+            d = {"kernel": TIMED[n][0], "calls_per_iter": round(len(rec) / iterations, 2), "avg_us": round(tot / len(rec), 2),
+                 "us_per_iter": round(tot / iterations, 1)}
+            if flops:
+                d["tflops"] = round(flops / (tot * 1e-6) / 1e12, 1)
+                d["mfma_frac"] = round(flops / (tot * 1e-6) / 1e12 / MFMA_PEAK_TF, 4)
+            if nbytes:
+                d["algorithmic_gbs"] = round(nbytes / (tot * 1e-6) / 1e9, 1)
+                d["hbm_frac"] = round(nbytes / (tot * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                d["algorithmic_bytes_per_call"] = int(nbytes / len(rec))
+            if flops:
+                d["algorithmic_flops_per_call"] = int(flops / len(rec))
+            out.append(d)
+        out.sort(key=lambda d: -d["us_per_iter"])
+        return out
 
 
 def cpu_baseline(seconds):
+    """all host threads (the headline cpu_baseline object) + the reference's own setting, torch.set_num_threads(1)
+    (training/holoscene_train.py:46), reported inside it as "one_thread"."""
+    n_all = torch.get_num_threads()
+    torch.set_num_threads(1)
+    one = _cpu_baseline_run(seconds * 0.4)
+    torch.set_num_threads(n_all)
+    out = _cpu_baseline_run(seconds * 0.6)
+    out["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+    return out
+
+
+def _cpu_baseline_run(seconds):
     """The CPU oracle (oracle/, a restatement of the reference: kind 'port') timed on this host's cores at
     BASELINE configs[0]: 256 rays x 64 samples, K=2, L=8 grid; full iteration incl. backward + Adam."""
     from oracle.stage1_oracle import Cfg, Stage1Oracle, make_state
@@ -177,11 +289,16 @@ def main():
         step()
     rounds_seen.clear()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # per-step GPU time stamps: no sync inside the loop
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -189,55 +306,94 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.rays * world * args.steps / elapsed
 
-    # ---- roofline of the dominant hand-written kernel on the hash side: k_hash_fwd<3,2,false>, the gather of the sampler's SDF
-    # sweeps (5 launches of R*S points per iteration: the largest hash-grid consumer once the scatter is binned / zero-skipped).
-    # Kernels inside a replayed HIP graph cannot be bracketed by events, so the same iteration is run eagerly a few times right
-    # after the timed region and every launch is timed with HIP events on the launching stream.
-    # Algorithmic bytes per point: gather G = L*8*C*4 = 1024 B + coordinates 12 B + features out L*C*4 = 128 B.
-    L, C = 16, 2
-    G = L * 8 * C * 4
-    bytes_per_point = G + 12 + L * C * 4
-    n_sweep = args.rays * args.samples
-    n_main = args.rays * (args.samples // 2 + args.samples // 4 + 2) + 4 * args.rays   # rendered points + Eikonal set (scatter launch)
-    scatter_bytes_per_point = 2 * G + L * C * 4 + L * 3 * C * 4 + 12
+    # ---- N > 1: how long the one exchange per iteration (reduce-scatter -> shard Adam -> all-gather) is exposed after the graph
+    exchange_ms = None
+    if world > 1:
+        ev = []
+        orig_x = dist_util.exchange_and_step_flat
+
+        def timed_exchange(*a, **k):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            r_ = orig_x(*a, **k)
+            e_.record()
+            ev.append((s_, e_))
+            return r_
+        dist_util.exchange_and_step_flat = timed_exchange
+        for _ in range(10):
+            step()
+        barrier()
+        dist_util.exchange_and_step_flat = orig_x
+        exchange_ms = round(sum(s_.elapsed_time(e_) for s_, e_ in ev) / max(1, len(ev)), 3)
+    # ---- rooflines.  Kernels inside a replayed HIP graph cannot be bracketed by events, so the same iteration is run eagerly a few
+    # times right after the timed region and every launch of the hand-written kernels is timed with HIP events on the launching
+    # stream.  Work models: SURVEY 8(d)'s ALGORITHMIC bytes / FLOPs on the unpadded layer shapes (71-wide trunk input, K objects).
     tr.use_graph = False
-    with KernelTimer(backend._HipBackend, "fwd", size_arg=4) as kf, KernelTimer(backend._HipBackend, "bwd_jac", size_arg=5) as kt, \
-            KernelTimer(backend._HipBackend, "sdf_mlp_fwd", size_arg=0) as km:
+    _K_OBJECTS[0] = args.objects
+    with KernelTimers(backend._HipBackend, list(TIMED)) as kt:
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        kf.enabled = kt.enabled = km.enabled = True
-        for _ in range(args.roofline_steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        skip_bg = 0
+        while tr.model.wants_background(tr.iter_step) and skip_bg < 2:   # time regular iterations (9 of 10), not the background-patch one
             step()
+            skip_bg += 1
+        kt.enabled = True
+        n_roof = 0
+        e0.record()
+        for _ in range(args.roofline_steps):
+            if tr.model.wants_background(tr.iter_step):
+                kt.enabled = False
+                step()
+                kt.enabled = True
+                continue
+            step()
+            n_roof += 1
+        e1.record()
         torch.cuda.synchronize()
-        kf.enabled = kt.enabled = km.enabled = False
-        ms = [t for t, b in zip(*kf.summary()) if b == n_sweep]
-        sc_ms = [t for t, b in zip(*kt.summary()) if b == n_main]
-        mfma_ms = km.summary()[0]
-        mfma_pts = [int(x_.shape[0]) for x_ in km.summary()[1]]
-    total_ms = sum(ms)
-    achieved = bytes_per_point * n_sweep * len(ms) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (corrected as the microarch guide says)
-        traffic = json.load(open(pmc_file)).get("k_hash_fwd_sweep_launch_bytes")
-    roofline = {"kernel": "k_hash_fwd<3,2,false> (hash-grid gather of one sampler SDF sweep: rays x samples points, geometry grid)", "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches": len(ms), "avg_launch_us": round(total_ms / max(1, len(ms)) * 1e3, 2),
-                "algorithmic_bytes_per_launch": bytes_per_point * n_sweep,
-                "note": "random 8-byte gathers: the 48.8 MB table is resident in the 256 MB memory-side cache, so the bound is the L2/fabric "
-                        "gather rate, not the HBM pins; the first sweep of an iteration runs cold (right after Adam streamed 0.7 GB)"}
-    if sc_ms:   # the scatter side: zero + record binning / wave-merged atomics + per-bin LDS reduction, timed as one operation
-        roofline["scatter_op"] = {"op": "hs_hash_bwd_jac (k_hash_bwd_jac + k_hash_bin_reduce; rendered points + Eikonal set)",
-                                  "avg_us": round(sum(sc_ms) / len(sc_ms) * 1e3, 2), "calls": len(sc_ms),
-                                  "algorithmic_bytes_per_call": scatter_bytes_per_point * n_main,
-                                  "achieved_GBs": round(scatter_bytes_per_point * n_main * len(sc_ms) / (sum(sc_ms) * 1e-3) / 1e9, 1),
-                                  "note": "exactly-zero contributions are skipped but counted as algorithmic bytes"}
-    if mfma_ms:  # the matrix-core kernel of the path (sampler SDF sweeps), for the MFMA side of the roofline
-        flops = sum(p * 2 * (96 * 256 + 256 * 256 + 256 * 32) for p in mfma_pts)
-        roofline["mfma_kernel"] = {"kernel": "k_sdf_mlp<1> (bf16 MFMA fused SDF trunk)", "achieved": round(flops / (sum(mfma_ms) * 1e-3) / 1e12, 1),
-                                   "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / (sum(mfma_ms) * 1e-3) / 1e12 / 2500.0, 4),
-                                   "launches": len(mfma_ms), "avg_launch_us": round(sum(mfma_ms) / len(mfma_ms) * 1e3, 2)}
+        kt.enabled = False
+        kernels = kt.summary(max(n_roof, 1))
+    rounds_mean = sum(int(r_) for r_ in rounds_seen[:args.steps]) / max(1, args.steps)
+    N_pts = args.samples // 2 + args.samples // 4 + 2
+    R, S, K = args.rays, args.samples, args.objects
+    # whole-iteration algorithmic work (SURVEY 8d formulas, realised sampler rounds)
+    T = trunk_flops_per_row(K)
+    iter_flops = rounds_mean * S * R * T + 3 * N_pts * R * (4 * T + CF + RN) + 3 * 4 * R * 4 * T
+    iter_bytes = rounds_mean * S * R * G_BYTES + N_pts * R * 2 * G_BYTES + N_pts * R * (2 * 2 * G_BYTES + 3 * G_BYTES) + 4 * R * 6 * G_BYTES \
+        + 7 * 4 * tr.flat.numel + 4 * tr.flat.numel
+    dom = kernels[0] if kernels else None
+    traffic, traffic_src = None, None
+    for cand in ("r02", "r01"):
+        pmc_file = os.path.join(ROOT, "profiles", cand, "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            pm = json.load(open(pmc_file))
+            traffic_src = {"file": f"profiles/{cand}/pmc_traffic.json", "commit": pm.get("commit"), "measured_in_this_run": False}
+            traffic = pm.get("per_kernel_launch_bytes", {}).get((dom or {}).get("kernel", "").split(" ")[0]) if dom else None
+            if traffic is None and dom and dom["kernel"].startswith("k_hash_fwd"):
+                traffic = pm.get("k_hash_fwd_sweep_launch_bytes")
+            break
+    roofline = {"kernel": None, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": traffic}
+    if dom is not None:
+        mf = "mfma_frac" in dom and dom.get("mfma_frac", 0) >= dom.get("hbm_frac", 0)
+        roofline.update({"kernel": dom["kernel"] + " -- the hand-written kernel with the largest share of an iteration",
+                         "bound": "mfma" if mf else "hbm",
+                         "achieved": dom["tflops"] if mf else dom.get("algorithmic_gbs"),
+                         "peak": MFMA_PEAK_TF if mf else HBM_PEAK_GBS, "unit": "TFLOP/s" if mf else "GB/s",
+                         "frac": dom["mfma_frac"] if mf else dom.get("hbm_frac"),
+                         "avg_launch_us": dom["avg_us"], "launches_per_iter": dom["calls_per_iter"],
+                         "algorithmic_flops_per_launch": dom.get("algorithmic_flops_per_call"),
+                         "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_call"),
+                         "other_roof_frac": dom.get("hbm_frac") if mf else dom.get("mfma_frac")})
+    roofline["traffic_source"] = traffic_src or "no PMC pass committed for this kernel yet"
+    roofline["kernels"] = kernels
+    roofline["whole_iteration"] = {
+        "algorithmic_gflop": round(iter_flops / 1e9, 1), "algorithmic_gb": round(iter_bytes / 1e9, 3),
+        "mfma_frac": round(iter_flops / (median_ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4),
+        "hbm_frac": round(iter_bytes / (median_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "note": "SURVEY 8(d) formulas at the realised sampler rounds, divided by the median step time of the timed region"}
+    roofline["eager_iteration_us"] = round(e0.elapsed_time(e1) * 1e3 / max(1, args.roofline_steps), 1)
+    roofline["timed_kernels_us_per_iter"] = round(sum(d["us_per_iter"] for d in kernels), 1)
     # ---- SURVEY 8(d)'s second reported point: beta = 0.1 (1 sampler round; no sample has an exactly-zero cotangent, so the
     # scatter kernels issue every atomic).  Same code path, shorter run, reported beside the headline value.
     second = None
@@ -267,22 +423,47 @@ def main():
             e2 = float(t)
         second = {"beta": 0.1, "value": round(args.rays * world * n2 / e2, 1), "unit": "rays/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
                   "sampler_rounds_mean": round(sum(int(r_) for r_ in r2[8:]) / n2, 2)}
+    fp32_point = None
+    if not args.no_fp32_point and args.precision == "bf16" and world == 1:
+        # the reference's own precision, same workload, reported beside the headline
+        conf3 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision="fp32",
+                           learning_rate=5.0e-4 * args.lr_scale)
+        tr3 = Stage1Trainer(conf3, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
+                            graph=(not args.no_graph) and args.optimizer == "flat")
+        benchmark_model_state(tr3.model, args.beta)
+        n3 = max(10, min(40, args.steps // 4))
+        for i in range(6 + n3):
+            if i == 6:
+                barrier()
+                t0 = time.perf_counter()
+            tr3.train_step_resident(scene)
+        barrier()
+        e3 = time.perf_counter() - t0
+        fp32_point = {"precision": "fp32", "value": round(args.rays * n3 / e3, 1), "unit": "rays/s", "ms_per_step": round(e3 / n3 * 1e3, 3),
+                      "steps": n3, "sampler_rounds": int(tr3.model.ray_sampler.last_rounds)}
+        del tr3
     if rank == 0:
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
                                    f"full iteration (pixel-batch gather from HBM-resident frames+sampler+render+eikonal+loss+backward+Adam; every 10th "
                                    f"iteration also the 32x32 background-patch pass, render_bg_iter=10), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
-                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(sum(int(r_) for r_ in rounds_seen) / max(1, len(rounds_seen)), 2),
+                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(rounds_mean, 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
         if second is not None:
             line["config"]["second_point"] = second
+        if fp32_point is not None:
+            line["config"]["fp32_point"] = fp32_point
+        if world > 1:
+            line["config"]["rccl_world_size"] = torch.distributed.get_world_size()
+            line["config"]["exchange_ms_exposed"] = exchange_ms
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line))
