@@ -80,6 +80,11 @@ def _work_sdf_mlp(a, k):
     return B * trunk_flops_per_row(K), B * (12 + 128 + 4)
 
 
+def _work_sdf_mlp2(a, k):
+    B, K = a[0].shape[0], a[3]
+    return B * trunk_flops_per_row(K), B * (12 + 128 + 4)
+
+
 def _work_trunk_fwd(a, k):
     M, K = a[10].shape[0], a[7]
     return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 96 * 2 + K * 4) + (M // 4) * (12 + 128 + 384)
@@ -117,7 +122,8 @@ _K_OBJECTS = [0]
 # backend entry point -> (kernel label, work model returning (algorithmic FLOPs, algorithmic bytes) of one call)
 TIMED = {
     "fwd": ("k_hash_fwd (hash-grid gather)", _work_hash_fwd),
-    "sdf_mlp_fwd": ("k_sdf_mlp (fused bf16 MFMA SDF trunk, sampler sweeps)", _work_sdf_mlp),
+    "sdf_mlp_fwd": ("k_sdf_mlp (fused bf16 MFMA SDF trunk, sampler sweeps; workgroup-tile form)", _work_sdf_mlp),
+    "sdf_mlp2_fwd": ("k_sdf_mlp2 (fused bf16 MFMA SDF trunk, sampler sweeps; wave-tile form)", _work_sdf_mlp2),
     "trunk_mlp_fwd": ("k_trunk_fwd (value+Jacobian trunk, 4 rows per point)", _work_trunk_fwd),
     "trunk_mlp_bwd": ("k_trunk_bwd (trunk data-gradient chain + last-layer wgrad)", _work_trunk_bwd),
     "appearance_fwd": ("k_appear_fwd (colour-feature MLP + rendering network)", _work_appear_fwd),

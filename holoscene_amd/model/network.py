@@ -129,6 +129,9 @@ class _trunk_input(torch.autograd.Function):
 # "mfma": the bf16 trunk forward runs in ONE matrix-core kernel (csrc/sdf_mlp.hip, k_trunk_fwd) when the layer shapes are the
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
 TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
+# inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
+# activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
+SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
 TRUNK_W2_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_W2_IN_KERNEL", "1") == "1"   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
 _FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
@@ -783,9 +786,33 @@ class ObjectImplicitNetworkGrid(nn.Module):
                               l2.bias.detach().float().contiguous())
         return self._packed_cache
 
+    def _packed_weights2(self):
+        """Fragment-order images for the wave-tile kernel (csrc/sdf_mlp2.hip), one pack launch per parameter state."""
+        if getattr(self, "_packed_cache2", None) is not None:
+            return self._packed_cache2
+        l0, l1, l2 = self._lins()
+        with torch.no_grad():
+            f0, f1, f2 = effective_weights([l0, l1, l2])
+        self._packed_cache2 = _be._backend.sdf_mlp2_pack(f0.detach().float().contiguous(), l0.bias.detach().float().contiguous(),
+                                                         f1.detach().float().contiguous(), l1.bias.detach().float().contiguous(),
+                                                         f2.detach().float().contiguous(), l2.bias.detach().float().contiguous(), l2.out_features)
+        return self._packed_cache2
+
+    def _sdf_mlp(self, x, feat, d_out, select, out, raw, gate, lm):
+        """The fused SDF trunk on already gathered hash features: wave-tile kernel for d_out <= 32, workgroup-tile kernel otherwise."""
+        be = _be._backend
+        if SDF_MLP_IMPL == "wave" and d_out <= 32:
+            be.sdf_mlp2_fwd(x, feat, self._packed_weights2(), d_out, select, out, raw, gate=gate, feat_level_major=lm)
+        elif SDF_MLP_IMPL in ("wave", "tile"):
+            w0, b0, w1, b1, w2, b2 = self._packed_weights()
+            be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, raw, gate=gate, feat_level_major=lm)
+        else:
+            raise RuntimeError(f"unknown HOLOSCENE_SDF_MLP_IMPL={SDF_MLP_IMPL!r}")
+
     def invalidate_packed_weights(self):
         """The packed bf16 images are valid for one parameter state; the sampler drops them at the start of every call."""
         self._packed_cache = None
+        self._packed_cache2 = None
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
         """min_k sdf_k (select -1), sdf_select (int) or the minimum over an object list [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
@@ -802,8 +829,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         d_out = self._lins()[2].out_features
         out = torch.empty(B, 1, device=x.device)
         raw = torch.empty(B, d_out, device=x.device) if want_raw else None
-        w0, b0, w1, b1, w2, b2 = self._packed_weights()
-        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, raw, feat_level_major=lm)
+        self._sdf_mlp(x, feat, d_out, select, out, raw, None, lm)
         return out, raw
 
     def sdf_along_rays(self, cam_loc, ray_dirs, z, select=-1, gate=None):
@@ -832,8 +858,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
                gate=gate, level_major=lm)
         d_out = self._lins()[2].out_features
         out = torch.empty(R, S, device=dev)
-        w0, b0, w1, b1, w2, b2 = self._packed_weights()
-        be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, None, gate=gate, feat_level_major=lm)
+        self._sdf_mlp(x, feat, d_out, select, out, None, gate, lm)
         return out
 
     def sdf_and_jacobian(self, x):

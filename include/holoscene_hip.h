@@ -287,7 +287,20 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
 int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const float *b0, const void *W1, const float *b1, const void *W2,
                    const float *b2, int32_t d_out, int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B,
                    const hsGate *gate /* NULL = none */,
-                   int32_t feat_level_major /* 0: feat [B,32]; 1: feat [16,B,2] (level-major, as hs_hash_fwd writes fully coalesced) */, void *stream);
+                   int32_t feat_level_major /* 0: feat [B,32], 1: feat [16,B,2] (level-major, as hs_hash_fwd writes fully coalesced) */, void *stream);
+
+/* The same function in "wave tile" form (csrc/sdf_mlp2.hip; d_out <= 32): every wave owns 32 points end to end, activations stay in
+ * registers, W1 / W2 are LDS-resident, no workgroup barrier in the steady state.  Operands are FRAGMENT-ORDER images written by
+ * hs_sdf_mlp2_pack from the fp32 effective matrices (row-major [out][in] like nn.Linear; W0 with row pitch ld0 >= 71 columns in the
+ * reference's input order x | sin/cos octaves | hash features) -- scaling for the log2-domain softplus included; buffer sizes in
+ * bytes from hs_sdf_mlp2_pack_bytes(0..3) = W0f, W1f, W2f, bias; W2f must directly follow W1f in memory (the LDS-resident image is
+ * one linear copy).  Arguments of hs_sdf_mlp2_fwd as hs_sdf_mlp_fwd. */
+int64_t hs_sdf_mlp2_pack_bytes(int32_t which);
+int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
+                     void *W0f, void *W1f, void *W2f, float *bias, void *stream);
+int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
+                    int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
+                    void *stream);
 
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
  * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).
