@@ -29,7 +29,7 @@
 #include "holoscene_hip.h"
 
 #ifdef HS_SDF2_PROFILE     // tools/exp/sdf2_prof.hip: per-phase s_memtime stamps of a steady-state wave tile
-__device__ unsigned long long g_sdf2_prof[256 * 8 * 8];   // [block][wave][stamp]
+__device__ unsigned long long g_sdf2_prof[256 * 8 * 16];   // [block][wave][stamp]
 #endif
 
 namespace {
@@ -131,47 +131,40 @@ __device__ __forceinline__ void init_acc(f32x16 &acc, const float *bias_tile, in
 
 // softplus + bf16 pack of accumulator registers r, r + 1 (r even) of a tile: half a register pair of the next layer's B fragment.
 // Register r of tile nt lands in word (r >> 1) of that tile's 8-word block = k-steps 2 nt (words 0-3) and 2 nt + 1 (words 4-7).
-__device__ __forceinline__ uint32_t epilogue_pair(const f32x16 &acc, int r) { return pack2(softplus_scaled2(acc[r]), softplus_scaled2(acc[r + 1])); }
+__device__ __forceinline__ uint32_t epilogue_pair(const f32x16 &acc, int r) {
+    uint32_t w = pack2(softplus_scaled2(acc[r]), softplus_scaled2(acc[r + 1]));
+    // the value is consumed many MFMAs later (as a B operand of the next layer): without an anchor the optimiser SINKS the whole softplus
+    // down to that use, out of the MFMA shadow it was placed in (measured: layer 1's epilogues piled up in front of layer 2)
+    asm volatile("" : "+v"(w));
+    return w;
+}
 
-// One 256-wide layer of a wave tile, software-pipelined over its four neuron quarters (2 tiles of 32 neurons each): the MFMAs of
-// quarter q are interleaved, k-step by k-step, with the softplus epilogue of quarter q - 1 (two accumulator sets), so that the
-// matrix pipe and the VALU of this wave overlap without relying on the SIMD's other wave being in the opposite phase.
-//   KS      k-steps of the layer;  hin: its B fragments (4 words per k-step);  hout: 64 words = the next layer's B fragments
-//   frag(s, nt) returns the A fragment (weights of neuron tile nt, k-step s);  bias: this layer's 256 scaled biases in LDS
-template <int KS, int AHEAD, class FragFn, class PrefetchFn>
-__device__ __forceinline__ void layer_pipelined(const uint32_t *hin, uint32_t *hout, const float *bias, int h, FragFn frag, PrefetchFn prefetch) {
-    f32x16 acc[2][2];
-    constexpr int kSlices = 16;            // a quarter's 32 elements per lane leave as 16 packed pairs
-    constexpr int per = (kSlices + KS - 1) / KS;      // pairs finished per k-step of the following quarter
+// One PHASE of a wave tile = the MFMAs of one neuron quarter (two 32-neuron tiles, KS k-steps) with, in their shadow, the softplus
+// epilogue of the accumulator set the previous phase filled (two sets alternate).  Phases chain ACROSS layers: the first quarter of
+// layer 1 only needs layer 0's quarters 0-2 for its k-steps 0..11, so layer 0's last epilogue is spread over its first E = 8 k-steps
+// (likewise layer 2 under layer 1's last) -- no epilogue runs un-overlapped, and the matrix pipe and the VALU of ONE wave overlap
+// without relying on the SIMD's other wave being in the opposite phase.
+//   frag(s, j): A fragment of k-step s, tile j (0/1) of this quarter;  hin: B fragments of this layer (4 words per k-step);
+//   prev/hprev: the previous phase's accumulators and the 16 words (2 tiles x 8) their epilogue writes (nullptr: nothing to finish);
+//   E: k-steps over which those 16 packed pairs are spread;  AHEAD: how many k-steps the A fragments travel in front of their MFMAs
+//   (explicit ring: at its register limit the scheduler otherwise issues every ds_read right before the MFMA that needs it).
+template <int KS, int AHEAD, int E, bool EPI, class FragFn>
+__device__ __forceinline__ void phase2(f32x16 (&cur)[2], const f32x16 (&prev)[2], const uint32_t *hin, uint32_t *hprev, FragFn frag) {
+    bf16x8 ring[AHEAD + 1][2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int cur = q & 1, prev = cur ^ 1;
-        init_acc(acc[cur][0], bias + 32 * (2 * q), h);
-        init_acc(acc[cur][1], bias + 32 * (2 * q + 1), h);
-        prefetch(q + 1);
-        // A fragments travel AHEAD k-steps in front of their MFMAs (explicit ring: the scheduler, at its register limit, otherwise
-        // issues every ds_read right before the MFMA that needs it and eats the LDS latency 32 times per quarter)
-        bf16x8 ring[AHEAD + 1][2];
+    for (int s = 0; s < AHEAD && s < KS; s++) { ring[s][0] = frag(s, 0); ring[s][1] = frag(s, 1); }
 #pragma unroll
-        for (int s = 0; s < AHEAD && s < KS; s++) { ring[s][0] = frag(s, 2 * q); ring[s][1] = frag(s, 2 * q + 1); }
+    for (int s = 0; s < KS; s++) {
+        if (s + AHEAD < KS) { ring[(s + AHEAD) % (AHEAD + 1)][0] = frag(s + AHEAD, 0); ring[(s + AHEAD) % (AHEAD + 1)][1] = frag(s + AHEAD, 1); }
+        const bf16x8 b = frag_of(hin + 4 * s);
+        cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][0], b, cur[0], 0, 0, 0);
+        cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][1], b, cur[1], 0, 0, 0);
+        if (EPI && s < E) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            if (s + AHEAD < KS) { ring[(s + AHEAD) % (AHEAD + 1)][0] = frag(s + AHEAD, 2 * q); ring[(s + AHEAD) % (AHEAD + 1)][1] = frag(s + AHEAD, 2 * q + 1); }
-            const bf16x8 b = frag_of(hin + 4 * s);
-            acc[cur][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][0], b, acc[cur][0], 0, 0, 0);
-            acc[cur][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][1], b, acc[cur][1], 0, 0, 0);
-            if (q > 0) {      // a slice of the previous quarter's epilogue rides in the shadow of these two MFMAs
-#pragma unroll
-                for (int j = 0; j < per; j++) {
-                    const int sl = s * per + j;
-                    if (sl < kSlices) hout[8 * (2 * (q - 1) + (sl >> 3)) + (sl & 7)] = epilogue_pair(acc[prev][sl >> 3], 2 * (sl & 7));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // pin the k-step order: loads of s + AHEAD | MFMAs of s | epilogue slice
+            for (int sl = (s * 16) / E; sl < ((s + 1) * 16) / E; sl++) hprev[8 * (sl >> 3) + (sl & 7)] = epilogue_pair(prev[sl >> 3], 2 * (sl & 7));
         }
+        __builtin_amdgcn_sched_barrier(0);      // pin the k-step order: loads of s + AHEAD | MFMAs of s | epilogue slice
     }
-#pragma unroll
-    for (int sl = 0; sl < kSlices; sl++) hout[8 * (2 * 3 + (sl >> 3)) + (sl & 7)] = epilogue_pair(acc[1][sl >> 3], 2 * (sl & 7));
 }
 
 __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
@@ -181,32 +174,38 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                                                             int feat_level_major) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
+#ifdef HS_SDF2_PROFILE
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
     float *bias = reinterpret_cast<float *>(W2l + kW2F);
-    // ---- one fill of the resident weights per workgroup (fragment order in global memory already: a straight copy of 144 KB).
-    //      All 18 loads of a thread are issued before the first store (a load -> store loop paid one L2 round trip per iteration:
-    //      16 us per launch, measured)
-    {
-        constexpr int kVec = (kW1F + kW2F) / 8 / kThreadsW;     // 18 x 16 B per thread; W2f follows W1f in the packed buffer
-        static_assert((kW1F + kW2F) / 8 == kVec * kThreadsW, "resident image must split evenly");
-        const uint4 *src = reinterpret_cast<const uint4 *>(W1f);
-        uint4 *dst = reinterpret_cast<uint4 *>(W1l);
-        uint4 t[kVec];
-#pragma unroll
-        for (int i = 0; i < kVec; i++) t[i] = src[threadIdx.x + i * kThreadsW];
-        for (int i = threadIdx.x; i < kBias; i += kThreadsW) bias[i] = biasg[i];
-#pragma unroll
-        for (int i = 0; i < kVec; i++) dst[threadIdx.x + i * kThreadsW] = t[i];
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+    // ---- one fill of the resident weights per workgroup (fragment order in global memory already: a straight copy of 144 KB), by
+    //      LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers): the 18 requests of a wave are in flight
+    //      while it builds the inputs of its first tile and runs layer 0 (whose weights come from L2); the workgroup meets once,
+    //      before the first layer-1 MFMA.  (A load -> ds_write loop cost 16 us per launch, a batched register copy 6 us, measured.)
+    {
+        constexpr int kChunks = (kW1F + kW2F) * 2 / 1024;          // 144 x 1 KB; W2f follows W1f in the packed buffer
+        static_assert(kChunks % kWaves == 0, "resident image must split evenly over the waves");
+        const char *src = reinterpret_cast<const char *>(W1f);
+        char *dst = reinterpret_cast<char *>(W1l);
+#pragma unroll
+        for (int i = 0; i < kChunks / kWaves; i++) {
+            const int c = wave + i * kWaves;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
+        }
+        for (int i = threadIdx.x; i < kBias; i += kThreadsW) bias[i] = biasg[i];
+    }
+    __syncthreads();            // the bias block (layer 0 initialises its accumulators from it); the weight image is still landing
+    bool resident = false;      // this wave has passed the rendezvous that makes the LDS weights visible
     const int64_t ntiles = (B + kRows - 1) / kRows;
     const bf16x8 *W0v = reinterpret_cast<const bf16x8 *>(W0f) + lane;
     const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
     const bf16x8 *W2v = reinterpret_cast<const bf16x8 *>(W2l) + lane;
 #ifdef HS_SDF2_PROFILE
-#define HS_STAMP(i) do { if (lane == 0 && tile >= (int64_t)gridDim.x * kWaves) g_sdf2_prof[(blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HS_STAMP(i) do { if (lane == 0) g_sdf2_prof[(blockIdx.x * 8 + wave) * 16 + (tile >= (int64_t)gridDim.x * kWaves ? 0 : 8) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HS_STAMP(i) do { } while (0)
 #endif
@@ -253,37 +252,71 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
             for (int j = 0; j < 40; j += 2) hin[j >> 1] = pack2(v[j], v[j + 1]);
         }
         HS_STAMP(1);
-        // ---- layer 0: 80 -> 256, weights from L2 (fragment order: one coalesced 1 KB load per wave and fragment), the next
-        //      quarter's ten fragments requested while this quarter multiplies
-        uint32_t h0p[64];
+        // ---- nine phases: layer 0 quarters 0-3 (weights from L2 in fragment order: one coalesced 1 KB load per wave and fragment,
+        //      a quarter's ten fragments requested one phase ahead), layer 1 quarters 0-3 (weights resident in LDS), layer 2
+        uint32_t h0p[64], h1p[64];
+        f32x16 acc[2][2];
         {
             bf16x8 w0[2][2 * K0S];
             uint32_t zoff = 0;
             asm volatile("" : "+v"(zoff));     // opaque zero: keeps the (tile-invariant) fragment loads inside the tile loop, 160 registers otherwise
             const bf16x8 *W0q = W0v + zoff;
-            auto prefetch0 = [&](int q) {
-                if (q < 4) {
+#define HS_W0_FETCH(q) do { _Pragma("unroll") for (int s_ = 0; s_ < K0S; s_++) { \
+        w0[(q) & 1][2 * s_] = W0q[(size_t)(s_ * NT + 2 * (q)) * 64]; w0[(q) & 1][2 * s_ + 1] = W0q[(size_t)(s_ * NT + 2 * (q) + 1) * 64]; } } while (0)
+            HS_W0_FETCH(0);
 #pragma unroll
-                    for (int s = 0; s < K0S; s++) {
-                        w0[q & 1][2 * s] = W0q[(size_t)(s * NT + 2 * q) * 64];
-                        w0[q & 1][2 * s + 1] = W0q[(size_t)(s * NT + 2 * q + 1) * 64];
-                    }
-                }
-            };
-            prefetch0(0);
-            layer_pipelined<K0S, 1>(hin, h0p, bias, h, [&](int s, int nt) { return w0[(nt >> 1) & 1][2 * s + (nt & 1)]; }, prefetch0);
+            for (int q = 0; q < 4; q++) {
+                init_acc(acc[q & 1][0], bias + 32 * (2 * q), h);
+                init_acc(acc[q & 1][1], bias + 32 * (2 * q + 1), h);
+                if (q < 3) HS_W0_FETCH(q + 1);
+                auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
+                if (q == 0) phase2<K0S, 1, K0S, false>(acc[0], acc[1], hin, nullptr, f0);
+                else phase2<K0S, 1, K0S, true>(acc[q & 1], acc[(q & 1) ^ 1], hin, h0p + 16 * (q - 1), f0);
+            }
+#undef HS_W0_FETCH
         }
         HS_STAMP(2);
-        // ---- layer 1: 256 -> 256, weights resident in LDS
-        uint32_t h1p[64];
-        layer_pipelined<HS, 2>(h0p, h1p, bias + 256, h, [&](int s, int nt) { return W1v[(size_t)(s * NT + nt) * 64]; }, [](int) {});
+        if (!resident) {        // first tile of this wave: its own DMA requests have landed, then everybody's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            resident = true;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            init_acc(acc[q & 1][0], bias + 256 + 32 * (2 * q), h);
+            init_acc(acc[q & 1][1], bias + 256 + 32 * (2 * q + 1), h);
+            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
+            // q = 0 finishes layer 0's last quarter (needed from k-step 12 on) within its first 8 k-steps
+            if (q == 0) phase2<HS, 2, 8, true>(acc[0], acc[1], h0p, h0p + 48, f1);
+            else phase2<HS, 2, HS, true>(acc[q & 1], acc[(q & 1) ^ 1], h0p, h1p + 16 * (q - 1), f1);
+        }
         HS_STAMP(3);
-        // ---- layer 2: 256 -> d_out (<= 32), then the minimum the caller asked for
+        // ---- layer 2: 256 -> d_out (<= 32) on two partial accumulators (even / odd k-steps: no dependent-MFMA chain), with layer 1's
+        //      last epilogue in its first 8 k-steps; then the minimum the caller asked for
         f32x16 y;
+        {
+            f32x16 &y0 = acc[0][0], &y1 = acc[0][1];     // set 0 is free: layer 1's last quarter lives in set 1
 #pragma unroll
-        for (int i = 0; i < 16; i++) y[i] = 0.f;
+            for (int i = 0; i < 16; i++) { y0[i] = 0.f; y1[i] = 0.f; }
+            auto f2 = [&](int s, int j) { return W2v[(size_t)(2 * s + j) * 64]; };
+            // "k-step" s of this phase = layer-2 k-steps 2s (accumulator 0) and 2s + 1 (accumulator 1); their B fragments are consecutive
+            bf16x8 ring[3][2];
 #pragma unroll
-        for (int s = 0; s < HS; s++) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)s * 64], frag_of(h1p + 4 * s), y, 0, 0, 0);
+            for (int s = 0; s < 2; s++) { ring[s][0] = f2(s, 0); ring[s][1] = f2(s, 1); }
+#pragma unroll
+            for (int s = 0; s < HS / 2; s++) {
+                if (s + 2 < HS / 2) { ring[(s + 2) % 3][0] = f2(s + 2, 0); ring[(s + 2) % 3][1] = f2(s + 2, 1); }
+                if (s < 4) {      // k-steps 0..7 only need layer 1's quarters 0-1; quarter 3's epilogue rides here
+#pragma unroll
+                    for (int sl = 4 * s; sl < 4 * s + 4; sl++) h1p[48 + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[1][sl >> 3], 2 * (sl & 7));
+                }
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][0], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) y[i] = y0[i] + y1[i];
+        }
         float best = INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -313,6 +346,18 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
         }
         HS_STAMP(4);
     }
+    if (!resident) {            // a wave without a tile still owes the workgroup its arrival (and its share of the copy)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#ifdef HS_SDF2_PROFILE
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *p = g_sdf2_prof + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        p[5] = __builtin_amdgcn_s_memtime() - prof_t0;
+        p[6] = __builtin_amdgcn_s_memrealtime() - prof_r0;
+        p[7] = prof_t0;
+    }
+#endif
 }
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }

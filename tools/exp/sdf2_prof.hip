@@ -28,11 +28,22 @@ int main(int argc, char **argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%lld: %.1f us per launch\n", (long long)B, ms * 100);
-    std::vector<unsigned long long> p(256 * 8 * 8);
+    std::vector<unsigned long long> p(256 * 8 * 16);
     hipMemcpyFromSymbol(p.data(), HIP_SYMBOL(g_sdf2_prof), p.size() * 8);
+    double life = 0, real = 0;
+    double first[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 256 * 8; w++) {
+        life += p[w * 16 + 5]; real += p[w * 16 + 6];
+        first[0] += (double)(p[w * 16 + 8] - p[w * 16 + 7]);                       // kernel entry -> first tile's start
+        for (int i = 0; i < 4; i++) first[i + 1] += (double)(p[w * 16 + 9 + i] - p[w * 16 + 8 + i]);
+    }
+    printf("first tile: entry->tile %.0f  inputs %.0f  layer0 %.0f  layer1(+rendezvous) %.0f  layer2+out %.0f\n", first[0] / 2048, first[1] / 2048, first[2] / 2048,
+           first[3] / 2048, first[4] / 2048);
+    printf("wave lifetime: %.0f shader ticks, %.0f realtime ticks (100 MHz => %.2f us) => shader clock %.2f GHz\n", life / 2048, real / 2048, real / 2048 / 100.0,
+           life / real * 0.1);
     double acc[4] = {0, 0, 0, 0}; int n = 0;
     for (int w = 0; w < 256 * 8; w++) {
-        const unsigned long long *q = &p[w * 8];
+        const unsigned long long *q = &p[w * 16];
         if (q[4] <= q[0]) continue;
         for (int i = 0; i < 4; i++) acc[i] += (double)(q[i + 1] - q[i]);
         n++;
