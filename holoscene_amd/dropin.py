@@ -27,6 +27,10 @@ _OVERLAY = {
 }
 
 
+# classes the reference keeps in model/network.py (:1835-2209) that live in their own module here
+_EXTRA = {"model.network": ("holoscene_amd.model.object_network", ("SingleObjectImplicitNetworkGrid", "SingleObjectRenderingNetwork", "ObjectSDFNetwork"))}
+
+
 def _bind(name, module):
     """sys.modules entry + attribute on the parent package (``__import__('a.b')`` returns ``a`` and the caller walks attributes)."""
     sys.modules[name] = module
@@ -43,6 +47,11 @@ def install():
         done[name] = "replaced"
     for name, symbols in _OVERLAY.items():
         ours = importlib.import_module("holoscene_amd." + name)
+        if name in _EXTRA:       # make the dotted names of the reference resolve on this package's module too
+            extra_mod, extra_syms = _EXTRA[name]
+            for sym in extra_syms:
+                setattr(ours, sym, getattr(importlib.import_module(extra_mod), sym))
+            symbols = tuple(symbols) + tuple(extra_syms)
         try:
             theirs = importlib.import_module(name)          # the reference's own module, when we run inside its checkout
         except ImportError:

@@ -92,17 +92,20 @@ class _trunk_input(torch.autograd.Function):
     backward: one slicing kernel + the fused value+Jacobian scatter into the table gradient."""
 
     @staticmethod
-    def forward(ctx, x, embeddings, offsets, S, H, nfreq, divide_factor, out_dtype):
+    def forward(ctx, x, embeddings, offsets, S, H, nfreq, divide_factor, out_dtype, center=None, obj_scale=1.0):
+        """center / obj_scale: the per-object frame of SingleObjectImplicitNetworkGrid (network.py:1947): the grid is looked up at
+        (x - center) / obj_scale / divide_factor while the positional encoding sees x itself."""
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         x = x.contiguous()
-        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()   # HashEncoder.forward's mapping to [0,1] (hashgrid.py:158)
+        xg = x if center is None else (x - center) / obj_scale
+        x01 = ((xg / divide_factor + 1.0) / 2.0).contiguous()   # HashEncoder.forward's mapping to [0,1] (hashgrid.py:158)
         B, D = x01.shape
         L = offsets.shape[0] - 1
         C = embeddings.shape[1]
         feat = torch.empty(B, L * C, device=x.device, dtype=x.dtype)
         dydx = torch.empty(L, B, D * C, device=x.device, dtype=x.dtype)
         _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, H, dydx)
-        jac_scale = 0.5 / divide_factor
+        jac_scale = 0.5 / (divide_factor * obj_scale)
         out = torch.empty(B, 4, 3 + 6 * nfreq + L * C, device=x.device, dtype=out_dtype)
         _be._backend.trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, jac_scale)
         ctx.save_for_backward(x01, embeddings, offsets)
@@ -123,7 +126,7 @@ class _trunk_input(torch.autograd.Function):
             target = table.grad if inplace else torch.zeros_like(embeddings)
             _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
             g_emb = None if inplace else target
-        return None, g_emb, None, None, None, None, None, None
+        return None, g_emb, None, None, None, None, None, None, None, None
 
 
 # "mfma": the bf16 trunk forward runs in ONE matrix-core kernel (csrc/sdf_mlp.hip, k_trunk_fwd) when the layer shapes are the

@@ -63,7 +63,7 @@ def _install_reference():
         return m
 
     import utils  # namespace package of the reference
-    utils.general = mod("utils.general", get_class=get_class)
+    utils.general = mod("utils.general", get_class=get_class, get_camera_perspective_projection_matrix=None, visualize_graph_tree=None)
     from model.network import HoloSceneNetwork
     from model.loss import HoloSceneLoss
     return HoloSceneNetwork, HoloSceneLoss
@@ -563,6 +563,123 @@ def run_hash_stock(name, *, seed, B=1000, L=16, base=16, end=2048, logmap=19, D=
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  touched rows {len(ge_rows)}")
 
 
+def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12):
+    """the per-object network with its own hash grid -- ObjectSDFNetwork.forward (network.py:2157-2209) over
+    SingleObjectImplicitNetworkGrid (:1835-2032) and SingleObjectRenderingNetwork (:2035-2109), plus direct calls of the implicit
+    network's query methods.  The reference's ObjectSDFNetwork constructor hard-codes the stock 48.8 MB grid; the object is assembled
+    from the same parts with a small hash table (every method used is the reference's own)."""
+    from model.network import ObjectSDFNetwork, SingleObjectImplicitNetworkGrid, SingleObjectRenderingNetwork
+    from model.density import LaplaceDensity
+    from model.ray_sampler import ErrorBoundSampler
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    center, scale = torch.tensor([0.1, -0.05, 0.08]), 0.8
+    m = object.__new__(ObjectSDFNetwork)
+    torch.nn.Module.__init__(m)
+    m.scene_bounding_sphere = 1.0
+    m.implicit_network = SingleObjectImplicitNetworkGrid(object_center=center, object_scale=scale, fg_bg=fg_bg, logmap=logmap)
+    m.rendering_network = SingleObjectRenderingNetwork()
+    m.density = LaplaceDensity(params_init=dict(beta=beta), beta_min=0.0001)
+    m.ray_sampler = ErrorBoundSampler(1.0, near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10, max_total_iters=5)
+    m.train()
+    with torch.no_grad():       # leave the dead-gradient state of geometric init (SURVEY Q5), make the grid matter
+        v = m.implicit_network.lin0.weight_v
+        v[:, 3:] = torch.randn(v[:, 3:].shape, generator=g) * 1e-2
+        e = m.implicit_network.encoding.embeddings
+        e.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * 2e-2)
+    uv, intr, _ = batch(R, 2, 64, seed + 2)
+    from utils import rend_util
+    dirs, loc = rend_util.get_camera_params(uv.clone(), look_at_pose((0.7, 0.0, 0.1)), intr)
+    d = dirs.reshape(-1, 3)
+    o = loc[:, None].repeat(1, R, 1).reshape(-1, 3)
+    rec = {"meta.S": S, "meta.R": R, "meta.logmap": logmap, "meta.fg_bg": int(fg_bg), "meta.scale": np.float64(scale), "meta.center": center.numpy()}
+    to_np("state.", m.state_dict(), rec)
+    to_np("in.", dict(ray_origins=o, ray_dirs=d), rec)
+    with DrawLog() as log:
+        out = m(o.clone(), d.clone())
+    names = ["t_rand", "u_final", "perm", "eik_idx", "eik_uniform", "eik_jitter"]
+    assert [k for k, _ in log.draws] == ["rand", "rand", "randperm", "randint", "uniform_", "rand_like"], [k for k, _ in log.draws]
+    for n, (_, v) in zip(names, log.draws):
+        rec[f"rand.{n}"] = v.numpy()
+    to_np("out.", out, rec)
+    cot = torch.Generator().manual_seed(seed + 3)
+    cots = {k: torch.randn(v.shape, generator=cot) for k, v in out.items() if k != "opacity"}
+    sum((out[k] * c).sum() for k, c in cots.items()).backward()
+    to_np("cot.", cots, rec)
+    to_np("grad.", {k: p.grad for k, p in m.named_parameters() if p.grad is not None}, rec)
+    # direct queries of the implicit network on points inside and outside the object's cube
+    x = torch.rand(40, 3, generator=g) * 2.2 - 1.1
+    net = m.implicit_network
+    to_np("q.", dict(x=x, forward=net.forward(x.clone()), sdf_vals=net.get_sdf_vals(x.clone()), gradient=net.gradient(x.clone())), rec)
+    sdf, fv, gr = net.get_outputs(x.clone())
+    to_np("q.get_outputs.", dict(sdf=sdf, feature_vectors=fv, gradients=gr), rec)
+    qdirs = torch.nn.functional.normalize(torch.randn(40, 3, generator=g), dim=-1)
+    to_np("q.", dict(dirs=qdirs, rendering=m.rendering_network(x, gr.detach(), qdirs, fv.detach())), rec)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  z={tuple(out['rgb_values'].shape)}")
+
+
+def run_dataset():
+    """the reference's class-balanced pixel sampler (datasets/ns_dataset.py:380-455), called on an NSDataset whose
+    tensors are synthetic (no image files exist here: the object is allocated without running __init__, which only reads files, and
+    given exactly the attributes __getitem__ uses).  Frames with different class sets, one class below its quota.  Records the frame
+    pick (random.randint), every torch.randperm in call order, and everything __getitem__ returned."""
+    import random as pyrandom
+    import importlib.util     # by path: an unrelated installed package is also called `datasets`
+    spec = importlib.util.spec_from_file_location("ref_ns_dataset", os.path.join(REF, "datasets", "ns_dataset.py"))
+    ref_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_mod)
+    NSDataset = ref_mod.NSDataset
+    H, W, F, R = 20, 24, 3, 64
+    g = torch.Generator().manual_seed(77)
+    P = H * W
+    ds = object.__new__(NSDataset)
+    ds.img_res, ds.total_pixels, ds.n_images, ds.fix_length = [H, W], P, F, 100
+    ds.sampling_class_id, ds.sampling_flag, ds.sampling_size, ds.sampling_idx = -1, True, R, None
+    ds.rgb_images = [torch.rand(P, 3, generator=g) for _ in range(F)]
+    ds.depth_images = [torch.rand(P, 1, generator=g) for _ in range(F)]
+    ds.normal_images = [torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1) for _ in range(F)]
+    ds.mask_images = [torch.ones(P, 1) for _ in range(F)]
+    ds.intrinsics_all = [torch.eye(4) + 0.01 * f for f in range(F)]
+    ds.pose_all = [torch.eye(4) * (1 + 0.1 * f) for f in range(F)]
+    layouts = [{0: 300, 1: 120, 3: 60}, {0: 400, 2: 80}, {0: 250, 1: 100, 2: 100, 3: 25, 5: 5}]      # frame 2: class 5 has 5 pixels < quota
+    ds.semantic_images, ds.semantic_images_classes = [], []
+    for lay in layouts:
+        lab = torch.cat([torch.full((n,), float(c)) for c, n in lay.items()])
+        lab = lab[torch.randperm(P, generator=g)].reshape(P, 1)
+        ds.semantic_images.append(lab)
+        ds.semantic_images_classes.append(torch.sort(torch.unique(lab).int())[0])
+    rec = {"meta.H": H, "meta.W": W, "meta.F": F, "meta.R": R, "meta.calls": 6}
+    for k in ("rgb_images", "depth_images", "normal_images", "mask_images", "semantic_images", "intrinsics_all", "pose_all"):
+        rec["data." + k] = torch.stack(getattr(ds, k)).numpy()
+    for f, c in enumerate(ds.semantic_images_classes):
+        rec[f"data.classes{f}"] = c.numpy()
+    saved = (pyrandom.randint, torch.randperm)
+    torch.manual_seed(78)
+    pyrandom.seed(79)
+    for call in range(6):
+        perms, picks = [], []
+        pyrandom.randint = lambda a, b: (picks.append(saved[0](a, b)), picks[-1])[1]
+        torch.randperm = lambda n, **k: (perms.append(saved[1](n, **k)), perms[-1])[1]
+        try:
+            idx, sample, gt = ds[0]
+        finally:
+            pyrandom.randint, torch.randperm = saved
+        rec[f"c{call}.frame"] = np.int64(idx)
+        assert picks == [idx]
+        rec[f"c{call}.nperm"] = np.int64(len(perms))
+        for i, pm in enumerate(perms):
+            rec[f"c{call}.perm{i}"] = pm.numpy()
+        rec[f"c{call}.sampling_idx"] = sample["sampling_idx"].numpy()
+        for k in ("uv", "intrinsics", "pose"):
+            rec[f"c{call}.in.{k}"] = sample[k].numpy()
+        for k in ("rgb", "depth", "mask", "normal", "segs"):
+            rec[f"c{call}.gt.{k}"] = gt[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "ns_sampler.npz"), **rec)
+    print("ns_sampler: ok", [int(rec[f"c{c}.frame"]) for c in range(6)], [rec[f"c{c}.sampling_idx"].shape[0] for c in range(6)])
+
+
 def run_conf():
     """The reference's stock Stage-1 configuration file read by the build's own HOCON reader (holoscene_amd/utils/conf.py; pyhocon is
     not installed here), stored as plain JSON: the file itself cannot travel, its parsed content is data (what
@@ -600,6 +717,12 @@ def main():
         run_tables()
     if sel("stock_conf_parsed"):
         run_conf()
+    if sel("ns_sampler"):
+        run_dataset()
+    if sel("object_sdf_fg"):
+        run_object_sdf("object_sdf_fg", fg_bg=True, seed=210)
+    if sel("object_sdf_bg"):
+        run_object_sdf("object_sdf_bg", fg_bg=False, seed=220)
     if sel("hash_small"):
         run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
     if sel("hash_mid"):

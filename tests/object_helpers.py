@@ -1,0 +1,53 @@
+"""Shared checks of the per-object networks (holoscene_amd/model/object_network.py) against tests/golden/object_sdf_*.npz."""
+import torch
+
+from helpers import section
+from model_helpers import close, z_close
+
+
+def build_object_model(rec, device="cpu"):
+    from holoscene_amd.model.object_network import ObjectSDFNetwork
+    from holoscene_amd.utils.conf import Conf
+    S = int(rec["meta.S"])
+    conf = Conf(density=dict(params_init=dict(beta=float(rec["state.density.beta"])), beta_min=0.0001),
+                ray_sampler=dict(near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10, max_total_iters=5))
+    m = ObjectSDFNetwork(torch.from_numpy(rec["meta.center"]), float(rec["meta.scale"]), bool(rec["meta.fg_bg"]), conf,
+                         implicit_kwargs=dict(logmap=int(rec["meta.logmap"])))
+    m.load_state_dict(section(rec, "state."))
+    return m.to(device)
+
+
+def check_object_model(rec, dev, strict):
+    """strict (CPU, deterministic oracle hash): everything elementwise.  GPU: depths may slide inside their bracket (z_close), per-ray
+    outputs on the reference's depths, gradients in relative L2."""
+    m = build_object_model(rec, dev).train()
+    assert sorted(m.state_dict().keys()) == sorted(section(rec, "state.").keys())
+    net = m.implicit_network
+    q = {k: v.to(dev) for k, v in section(rec, "q.").items()}
+    x = q["x"]
+    close(net.forward(x.clone()), q["forward"], 1e-4, 1e-5, "forward")
+    close(net.get_sdf_vals(x.clone()), q["sdf_vals"], 1e-4, 1e-5, "get_sdf_vals")
+    close(net.gradient(x.clone()), q["gradient"], 1e-4, 1e-5, "gradient")
+    sdf, fv, gr = net.get_outputs(x.clone())
+    close(sdf, q["get_outputs.sdf"], 1e-4, 1e-5, "get_outputs.sdf")
+    close(fv, q["get_outputs.feature_vectors"], 1e-4, 1e-5, "get_outputs.feature_vectors")
+    close(gr, q["get_outputs.gradients"], 1e-4, 1e-5, "get_outputs.gradients")
+    close(m.rendering_network(x, q["get_outputs.gradients"], q["dirs"], q["get_outputs.feature_vectors"]), q["rendering"], 1e-4, 1e-5, "rendering")
+    # ObjectSDFNetwork.forward on the reference's rays and draws
+    ins = {k: v.to(dev) for k, v in section(rec, "in.").items()}
+    rng = {k: v.to(dev) for k, v in section(rec, "rand.").items()}
+    ref = section(rec, "out.")
+    cots = {k: v.to(dev) for k, v in section(rec, "cot.").items()}
+    m.zero_grad()
+    out = m(ins["ray_origins"], ins["ray_dirs"], rng=rng)
+    assert set(out) == set(ref)
+    for k, v in ref.items():
+        close(out[k], v, 2e-3 if not strict else 1e-3, 5e-4 if not strict else 2e-4, k)
+    sum((out[k] * c).sum() for k, c in cots.items()).backward()
+    params = dict(m.named_parameters())
+    for k, v in section(rec, "grad.").items():
+        g = params[k].grad
+        assert g is not None, k
+        rel = float((g.cpu() - v).norm() / (v.norm() + 1e-12))
+        assert rel < (2e-3 if strict else 1e-2), (k, rel)
+    return m

@@ -53,6 +53,9 @@ import holoscene_amd.hashencoder.hashgrid as hg
 assert HashEncoder is hg.HashEncoder
 model = Net(conf=conf.get_config('model'), graph_node_dict=None, num_images=8)      # holoscene_train.py:137-143
 loss = Loss(**conf.get_config('loss'))                                              # holoscene_train.py:148-151
+from model.network import ObjectSDFNetwork, SingleObjectImplicitNetworkGrid      # holoscene_train_post.py:58
+import holoscene_amd.model.object_network as on
+assert ObjectSDFNetwork is on.ObjectSDFNetwork and get_class('model.network.SingleObjectImplicitNetworkGrid') is on.SingleObjectImplicitNetworkGrid
 print('PARAMS', sum(p.numel() for p in model.parameters()))
 print('DOUT', model.implicit_network.d_out, type(model.ray_sampler).__name__, model.ray_sampler.N_samples_eval)
 """, cwd=str(tmp_path))

@@ -144,3 +144,12 @@ def test_fused_sampler_refuses_cpu_tensors(monkeypatch):
     ins = section(rec, "in.")
     with pytest.raises(RuntimeError, match="CUDA tensors"):
         model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model)
+
+
+@pytest.mark.parametrize("name", ["object_sdf_fg", "object_sdf_bg"])
+def test_per_object_networks_match_reference(name):
+    """SingleObjectImplicitNetworkGrid / SingleObjectRenderingNetwork / ObjectSDFNetwork (network.py:1835-2209) --
+    query methods, forward on the reference's rays and draws, parameter gradients of a fixed cotangent; an object (fg) and a
+    background (bg) initialisation."""
+    from object_helpers import check_object_model
+    check_object_model(load(name), "cpu", strict=True)

@@ -1092,3 +1092,38 @@ def test_eval_mode_forward_through_fused_paths():
     for k, tol in (("rgb_values", 2e-2), ("depth_values", 5e-2), ("normal_map", 5e-2)):
         d = (a[k] - b[k]).abs()
         assert float(d.mean()) < 0.2 * tol and float(d.max()) < 5 * tol, (k, float(d.mean()), float(d.max()))
+
+
+def test_resident_ns_dataset_gather_equals_indexed_batches():
+    """ResidentNSDataset.write_batch (one hs_gather_rows launch into a static block) == next_batch() on the same
+    ring; a ragged batch (class below its quota, ns_dataset.py:422-427) is refused for the static block."""
+    from test_dataset_cpu import _dataset
+    rec = load("ns_sampler")
+    a, b = _dataset(rec, DEV, seed=3, ring=8), _dataset(rec, DEV, seed=3, ring=8)
+    R = int(rec["meta.R"])
+    dst_in = {"uv": torch.zeros(1, R, 2, device=DEV), "pose": torch.zeros(1, 4, 4, device=DEV), "intrinsics": torch.zeros(1, 4, 4, device=DEV)}
+    dst_gt = {"rgb": torch.zeros(1, R, 3, device=DEV), "depth": torch.zeros(1, R, 1, device=DEV), "normal": torch.zeros(1, R, 3, device=DEV),
+              "mask": torch.zeros(1, R, 1, device=DEV), "segs": torch.zeros(1, R, 1, device=DEV)}
+    done = ragged = 0
+    for _ in range(16):
+        _, si, gi = a.next_batch()
+        if si["uv"].shape[1] != R:
+            with pytest.raises(RuntimeError, match="static block"):
+                b.write_batch(dst_in, dst_gt)
+            ragged += 1
+            continue
+        b.write_batch(dst_in, dst_gt)
+        for k, v in si.items():
+            assert torch.equal(dst_in[k], v), k
+        for k, v in gi.items():
+            assert torch.equal(dst_gt[k], v), k
+        done += 1
+    assert done >= 8
+
+
+@pytest.mark.parametrize("name", ["object_sdf_fg", "object_sdf_bg"])
+def test_per_object_networks_match_reference(name):
+    """SURVEY 8f rank 3 on the HIP path: the per-object grid through csrc/hash_encode.hip (object-frame lookups, fused value+Jacobian
+    scatter), the fused sampler kernels, K = 1 compositing (csrc/composite.hip)."""
+    from object_helpers import check_object_model
+    check_object_model(load(name), DEV, strict=False)
