@@ -25,13 +25,16 @@ def check_object_model(rec, dev, strict):
     net = m.implicit_network
     q = {k: v.to(dev) for k, v in section(rec, "q.").items()}
     x = q["x"]
+    # the SDF gradient passes two Softplus(beta = 100) layers whose derivative amplifies a pre-activation difference up to 25x each:
+    # 1e-7 differences of the fp32 library GEMMs reach 2e-4 on an O(1) gradient (measured on the MI355X; CPU: 1e-5)
+    g_rtol, g_atol = (1e-4, 1e-5) if strict else (5e-4, 3e-4)
     close(net.forward(x.clone()), q["forward"], 1e-4, 1e-5, "forward")
     close(net.get_sdf_vals(x.clone()), q["sdf_vals"], 1e-4, 1e-5, "get_sdf_vals")
-    close(net.gradient(x.clone()), q["gradient"], 1e-4, 1e-5, "gradient")
+    close(net.gradient(x.clone()), q["gradient"], g_rtol, g_atol, "gradient")
     sdf, fv, gr = net.get_outputs(x.clone())
     close(sdf, q["get_outputs.sdf"], 1e-4, 1e-5, "get_outputs.sdf")
     close(fv, q["get_outputs.feature_vectors"], 1e-4, 1e-5, "get_outputs.feature_vectors")
-    close(gr, q["get_outputs.gradients"], 1e-4, 1e-5, "get_outputs.gradients")
+    close(gr, q["get_outputs.gradients"], g_rtol, g_atol, "get_outputs.gradients")
     close(m.rendering_network(x, q["get_outputs.gradients"], q["dirs"], q["get_outputs.feature_vectors"]), q["rendering"], 1e-4, 1e-5, "rendering")
     # ObjectSDFNetwork.forward on the reference's rays and draws
     ins = {k: v.to(dev) for k, v in section(rec, "in.").items()}
@@ -42,6 +45,11 @@ def check_object_model(rec, dev, strict):
     out = m(ins["ray_origins"], ins["ray_dirs"], rng=rng)
     assert set(out) == set(ref)
     for k, v in ref.items():
+        if not strict and k.startswith("grad_theta"):
+            # R of the 2 (2048 + R) Eikonal points sit on sampled depths, which may slide inside their bracket on the GPU (z_close)
+            bad = (out[k].detach().cpu() - v).abs() > 5e-4 + 2e-3 * v.abs()
+            assert float(bad.float().mean()) < 0.01, (k, float(bad.float().mean()))
+            continue
         close(out[k], v, 2e-3 if not strict else 1e-3, 5e-4 if not strict else 2e-4, k)
     sum((out[k] * c).sum() for k, c in cots.items()).backward()
     params = dict(m.named_parameters())
