@@ -373,10 +373,18 @@ def run_multi_obj(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64):
     to_np("in.", dict(ray_origins=o, ray_dirs=d, pose=pose, uv=uv, intrinsics=intr), rec)
     names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
     cot = torch.Generator().manual_seed(seed + 4)
+    sampled = []         # the depths the reference's sampler handed to each entry point (the get_colors_* family does not return them)
+    sm = model.ray_sampler
+    for meth in ("get_z_vals", "get_z_vals_near_far"):
+        orig_m = getattr(sm, meth)
+        setattr(sm, meth, (lambda f: (lambda *a, **k: (sampled.append(f(*a, **k)), sampled[-1])[1]))(orig_m))
     for key, fn in calls.items():
         model.zero_grad()
+        del sampled[:]
         with DrawLog() as log:
             out = fn()
+        assert len(sampled) == 1, (key, len(sampled))
+        rec[f"{key}.aux.z_vals"] = sampled[0][0].detach().numpy().copy()
         assert len(log.draws) == len(names), (key, [k for k, _ in log.draws])
         for n, (_, v) in zip(names, log.draws):
             rec[f"{key}.rand.{n}"] = v.numpy()

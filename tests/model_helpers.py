@@ -92,51 +92,62 @@ def multi_obj_calls(model, rec, dev="cpu"):
 def check_multi_obj(model, rec, dev="cpu", rtol=1e-3, atol=2e-4, grad_rtol=5e-3, strict=True):
     """Every entry point against the reference's outputs on the reference's draws; for three of them also the parameter
     gradients of a fixed scalar of the colour and depth outputs (that is what the detach variant changes).
-    strict=False (GPU kernels: sample placement is ill-conditioned, see z_close): a few depths may slide inside their bracket;
-    per-ray outputs are then compared on the rays whose samples did not move, gradients by relative norm."""
+    strict=True (CPU, deterministic hash oracle): the entry point's own depths must match (z_close) and everything is compared
+    elementwise.  strict=False (GPU kernels): sample placement is ill-conditioned (see z_close), so each entry point is called TWICE --
+    once as is, to check the depths the fused sampler produced; once with the sampler answering with the reference's own depths
+    (fixture `<call>.aux.z_vals`), and then EVERY output and gradient is compared elementwise, no per-ray allowance."""
     calls = multi_obj_calls(model, rec, dev)
     params = dict(model.named_parameters())
+    sm = model.ray_sampler
     for key, fn in calls.items():
         rng = {k: v.to(dev) for k, v in section(rec, f"{key}.rand.").items()}
-        model.zero_grad()
-        out = fn(rng)
         ref = section(rec, f"{key}.out.")
+        z_ref = torch.from_numpy(rec[f"{key}.aux.z_vals"])
+        model.zero_grad()
+        if strict:
+            out = fn(rng)
+            if "z_vals" in ref:
+                z_close(out["z_vals"], ref["z_vals"])
+        else:
+            own = []
+            saved = (sm.get_z_vals, sm.get_z_vals_near_far)
+
+            def logged(f):
+                return lambda *a, **k: (own.append(f(*a, **k)), own[-1])[1]
+            sm.get_z_vals, sm.get_z_vals_near_far = logged(saved[0]), logged(saved[1])
+            try:
+                with torch.no_grad():
+                    fn(rng)
+            finally:
+                sm.get_z_vals, sm.get_z_vals_near_far = saved
+            z_close(own[0][0], z_ref, frac_loose=0.05)
+            z_fix = z_ref.to(dev)
+            eik = rng.get("eik_idx")
+            z_eik = torch.gather(z_fix, 1, eik.long()[:, None]) if eik is not None else None
+            sm.get_z_vals = sm.get_z_vals_near_far = lambda *a, **k: (z_fix, z_eik)
+            try:
+                out = fn(rng)
+            finally:
+                sm.get_z_vals, sm.get_z_vals_near_far = saved
         if not isinstance(out, dict):
             out = {f"ret{i}": v for i, v in enumerate(out if isinstance(out, tuple) else (out,))}
         assert set(ref) <= set(k for k, v in out.items() if torch.is_tensor(v)), (key, sorted(ref), sorted(out))
-        same = None
-        z_ref = ref.get("z_vals")
-        if z_ref is not None:
-            z_close(out["z_vals"], z_ref, frac_loose=0.02 if strict else 0.05)
-            if not strict:
-                same = ((out["z_vals"].cpu() - z_ref).abs() < 1e-4).all(dim=1)
-                assert same.float().mean() > 0.7, key
         for k, v in ref.items():
             if k == "z_vals":
                 continue
             o = out[k].detach().cpu()
-            if same is not None and v.ndim >= 1 and v.shape[0] == same.shape[0]:
-                o, v = o[same], v[same]
             if v.dtype in (torch.int64, torch.int32):      # arg-max labels
                 assert float((o == v).float().mean()) > 0.95, (key, k)
-            elif strict or same is not None:
-                close(o, v, rtol, atol, f"{key}.{k}")
-            else:      # no depths returned (get_colors_*): rays with a slid sample cannot be told apart -- nearly all must agree
+            elif not strict and key.endswith("_nf") and v.ndim >= 1 and v.shape[0] == z_ref.shape[0]:
+                # `far` of the *_near_far variants lies INSIDE the scene, so the 1e10-wide last interval (network.py:1808) follows a
+                # sample in non-empty space: its weight is (1 - exp(-1e10 sigma)) T with sigma = (0.5 + 0.5 expm1(-s/beta)) / beta, and in
+                # fp32 expm1(-x) rounds to exactly -1 for x > 16.6 -- sigma is 0 or >= 6e-8/beta, i.e. the weight is 0 or T.  A ray whose
+                # last sample sits at s/beta ~ 17 flips on the last bit of expm1 (libm vs the device's): at most one such ray here
                 bad = ((o - v).abs() > atol + rtol * v.abs()).reshape(v.shape[0], -1).any(dim=1)
-                assert bad.float().mean() <= 0.25, (key, k, float(bad.float().mean()))
+                assert int(bad.sum()) <= 1, (key, k, int(bad.sum()))
+            else:
+                close(o, v, rtol, atol, f"{key}.{k}")
         grads = section(rec, f"{key}.grad.")
-        if grads and not strict:
-            # gradients on the reference's own depths (a slid sample changes which points the gradient flows through): re-run the
-            # entry point with the sampler answering with the fixture's z_vals
-            sm = model.ray_sampler
-            saved = (sm.get_z_vals, sm.get_z_vals_near_far)
-            z_fix = z_ref.to(dev)
-            sm.get_z_vals = sm.get_z_vals_near_far = lambda *a, **k: (z_fix, None)
-            try:
-                model.zero_grad()
-                out = fn(rng)
-            finally:
-                sm.get_z_vals, sm.get_z_vals_near_far = saved
         if grads:
             c_rgb, c_dep = torch.from_numpy(rec[f"{key}.cot.rgb_values"]).to(dev), torch.from_numpy(rec[f"{key}.cot.depth_values"]).to(dev)
             ((out["rgb_values"] * c_rgb).sum() + (out["depth_values"] * c_dep).sum()).backward()
@@ -147,7 +158,7 @@ def check_multi_obj(model, rec, dev="cpu", rtol=1e-3, atol=2e-4, grad_rtol=5e-3,
                     close(g, v, grad_rtol, 2e-4 * max(1e-3, float(v.abs().max())), f"{key}.grad.{k}")
                 else:
                     rel = float((g.cpu() - v).norm() / (v.norm() + 1e-12))
-                    assert rel < 1e-2, (key, k, rel)
+                    assert rel < 2e-3, (key, k, rel)
 
 
 def check_network_methods(model, rec, dev="cpu", rtol=1e-4, atol=1e-5):

@@ -778,7 +778,7 @@ def test_stage23_entry_points(name):
     rec = load(name)
     model = build_model(rec, DEV)
     model.train(bool(rec["meta.train"]))
-    check_multi_obj(model, rec, DEV, rtol=2e-3, atol=5e-4, strict=False)
+    check_multi_obj(model, rec, DEV, rtol=5e-4, atol=1e-4, strict=False)      # on the reference depths: measured <= 1e-5
 
 
 def test_stage23_entry_points_fused_colour_path(monkeypatch):
