@@ -45,6 +45,9 @@ def parse():
                         "but makes it small enough that all timed steps see the 8(d) state (5 sampler rounds at beta=0.001).  1.0 = stock rates.")
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                    help="MLP GEMM operand precision (BASELINE configs[1] names bf16; fp32 is the reference's own precision)")
+    p.add_argument("--eikonal", choices=["analytic", "fd"], default="analytic",
+                   help="gradients of the Eikonal set: analytic (the reference's, the parity path) or the opt-in 4-tap finite difference "
+                        "BASELINE configs[4] words; 'fd' is an extra, never the headline")
     p.add_argument("--no-graph", action="store_true", help="run the post-sampler part eagerly instead of as a captured HIP graph")
     p.add_argument("--optimizer", choices=["flat", "torch"], default="flat")
     p.add_argument("--roofline-steps", type=int, default=6, help="eager iterations after the timed region used to time single kernels")
@@ -272,7 +275,7 @@ def main():
     from holoscene_amd.training import distributed as dist_util
 
     conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision,
-                      learning_rate=5.0e-4 * args.lr_scale)
+                      learning_rate=5.0e-4 * args.lr_scale, eikonal_mode=args.eikonal)
     tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
                        graph=(not args.no_graph) and args.optimizer == "flat")
     benchmark_model_state(tr.model, args.beta)
@@ -458,7 +461,8 @@ def main():
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
                                    f"full iteration (pixel-batch gather from HBM-resident frames+sampler+render+eikonal+loss+backward+Adam; every 10th "
                                    f"iteration also the 32x32 background-patch pass, render_bg_iter=10), beta={args.beta}, lr x{args.lr_scale:g}, "
-                                   f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)",
+                                   f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)"
+                                   + ("" if args.eikonal == "analytic" else ", Eikonal set by 4-tap finite differences (opt-in extra, not the reference's analytic gradients)"),
                        "rays_per_gpu": args.rays, "sampler_rounds_mean": round(rounds_mean, 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,

@@ -1100,6 +1100,13 @@ class HoloSceneNetwork(nn.Module):
         self.register_buffer("bg_color", torch.tensor(conf.get_list("bg_color", default=[1.0, 1.0, 1.0])).float(), persistent=False)
         self.use_bg_reg = conf.get_bool("use_bg_reg", default=False)
         self.render_bg_iter = conf.get_int("render_bg_iter", default=10)
+        # Eikonal / smoothness gradients of the 4R-point regulariser set: "analytic" = d sdf_k / dx from the value+Jacobian pass, which is
+        # what the reference computes (autograd, network.py:212-254) and the parity path; "fd" = the opt-in 4-tap tetrahedral finite
+        # difference BASELINE.json's configs[4] words ("4-tap Eikonal finite-difference"), reported as an extra
+        self.eikonal_mode = conf.get_string("eikonal_mode", default="analytic")
+        self.eikonal_fd_h = conf.get_float("eikonal_fd_h", default=1.0e-3)
+        if self.eikonal_mode not in ("analytic", "fd"):
+            raise ValueError(f"eikonal_mode must be 'analytic' or 'fd', got {self.eikonal_mode!r}")
         self.graph_node_dict = graph_node_dict
         self.implicit_network = ObjectImplicitNetworkGrid(self.feature_vector_size, 0.0 if self.white_bkgd else self.scene_bounding_sphere,
                                                           **conf.get_config("implicit_network"))
@@ -1361,6 +1368,28 @@ class HoloSceneNetwork(nn.Module):
     # forward() = prepare_rays -> sample -> (prepare_background) -> render.  The stages exist so the trainer can
     # run the data-dependent part (rays + Algorithm-1 sampler, which needs a host decision per round) eagerly and
     # replay everything after it -- render, loss, backward, Adam -- as one captured HIP graph.
+    _FD_TAPS = ((1.0, -1.0, -1.0), (-1.0, -1.0, 1.0), (-1.0, 1.0, -1.0), (1.0, 1.0, 1.0))
+
+    def _eikonal_gradients_fd(self, x, y_centre):
+        """Opt-in replacement of the analytic Eikonal-set gradients: grad f(x) ~ sum_i k_i f(x + h k_i) / (4 h) over the four tetrahedral
+        taps k_i (truncation error of order h^2 times the third derivatives), for every object SDF and -- with the centre point's arg-min
+        object -- for the scene SDF; same stacking as gradient() ([(K + 1) * B, 3], network.py:212-254).  The taps go through the
+        differentiable value-only trunk, so the parameters receive the finite-difference form's own gradient.  4 x the Eikonal set's
+        points (16 R) instead of its 3 tangent rows."""
+        net, h = self.implicit_network, self.eikonal_fd_h
+        if net.mlp_bf16:
+            # measured: relative L2 distance 1.4 from the analytic rows -- a bf16 trunk rounds its INPUTS to 8 bits (spacing 2e-3 .. 4e-3 at
+            # |x| ~ 0.5), so taps 1e-3 apart collapse onto the same operand, and its output noise (3e-3 relative) exceeds the differences
+            raise ValueError("eikonal_mode='fd' needs mlp_precision='fp32': finite differences at h = 1e-3 are below the resolution of bf16 operands")
+        B = x.shape[0]
+        taps = torch.tensor(self._FD_TAPS, device=x.device, dtype=x.dtype)                  # [4,3]
+        pts = (x.detach().unsqueeze(0) + h * taps.unsqueeze(1)).reshape(-1, 3)              # [4B,3]
+        y = net._trunk(pts)[:, :net.d_out].float().reshape(4, B, net.d_out)                 # [4,B,K]
+        J = torch.einsum("tbk,td->bkd", y, taps) / (4.0 * h)                                # [B,K,3]
+        idx = y_centre.detach().argmin(dim=-1, keepdim=True)
+        g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+        return torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
+
     def weight_norm_layers(self):
         """Every weight-normalised layer a Stage-1 iteration evaluates (for shared_effective_weights)."""
         rn = self.rendering_network
@@ -1591,6 +1620,9 @@ class HoloSceneNetwork(nn.Module):
                 min_sdf, idx = y.min(dim=-1, keepdim=True)
                 g_min = torch.gather(J, 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
                 grad_theta = torch.cat([J.transpose(0, 1).reshape(-1, 3), g_min], 0)
+            if self.eikonal_mode == "fd":
+                grad_theta = self._eikonal_gradients_fd(x_all[n_main:], y)
+                output.pop("grad_theta_all", None)
             output["sample_sdf"] = y
             output["sample_minsdf"] = min_sdf
             half = grad_theta.shape[0] // 2  # quirk Q2: halves of the stacked rows, not original/jittered

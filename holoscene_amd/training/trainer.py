@@ -15,7 +15,7 @@ from .optim import build_optimizer, build_scheduler
 
 
 def stock_conf(num_rays=1024, S=128, d_out=32, num_levels=16, base_size=16, end_size=2048, logmap=19, beta=0.1, use_bg_reg=True,
-               mlp_precision="fp32", learning_rate=5.0e-4):
+               mlp_precision="fp32", learning_rate=5.0e-4, eikonal_mode="analytic"):
     """confs/replica/room_0/replica_room_0.conf with 'R rays x S samples' mapped as SURVEY D5:
     N_samples_eval=S, N_samples=S/2, N_samples_extra=S/4."""
     return Conf(
@@ -26,6 +26,7 @@ def stock_conf(num_rays=1024, S=128, d_out=32, num_levels=16, base_size=16, end_
                   bg_reg_weight=0.01, depth_type="marigold"),
         model=Conf(
             feature_vector_size=256, scene_bounding_sphere=1.0, use_bg_reg=use_bg_reg, render_bg_iter=10, mlp_precision=mlp_precision,
+            eikonal_mode=eikonal_mode,
             implicit_network=Conf(d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], weight_norm=True,
                                   multires=6, inside_outside=True, use_grid_feature=True, divide_factor=1.0, sigmoid=10,
                                   color_grid_feature=True, num_levels=num_levels, base_size=base_size, end_size=end_size, logmap=logmap),
