@@ -388,7 +388,7 @@ def test_fused_loss_matches_torch_formulation(R, N, K, monkeypatch):
         close(a, b, 2e-3, 2e-5 * max(1e-6, float(b.abs().max())), "d/d" + n_)
 
 
-@pytest.mark.parametrize("rays,S,K,precision", [(1024, 128, 21, "fp32"), (2048, 192, 32, "bf16"), (512, 128, 32, "bf16")])
+@pytest.mark.parametrize("rays,S,K,precision", [(1024, 128, 21, "fp32"), (1024, 128, 21, "bf16"), (2048, 192, 32, "bf16"), (512, 128, 32, "bf16")])
 def test_other_baseline_config_shapes(rays, S, K, precision):
     """BASELINE configs[3] (K=21 on the shared net), configs[4] (2 048 rays x 192 samples -> 146 pts/ray) and the per-rank
     shape of configs[2] (512 rays): two graph-replayed training iterations, size-independent invariants."""
