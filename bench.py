@@ -93,6 +93,12 @@ def _work_trunk_fwd(a, k):
     return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 96 * 2 + K * 4) + (M // 4) * (12 + 128 + 384)
 
 
+def _work_trunk_fwd2(a, k):
+    Y, K = a[7], a[4]
+    M = Y.shape[0]
+    return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 80 * 2 + K * 4) + (M // 4) * (12 + 128 + 384)
+
+
 def _work_trunk_bwd(a, k):
     g = a[0]
     M, Kp = g.shape[0], g.shape[-1]
@@ -128,6 +134,7 @@ TIMED = {
     "sdf_mlp_fwd": ("k_sdf_mlp (fused bf16 MFMA SDF trunk, sampler sweeps; workgroup-tile form)", _work_sdf_mlp),
     "sdf_mlp2_fwd": ("k_sdf_mlp2 (fused bf16 MFMA SDF trunk, sampler sweeps; wave-tile form)", _work_sdf_mlp2),
     "trunk_mlp_fwd": ("k_trunk_fwd (value+Jacobian trunk, 4 rows per point)", _work_trunk_fwd),
+    "trunk_mlp2_fwd": ("k_trunk_fwd2 (value+Jacobian trunk, 4 rows per point; wave-tile form, builds its own input rows)", _work_trunk_fwd2),
     "trunk_mlp_bwd": ("k_trunk_bwd (trunk data-gradient chain + last-layer wgrad)", _work_trunk_bwd),
     "appearance_fwd": ("k_appear_fwd (colour-feature MLP + rendering network)", _work_appear_fwd),
     "appearance_bwd": ("k_appear_bwd", _work_appear_bwd),

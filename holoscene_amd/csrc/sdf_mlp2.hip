@@ -21,47 +21,13 @@
 //
 // Softplus(beta = 100) is evaluated in the scaled domain of sdf_mlp.hip (t = 100 log2(e) v: log2(1 + 2^t)), the biases initialise
 // the accumulators.  d_out <= 32 (one output tile); wider heads keep the workgroup-tile kernel.
-#include <hip/hip_runtime.h>
-#include <hip/hip_bf16.h>
-#include <math.h>
-#include <stdint.h>
-
-#include "holoscene_hip.h"
+#include "wave_tile.h"
 
 #ifdef HS_SDF2_PROFILE     // tools/exp/sdf2_prof.hip: per-phase s_memtime stamps of a steady-state wave tile
 __device__ unsigned long long g_sdf2_prof[256 * 8 * 16];   // [block][wave][stamp]
 #endif
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-constexpr int kRows = 32;            // points per wave tile
-constexpr int kWaves = 8;
-constexpr int kThreadsW = 64 * kWaves;
-constexpr int K0S = 5;               // k-steps of layer 0: 80 padded inputs
-constexpr int HS = 16;               // k-steps of a 256-deep layer
-constexpr int NT = 8;                // 32-neuron tiles of a 256-wide layer
-constexpr int kW0F = K0S * NT * 64 * 8;   // bf16 elements of the packed matrices
-constexpr int kW1F = HS * NT * 64 * 8;
-constexpr int kW2F = HS * 64 * 8;
-constexpr int kBias = 256 + 256 + 32;     // b0 (scaled) | b1 (scaled) | b2
-constexpr float kAct = 100.f * 1.44269504f;
-
-__device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_bf16_f32 (round-to-nearest-even)
-    const float2_t v = {a, b};
-    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-    return *reinterpret_cast<const uint32_t *>(&r);
-}
-
-__device__ __forceinline__ bf16x8 frag_of(const uint32_t *p) {
-    union { uint32_t u[4]; bf16x8 v; } c;
-    c.u[0] = p[0]; c.u[1] = p[1]; c.u[2] = p[2]; c.u[3] = p[3];
-    return c.v;
-}
 
 // log2(1 + 2^t); above t = 30 that IS t in fp32 (sdf_mlp.hip: softplus_scaled).  No clamp of the exponential's argument: beyond
 // t = 128 it overflows to +inf, the logarithm returns +inf, and the select below never looks at it.
@@ -70,101 +36,11 @@ __device__ __forceinline__ float softplus_scaled2(float t) {
     return t > 30.f ? t : l;
 }
 
-// input column (reference order: x, then per octave k sin(2^k x) cos(2^k x), then the 32 hash features) held by lane half h at
-// position j of its 40-value list; -1 = zero padding
-__host__ __device__ inline int input_column(int h, int j) {
-    if (j < 18) return 3 + 18 * h + j;                 // octaves 3h .. 3h+2: [sin x3, cos x3] each
-    if (j < 34) return 39 + 16 * h + (j - 18);         // hash levels 8h .. 8h+7, two channels each
-    if (j < 37) return h == 0 ? j - 34 : -1;           // the raw coordinates ride in half 0
-    return -1;
-}
-
-// ---------------------------------------------------------------------------------------------------------------- weight packing
-// fp32 effective (weight-normalised) matrices, row-major [out][in] -> bf16 fragment images + the bias block
-__global__ __launch_bounds__(256) void k_sdf_pack2(const float *__restrict__ W0, int ld0, const float *__restrict__ b0, const float *__restrict__ W1,
-                                                   const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
-                                                   uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
-                                                   float *__restrict__ bias) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;      // one 16-byte fragment slot per thread
-    constexpr int n0 = K0S * NT * 64, n1 = HS * NT * 64, n2 = HS * 64;
-    float v[8];
-    uint16_t *dst;
-    if (idx < n0) {
-        const int s = idx / (NT * 64), nt = (idx / 64) % NT, lane = idx & 63, n = 32 * nt + (lane & 31), h = lane >> 5;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int c = input_column(h, 8 * s + e);
-            v[e] = c >= 0 ? kAct * W0[(size_t)n * ld0 + c] : 0.f;
-        }
-        dst = W0f + (size_t)idx * 8;
-    } else if (idx < n0 + n1) {
-        const int i = idx - n0, s = i / (NT * 64), nt = (i / 64) % NT, lane = i & 63, n = 32 * nt + (lane & 31), h = lane >> 5;
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = W1[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)];
-        dst = W1f + (size_t)i * 8;
-    } else if (idx < n0 + n1 + n2) {
-        const int i = idx - n0 - n1, s = i / 64, lane = i & 63, n = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = n < d_out ? W2[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)] * (1.f / kAct) : 0.f;
-        dst = W2f + (size_t)i * 8;
-    } else {
-        const int i = idx - n0 - n1 - n2;
-        if (i < 256) bias[i] = b0[i] * kAct;
-        else if (i < 512) bias[i] = b1[i - 256] * kAct;
-        else if (i < kBias) bias[i] = (i - 512) < d_out ? b2[i - 512] : 0.f;
-        return;
-    }
-    uint4 pk;
-    pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
-    *reinterpret_cast<uint4 *>(dst) = pk;
-}
-
-// ---------------------------------------------------------------------------------------------------------------- the kernel
-// accumulator register r of a 32-neuron tile <-> neuron 8 (r >> 2) + 4 h + (r & 3)
-__device__ __forceinline__ void init_acc(f32x16 &acc, const float *bias_tile, int h) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float4 b = *reinterpret_cast<const float4 *>(bias_tile + 8 * q + 4 * h);
-        acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
-    }
-}
-
 // softplus + bf16 pack of accumulator registers r, r + 1 (r even) of a tile: half a register pair of the next layer's B fragment.
 // Register r of tile nt lands in word (r >> 1) of that tile's 8-word block = k-steps 2 nt (words 0-3) and 2 nt + 1 (words 4-7).
 __device__ __forceinline__ uint32_t epilogue_pair(const f32x16 &acc, int r) {
     uint32_t w = pack2(softplus_scaled2(acc[r]), softplus_scaled2(acc[r + 1]));
-    // the value is consumed many MFMAs later (as a B operand of the next layer): without an anchor the optimiser SINKS the whole softplus
-    // down to that use, out of the MFMA shadow it was placed in (measured: layer 1's epilogues piled up in front of layer 2)
-    asm volatile("" : "+v"(w));
-    return w;
-}
-
-// One PHASE of a wave tile = the MFMAs of one neuron quarter (two 32-neuron tiles, KS k-steps) with, in their shadow, the softplus
-// epilogue of the accumulator set the previous phase filled (two sets alternate).  Phases chain ACROSS layers: the first quarter of
-// layer 1 only needs layer 0's quarters 0-2 for its k-steps 0..11, so layer 0's last epilogue is spread over its first E = 8 k-steps
-// (likewise layer 2 under layer 1's last) -- no epilogue runs un-overlapped, and the matrix pipe and the VALU of ONE wave overlap
-// without relying on the SIMD's other wave being in the opposite phase.
-//   frag(s, j): A fragment of k-step s, tile j (0/1) of this quarter;  hin: B fragments of this layer (4 words per k-step);
-//   prev/hprev: the previous phase's accumulators and the 16 words (2 tiles x 8) their epilogue writes (nullptr: nothing to finish);
-//   E: k-steps over which those 16 packed pairs are spread;  AHEAD: how many k-steps the A fragments travel in front of their MFMAs
-//   (explicit ring: at its register limit the scheduler otherwise issues every ds_read right before the MFMA that needs it).
-template <int KS, int AHEAD, int E, bool EPI, class FragFn>
-__device__ __forceinline__ void phase2(f32x16 (&cur)[2], const f32x16 (&prev)[2], const uint32_t *hin, uint32_t *hprev, FragFn frag) {
-    bf16x8 ring[AHEAD + 1][2];
-#pragma unroll
-    for (int s = 0; s < AHEAD && s < KS; s++) { ring[s][0] = frag(s, 0); ring[s][1] = frag(s, 1); }
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-        if (s + AHEAD < KS) { ring[(s + AHEAD) % (AHEAD + 1)][0] = frag(s + AHEAD, 0); ring[(s + AHEAD) % (AHEAD + 1)][1] = frag(s + AHEAD, 1); }
-        const bf16x8 b = frag_of(hin + 4 * s);
-        cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][0], b, cur[0], 0, 0, 0);
-        cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)][1], b, cur[1], 0, 0, 0);
-        if (EPI && s < E) {
-#pragma unroll
-            for (int sl = (s * 16) / E; sl < ((s + 1) * 16) / E; sl++) hprev[8 * (sl >> 3) + (sl & 7)] = epilogue_pair(prev[sl >> 3], 2 * (sl & 7));
-        }
-        __builtin_amdgcn_sched_barrier(0);      // pin the k-step order: loads of s + AHEAD | MFMAs of s | epilogue slice
-    }
+    return anchor(w);      // keeps the softplus in the MFMA shadow it was placed in (wave_tile.h)
 }
 
 __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
@@ -270,8 +146,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                 init_acc(acc[q & 1][1], bias + 32 * (2 * q + 1), h);
                 if (q < 3) HS_W0_FETCH(q + 1);
                 auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
-                if (q == 0) phase2<K0S, 1, K0S, false>(acc[0], acc[1], hin, nullptr, f0);
-                else phase2<K0S, 1, K0S, true>(acc[q & 1], acc[(q & 1) ^ 1], hin, h0p + 16 * (q - 1), f0);
+                if (q == 0) phase2<K0S, 1, K0S, 16, false>(acc[0], hin, f0, [](auto) {});
+                else phase2<K0S, 1, K0S, 16, true>(acc[q & 1], hin, f0, [&](auto slc) { constexpr int sl = decltype(slc)::value;
+                    h0p[16 * (q - 1) + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[(q & 1) ^ 1][sl >> 3], 2 * (sl & 7)); });
             }
 #undef HS_W0_FETCH
         }
@@ -287,8 +164,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
             init_acc(acc[q & 1][1], bias + 256 + 32 * (2 * q + 1), h);
             auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
             // q = 0 finishes layer 0's last quarter (needed from k-step 12 on) within its first 8 k-steps
-            if (q == 0) phase2<HS, 2, 8, true>(acc[0], acc[1], h0p, h0p + 48, f1);
-            else phase2<HS, 2, HS, true>(acc[q & 1], acc[(q & 1) ^ 1], h0p, h1p + 16 * (q - 1), f1);
+            if (q == 0) phase2<HS, 2, 8, 16, true>(acc[0], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value; h0p[48 + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[1][sl >> 3], 2 * (sl & 7)); });
+            else phase2<HS, 2, HS, 16, true>(acc[q & 1], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value;
+                h1p[16 * (q - 1) + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[(q & 1) ^ 1][sl >> 3], 2 * (sl & 7)); });
         }
         HS_STAMP(3);
         // ---- layer 2: 256 -> d_out (<= 32) on two partial accumulators (even / odd k-steps: no dependent-MFMA chain), with layer 1's
@@ -360,8 +238,6 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
 #endif
 }
 
-int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
-
 }  // namespace
 
 extern "C" {
@@ -377,13 +253,13 @@ int64_t hs_sdf_mlp2_pack_bytes(int32_t which) {
 }
 
 int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
-                     void *W0f, void *W1f, void *W2f, float *bias, void *stream) {
+                     void *W0f, void *W1f, void *W2f, float *bias, int32_t log2_domain, void *stream) {
     if (d_out < 1 || d_out > 32 || ld0 < 71) return HS_ERR_ARG;
     if (!W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !W0f || !W1f || !W2f || !bias) return HS_ERR_NULL;
     const int slots = K0S * NT * 64 + HS * NT * 64 + HS * 64 + kBias;
     k_sdf_pack2<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(W0, ld0, b0, W1, b1, W2, b2, d_out, (uint16_t *)W0f, (uint16_t *)W1f,
-                                                                      (uint16_t *)W2f, bias);
-    return check_launch();
+                                                                      (uint16_t *)W2f, bias, log2_domain ? kAct : 1.f);
+    return wt_check_launch();
 }
 
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
@@ -403,7 +279,7 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     k_sdf_mlp2<<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
                                                                feat_level_major);
-    return check_launch();
+    return wt_check_launch();
 }
 
 }  // extern "C"

@@ -86,7 +86,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
 
 
 def _check(rc, what):
@@ -347,8 +347,9 @@ class _HipBackend:
                                   ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp_fwd")
 
     @staticmethod
-    def sdf_mlp2_pack(W0, b0, W1, b1, W2, b2, d_out):
-        """fp32 effective matrices -> (W0f, W1f, W2f, bias): the fragment-order bf16 images + scaled bias block of csrc/sdf_mlp2.hip."""
+    def sdf_mlp2_pack(W0, b0, W1, b1, W2, b2, d_out, log2_domain=True):
+        """fp32 effective matrices -> (W0f, W1f, W2f, bias): the fragment-order bf16 images + bias block of the wave-tile kernels
+        (log2_domain: csrc/sdf_mlp2.hip's scaled softplus; False: csrc/trunk_mlp2.hip, plain-domain activations)."""
         lib = load_library()
         lib.hs_sdf_mlp2_pack_bytes.restype = ctypes.c_int64
         dev = W0.device
@@ -359,7 +360,7 @@ class _HipBackend:
         if W0.stride(1) != 1 or W0.stride(0) < 71:
             raise RuntimeError("sdf_mlp2_pack: W0 must be row-major with at least 71 columns")
         _check(lib.hs_sdf_mlp2_pack(_dev(W0, "W0"), int(W0.stride(0)), _dev(b0, "b0"), _dev(W1, "W1"), _dev(b1, "b1"), _dev(W2, "W2"), _dev(b2, "b2"),
-                                    d_out, *[_dev(b, "frag", torch.bfloat16) for b in bufs], _dev(bias, "bias"), _stream()), "hs_sdf_mlp2_pack")
+                                    d_out, *[_dev(b, "frag", torch.bfloat16) for b in bufs], _dev(bias, "bias"), int(log2_domain), _stream()), "hs_sdf_mlp2_pack")
         return (*bufs, bias)
 
     @staticmethod
@@ -377,6 +378,21 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
                                    d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
+
+    @staticmethod
+    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale):
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, W2f, bias = packed
+        _check(lib.hs_trunk_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
+                                     _dev(bias, "bias"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y"), _dev(Xp, "Xp", bf),
+                                     ctypes.c_int64(Y.shape[0]), ctypes.c_float(jac_scale), _stream()), "hs_trunk_mlp2_fwd")
+
+    @staticmethod
+    def trunk_mlp2_columns():
+        """Xp column of every reference input column (x | 6 octaves of sin, cos | 32 hash features): int64 [71]."""
+        lib = load_library()
+        return torch.tensor([int(lib.hs_trunk_mlp2_input_column(c)) for c in range(71)], dtype=torch.int64)
 
     @staticmethod
     def pack_bf16(jobs):

@@ -142,6 +142,18 @@ _BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 red
 # 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
 # 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
 TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") != "0"
+# forward pass of the training trunk: "wave" = csrc/trunk_mlp2.hip (wave-tile form: builds its own input rows from x / features / dy_dx,
+# register-resident activations; d_out <= 32), "tile" = k_trunk_fwd of csrc/sdf_mlp.hip fed by k_trunk_input_fwd
+TRUNK_FWD_IMPL = os.environ.get("HOLOSCENE_TRUNK_FWD_IMPL", "wave")
+_XP_COLUMNS = {}
+
+
+def _xp_columns(dev):
+    """Position in the wave-tile kernel's 80-column input image of each of the 71 reference input columns (device int64)."""
+    key = str(dev)
+    if key not in _XP_COLUMNS:
+        _XP_COLUMNS[key] = _be._backend.trunk_mlp2_columns().to(dev)
+    return _XP_COLUMNS[key]
 
 
 def _wgrad_rows(g, x):
@@ -186,24 +198,34 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     dydx = torch.empty(L, B, D * C, device=dev, dtype=x.dtype)
     _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
     jac_scale = 0.5 / divide_factor
-    X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
-    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L * C == 32 and D == 3   # k_trunk_fwd assembles its input rows itself
-    if not build_in_kernel:
-        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
     F_in, d_out = W0.shape[1], W2.shape[0]
     KP = 32 * ((d_out + 31) // 32)
-    w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
-                  torch.empty(KP, 256, device=dev, dtype=bf))
-    w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
-    w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
-    f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
-                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
     M = 4 * B
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
     Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
     bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
+    w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
+    w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
+    f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
+    if TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L * C == 32 and D == 3 and F_in == 71:
+        # wave-tile forward (csrc/trunk_mlp2.hip): fragment-order operands, input rows assembled in the kernel and kept as Xp [M,80]
+        _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
+        packed = _be._backend.sdf_mlp2_pack(f0, bb[0], f1, bb[1], f2, bb[2], d_out, log2_domain=False)
+        Xp = torch.empty(M, 80, device=dev, dtype=bf)
+        _be._backend.trunk_mlp2_fwd(x.float(), feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale)
+        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
+        return Y, (x01, embeddings, offsets, Xp, H0, H1, w0t, w1t, w2t)
+    if TRUNK_FWD_IMPL not in ("wave", "tile"):
+        raise RuntimeError(f"unknown HOLOSCENE_TRUNK_FWD_IMPL={TRUNK_FWD_IMPL!r}")
+    X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
+    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L * C == 32 and D == 3   # k_trunk_fwd assembles its input rows itself
+    if not build_in_kernel:
+        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
+    w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
+                  torch.empty(KP, 256, device=dev, dtype=bf))
+    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
+                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
     if build_in_kernel:
         _be._backend.trunk_mlp_fwd(None, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y, x.float(), feat, dydx, X, L, C, jac_scale)
     else:
@@ -246,11 +268,13 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
                              ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
     gW2 = gW1 = gW0 = None
     if need_w:
+        Xm = X.view(M, X.shape[-1])       # [M, 96] reference column order, or the wave-tile kernel's [M, 80] image in its own order
         if w2_part is not None:
-            gW1, gW0, gW2 = _wgrad_rows_many([(gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))], ready_parts=[w2_part])
+            gW1, gW0, gW2 = _wgrad_rows_many([(gA1, H0), (gA0, Xm)], ready_parts=[w2_part])
         else:
-            gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, X.view(M, _TRUNK_PITCH))])
-        gW2, gW0 = gW2[:d_out], gW0[:, :F_in]
+            gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, Xm)])
+        gW2 = gW2[:d_out]
+        gW0 = gW0[:, :F_in] if Xm.shape[1] == _TRUNK_PITCH else gW0.index_select(1, _xp_columns(dev))
     return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
 
 

@@ -297,7 +297,17 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
  * one linear copy).  Arguments of hs_sdf_mlp2_fwd as hs_sdf_mlp_fwd. */
 int64_t hs_sdf_mlp2_pack_bytes(int32_t which);
 int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
-                     void *W0f, void *W1f, void *W2f, float *bias, void *stream);
+                     void *W0f, void *W1f, void *W2f, float *bias, int32_t log2_domain /* 1: hs_sdf_mlp2_fwd; 0: hs_trunk_mlp2_fwd */, void *stream);
+
+/* Training form of the wave-tile kernel (csrc/trunk_mlp2.hip; d_out <= 32, L*C = 32, 6 encoding octaves): the value+Jacobian trunk pass of
+ * hs_trunk_mlp_fwd below, same rows (4 per point: value, d/dx, d/dy, d/dz) and the same saved tensors for hs_trunk_mlp_bwd -- H0, H1
+ * [M,256] bf16 row-major layer OUTPUTS, Y [M,d_out] f32 -- built straight from x [M/4,3], feat [M/4,32] (point-major) and dydx [L,M/4,3C]
+ * (level-major, as hs_hash_fwd writes them), with the input rows it assembled stored as Xp [M,80] bf16 in the kernel's own column order
+ * (hs_trunk_mlp2_input_column(c) = position of reference input column c, for un-permuting the first layer's weight gradient).
+ * Operands: hs_sdf_mlp2_pack(..., log2_domain = 0). */
+int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
+int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, void *stream);
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);
