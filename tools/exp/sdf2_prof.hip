@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
     hipMemcpy(W0, h.data(), 256 * 71 * 4, hipMemcpyHostToDevice); hipMemcpy(W1, h.data(), 256 * 256 * 4, hipMemcpyHostToDevice);
     hipMemcpy(W2, h.data(), 32 * 256 * 4, hipMemcpyHostToDevice); hipMemcpy(b, h.data(), 1024 * 4, hipMemcpyHostToDevice);
     void *W2f = (char *)W12f + hs_sdf_mlp2_pack_bytes(1);
-    printf("pack rc %d\n", hs_sdf_mlp2_pack(W0, 71, b, W1, b + 256, W2, b + 512, 32, W0f, W12f, W2f, bias, nullptr));
+    printf("pack rc %d\n", hs_sdf_mlp2_pack(W0, 71, b, W1, b + 256, W2, b + 512, 32, W0f, W12f, W2f, bias, 1, nullptr));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int r = 0; r < 3; r++) hs_sdf_mlp2_fwd(x, feat, W0f, W12f, W2f, bias, 32, -1, 0, out, nullptr, B, nullptr, 1, nullptr);
     hipDeviceSynchronize();
