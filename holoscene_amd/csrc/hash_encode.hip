@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -217,6 +219,68 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
             }
 #pragma unroll
             for (int c = 0; c < C; c++) j[gd * C + c] = ga[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward, two lanes per point
+// The value-only sweep (D = 3) with the two x-corners of a cell on NEIGHBOURING LANES.  The gather's cost is the L1's tag rate -- one
+// 128-byte line per clock and CU: 16.8 M corner reads of a 131 072-point sweep over 256 CUs are 33 us of lookups, the kernel took
+// 40-49 -- and with one point per lane every corner is its own instruction, so the x-neighbour's line (the same one for 15 of 16 cells,
+// hashed levels included: x and x + 1 differ in their low bits only, the hash XORs them into the low index bits) is looked up again.
+// With lanes (2p, 2p + 1) = corners (x, x + 1) of point p one gather instruction covers 32 points x 2 corners and touches ~half the
+// lines.  The sum keeps the reference's order (corner 0, 1, ..., 7: the x bit alternates): lane 2p adds its own product, then its
+// neighbour's through a DPP operand, so the result stays bit-exact with the one-lane kernel.
+template <int C>
+__global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restrict__ x, const float *__restrict__ emb,
+                                                             const int32_t *__restrict__ offsets, float *__restrict__ out, uint32_t B,
+                                                             uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
+    constexpr int D = 3;
+    uint32_t level, chunk;
+    if (lay.gate.a != nullptr && !(*lay.gate.a > *lay.gate.b)) return;
+    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    const uint32_t t = chunk * kThreads + threadIdx.x, b = t >> 1, xb = t & 1u;
+    if (b >= B) return;                      // both lanes of a pair leave together
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    const float *__restrict__ grid = emb + (size_t)li.offset * C;
+    float *o = out + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+    uint32_t g[D];
+    float w[D], dw[D];
+    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
+        if (xb == 0) {
+#pragma unroll
+            for (int c = 0; c < C; c++) o[c] = 0.f;
+        }
+        return;
+    }
+    Vec<C> e[4];
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) {
+        const uint32_t gl[D] = {g[0] + xb, g[1] + (yz & 1), g[2] + (yz >> 1)};
+        e[yz] = load_entry<C>(grid + (size_t)cell_index<D>(li, gl) * C);
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0.f;
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) {
+        float wt = 1.f;
+        wt *= xb ? w[0] : 1 - w[0];
+        wt *= (yz & 1) ? w[1] : 1 - w[1];
+        wt *= (yz >> 1) ? w[2] : 1 - w[2];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float p = wt * e[yz].v[c];
+            acc[c] += p;                                                                                     // corner (0, yz) on the even lane
+            acc[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, true));   // corner (1, yz): quad_perm [1,0,3,2]
+        }
+    }
+    if (xb == 0) {
+        if constexpr (C == 2) {
+            *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) o[c] = acc[c];
         }
     }
 }
@@ -649,6 +713,12 @@ void dispatch_dc(uint32_t D, uint32_t C, F &&f) {
     else with_c(Int<2>{});
 }
 
+// HOLOSCENE_HASH_FWD=point selects the one-lane-per-point value kernel (the A/B switch of k_hash_fwd_pair)
+bool pair_forward() {
+    static const bool v = [] { const char *e = getenv("HOLOSCENE_HASH_FWD"); return !(e && strcmp(e, "point") == 0); }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -668,7 +738,10 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
         constexpr int D_ = decltype(d)::value, C_ = decltype(c)::value;
         if (dy_dx)
             k_hash_fwd<D_, C_, true><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
-        else
+        else if (D_ == 3 && pair_forward()) {
+            const uint32_t n_chunks2 = (2 * B + kThreads - 1) / kThreads;      // two lanes per point
+            k_hash_fwd_pair<C_><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, B, L, sc, lay, n_chunks2);
+        } else
             k_hash_fwd<D_, C_, false><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
     });
     return check_launch();
