@@ -18,8 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "holoscene_hip.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -27,26 +29,10 @@ __device__ __forceinline__ bool gate_closed(const hsGate &g) { return g.a != nul
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const float t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+// wave-level scans and reductions on DPP operands (wave_ops.h)
+__device__ __forceinline__ float wave_incl_scan(float v, int) { return hs_wave::incl_scan(v); }
+__device__ __forceinline__ float wave_max(float v) { return hs_wave::max(v); }
+__device__ __forceinline__ float wave_sum(float v) { return hs_wave::sum(v); }
 
 // Laplace density sigma(s; beta) (model/density.py:21-26)
 __device__ __forceinline__ float laplace_sigma(float s, float beta) {
@@ -74,8 +60,7 @@ __device__ __forceinline__ void lane_chunk(int n, int lane, int &lo, int &hi) {
 
 // ---- workgroup-wide (kUpd threads = 4 waves per ray) scan / max for the beta line search.  One wave per ray left the
 // chip at one wave per SIMD with every lane walking ~10 sections serially through libm exp/expm1: 100 us at 640 sections.
-constexpr int kUpd = 256;
-constexpr int kUpdWaves = kUpd / kWave;
+constexpr int kUpd = 256;       // default threads per ray; HOLOSCENE_SAMPLER_UPDATE_THREADS = 64 | 128 | 256 (A/B switch)
 
 __device__ __forceinline__ void chunk_of(int n, int tid, int nthreads, int &lo, int &hi) {
     const int ch = (n + nthreads - 1) / nthreads;
@@ -84,19 +69,26 @@ __device__ __forceinline__ void chunk_of(int n, int tid, int nthreads, int &lo, 
 }
 
 // exclusive prefix sums of (a, b) over the workgroup's threads; sc: 2*kUpdWaves floats
+template <int NT>
 __device__ __forceinline__ void block_excl_scan2(float &a, float &b, float *sc, int tid) {
+    constexpr int kUpdWaves = NT / kWave;
     const int lane = tid & 63, w = tid >> 6;
     const float ai = wave_incl_scan(a, lane), bi = wave_incl_scan(b, lane);
-    if (lane == 63) { sc[w] = ai; sc[kUpdWaves + w] = bi; }
-    __syncthreads();
     float pa = 0.f, pb = 0.f;
-    for (int j = 0; j < w; j++) { pa += sc[j]; pb += sc[kUpdWaves + j]; }
+    if constexpr (kUpdWaves > 1) {
+        if (lane == 63) { sc[w] = ai; sc[kUpdWaves + w] = bi; }
+        __syncthreads();
+        for (int j = 0; j < w; j++) { pa += sc[j]; pb += sc[kUpdWaves + j]; }
+    }
     a = pa + (ai - a);
     b = pb + (bi - b);
 }
 
+template <int NT>
 __device__ __forceinline__ float block_max(float v, float *sc, int tid) {   // sc: kUpdWaves floats, distinct from the scan's
+    constexpr int kUpdWaves = NT / kWave;
     v = wave_max(v);
+    if constexpr (kUpdWaves == 1) return v;
     if ((tid & 63) == 0) sc[tid >> 6] = v;
     __syncthreads();
     float r = sc[0];
@@ -107,10 +99,11 @@ __device__ __forceinline__ float block_max(float v, float *sc, int tid) {   // s
 
 // max_i (min(exp(E_i), 1e6) - 1) * exp(-F_i), E inclusive cumsum of err terms, F exclusive cumsum of free energy
 // (ray_sampler.py:450-458).  sdf[0..n], dists/dstar[0..n); fe/ee: per-section scratch (each thread touches only its chunk)
+template <int NT>
 __device__ float error_bound(const float *__restrict__ sdf, const float *__restrict__ dists, const float *__restrict__ dstar,
                              float *__restrict__ fe, float *__restrict__ ee, int n, float beta, int tid, float *sc) {
     int lo, hi;
-    chunk_of(n, tid, kUpd, lo, hi);
+    chunk_of(n, tid, NT, lo, hi);
     // The kernel is instruction-issue-bound (1 024 rays x 4 waves x 11 evaluations of this function): the four IEEE divisions per
     // section of the textbook form (|s| / beta, d* / beta, 1 / beta, 1 / (4 beta^2); ~10 instructions each) become multiplications by
     // ONE reciprocal per evaluation.  That moves the bound by <= 1 ulp per factor -- the same order as the hardware exponentials
@@ -127,7 +120,7 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
         fsum += f_i; esum += e_i;
     }
     float f = fsum, e = esum;
-    block_excl_scan2(f, e, sc, tid);
+    block_excl_scan2<NT>(f, e, sc, tid);
     float best = -INFINITY;
     for (int i = lo; i < hi; i++) {
         e += ee[i];
@@ -135,7 +128,7 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
         best = fmaxf(best, b);
         f += fe[i];
     }
-    return block_max(best, sc + 2 * kUpdWaves, tid);
+    return block_max<NT>(best, sc + 2 * (NT / kWave), tid);
 }
 
 __device__ __forceinline__ int lower_bound(const float *a, int n, float v) {  // # elements < v
@@ -161,6 +154,7 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
 }
 
 // ------------------------------------------------------------------------------------ update
+template <int kUpd>
 __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
                                                            const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
                                                            float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
@@ -207,14 +201,14 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     __syncthreads();
     const float beta0 = *beta0_p;
     float hi = beta_io[r];
-    if (error_bound(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
+    if (error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
     float lo = beta0;
     // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
     // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
     if (hi != lo)
     for (int it = 0; it < beta_iters; it++) {
         const float mid = (lo + hi) / 2.f;
-        const float err = error_bound(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
+        const float err = error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
         if (err <= eps) hi = mid;
         else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
     }
@@ -508,8 +502,14 @@ int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const flo
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_dev ? ld : m_old + s_new;   // device-side count: size the scratch for the row capacity
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
-    k_sampler_update<<<dim3(R), dim3(kUpd), (6 * m + 3 * kUpdWaves) * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0,
-                                                                                           eps, beta_iters, beta_max, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev);
+    static const int nt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_THREADS"); const int v = e ? atoi(e) : kUpd; return v == 64 || v == 128 || v == 512 ? v : 256; }();
+    const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
+    const size_t lds = (6 * m + 3 * 8) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
+    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
+    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
+    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
     return check_launch();
 }
 
