@@ -50,22 +50,25 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // one v_cvt_
 constexpr int kChunkTPR = kThreads / HID;            // threads per weight row: 2 (512 threads) or 1 (256 threads)
 template <int KCH> struct ChunkRegs { uint4 v[KCH / 8 / kChunkTPR]; };
 
-template <int KCH>
+// NR < HID: only the first NR rows are streamed (the rest of the matrix is padding nobody multiplies by; their LDS rows keep stale data)
+template <int KCH, int NR = HID>
 __device__ __forceinline__ ChunkRegs<KCH> load_chunk(const uint16_t *__restrict__ W, int ldw, int k0) {
     ChunkRegs<KCH> r;
     constexpr int NV = KCH / 8 / kChunkTPR;
     const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
     const uint16_t *src = W + (size_t)row * ldw + k0 + part * (8 * NV);
+    if (NR < HID && row >= NR) return r;
 #pragma unroll
     for (int i = 0; i < NV; i++) r.v[i] = *reinterpret_cast<const uint4 *>(src + 8 * i);
     return r;
 }
 
-template <int KCH>
+template <int KCH, int NR = HID>
 __device__ __forceinline__ void store_chunk(uint16_t *Wc, const ChunkRegs<KCH> &r) {
     constexpr int NV = KCH / 8 / kChunkTPR;
     const int row = threadIdx.x / kChunkTPR, part = threadIdx.x % kChunkTPR;
     uint16_t *dst = Wc + (size_t)row * (KCH + 8) + part * (8 * NV);
+    if (NR < HID && row >= NR) return;
 #pragma unroll
     for (int i = 0; i < NV; i++) *reinterpret_cast<uint4 *>(dst + 8 * i) = r.v[i];
 }
@@ -90,17 +93,17 @@ __device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *
 
 // One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KCH.  wave -> neurons [nq*64,+64), points [ph*64,+64)
 // compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
-template <int AP = HP, int KCH = KC>
+template <int AP = HP, int KCH = KC, int NR = HID>
 __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
                                           int nq, int ph, int lane, bool compute = true) {
     constexpr int KS = KCH / 16;
     const int nchunks = K / KCH;
-    ChunkRegs<KCH> pre = load_chunk<KCH>(W, ldw, 0);
-    store_chunk<KCH>(Wc, pre);
+    ChunkRegs<KCH> pre = load_chunk<KCH, NR>(W, ldw, 0);
+    store_chunk<KCH, NR>(Wc, pre);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
 #ifndef HS_EXP_NO_WLOAD
-        if (c + 1 < nchunks) pre = load_chunk<KCH>(W, ldw, (c + 1) * KCH);
+        if (c + 1 < nchunks) pre = load_chunk<KCH, NR>(W, ldw, (c + 1) * KCH);
 #endif
 #ifndef HS_EXP_NO_MMA
         if (compute) {
@@ -117,7 +120,7 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
             }
         }
 #endif
-        if (c + 1 < nchunks) store_chunk<KCH>(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
+        if (c + 1 < nchunks) store_chunk<KCH, NR>(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
         __syncthreads();
     }
 }

@@ -385,22 +385,94 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
 // The library path needs 2 GEMM launches + 2 elementwise launches and moves 2.2 GB for this (DESIGN); here every
 // operand is read once and every result written once (0.9 GB).  Weight operands arrive TRANSPOSED ([in][out] row-major),
 // so the same D = W . H^T machinery applies.  The value-row rule  gA_v = s*g_v + 100(1-s) * sum_d H_d*g_d  needs the three
-// tangent lanes of the quad: two DPP quad_perm adds.
-__device__ __forceinline__ float bwd_act(float G, float h, bool is_value) {
-#ifdef HS_EXP_NO_EPILOGUE
-    return G + h;
-#endif
-    const float e = __builtin_amdgcn_exp2f(h * (-100.f * 1.44269504f));   // value lanes: 1 - sigmoid(100 v), from h = softplus100(v)
-    const float s = quad_bcast0(1.f - e), c = quad_bcast0(100.f * e);
-    const float prod = is_value ? 0.f : h * G;
-    const float d1 = prod + dpp_quad<0xB1>(prod);     // quad_perm [1,0,3,2]
-    const float dot = d1 + dpp_quad<0x4E>(d1);        // quad_perm [2,3,0,1]
-    return is_value ? s * G + c * dot : s * G;
+// tangent lanes of the quad.
+//
+// Four consecutive neurons of one row (the lane's 8-byte cell of the tile): G = cotangents of the layer OUTPUTS, hv = the four outputs
+// (bf16), result = cotangents of the pre-activations.  Lane j of the quad evaluates the value row's neuron j ONCE (1 - sigmoid and its
+// slope from h = softplus100(v): one exponential per four elements instead of one per element on every lane of the quad), and the
+// cross-lane reads are folded into the consuming multiply / add as DPP operands (hand-written: the compiler emits v_mov_dpp + the
+// arithmetic separately; see trunk_mlp2.hip's forward epilogue).  9.7 k -> 6.5 k cycles per layer and 128-row tile (tools/exp/tbwd_prof.hip).
+// LDS byte address of a pointer into the dynamic shared segment, and an 8-row MFMA fragment (rows r0..r0+7 of the lane's column) by two
+// transposing reads `step` bytes (4 rows) apart
+__device__ __forceinline__ uint32_t lds_addr_of(const uint16_t *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t *)p; }
+__device__ __forceinline__ bf16x8 tr_frag(uint32_t addr, uint32_t step) {
+    uint2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+                 "ds_read_b64_tr_b16 %1, %3\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "v"(addr + step)
+                 : "memory");
+    const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+    return *reinterpret_cast<const bf16x8 *>(w);
 }
+
+struct BwdMasks { uint64_t n1, n2, n3; };      // lanes whose index in the quad is NOT 1 / 2 / 3 (wave masks in SGPR pairs)
+__device__ __forceinline__ BwdMasks bwd_masks() {
+    BwdMasks m = {0xddddddddddddddddull, 0xbbbbbbbbbbbbbbbbull, 0x7777777777777777ull};
+    asm volatile("" : "+s"(m.n1), "+s"(m.n2), "+s"(m.n3));
+    return m;
+}
+#define HS_DPPQ(k) " quad_perm:[" #k "," #k "," #k "," #k "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void bwd_act4(const float G[4], uint2 hv, const BwdMasks &m, bool is_value, float out[4]) {
+    const float h[4] = {__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xffff0000u), __uint_as_float(hv.y << 16), __uint_as_float(hv.y & 0xffff0000u)};
+#ifdef HS_EXP_NO_EPILOGUE
+    for (int k = 0; k < 4; k++) out[k] = G[k] + h[k];
+    return;
+#endif
+    // lane j takes the value lane's h[j] (first read compiler-visible: it covers the hazards of a freshly written source)
+    float hj = dpp_quad<0x00>(h[0]);
+    asm("s_mov_b64 vcc, %4\n\t"
+        "v_cndmask_b32_dpp %0, %1, %0, vcc" HS_DPPQ(0)
+        "s_mov_b64 vcc, %5\n\t"
+        "v_cndmask_b32_dpp %0, %2, %0, vcc" HS_DPPQ(0)
+        "s_mov_b64 vcc, %6\n\t"
+        "v_cndmask_b32_dpp %0, %3, %0, vcc" HS_DPPQ(0)
+        : "+v"(hj)
+        : "v"(h[1]), "v"(h[2]), "v"(h[3]), "s"(m.n1), "s"(m.n2), "s"(m.n3)
+        : "vcc");
+    const float e = __builtin_amdgcn_exp2f(hj * (-100.f * 1.44269504f));      // 1 - sigmoid(100 v) from h = softplus100(v)
+    const float sj = 1.f - e, cj = 100.f * e;
+    float p[4], dot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = h[k] * G[k];
+    // dot_k = sum over the three tangent lanes of h_k * G_k (every lane of the quad gets it; only the value lane uses it)
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %4" HS_DPPQ(1)
+        "v_mov_b32_dpp %1, %5" HS_DPPQ(1)
+        "v_mov_b32_dpp %2, %6" HS_DPPQ(1)
+        "v_mov_b32_dpp %3, %7" HS_DPPQ(1)
+        "v_add_f32_dpp %0, %4, %0" HS_DPPQ(2)
+        "v_add_f32_dpp %1, %5, %1" HS_DPPQ(2)
+        "v_add_f32_dpp %2, %6, %2" HS_DPPQ(2)
+        "v_add_f32_dpp %3, %7, %3" HS_DPPQ(2)
+        "v_add_f32_dpp %0, %4, %0" HS_DPPQ(3)
+        "v_add_f32_dpp %1, %5, %1" HS_DPPQ(3)
+        "v_add_f32_dpp %2, %6, %2" HS_DPPQ(3)
+        "v_add_f32_dpp %3, %7, %3" HS_DPPQ(3)
+        : "=&v"(dot[0]), "=&v"(dot[1]), "=&v"(dot[2]), "=&v"(dot[3])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) dot[k] = is_value ? dot[k] : 0.f;
+    // out_k = s_k G_k (+ c_k dot_k on the value lane), s_k / c_k from lane k
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %4, %6" HS_DPPQ(0)
+        "v_mul_f32_dpp %1, %4, %7" HS_DPPQ(1)
+        "v_mul_f32_dpp %2, %4, %8" HS_DPPQ(2)
+        "v_mul_f32_dpp %3, %4, %9" HS_DPPQ(3)
+        "v_fmac_f32_dpp %0, %5, %10" HS_DPPQ(0)
+        "v_fmac_f32_dpp %1, %5, %11" HS_DPPQ(1)
+        "v_fmac_f32_dpp %2, %5, %12" HS_DPPQ(2)
+        "v_fmac_f32_dpp %3, %5, %13" HS_DPPQ(3)
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+        : "v"(sj), "v"(cj), "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(dot[0]), "v"(dot[1]), "v"(dot[2]), "v"(dot[3]));
+}
+#undef HS_DPPQ
 
 // H holds the layer-output tile on entry and the pre-activation cotangent tile on exit (same element, same lane: in place)
 __device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
     const bool is_value = (lane & 3) == 0;
+    const BwdMasks bm = bwd_masks();
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
@@ -410,19 +482,24 @@ __device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int 
             for (int pt = 0; pt < 2; pt++) {
                 const int p = ph * 64 + pt * 32 + (lane & 31);
                 uint2 *cell = reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0);
-                const uint2 hv = *cell;
-                const float v0 = bwd_act(acc[nt][pt][q * 4 + 0], __uint_as_float(hv.x << 16), is_value);
-                const float v1 = bwd_act(acc[nt][pt][q * 4 + 1], __uint_as_float(hv.x & 0xffff0000u), is_value);
-                const float v2 = bwd_act(acc[nt][pt][q * 4 + 2], __uint_as_float(hv.y << 16), is_value);
-                const float v3 = bwd_act(acc[nt][pt][q * 4 + 3], __uint_as_float(hv.y & 0xffff0000u), is_value);
+                const float G[4] = {acc[nt][pt][q * 4 + 0], acc[nt][pt][q * 4 + 1], acc[nt][pt][q * 4 + 2], acc[nt][pt][q * 4 + 3]};
+                float v[4];
+                bwd_act4(G, *cell, bm, is_value, v);
                 uint2 pk;
-                pk.x = pack_bf16(v0, v1);
-                pk.y = pack_bf16(v2, v3);
+                pk.x = pack_bf16(v[0], v[1]);
+                pk.y = pack_bf16(v[2], v[3]);
                 *cell = pk;
             }
         }
     }
 }
+
+#ifdef HS_TBWD_PROFILE     // tools/exp/tbwd_prof.hip: s_memtime stamps of the phases of one tile (the third of every workgroup)
+__device__ unsigned long long g_tbwd_prof[256 * 16];
+#define HS_BSTAMP(i) do { if (threadIdx.x == 0 && tile == (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x) g_tbwd_prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HS_BSTAMP(i) do { } while (0)
+#endif
 
 template <int KP>  // padded d_out: 32 or 64
 __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restrict__ g, const uint16_t *__restrict__ H1, const uint16_t *__restrict__ H0,
@@ -449,8 +526,13 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
 #pragma unroll
         for (int i = 0; i < 16; i++) accW[mt][i] = 0.f;
     const int64_t ntiles = (M + BM - 1) / BM;
+    // The layer-output tiles (64 KB each) are requested early: H1 of the NEXT tile under this tile's input-cotangent phase, H0 right after
+    // the K = 32 product.  Requested where they are consumed, the two-k-step product G1 = g.W2 spent 8-9 k of a tile's 61 k cycles
+    // waiting for H1 (tools/exp/tbwd_prof.hip); early, the tile takes 54.6 k (395-405 -> 381 us per launch on one box).
+    TileRegs hr1 = load_tile_regs(H1, (int64_t)blockIdx.x * BM, M);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
+        HS_BSTAMP(0);
         const int64_t r0 = tile * BM;
         for (int idx = threadIdx.x; idx < BM * (KP / 8); idx += kThreads) {
             const int row = idx / (KP / 8), seg = idx - row * (KP / 8);
@@ -465,50 +547,61 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             for (int r = 4 * rg; r < BM; r += 4 * (kThreads / KP)) sum2 += __uint_as_float((uint32_t)H[(size_t)r * HP + col] << 16);
         }
         f32x16 acc[2][2];
-        TileRegs hr = load_tile_regs(H1, r0, M);   // in flight under the matrix product
+        HS_BSTAMP(1);
         zero_acc(acc);
         layer_mma<HP, 32>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
-        store_tile_regs(H, hr);
+        store_tile_regs(H, hr1);
+        TileRegs hr = load_tile_regs(H0, r0, M);    // in flight under the epilogue, the gA1 store and the 256-deep product
         __syncthreads();
+        HS_BSTAMP(2);
         if (dW2_part) {   // H = H1 tile, Gs = g tile: accW[kout][col] += sum_rows g[row][kout] * H1[row][col], this wave's 32 columns
-            const uint16_t *hcol = H + wave * 32 + (lane & 31);
+            // Both operands run along the ROWS of row-major tiles.  gfx950's transposing LDS read does that gather: in every group of 16
+            // lanes, lane L passes the address of 4 consecutive bf16 and lane i receives element i & 3 of the slots of lanes (i >> 2) + 4 j,
+            // j = 0..3 (tools/exp/tr_b16_sem.hip) -- with lane L pointing at tile[r0 + (L >> 2)][c0 + 4 (L & 3)], lane i gets rows
+            // r0..r0+3 of column c0 + i.  Two reads per 8-row fragment instead of eight 2-byte reads and seven shifts / ors
+            // (this phase: 4.9 k -> see tools/exp/tbwd_prof.hip).
+            const int L16 = lane & 15, cg = (lane >> 4) & 1;
+            const uint32_t hb = lds_addr_of(H + (size_t)((lane >> 5) * 8 + (L16 >> 2)) * HP + wave * 32 + 16 * cg + 4 * (L16 & 3));
+            const uint32_t gb_ = lds_addr_of(Gs + (size_t)((lane >> 5) * 8 + (L16 >> 2)) * GP + 16 * cg + 4 * (L16 & 3));
 #pragma unroll 2
             for (int ks = 0; ks < BM / 16; ks++) {
-                const int rb = ks * 16 + (lane >> 5) * 8;
-                uint32_t bw[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) bw[j] = (uint32_t)hcol[(size_t)(rb + 2 * j) * HP] | ((uint32_t)hcol[(size_t)(rb + 2 * j + 1) * HP] << 16);
-                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(bw);
+                const bf16x8 bfrag = tr_frag(hb + (uint32_t)(ks * 16 * HP * 2), 4 * HP * 2);
 #pragma unroll
                 for (int mt = 0; mt < KP / 32; mt++) {
-                    const uint16_t *gcol = Gs + mt * 32 + (lane & 31);
-                    uint32_t aw[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) aw[j] = (uint32_t)gcol[(size_t)(rb + 2 * j) * GP] | ((uint32_t)gcol[(size_t)(rb + 2 * j + 1) * GP] << 16);
-                    accW[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(aw), bfrag, accW[mt], 0, 0, 0);
+                    const bf16x8 afrag = tr_frag(gb_ + (uint32_t)((ks * 16 * GP + mt * 32) * 2), 4 * GP * 2);
+                    accW[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, accW[mt], 0, 0, 0);
                 }
             }
             __syncthreads();   // the epilogue below rewrites H in place
         }
+        HS_BSTAMP(3);
         epilogue_bwd(H, acc, nq, ph, lane);
         __syncthreads();
+        HS_BSTAMP(4);
         store_tile(H, gA1, r0, M);
         sum1 += tile_colsum<4>(H);
-        hr = load_tile_regs(H0, r0, M);
+        HS_BSTAMP(5);
         zero_acc(acc);
         layer_mma(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
         __syncthreads();
+        HS_BSTAMP(6);
         epilogue_bwd(H, acc, nq, ph, lane);
         __syncthreads();
+        HS_BSTAMP(7);
         store_tile(H, gA0, r0, M);
         sum0 += tile_colsum<4>(H);
+        HS_BSTAMP(8);
+        if (tile + gridDim.x < ntiles) hr1 = load_tile_regs(H1, (tile + gridDim.x) * BM, M);
         if (W0t) {
             // ---- cotangent of the trunk input: gX = gA0 . W0 (K0 = 96 columns; W0t = W0^T zero-padded to 256 rows).  Only the
             //      waves owning neurons < 96 multiply; the others keep streaming weight chunks.  Saves the library GEMM's
             //      second read of gA0 (214 MB at M = 417 792).
             zero_acc(acc);
-            layer_mma(W0t, HID, HID, H, Wc, acc, nq, ph, lane, nq < 2);
+            // rows >= 128 of W0^T are padding and are not streamed.  (Staging the live 128 x 256 part in ONE round -- it fits the two chunk
+            // buffers -- instead of four 64-deep ones was slower: 9.5 k vs 6.6 k cycles, the whole load latency exposed at once.)
+            layer_mma<HP, KC, 128>(W0t, HID, HID, H, Wc, acc, nq, ph, lane, nq < 2);
+            HS_BSTAMP(10);
             if (nq < 2) {
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
@@ -528,10 +621,24 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                 }
             }
             __syncthreads();
+            HS_BSTAMP(11);
             // the hash-feature columns of that tile ARE the cotangents the table scatter consumes (hs_trunk_input_bwd's slicing):
             // value rows -> g_feat [L, B, C] (level-major); tangent row d -> g_dydx [L, B, 3*C] scaled by d(x01)/dx.  Coalesced fp32 runs.
             const int64_t Bp = M >> 2, pb = r0 >> 2;     // points in total / first point of this tile (BM/4 points per tile)
             const int LC = L * C;
+            if (C == 2) {       // the stock grid: every divisor below a compile-time constant (the generic loops spend 7 k cycles per tile
+                                // in integer divisions by (BM / 4) * C and 3 * C -- as much as the product itself, tools/exp/tbwd_prof.hip)
+                constexpr int P = BM / 4;
+                for (int idx = threadIdx.x; idx < P * NFEAT; idx += kThreads) {          // [L, B, 2]: 2 P floats per level
+                    const int l = idx / (2 * P), rem = idx % (2 * P), pt = rem >> 1, c = rem & 1;
+                    if (pb + pt < Bp) g_feat[((size_t)l * Bp + pb + pt) * 2 + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * 2 + c] << 16);
+                }
+                for (int idx = threadIdx.x; idx < (NFEAT / 2) * P * 6; idx += kThreads) {  // [L, B, 3, 2]: 6 P floats per level
+                    const int l = idx / (6 * P), rem = idx % (6 * P), pt = rem / 6, dc = rem % 6, d = dc >> 1, c = dc & 1;
+                    if (pb + pt < Bp)
+                        g_dydx[((size_t)l * Bp + pb + pt) * 6 + dc] = jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * 2 + c] << 16);
+                }
+            } else {
             for (int idx = threadIdx.x; idx < (BM / 4) * LC; idx += kThreads) {   // level-major [L, B, C]
                 const int l = idx / ((BM / 4) * C), rem = idx - l * ((BM / 4) * C), pt = rem / C, c = rem - pt * C;
                 if (pb + pt < Bp)
@@ -544,8 +651,10 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                     g_dydx[((size_t)l * Bp + pb + pt) * (3 * C) + dc] =
                         jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * C + c] << 16);
             }
+            }
         }
         __syncthreads();
+        HS_BSTAMP(9);
     }
     if (dW2_part) {   // this workgroup's slice [KP][256]; lane: column wave*32 + (lane & 31), outputs (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
         float *dst = dW2_part + (size_t)blockIdx.x * KP * HID + wave * 32 + (lane & 31);
