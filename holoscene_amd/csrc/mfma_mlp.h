@@ -91,10 +91,9 @@ __device__ __forceinline__ Frags load_frags(const uint16_t *Wc, const uint16_t *
     return f;
 }
 
-// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KCH.  wave -> neurons [nq*64,+64), points [ph*64,+64)
-// compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
-template <int AP = HP, int KCH = KC, int NR = HID>
-__device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
+// (the one-chunk-ahead form of layer_mma below, kept verbatim for the kernel that has no registers for a second chunk set)
+template <int AP, int KCH, int NR>
+__device__ __forceinline__ void layer_mma_shallow(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
                                           int nq, int ph, int lane, bool compute = true) {
     constexpr int KS = KCH / 16;
     const int nchunks = K / KCH;
@@ -121,6 +120,55 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
         }
 #endif
         if (c + 1 < nchunks) store_chunk<KCH, NR>(Wc + (size_t)((c + 1) & 1) * HID * WP, pre);
+        __syncthreads();
+    }
+}
+
+// One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KCH.  wave -> neurons [nq*64,+64), points [ph*64,+64)
+// compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
+template <int AP = HP, int KCH = KC, int NR = HID, bool DEEP = true>
+__device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
+                                          int nq, int ph, int lane, bool compute = true) {
+    if constexpr (!DEEP) { layer_mma_shallow<AP, KCH, NR>(W, ldw, K, H, Wc, acc, nq, ph, lane, compute); return; }
+    constexpr int KS = KCH / 16;
+    const int nchunks = K / KCH;
+    // Weight chunks travel TWO rounds ahead of their use (two register sets, chunk k in set k & 1): a round is as long as the L2
+    // latency of the chunk it waits for (~2.5 k cycles on the loaded chip against 0.5 k of MFMA per 64-deep chunk), so with one chunk
+    // in flight a 256-deep layer costs four latencies (tools/exp/tbwd_prof.hip: 10 k cycles for 2 k of MFMA).
+    //   round c:  request chunk c + 2 (its set held chunk c, stored to LDS a round ago) | MFMAs of chunk c from buffer c & 1 |
+    //             store chunk c + 1 (requested a round ago) to buffer (c + 1) & 1 -- last read in round c - 1, before its barrier | barrier
+    // (two named register sets and the loop unrolled by hand in pairs: indexed as pre[c & 1] the sets live in scratch memory)
+    auto compute_chunk = [&](int c) {
+#ifndef HS_EXP_NO_MMA
+        if (compute) {
+            Frags f[2];
+            f[0] = load_frags<AP, KCH>(Wc, H, c * KS, nq, ph, lane);
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+                if (kk + 1 < KS) f[(kk + 1) & 1] = load_frags<AP, KCH>(Wc, H, c * KS + kk + 1, nq, ph, lane);   // in flight under this step's MFMAs
+                const Frags &g = f[kk & 1];
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int pt = 0; pt < 2; pt++) acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.a[nt], g.b[pt], acc[nt][pt], 0, 0, 0);
+            }
+        }
+#endif
+    };
+    uint16_t *buf0 = Wc, *buf1 = Wc + (size_t)HID * WP;
+    ChunkRegs<KCH> pre0 = load_chunk<KCH, NR>(W, ldw, 0), pre1;
+    if (nchunks > 1) pre1 = load_chunk<KCH, NR>(W, ldw, KCH);
+    store_chunk<KCH, NR>(buf0, pre0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) pre0 = load_chunk<KCH, NR>(W, ldw, (c + 2) * KCH);
+        compute_chunk(c);
+        if (c + 1 < nchunks) store_chunk<KCH, NR>(buf1, pre1);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) pre1 = load_chunk<KCH, NR>(W, ldw, (c + 3) * KCH);
+        compute_chunk(c + 1);
+        if (c + 2 < nchunks) store_chunk<KCH, NR>(buf0, pre0);
         __syncthreads();
     }
 }

@@ -494,6 +494,9 @@ __device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int 
     }
 }
 
+#ifndef HS_TBWD_DEEP
+#define HS_TBWD_DEEP false      // weight chunks one round ahead (mfma_mlp.h: layer_mma); two rounds ahead spills here
+#endif
 #ifdef HS_TBWD_PROFILE     // tools/exp/tbwd_prof.hip: s_memtime stamps of the phases of one tile (the third of every workgroup)
 __device__ unsigned long long g_tbwd_prof[256 * 16];
 #define HS_BSTAMP(i) do { if (threadIdx.x == 0 && tile == (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x) g_tbwd_prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         f32x16 acc[2][2];
         HS_BSTAMP(1);
         zero_acc(acc);
-        layer_mma<HP, 32>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
+        layer_mma<HP, 32, HID, HS_TBWD_DEEP>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr1);
         TileRegs hr = load_tile_regs(H0, r0, M);    // in flight under the epilogue, the gA1 store and the 256-deep product
         __syncthreads();
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         sum1 += tile_colsum<4>(H);
         HS_BSTAMP(5);
         zero_acc(acc);
-        layer_mma(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        layer_mma<HP, KC, HID, HS_TBWD_DEEP>(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
         __syncthreads();
         HS_BSTAMP(6);
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             zero_acc(acc);
             // rows >= 128 of W0^T are padding and are not streamed.  (Staging the live 128 x 256 part in ONE round -- it fits the two chunk
             // buffers -- instead of four 64-deep ones was slower: 9.5 k vs 6.6 k cycles, the whole load latency exposed at once.)
-            layer_mma<HP, KC, 128>(W0t, HID, HID, H, Wc, acc, nq, ph, lane, nq < 2);
+            layer_mma<HP, KC, 128, HS_TBWD_DEEP>(W0t, HID, HID, H, Wc, acc, nq, ph, lane, nq < 2);
             HS_BSTAMP(10);
             if (nq < 2) {
 #pragma unroll
