@@ -495,7 +495,7 @@ __device__ __forceinline__ void epilogue_bwd(uint16_t *H, f32x16 acc[2][2], int 
 }
 
 #ifndef HS_TBWD_DEEP
-#define HS_TBWD_DEEP false      // weight chunks one round ahead (mfma_mlp.h: layer_mma); two rounds ahead spills here
+#define HS_TBWD_DEEP true       // weight chunks two rounds ahead (mfma_mlp.h: layer_mma): 357-376 -> 344-352 us per launch, same box
 #endif
 #ifdef HS_TBWD_PROFILE     // tools/exp/tbwd_prof.hip: s_memtime stamps of the phases of one tile (the third of every workgroup)
 __device__ unsigned long long g_tbwd_prof[256 * 16];
@@ -554,7 +554,9 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         zero_acc(acc);
         layer_mma<HP, 32, HID, HS_TBWD_DEEP>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr1);
+#ifndef HS_TBWD_H0_LATE
         TileRegs hr = load_tile_regs(H0, r0, M);    // in flight under the epilogue, the gA1 store and the 256-deep product
+#endif
         __syncthreads();
         HS_BSTAMP(2);
         if (dW2_part) {   // H = H1 tile, Gs = g tile: accW[kout][col] += sum_rows g[row][kout] * H1[row][col], this wave's 32 columns
@@ -584,6 +586,9 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         store_tile(H, gA1, r0, M);
         sum1 += tile_colsum<4>(H);
         HS_BSTAMP(5);
+#ifdef HS_TBWD_H0_LATE
+        TileRegs hr = load_tile_regs(H0, r0, M);
+#endif
         zero_acc(acc);
         layer_mma<HP, KC, HID, HS_TBWD_DEEP>(W1t, HID, HID, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
