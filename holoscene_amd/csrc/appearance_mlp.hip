@@ -181,22 +181,25 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
         f32x16 acc[2][2];
         zero_acc(acc);
         layer_mma(Wc0, NFC, NFC, H, Wc, acc, nq, ph, lane);
+        ChunkRegs<KC> wn = first_chunk(Wc1, HID);     // the next layer's first weight chunk rides under this layer's epilogue and store
         epilogue_act<1>(bias, H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, hc, p0, B);
         zero_acc(acc);
-        layer_mma(Wc1, HID, HID, H, Wc, acc, nq, ph, lane);
+        layer_mma(Wc1, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
+        wn = first_chunk(Wr0f, HID);
         epilogue_act<0>(bias + HID, H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, fv, p0, B);
         zero_acc(acc);
-        layer_mma(Wr0f, HID, HID, H, Wc, acc, nq, ph, lane);          // feature-vector columns 81..336 of W_R0
+        layer_mma(Wr0f, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);   // feature-vector columns 81..336 of W_R0
         layer_mma<PP>(Wr0p, PW, PW, P, Wc, acc, nq, ph, lane);        // + positional-encoding columns 0..80
+        wn = first_chunk(Wr1, HID);
         epilogue_act<1>(bias + 2 * HID, H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, r0o, p0, B);
         zero_acc(acc);
-        layer_mma(Wr1, HID, HID, H, Wc, acc, nq, ph, lane);
+        layer_mma(Wr1, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
         epilogue_act<1>(bias + 3 * HID, H, acc, nq, ph, lane);
         stage_small(Wc, Wr2);
         __syncthreads();
@@ -261,13 +264,14 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         layer_mma(Wr2t, 32, 32, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr);
         __syncthreads();
+        ChunkRegs<KC> wn = first_chunk(Wr1t, HID);    // the next product's first weight chunk rides under the epilogue and the store
         epilogue_grad<1>(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, gA_r1, p0, B);
         s_r1 += tile_colsum<1>(H);
         hr = load_tile_regs(r0, p0, B);
         zero_acc(acc);
-        layer_mma(Wr1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        layer_mma(Wr1t, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
         store_tile_regs(H, hr);
         __syncthreads();
         epilogue_grad<1>(H, acc, nq, ph, lane);
@@ -303,13 +307,14 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         // ---- feature vector: g_fv = gA_r0 . W_R0[:, 81:]  (no activation between the colour MLP and the rendering MLP)
         zero_acc(acc);
         layer_mma(Wr0ft, HID, HID, H, Wc, acc, nq, ph, lane);   // its first barrier also fences the scratch reads above
+        wn = first_chunk(Wc1t, HID);
         epilogue_grad<0>(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, g_fv, p0, B);
         s_c1 += tile_colsum<1>(H);
         hr = load_tile_regs(hc, p0, B);
         zero_acc(acc);
-        layer_mma(Wc1t, HID, HID, H, Wc, acc, nq, ph, lane);
+        layer_mma(Wc1t, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
         store_tile_regs(H, hr);
         __syncthreads();
         epilogue_grad<1>(H, acc, nq, ph, lane);

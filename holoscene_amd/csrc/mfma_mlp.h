@@ -126,9 +126,11 @@ __device__ __forceinline__ void layer_mma_shallow(const uint16_t *__restrict__ W
 
 // One hidden layer: acc[nt][pt] += W[neurons][K] . H[points][K]^T, K a multiple of KCH.  wave -> neurons [nq*64,+64), points [ph*64,+64)
 // compute = false: the wave only helps stream the weights and keeps the barriers (its neurons are padding)
+// first: the layer's chunk 0 if the caller requested it earlier (first_chunk below, issued before the previous layer's epilogue): every
+// layer otherwise opens with one fully exposed L2 latency (~2.5 k cycles) before its first MFMA
 template <int AP = HP, int KCH = KC, int NR = HID, bool DEEP = true>
 __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ldw, int K, const uint16_t *H, uint16_t *Wc, f32x16 acc[2][2],
-                                          int nq, int ph, int lane, bool compute = true) {
+                                          int nq, int ph, int lane, bool compute = true, const ChunkRegs<KCH> *first = nullptr) {
     if constexpr (!DEEP) { layer_mma_shallow<AP, KCH, NR>(W, ldw, K, H, Wc, acc, nq, ph, lane, compute); return; }
     constexpr int KS = KCH / 16;
     const int nchunks = K / KCH;
@@ -156,7 +158,7 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
 #endif
     };
     uint16_t *buf0 = Wc, *buf1 = Wc + (size_t)HID * WP;
-    ChunkRegs<KCH> pre0 = load_chunk<KCH, NR>(W, ldw, 0), pre1;
+    ChunkRegs<KCH> pre0 = first ? *first : load_chunk<KCH, NR>(W, ldw, 0), pre1;
     if (nchunks > 1) pre1 = load_chunk<KCH, NR>(W, ldw, KCH);
     store_chunk<KCH, NR>(buf0, pre0);
     __syncthreads();
@@ -172,6 +174,9 @@ __device__ __forceinline__ void layer_mma(const uint16_t *__restrict__ W, int ld
         __syncthreads();
     }
 }
+
+template <int KCH = KC, int NR = HID>
+__device__ __forceinline__ ChunkRegs<KCH> first_chunk(const uint16_t *__restrict__ W, int ldw) { return load_chunk<KCH, NR>(W, ldw, 0); }
 
 __device__ __forceinline__ void zero_acc(f32x16 acc[2][2]) {
 #pragma unroll
