@@ -154,12 +154,24 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
                                                           const float *__restrict__ depth_scale, float sem_scale, int N, int K,
                                                           float *__restrict__ weights, float *__restrict__ trans, float *__restrict__ rgb_out,
                                                           float *__restrict__ depth_out, float *__restrict__ normal_out, float *__restrict__ sem_out,
-                                                          float *__restrict__ opac_out, const float *__restrict__ rot) {
+                                                          float *__restrict__ opac_out, const float *__restrict__ rot, int stage) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, i = threadIdx.x;
     const int C = 8 + 2 * K;
     float *scratch = lds;            // [4]
     float *contrib = lds + 4;        // [N][C]
+    float *rawS = contrib + (size_t)N * C;   // [N][K + 1]: the ray's per-object SDF block, staged with coalesced 16-byte reads (k_composite_bwd)
+    const bool staged = stage != 0;
+    if (staged) {
+        const float4 *src = reinterpret_cast<const float4 *>(raw + (size_t)blockIdx.x * N * K);
+        for (int idx = i; idx < N * K / 4; idx += BLOCK) {
+            const float4 v = src[idx];
+            const int e = idx * 4, row = e / K, col = e - row * K;
+            float *dst = rawS + row * (K + 1) + col;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+    }
     const bool act = i < N;
     const float beta = *beta_p;
     const size_t p = (size_t)r * N + (act ? i : 0);
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
         const float gx = g[3 * p], gy = g[3 * p + 1], gz = g[3 * p + 2];
         const float inv = 1.f / (sqrtf(gx * gx + gy * gy + gz * gz) + 1e-6f);
         c[5] = w * gx * inv; c[6] = w * gy * inv; c[7] = w * gz * inv;
-        const float *rw = raw + p * K;
+        const float *rw = staged ? rawS + i * (K + 1) : raw + p * K;
         for (int k = 0; k < K; k++) {
             const float s = rw[k];
             c[8 + k] = w * sem_scale / (1.f + __expf(sem_scale * s));           // s*sigmoid(-s*raw)
@@ -219,15 +231,29 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
                                                           const float *__restrict__ g_depth, const float *__restrict__ g_normal,
                                                           const float *__restrict__ g_sem, const float *__restrict__ g_opac,
                                                           float *__restrict__ d_sdf, float *__restrict__ d_raw, float *__restrict__ d_rgb,
-                                                          float *__restrict__ d_g, float *__restrict__ d_beta, const float *__restrict__ rot) {
+                                                          float *__restrict__ d_g, float *__restrict__ d_beta, const float *__restrict__ rot, int stage) {
     extern __shared__ float lds[];
     const int r = blockIdx.x, i = threadIdx.x;
     float *scratch = lds;          // [4]
     float *gs = lds + 4;           // g_sem[K]
     float *go = lds + 4 + K;       // g_opac[K]
+    float *rawS = lds + 4 + 2 * K; // [N][K + 1] when staged: the ray's block of per-object SDFs, later their cotangents (in place)
     for (int k = i; k < K; k += BLOCK) {
         gs[k] = g_sem ? g_sem[(size_t)r * K + k] : 0.f;
         go[k] = g_opac ? g_opac[(size_t)r * K + k] : 0.f;
+    }
+    // A lane walks the K objects of ITS sample: lane-strided 4-byte reads and writes, 64 cache lines per instruction, the cotangents
+    // leaving as 4-byte pieces of lines finished 32 instructions later.  The ray's [N, K] block is contiguous, so it is staged through LDS
+    // with 16-byte coalesced accesses both ways (pitch K + 1: the per-sample walks are conflict-free).
+    const bool staged = stage != 0;
+    if (staged) {
+        const float4 *src = reinterpret_cast<const float4 *>(raw + (size_t)r * N * K);
+        for (int idx = i; idx < N * K / 4; idx += BLOCK) {
+            const float4 v = src[idx];
+            const int e = idx * 4, row = e / K, col = e - row * K;
+            float *dst = rawS + row * (K + 1) + col;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
     }
     __syncthreads();
     const bool act = i < N;
@@ -278,8 +304,8 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
             d_g[3 * p + 2] = w * n2 * inv - gz * c2;
         }
         if (g_w) gw += g_w[p];
-        const float *rw = raw + p * K;
-        float *dr = d_raw + p * K;
+        const float *rw = staged ? rawS + i * (K + 1) : raw + p * K;
+        float *dr = staged ? rawS + i * (K + 1) : d_raw + p * K;
         for (int k = 0; k < K; k++) {
             const float s = rw[k];
             const float ex = __expf(sem_scale * s);
@@ -292,6 +318,15 @@ __global__ __launch_bounds__(BLOCK) void k_composite_bwd(const float *__restrict
             // d sem/d raw = -s^2 * sigmoid(-s raw) * (1 - sigmoid(-s raw)) = -sem * s*ex/(1+ex)
             dr[k] = gsig * lk.ds + gs[k] * w * (-sem * sem_scale * ex / (1.f + ex));
             gbeta += gsig * lk.db;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        float4 *dst = reinterpret_cast<float4 *>(d_raw + (size_t)r * N * K);
+        for (int idx = i; idx < N * K / 4; idx += BLOCK) {
+            const int e = idx * 4, row = e / K, col = e - row * K;
+            const float *sp = rawS + row * (K + 1) + col;
+            dst[idx] = make_float4(sp[0], sp[1], sp[2], sp[3]);
         }
     }
     const float gT = gw * alpha + gT_obj;
@@ -320,12 +355,15 @@ int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const f
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !weights || !rgb_out || !depth_out || !normal_out || !sem_out || !opac_out)
         return HS_ERR_NULL;
-    const size_t lds = (4 + (size_t)N * (8 + 2 * K)) * sizeof(float);
+    size_t lds = (4 + (size_t)N * (8 + 2 * K)) * sizeof(float);
     if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix must fit the default dynamic-LDS window
+    // (staging the per-object SDF block as the backward does was slower here: 33 -> 47 us -- with the 28 KB contribution matrix the
+    //  extra 13 KB cost a workgroup per CU)
+    const int stage = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) k_composite_fwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
-    else if (N <= 128) k_composite_fwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
-    else k_composite_fwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot);
+    if (N <= 64) k_composite_fwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot, stage);
+    else if (N <= 128) k_composite_fwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot, stage);
+    else k_composite_fwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, weights, transmittance, rgb_out, depth_out, normal_out, sem_out, opac_out, rot, stage);
     return check_launch();
 }
 
@@ -336,11 +374,14 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
     if (R <= 0) return HS_OK;
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !d_sdf || !d_raw) return HS_ERR_NULL;
-    const size_t lds = (4 + 2 * (size_t)K) * sizeof(float);
+    size_t lds = (4 + 2 * (size_t)K) * sizeof(float);
+    const size_t lds_staged = lds + (size_t)N * (K + 1) * sizeof(float);
+    const int stage = (K & 3) == 0 && lds_staged <= 64 * 1024;
+    if (stage) lds = lds_staged;
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) k_composite_bwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
-    else if (N <= 128) k_composite_bwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
-    else k_composite_bwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot);
+    if (N <= 64) k_composite_bwd<64><<<R, 64, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot, stage);
+    else if (N <= 128) k_composite_bwd<128><<<R, 128, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot, stage);
+    else k_composite_bwd<256><<<R, 256, lds, st>>>(z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, N, K, g_weights, g_rgb_out, g_depth, g_normal, g_sem, g_opac, d_sdf, d_raw, d_rgb, d_g, d_beta, rot, stage);
     return check_launch();
 }
 
