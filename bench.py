@@ -94,9 +94,15 @@ def _work_trunk_fwd(a, k):
 
 
 def _work_trunk_fwd2(a, k):
-    Y, K = a[7], a[4]
-    M = Y.shape[0]
-    return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 80 * 2 + K * 4) + (M // 4) * (12 + 128 + 384)
+    K, H0, Y = a[4], a[5], a[7]
+    M = H0.shape[0]
+    split = a[10] if len(a) > 10 else k.get("split")
+    if Y is None and split is not None:      # the kernel writes the split outputs instead of Y [M, K]: per point K + 1 + 3 floats and an int64
+        n_main = int(split[0])              # (Eikonal points: K + 1 + 3 (K + 1) floats)
+        out = n_main * (K * 4 + 4 + 12 + 8) + (M // 4 - n_main) * (K * 4 + 4 + 12 * (K + 1) + 8)
+    else:
+        out = M * K * 4
+    return M * trunk_flops_per_row(K), M * (2 * 256 * 2 + 80 * 2) + out + (M // 4) * (12 + 128 + 384)
 
 
 def _work_trunk_bwd(a, k):

@@ -128,11 +128,12 @@ __device__ __forceinline__ void store_line(const uint32_t *hw16, int nt, uint16_
     for (int i = 0; i < 2 * TILES; i++) store_pair(hw16 + 8 * (i >> 1), i & 1, nt + (i >> 1), Hrow, ok, h);
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__restrict__ x, const float *__restrict__ feat, const float *__restrict__ dydx,
                                                               const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f,
                                                               const uint16_t *__restrict__ W2f, const float *__restrict__ biasg, int d_out,
                                                               uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y,
-                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale) {
+                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
             });
         }
         // ---- outputs: register i <-> output 8 (i >> 2) + 4 h + (i & 3); the bias belongs to the value row only
-        if (ok) {
+        if constexpr (!SPLIT) {
+          if (ok) {
             float *dst = Y + gr * d_out;
             if ((d_out & 3) == 0) {
 #pragma unroll
@@ -346,6 +348,78 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
                 for (int i = 0; i < 16; i++) {
                     const int n = 8 * (i >> 2) + 4 * h + (i & 3);
                     if (n < d_out) dst[n] = y0[i] + y1[i] + (is_value ? bias[512 + n] : 0.f);
+                }
+            }
+          }
+        } else {
+            // ---- split outputs (hs_trunk_split_fwd's, encode_ops.hip): the K = d_out per-object SDFs of the value row, their minimum and its
+            //      index (lowest among equals), the gradient of the minimum from the three tangent rows -- and for the Eikonal points every
+            //      object's gradient.  A row's 32 outputs sit in two lanes (h = 0 / 1, 16 registers each); the quad = the point's four rows.
+            const int K = d_out;
+            const int64_t b = gr >> 2, Bp4 = M >> 2, Be = Bp4 - sp.n_main;
+            float o[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bv = lds_at<f32x4>(bo, (uint32_t)(8 * q) * 4u);
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[4 * q + k] = y0[4 * q + k] + y1[4 * q + k] + (is_value ? bv[k] : 0.f);
+            }
+            float best = INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {          // this half's columns in increasing order: strict < keeps the lowest index
+                const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                if (n < K && o[i] < best) { best = o[i]; bi = n; }
+            }
+            {
+                const float ob = __shfl_xor(best, 32);
+                const int oi = __shfl_xor(bi, 32);
+                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const int hit = __builtin_amdgcn_update_dpp(0, bi, 0x00, 0xf, 0xf, true);      // the value row's index, on the quad's four lanes
+            // this lane's output at column `hit` (if the column lives in this half)
+            float at_hit = 0.f;
+            const bool mine = ((hit >> 2) & 1) == h;
+            const int ih = 4 * (hit >> 3) + (hit & 3);
+#pragma unroll
+            for (int i = 0; i < 16; i++) at_hit = i == ih ? o[i] : at_hit;
+            if (ok) {
+                const bool main_pt = b < sp.n_main;
+                const int64_t e = b - sp.n_main;
+                if (is_value) {
+                    float *dst = main_pt ? sp.sdf_raw + b * K : sp.y_eik + e * K;
+                    if ((K & 3) == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (8 * q + 4 * h < K) *reinterpret_cast<float4 *>(dst + 8 * q + 4 * h) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                            if (n < K) dst[n] = o[i];
+                        }
+                    }
+                    if (h == 0) {
+                        sp.idx[b] = bi;
+                        if (main_pt) sp.sdf[b] = best; else sp.min_eik[e] = best;
+                    }
+                } else {
+                    const int d = t - 1;
+                    if (main_pt) {
+                        if (mine) sp.grad[b * 3 + d] = at_hit;
+                    } else {
+                        // (column stride kept opaque: as a visible loop invariant the sixteen column offsets are hoisted out of the tile
+                        //  loop into 32 registers, and this kernel has none to spare)
+                        int64_t step = Be * 3;
+                        asm volatile("" : "+s"(step));
+                        float *gp = sp.grad_theta + ((int64_t)(4 * h) * Be + e) * 3 + d;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                            if (n < K) gp[(int64_t)(8 * (i >> 2) + (i & 3)) * step] = o[i];
+                        }
+                        if (mine) sp.grad_theta[((int64_t)K * Be + e) * 3 + d] = at_hit;
+                    }
                 }
             }
         }
@@ -369,19 +443,35 @@ int32_t hs_trunk_mlp2_input_column(int32_t c) {
 }
 
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, void *stream) {
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, void *stream) {
     if (d_out < 1 || d_out > 32 || (M & 3)) return HS_ERR_ARG;
     if (M == 0) return HS_OK;
-    if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !H0 || !H1 || !Y || !Xp) return HS_ERR_NULL;
+    if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !H0 || !H1 || (!Y && !split) || !Xp) return HS_ERR_NULL;
+    hsTrunkSplit sp = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (split) {
+        sp = *split;
+        const int64_t Bp = M >> 2;
+        if (sp.n_main < 0 || sp.n_main > Bp) return HS_ERR_ARG;
+        if (!sp.idx || (sp.n_main > 0 && (!sp.sdf_raw || !sp.sdf || !sp.grad)) || (sp.n_main < Bp && (!sp.y_eik || !sp.min_eik || !sp.grad_theta))) return HS_ERR_NULL;
+        Y = nullptr;       // the split outputs replace it
+    }
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)k_trunk_fwd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_trunk_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
     const int64_t ntiles = (M + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
-    k_trunk_fwd2<<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale);
+    if (split)
+        k_trunk_fwd2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp);
+    else
+        k_trunk_fwd2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp);
     return wt_check_launch();
 }
 

@@ -37,6 +37,11 @@ class hsPackJob(ctypes.Structure):
                 ("transpose", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
+class hsTrunkSplit(ctypes.Structure):
+    _fields_ = [("n_main", ctypes.c_int64), ("sdf_raw", ctypes.c_void_p), ("sdf", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+                ("y_eik", ctypes.c_void_p), ("min_eik", ctypes.c_void_p), ("grad_theta", ctypes.c_void_p)]
+
+
 class hsSumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32), ("src_f32", ctypes.c_int32)]
 
@@ -380,13 +385,22 @@ class _HipBackend:
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
 
     @staticmethod
-    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale):
+    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None):
+        """split = (n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta): the kernel writes hs_trunk_split_fwd's outputs itself and
+        Y (then None) is never stored."""
         lib = load_library()
         bf = torch.bfloat16
         W0f, W1f, W2f, bias = packed
+        sp = None
+        if split is not None:
+            n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta = split
+            opt = lambda t, name, dt=torch.float32: _dev(t, name, dt).value if t is not None and t.numel() else None   # noqa: E731
+            sp = hsTrunkSplit(int(n_main), opt(sdf_raw, "sdf_raw"), opt(sdf, "sdf"), _dev(idx, "idx", torch.int64).value, opt(grad, "grad"),
+                              opt(y_eik, "y_eik"), opt(min_eik, "min_eik"), opt(gtheta, "grad_theta"))
         _check(lib.hs_trunk_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
-                                     _dev(bias, "bias"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y"), _dev(Xp, "Xp", bf),
-                                     ctypes.c_int64(Y.shape[0]), ctypes.c_float(jac_scale), _stream()), "hs_trunk_mlp2_fwd")
+                                     _dev(bias, "bias"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y") if Y is not None else None,
+                                     _dev(Xp, "Xp", bf), ctypes.c_int64(H0.shape[0]), ctypes.c_float(jac_scale),
+                                     ctypes.byref(sp) if sp is not None else None, _stream()), "hs_trunk_mlp2_fwd")
 
     @staticmethod
     def trunk_mlp2_columns():

@@ -145,6 +145,8 @@ TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") !
 # forward pass of the training trunk: "wave" = csrc/trunk_mlp2.hip (wave-tile form: builds its own input rows from x / features / dy_dx,
 # register-resident activations; d_out <= 32), "tile" = k_trunk_fwd of csrc/sdf_mlp.hip fed by k_trunk_input_fwd
 TRUNK_FWD_IMPL = os.environ.get("HOLOSCENE_TRUNK_FWD_IMPL", "wave")
+# the wave-tile trunk kernel writes the per-object SDFs / minimum / its gradient itself ("1") or stores Y for hs_trunk_split_fwd ("0")
+TRUNK_SPLIT_FUSED = os.environ.get("HOLOSCENE_TRUNK_SPLIT_FUSED", "1") != "0"
 _XP_COLUMNS = {}
 
 
@@ -183,9 +185,11 @@ def _wgrad_rows_many(pairs, ready_parts=()):
     return [direct[i] for i in range(len(pairs))] + sums[len(parts):]
 
 
-def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None, split=None):
     """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save.
-    x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points)."""
+    x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points).
+    split: hs_trunk_split_fwd's (n_main, outputs...) -- where the wave-tile kernel runs it writes them itself and the returned Y is
+    None (nothing stored); otherwise Y is returned and the caller runs the split kernel."""
     ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
     x = x.contiguous()
     if x01 is None:
@@ -203,17 +207,19 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     M = 4 * B
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
-    Y = torch.empty(M, d_out, device=dev, dtype=torch.float32)
+    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L * C == 32 and D == 3 and F_in == 71
+    fuse_split = wave and split is not None and TRUNK_SPLIT_FUSED      # the kernel writes the split outputs itself: no Y at all
+    Y = None if fuse_split else torch.empty(M, d_out, device=dev, dtype=torch.float32)
     bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
     w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
     w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
     f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-    if TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L * C == 32 and D == 3 and F_in == 71:
+    if wave:
         # wave-tile forward (csrc/trunk_mlp2.hip): fragment-order operands, input rows assembled in the kernel and kept as Xp [M,80]
         _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
         packed = _be._backend.sdf_mlp2_pack(f0, bb[0], f1, bb[1], f2, bb[2], d_out, log2_domain=False)
         Xp = torch.empty(M, 80, device=dev, dtype=bf)
-        _be._backend.trunk_mlp2_fwd(x.float(), feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale)
+        _be._backend.trunk_mlp2_fwd(x.float(), feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split if fuse_split else None)
         ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
         return Y, (x01, embeddings, offsets, Xp, H0, H1, w0t, w1t, w2t)
     if TRUNK_FWD_IMPL not in ("wave", "tile"):
@@ -317,7 +323,6 @@ class _fused_trunk_render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
         ctx.set_materialize_grads(False)    # unused outputs reach backward as None (the kernels take NULL), not as zero-filled tensors
-        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
         B, K = x.shape[0], W2.shape[0]
         dev = x.device
         Be = B - n_main
@@ -325,7 +330,10 @@ class _fused_trunk_render(torch.autograd.Function):
         idx = torch.empty(B, 1, device=dev, dtype=torch.int64)
         grad = torch.empty(n_main, 3, device=dev)
         y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
-        _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta)
+        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01,
+                                   split=(n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta))
+        if Y is not None:       # the kernel that ran does not produce the split outputs itself
+            _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta)
         ctx.save_for_backward(*saved, idx)
         ctx.n_main = n_main
         ctx.mark_non_differentiable(idx)

@@ -74,8 +74,17 @@ class FlatAdam:
             p.grad = None
 
     def gather_grads(self):
+        """Dense-update semantics: the fused Adam walks the WHOLE flat buffer, so a parameter that received no gradient this
+        iteration is updated with a zero gradient (its moments decay, its momentum still moves it), whereas torch.optim.Adam after
+        `zero_grad(set_to_none=True)` -- the reference's loop -- skips it.  Stage 1 uses every parameter in every iteration, so the
+        two agree there; a model with conditionally used parameters is told once."""
         src = [p.grad for p, _ in self.small if p.grad is not None]
         dst = [v for p, v in self.small if p.grad is not None]
+        if len(src) != len(self.small) and not getattr(self, "_warned_missing_grad", False):
+            import warnings
+            self._warned_missing_grad = True
+            warnings.warn(f"FlatAdam: {len(self.small) - len(src)} of {len(self.small)} small parameters received no gradient; the flat "
+                          "optimiser updates them with a zero gradient (torch.optim.Adam would skip them)")
         if src:
             torch._foreach_copy_(dst, src)
         for p, v in self.small:

@@ -305,9 +305,22 @@ int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float 
  * (level-major, as hs_hash_fwd writes them), with the input rows it assembled stored as Xp [M,80] bf16 in the kernel's own column order
  * (hs_trunk_mlp2_input_column(c) = position of reference input column c, for un-permuting the first layer's weight gradient).
  * Operands: hs_sdf_mlp2_pack(..., log2_domain = 0). */
+/* split != NULL (then Y may be NULL): the kernel writes what hs_trunk_split_fwd would derive from Y -- per-object SDFs, their minimum, its
+ * index (lowest among equals) and the gradient of the minimum for the rendered points [0, n_main), the Eikonal outputs for the rest -- from
+ * its output registers instead of storing Y [M, d_out] for a second kernel to read back (d_out = K objects). */
+typedef struct hsTrunkSplit {
+    int64_t n_main;        /* points [0, n_main) are rendered samples, [n_main, M/4) the Eikonal set */
+    float *sdf_raw;        /* [n_main, K] */
+    float *sdf;            /* [n_main] */
+    int64_t *idx;          /* [M/4] */
+    float *grad;           /* [n_main, 3] */
+    float *y_eik;          /* [Be, K] */
+    float *min_eik;        /* [Be] */
+    float *grad_theta;     /* [(K+1) Be, 3] */
+} hsTrunkSplit;
 int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, void *stream);
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, void *stream);
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);

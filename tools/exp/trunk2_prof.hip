@@ -29,10 +29,10 @@ int main(int argc, char **argv) {
     void *W2f = (char *)W12f + (size_t)kW1F * 2;
     pack(W0, b, W1, W2, W0f, W12f, W2f, bias);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int r = 0; r < 3; r++) hs_trunk_mlp2_fwd(x, feat, dydx, W0f, W12f, W2f, bias, 32, H0, H1, Y, Xp, M, 0.5f, nullptr);
+    for (int r = 0; r < 3; r++) hs_trunk_mlp2_fwd(x, feat, dydx, W0f, W12f, W2f, bias, 32, H0, H1, Y, Xp, M, 0.5f, nullptr, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 10; r++) hs_trunk_mlp2_fwd(x, feat, dydx, W0f, W12f, W2f, bias, 32, H0, H1, Y, Xp, M, 0.5f, nullptr);
+    for (int r = 0; r < 10; r++) hs_trunk_mlp2_fwd(x, feat, dydx, W0f, W12f, W2f, bias, 32, H0, H1, Y, Xp, M, 0.5f, nullptr, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("M=%lld rows: %.1f us per launch\n", (long long)M, ms * 100);
