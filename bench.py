@@ -106,12 +106,18 @@ def _work_trunk_fwd2(a, k):
 
 
 def _work_trunk_bwd(a, k):
-    g = a[0]
-    M, Kp = g.shape[0], g.shape[-1]
+    g, H1, W2t = a[0], a[1], a[3]
+    M, Kp = H1.shape[0], W2t.shape[-1]
     K = min(Kp, 32) if Kp <= 32 else Kp          # padded pitch; the unpadded K is set by the caller through _K_OBJECTS
     K = _K_OBJECTS[0] or K
     flops = M * 2 * (256 * K + 256 * 256 + K_IN * 256) + (M * 2 * K * 256 if k.get("dW2_part") is not None else 0)
-    return flops, M * (Kp * 2 + 4 * 256 * 2) + (M // 4) * (128 + 384)
+    cot = k.get("cot")
+    if g is None and cot is not None:          # the cotangent image is assembled in the kernel from the split outputs' cotangents
+        n_main = int(cot[0])                  # rendered point: K + 1 + 3 floats and the int64 index; Eikonal point: K + 1 + 3 (K + 1) floats
+        g_bytes = n_main * (K * 4 + 4 + 12 + 8) + (M // 4 - n_main) * (K * 4 + 4 + 12 * (K + 1) + 8)
+    else:
+        g_bytes = M * Kp * 2
+    return flops, g_bytes + M * 4 * 256 * 2 + (M // 4) * (128 + 384)
 
 
 def _work_appear_fwd(a, k):
