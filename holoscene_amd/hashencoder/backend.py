@@ -42,6 +42,10 @@ class hsTrunkSplit(ctypes.Structure):
                 ("y_eik", ctypes.c_void_p), ("min_eik", ctypes.c_void_p), ("grad_theta", ctypes.c_void_p)]
 
 
+class hsWgradJob(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("part", ctypes.c_void_p), ("M", ctypes.c_int64), ("NA", ctypes.c_int32), ("MB", ctypes.c_int32)]
+
+
 class hsSumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32), ("src_f32", ctypes.c_int32)]
 
@@ -91,7 +95,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
 
 
 def _check(rc, what):
@@ -468,6 +472,28 @@ class _HipBackend:
     def gather_rows(plan):
         lib = load_library()
         _check(lib.hs_gather_rows(plan[0], plan[1], _stream()), "hs_gather_rows")
+
+    WGRAD_SHAPES = ((256, 256), (256, 128), (32, 256))
+
+    @staticmethod
+    def wgrad_rows(pairs, slices):
+        """pairs: [(A [M, NA] bf16, B [M, MB] bf16)] with (NA, MB) in WGRAD_SHAPES and M % slices == 0 -> bf16 stacks [slices, NA, MB] of the
+        per-slice products A^T . B, all in one launch (at most 8 pairs per launch)."""
+        lib = load_library()
+        bf = torch.bfloat16
+        outs = []
+        for i0 in range(0, len(pairs), 8):
+            grp = pairs[i0:i0 + 8]
+            arr = (hsWgradJob * len(grp))()
+            for a, (A, B) in zip(arr, grp):
+                part = torch.empty(slices, A.shape[1], B.shape[1], device=A.device, dtype=bf)
+                a.A, a.B, a.part = _dev(A, "A", bf).value, _dev(B, "B", bf).value, part.data_ptr()
+                a.M, a.NA, a.MB = A.shape[0], A.shape[1], B.shape[1]
+                if B.shape[0] != A.shape[0]:
+                    raise RuntimeError("wgrad_rows: operands disagree on the number of rows")
+                outs.append(part)
+            _check(lib.hs_wgrad_rows(arr, len(grp), slices, _stream()), "hs_wgrad_rows")
+        return outs
 
     @staticmethod
     def sum_slices(partials):

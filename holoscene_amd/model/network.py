@@ -136,6 +136,8 @@ TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 # activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
 SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
+# weight gradients of the fused MLPs: "hip" = csrc/wgrad.hip (all products of a backward stage in one launch), "gemm" = library batched GEMMs
+WGRAD_IMPL = os.environ.get("HOLOSCENE_WGRAD_IMPL", "hip")
 TRUNK_W2_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_W2_IN_KERNEL", "1") == "1"   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
 _FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
 _BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
@@ -170,14 +172,23 @@ def _wgrad_rows(g, x):
 def _wgrad_rows_many(pairs, ready_parts=()):
     """[_wgrad_rows(g, x) for g, x in pairs] with the slice sums of all of them in ONE launch (hs_sum_slices); `ready_parts` are
     slice stacks some kernel already produced (k_trunk_bwd's dW2 slices): their sums are appended to the result."""
-    parts, direct = [], {}
+    parts, direct, mine = [], {}, []
     for i, (g, x) in enumerate(pairs):
         M = x.shape[0]
         S = _split_rows(M)
-        if S > 1 and g.dtype == torch.bfloat16 and g.is_cuda and (g.shape[1] * x.shape[1]) % 4 == 0:
+        if (WGRAD_IMPL == "hip" and S == 128 and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_cuda and g.is_contiguous()
+                and x.is_contiguous() and (g.shape[1], x.shape[1]) in _be._backend.WGRAD_SHAPES):
+            mine.append((i, g, x))          # hs_wgrad_rows: all such products of this call in one launch (csrc/wgrad.hip)
+        elif S > 1 and g.dtype == torch.bfloat16 and g.is_cuda and (g.shape[1] * x.shape[1]) % 4 == 0:
             parts.append((i, torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1))))
         else:
             direct[i] = _wgrad_rows(g, x)
+    if len(mine) >= 2:     # two or more products fill the chip together (tools/microbench_wgrad.py: six appearance products 123 vs 171 us)
+        parts += [(i, p) for (i, _, _), p in zip(mine, _be._backend.wgrad_rows([(g, x) for _, g, x in mine], 128))]
+    else:                  # a single product is 128 workgroups here; the library's kernel for it is faster (89 vs 168 us at M = 417 792)
+        for i, g, x in mine:
+            M = x.shape[0]
+            parts.append((i, torch.bmm(g.view(128, M // 128, -1).transpose(1, 2), x.view(128, M // 128, -1))))
     stacks = [p for _, p in parts] + list(ready_parts)
     sums = _be._backend.sum_slices(stacks) if stacks else []
     for (i, _), s_ in zip(parts, sums):

@@ -405,6 +405,20 @@ typedef struct hsPackJob {
 } hsPackJob;
 int hs_pack_bf16(const hsPackJob *jobs, int32_t n_jobs, void *stream);
 
+/* Weight gradients as split-M streaming reductions (csrc/wgrad.hip): for each job, part[s] = A[rows of slice s]^T . B[rows of slice s] as a
+ * bf16 [slices, NA, MB] stack (sum it with hs_sum_slices), A [M, NA] and B [M, MB] row-major bf16, M % slices == 0.  All jobs of a call
+ * run in ONE launch (workgroup = (job, slice)), so two 256 x 256 products fill the chip where the library's batched GEMM leaves half
+ * of it idle.  Shapes: (NA, MB) in {(256, 256), (256, 128), (32, 256)}.  Replaces autograd's grad_output.t() @ input of nn.Linear. */
+#define HS_WGRAD_MAX_JOBS 8
+typedef struct hsWgradJob {
+    const void *A;      /* [M, NA] bf16: cotangent of the layer's pre-activation (rows of the result) */
+    const void *B;      /* [M, MB] bf16: the layer's input (columns of the result) */
+    void *part;         /* [slices, NA, MB] bf16 */
+    int64_t M;
+    int32_t NA, MB;
+} hsWgradJob;
+int hs_wgrad_rows(const hsWgradJob *jobs, int32_t n_jobs, int32_t slices, void *stream);
+
 /* dst[i] = sum_s src[s*n + i] (src bf16 or fp32 [slices, n], dst fp32 [n], n % 4 == 0) for up to HS_PACK_MAX_JOBS matrices in one launch:
  * the final reduction of the split-M weight-gradient GEMMs. */
 typedef struct hsSumJob {

@@ -1013,6 +1013,32 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
         assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
 
 
+@pytest.mark.parametrize("M", [128 * 784, 128 * 64, 128 * 3])
+def test_wgrad_rows_vs_matmul(M):
+    """hs_wgrad_rows (csrc/wgrad.hip: split-M streaming reduction with transposing LDS reads, several products per launch) vs the fp32 product
+    of the same bf16 operands: slices end in a ragged chunk (784 = 12 x 64 + 16 rows), fill exactly one, or are shorter than one."""
+    from holoscene_amd.hashencoder import backend as B
+    be = B._backend
+    torch.manual_seed(M % 1000)
+    bf = torch.bfloat16
+    mats = {w: (torch.randn(M, w, device=DEV) * (torch.rand(1, w, device=DEV) + 0.1)).to(bf) for w in (32, 128, 256)}
+    other = (torch.randn(M, 256, device=DEV) * 0.3).to(bf)
+    pairs = [(mats[256], other), (mats[256], mats[128]), (mats[32], other), (other, mats[256])]
+    stacks = be.wgrad_rows(pairs, 128)
+    sums = be.sum_slices(stacks)
+    for (A, Bm), st, got in zip(pairs, stacks, sums):
+        assert st.shape == (128, A.shape[1], Bm.shape[1]) and st.dtype == bf
+        rows = M // 128
+        # every slice against its own rows (bf16 rounding of a slice's result: 2^-9 relative)
+        for s_ in (0, 77, 127):
+            ref = A[s_ * rows:(s_ + 1) * rows].float().t() @ Bm[s_ * rows:(s_ + 1) * rows].float()
+            err = (st[s_].float() - ref).abs().max() / ref.abs().max()
+            assert err < 6e-3, (A.shape, Bm.shape, s_, float(err))
+        ref = A.float().t() @ Bm.float()
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel < 2e-3, (A.shape, Bm.shape, rel)
+
+
 def test_batched_weight_norm_vs_torch():
     """hs_weight_norm (all layers of a network in one launch per direction) vs torch._weight_norm and its autograd backward."""
     from holoscene_amd.model import network as N
