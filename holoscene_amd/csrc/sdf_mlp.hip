@@ -529,10 +529,10 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
 #pragma unroll
         for (int i = 0; i < 16; i++) accW[mt][i] = 0.f;
     const int64_t ntiles = (M + BM - 1) / BM;
-    // The layer-output tiles (64 KB each) are requested early: H1 of the NEXT tile under this tile's input-cotangent phase, H0 right after
-    // the K = 32 product.  Requested where they are consumed, the two-k-step product G1 = g.W2 spent 8-9 k of a tile's 61 k cycles
-    // waiting for H1 (tools/exp/tbwd_prof.hip); early, the tile takes 54.6 k (395-405 -> 381 us per launch on one box).
-    TileRegs hr1 = load_tile_regs(H1, (int64_t)blockIdx.x * BM, M);
+    // The H0 tile (64 KB) is requested early, right after the K = 32 product -- requested where it is consumed, each layer-output tile
+    // costs ~8 k cycles of exposed wait (tools/exp/tbwd_prof.hip).  Requesting the NEXT tile's H1 under the input-cotangent phase as well
+    // measured the same in isolation (353-357 vs 354 us) but keeps 32 more registers live across the loop: 22 spilled registers and
+    // 140 MB of scratch traffic per launch in the production build; not done.
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" ::: "memory");
         HS_BSTAMP(0);
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         }
         f32x16 acc[2][2];
         HS_BSTAMP(1);
+        TileRegs hr1 = load_tile_regs(H1, r0, M);      // in flight under the K = 32 product
         zero_acc(acc);
         layer_mma<HP, 32, HID, HS_TBWD_DEEP>(W2t, KP, KP, H, Wc, acc, nq, ph, lane);
         store_tile_regs(H, hr1);
@@ -600,7 +601,6 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
         store_tile(H, gA0, r0, M);
         sum0 += tile_colsum<4>(H);
         HS_BSTAMP(8);
-        if (tile + gridDim.x < ntiles) hr1 = load_tile_regs(H1, (tile + gridDim.x) * BM, M);
         if (W0t) {
             // ---- cotangent of the trunk input: gX = gA0 . W0 (K0 = 96 columns; W0t = W0^T zero-padded to 256 rows).  Only the
             //      waves owning neurons < 96 multiply; the others keep streaming weight chunks.  Saves the library GEMM's
