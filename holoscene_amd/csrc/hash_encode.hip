@@ -231,10 +231,12 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
 // With lanes (2p, 2p + 1) = corners (x, x + 1) of point p one gather instruction covers 32 points x 2 corners and touches ~half the
 // lines.  The sum keeps the reference's order (corner 0, 1, ..., 7: the x bit alternates): lane 2p adds its own product, then its
 // neighbour's through a DPP operand, so the result stays bit-exact with the one-lane kernel.
-template <int C>
+// DYDX: also d out / d x01 (the one-lane kernel's expressions and summation order: for the x derivative the even lane takes its
+// neighbour's four entries through DPP, for y / z the two lanes' terms alternate in the sum as in the value).
+template <int C, bool DYDX>
 __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restrict__ x, const float *__restrict__ emb,
-                                                             const int32_t *__restrict__ offsets, float *__restrict__ out, uint32_t B,
-                                                             uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
+                                                             const int32_t *__restrict__ offsets, float *__restrict__ out, float *__restrict__ dydx,
+                                                             uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
     constexpr int D = 3;
     uint32_t level, chunk;
     if (lay.gate.a != nullptr && !(*lay.gate.a > *lay.gate.b)) return;
@@ -244,12 +246,17 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
     const LevelInfo li = level_info<D>(offsets, level, sc);
     const float *__restrict__ grid = emb + (size_t)li.offset * C;
     float *o = out + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
+    float *jo = DYDX ? dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride : nullptr;
     uint32_t g[D];
     float w[D], dw[D];
     if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
         if (xb == 0) {
 #pragma unroll
             for (int c = 0; c < C; c++) o[c] = 0.f;
+            if (DYDX) {
+#pragma unroll
+                for (int i = 0; i < D * C; i++) jo[i] = 0.f;
+            }
         }
         return;
     }
@@ -281,6 +288,46 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
         } else {
 #pragma unroll
             for (int c = 0; c < C; c++) o[c] = acc[c];
+        }
+    }
+    if constexpr (DYDX) {
+        auto swap = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)); };
+        float ga[D][C];
+        // d/dx: term k = (y, z) = yz: scale (y ? w1 : 1 - w1) (z ? w2 : 1 - w2) * (e[x = 1] - e[x = 0]) * dw0, all four on the even lane
+#pragma unroll
+        for (int c = 0; c < C; c++) ga[0][c] = 0.f;
+#pragma unroll
+        for (int yz = 0; yz < 4; yz++) {
+            float wt = li.scale;
+            wt *= (yz & 1) ? w[1] : 1 - w[1];
+            wt *= (yz >> 1) ? w[2] : 1 - w[2];
+#pragma unroll
+            for (int c = 0; c < C; c++) ga[0][c] += wt * (swap(e[yz].v[c]) - e[yz].v[c]) * dw[0];
+        }
+        // d/dy, d/dz: term k = (x, o) with o the other of (y, z): the lane holding x computes it, the even lane adds them in k order
+#pragma unroll
+        for (int gd = 1; gd < D; gd++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) ga[gd][c] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {            // bit of the other dimension (z for gd = 1, y for gd = 2)
+                float wt = li.scale;
+                wt *= xb ? w[0] : 1 - w[0];
+                wt *= ob ? w[3 - gd] : 1 - w[3 - gd];
+                const int lo = gd == 1 ? (ob << 1) : ob, hi = gd == 1 ? (1 | (ob << 1)) : (ob | 2);     // yz without / with bit gd
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float t = wt * (e[hi].v[c] - e[lo].v[c]) * dw[gd];
+                    ga[gd][c] += t;             // k = (x = 0, ob)
+                    ga[gd][c] += swap(t);       // k = (x = 1, ob)
+                }
+            }
+        }
+        if (xb == 0) {
+#pragma unroll
+            for (int gd = 0; gd < D; gd++)
+#pragma unroll
+                for (int c = 0; c < C; c++) jo[gd * C + c] = ga[gd][c];
         }
     }
 }
@@ -736,12 +783,15 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
     const dim3 grid(n_chunks * L), block(kThreads);
     dispatch_dc(D, C, [&](auto d, auto c) {
         constexpr int D_ = decltype(d)::value, C_ = decltype(c)::value;
-        if (dy_dx)
-            k_hash_fwd<D_, C_, true><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
-        else if (D_ == 3 && pair_forward()) {
+        if (D_ == 3 && pair_forward()) {
             const uint32_t n_chunks2 = (2 * B + kThreads - 1) / kThreads;      // two lanes per point
-            k_hash_fwd_pair<C_><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, B, L, sc, lay, n_chunks2);
-        } else
+            if (dy_dx)
+                k_hash_fwd_pair<C_, true><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks2);
+            else
+                k_hash_fwd_pair<C_, false><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, nullptr, B, L, sc, lay, n_chunks2);
+        } else if (dy_dx)
+            k_hash_fwd<D_, C_, true><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
+        else
             k_hash_fwd<D_, C_, false><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
     });
     return check_launch();
