@@ -221,21 +221,40 @@ __global__ __launch_bounds__(256) void k_trunk_split_bwd(const float *__restrict
         const int hit_k = (int)idx[b];
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = k0 + j;
-            float x = 0.f;
-            if (k < K) {
-                const bool hit = k == hit_k;
-                if (b < n_main) {
-                    if (r == 0) x = (g_raw ? g_raw[b * K + k] : 0.f) + (hit && g_sdf ? g_sdf[b] : 0.f);
-                    else if (hit && g_grad) x = g_grad[b * 3 + (r - 1)];
+        for (int j = 0; j < 8; j++) v[j] = 0.f;
+        const int jh = hit_k - k0;                       // position of the minimum's column inside this 8-column segment, if any
+        const bool main_pt = b < n_main;
+        const int64_t e = b - n_main;
+        if (r == 0) {                                    // value row: the per-object cotangents (+ the minimum's at its column)
+            const float *src = main_pt ? (g_raw ? g_raw + b * K + k0 : nullptr) : (g_yeik ? g_yeik + e * K + k0 : nullptr);
+            if (src != nullptr) {
+                if ((K & 3) == 0 && k0 + 8 <= K) {       // two 16-byte reads (rows of K floats, K % 4 == 0: aligned)
+                    const float4 a = reinterpret_cast<const float4 *>(src)[0], c4 = reinterpret_cast<const float4 *>(src)[1];
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c4.x; v[5] = c4.y; v[6] = c4.z; v[7] = c4.w;
                 } else {
-                    const int64_t e = b - n_main;
-                    if (r == 0) x = (g_yeik ? g_yeik[e * K + k] : 0.f) + (hit && g_mineik ? g_mineik[e] : 0.f);
-                    else if (g_theta) x = g_theta[((int64_t)k * Be + e) * 3 + (r - 1)] + (hit ? g_theta[((int64_t)K * Be + e) * 3 + (r - 1)] : 0.f);
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (k0 + j < K) v[j] = src[j];
                 }
             }
-            v[j] = x;
+            const float *gm = main_pt ? g_sdf : g_mineik;
+            if (gm != nullptr && jh >= 0 && jh < 8 && hit_k < K) {
+                const float add = gm[main_pt ? b : e];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = j == jh ? v[j] + add : v[j];
+            }
+        } else if (main_pt) {                            // tangent row of a rendered point: only the minimum's column is live
+            if (g_grad != nullptr && jh >= 0 && jh < 8 && hit_k < K) {
+                const float gv = g_grad[b * 3 + (r - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = j == jh ? gv : v[j];
+            }
+        } else if (g_theta != nullptr) {                 // tangent row of an Eikonal point: every object's gradient row (+ the minimum's)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = k0 + j;
+                if (k < K) v[j] = g_theta[((int64_t)k * Be + e) * 3 + (r - 1)] + (k == hit_k ? g_theta[((int64_t)K * Be + e) * 3 + (r - 1)] : 0.f);
+            }
         }
         typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
         typedef float f2 __attribute__((ext_vector_type(2)));
