@@ -376,39 +376,53 @@ __global__ __launch_bounds__(256) void k_pack_bf16(PackJobs jobs) {
 // one launch (was one ATen reduce launch of ~11 us per matrix, 11 per iteration; the data is 17 MB each).
 struct SumJobs { hsSumJob j[HS_PACK_MAX_JOBS]; };
 
+// 256 threads = 32 element quads x 8 slice groups: group y adds slices y, y + 8, ... of its four elements, the eight partial sums meet in
+// LDS.  (One thread per quad walking all 128 slices left a 256 x 256 result with 64 workgroups of 128 dependent loads each: 19 us.)
 __global__ __launch_bounds__(256) void k_sum_slices(SumJobs jobs) {
+    __shared__ float4 part[8][32];
     const hsSumJob jb = jobs.j[blockIdx.y];
-    if (jb.src_f32) {   // fp32 slices (n % 4 == 0)
-        const float *sf = reinterpret_cast<const float *>(jb.src);
-        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < jb.n; i += (int64_t)gridDim.x * 256 * 4) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int s_ = 0; s_ < jb.slices; s_++) {
-                const float4 v = *reinterpret_cast<const float4 *>(sf + (size_t)s_ * jb.n + i);
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-            }
-            *reinterpret_cast<float4 *>(jb.dst + i) = a;
-        }
-        return;
-    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const uint16_t *src = reinterpret_cast<const uint16_t *>(jb.src);
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < jb.n; i += (int64_t)gridDim.x * 256 * 4) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float *sf = reinterpret_cast<const float *>(jb.src);
+    for (int64_t i0 = (int64_t)blockIdx.x * 128; i0 < jb.n; i0 += (int64_t)gridDim.x * 128) {
+        const int64_t i = i0 + tx * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i + 3 < jb.n) {
-#pragma unroll 8
-            for (int s_ = 0; s_ < jb.slices; s_++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)s_ * jb.n + i);
-                a0 += __uint_as_float(v.x << 16); a1 += __uint_as_float(v.x & 0xffff0000u);
-                a2 += __uint_as_float(v.y << 16); a3 += __uint_as_float(v.y & 0xffff0000u);
+            if (jb.src_f32) {
+#pragma unroll 4
+                for (int s_ = ty; s_ < jb.slices; s_ += 8) {
+                    const float4 v = *reinterpret_cast<const float4 *>(sf + (size_t)s_ * jb.n + i);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+            } else {
+#pragma unroll 4
+                for (int s_ = ty; s_ < jb.slices; s_ += 8) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src + (size_t)s_ * jb.n + i);
+                    a.x += __uint_as_float(v.x << 16); a.y += __uint_as_float(v.x & 0xffff0000u);
+                    a.z += __uint_as_float(v.y << 16); a.w += __uint_as_float(v.y & 0xffff0000u);
+                }
             }
-            *reinterpret_cast<float4 *>(jb.dst + i) = make_float4(a0, a1, a2, a3);
-        } else {
-            for (int64_t k = i; k < jb.n; k++) {
-                float a = 0.f;
-                for (int s_ = 0; s_ < jb.slices; s_++) a += __uint_as_float((uint32_t)src[(size_t)s_ * jb.n + k] << 16);
-                jb.dst[k] = a;
+        } else {                      // ragged tail of a bf16 stack (fp32 stacks have n % 4 == 0)
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 4; k++)
+                if (i + k < jb.n)
+                    for (int s_ = ty; s_ < jb.slices; s_ += 8)
+                        t[k] += jb.src_f32 ? sf[(size_t)s_ * jb.n + i + k] : __uint_as_float((uint32_t)src[(size_t)s_ * jb.n + i + k] << 16);
+            a = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        part[ty][tx] = a;
+        __syncthreads();
+        if (ty == 0 && i < jb.n) {
+            float4 r = part[0][tx];
+#pragma unroll
+            for (int y = 1; y < 8; y++) { const float4 v = part[y][tx]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+            if (i + 3 < jb.n) *reinterpret_cast<float4 *>(jb.dst + i) = r;
+            else {
+                const float t[4] = {r.x, r.y, r.z, r.w};
+                for (int k = 0; k < 4 && i + k < jb.n; k++) jb.dst[i + k] = t[k];
             }
         }
+        __syncthreads();
     }
 }
 
@@ -524,8 +538,8 @@ int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream) {
         if (jobs[i].slices < 1 || jobs[i].n < 1 || (jobs[i].n & 3)) return HS_ERR_ARG;   // rows of 4 elements: 8-byte loads, 16-byte stores
         max_n = jobs[i].n > max_n ? jobs[i].n : max_n;
     }
-    const int64_t want = (max_n / 4 + 255) / 256;
-    k_sum_slices<<<dim3((unsigned)(want < 256 ? want : 256), n_jobs), 256, 0, (hipStream_t)stream>>>(sj);
+    const int64_t want = (max_n + 127) / 128;
+    k_sum_slices<<<dim3((unsigned)(want < 1024 ? want : 1024), n_jobs), 256, 0, (hipStream_t)stream>>>(sj);
     return check_launch();
 }
 
