@@ -402,13 +402,6 @@ __global__ __launch_bounds__(256) void k_sum_slices(SumJobs jobs) {
                     a.z += __uint_as_float(v.y << 16); a.w += __uint_as_float(v.y & 0xffff0000u);
                 }
             }
-        } else {                      // ragged tail of a bf16 stack (fp32 stacks have n % 4 == 0)
-            float t[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < 4; k++)
-                if (i + k < jb.n)
-                    for (int s_ = ty; s_ < jb.slices; s_ += 8)
-                        t[k] += jb.src_f32 ? sf[(size_t)s_ * jb.n + i + k] : __uint_as_float((uint32_t)src[(size_t)s_ * jb.n + i + k] << 16);
-            a = make_float4(t[0], t[1], t[2], t[3]);
         }
         part[ty][tx] = a;
         __syncthreads();
@@ -416,11 +409,7 @@ __global__ __launch_bounds__(256) void k_sum_slices(SumJobs jobs) {
             float4 r = part[0][tx];
 #pragma unroll
             for (int y = 1; y < 8; y++) { const float4 v = part[y][tx]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
-            if (i + 3 < jb.n) *reinterpret_cast<float4 *>(jb.dst + i) = r;
-            else {
-                const float t[4] = {r.x, r.y, r.z, r.w};
-                for (int k = 0; k < 4 && i + k < jb.n; k++) jb.dst[i + k] = t[k];
-            }
+            *reinterpret_cast<float4 *>(jb.dst + i) = r;       // n % 4 == 0 (checked by hs_sum_slices)
         }
         __syncthreads();
     }

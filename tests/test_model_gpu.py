@@ -1013,6 +1013,25 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
         assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
 
 
+@pytest.mark.parametrize("n,slices,dtype", [(256 * 256, 128, "bf16"), (32 * 256, 256, "f32"), (1028, 37, "bf16"), (4, 3, "f32"), (132, 9, "bf16")])
+def test_sum_slices_vs_torch(n, slices, dtype):
+    """hs_sum_slices (eight slice groups per element quad, LDS meeting point) vs torch.sum over dim 0: a partly filled last workgroup,
+    fewer slices than groups; n % 4 != 0 is refused."""
+    from holoscene_amd.hashencoder import backend as B
+    torch.manual_seed(n + slices)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    a = torch.randn(slices, n, device=DEV).to(dt)
+    b = torch.randn(slices, 2, n // 2, device=DEV).to(dt) if n % 2 == 0 else None
+    outs = B._backend.sum_slices([a] + ([b] if b is not None else []))
+    ref = a.float().sum(0)
+    assert outs[0].shape == ref.shape and float((outs[0] - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max())) * slices ** 0.5
+    if b is not None:
+        assert outs[1].shape == (2, n // 2)
+        assert float((outs[1] - b.float().sum(0)).abs().max()) <= 1e-5 * (1 + float(ref.abs().max())) * slices ** 0.5
+    with pytest.raises(RuntimeError):
+        B._backend.sum_slices([torch.zeros(3, 6, device=DEV)])
+
+
 @pytest.mark.parametrize("M", [128 * 784, 128 * 64, 128 * 3])
 def test_wgrad_rows_vs_matmul(M):
     """hs_wgrad_rows (csrc/wgrad.hip: split-M streaming reduction with transposing LDS reads, several products per launch) vs the fp32 product
