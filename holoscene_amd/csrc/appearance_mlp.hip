@@ -31,8 +31,13 @@ constexpr int PP = PW + 8;     // LDS pitch of the posenc tile
 constexpr int XW = NFC + PW;   // row of the saved input image: [featc(32) | posenc(96)]
 constexpr int SP = 33;         // fp32 scratch pitch
 
+// ReLU masks: the backward only needs the SIGN of the three ReLU layers' outputs, so the forward leaves them as wave ballots -- ballot
+// k = ((nt 4 + q) 2 + pt) 4 + j of a wave covers its 64 lanes' element j of cell (nt, q, pt), the same decomposition both kernels'
+// epilogues walk -- 4 KB per 128-point tile and layer instead of the 64 KB bf16 tile the backward used to read back (3 x 51 MB per
+// iteration).  Lane k of the wave keeps ballot k and stores it as one 8-byte word: masks[((tile 3 + layer) 8 + wave) 64 + lane].
 template <int ACT>  // 0: linear, 1: ReLU
-__device__ __forceinline__ void epilogue_act(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+__device__ __forceinline__ void epilogue_act(const float *bias_lds, uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane, uint64_t *mask_out = nullptr) {
+    uint32_t mlo = 0u, mhi = 0u;
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
@@ -49,14 +54,38 @@ __device__ __forceinline__ void epilogue_act(const float *bias_lds, uint16_t *H,
                 pk.x = pack_bf16(v0, v1);
                 pk.y = pack_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(H + (size_t)p * HP + n0) = pk;
+                if (ACT == 1 && mask_out != nullptr) {     // positive AFTER the bf16 rounding: exactly what the backward's old test on the stored tile saw
+                    const int k = ((nt * 4 + q) * 2 + pt) * 4;
+                    const bool on[4] = {(int16_t)(pk.x & 0xffffu) > 0, (int32_t)pk.x > 0xffff, (int16_t)(pk.y & 0xffffu) > 0, (int32_t)pk.y > 0xffff};
+                    const uint64_t b0 = __builtin_amdgcn_ballot_w64(on[0]), b1 = __builtin_amdgcn_ballot_w64(on[1]);
+                    const uint64_t b2 = __builtin_amdgcn_ballot_w64(on[2]), b3 = __builtin_amdgcn_ballot_w64(on[3]);
+                    // (s_nop 3: a ballot is a VALU write of an SGPR pair, and v_writelane reading it needs four wait states that the
+                    //  assembler does not insert inside an asm block -- without them 22 % of the mask bits were stale)
+                    asm("s_nop 3\n\t"
+                        "v_writelane_b32 %0, %2, %10\n\t"
+                        "v_writelane_b32 %1, %3, %10\n\t"
+                        "v_writelane_b32 %0, %4, %11\n\t"
+                        "v_writelane_b32 %1, %5, %11\n\t"
+                        "v_writelane_b32 %0, %6, %12\n\t"
+                        "v_writelane_b32 %1, %7, %12\n\t"
+                        "v_writelane_b32 %0, %8, %13\n\t"
+                        "v_writelane_b32 %1, %9, %13"
+                        : "+v"(mlo), "+v"(mhi)
+                        : "s"((uint32_t)b0), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)b1), "s"((uint32_t)(b1 >> 32)), "s"((uint32_t)b2),
+                          "s"((uint32_t)(b2 >> 32)), "s"((uint32_t)b3), "s"((uint32_t)(b3 >> 32)), "n"(k), "n"(k + 1), "n"(k + 2), "n"(k + 3));
+                }
             }
         }
     }
+    if (ACT == 1 && mask_out != nullptr) mask_out[lane] = ((uint64_t)mhi << 32) | mlo;
 }
 
 // MASK = 1: H holds the layer's ReLU output r on entry; exit: (r > 0 ? acc : 0) in place.  MASK = 0: H = acc.
+// MASK = 2: the ReLU mask comes from the forward's ballots (epilogue_act): `mine` = this lane's word of the wave's 64, ballot k read back
+// with v_readlane and applied as the select's lane mask
 template <int MASK>
-__device__ __forceinline__ void epilogue_grad(uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane) {
+__device__ __forceinline__ void epilogue_grad(uint16_t *H, f32x16 acc[2][2], int nq, int ph, int lane, uint64_t mine = 0) {
+    const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
@@ -73,6 +102,17 @@ __device__ __forceinline__ void epilogue_grad(uint16_t *H, f32x16 acc[2][2], int
                     v1 = (int32_t)r.x > 0xffff ? v1 : 0.f;
                     v2 = (int16_t)(r.y & 0xffffu) > 0 ? v2 : 0.f;
                     v3 = (int32_t)r.y > 0xffff ? v3 : 0.f;
+                }
+                if (MASK == 2) {
+                    const int k = ((nt * 4 + q) * 2 + pt) * 4;
+                    float *vv[4] = {&v0, &v1, &v2, &v3};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, k + j) << 32) | (uint32_t)__builtin_amdgcn_readlane(mlo, k + j);
+                        float o;
+                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(*vv[j]), "s"(m));
+                        *vv[j] = o;
+                    }
                 }
                 uint2 pk;
                 pk.x = pack_bf16(v0, v1);
@@ -113,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
                                                           const uint16_t *__restrict__ Wr2, const float *__restrict__ bc0, const float *__restrict__ bc1,
                                                           const float *__restrict__ br0, const float *__restrict__ br1, const float *__restrict__ br2,
                                                           uint16_t *__restrict__ xin, uint16_t *__restrict__ hc, uint16_t *__restrict__ fv,
-                                                          uint16_t *__restrict__ r0o, uint16_t *__restrict__ r1o, float *__restrict__ rgb, int64_t B) {
+                                                          uint16_t *__restrict__ r0o, uint16_t *__restrict__ r1o, float *__restrict__ rgb, int64_t B, uint64_t *__restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;                                   // [BM][HP]
     uint16_t *Wc = H + (size_t)BM * HP;                  // 2 x [HID][WP]
@@ -182,7 +222,8 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
         zero_acc(acc);
         layer_mma(Wc0, NFC, NFC, H, Wc, acc, nq, ph, lane);
         ChunkRegs<KC> wn = first_chunk(Wc1, HID);     // the next layer's first weight chunk rides under this layer's epilogue and store
-        epilogue_act<1>(bias, H, acc, nq, ph, lane);
+        uint64_t *mk = masks ? masks + ((size_t)tile * 3 * 8 + wave) * 64 : nullptr;      // this wave's words of layer 0 (layers 1, 2: + 512, + 1024)
+        epilogue_act<1>(bias, H, acc, nq, ph, lane, mk);
         __syncthreads();
         store_tile(H, hc, p0, B);
         zero_acc(acc);
@@ -195,12 +236,12 @@ __global__ __launch_bounds__(kThreads) void k_appear_fwd(const float *__restrict
         layer_mma(Wr0f, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);   // feature-vector columns 81..336 of W_R0
         layer_mma<PP>(Wr0p, PW, PW, P, Wc, acc, nq, ph, lane);        // + positional-encoding columns 0..80
         wn = first_chunk(Wr1, HID);
-        epilogue_act<1>(bias + 2 * HID, H, acc, nq, ph, lane);
+        epilogue_act<1>(bias + 2 * HID, H, acc, nq, ph, lane, mk ? mk + 512 : nullptr);
         __syncthreads();
         store_tile(H, r0o, p0, B);
         zero_acc(acc);
         layer_mma(Wr1, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
-        epilogue_act<1>(bias + 3 * HID, H, acc, nq, ph, lane);
+        epilogue_act<1>(bias + 3 * HID, H, acc, nq, ph, lane, mk ? mk + 1024 : nullptr);
         stage_small(Wc, Wr2);
         __syncthreads();
         store_tile(H, r1o, p0, B);
@@ -223,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
                                                           const uint16_t *__restrict__ Wc1t, const uint16_t *__restrict__ Wc0t,
                                                           uint16_t *__restrict__ gy, uint16_t *__restrict__ gA_r1, uint16_t *__restrict__ gA_r0,
                                                           uint16_t *__restrict__ g_fv, uint16_t *__restrict__ gA_hc, float *__restrict__ d_nrm,
-                                                          float *__restrict__ g_featc, float *__restrict__ gb, int64_t B) {
+                                                          float *__restrict__ g_featc, float *__restrict__ gb, int64_t B, const uint64_t *__restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = H + (size_t)BM * HP;
@@ -259,22 +300,25 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
                 for (int r = rg; r < BM; r += kThreads / 4) s_y += __uint_as_float((uint32_t)H[(size_t)r * HP + col] << 16);
         }
         f32x16 acc[2][2];
-        TileRegs hr = load_tile_regs(r1, p0, B);
+        // ReLU masks of the three masked layers: with the forward's ballots (masks != NULL) three 8-byte words per lane replace three
+        // 64 KB tiles of saved layer outputs per workgroup tile (and their trip through registers and LDS)
+        const uint64_t *mk = masks ? masks + ((size_t)tile * 3 * 8 + wave) * 64 + lane : nullptr;
+        const uint64_t m_hc = mk ? mk[0] : 0, m_r0 = mk ? mk[512] : 0, m_r1 = mk ? mk[1024] : 0;
+        TileRegs hr;
+        if (!mk) hr = load_tile_regs(r1, p0, B);
         zero_acc(acc);
         layer_mma(Wr2t, 32, 32, H, Wc, acc, nq, ph, lane);
-        store_tile_regs(H, hr);
-        __syncthreads();
+        if (!mk) { store_tile_regs(H, hr); __syncthreads(); }
         ChunkRegs<KC> wn = first_chunk(Wr1t, HID);    // the next product's first weight chunk rides under the epilogue and the store
-        epilogue_grad<1>(H, acc, nq, ph, lane);
+        if (mk) epilogue_grad<2>(H, acc, nq, ph, lane, m_r1); else epilogue_grad<1>(H, acc, nq, ph, lane);
         __syncthreads();
         store_tile(H, gA_r1, p0, B);
         s_r1 += tile_colsum<1>(H);
-        hr = load_tile_regs(r0, p0, B);
+        if (!mk) hr = load_tile_regs(r0, p0, B);
         zero_acc(acc);
         layer_mma(Wr1t, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
-        store_tile_regs(H, hr);
-        __syncthreads();
-        epilogue_grad<1>(H, acc, nq, ph, lane);
+        if (!mk) { store_tile_regs(H, hr); __syncthreads(); }
+        if (mk) epilogue_grad<2>(H, acc, nq, ph, lane, m_r0); else epilogue_grad<1>(H, acc, nq, ph, lane);
         stage_small(Wc, Wr0nt);
         __syncthreads();
         store_tile(H, gA_r0, p0, B);
@@ -312,12 +356,11 @@ __global__ __launch_bounds__(kThreads) void k_appear_bwd(const float *__restrict
         __syncthreads();
         store_tile(H, g_fv, p0, B);
         s_c1 += tile_colsum<1>(H);
-        hr = load_tile_regs(hc, p0, B);
+        if (!mk) hr = load_tile_regs(hc, p0, B);
         zero_acc(acc);
         layer_mma(Wc1t, HID, HID, H, Wc, acc, nq, ph, lane, true, &wn);
-        store_tile_regs(H, hr);
-        __syncthreads();
-        epilogue_grad<1>(H, acc, nq, ph, lane);
+        if (!mk) { store_tile_regs(H, hr); __syncthreads(); }
+        if (mk) epilogue_grad<2>(H, acc, nq, ph, lane, m_hc); else epilogue_grad<1>(H, acc, nq, ph, lane);
         stage_small(Wc, Wc0t);
         __syncthreads();
         store_tile(H, gA_hc, p0, B);
@@ -462,9 +505,12 @@ constexpr size_t kLdsBwd = ((size_t)BM * HP + 2 * (size_t)HID * WP) * sizeof(uin
 
 extern "C" {
 
+int64_t hs_appearance_mask_words(int64_t B) { return ((B + BM - 1) / BM) * 3 * 8 * 64; }
+
 int hs_appearance_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *Wc0, const void *Wc1,
                       const void *Wr0f, const void *Wr0p, const void *Wr1, const void *Wr2, const float *bc0, const float *bc1, const float *br0,
-                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B, void *stream) {
+                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B, uint64_t *relu_masks,
+                      void *stream) {
     if (B == 0) return HS_OK;
     if (!featc || !points || !dirs || !normals || !Wc0 || !Wc1 || !Wr0f || !Wr0p || !Wr1 || !Wr2 || !bc0 || !bc1 || !br0 || !br1 || !br2 || !xin ||
         !hc || !fv || !r0 || !r1 || !rgb)
@@ -475,15 +521,15 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     k_appear_fwd<<<grid, kThreads, kLdsFwd, (hipStream_t)stream>>>(
         featc, points, dirs, normals, (const uint16_t *)Wc0, (const uint16_t *)Wc1, (const uint16_t *)Wr0f, (const uint16_t *)Wr0p, (const uint16_t *)Wr1,
-        (const uint16_t *)Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)xin, (uint16_t *)hc, (uint16_t *)fv, (uint16_t *)r0, (uint16_t *)r1, rgb, B);
+        (const uint16_t *)Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)xin, (uint16_t *)hc, (uint16_t *)fv, (uint16_t *)r0, (uint16_t *)r1, rgb, B, relu_masks);
     return check_launch();
 }
 
 int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
                       const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
-                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, void *stream) {
+                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, const uint64_t *relu_masks, void *stream) {
     if (B == 0) return HS_OK;
-    if (!g_rgb || !rgb || !normals || !r1 || !r0 || !hc || !Wr2t || !Wr1t || !Wr0ft || !Wr0nt || !Wc1t || !Wc0t || !gy || !gA_r1 || !gA_r0 || !g_fv ||
+    if (!g_rgb || !rgb || !normals || (!relu_masks && (!r1 || !r0 || !hc)) || !Wr2t || !Wr1t || !Wr0ft || !Wr0nt || !Wc1t || !Wc0t || !gy || !gA_r1 || !gA_r0 || !g_fv ||
         !gA_hc || !d_normals || !g_featc)
         return HS_ERR_NULL;
     static bool attr = false;
@@ -493,7 +539,7 @@ int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals
     k_appear_bwd<<<grid, kThreads, kLdsBwd, (hipStream_t)stream>>>(
         g_rgb, rgb, normals, (const uint16_t *)r1, (const uint16_t *)r0, (const uint16_t *)hc, (const uint16_t *)Wr2t, (const uint16_t *)Wr1t,
         (const uint16_t *)Wr0ft, (const uint16_t *)Wr0nt, (const uint16_t *)Wc1t, (const uint16_t *)Wc0t, (uint16_t *)gy, (uint16_t *)gA_r1,
-        (uint16_t *)gA_r0, (uint16_t *)g_fv, (uint16_t *)gA_hc, d_normals, g_featc, gbias, B);
+        (uint16_t *)gA_r0, (uint16_t *)g_fv, (uint16_t *)gA_hc, d_normals, g_featc, gbias, B, relu_masks);
     return check_launch();
 }
 

@@ -95,7 +95,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
 
 
 def _check(rc, what):
@@ -512,25 +512,34 @@ class _HipBackend:
         return outs
 
     @staticmethod
-    def appearance_fwd(featc, points, dirs, normals, W, biases, xin, hc, fv, r0, r1, rgb):
-        """W: dict of packed bf16 operands (Wc0, Wc1, Wr0f, Wr0p, Wr1, Wr2); biases: (bc0, bc1, br0, br1, br2) fp32."""
+    def appearance_mask_words(B):
+        lib = load_library()
+        lib.hs_appearance_mask_words.restype = ctypes.c_int64
+        return int(lib.hs_appearance_mask_words(ctypes.c_int64(B)))
+
+    @staticmethod
+    def appearance_fwd(featc, points, dirs, normals, W, biases, xin, hc, fv, r0, r1, rgb, relu_masks=None):
+        """W: dict of packed bf16 operands (Wc0, Wc1, Wr0f, Wr0p, Wr1, Wr2); biases: (bc0, bc1, br0, br1, br2) fp32.
+        relu_masks: optional int64 [appearance_mask_words(B)] receiving the ReLU signs as wave ballots (for appearance_bwd)."""
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_appearance_fwd(_dev(featc, "featc"), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
                                      *[_dev(W[k], k, bf) for k in ("Wc0", "Wc1", "Wr0f", "Wr0p", "Wr1", "Wr2")],
                                      *[_dev(b, "bias") for b in biases], _dev(xin, "xin", bf), _dev(hc, "hc", bf), _dev(fv, "fv", bf),
-                                     _dev(r0, "r0", bf), _dev(r1, "r1", bf), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]), _stream()),
+                                     _dev(r0, "r0", bf), _dev(r1, "r1", bf), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]),
+                                     _dev(relu_masks, "relu_masks", torch.int64), _stream()),
                "hs_appearance_fwd")
 
     @staticmethod
-    def appearance_bwd(g_rgb, rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gbias):
+    def appearance_bwd(g_rgb, rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gbias, relu_masks=None):
+        """relu_masks: appearance_fwd's ballots -- then r1, r0, hc are not read (may be None)."""
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_appearance_bwd(_dev(g_rgb, "g_rgb"), _dev(rgb, "rgb"), _dev(normals, "normals"), _dev(r1, "r1", bf), _dev(r0, "r0", bf),
                                      _dev(hc, "hc", bf), *[_dev(W[k], k, bf) for k in ("Wr2t", "Wr1t", "Wr0ft", "Wr0nt", "Wc1t", "Wc0t")],
                                      _dev(gy, "gy", bf), _dev(gA_r1, "gA_r1", bf), _dev(gA_r0, "gA_r0", bf), _dev(g_fv, "g_fv", bf),
                                      _dev(gA_hc, "gA_hc", bf), _dev(d_normals, "d_normals"), _dev(g_featc, "g_featc"), _dev(gbias, "gbias"),
-                                     ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance_bwd")
+                                     ctypes.c_int64(g_rgb.shape[0]), _dev(relu_masks, "relu_masks", torch.int64), _stream()), "hs_appearance_bwd")
 
     @staticmethod
     def render_points(cam_loc, ray_dirs, z_vals, z_eik, eik_uniform, eik_jitter, divide_factor, x, x01, dirs_flat, eik_scale=1.0, eik_shift=0.0):

@@ -366,6 +366,8 @@ class _fused_trunk_render(torch.autograd.Function):
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
 # bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
 APPEARANCE_IMPL = os.environ.get("HOLOSCENE_APPEARANCE_IMPL", "mfma")
+# k_appear_bwd takes the ReLU signs from ballots the forward kernel wrote ("1") or from the saved layer outputs hc, r0, r1 ("0")
+APPEARANCE_RELU_MASKS = os.environ.get("HOLOSCENE_APPEARANCE_RELU_MASKS", "1") != "0"
 # background-surface pass of render(): "hip" = the main pass's fused kernels (trunk + split, compositing) when their shapes are
 # supported; "torch" = the whole-tensor formulation (always used otherwise)
 BG_IMPL = os.environ.get("HOLOSCENE_BG_IMPL", "hip")
@@ -401,7 +403,10 @@ class _fused_appearance(torch.autograd.Function):
                       (wr0, W["Wr0nt"], 0, 54, 27, 256, True), (wc1, W["Wc1t"], 0, 0, 256, 256, True), (wc0, W["Wc0t"], 0, 0, 32, 256, True)])
         xin, hc, fv, r0, r1 = new(B, 128), new(B, 256), new(B, 256), new(B, 256), new(B, 256)
         rgb = torch.empty(B, 3, device=dev)
-        be.appearance_fwd(featc, points, dirs, normals, W, (f32(bc0), f32(bc1), f32(br0), f32(br1), f32(br2)), xin, hc, fv, r0, r1, rgb)
+        # signs of the three ReLU layers as wave ballots: the backward kernel reads these 2.4 MB instead of hc, r0 and r1 (154 MB)
+        masks = torch.empty(be.appearance_mask_words(B), device=dev, dtype=torch.int64) if APPEARANCE_RELU_MASKS else None
+        be.appearance_fwd(featc, points, dirs, normals, W, (f32(bc0), f32(bc1), f32(br0), f32(br1), f32(br2)), xin, hc, fv, r0, r1, rgb, masks)
+        ctx.masks = masks
         ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, xin, hc, fv, r0, r1, *[W[k] for k in ("Wr2t", "Wr1t", "Wr0ft", "Wr0nt", "Wc1t", "Wc0t")])
         ctx.cfg = (B, C, L, S, Hres)
         return rgb
@@ -418,7 +423,7 @@ class _fused_appearance(torch.autograd.Function):
         g_featc = torch.empty(L, B, C, device=dev)
         gb = torch.zeros(5, 256, device=dev)
         W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
-        be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb)
+        be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb, ctx.masks)
         need_w = ctx.needs_input_grad[8]
         gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbr2 = None
         if need_w:

@@ -376,10 +376,14 @@ int hs_trunk_split_bwd(const float *g_sdf_raw, const float *g_sdf, const int64_t
  *   view dir | normal, zero-padded) and Wr0f [256,256] (columns 81..336 = feature vector);  Wr1 [256,256];  Wr2 [32,256]
  *   (rows 0..2 used).  All bf16 row-major (hs_pack_bf16 builds them); biases fp32 (br2: 3 values).
  *   Kept for the backward pass / weight gradients, all bf16: xin [B,128] = [featc | encoded inputs], hc, fv, r0, r1 [B,256]
- *   (layer outputs).  rgb [B,3] fp32 = sigmoid(...). */
+ *   (layer outputs).  rgb [B,3] fp32 = sigmoid(...).
+ *   relu_masks (may be NULL): hs_appearance_mask_words(B) 8-byte words receiving the signs of the three ReLU layers' outputs as wave
+ *   ballots; given to hs_appearance_bwd they replace its reads of hc, r0, r1 (3 x B x 256 bf16 -> 3 x B x 256 bits). */
+int64_t hs_appearance_mask_words(int64_t B);
 int hs_appearance_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *Wc0, const void *Wc1,
                       const void *Wr0f, const void *Wr0p, const void *Wr1, const void *Wr2, const float *bc0, const float *bc1, const float *br0,
-                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B, void *stream);
+                      const float *br1, const float *br2, void *xin, void *hc, void *fv, void *r0, void *r1, float *rgb, int64_t B,
+                      uint64_t *relu_masks, void *stream);
 
 /* Backward data path.  Transposed bf16 weights: Wr2t [256,32], Wr1t [256,256], Wr0ft [256,256] (= Wr0f^T), Wr0nt [32,256]
  * (rows j < 27 = column 54+j of W_R0: the encoded-normal inputs), Wc1t [256,256], Wc0t [32,256].
@@ -388,7 +392,8 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
  * gbias [5,256] fp32 (+=; rows: br1, br0, bc1, bc0, br2 (3 values); may be NULL). */
 int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals, const void *r1, const void *r0, const void *hc, const void *Wr2t,
                       const void *Wr1t, const void *Wr0ft, const void *Wr0nt, const void *Wc1t, const void *Wc0t, void *gy, void *gA_r1, void *gA_r0,
-                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B, void *stream);
+                      void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B,
+                      const uint64_t *relu_masks /* NULL: the masks are taken from r1, r0, hc; else those three may be NULL */, void *stream);
 
 /* fp32 master matrices -> bf16 operand images in ONE launch: dst [dst_rows, dst_cols] (row-major bf16) receives the
  * [rows, cols] block of src (leading dimension ld) starting at (row0, col0) -- or, with transpose != 0, its transpose

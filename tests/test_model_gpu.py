@@ -1013,6 +1013,44 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
         assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
 
 
+@pytest.mark.parametrize("Bn", [256, 300])
+def test_appearance_relu_masks_equal_saved_signs(Bn):
+    """The ballots hs_appearance_fwd leaves for the backward (3 layers x 8 waves x 64 words per 128-point tile) decode to exactly the signs
+    of the saved layer outputs hc, r0, r1 -- the information hs_appearance_bwd used to read back from them."""
+    from holoscene_amd.hashencoder import backend as B
+    be = B._backend
+    bf = torch.bfloat16
+    torch.manual_seed(Bn)
+    new = lambda c: torch.empty(Bn, c, device=DEV, dtype=bf)  # noqa: E731
+    featc, pts, dirs, nrm = torch.randn(16, Bn, 2, device=DEV), torch.randn(Bn, 3, device=DEV), torch.randn(Bn, 3, device=DEV), torch.randn(Bn, 3, device=DEV)
+    W = {"Wc0": (torch.randn(256, 32, device=DEV) * 0.2).to(bf), "Wc1": (torch.randn(256, 256, device=DEV) * 0.06).to(bf),
+         "Wr0f": (torch.randn(256, 256, device=DEV) * 0.06).to(bf), "Wr0p": (torch.randn(256, 96, device=DEV) * 0.1).to(bf),
+         "Wr1": (torch.randn(256, 256, device=DEV) * 0.06).to(bf), "Wr2": (torch.randn(32, 256, device=DEV) * 0.06).to(bf)}
+    biases = [torch.randn(256, device=DEV) * 0.1 for _ in range(4)] + [torch.randn(3, device=DEV)]
+    xin, hc, fv, r0, r1 = new(128), new(256), new(256), new(256), new(256)
+    rgb = torch.empty(Bn, 3, device=DEV)
+    words = be.appearance_mask_words(Bn)
+    ntiles = (Bn + 127) // 128
+    assert words == ntiles * 3 * 8 * 64
+    masks = torch.zeros(words, device=DEV, dtype=torch.int64)
+    be.appearance_fwd(featc, pts, dirs, nrm, W, biases, xin, hc, fv, r0, r1, rgb, masks)
+    m = masks.cpu().numpy().view(np.uint64).reshape(ntiles, 3, 8, 64)
+    bits = ((m[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool)      # [tile, layer, wave, k, lane]
+    # element (wave, k, lane) -> (row, neuron) of the tile: the decomposition both kernels' epilogues walk
+    wave, k, lane = np.meshgrid(np.arange(8), np.arange(64), np.arange(64), indexing="ij")
+    nq, ph, j, pt, q, nt = wave & 3, wave >> 2, k & 3, (k >> 2) & 1, (k >> 3) & 3, k >> 5
+    row = ph * 64 + pt * 32 + (lane & 31)
+    neuron = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5) + j
+    for layer, t in enumerate((hc, r0, r1)):
+        ref = np.zeros((ntiles * 128, 256), dtype=bool)
+        ref[:Bn] = (t.float() > 0).cpu().numpy()
+        for tile in range(ntiles):
+            got = np.zeros((128, 256), dtype=bool)
+            got[row, neuron] = bits[tile, layer]
+            valid = min(128, Bn - tile * 128)
+            assert np.array_equal(got[:valid], ref[tile * 128:tile * 128 + valid]), (layer, tile)
+
+
 @pytest.mark.parametrize("n,slices,dtype", [(256 * 256, 128, "bf16"), (32 * 256, 256, "f32"), (1028, 37, "bf16"), (4, 3, "f32"), (132, 9, "bf16")])
 def test_sum_slices_vs_torch(n, slices, dtype):
     """hs_sum_slices (eight slice groups per element quad, LDS meeting point) vs torch.sum over dim 0: a partly filled last workgroup,
