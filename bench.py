@@ -336,7 +336,11 @@ def main():
 
     # ---- N > 1: how long the one exchange per iteration (reduce-scatter -> shard Adam -> all-gather) is exposed after the graph
     exchange_ms = None
+    exchange_form = None
     if world > 1:
+        exchange_form = ("in-graph: colour-table segment (reduce-scatter, shard Adam, all-gather) on a side stream under the trunk backward, "
+                         "remaining segment at the end of the backward pass" if tr._overlap else "serial, after the iteration graph")
+    if world > 1 and not tr._overlap:     # (captured collectives cannot be bracketed by events; the driver's N=1 line is the comparison)
         ev = []
         orig_x = dist_util.exchange_and_step_flat
 
@@ -492,6 +496,7 @@ def main():
             line["config"]["fp32_point"] = fp32_point
         if world > 1:
             line["config"]["rccl_world_size"] = torch.distributed.get_world_size()
+            line["config"]["exchange"] = exchange_form
             line["config"]["exchange_ms_exposed"] = exchange_ms
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

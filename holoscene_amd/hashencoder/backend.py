@@ -132,6 +132,38 @@ def accumulates_into_grad(table):
     return table is not None and getattr(table, "_hs_flat_owner", False) and table.grad is not None
 
 
+class ScatterWatch:
+    """Tells a listener when a flat-owned table's gradient is FINAL inside a backward pass (data parallelism: the table's segment
+    can be exchanged from that moment on, training/trainer.py).  Every autograd Function that will scatter into the table in
+    place calls `expect_scatter` in its forward (only when the table requires a gradient there) and `scatter_done` after the
+    scatter; the callback runs -- on the autograd thread, with the scatter's stream current -- when the count returns to zero.
+    A producer that takes another route to the gradient (double backward) never reports done, so the callback simply does
+    not fire and the listener exchanges the segment at the end of the pass.  Reporting producers: the colour table's --
+    _fused_appearance (model/network.py) and HashEncoder's own Function (hashgrid.py); the SDF table's gradient is final only
+    with the last kernels of the pass, so its producers do not report."""
+
+    def __init__(self):
+        self.pending, self.callback = 0, None
+
+    def arm(self, callback):
+        self.pending, self.callback = 0, callback
+
+
+def expect_scatter(table):
+    w = getattr(table, "_hs_scatter_watch", None) if table is not None else None
+    if w is not None and accumulates_into_grad(table):
+        w.pending += 1
+
+
+def scatter_done(table):
+    w = getattr(table, "_hs_scatter_watch", None) if table is not None else None
+    if w is not None and w.pending > 0:
+        w.pending -= 1
+        if w.pending == 0 and w.callback is not None:
+            cb, w.callback = w.callback, None
+            cb()
+
+
 def point_major_layout(C, L, D):
     """features [B, L*C]; dy_dx [L, B, D*C] (level stride filled in per call)."""
     return dict(level_stride=C, point_stride=L * C, dydx_point_stride=D * C)

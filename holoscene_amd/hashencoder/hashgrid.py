@@ -41,6 +41,8 @@ class _hash_encode(Function):
         ctx.dims = (B, D, C, L, S, H)
         ctx.calc_grad_inputs = calc_grad_inputs
         ctx.table = embeddings_param if embeddings_param is not None else None
+        if ctx.needs_input_grad[1]:
+            _be.expect_scatter(ctx.table)
         return outputs
 
     @staticmethod
@@ -53,6 +55,7 @@ class _hash_encode(Function):
             B, D, C, L, S, H = ctx.dims
             gx = torch.empty_like(inputs) if need_x else None
             _be._backend.bwd(grad.contiguous(), inputs, offsets, table.grad, B, D, C, L, S, H, dy_dx, gx)
+            _be.scatter_done(table)
             return gx, None, None, None, None, None
         grad_inputs, grad_embeddings = _hash_encode_backward.apply(grad.contiguous(), inputs, embeddings, offsets, dy_dx, ctx.dims,
                                                                    need_x, need_e)

@@ -383,6 +383,8 @@ class _fused_appearance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        if ctx.needs_input_grad[3]:
+            _be.expect_scatter(ctx.table)      # data parallelism: the colour table's segment is exchanged once its last scatter has run
         be = _be._backend
         points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
         if x01 is None:
@@ -440,6 +442,8 @@ class _fused_appearance(torch.autograd.Function):
             be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
                    ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
             g_emb = None if inplace else target
+            if inplace:
+                _be.scatter_done(table)
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 
 

@@ -52,21 +52,36 @@ def reduce_scatter_sum(out_shard, full, world_size, rank, group=None):
         dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
 
 
-def exchange_and_step_flat(flat, world_size, zero1=True, group=None):
+def exchange_segment(flat, s, world_size, group=None):
+    """ZeRO-1 on segment s of the flat buffers (training/flat.py): reduce-scatter its gradient (each rank receives the SUM of its
+    1/N slice in a staging slice), fused Adam on that slice straight from the staging slice (gradient scaled by 1/N inside the
+    kernel), all-gather of the updated parameter slices.  `flat.tick()` must have run for this update.  Everything is enqueued on
+    the CURRENT stream: the trainer calls this for the early segment on a side stream while the backward pass is still running."""
+    b, e = flat.shards[s]
+    sb, se = flat.segments[s]
+    shard_g = flat.shard_grad(s)
+    reduce_scatter_sum(shard_g, flat.flat_g[sb:se], world_size, flat.rank, group)
+    flat.step_segment(s, grad_scale=1.0 / world_size, grad_shard=shard_g)
+    send = flat.shard_send(s)
+    send.copy_(flat.flat_p[b:e])
+    dist.all_gather_into_tensor(flat.flat_p[sb:se], send, group=group)
+
+
+def exchange_and_step_flat(flat, world_size, zero1=True, group=None, done=()):
     """Data-parallel step over flat buffers (training/flat.py).
 
-    zero1=True (default): reduce-scatter the flat gradient (each rank receives the SUM of its 1/N slice in a staging slice), run the
-    fused Adam on that slice only, straight from the staging slice (gradient scaled by 1/N inside the kernel), all-gather the
-    updated parameter slices.  Per rank this moves (N-1)/N of the buffer twice -- the same volume as a ring all-reduce -- and
-    cuts the optimiser's HBM traffic by N; with FlatAdam(shard_moments=True) (what Stage1Trainer builds for zero1) also the moment
-    storage.  Element-for-element identical to "all-reduce mean, full Adam".
+    zero1=True (default): per segment of the buffer, reduce-scatter -> shard-local fused Adam -> all-gather (exchange_segment).
+    Per rank this moves (N-1)/N of the buffer twice -- the same volume as a ring all-reduce -- and cuts the optimiser's HBM
+    traffic by N; with FlatAdam(shard_moments=True) (what Stage1Trainer builds for zero1) also the moment storage.
+    Element-for-element identical to "all-reduce mean, full Adam".  done: segments the caller has already exchanged in this update
+    (the trainer's overlapped early segment).
     zero1=False: one all-reduce over the flat gradient, full Adam on every rank."""
     if zero1:
-        b, e = flat.shard
-        shard_g = flat.shard_grad()
-        reduce_scatter_sum(shard_g, flat.flat_g, world_size, flat.rank, group)
-        flat.step(grad_scale=1.0 / world_size, shard_only=True, grad_shard=shard_g)
-        dist.all_gather_into_tensor(flat.flat_p, flat.flat_p[b:e].clone(), group=group)
+        flat.tick()
+        for s in range(len(flat.segments)):
+            if s not in done:
+                exchange_segment(flat, s, world_size, group)
+        flat.end_update()
     else:
         dist.all_reduce(flat.flat_g, op=dist.ReduceOp.SUM, group=group)
         flat.step(grad_scale=1.0 / world_size)

@@ -8,6 +8,14 @@ buffer that stays attached (``p.grad``), so
     around a shard-local Adam: ZeRO-1),
   * Adam is one streaming kernel (csrc/optim.hip) -- no host work, capturable in a HIP graph.
 State-dict names and shapes are untouched (the views keep their module attributes).
+
+Segments (data parallelism only).  The exchange of a parameter can start as soon as ITS gradient is final, and the colour table's is
+final 0.6-0.75 ms before the iteration's last kernel (its scatter runs right after the appearance backward; the trunk backward,
+the SDF table's scatter and the weight gradients follow).  ``early_params`` therefore splits the buffer into two independently
+sharded segments, [early tables | pad] and [everything else | pad]: each is reduce-scattered / stepped / all-gathered on its own
+(training/distributed.py::exchange_segment), the first one on a side stream under the trunk backward (trainer.py).  Each
+segment is a whole number of 16-byte quads per rank; the pad elements are zero parameters with zero gradients.  Without
+``early_params`` there is one segment and the layout is the plain concatenation.
 """
 import ctypes
 
@@ -18,47 +26,70 @@ from ..hashencoder import backend as _be
 
 class FlatAdam:
     def __init__(self, model, lr, lr_factor_for_grid, decay_rate, decay_steps, betas=(0.9, 0.99), eps=1e-15, world_size=1, rank=0,
-                 shard_moments=False):
-        """shard_moments (ZeRO-1): this rank stores the Adam moments of its own 1/world_size slice only; `step` must then be
-        called with shard_only=True and checkpoints gather the slices (`gather_moments`)."""
+                 shard_moments=False, early_params=None):
+        """shard_moments (ZeRO-1): this rank stores the Adam moments of its own 1/world_size slice (of every segment) only; the
+        update then goes through `tick` + `step_segment` and checkpoints gather the slices (`gather_moments`).
+        early_params: hash tables (members of the first optimiser group) whose gradients are final early in the backward pass;
+        they are laid out first and form a segment of their own (module docstring)."""
         groups = [list(model.implicit_network.grid_parameters()),
                   list(model.implicit_network.mlp_parameters()) + list(model.rendering_network.parameters()),
                   list(model.density.parameters())]
+        early = list(early_params or [])
+        early_ids = {id(p) for p in early}
+        if early_ids - {id(p) for p in groups[0]}:
+            raise ValueError("early_params must be hash tables of the first optimiser group")
+        groups[0] = early + [p for p in groups[0] if id(p) not in early_ids]
         self.params = [p for g in groups for p in g]
         dev = self.params[0].device
-        sizes = [sum(p.numel() for p in g) for g in groups]
-        total = sum(sizes)
-        align = 4 * world_size                      # every rank's shard is a whole number of 16-byte quads
-        self.numel = total
-        self.padded = (total + align - 1) // align * align
+        align = 4 * world_size                      # every rank's shard of every segment is a whole number of 16-byte quads
+        up = lambda n: (n + align - 1) // align * align  # noqa: E731
+        self.offsets, off, split = [], 0, None      # flat index of each parameter's first element
+        for i, p in enumerate(self.params):
+            if early and i == len(early):
+                off = split = up(off)
+            self.offsets.append(off)
+            off += p.numel()
+        self.numel = off                            # end of the last parameter (flat index space, inner pad included)
+        self.padded = up(off)
+        self.segments = [(0, self.padded)] if split is None or split == self.padded else [(0, split), (split, self.padded)]
         self.flat_p = torch.zeros(self.padded, device=dev)
         self.flat_g = torch.zeros(self.padded, device=dev)
-        shard = self.padded // world_size
-        self.shard = (rank * shard, (rank + 1) * shard)
+        self.shards = [(b + rank * ((e - b) // world_size), b + (rank + 1) * ((e - b) // world_size)) for b, e in self.segments]
         self.shard_moments = bool(shard_moments) and world_size > 1
-        self.mv_base = self.shard[0] if self.shard_moments else 0       # flat index of flat_m[0] / flat_v[0]
-        self.flat_m = torch.zeros(shard if self.shard_moments else self.padded, device=dev)
-        self.flat_v = torch.zeros(shard if self.shard_moments else self.padded, device=dev)
-        self._shard_g = None            # staging slice the reduce-scatter writes (distributed.py)
-        off = 0
+        # moment storage: full length, or this rank's slices of the segments back to back; mv_bases[s] = flat index that
+        # element 0 of the moment buffers would have for segment s (the kernel indexes m[i - mv_base])
+        held = sum(e - b for b, e in self.shards)
+        self.flat_m = torch.zeros(held if self.shard_moments else self.padded, device=dev)
+        self.flat_v = torch.zeros(held if self.shard_moments else self.padded, device=dev)
+        self.mv_bases, o = [], 0
+        for b, e in self.shards:
+            self.mv_bases.append(b - o if self.shard_moments else 0)
+            o += e - b
+        self._shard_g = {}              # per segment: staging slice the reduce-scatter writes (distributed.py)
+        self._shard_p = {}              # per segment: send buffer of the all-gather
+        self._ticked = False            # tick() already ran for the update in flight (segment-wise stepping)
         self.small = []          # (parameter, gradient view) of everything that is not a hash table
         n_tables = len(groups[0])
+        sizes_end = [0, 0]
         for i, p in enumerate(self.params):
-            n = p.numel()
+            n, off = p.numel(), self.offsets[i]
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + n].view_as(p)
             p.grad = self.flat_g[off:off + n].view_as(p)
             if i >= n_tables:
                 self.small.append((p, p.grad))
             else:
-                p._hs_flat_owner = True   # its gradient is consumed through gather_grads() only: scatters may use the side stream
-            off += n
+                p._hs_flat_owner = True   # its gradient is consumed through gather_grads() only: the scatters write it in place
+            if i < n_tables:
+                sizes_end[0] = off + n
+            if i < n_tables + len(groups[1]):
+                sizes_end[1] = off + n
         self.betas, self.eps = betas, eps
         self.gamma = float(decay_rate) ** (1.0 / float(decay_steps))
         self.world_size, self.rank = world_size, rank
         st = _be.hsAdamState()
         st.step = 0
-        st.group_end[0], st.group_end[1] = sizes[0], sizes[0] + sizes[1]
+        st.group_end[0], st.group_end[1] = sizes_end[0], max(sizes_end)
         for i, v in enumerate((lr * lr_factor_for_grid, lr, lr)):
             st.lr0[i] = v
             st.lr[i] = v
@@ -98,35 +129,37 @@ class FlatAdam:
                 raise RuntimeError("moments are sharded across ranks (ZeRO-1): pass full=gather_moments()")
             full = (self.flat_m, self.flat_v)
         fm, fv = full
-        out, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            out.append((fm[off:off + n].view_as(p), fv[off:off + n].view_as(p)))
-            off += n
-        return out
+        return [(fm[off:off + p.numel()].view_as(p), fv[off:off + p.numel()].view_as(p)) for p, off in zip(self.params, self.offsets)]
+
+    def _held(self, t, s):
+        """This rank's slice of segment s inside a moment buffer (shard-sized or full-length storage)."""
+        b, e = self.shards[s]
+        return t[b - self.mv_bases[s]:e - self.mv_bases[s]]
 
     def gather_moments(self, group=None):
-        """Full-length (m, v).  ZeRO-1 leaves every rank with valid moments for its own slice only -- whether the buffers are
-        shard-sized (shard_moments) or full-sized and stepped with shard_only=True -- so an export must collect the slices:
+        """Full-length (m, v).  ZeRO-1 leaves every rank with valid moments for its own slices only -- whether the buffers are
+        shard-sized (shard_moments) or full-sized and stepped segment-wise -- so an export must collect the slices:
         a COLLECTIVE call (all ranks) when world_size > 1."""
         if self.world_size == 1:
             return self.flat_m, self.flat_v
         import torch.distributed as dist
-        b, e = self.shard
         out = []
         for t in (self.flat_m, self.flat_v):
-            mine = (t if self.shard_moments else t[b:e]).contiguous().clone()
-            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
-            dist.all_gather(parts, mine, group=group)
-            out.append(torch.cat(parts))
+            full = torch.zeros(self.padded, device=t.device, dtype=t.dtype)
+            for s, (b, e) in enumerate(self.segments):
+                mine = self._held(t, s).contiguous().clone()
+                parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+                dist.all_gather(parts, mine, group=group)
+                full[b:e] = torch.cat(parts)
+            out.append(full)
         return tuple(out)
 
     def load_moments(self, full_m, full_v):
-        """Inverse of gather_moments: every rank keeps (at least) its own slice."""
-        b, e = self.shard
+        """Inverse of gather_moments: every rank keeps (at least) its own slices."""
         if self.shard_moments:
-            self.flat_m.copy_(full_m[b:e])
-            self.flat_v.copy_(full_v[b:e])
+            for s, (b, e) in enumerate(self.shards):
+                self._held(self.flat_m, s).copy_(full_m[b:e])
+                self._held(self.flat_v, s).copy_(full_v[b:e])
         else:
             self.flat_m.copy_(full_m)
             self.flat_v.copy_(full_v)
@@ -144,24 +177,48 @@ class FlatAdam:
         return _be.hsAdamState.from_buffer_copy(bytes(self.state.cpu().numpy().tobytes()))
 
     # ---- update
-    def shard_grad(self):
-        """Staging slice for the reduce-scatter output (1/world_size of the flat gradient)."""
-        if self._shard_g is None:
-            b, e = self.shard
-            self._shard_g = torch.empty(e - b, device=self.flat_g.device, dtype=self.flat_g.dtype)
-        return self._shard_g
+    def shard_grad(self, s=0):
+        """Staging slice for the reduce-scatter output of segment s (1/world_size of the segment's gradient)."""
+        if s not in self._shard_g:
+            b, e = self.shards[s]
+            self._shard_g[s] = torch.empty(e - b, device=self.flat_g.device, dtype=self.flat_g.dtype)
+        return self._shard_g[s]
 
-    def step(self, grad_scale=1.0, shard_only=False, grad_shard=None):
-        """One Adam + ExponentialLR step.  shard_only=True updates this rank's slice only (ZeRO-1); grad_shard: that slice's
-        summed gradient in its own buffer (the reduce-scatter output) instead of flat_g[shard]."""
-        be = _be._backend
-        if self.shard_moments and not shard_only:
-            raise RuntimeError("this rank stores only its shard of the Adam moments: step(shard_only=True)")
-        be.adam_tick(self.state, self.betas[0], self.betas[1], self.gamma)
-        b, e = self.shard if shard_only else (0, self.padded)
-        g, g_base = (self.flat_g, 0) if grad_shard is None else (grad_shard, self.shard[0])
-        be.adam_flat(self.flat_p, g, self.flat_m, self.flat_v, b, e, self.state, self.betas[0], self.betas[1], self.eps, grad_scale,
-                     g_base=g_base, mv_base=self.mv_base)
+    def shard_send(self, s=0):
+        """Send buffer of segment s's all-gather (the updated parameter slice, copied out of the buffer the gather writes)."""
+        if s not in self._shard_p:
+            b, e = self.shards[s]
+            self._shard_p[s] = torch.empty(e - b, device=self.flat_p.device, dtype=self.flat_p.dtype)
+        return self._shard_p[s]
+
+    def tick(self):
+        """Advance the step count, bias corrections and learning rates (ExponentialLR) ONCE per update; the segment steps of that
+        update then all read the same state.  Idempotent until `end_update`."""
+        if not self._ticked:
+            _be._backend.adam_tick(self.state, self.betas[0], self.betas[1], self.gamma)
+            self._ticked = True
+
+    def end_update(self):
+        self._ticked = False
+
+    def step_segment(self, s, grad_scale=1.0, grad_shard=None):
+        """Adam on this rank's slice of segment s (ZeRO-1); grad_shard: that slice's summed gradient in its own buffer (the
+        reduce-scatter output) instead of flat_g[slice].  `tick()` must have run for this update."""
+        if not self._ticked:
+            raise RuntimeError("step_segment before tick()")
+        b, e = self.shards[s]
+        g, g_base = (self.flat_g, 0) if grad_shard is None else (grad_shard, b)
+        _be._backend.adam_flat(self.flat_p, g, self.flat_m, self.flat_v, b, e, self.state, self.betas[0], self.betas[1], self.eps, grad_scale,
+                               g_base=g_base, mv_base=self.mv_bases[s])
+
+    def step(self, grad_scale=1.0):
+        """One Adam + ExponentialLR step over the whole buffer (single process, or after an all-reduce of the gradient)."""
+        if self.shard_moments:
+            raise RuntimeError("this rank stores only its shards of the Adam moments: tick() + step_segment(s)")
+        self.tick()
+        _be._backend.adam_flat(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0, self.padded, self.state, self.betas[0], self.betas[1],
+                               self.eps, grad_scale, g_base=0, mv_base=0)
+        self.end_update()
 
     def state_dict(self):
         """This rank's optimiser state (with sharded moments: its slice)."""

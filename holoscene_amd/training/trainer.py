@@ -59,11 +59,16 @@ class Stage1Trainer:
     """
 
     def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, rank=0, optimizer="flat", graph=False, zero1=True,
-                 freeze_parameters=False, inject_draws=False):
+                 freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None):
+        """data_parallel: run the gradient exchange (default: world_size > 1; True with a one-rank process group exercises the
+        collectives' code path on a single GPU).  exchange: "overlap" (default; env HOLOSCENE_EXCHANGE) = ZeRO-1 per segment with
+        the colour table's segment exchanged on a side stream as soon as its gradient is final, collectives captured inside the
+        iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph."""
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
         self.world_size, self.rank = world_size, rank
+        self.dp = world_size > 1 if data_parallel is None else bool(data_parallel)
         self.model = HoloSceneNetwork(conf=conf.get_config("model"), graph_node_dict=None, num_images=num_images).to(self.device)
         self.loss = HoloSceneLoss(**conf.get_config("loss"))
         self.lr = conf.get_float("train.learning_rate")
@@ -74,8 +79,12 @@ class Stage1Trainer:
         self.flat = None
         if optimizer == "flat":
             from .flat import FlatAdam
+            # ZeRO-1 under data parallelism: the colour table becomes a segment of its own (its gradient is final right after the
+            # appearance backward, 0.6-0.75 ms before the end of the pass: flat.py)
+            net = self.model.implicit_network
+            early = [net.color_encoding.embeddings] if (self.dp and zero1 and getattr(net, "color_grid_feature", False)) else None
             self.flat = FlatAdam(self.model, self.lr, lr_factor, decay_rate, decay_steps, world_size=world_size, rank=rank,
-                                 shard_moments=zero1 and world_size > 1)
+                                 shard_moments=zero1 and world_size > 1, early_params=early)
             self.optimizer = self.scheduler = None
         elif optimizer == "torch":
             self.optimizer = build_optimizer(self.model, self.lr, lr_factor)
@@ -91,7 +100,8 @@ class Stage1Trainer:
         self.use_graph = graph
         self.freeze_parameters = freeze_parameters  # tests: compute gradients but skip the update
         self.inject_draws = inject_draws            # tests: explicit random draws live in the graph's static input block
-        self.zero1 = zero1 and world_size > 1
+        self.zero1 = zero1 and self.dp
+        self._setup_exchange(exchange)
         self.add_objectvio_iter = conf.get_int("train.add_objectvio_iter", default=100000)
         self.iter_step = 0
         self._graphs = {}
@@ -100,15 +110,88 @@ class Stage1Trainer:
         if world_size > 1:
             torch.manual_seed(seed + 7919 * (rank + 1))
 
+    # ------------------------------------------------------------------ data-parallel exchange
+    def _setup_exchange(self, mode):
+        """Decide how the per-iteration exchange runs (class docstring of `exchange`).  Overlap needs ZeRO-1 over flat buffers, a
+        second segment and a backend whose collectives are stream-ordered and graph-capturable (RCCL): it is probed once --
+        a captured all-reduce on a forked side stream, replayed and checked, agreed on by all ranks -- and the trainer falls back
+        to the serial form with a warning if this software stack refuses."""
+        import os
+        mode = mode or os.environ.get("HOLOSCENE_EXCHANGE", "overlap")
+        if mode not in ("overlap", "serial"):
+            raise ValueError(f"exchange must be 'overlap' or 'serial', not {mode!r}")
+        self._overlap = False
+        self._early_done = ()
+        self._xchg_stream = None
+        if not (self.dp and self.zero1 and self.flat is not None and len(self.flat.segments) > 1 and mode == "overlap"):
+            return
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_backend() == "nccl"):
+            return
+        self._xchg_stream = torch.cuda.Stream(self.device)
+        ok = self._probe_captured_collective() if self.use_graph else True
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        self._overlap = bool(flag.item() > 0)
+        if not self._overlap and self.rank == 0:
+            import warnings
+            warnings.warn("collectives could not be captured in a HIP graph on a side stream: exchanging serially after the graph")
+        if self._overlap:
+            from ..hashencoder.backend import ScatterWatch
+            self.flat.params[0]._hs_scatter_watch = ScatterWatch()     # the early segment's table (flat.py lays it out first)
+
+    def _probe_captured_collective(self):
+        import torch.distributed as dist
+        try:
+            t = torch.ones(1024, device=self.device)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                cur = torch.cuda.current_stream()
+                self._xchg_stream.wait_stream(cur)
+                with torch.cuda.stream(self._xchg_stream):
+                    dist.all_reduce(t)
+                cur.wait_stream(self._xchg_stream)
+            g.replay()
+            torch.cuda.synchronize()
+            return bool((t == float(dist.get_world_size())).all())
+        except Exception:       # noqa: BLE001 -- any refusal means "serial"
+            return False
+
+    def _arm_early_exchange(self):
+        """Start of an iteration body (before the forward pass, so that the producers of the colour table's gradient are counted):
+        advance the optimiser state once and ask to be told when that gradient is final."""
+        self._early_done = ()
+        if self._overlap:
+            self.flat.tick()
+            self.flat.params[0]._hs_scatter_watch.arm(self._exchange_early_segment)
+
+    def _exchange_early_segment(self):
+        """Called by the colour table's last scatter (autograd thread, the scatter's stream current): fork the exchange stream off
+        that point and run the segment's reduce-scatter -> shard Adam -> all-gather there, under the trunk backward.  Inside a
+        capture this forks the graph; `_finish_exchange` joins it."""
+        cur = torch.cuda.current_stream()
+        self._xchg_stream.wait_stream(cur)
+        with torch.cuda.stream(self._xchg_stream):
+            dist_util.exchange_segment(self.flat, 0, self.world_size)
+        self._early_done = (0,)
+
+    def _finish_exchange(self):
+        """End of the backward pass: exchange what has not been exchanged yet, join the exchange stream."""
+        dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1, done=self._early_done)
+        if self._early_done:
+            torch.cuda.current_stream().wait_stream(self._xchg_stream)
+        self._early_done = ()
+
     # ------------------------------------------------------------------ eager path
     def _exchange_and_step(self):
         if self.flat is not None:
-            if self.world_size > 1:
-                dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+            if self.dp:
+                self._finish_exchange()
             else:
                 self.flat.step()
         else:
-            if self.world_size > 1:
+            if self.dp:
                 dist_util.average_gradients(self.model.parameters(), self.world_size)
             self.optimizer.step()
             self.scheduler.step()
@@ -127,6 +210,7 @@ class Stage1Trainer:
         self.model.train()
         if self.flat is not None:
             self.flat.zero_grad()
+            self._arm_early_exchange()
         else:
             self.optimizer.zero_grad(set_to_none=True)
         out = self.model(model_input, indices, iter_step=self.iter_step, rng=rng)
@@ -142,22 +226,35 @@ class Stage1Trainer:
     # ------------------------------------------------------------------ graph path
     def _graph_body(self, st, with_bg, call_reg):
         self.flat.zero_grad()
+        self._arm_early_exchange()
         bg = st["bg"] if with_bg else None
         out = self.model.render(st["rays"], st["z_vals"], st["z_eik"], None, bg=bg)
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
-        if self.world_size == 1 and not self.freeze_parameters:
-            self.flat.step()
+        self._update_in_body()
         return out, loss_out
+
+    def _update_in_body(self):
+        """Tail of a captured iteration body: the Adam step (single process), or -- when the collectives are capturable -- the
+        whole data-parallel exchange; otherwise the exchange follows the replay (`_after_replay`)."""
+        if not self.dp:
+            if not self.freeze_parameters:
+                self.flat.step()
+        elif self._overlap:
+            self._finish_exchange()
+
+    def _after_replay(self):
+        if self.dp and not self._overlap:
+            dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
 
     # ------------------------------------------------------------------ whole-iteration graph
     def _capture_mode(self):
         """With a process group alive, its watchdog thread polls events of in-flight collectives (cudaEventQuery / hipEventQuery) --
         a call that is illegal for ANY thread while some stream captures in "global" mode and would invalidate the capture.  The
         captured region itself contains no collective, so thread-local capture checking is the right scope for N > 1."""
-        return "thread_local" if self.world_size > 1 else "global"
+        return "thread_local" if self.dp else "global"
 
     def _full_graph_ok(self):
         """Rays, sampler (device-side loop control), render, loss, backward and Adam in ONE graph: possible whenever the sampler
@@ -168,6 +265,7 @@ class Stage1Trainer:
     def _full_body(self, st, with_bg, call_reg):
         model = self.model
         self.flat.zero_grad()
+        self._arm_early_exchange()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         with model.density.shared_beta(), _net.shared_effective_weights(model.weight_norm_layers()):
             with torch.no_grad():
@@ -191,8 +289,7 @@ class Stage1Trainer:
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
-        if self.world_size == 1 and not self.freeze_parameters:
-            self.flat.step()
+        self._update_in_body()
         return out, loss_out
 
     @staticmethod
@@ -268,8 +365,7 @@ class Stage1Trainer:
             self._copy_tree(st["depths"], {k: v.to(self.device) for k, v in depths.items()})
         entry["graph"].replay()
         self.model.ray_sampler._rounds = entry["rounds"]
-        if self.world_size > 1:
-            dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+        self._after_replay()
         self.iter_step += 1
         return entry["out"], entry["loss"]
 
@@ -285,8 +381,7 @@ class Stage1Trainer:
                 dataset.write_batch(entry["static"]["input"], entry["static"]["gt"])
                 entry["graph"].replay()
                 self.model.ray_sampler._rounds = entry["rounds"]
-                if self.world_size > 1:
-                    dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+                self._after_replay()
                 self.iter_step += 1
                 return entry["out"], entry["loss"]
         return self.train_step(*dataset.next_batch())
@@ -342,7 +437,6 @@ class Stage1Trainer:
         for dl, sl in groups.values():
             torch._foreach_copy_(dl, sl)
         entry["graph"].replay()
-        if self.world_size > 1:
-            dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
+        self._after_replay()
         self.iter_step += 1
         return entry["out"], entry["loss"]

@@ -104,6 +104,7 @@ class _TinyModel(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.grid = torch.nn.Parameter(torch.randn(1001, 2))
+        self.cgrid = torch.nn.Parameter(torch.randn(1003, 2))       # the "colour table": 2 006 elements, not a multiple of 4 * world
         self.net = torch.nn.Linear(7, 5)
         self.beta = torch.nn.Parameter(torch.tensor(0.1))
         me = self
@@ -111,13 +112,13 @@ class _TinyModel(torch.nn.Module):
         class NS:
             pass
         self.implicit_network, self.rendering_network, self.density = NS(), NS(), NS()
-        self.implicit_network.grid_parameters = lambda: [me.grid]
+        self.implicit_network.grid_parameters = lambda: [me.grid, me.cgrid]
         self.implicit_network.mlp_parameters = lambda: list(me.net.parameters())
         self.rendering_network.parameters = lambda: []
         self.density.parameters = lambda: [me.beta]
 
 
-def _flat_worker(rank, world, port, q, zero1):
+def _flat_worker(rank, world, port, q, zero1, segmented):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from holoscene_amd.hashencoder import backend
@@ -127,70 +128,90 @@ def _flat_worker(rank, world, port, q, zero1):
         setattr(backend._HipBackend, name, staticmethod(getattr(_TorchAdamKernels, name)))
     torch.manual_seed(0)            # identical replicas
     model = _TinyModel()
-    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1)
+    flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1,
+                    early_params=[model.cgrid] if segmented else None)
     assert flat.flat_m.numel() == (flat.padded // world if zero1 else flat.padded)
+    assert len(flat.segments) == (2 if segmented else 1)
+    if segmented:       # colour table first, then a pad up to the next multiple of 4 * world, then everything else
+        assert flat.params[0] is model.cgrid and flat.offsets[:2] == [0, 2008] and flat.segments == [(0, 2008), (2008, flat.padded)]
+    used = torch.zeros(flat.padded, dtype=torch.bool)
+    for p_, off in zip(flat.params, flat.offsets):
+        used[off:off + p_.numel()] = True
     g = torch.Generator().manual_seed(50 + rank)
     hist = []
-    for _ in range(2):
+    for it in range(2):
         flat.zero_grad()
-        local = torch.randn(flat.padded, generator=g)
-        local[flat.numel:] = 0
+        local = torch.randn(flat.padded, generator=g) * used        # pads carry zero gradients
         flat.flat_g.copy_(local)
-        hist.append(local.clone())
-        exchange_and_step_flat(flat, world, zero1=zero1)
+        hist.append({n: local[off:off + p_.numel()].clone().numpy() for (n, p_), off in zip(_named(model, flat), flat.offsets)})
+        if segmented and zero1 and it == 1:
+            # the trainer's overlapped form: the early segment is exchanged first (there: on a side stream, under the trunk
+            # backward), the rest at the end of the backward pass
+            from holoscene_amd.training.distributed import exchange_segment
+            flat.tick()
+            exchange_segment(flat, 0, world)
+            exchange_and_step_flat(flat, world, zero1=True, done=(0,))
+        else:
+            exchange_and_step_flat(flat, world, zero1=zero1)
     # checkpoint export under ZeRO-1: the per-parameter Adam state must be the FULL moments on whichever rank saves
     from types import SimpleNamespace
     from holoscene_amd.training import checkpoint as ck
     tr = SimpleNamespace(flat=flat, model=model, lr=5e-4, lr_factor=20.0, decay_rate=0.1, decay_steps=1000, zero1=zero1, world_size=world)
     opt_sd, _ = ck.optimizer_state_dicts(tr)
-    moments = [(s_["exp_avg"].numpy().copy(), s_["exp_avg_sq"].numpy().copy(), float(s_["step"])) for s_ in opt_sd["state"].values()]
-    q.put((rank, [h.numpy() for h in hist], flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()},
-           moments))
+    moments = [(s_["exp_avg"].numpy().copy(), s_["exp_avg_sq"].numpy().copy(), float(s_["step"])) for _, s_ in sorted(opt_sd["state"].items())]      # by parameter index of the saved format
+    q.put((rank, hist, flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()},
+           moments, [n for n, _ in _named(model, flat)]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _named(model, flat):
+    """(name, parameter) in the flat optimiser's order."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    return [(names[id(p)], p) for p in flat.params]
 
 
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("zero1", [True, False])
-def test_flat_exchange_equals_single_process_mean_gradient(zero1):
+@pytest.mark.parametrize("zero1,segmented", [(True, False), (False, False), (True, True), (False, True)])
+def test_flat_exchange_equals_single_process_mean_gradient(zero1, segmented):
     """reduce-scatter -> shard-local Adam -> all-gather (ZeRO-1) and all-reduce -> full Adam both equal one process
     applying Adam to the mean of the ranks' gradients; replicas stay bit-identical."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q, zero1)) for r in range(world)]
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q, zero1, segmented)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, h0, flat0, params0, mom0), (_, h1, flat1, _, mom1) = res
+    (_, h0, flat0, params0, mom0, order), (_, h1, flat1, _, mom1, _) = res
     assert (flat0 == flat1).all(), "replicas diverged"
     # single-process reference with torch.optim.Adam on the same groups
     torch.manual_seed(0)
     ref = _TinyModel()
-    opt = torch.optim.Adam([{"params": [ref.grid], "lr": 5e-4 * 20}, {"params": list(ref.net.parameters()), "lr": 5e-4},
+    opt = torch.optim.Adam([{"params": [ref.grid, ref.cgrid], "lr": 5e-4 * 20}, {"params": list(ref.net.parameters()), "lr": 5e-4},
                             {"params": [ref.beta], "lr": 5e-4}], betas=(0.9, 0.99), eps=1e-15)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.1 ** (1 / 1000))
-    plist = [ref.grid] + list(ref.net.parameters()) + [ref.beta]
+    by_name = dict(ref.named_parameters())
+    plist = [by_name[n] for n in order]          # the flat optimiser's order (colour table first when segmented)
     for a, b in zip(h0, h1):
-        mean = (torch.from_numpy(a) + torch.from_numpy(b)) / 2
-        off = 0
-        for p in plist:
-            p.grad = mean[off:off + p.numel()].view_as(p).clone()
-            off += p.numel()
+        for n, p in by_name.items():
+            p.grad = ((torch.from_numpy(a[n]) + torch.from_numpy(b[n])) / 2).view_as(p).clone()
         opt.step()
         sched.step()
     for n, p in ref.named_parameters():
         assert torch.allclose(p.detach(), torch.from_numpy(params0[n]), rtol=1e-5, atol=1e-7), n
     # the exported optimiser state (either rank's) = single-process Adam's moments for EVERY parameter, not just the saver's shard
+    assert len(plist) == 5
+    saved_order = [ref.grid, ref.cgrid] + list(ref.net.parameters()) + [ref.beta]    # torch.optim.Adam's (checkpoint format), not the flat one
     for mom in (mom0, mom1):
-        assert len(mom) == len(plist)
-        for p, (m, v, step) in zip(plist, mom):
+        assert len(mom) == len(saved_order)
+        for p, (m, v, step) in zip(saved_order, mom):
             st = opt.state[p]
             assert step == 2.0
             assert torch.allclose(st["exp_avg"], torch.from_numpy(m).view_as(p), rtol=1e-4, atol=1e-7)
