@@ -138,9 +138,9 @@ class ScatterWatch:
     place calls `expect_scatter` in its forward (only when the table requires a gradient there) and `scatter_done` after the
     scatter; the callback runs -- on the autograd thread, with the scatter's stream current -- when the count returns to zero.
     A producer that takes another route to the gradient (double backward) never reports done, so the callback simply does
-    not fire and the listener exchanges the segment at the end of the pass.  Reporting producers: the colour table's --
-    _fused_appearance (model/network.py) and HashEncoder's own Function (hashgrid.py); the SDF table's gradient is final only
-    with the last kernels of the pass, so its producers do not report."""
+    not fire and the listener exchanges the segment at the end of the pass.  Every Function that scatters into a table in
+    place reports (model/network.py: _hash_encode_jac, _trunk_input, _fused_trunk, _fused_trunk_render, _fused_appearance;
+    hashgrid.py: _hash_encode), so a watched table never has an uncounted in-place producer."""
 
     def __init__(self):
         self.pending, self.callback = 0, None

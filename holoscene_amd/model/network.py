@@ -45,6 +45,8 @@ class _hash_encode_jac(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x01, embeddings, offsets, S, H):
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        if ctx.needs_input_grad[1]:
+            _be.expect_scatter(ctx.table)
         x01 = x01.contiguous()
         B, D = x01.shape
         L = offsets.shape[0] - 1
@@ -68,6 +70,8 @@ class _hash_encode_jac(torch.autograd.Function):
             _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(),
                                  x01, offsets, target, B, D, C, L, S, H)
             g_emb = None if inplace else target
+            if inplace:
+                _be.scatter_done(table)
         if ctx.needs_input_grad[0] and g_feat is not None:
             g_x = torch.empty_like(x01)
             _be._backend.bwd(g_feat.contiguous(), x01, offsets, None, B, D, C, L, S, H, dydx, g_x)
@@ -96,6 +100,8 @@ class _trunk_input(torch.autograd.Function):
         """center / obj_scale: the per-object frame of SingleObjectImplicitNetworkGrid (network.py:1947): the grid is looked up at
         (x - center) / obj_scale / divide_factor while the positional encoding sees x itself."""
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        if ctx.needs_input_grad[1]:
+            _be.expect_scatter(ctx.table)
         x = x.contiguous()
         xg = x if center is None else (x - center) / obj_scale
         x01 = ((xg / divide_factor + 1.0) / 2.0).contiguous()   # HashEncoder.forward's mapping to [0,1] (hashgrid.py:158)
@@ -126,6 +132,8 @@ class _trunk_input(torch.autograd.Function):
             target = table.grad if inplace else torch.zeros_like(embeddings)
             _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
             g_emb = None if inplace else target
+            if inplace:
+                _be.scatter_done(table)
         return None, g_emb, None, None, None, None, None, None, None, None
 
 
@@ -283,6 +291,8 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
         g_emb = None if inplace else target
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
                              ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
+        if inplace:
+            _be.scatter_done(table)     # data parallelism: the SDF table's segment can go while the weight-gradient GEMMs below run
     gW2 = gW1 = gW0 = None
     if need_w:
         Xm = X.view(M, X.shape[-1])       # [M, 96] reference column order, or the wave-tile kernel's [M, 80] image in its own order
@@ -303,6 +313,8 @@ class _fused_trunk(torch.autograd.Function):
     def forward(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
         ctx.set_materialize_grads(False)
         Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
+        if ctx.needs_input_grad[1]:
+            _be.expect_scatter(ctx.table)
         ctx.save_for_backward(*saved)
         Y = Y.view(x.shape[0], 4, -1)
         return Y[:, 0].contiguous(), Y[:, 1:].transpose(1, 2).contiguous()
@@ -345,6 +357,8 @@ class _fused_trunk_render(torch.autograd.Function):
                                    split=(n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta))
         if Y is not None:       # the kernel that ran does not produce the split outputs itself
             _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta)
+        if ctx.needs_input_grad[2]:
+            _be.expect_scatter(ctx.table)
         ctx.save_for_backward(*saved, idx)
         ctx.n_main = n_main
         ctx.mark_non_differentiable(idx)
@@ -384,7 +398,7 @@ class _fused_appearance(torch.autograd.Function):
     def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         if ctx.needs_input_grad[3]:
-            _be.expect_scatter(ctx.table)      # data parallelism: the colour table's segment is exchanged once its last scatter has run
+            _be.expect_scatter(ctx.table)      # data parallelism: a table's segment is exchanged once its last scatter has run
         be = _be._backend
         points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
         if x01 is None:

@@ -11,11 +11,12 @@ State-dict names and shapes are untouched (the views keep their module attribute
 
 Segments (data parallelism only).  The exchange of a parameter can start as soon as ITS gradient is final, and the colour table's is
 final 0.6-0.75 ms before the iteration's last kernel (its scatter runs right after the appearance backward; the trunk backward,
-the SDF table's scatter and the weight gradients follow).  ``early_params`` therefore splits the buffer into two independently
-sharded segments, [early tables | pad] and [everything else | pad]: each is reduce-scattered / stepped / all-gathered on its own
-(training/distributed.py::exchange_segment), the first one on a side stream under the trunk backward (trainer.py).  Each
-segment is a whole number of 16-byte quads per rank; the pad elements are zero parameters with zero gradients.  Without
-``early_params`` there is one segment and the layout is the plain concatenation.
+the SDF table's scatter and the trunk's weight-gradient GEMMs follow), the SDF table's ~0.2 ms before it.  ``early_params``
+therefore splits the buffer into independently sharded segments, [early table 0 | pad] [early table 1 | pad] ... [everything
+else | pad]: each is reduce-scattered / stepped / all-gathered on its own (training/distributed.py::exchange_segment), the early
+ones on a side stream under the rest of the backward pass (trainer.py).  Each segment is a whole number of 16-byte quads per
+rank; the pad elements are zero parameters with zero gradients.  Without ``early_params`` there is one segment and the layout is
+the plain concatenation.
 """
 import ctypes
 
@@ -29,8 +30,8 @@ class FlatAdam:
                  shard_moments=False, early_params=None):
         """shard_moments (ZeRO-1): this rank stores the Adam moments of its own 1/world_size slice (of every segment) only; the
         update then goes through `tick` + `step_segment` and checkpoints gather the slices (`gather_moments`).
-        early_params: hash tables (members of the first optimiser group) whose gradients are final early in the backward pass;
-        they are laid out first and form a segment of their own (module docstring)."""
+        early_params: hash tables (members of the first optimiser group) in the order in which their gradients become final in the
+        backward pass; they are laid out first, each as a segment of its own (module docstring)."""
         groups = [list(model.implicit_network.grid_parameters()),
                   list(model.implicit_network.mlp_parameters()) + list(model.rendering_network.parameters()),
                   list(model.density.parameters())]
@@ -43,15 +44,18 @@ class FlatAdam:
         dev = self.params[0].device
         align = 4 * world_size                      # every rank's shard of every segment is a whole number of 16-byte quads
         up = lambda n: (n + align - 1) // align * align  # noqa: E731
-        self.offsets, off, split = [], 0, None      # flat index of each parameter's first element
+        self.offsets, off, cuts = [], 0, [0]        # flat index of each parameter's first element; segment boundaries
         for i, p in enumerate(self.params):
-            if early and i == len(early):
-                off = split = up(off)
+            if 0 < i <= len(early):                 # a boundary after every early table
+                off = up(off)
+                cuts.append(off)
             self.offsets.append(off)
             off += p.numel()
-        self.numel = off                            # end of the last parameter (flat index space, inner pad included)
+        self.numel = off                            # end of the last parameter (flat index space, inner pads included)
         self.padded = up(off)
-        self.segments = [(0, self.padded)] if split is None or split == self.padded else [(0, split), (split, self.padded)]
+        if cuts[-1] != self.padded:
+            cuts.append(self.padded)
+        self.segments = list(zip(cuts[:-1], cuts[1:]))
         self.flat_p = torch.zeros(self.padded, device=dev)
         self.flat_g = torch.zeros(self.padded, device=dev)
         self.shards = [(b + rank * ((e - b) // world_size), b + (rank + 1) * ((e - b) // world_size)) for b, e in self.segments]

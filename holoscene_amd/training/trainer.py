@@ -62,7 +62,7 @@ class Stage1Trainer:
                  freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None):
         """data_parallel: run the gradient exchange (default: world_size > 1; True with a one-rank process group exercises the
         collectives' code path on a single GPU).  exchange: "overlap" (default; env HOLOSCENE_EXCHANGE) = ZeRO-1 per segment with
-        the colour table's segment exchanged on a side stream as soon as its gradient is final, collectives captured inside the
+        each hash table's segment exchanged on a side stream as soon as its gradient is final, collectives captured inside the
         iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph."""
         torch.manual_seed(seed)
         self.conf = conf
@@ -79,10 +79,13 @@ class Stage1Trainer:
         self.flat = None
         if optimizer == "flat":
             from .flat import FlatAdam
-            # ZeRO-1 under data parallelism: the colour table becomes a segment of its own (its gradient is final right after the
-            # appearance backward, 0.6-0.75 ms before the end of the pass: flat.py)
+            # ZeRO-1 under data parallelism: the hash tables become segments of their own, in the order in which the backward pass
+            # finishes their gradients -- colour table (right after the appearance backward, 0.6-0.75 ms before the end of the
+            # pass), SDF table (before the trunk's weight-gradient GEMMs): flat.py
             net = self.model.implicit_network
-            early = [net.color_encoding.embeddings] if (self.dp and zero1 and getattr(net, "color_grid_feature", False)) else None
+            early = None
+            if self.dp and zero1 and getattr(net, "use_grid_feature", False):
+                early = ([net.color_encoding.embeddings] if getattr(net, "color_grid_feature", False) else []) + [net.encoding.embeddings]
             self.flat = FlatAdam(self.model, self.lr, lr_factor, decay_rate, decay_steps, world_size=world_size, rank=rank,
                                  shard_moments=zero1 and world_size > 1, early_params=early)
             self.optimizer = self.scheduler = None
@@ -138,7 +141,8 @@ class Stage1Trainer:
             warnings.warn("collectives could not be captured in a HIP graph on a side stream: exchanging serially after the graph")
         if self._overlap:
             from ..hashencoder.backend import ScatterWatch
-            self.flat.params[0]._hs_scatter_watch = ScatterWatch()     # the early segment's table (flat.py lays it out first)
+            for t in self._early_tables():
+                t._hs_scatter_watch = ScatterWatch()
 
     def _probe_captured_collective(self):
         import torch.distributed as dist
@@ -158,23 +162,28 @@ class Stage1Trainer:
         except Exception:       # noqa: BLE001 -- any refusal means "serial"
             return False
 
+    def _early_tables(self):
+        """The tables that own segments 0 .. n-2 of the flat buffers (flat.py lays them out first, one segment each)."""
+        return self.flat.params[:len(self.flat.segments) - 1]
+
     def _arm_early_exchange(self):
-        """Start of an iteration body (before the forward pass, so that the producers of the colour table's gradient are counted):
-        advance the optimiser state once and ask to be told when that gradient is final."""
+        """Start of an iteration body (before the forward pass, so that the producers of the tables' gradients are counted):
+        advance the optimiser state once and ask to be told when each table's gradient is final."""
         self._early_done = ()
         if self._overlap:
             self.flat.tick()
-            self.flat.params[0]._hs_scatter_watch.arm(self._exchange_early_segment)
+            for s_, t in enumerate(self._early_tables()):
+                t._hs_scatter_watch.arm(lambda s_=s_: self._exchange_early_segment(s_))
 
-    def _exchange_early_segment(self):
-        """Called by the colour table's last scatter (autograd thread, the scatter's stream current): fork the exchange stream off
-        that point and run the segment's reduce-scatter -> shard Adam -> all-gather there, under the trunk backward.  Inside a
-        capture this forks the graph; `_finish_exchange` joins it."""
+    def _exchange_early_segment(self, s_):
+        """Called by the last scatter into table s_ (autograd thread, the scatter's stream current): fork the exchange stream off
+        that point and run the segment's reduce-scatter -> shard Adam -> all-gather there, under the rest of the backward
+        pass.  Inside a capture this forks the graph; `_finish_exchange` joins it."""
         cur = torch.cuda.current_stream()
         self._xchg_stream.wait_stream(cur)
         with torch.cuda.stream(self._xchg_stream):
-            dist_util.exchange_segment(self.flat, 0, self.world_size)
-        self._early_done = (0,)
+            dist_util.exchange_segment(self.flat, s_, self.world_size)
+        self._early_done = self._early_done + (s_,)
 
     def _finish_exchange(self):
         """End of the backward pass: exchange what has not been exchanged yet, join the exchange stream."""

@@ -129,11 +129,12 @@ def _flat_worker(rank, world, port, q, zero1, segmented):
     torch.manual_seed(0)            # identical replicas
     model = _TinyModel()
     flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1,
-                    early_params=[model.cgrid] if segmented else None)
+                    early_params=[model.cgrid, model.grid] if segmented else None)
     assert flat.flat_m.numel() == (flat.padded // world if zero1 else flat.padded)
-    assert len(flat.segments) == (2 if segmented else 1)
-    if segmented:       # colour table first, then a pad up to the next multiple of 4 * world, then everything else
-        assert flat.params[0] is model.cgrid and flat.offsets[:2] == [0, 2008] and flat.segments == [(0, 2008), (2008, flat.padded)]
+    assert len(flat.segments) == (3 if segmented else 1)
+    if segmented:       # colour table, SDF table, everything else -- each padded up to the next multiple of 4 * world
+        assert flat.params[0] is model.cgrid and flat.params[1] is model.grid and flat.offsets[:3] == [0, 2008, 4016]
+        assert flat.segments == [(0, 2008), (2008, 4016), (4016, flat.padded)]
     used = torch.zeros(flat.padded, dtype=torch.bool)
     for p_, off in zip(flat.params, flat.offsets):
         used[off:off + p_.numel()] = True
@@ -145,12 +146,13 @@ def _flat_worker(rank, world, port, q, zero1, segmented):
         flat.flat_g.copy_(local)
         hist.append({n: local[off:off + p_.numel()].clone().numpy() for (n, p_), off in zip(_named(model, flat), flat.offsets)})
         if segmented and zero1 and it == 1:
-            # the trainer's overlapped form: the early segment is exchanged first (there: on a side stream, under the trunk
-            # backward), the rest at the end of the backward pass
+            # the trainer's overlapped form: the tables' segments are exchanged as their gradients become final (there: on a
+            # side stream, under the rest of the backward pass), what is left at the end of the pass
             from holoscene_amd.training.distributed import exchange_segment
             flat.tick()
             exchange_segment(flat, 0, world)
-            exchange_and_step_flat(flat, world, zero1=True, done=(0,))
+            exchange_segment(flat, 1, world)
+            exchange_and_step_flat(flat, world, zero1=True, done=(0, 1))
         else:
             exchange_and_step_flat(flat, world, zero1=zero1)
     # checkpoint export under ZeRO-1: the per-parameter Adam state must be the FULL moments on whichever rank saves

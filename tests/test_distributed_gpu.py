@@ -129,8 +129,9 @@ def test_two_ranks_sharing_the_gpu_over_gloo(zero1):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The trainer's overlapped exchange: colour-table segment exchanged on a side stream as soon as its last scatter has run,
-# all collectives captured INSIDE the whole-iteration graph.  One GPU: a one-rank RCCL group (data_parallel=True) takes
+# The trainer's overlapped exchange: each hash table's segment exchanged on a side stream as soon as its last scatter has run
+# (colour table under the trunk backward, SDF table under the trunk's weight-gradient GEMMs), all collectives captured INSIDE
+# the whole-iteration graph.  One GPU: a one-rank RCCL group (data_parallel=True) takes
 # exactly the code path of an N-rank run -- graph fork in the autograd thread, captured reduce_scatter_tensor /
 # all_gather_into_tensor, segment-wise Adam -- and must reproduce the single-process trainer.
 def _trainer_worker(port, q):
@@ -152,9 +153,9 @@ def _trainer_worker(port, q):
         if tr._overlap:
             orig = tr._exchange_early_segment
 
-            def counted():
+            def counted(s_):
                 fired[0] += 1
-                orig()
+                orig(s_)
             tr._exchange_early_segment = counted
         torch.manual_seed(77)
         for _ in range(steps):          # iteration 0 also runs the background-patch pass: two producers of the colour table's gradient
@@ -182,11 +183,11 @@ def test_trainer_overlapped_exchange_in_graph_equals_single_process():
     p.join(120)
     assert p.exitcode == 0
     assert not pinfo["overlap"] and len(pinfo["segments"]) == 1
-    assert oinfo["overlap"] and len(oinfo["segments"]) == 2 and "color_encoding" in oinfo["first"]
-    assert not sinfo["overlap"] and len(sinfo["segments"]) == 2
+    assert oinfo["overlap"] and len(oinfo["segments"]) == 3 and "color_encoding" in oinfo["first"]
+    assert not sinfo["overlap"] and len(sinfo["segments"]) == 3
     # every captured variant (with / without the background pass) ran its body three times (two warm-ups + the capture), and in
-    # every one of them the colour table reported its gradient final -> the early segment went to the side stream each time
-    assert oinfo["graphs"] == 2 and oinfo["fired"] == 3 * oinfo["graphs"], oinfo
+    # every one of them both tables reported their gradients final -> both early segments went to the side stream each time
+    assert oinfo["graphs"] == 2 and oinfo["fired"] == 2 * 3 * oinfo["graphs"], oinfo
     assert pinfo["step"] == oinfo["step"] == sinfo["step"] == 2
     for name, want in plain.items():
         scale = float(np.abs(want).max())
