@@ -104,7 +104,11 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
                              float *__restrict__ fe, float *__restrict__ ee, int n, float beta, int tid, float *sc) {
     int lo, hi;
     chunk_of(n, tid, NT, lo, hi);
-    // The kernel is instruction-issue-bound (1 024 rays x 4 waves x 11 evaluations of this function): the four IEEE divisions per
+    // The kernel is instruction-issue-bound (1 024 rays x 4 waves x 11 evaluations of this function; tools/exp/sampler_prof.hip: an
+    // evaluation takes ~2 650 cycles with four waves sharing each SIMD = ~660 issue cycles per wave = ~165 wave instructions at 4
+    // cycles each.  A speculative search that resolves two bisection levels per pass -- mid and both candidates for the next
+    // midpoint in one evaluation, bit-identical results -- does 1.5x the work in 6 instead of 11 passes and was SLOWER, 27.5 ->
+    // 34.8 us: there is no latency chain to shorten): the four IEEE divisions per
     // section of the textbook form (|s| / beta, d* / beta, 1 / beta, 1 / (4 beta^2); ~10 instructions each) become multiplications by
     // ONE reciprocal per evaluation.  That moves the bound by <= 1 ulp per factor -- the same order as the hardware exponentials
     // above, and like them it can flip a bisection decision only if the bound lies that close to eps.
@@ -153,6 +157,13 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
     atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
+#ifdef HS_SAMPLER_PROFILE      // tools/exp/sampler_prof.hip: s_memtime stamps of the phases of one ray's update
+__device__ unsigned long long g_sampler_prof[1024 * 8];
+#define HS_SSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_sampler_prof[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HS_SSTAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------ update
 template <int kUpd>
 __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
     if (r >= R) return;
     if (m_dev) m_old = *m_dev;                      // device-controlled rounds: the merged count lives in hsSamplerCtl
+    HS_SSTAMP(0);
     const int m = m_old + s_new;
     float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m, *sc = lds + 6 * m;
     float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
@@ -172,6 +184,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     for (int i = lane; i < m_old; i += kUpd) { tz[i] = zr[i]; ts[i] = sr[i]; }
     for (int i = lane; i < s_new; i += kUpd) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
     __syncthreads();
+    HS_SSTAMP(1);
     // stable merge by rank (old before new on ties)
     for (int i = lane; i < m_old; i += kUpd) {
         const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
         z[p] = tz[m_old + i]; sdf[p] = ts[m_old + i];
     }
     __syncthreads();
+    HS_SSTAMP(2);
     for (int i = lane; i < m; i += kUpd) { zr[i] = z[i]; sr[i] = sdf[i]; }
     const int n = m - 1;
     for (int i = lane; i < n; i += kUpd) {  // Theorem 1 bound d* per section
@@ -199,9 +213,11 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
         dstar[i] = (sa * sb == 1.f) ? d : 0.f;
     }
     __syncthreads();
+    HS_SSTAMP(3);
     const float beta0 = *beta0_p;
     float hi = beta_io[r];
     if (error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
+    HS_SSTAMP(4);
     float lo = beta0;
     // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
     // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
@@ -212,6 +228,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
         if (err <= eps) hi = mid;
         else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
     }
+    HS_SSTAMP(5);
     if (lane == 0) {
         beta_io[r] = hi;
         // only rays still above beta0 can make the round's test (max beta > beta0, ray_sampler.py:204) true; the others skip the
