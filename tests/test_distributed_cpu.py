@@ -161,6 +161,16 @@ def _flat_worker(rank, world, port, q, zero1, segmented):
     tr = SimpleNamespace(flat=flat, model=model, lr=5e-4, lr_factor=20.0, decay_rate=0.1, decay_steps=1000, zero1=zero1, world_size=world)
     opt_sd, _ = ck.optimizer_state_dicts(tr)
     moments = [(s_["exp_avg"].numpy().copy(), s_["exp_avg_sq"].numpy().copy(), float(s_["step"])) for _, s_ in sorted(opt_sd["state"].items())]      # by parameter index of the saved format
+    # ... and loading that export puts every rank's own slices (of every segment) back where they were
+    sched_sd = ck.optimizer_state_dicts(tr)[1]
+    keep_m, keep_v = flat.flat_m.clone(), flat.flat_v.clone()
+    flat.flat_m.zero_()
+    flat.flat_v.zero_()
+    assert ck.load_optimizer_state(tr, opt_sd, sched_sd) == 2
+    mask = torch.ones_like(keep_m, dtype=torch.bool)
+    if not zero1:        # full-length buffers: compare the parameters' elements (the pads are not part of the saved format)
+        mask = used
+    assert torch.equal(flat.flat_m[mask], keep_m[mask]) and torch.equal(flat.flat_v[mask], keep_v[mask])
     q.put((rank, hist, flat.flat_p.numpy().copy(), {n: p.detach().numpy().copy() for n, p in model.named_parameters()},
            moments, [n for n, _ in _named(model, flat)]))
     dist.barrier()
