@@ -3,11 +3,12 @@
 // Replaces the ~540 tiny PyTorch kernels per sampler round of the reference's
 // ErrorBoundSampler.get_z_vals (model/ray_sampler.py:130-287, get_error_bound :450-458).
 //
-// One 64-lane wave owns one ray.  The ray's sorted sample depths, SDF values and
-// derived per-section quantities live in LDS (<= 6 arrays x M floats, M <= 1024);
-// every cumulative sum is a two-level scan (serial inside a lane's contiguous
-// chunk, wave shuffle scan across lanes), every max a wave shuffle reduction, the
-// 10-step beta bisection runs entirely in registers/LDS with no global traffic.
+// One workgroup owns one ray (four waves in the update kernel, two in the draw kernel, one in
+// the rest).  The ray's sorted sample depths, SDF values and derived per-section quantities live
+// in LDS (<= 6 arrays x M floats, M <= 1024); every cumulative sum is a three-level scan (serial
+// inside a thread's contiguous chunk, DPP scan across the lanes of a wave, prefix over the waves
+// through LDS), every max likewise, the 10-step beta bisection runs entirely in registers/LDS
+// with no global traffic.
 //
 //   k_sampler_update  merge the round's new samples+SDFs into the sorted set (merge by
 //                     rank: both inputs are sorted), d* (Heron bound, :165-178), beta line
@@ -94,6 +95,19 @@ __device__ __forceinline__ float block_max(float v, float *sc, int tid) {   // s
     float r = sc[0];
 #pragma unroll
     for (int j = 1; j < kUpdWaves; j++) r = fmaxf(r, sc[j]);
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float *sc, int tid) {   // sc: NT / 64 floats, distinct from the scan's
+    constexpr int kW = NT / kWave;
+    v = wave_sum(v);
+    if constexpr (kW == 1) return v;
+    if ((tid & 63) == 0) sc[tid >> 6] = v;
+    __syncthreads();
+    float r = sc[0];
+#pragma unroll
+    for (int j = 1; j < kW; j++) r += sc[j];
     return r;
 }
 
@@ -291,7 +305,13 @@ struct DrawExt {
     float divide_factor;
 };
 
-__global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
+// kDraw threads per ray (default 128: one wave per ray leaves a SIMD with ONE wave walking 6-7 sections through libm exp / expm1
+// with every LDS and transcendental latency exposed -- 15.9-17.6 us per launch at 64 threads, 11.9-12.4 at 128, 11.6-15.3 at 256 in
+// the iteration; HOLOSCENE_SAMPLER_DRAW_THREADS = 64 | 128 | 256 for A/B).
+// The cumulative sums are chunk sums in section order + a scan over the threads, so their rounding depends on the chunking -- as
+// it does against torch.cumsum in any case; the parity tests bound the drawn depths, not the bit pattern.
+template <int kDraw>
+__global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
                                                          const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
                                                          int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev,
                                                          DrawExt ext) {
@@ -314,13 +334,13 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
     if (r >= R) return;
     float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
     const float *zr = z_in + (size_t)r * ld, *sr = sdf_in + (size_t)r * ld;
-    float *sdf = lds + 3 * m;
-    for (int i = lane; i < m; i += kWave) { z[i] = zr[i]; sdf[i] = sr[i]; }
+    float *sdf = lds + 3 * m, *sc = lds + 4 * m;      // sc: 2 * waves (scan) + waves (sum) floats
+    for (int i = lane; i < m; i += kDraw) { z[i] = zr[i]; sdf[i] = sr[i]; }
     __syncthreads();
     const float beta = beta_in[r];
     const int n = m - 1;
     int lo, hi;
-    lane_chunk(n, lane, lo, hi);
+    chunk_of(n, lane, kDraw, lo, hi);
     // transmittance at the start of each section (exclusive scan of free energy)
     float fsum = 0.f, esum = 0.f;
     for (int i = lo; i < hi; i++) {
@@ -342,8 +362,9 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
             pdf[i] = ds;  // park d* for the second sweep
         }
     }
-    float f = wave_incl_scan(fsum, lane) - fsum;
-    float e = (mode == 0) ? wave_incl_scan(esum, lane) - esum : 0.f;
+    float f = fsum, e = esum;
+    block_excl_scan2<kDraw>(f, e, sc, lane);      // exclusive prefixes over the ray's threads
+    if (mode != 0) e = 0.f;
     float psum = 0.f;
     for (int i = lo; i < hi; i++) {
         const float d = z[i + 1] - z[i];
@@ -360,15 +381,16 @@ __global__ __launch_bounds__(kWave) void k_sampler_draw(const float *__restrict_
         psum += p;
         f += fe;
     }
-    const float total = wave_sum(psum);
+    const float total = block_sum<kDraw>(psum, sc + 2 * (kDraw / kWave), lane);
     // cdf[0] = 0, cdf[i+1] = cumsum(pdf/total)
     float csum = 0.f;
     for (int i = lo; i < hi; i++) { pdf[i] = pdf[i] / total; csum += pdf[i]; }
-    float c = wave_incl_scan(csum, lane) - csum;
+    float c = csum, unused = 0.f;
+    block_excl_scan2<kDraw>(c, unused, sc, lane);
     for (int i = lo; i < hi; i++) { c += pdf[i]; cdf[i + 1] = c; }
     if (lane == 0) cdf[0] = 0.f;
     __syncthreads();
-    for (int j = lane; j < n_out; j += kWave) {
+    for (int j = lane; j < n_out; j += kDraw) {
         float u;
         if (u_in) {
             u = u_in[(size_t)r * n_out + j];
@@ -508,6 +530,15 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
+template <typename... Args>
+void launch_draw(int R, int m_cap, hipStream_t st, Args... args) {
+    static const int nt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_DRAW_THREADS"); const int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
+    const size_t lds = (4 * (size_t)m_cap + 3 * 4) * sizeof(float);
+    if (nt == 64) k_sampler_draw<64><<<dim3(R), dim3(64), lds, st>>>(args...);
+    else if (nt == 128) k_sampler_draw<128><<<dim3(R), dim3(128), lds, st>>>(args...);
+    else k_sampler_draw<256><<<dim3(R), dim3(256), lds, st>>>(args...);
+}
+
 }  // namespace
 
 extern "C" {
@@ -536,7 +567,7 @@ int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, con
     if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
     if (m_dev) m = ld;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * m * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev, DrawExt{});
+    launch_draw(R, m, (hipStream_t)stream, z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev, DrawExt{});
     return check_launch();
 }
 
@@ -550,8 +581,7 @@ int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const flo
     if (x && (!x01 || !cam_loc || !ray_dirs || divide_factor == 0.f)) return HS_ERR_NULL;
     if (ld < 2 || ld > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
     const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, cam_loc, ray_dirs, x, x01, divide_factor};
-    k_sampler_draw<<<dim3(R), dim3(kWave), 4 * ld * sizeof(float), (hipStream_t)stream>>>(z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R,
-                                                                                          hsGate{nullptr, nullptr}, nullptr, ext);
+    launch_draw(R, ld, (hipStream_t)stream, z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R, hsGate{nullptr, nullptr}, (const int32_t *)nullptr, ext);
     return check_launch();
 }
 
