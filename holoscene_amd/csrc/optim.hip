@@ -77,7 +77,38 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 
 }  // namespace
 
+// ---- many small tensors -> their slots in a flat buffer, one launch.  (torch._foreach_copy_ over the ~30 MLP gradients of an
+// iteration, 1.3 MB, is 24 workgroups that each walk a 64 k-element chunk: 17 us.)
+struct CopyJobs { hsCopyJob j[HS_COPY_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_copy_many(CopyJobs jobs) {
+    const hsCopyJob jb = jobs.j[blockIdx.y];
+    const bool quads = (((uintptr_t)jb.src | (uintptr_t)jb.dst) & 15) == 0;
+    const int64_t nq = quads ? jb.n >> 2 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<float4 *>(jb.dst)[i] = reinterpret_cast<const float4 *>(jb.src)[i];
+    for (int64_t i = 4 * nq + (int64_t)blockIdx.x * 256 + threadIdx.x; i < jb.n; i += (int64_t)gridDim.x * 256) jb.dst[i] = jb.src[i];
+}
+
 extern "C" {
+
+int hs_copy_many(const hsCopyJob *jobs, int32_t n_jobs, void *stream) {
+    if (n_jobs <= 0) return HS_OK;
+    if (!jobs) return HS_ERR_NULL;
+    if (n_jobs > HS_COPY_MAX_JOBS) return HS_ERR_ARG;
+    CopyJobs cj;
+    int64_t most = 0;
+    for (int i = 0; i < n_jobs; i++) {
+        if (!jobs[i].src || !jobs[i].dst) return HS_ERR_NULL;
+        if (jobs[i].n < 0) return HS_ERR_ARG;
+        cj.j[i] = jobs[i];
+        most = jobs[i].n > most ? jobs[i].n : most;
+    }
+    int64_t gx = (most / 4 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    k_copy_many<<<dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream>>>(cj);
+    return check_launch();
+}
 
 int hs_adam_tick(hsAdamState *state, float beta1, float beta2, double gamma, void *stream) {
     if (!state) return HS_ERR_NULL;

@@ -50,6 +50,10 @@ class hsSumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("slices", ctypes.c_int32), ("src_f32", ctypes.c_int32)]
 
 
+class hsCopyJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64)]
+
+
 class hsWnJob(ctypes.Structure):
     _fields_ = [("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("gW", ctypes.c_void_p), ("W", ctypes.c_void_p), ("gv", ctypes.c_void_p),
                 ("gg", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
@@ -95,7 +99,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
 
 
 def _check(rc, what):
@@ -526,6 +530,19 @@ class _HipBackend:
                 outs.append(part)
             _check(lib.hs_wgrad_rows(arr, len(grp), slices, _stream()), "hs_wgrad_rows")
         return outs
+
+    @staticmethod
+    def copy_many(dst, src):
+        """dst[i].copy_(src[i]) for lists of contiguous fp32 CUDA tensors of equal sizes, one launch per 64 pairs (hs_copy_many)."""
+        lib = load_library()
+        for k in range(0, len(dst), 64):
+            d_, s_ = dst[k:k + 64], src[k:k + 64]
+            arr = (hsCopyJob * len(d_))()
+            for a, d, s in zip(arr, d_, s_):
+                if d.numel() != s.numel():
+                    raise RuntimeError("copy_many: size mismatch")
+                a.src, a.dst, a.n = _dev(s, "src").value, _dev(d, "dst").value, d.numel()
+            _check(lib.hs_copy_many(arr, len(d_), _stream()), "hs_copy_many")
 
     @staticmethod
     def sum_slices(partials):

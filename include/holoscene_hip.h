@@ -251,6 +251,17 @@ int hs_adam_flat(float *p, const float *g, float *m, float *v, int64_t begin, in
 int hs_adam_flat_shard(float *p, const float *g, float *m, float *v, int64_t begin, int64_t end, int64_t g_base, int64_t mv_base,
                        const hsAdamState *state, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
+/* dst[0..n) = src[0..n) (fp32) for up to HS_COPY_MAX_JOBS tensor pairs in ONE launch: the per-parameter gradient tensors autograd hands
+ * over -> their views in the flat gradient buffer (training/flat.py: gather_grads; the reference has no counterpart, its optimiser walks
+ * the parameters one by one, training/holoscene_train.py:374). */
+#define HS_COPY_MAX_JOBS 64
+typedef struct hsCopyJob {
+    const float *src;
+    float *dst;
+    int64_t n;
+} hsCopyJob;
+int hs_copy_many(const hsCopyJob *jobs, int32_t n_jobs, void *stream);
+
 /* ------------------------------------------------------------------ 6. fused volume-rendering composite
  *
  * One workgroup per ray.  Replaces volume_rendering / occlusion_opacity and the weighted sums of
