@@ -157,6 +157,8 @@ TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") !
 TRUNK_FWD_IMPL = os.environ.get("HOLOSCENE_TRUNK_FWD_IMPL", "wave")
 # the wave-tile trunk kernel writes the per-object SDFs / minimum / its gradient itself ("1") or stores Y for hs_trunk_split_fwd ("0")
 TRUNK_SPLIT_FUSED = os.environ.get("HOLOSCENE_TRUNK_SPLIT_FUSED", "1") != "0"
+# the trunk's weight-gradient GEMMs before ("1") or after ("0") the table scatter of the same backward stage (_trunk_bwd_core)
+TRUNK_WGRAD_FIRST = os.environ.get("HOLOSCENE_TRUNK_WGRAD_FIRST", "1") != "0"
 _XP_COLUMNS = {}
 
 
@@ -283,25 +285,38 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     if gb2 is _FROM_KERNEL:
         gb2 = gb2k[:d_out]
 
-    g_emb = target = None
-    if need_table:
+    def scatter():
         table = ctx.table
         inplace = _be.accumulates_into_grad(table)
         target = table.grad if inplace else torch.zeros_like(embeddings)
-        g_emb = None if inplace else target
         _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
                              ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
         if inplace:
-            _be.scatter_done(table)     # data parallelism: the SDF table's segment can go while the weight-gradient GEMMs below run
-    gW2 = gW1 = gW0 = None
-    if need_w:
+            _be.scatter_done(table)     # data parallelism: the SDF table's segment can go while the weight-gradient GEMMs run
+        return None if inplace else target
+
+    def weight_gradients():
         Xm = X.view(M, X.shape[-1])       # [M, 96] reference column order, or the wave-tile kernel's [M, 80] image in its own order
         if w2_part is not None:
             gW1, gW0, gW2 = _wgrad_rows_many([(gA1, H0), (gA0, Xm)], ready_parts=[w2_part])
         else:
             gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, Xm)])
-        gW2 = gW2[:d_out]
         gW0 = gW0[:, :F_in] if Xm.shape[1] == _TRUNK_PITCH else gW0.index_select(1, _xp_columns(dev))
+        return gW2[:d_out], gW1, gW0
+
+    # Order of the two consumers of k_trunk_bwd's outputs.  The weight-gradient GEMMs are HBM-bound readers of gA1 / gA0 (0.59 GB
+    # the kernel has just written): run FIRST they find the tail of it in the 256 MB memory-side cache, run after the scatter
+    # (0.25 GB of its own traffic) they do not.  Under data parallelism the scatter goes first instead: the SDF table's exchange
+    # then runs under the GEMMs (training/trainer.py), which is worth more than the cache hits.
+    g_emb = None
+    gW2 = gW1 = gW0 = None
+    wgrad_first = TRUNK_WGRAD_FIRST and getattr(ctx.table, "_hs_scatter_watch", None) is None
+    if need_w and wgrad_first:
+        gW2, gW1, gW0 = weight_gradients()
+    if need_table:
+        g_emb = scatter()
+    if need_w and not wgrad_first:
+        gW2, gW1, gW0 = weight_gradients()
     return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
 
 
