@@ -4,6 +4,9 @@ without its logging: zero_grad, forward, loss, backward, (gradient exchange), Ad
 No ``.item()`` inside the step (the reference pays ~25 device syncs per iteration for its grad-norm
 print, holoscene_train.py:366-372); scalars are returned as device tensors.
 """
+import os
+import warnings
+
 import torch
 
 from ..model.loss import HoloSceneLoss, unit_cotangent
@@ -119,7 +122,6 @@ class Stage1Trainer:
         second segment and a backend whose collectives are stream-ordered and graph-capturable (RCCL): it is probed once --
         a captured all-reduce on a forked side stream, replayed and checked, agreed on by all ranks -- and the trainer falls back
         to the serial form with a warning if this software stack refuses."""
-        import os
         mode = mode or os.environ.get("HOLOSCENE_EXCHANGE", "overlap")
         if mode not in ("overlap", "serial"):
             raise ValueError(f"exchange must be 'overlap' or 'serial', not {mode!r}")
@@ -137,7 +139,6 @@ class Stage1Trainer:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         self._overlap = bool(flag.item() > 0)
         if not self._overlap and self.rank == 0:
-            import warnings
             warnings.warn("collectives could not be captured in a HIP graph on a side stream: exchanging serially after the graph")
         if self._overlap:
             from ..hashencoder.backend import ScatterWatch
