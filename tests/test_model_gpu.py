@@ -1070,6 +1070,31 @@ def test_sum_slices_vs_torch(n, slices, dtype):
         B._backend.sum_slices([torch.zeros(3, 6, device=DEV)])
 
 
+def test_copy_many_moves_every_tensor_bit_for_bit():
+    """hs_copy_many (the iteration's small parameter gradients -> their views in the flat gradient buffer, one launch): sizes from 1
+    element to more than one grid pass, 16-byte aligned and unaligned views, more pairs than one launch takes (64); nothing outside the
+    destinations is touched."""
+    from holoscene_amd.hashencoder import backend as B
+    torch.manual_seed(3)
+    sizes = [1, 3, 4, 5, 255, 256, 1023, 65536, 86272, 300001] + [7 + 13 * i for i in range(60)]
+    flat = torch.full((sum(sizes) + 3 * len(sizes) + 8,), -7.0, device=DEV)
+    src, dst, off = [], [], 1          # start one element in: most destinations are not 16-byte aligned
+    for n in sizes:
+        src.append(torch.randn(n, device=DEV))
+        dst.append(flat[off:off + n])
+        off += n + 3
+    B._backend.copy_many(dst, src)
+    torch.cuda.synchronize()
+    want = torch.full_like(flat, -7.0)
+    off = 1
+    for n, t in zip(sizes, src):
+        want[off:off + n] = t
+        off += n + 3
+    assert torch.equal(flat, want)
+    with pytest.raises(RuntimeError):
+        B._backend.copy_many([flat[:4]], [torch.zeros(5, device=DEV)])
+
+
 @pytest.mark.parametrize("M", [128 * 784, 128 * 64, 128 * 3])
 def test_wgrad_rows_vs_matmul(M):
     """hs_wgrad_rows (csrc/wgrad.hip: split-M streaming reduction with transposing LDS reads, several products per launch) vs the fp32 product
