@@ -79,7 +79,16 @@ __device__ __forceinline__ void block_excl_scan2(float &a, float &b, float *sc, 
     if constexpr (kUpdWaves > 1) {
         if (lane == 63) { sc[w] = ai; sc[kUpdWaves + w] = bi; }
         __syncthreads();
-        for (int j = 0; j < w; j++) { pa += sc[j]; pb += sc[kUpdWaves + j]; }
+        // prefix over the waves before this one: the left-to-right sums of a loop j < w, written as selects on the wave-uniform w
+        // (the loop compiled to ~80 instructions of scalar control flow per evaluation of an issue-bound kernel)
+        float va[kUpdWaves], vb[kUpdWaves];
+#pragma unroll
+        for (int j = 0; j < kUpdWaves; j++) { va[j] = sc[j]; vb[j] = sc[kUpdWaves + j]; }
+#pragma unroll
+        for (int j = 0; j < kUpdWaves - 1; j++) {
+            pa = j < w ? pa + va[j] : pa;
+            pb = j < w ? pb + vb[j] : pb;
+        }
     }
     a = pa + (ai - a);
     b = pb + (bi - b);
@@ -130,7 +139,8 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
     float fsum = 0.f, esum = 0.f;
     for (int i = lo; i < hi; i++) {
         const float s = sdf[i], x = -fabsf(s) * inv_b, d = dists[i];
-        const float em1 = x > -1e-3f ? x + 0.5f * x * x : __expf(x) - 1.f;        // expm1 near 0 by its series
+        const float ser = x + 0.5f * x * x, ex = __expf(x) - 1.f;                 // both sides evaluated: a select, not a divergent branch
+        const float em1 = x > -1e-3f ? ser : ex;                                  // expm1 near 0 by its series
         const float sig = half_inv_b + half_inv_b * (s > 0.f ? em1 : (s < 0.f ? -em1 : 0.f));   // Laplace density (model/density.py:21-26)
         const float f_i = d * sig;
         const float e_i = fast_exp(-dstar[i] * inv_b) * (d * d) * q;
