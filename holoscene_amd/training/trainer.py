@@ -134,6 +134,9 @@ class Stage1Trainer:
         if not (dist.is_initialized() and dist.get_backend() == "nccl"):
             return
         self._xchg_stream = torch.cuda.Stream(self.device)
+        warm = torch.zeros(1, device=self.device)
+        dist.all_reduce(warm)            # an eager collective first: communicator set-up (allocations, handle exchange) must not
+        torch.cuda.synchronize()         # happen inside the capture the probe is about to start
         ok = self._probe_captured_collective() if self.use_graph else True
         flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
