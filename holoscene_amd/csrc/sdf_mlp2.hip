@@ -60,9 +60,12 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
     float *bias = reinterpret_cast<float *>(W2l + kW2F);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
     // ---- one fill of the resident weights per workgroup (fragment order in global memory already: a straight copy of 144 KB), by
-    //      LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers): the 18 requests of a wave are in flight
-    //      while it builds the inputs of its first tile and runs layer 0 (whose weights come from L2); the workgroup meets once,
-    //      before the first layer-1 MFMA.  (A load -> ds_write loop cost 16 us per launch, a batched register copy 6 us, measured.)
+    //      LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers); the workgroup meets once, before the
+    //      first layer-1 MFMA.  (A load -> ds_write loop cost 16 us per launch, a batched register copy 6 us, measured.)  The 18
+    //      requests of a wave are NOT hidden behind its first tile: vector-memory loads return in order, so the bias loads below,
+    //      the first tile's inputs and layer 0's weight fragments from L2 -- all issued after them -- wait for the whole image
+    //      (tools/exp/sdf2_prof.hip: kernel entry -> first tile 5.1 k cycles = 2.7 us; a launch is ~9 us of fixed cost + ~11 us
+    //      per 65 536 points).  Interleaving the requests with layer 0's fragment loads would overlap the two; not built.
     {
         constexpr int kChunks = (kW1F + kW2F) * 2 / 1024;          // 144 x 1 KB; W2f follows W1f in the packed buffer
         static_assert(kChunks % kWaves == 0, "resident image must split evenly over the waves");
