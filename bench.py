@@ -153,7 +153,9 @@ TIMED = {
     "bwd_jac": ("hs_hash_bwd_jac (table scatter: k_hash_bwd_jac + k_hash_bin_reduce)", _work_scatter),
     "adam_flat": ("k_adam_flat", _work_adam),
     "sampler_update": ("k_sampler_update", None),
+    "sampler_update_draw": ("k_sampler_update + the next round's draw and positions (one launch)", None),
     "sampler_draw_step": ("k_sampler_draw (+ loop control + positions)", None),
+    "sampler_draw_steps": ("k_sampler_draw (final draw + realised loop state)", None),
     "composite_fwd": ("k_composite_fwd", None),
     "composite_bwd": ("k_composite_bwd", None),
 }

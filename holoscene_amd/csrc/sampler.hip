@@ -181,124 +181,6 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {  // v >
     atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-#ifdef HS_SAMPLER_PROFILE      // tools/exp/sampler_prof.hip: s_memtime stamps of the phases of one ray's update
-__device__ unsigned long long g_sampler_prof[1024 * 8];
-#define HS_SSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_sampler_prof[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define HS_SSTAMP(i) do {} while (0)
-#endif
-
-// ------------------------------------------------------------------------------------ update
-template <int kUpd>
-__global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
-                                                           const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
-                                                           float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
-                                                           int beta_iters, float *__restrict__ beta_max, int R, hsGate gate, const int32_t *__restrict__ m_dev) {
-    extern __shared__ float lds[];
-    if (gate_closed(gate)) return;
-    const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
-    if (r >= R) return;
-    if (m_dev) m_old = *m_dev;                      // device-controlled rounds: the merged count lives in hsSamplerCtl
-    HS_SSTAMP(0);
-    const int m = m_old + s_new;
-    float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m, *sc = lds + 6 * m;
-    float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
-    const float *nz = samples + (size_t)r * s_new, *ns = new_sdf + (size_t)r * s_new;
-    // stage old set (tz[0..m_old)) and new samples (tz[m_old..m))
-    for (int i = lane; i < m_old; i += kUpd) { tz[i] = zr[i]; ts[i] = sr[i]; }
-    for (int i = lane; i < s_new; i += kUpd) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
-    __syncthreads();
-    HS_SSTAMP(1);
-    // stable merge by rank (old before new on ties)
-    for (int i = lane; i < m_old; i += kUpd) {
-        const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
-        z[p] = tz[i]; sdf[p] = ts[i];
-    }
-    for (int i = lane; i < s_new; i += kUpd) {
-        const int p = i + upper_bound(tz, m_old, tz[m_old + i]);
-        z[p] = tz[m_old + i]; sdf[p] = ts[m_old + i];
-    }
-    __syncthreads();
-    HS_SSTAMP(2);
-    for (int i = lane; i < m; i += kUpd) { zr[i] = z[i]; sr[i] = sdf[i]; }
-    const int n = m - 1;
-    for (int i = lane; i < n; i += kUpd) {  // Theorem 1 bound d* per section
-        const float a = z[i + 1] - z[i], b = fabsf(sdf[i]), c = fabsf(sdf[i + 1]);
-        const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
-        float d = 0.f;
-        if (first) d = b;
-        if (second) d = c;
-        if (!first && !second && (b + c - a > 0.f)) {
-            const float s = (a + b + c) / 2.0f;
-            d = (2.0f * sqrtf(s * (s - a) * (s - b) * (s - c))) / a;
-        }
-        const float sa = (sdf[i] > 0.f) - (sdf[i] < 0.f), sb = (sdf[i + 1] > 0.f) - (sdf[i + 1] < 0.f);
-        dists[i] = a;
-        dstar[i] = (sa * sb == 1.f) ? d : 0.f;
-    }
-    __syncthreads();
-    HS_SSTAMP(3);
-    const float beta0 = *beta0_p;
-    float hi = beta_io[r];
-    if (error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
-    HS_SSTAMP(4);
-    float lo = beta0;
-    // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
-    // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
-    if (hi != lo)
-    for (int it = 0; it < beta_iters; it++) {
-        const float mid = (lo + hi) / 2.f;
-        const float err = error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
-        if (err <= eps) hi = mid;
-        else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
-    }
-    HS_SSTAMP(5);
-    if (lane == 0) {
-        beta_io[r] = hi;
-        // only rays still above beta0 can make the round's test (max beta > beta0, ray_sampler.py:204) true; the others skip the
-        // same-address atomic (1 024 of them per launch serialise in the L2)
-        if (hi > beta0) atomic_max_float(beta_max, hi);
-    }
-}
-
-
-// ------------------------------------------------------------------------------------ device-side round control
-// Algorithm 1's loop test (ray_sampler.py:204, 130-287) without the host: after round r's update kernel, one thread
-// advances the counters and clears `running` when max beta no longer exceeds beta0 or the round budget is spent.
-// Every later kernel of the (fully unrolled) loop is gated on `running` and returns at once.
-__global__ void k_sampler_step(hsSamplerCtl *ctl, const float *__restrict__ beta_max, const float *__restrict__ beta0, int s_new, int max_rounds) {
-    if (!(ctl->running > ctl->half)) return;
-    ctl->m += s_new;
-    ctl->rounds += 1;
-    if (!(*beta_max > *beta0) || ctl->rounds >= max_rounds) ctl->running = 0.f;
-}
-
-// n_extra DISTINCT indices uniformly from [0, m): the first n_extra entries of a random permutation (ray_sampler.py:269,
-// torch.randperm(m)[:n_extra]) by a partial Fisher-Yates shuffle driven by u[j] ~ U[0,1); u == NULL: eval mode,
-// torch.linspace(0, m-1, n_extra).long() (:271).
-__global__ void k_sampler_pick(const hsSamplerCtl *__restrict__ ctl, const float *__restrict__ u, int n_extra, int64_t *__restrict__ pick) {
-    __shared__ int idx[HS_SAMPLER_MAX_M];
-    const int m = ctl->m;
-    if (u == nullptr) {
-        for (int j = threadIdx.x; j < n_extra; j += blockDim.x) {
-            const float step = (float)(m - 1) / (float)(n_extra - 1 > 0 ? n_extra - 1 : 1);
-            const float v = j < n_extra / 2 ? step * (float)j : (float)(m - 1) - step * (float)(n_extra - 1 - j);
-            pick[j] = (int64_t)v;
-        }
-        return;
-    }
-    for (int i = threadIdx.x; i < m; i += blockDim.x) idx[i] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int j = 0; j < n_extra && j < m; j++) {
-            int k = j + (int)(u[j] * (float)(m - j));
-            k = k > m - 1 ? m - 1 : k;
-            const int t = idx[j]; idx[j] = idx[k]; idx[k] = t;
-            pick[j] = idx[j];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------ draw
 // mode 0: pdf ~ error-bound opacity (+tiny); mode 1: pdf ~ rendering weights (+1e-5).  u: explicit [R,n_out] or NULL = linspace(0,1,n_out)
 // Optional fused duties of a draw launch in the device-controlled loop (hs_sampler_draw_step):
@@ -310,44 +192,20 @@ struct DrawExt {
     hsSamplerCtl *ctl_out;
     const float *beta_max, *beta0;
     int s_new, max_rounds;
+    int n_steps;            // how many times the step rule is applied, on beta_max[0 .. n_steps) (hs_sampler_draw_steps); 0 means 1
     const float *o, *d;
     float *x, *x01;
     float divide_factor;
 };
 
-// kDraw threads per ray (default 128: one wave per ray leaves a SIMD with ONE wave walking 6-7 sections through libm exp / expm1
-// with every LDS and transcendental latency exposed -- 15.9-17.6 us per launch at 64 threads, 11.9-12.4 at 128, 11.6-15.3 at 256 in
-// the iteration; HOLOSCENE_SAMPLER_DRAW_THREADS = 64 | 128 | 256 for A/B).
-// The cumulative sums are chunk sums in section order + a scan over the threads, so their rounding depends on the chunking -- as
-// it does against torch.cumsum in any case; the parity tests bound the drawn depths, not the bit pattern.
-template <int kDraw>
-__global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
-                                                         const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
-                                                         int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev,
-                                                         DrawExt ext) {
-    extern __shared__ float lds[];
-    if (ext.ctl_in) {
-        hsSamplerCtl c = *ext.ctl_in;
-        if (c.running > c.half) {   // k_sampler_step
-            c.m += ext.s_new;
-            c.rounds += 1;
-            if (!(*ext.beta_max > *ext.beta0) || c.rounds >= ext.max_rounds) c.running = 0.f;
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0) *ext.ctl_out = c;
-        if (mode == 0 && !(c.running > c.half)) return;
-        m = c.m;
-    } else {
-        if (gate_closed(gate)) return;
-        if (m_dev) m = *m_dev;
-    }
-    const int r = blockIdx.x, lane = threadIdx.x;
-    if (r >= R) return;
-    float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
-    const float *zr = z_in + (size_t)r * ld, *sr = sdf_in + (size_t)r * ld;
-    float *sdf = lds + 3 * m, *sc = lds + 4 * m;      // sc: 2 * waves (scan) + waves (sum) floats
-    for (int i = lane; i < m; i += kDraw) { z[i] = zr[i]; sdf[i] = sr[i]; }
-    __syncthreads();
-    const float beta = beta_in[r];
+// The draw itself, on a ray whose merged depths / SDF values are in LDS (z, sdf: m entries; cdf, pdf: scratch of m floats each; sc: 3 x
+// NT / 64 floats): shared by k_sampler_draw (which stages the ray first) and by the fused update + draw kernel (whose update phase
+// has just produced them).  All NT threads of the workgroup call it.
+template <int NT>
+__device__ __forceinline__ void draw_phase(const float *__restrict__ z, const float *__restrict__ sdf, float *__restrict__ cdf, float *__restrict__ pdf,
+                                           float *__restrict__ sc, int m, float beta, int mode, float add_tiny, const float *__restrict__ u_in, int n_out,
+                                           float *__restrict__ out, int r, int lane, const DrawExt &ext) {
+    constexpr int kDraw = NT;
     const int n = m - 1;
     int lo, hi;
     chunk_of(n, lane, kDraw, lo, hi);
@@ -426,6 +284,178 @@ __global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict_
             }
         }
     }
+}
+
+#ifdef HS_SAMPLER_PROFILE      // tools/exp/sampler_prof.hip: s_memtime stamps of the phases of one ray's update
+__device__ unsigned long long g_sampler_prof[1024 * 8];
+#define HS_SSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_sampler_prof[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HS_SSTAMP(i) do {} while (0)
+#endif
+
+// ------------------------------------------------------------------------------------ update
+// The draw of the NEXT round's depths fused into the update launch (hs_sampler_update_draw): the ray's merged set is in LDS already and
+// beta has just been found, so the separate draw launch's staging and its launch go away.  Speculative -- whether another round
+// runs is only known once every ray has reported its beta -- but the drawn depths and positions are only ever read by the next
+// round's kernels, which are gated on this round's max beta.
+struct UpdDraw {
+    float *out;             // [R, n_out] next depths, or NULL: plain update
+    int n_out;
+    float add_tiny;
+    DrawExt ext;            // only the position outputs (o, d, x, x01, divide_factor) are used
+};
+
+template <int kUpd>
+__global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_io, float *__restrict__ sdf_io, int ld, int m_old,
+                                                           const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
+                                                           float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
+                                                           int beta_iters, float *__restrict__ beta_max, int R, hsGate gate, const int32_t *__restrict__ m_dev,
+                                                           UpdDraw dr) {
+    extern __shared__ float lds[];
+    if (gate_closed(gate)) return;
+    const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
+    if (r >= R) return;
+    if (m_dev) m_old = *m_dev;                      // device-controlled rounds: the merged count lives in hsSamplerCtl
+    HS_SSTAMP(0);
+    const int m = m_old + s_new;
+    float *z = lds, *sdf = lds + m, *dists = lds + 2 * m, *dstar = lds + 3 * m, *tz = lds + 4 * m, *ts = lds + 5 * m, *sc = lds + 6 * m;
+    float *zr = z_io + (size_t)r * ld, *sr = sdf_io + (size_t)r * ld;
+    const float *nz = samples + (size_t)r * s_new, *ns = new_sdf + (size_t)r * s_new;
+    // stage old set (tz[0..m_old)) and new samples (tz[m_old..m))
+    for (int i = lane; i < m_old; i += kUpd) { tz[i] = zr[i]; ts[i] = sr[i]; }
+    for (int i = lane; i < s_new; i += kUpd) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
+    __syncthreads();
+    HS_SSTAMP(1);
+    // stable merge by rank (old before new on ties)
+    for (int i = lane; i < m_old; i += kUpd) {
+        const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
+        z[p] = tz[i]; sdf[p] = ts[i];
+    }
+    for (int i = lane; i < s_new; i += kUpd) {
+        const int p = i + upper_bound(tz, m_old, tz[m_old + i]);
+        z[p] = tz[m_old + i]; sdf[p] = ts[m_old + i];
+    }
+    __syncthreads();
+    HS_SSTAMP(2);
+    for (int i = lane; i < m; i += kUpd) { zr[i] = z[i]; sr[i] = sdf[i]; }
+    const int n = m - 1;
+    for (int i = lane; i < n; i += kUpd) {  // Theorem 1 bound d* per section
+        const float a = z[i + 1] - z[i], b = fabsf(sdf[i]), c = fabsf(sdf[i + 1]);
+        const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
+        float d = 0.f;
+        if (first) d = b;
+        if (second) d = c;
+        if (!first && !second && (b + c - a > 0.f)) {
+            const float s = (a + b + c) / 2.0f;
+            d = (2.0f * sqrtf(s * (s - a) * (s - b) * (s - c))) / a;
+        }
+        const float sa = (sdf[i] > 0.f) - (sdf[i] < 0.f), sb = (sdf[i + 1] > 0.f) - (sdf[i + 1] < 0.f);
+        dists[i] = a;
+        dstar[i] = (sa * sb == 1.f) ? d : 0.f;
+    }
+    __syncthreads();
+    HS_SSTAMP(3);
+    const float beta0 = *beta0_p;
+    float hi = beta_io[r];
+    if (error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
+    HS_SSTAMP(4);
+    float lo = beta0;
+    // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
+    // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
+    if (hi != lo)
+    for (int it = 0; it < beta_iters; it++) {
+        const float mid = (lo + hi) / 2.f;
+        const float err = error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
+        if (err <= eps) hi = mid;
+        else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
+    }
+    HS_SSTAMP(5);
+    if (lane == 0) {
+        beta_io[r] = hi;
+        // only rays still above beta0 can make the round's test (max beta > beta0, ray_sampler.py:204) true; the others skip the
+        // same-address atomic (1 024 of them per launch serialise in the L2)
+        if (hi > beta0) atomic_max_float(beta_max, hi);
+    }
+    if (dr.out) {           // workgroup-uniform
+        __syncthreads();    // the line search's scratch (tz, ts, sc) is free from here on
+        draw_phase<kUpd>(z, sdf, tz, ts, sc, m, hi, 0, dr.add_tiny, nullptr, dr.n_out, dr.out, r, lane, dr.ext);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------ device-side round control
+// Algorithm 1's loop test (ray_sampler.py:204, 130-287) without the host: after round r's update kernel, one thread
+// advances the counters and clears `running` when max beta no longer exceeds beta0 or the round budget is spent.
+// Every later kernel of the (fully unrolled) loop is gated on `running` and returns at once.
+__global__ void k_sampler_step(hsSamplerCtl *ctl, const float *__restrict__ beta_max, const float *__restrict__ beta0, int s_new, int max_rounds) {
+    if (!(ctl->running > ctl->half)) return;
+    ctl->m += s_new;
+    ctl->rounds += 1;
+    if (!(*beta_max > *beta0) || ctl->rounds >= max_rounds) ctl->running = 0.f;
+}
+
+// n_extra DISTINCT indices uniformly from [0, m): the first n_extra entries of a random permutation (ray_sampler.py:269,
+// torch.randperm(m)[:n_extra]) by a partial Fisher-Yates shuffle driven by u[j] ~ U[0,1); u == NULL: eval mode,
+// torch.linspace(0, m-1, n_extra).long() (:271).
+__global__ void k_sampler_pick(const hsSamplerCtl *__restrict__ ctl, const float *__restrict__ u, int n_extra, int64_t *__restrict__ pick) {
+    __shared__ int idx[HS_SAMPLER_MAX_M];
+    const int m = ctl->m;
+    if (u == nullptr) {
+        for (int j = threadIdx.x; j < n_extra; j += blockDim.x) {
+            const float step = (float)(m - 1) / (float)(n_extra - 1 > 0 ? n_extra - 1 : 1);
+            const float v = j < n_extra / 2 ? step * (float)j : (float)(m - 1) - step * (float)(n_extra - 1 - j);
+            pick[j] = (int64_t)v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) idx[i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < n_extra && j < m; j++) {
+            int k = j + (int)(u[j] * (float)(m - j));
+            k = k > m - 1 ? m - 1 : k;
+            const int t = idx[j]; idx[j] = idx[k]; idx[k] = t;
+            pick[j] = idx[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ draw (own launch)
+// kDraw threads per ray (default 128: one wave per ray leaves a SIMD with ONE wave walking 6-7 sections through libm exp / expm1
+// with every LDS and transcendental latency exposed -- 15.9-17.6 us per launch at 64 threads, 11.9-12.4 at 128, 11.6-15.3 at 256 in
+// the iteration; HOLOSCENE_SAMPLER_DRAW_THREADS = 64 | 128 | 256 for A/B).
+// The cumulative sums are chunk sums in section order + a scan over the threads, so their rounding depends on the chunking -- as
+// it does against torch.cumsum in any case; the parity tests bound the drawn depths, not the bit pattern.
+template <int kDraw>
+__global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
+                                                         const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
+                                                         int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev,
+                                                         DrawExt ext) {
+    extern __shared__ float lds[];
+    if (ext.ctl_in) {
+        hsSamplerCtl c = *ext.ctl_in;
+        const int steps = ext.n_steps > 0 ? ext.n_steps : 1;
+        for (int k = 0; k < steps; k++)
+            if (c.running > c.half) {   // k_sampler_step, once per round that has run
+                c.m += ext.s_new;
+                c.rounds += 1;
+                if (!(ext.beta_max[k] > *ext.beta0) || c.rounds >= ext.max_rounds) c.running = 0.f;
+            }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ext.ctl_out = c;
+        if (mode == 0 && !(c.running > c.half)) return;
+        m = c.m;
+    } else {
+        if (gate_closed(gate)) return;
+        if (m_dev) m = *m_dev;
+    }
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= R) return;
+    float *z = lds, *cdf = lds + m, *pdf = lds + 2 * m;
+    const float *zr = z_in + (size_t)r * ld, *sr = sdf_in + (size_t)r * ld;
+    float *sdf = lds + 3 * m, *sc = lds + 4 * m;      // sc: 2 * waves (scan) + waves (sum) floats
+    for (int i = lane; i < m; i += kDraw) { z[i] = zr[i]; sdf[i] = sr[i]; }
+    __syncthreads();
+    draw_phase<kDraw>(z, sdf, cdf, pdf, sc, m, beta_in[r], mode, add_tiny, u_in, n_out, out, r, lane, ext);
 }
 
 // ------------------------------------------------------------------------------------ final
@@ -553,9 +583,9 @@ void launch_draw(int R, int m_cap, hipStream_t st, Args... args) {
 
 extern "C" {
 
-int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
-                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate, const int32_t *m_dev,
-                      void *stream) {
+static int sampler_update_launch(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                                 float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate,
+                                 const int32_t *m_dev, const UpdDraw &dr, void *stream) {
     if (R <= 0) return HS_OK;
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_dev ? ld : m_old + s_new;   // device-side count: size the scratch for the row capacity
@@ -564,11 +594,29 @@ int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const flo
     const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
     const size_t lds = (6 * m + 3 * 8) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
-    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
-    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
-    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev);
+    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
+    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
+    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
+    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
     return check_launch();
+}
+
+int hs_sampler_update(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                      float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate, const int32_t *m_dev,
+                      void *stream) {
+    return sampler_update_launch(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, gate, m_dev, UpdDraw{}, stream);
+}
+
+int hs_sampler_update_draw(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                           float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R, const hsGate *gate,
+                           float add_tiny, int32_t n_out, float *out, const float *cam_loc, const float *ray_dirs, float divide_factor, float *x,
+                           float *x01, void *stream) {
+    if (!out || n_out <= 0) return HS_ERR_NULL;
+    if (x && (!x01 || !cam_loc || !ray_dirs || divide_factor == 0.f)) return HS_ERR_NULL;
+    UpdDraw dr{};
+    dr.out = out; dr.n_out = n_out; dr.add_tiny = add_tiny;
+    dr.ext.o = cam_loc; dr.ext.d = ray_dirs; dr.ext.x = x; dr.ext.x01 = x01; dr.ext.divide_factor = divide_factor;
+    return sampler_update_launch(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, gate, nullptr, dr, stream);
 }
 
 int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, const float *beta, int32_t mode, float add_tiny, const float *u,
@@ -585,12 +633,21 @@ int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const flo
                          float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0,
                          int32_t s_new, int32_t max_rounds, const float *cam_loc, const float *ray_dirs, float divide_factor, float *x, float *x01,
                          void *stream) {
+    return hs_sampler_draw_steps(z, sdf, ld, beta, mode, add_tiny, u, n_out, out, R, ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, 1, cam_loc,
+                                 ray_dirs, divide_factor, x, x01, stream);
+}
+
+int hs_sampler_draw_steps(const float *z, const float *sdf, int32_t ld, const float *beta, int32_t mode, float add_tiny, const float *u, int32_t n_out,
+                          float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0,
+                          int32_t s_new, int32_t max_rounds, int32_t n_steps, const float *cam_loc, const float *ray_dirs, float divide_factor,
+                          float *x, float *x01, void *stream) {
+    if (n_steps < 1) return HS_ERR_ARG;
     if (R <= 0 || n_out <= 0) return HS_OK;
     if (!z || !sdf || !beta || !out || !ctl_in || !ctl_out || !beta_max || !beta0) return HS_ERR_NULL;
     if (ctl_in == ctl_out) return HS_ERR_ARG;
     if (x && (!x01 || !cam_loc || !ray_dirs || divide_factor == 0.f)) return HS_ERR_NULL;
     if (ld < 2 || ld > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, cam_loc, ray_dirs, x, x01, divide_factor};
+    const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, n_steps, cam_loc, ray_dirs, x, x01, divide_factor};
     launch_draw(R, ld, (hipStream_t)stream, z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R, hsGate{nullptr, nullptr}, (const int32_t *)nullptr, ext);
     return check_launch();
 }

@@ -99,7 +99,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows"]
 
 
 def _check(rc, what):
@@ -268,6 +268,18 @@ class _HipBackend:
                "hs_sampler_update")
 
     @staticmethod
+    def sampler_update_draw(z, sdf, m_old, samples, new_sdf, beta, beta0, eps, beta_iters, beta_max, gate, add_tiny, out, cam_loc, ray_dirs,
+                            divide_factor, x, x01):
+        """hs_sampler_update with the next round's draw (and its positions) fused in; out [R, n_out]."""
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_update_draw(_dev(z, "z"), _dev(sdf, "sdf"), ld, m_old, _dev(samples, "samples"), _dev(new_sdf, "new_sdf"),
+                                          samples.shape[1], _dev(beta, "beta"), _dev(beta0, "beta0"), ctypes.c_float(eps), beta_iters,
+                                          _dev(beta_max, "beta_max"), R, ctypes.byref(_gate(gate)), ctypes.c_float(add_tiny), out.shape[1],
+                                          _dev(out, "out"), _dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"), ctypes.c_float(divide_factor),
+                                          _dev(x, "x"), _dev(x01, "x01"), _stream()), "hs_sampler_update_draw")
+
+    @staticmethod
     def sampler_draw(z, sdf, m, beta, mode, add_tiny, u, n_out, out, gate=None, m_dev=None):
         lib = load_library()
         R, ld = z.shape
@@ -285,6 +297,16 @@ class _HipBackend:
                                         _dev(out, "out"), R, _dev(ctl_in, "ctl_in"), _dev(ctl_out, "ctl_out"), _dev(beta_max, "beta_max"),
                                         _dev(beta0, "beta0"), s_new, max_rounds, _dev(cam_loc, "cam_loc"), _dev(ray_dirs, "ray_dirs"),
                                         ctypes.c_float(divide_factor), _dev(x, "x"), _dev(x01, "x01"), _stream()), "hs_sampler_draw_step")
+
+    @staticmethod
+    def sampler_draw_steps(z, sdf, beta, mode, add_tiny, u, n_out, out, ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, n_steps):
+        """sampler_draw_step with the step rule applied n_steps times on beta_max[0 .. n_steps) (the state after all rounds in one go)."""
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_draw_steps(_dev(z, "z"), _dev(sdf, "sdf"), ld, _dev(beta, "beta"), mode, ctypes.c_float(add_tiny), _dev(u, "u"), n_out,
+                                         _dev(out, "out"), R, _dev(ctl_in, "ctl_in"), _dev(ctl_out, "ctl_out"), _dev(beta_max, "beta_max"),
+                                         _dev(beta0, "beta0"), s_new, max_rounds, n_steps, None, None, ctypes.c_float(1.0), None, None, _stream()),
+               "hs_sampler_draw_steps")
 
     @staticmethod
     def sampler_step(ctl, beta_max, beta0, s_new, max_rounds):

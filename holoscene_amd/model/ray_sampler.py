@@ -32,6 +32,9 @@ SAMPLER_IMPL = os.environ.get("HOLOSCENE_SAMPLER_IMPL", "hip")
 #           Needs the fused ray-mode SDF query (bf16 MLP mode, stock trunk shape); other configurations use "host".
 # "host":   the host reads one convergence flag per round (the reference's control flow, ray_sampler.py:204).
 CONTROL = os.environ.get("HOLOSCENE_SAMPLER_CONTROL", "device")
+# device-controlled loop: the next round's draw fused into the update launch, rounds gated on the previous round's max beta ("1"),
+# or one draw + control-step launch per round between control slots ("0")
+FUSE_DRAW = os.environ.get("HOLOSCENE_SAMPLER_FUSE_DRAW", "1") != "0"
 
 
 def _rand(shape, device, cpu_rng):
@@ -320,22 +323,41 @@ class ErrorBoundSampler(RaySampler):
             x, x01 = x0
         # per round: hash gather, fused trunk, update, then ONE launch that steps the loop control, draws the next depths and
         # writes their positions (csrc/sampler.hip: hs_sampler_draw_step); every kernel of round r is gated on slot r
-        for r in range(nr):
-            gate, m_dev = (ctl[r, 0:1], ctl[r, 1:2]), ci[r, 2:3]
-            new_sdf = net.sdf_at_points(x, x01, R, S, sel, gate=gate)
-            be.sampler_update(z, sdf, 0, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1], gate=gate,
-                              m_dev=m_dev)
-            if r + 1 < nr:
-                samples = torch.empty(R, S, device=dev)
-                x, x01 = torch.empty(R * S, 3, device=dev), torch.empty(R * S, 3, device=dev)
-                be.sampler_draw_step(z, sdf, beta, 0, float(self.add_tiny), None, S, samples, ctl[r], ctl[r + 1], beta_max_all[r:r + 1], beta0, S, nr,
-                                     cam, dirs, df, x, x01)
         n = self.N_samples
         u = None
         if model.training:
             u = (rng["u_final"].to(dev) if "u_final" in rng else _rand((R, n), dev, self.cpu_rng)).contiguous()
         final = torch.empty(R, n, device=dev)
-        be.sampler_draw_step(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[nr - 1], ctl[nr], beta_max_all[nr - 1:nr], beta0, S, nr)
+        if FUSE_DRAW:
+            # three launches per round: gather, trunk, update + the next round's draw (hs_sampler_update_draw).  No control slots
+            # between the rounds: round r is gated on round r - 1's max beta (a round that did not run leaves its maximum at zero, so
+            # the gates chain by themselves) and merges into r * S entries; the final draw derives the realised state (merged count,
+            # rounds) from the per-round maxima in one go
+            for r in range(nr):
+                gate = None if r == 0 else (beta_max_all[r - 1:r], beta0)
+                new_sdf = net.sdf_at_points(x, x01, R, S, sel, gate=gate)
+                if r + 1 < nr:
+                    nxt = torch.empty(R, S, device=dev)
+                    xn, xn01 = torch.empty(R * S, 3, device=dev), torch.empty(R * S, 3, device=dev)
+                    be.sampler_update_draw(z, sdf, r * S, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1],
+                                           gate, float(self.add_tiny), nxt, cam, dirs, df, xn, xn01)
+                    samples, x, x01 = nxt, xn, xn01
+                else:
+                    be.sampler_update(z, sdf, r * S, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1],
+                                      gate=gate)
+            be.sampler_draw_steps(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[0], ctl[nr], beta_max_all, beta0, S, nr, nr)
+        else:
+            for r in range(nr):
+                gate, m_dev = (ctl[r, 0:1], ctl[r, 1:2]), ci[r, 2:3]
+                new_sdf = net.sdf_at_points(x, x01, R, S, sel, gate=gate)
+                be.sampler_update(z, sdf, 0, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1], gate=gate,
+                                  m_dev=m_dev)
+                if r + 1 < nr:
+                    samples = torch.empty(R, S, device=dev)
+                    x, x01 = torch.empty(R * S, 3, device=dev), torch.empty(R * S, 3, device=dev)
+                    be.sampler_draw_step(z, sdf, beta, 0, float(self.add_tiny), None, S, samples, ctl[r], ctl[r + 1], beta_max_all[r:r + 1], beta0, S,
+                                         nr, cam, dirs, df, x, x01)
+            be.sampler_draw_step(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[nr - 1], ctl[nr], beta_max_all[nr - 1:nr], beta0, S, nr)
         ctl_end = ctl[nr]
         pick = None
         if self.N_samples_extra > 0:

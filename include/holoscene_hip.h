@@ -181,6 +181,24 @@ int hs_sampler_draw_step(const float *z, const float *sdf, int32_t ld, const flo
                          int32_t s_new, int32_t max_rounds, const float *cam_loc, const float *ray_dirs, float divide_factor,
                          float *x /* or NULL */, float *x01, void *stream);
 
+/* The same with the step rule applied n_steps times, on beta_max[0 .. n_steps): the state after n_steps rounds derived in one go from the
+ * initial slot and the per-round maxima.  With hs_sampler_update_draw the rounds themselves need no control slots: round r + 1 is gated
+ * on hsGate{beta_max + r, beta0} (a round that did not run leaves its maximum at zero, so the gates chain by themselves) and its
+ * merged count is the constant (r + 1) * s_new; only the final draw / pick / final need the realised state. */
+int hs_sampler_draw_steps(const float *z, const float *sdf, int32_t ld, const float *beta, int32_t mode, float add_tiny, const float *u, int32_t n_out,
+                          float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max /* [n_steps] */,
+                          const float *beta0, int32_t s_new, int32_t max_rounds, int32_t n_steps, const float *cam_loc, const float *ray_dirs,
+                          float divide_factor, float *x /* or NULL */, float *x01, void *stream);
+
+/* hs_sampler_update with the NEXT round's draw fused in (mode 0, u = linspace: ray_sampler.py:206-253 on the set just merged, with
+ * the beta just found): out [R, n_out] next depths and, with x != NULL, their positions x / x01 [R*n_out,3] as hs_ray_points writes
+ * them.  The draw is speculative (whether a next round runs is known only when every ray has reported its beta); nothing but the
+ * next round's gated kernels reads its outputs.  m_old is a host constant here (no device count). */
+int hs_sampler_update_draw(float *z, float *sdf, int32_t ld, int32_t m_old, const float *samples, const float *new_sdf, int32_t s_new,
+                           float *beta, const float *beta0, float eps, int32_t beta_iters, float *beta_max, int32_t R,
+                           const hsGate *gate /* NULL = none */, float add_tiny, int32_t n_out, float *out, const float *cam_loc,
+                           const float *ray_dirs, float divide_factor, float *x /* or NULL */, float *x01, void *stream);
+
 /* Final sample set (ray_sampler.py:261-280): z_out [R, n_s+2+n_extra] = sort(z_samples ++ near ++ far ++ z[:, pick]);
  * z_eik [R] = z_out[r, eik_idx[r]] (skipped when z_eik is NULL).  pick [n_extra], eik_idx [R]: int64. */
 int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_t ld, const int64_t *pick, int32_t n_extra, float near, float far,
