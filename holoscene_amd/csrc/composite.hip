@@ -158,9 +158,11 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
     extern __shared__ float lds[];
     const int r = blockIdx.x, i = threadIdx.x;
     const int C = 8 + 2 * K;
+    const int CP = C | 1;            // row pitch of the contribution matrix: odd, so the per-sample writes c[col] (lane = sample) fall on
+                                     // different LDS banks -- with the even pitch 72 (K = 32) the 64 lanes of a wave shared 8 of them
     float *scratch = lds;            // [4]
-    float *contrib = lds + 4;        // [N][C]
-    float *rawS = contrib + (size_t)N * C;   // [N][K + 1]: the ray's per-object SDF block, staged with coalesced 16-byte reads (k_composite_bwd)
+    float *contrib = lds + 4;        // [N][CP]
+    float *rawS = contrib + (size_t)N * CP;   // [N][K + 1]: the ray's per-object SDF block, staged with coalesced 16-byte reads (k_composite_bwd)
     const bool staged = stage != 0;
     if (staged) {
         const float4 *src = reinterpret_cast<const float4 *>(raw + (size_t)blockIdx.x * N * K);
@@ -187,17 +189,27 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
     if (act) {
         weights[p] = w;
         if (trans) trans[p] = T;
-        float *c = contrib + (size_t)i * C;
+        float *c = contrib + (size_t)i * CP;
         c[0] = w * rgb[3 * p]; c[1] = w * rgb[3 * p + 1]; c[2] = w * rgb[3 * p + 2];
         c[3] = w * zi; c[4] = w;
         const float gx = g[3 * p], gy = g[3 * p + 1], gz = g[3 * p + 2];
         const float inv = 1.f / (sqrtf(gx * gx + gy * gy + gz * gz) + 1e-6f);
         c[5] = w * gx * inv; c[6] = w * gy * inv; c[7] = w * gz * inv;
         const float *rw = staged ? rawS + i * (K + 1) : raw + p * K;
-        for (int k = 0; k < K; k++) {
-            const float s = rw[k];
+        auto object = [&](int k, float s) {
             c[8 + k] = w * sem_scale / (1.f + __expf(sem_scale * s));           // s*sigmoid(-s*raw)
             c[8 + K + k] = (1.f - __expf(-d * lap_sigma_fast(s, beta))) * T;
+        };
+        if (!staged && (K & 3) == 0) {
+            // a lane's K values are contiguous (its own 4 K bytes): 16-byte loads touch one line per lane and quarter, where 4-byte loads at
+            // the row stride looked up 64 lines per instruction, K instructions per lane
+            const float4 *rw4 = reinterpret_cast<const float4 *>(rw);
+            for (int k = 0; k < K; k += 4) {
+                const float4 v = rw4[k >> 2];
+                object(k, v.x); object(k + 1, v.y); object(k + 2, v.z); object(k + 3, v.w);
+            }
+        } else {
+            for (int k = 0; k < K; k++) object(k, rw[k]);
         }
     }
     __syncthreads();
@@ -206,9 +218,9 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
         if (rot && (j == 6 || j == 7)) continue;   // the thread of column 5 sums all three normal components and rotates them
         float acc = 0.f, acc_w = 0.f, acc1 = 0.f, acc2 = 0.f;
         for (int n = 0; n < N; n++) {
-            acc += contrib[(size_t)n * C + j];
-            if (j == 3) acc_w += contrib[(size_t)n * C + 4];
-            if (rot && j == 5) { acc1 += contrib[(size_t)n * C + 6]; acc2 += contrib[(size_t)n * C + 7]; }
+            acc += contrib[(size_t)n * CP + j];
+            if (j == 3) acc_w += contrib[(size_t)n * CP + 4];
+            if (rot && j == 5) { acc1 += contrib[(size_t)n * CP + 6]; acc2 += contrib[(size_t)n * CP + 7]; }
         }
         if (j < 3) rgb_out[3 * r + j] = acc;
         else if (j == 3) depth_out[r] = depth_scale[r] * (acc / (acc_w + 1e-8f));
@@ -355,8 +367,8 @@ int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const f
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !weights || !rgb_out || !depth_out || !normal_out || !sem_out || !opac_out)
         return HS_ERR_NULL;
-    size_t lds = (4 + (size_t)N * (8 + 2 * K)) * sizeof(float);
-    if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix must fit the default dynamic-LDS window
+    size_t lds = (4 + (size_t)N * ((8 + 2 * K) | 1)) * sizeof(float);
+    if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix (odd row pitch) must fit the default dynamic-LDS window
     // (staging the per-object SDF block as the backward does was slower here: 33 -> 47 us -- with the 28 KB contribution matrix the
     //  extra 13 KB cost a workgroup per CU)
     const int stage = 0;
