@@ -1450,6 +1450,7 @@ class HoloSceneNetwork(nn.Module):
     # run the data-dependent part (rays + Algorithm-1 sampler, which needs a host decision per round) eagerly and
     # replay everything after it -- render, loss, backward, Adam -- as one captured HIP graph.
     _FD_TAPS = ((1.0, -1.0, -1.0), (-1.0, -1.0, 1.0), (-1.0, 1.0, -1.0), (1.0, 1.0, 1.0))
+    _fd_taps_dev = {}
 
     def _eikonal_gradients_fd(self, x, y_centre):
         """Opt-in replacement of the analytic Eikonal-set gradients: grad f(x) ~ sum_i k_i f(x + h k_i) / (4 h) over the four tetrahedral
@@ -1463,7 +1464,10 @@ class HoloSceneNetwork(nn.Module):
             # |x| ~ 0.5), so taps 1e-3 apart collapse onto the same operand, and its output noise (3e-3 relative) exceeds the differences
             raise ValueError("eikonal_mode='fd' needs mlp_precision='fp32': finite differences at h = 1e-3 are below the resolution of bf16 operands")
         B = x.shape[0]
-        taps = torch.tensor(self._FD_TAPS, device=x.device, dtype=x.dtype)                  # [4,3]
+        key = (str(x.device), x.dtype)          # built once per device: a host-to-device copy is not allowed inside a graph capture
+        if key not in self._fd_taps_dev:       # (the trainer's eager warm-up passes fill the cache before it captures)
+            self._fd_taps_dev[key] = torch.tensor(self._FD_TAPS, device=x.device, dtype=x.dtype)
+        taps = self._fd_taps_dev[key]                                                       # [4,3]
         pts = (x.detach().unsqueeze(0) + h * taps.unsqueeze(1)).reshape(-1, 3)              # [4B,3]
         y = net._trunk(pts)[:, :net.d_out].float().reshape(4, B, net.d_out)                 # [4,B,K]
         J = torch.einsum("tbk,td->bkd", y, taps) / (4.0 * h)                                # [B,K,3]

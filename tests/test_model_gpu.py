@@ -1272,3 +1272,14 @@ def test_opt_in_finite_difference_eikonal_mode():
                        device=DEV, optimizer="flat", freeze_parameters=True)
     with pytest.raises(ValueError, match="fp32"):
         tr.train_step(idx, mi, gt)
+    # ... and the mode survives graph capture (what `bench.py --eikonal fd --precision fp32` runs: the tap table must not be
+    # uploaded inside the capture)
+    from holoscene_amd.model.network import HoloSceneNetwork
+    HoloSceneNetwork._fd_taps_dev.clear()
+    tr = Stage1Trainer(stock_conf(num_rays=256, S=32, d_out=5, logmap=14, beta=0.05, mlp_precision="fp32", eikonal_mode="fd", use_bg_reg=False),
+                       device=DEV, optimizer="flat", graph=True)
+    benchmark_model_state(tr.model, 0.05)
+    for _ in range(3):
+        out, lo = tr.train_step(*scene.next_batch())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lo["loss"])) and bool(torch.isfinite(tr.flat.flat_p).all())
