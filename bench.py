@@ -391,11 +391,12 @@ def main():
     rounds_mean = sum(int(r_) for r_ in rounds_seen[:args.steps]) / max(1, args.steps)
     N_pts = args.samples // 2 + args.samples // 4 + 2
     R, S, K = args.rays, args.samples, args.objects
+    n_params = tr.flat.numel if tr.flat is not None else sum(p.numel() for p in tr.model.parameters())    # (--optimizer torch has no flat buffers)
     # whole-iteration algorithmic work (SURVEY 8d formulas, realised sampler rounds)
     T = trunk_flops_per_row(K)
     iter_flops = rounds_mean * S * R * T + 3 * N_pts * R * (4 * T + CF + RN) + 3 * 4 * R * 4 * T
     iter_bytes = rounds_mean * S * R * G_BYTES + N_pts * R * 2 * G_BYTES + N_pts * R * (2 * 2 * G_BYTES + 3 * G_BYTES) + 4 * R * 6 * G_BYTES \
-        + 7 * 4 * tr.flat.numel + 4 * tr.flat.numel
+        + 7 * 4 * n_params + 4 * n_params
     dom = kernels[0] if kernels else None
     traffic, traffic_src = None, None
     for cand in ("r02", "r01"):
