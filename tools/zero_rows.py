@@ -11,20 +11,26 @@ scene = SyntheticScene(1024, 32, num_frames=8, ring=64, device='cuda')
 B_ = be._backend
 orig_jac, orig_bwd = B_.bwd_jac, B_.bwd
 log = []
-def jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H):
-    zf = (g_feat == 0).all(1) if g_feat is not None else torch.ones(B, dtype=torch.bool, device=x01.device)
-    zj = (g_dydx == 0).all(2).all(0) if g_dydx is not None else torch.ones(B, dtype=torch.bool, device=x01.device)
-    lvl = ((g_feat.view(B, L, C) == 0).all(2) & (g_dydx.view(L, B, -1) == 0).all(2).t()).float().mean().item() if g_feat is not None and g_dydx is not None else -1
-    log.append(("jac", B, float((zf & zj).float().mean()), lvl))
-    return orig_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
-def bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs):
+def rows(t, B, L, per, level_major):
+    """[B, L, per] view of a cotangent image stored point-major [B, L*per] or level-major [L, B, per]."""
+    return t.view(L, B, per).transpose(0, 1) if level_major else t.view(B, L, per)
+def jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H, **kw):
+    lm = bool(kw.get("level_major"))
+    zf = (rows(g_feat, B, L, C, lm) == 0).all(2) if g_feat is not None else torch.ones(B, L, dtype=torch.bool, device=x01.device)
+    zj = (g_dydx.view(L, B, -1) == 0).all(2).t() if g_dydx is not None else torch.ones(B, L, dtype=torch.bool, device=x01.device)
+    both = zf & zj
+    log.append(("jac", B, float(both.all(1).float().mean()), float(both.float().mean())))
+    return orig_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H, **kw)
+def bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, **kw):
     if grad_embeddings is not None:
-        log.append(("bwd", B, float((grad == 0).all(1).float().mean()), float((grad.view(B, L, C) == 0).all(2).float().mean())))
-    return orig_bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs)
+        z = rows(grad, B, L, C, bool(kw.get("level_major"))) == 0
+        log.append(("bwd", B, float(z.all(2).all(1).float().mean()), float(z.all(2).float().mean())))
+    return orig_bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, **kw)
 B_.bwd_jac, B_.bwd = staticmethod(jac), staticmethod(bwd)
 for it in range(40):
     idx, mi, gt = scene.next_batch()
     log.clear()
     out, lo = tr.train_step(idx, mi, gt)
     if it in (0, 5, 39):
+        # (kernel, points, fraction of points whose whole cotangent is exactly zero, fraction of (point, level) cells that are)
         print("iter", it, "loss", float(lo["loss"]), [(k, b, round(z, 4), round(l, 4)) for k, b, z, l in log])
