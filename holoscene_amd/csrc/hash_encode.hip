@@ -406,9 +406,18 @@ constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4
 template <int C>
 struct BinRecord { uint32_t cell; float v[C]; };
 
+// cells per bin: table / kBins for the power-of-two hashed tables; for a dense level (res^3 cells) the quotient rounded up to an even
+// number -- the last bins are then partly or wholly empty.
+__device__ __forceinline__ uint32_t bin_width(const LevelInfo &li) {
+    const uint32_t w = (li.table + kBins - 1u) / kBins;
+    return (w + 1u) & ~1u;
+}
+
+__device__ int g_bin_dense = 1;      // HOLOSCENE_BIN_DENSE=0 (A/B): dense levels keep the wave-merged atomic path (set once by the launchers)
 __device__ __forceinline__ bool binned_level(const LevelInfo &li, int C, const void *ws) {
-    return ws != nullptr && li.hashed && (li.table & (li.table - 1u)) == 0u && li.table >= 64u * kBins &&
-           (size_t)(li.table / kBins) * C * sizeof(float) <= kReduceLds;
+    if (ws == nullptr || (size_t)bin_width(li) * C * sizeof(float) > kReduceLds) return false;
+    if (li.hashed) return (li.table & (li.table - 1u)) == 0u && li.table >= 64u * kBins;
+    return g_bin_dense != 0 && li.table >= 32u * kBins;
 }
 
 // all threads of the workgroup call this (level is workgroup-uniform)
@@ -421,7 +430,7 @@ __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restr
     valid = wave_merge<D, C>(g, cache, valid);
     uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
     BinRecord<C> *records = reinterpret_cast<BinRecord<C> *>(reinterpret_cast<char *>(lay.scatter_ws) + HS_MAX_LEVELS * kBins * sizeof(uint32_t));
-    const uint32_t per_bin = li.table / kBins;
+    const uint32_t per_bin = bin_width(li);
     if (threadIdx.x < kBins) hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t cell[1 << D], rank[1 << D];
@@ -480,8 +489,10 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
                                   ((size_t)level * kBins + bin) * lay.scatter_cap;
     const uint32_t n = min(counts[level * kBins + bin], lay.scatter_cap);
     if (n == 0u) return;
-    const uint32_t per_bin = li.table / kBins;
-    const uint32_t nvec = per_bin * C / 4;                       // per_bin >= 64: a whole number of float4
+    const uint32_t per_bin = bin_width(li), first = bin * per_bin;
+    if (first >= li.table) return;                               // (dense levels: bins past the end of the table hold nothing)
+    const uint32_t nfl = min(per_bin, li.table - first) * C;     // floats of the table this bin covers
+    const uint32_t nvec = per_bin * C / 4;                       // per_bin is even: a whole number of float4
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
     for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -502,8 +513,18 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
         for (int c = 0; c < C; c++) atomicAdd(&acc[r.cell * C + c], r.v[c]);
     }
     __syncthreads();
-    // this workgroup owns the bin's cells: plain 16-byte read-modify-writes, all loads of a thread issued before its stores
-    float4 *dst = reinterpret_cast<float4 *>(gemb + ((size_t)li.offset + (size_t)bin * per_bin) * C);
+    // this workgroup owns the bin's cells: plain read-modify-writes.  A dense level may start at an odd entry and end inside the bin:
+    // 4-byte accesses there (at most ~3 200 floats per bin)
+    float *dstf = gemb + ((size_t)li.offset + (size_t)first) * C;
+    if ((reinterpret_cast<uintptr_t>(dstf) & 15) != 0 || nfl != per_bin * C) {
+        for (uint32_t j = threadIdx.x; j < nfl; j += blockDim.x) {
+            const float a = acc[j];
+            if (a != 0.f) dstf[j] += a;
+        }
+        return;
+    }
+    // 16-byte read-modify-writes, all loads of a thread issued before its stores
+    float4 *dst = reinterpret_cast<float4 *>(dstf);
     constexpr int kV = 4;
     for (uint32_t j0 = threadIdx.x; j0 < nvec; j0 += kV * blockDim.x) {
         float4 a[kV], t[kV];
@@ -740,6 +761,16 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
+// the dense-level switch is read from the environment once, on the first scatter launch (an eager one: warm-up passes precede captures)
+void apply_bin_dense_switch() {
+    static const bool done = [] {
+        const char *e = getenv("HOLOSCENE_BIN_DENSE");
+        if (e && e[0] == '0') { const int v = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_dense), &v, sizeof(v)); }
+        return true;
+    }();
+    (void)done;
+}
+
 bool dims_ok(uint32_t D, uint32_t C, uint32_t L) { return (D == 2 || D == 3) && (C == 1 || C == 2 || C == 4 || C == 8) && L >= 1 && L <= HS_MAX_LEVELS; }
 
 template <int V>
@@ -810,7 +841,8 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
     hipStream_t st = (hipStream_t)stream;
     if (grad_embeddings) {
         const LevelScales sc = make_scales(L, S, H);
-        if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
+        apply_bin_dense_switch();
+    if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
         dispatch_dc(D, C, [&](auto d, auto c) {
             k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
                 grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
@@ -853,6 +885,7 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);
     hipStream_t st = (hipStream_t)stream;
+    apply_bin_dense_switch();
     if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
     dispatch_dc(D, C, [&](auto d, auto c) {
         k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
