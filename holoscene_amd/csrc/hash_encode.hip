@@ -398,8 +398,9 @@ __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const Level
 //      global atomic per (workgroup, touched bin) to reserve space;
 //   2. k_hash_bin_reduce: one workgroup per (level, bin) accumulates its records in LDS (32 KB = 4 096 cells x 2 floats at
 //      T = 2^19) and adds the result to the table with plain coalesced read-modify-writes -- it owns those cells.
-// Dense (coarse) levels keep the wave-merged atomic path, which already removes most of their traffic.  Records that do not
-// fit the bin's capacity fall back to atomics.
+// Dense (coarse) levels went through the wave-merged atomic path alone at first; with dense cotangents (early training: every sample
+// contributes) their atomics were the tail of the launch (418 us of hs_hash_bwd_jac at beta = 0.1, 251 us since they are binned too:
+// bins = slabs of ceil(res^3 / kBins) cells).  Records that do not fit the bin's capacity fall back to atomics.
 constexpr uint32_t kBins = HS_SCATTER_BINS;
 constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4 096 cells x 2 floats; five workgroups per CU hide each other's latency
 
