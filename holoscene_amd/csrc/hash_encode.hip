@@ -495,9 +495,24 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     const uint32_t nfl = min(per_bin, li.table - first) * C;     // floats of the table this bin covers
     const uint32_t nvec = per_bin * C / 4;                       // per_bin is even: a whole number of float4
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
+    // the table's current content of this thread's quads does not depend on the records: requested now, it arrives under the record
+    // phase instead of costing a memory round trip (four serialised ones, when the loads were issued per touched quad) at the end of a
+    // workgroup whose whole life is a chain of such round trips (2 048 workgroups on 1 280 slots: the launch lasts ~2 workgroup lives)
+    float *dstf = gemb + ((size_t)li.offset + (size_t)first) * C;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dstf) & 15) == 0 && nfl == per_bin * C;
+    constexpr int kV = 4;                                        // kReduceLds / 16 B = 2 048 quads = kV x 512 threads: one pass
+    float4 t[kV];
+    if (vec_ok) {
+#pragma unroll
+        for (int k = 0; k < kV; k++) {
+            const uint32_t j = threadIdx.x + k * blockDim.x;
+            if (j < nvec) t[k] = reinterpret_cast<const float4 *>(dstf)[j];
+        }
+    }
     for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    // records: independent loads, four in flight per thread before the first LDS atomic
+    // records: independent loads, four in flight per thread before the first LDS atomic (eight cost an occupancy step: 74 registers,
+    // 104 vs 101 us per scatter)
     uint32_t i = threadIdx.x;
     for (; i + 3 * blockDim.x < n; i += 4 * blockDim.x) {
         BinRecord<C> r[4];
@@ -516,32 +531,21 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     __syncthreads();
     // this workgroup owns the bin's cells: plain read-modify-writes.  A dense level may start at an odd entry and end inside the bin:
     // 4-byte accesses there (at most ~3 200 floats per bin)
-    float *dstf = gemb + ((size_t)li.offset + (size_t)first) * C;
-    if ((reinterpret_cast<uintptr_t>(dstf) & 15) != 0 || nfl != per_bin * C) {
+    if (!vec_ok) {
         for (uint32_t j = threadIdx.x; j < nfl; j += blockDim.x) {
             const float a = acc[j];
             if (a != 0.f) dstf[j] += a;
         }
         return;
     }
-    // 16-byte read-modify-writes, all loads of a thread issued before its stores
     float4 *dst = reinterpret_cast<float4 *>(dstf);
-    constexpr int kV = 4;
-    for (uint32_t j0 = threadIdx.x; j0 < nvec; j0 += kV * blockDim.x) {
-        float4 a[kV], t[kV];
-        bool any[kV];
 #pragma unroll
-        for (int k = 0; k < kV; k++) {
-            const uint32_t j = j0 + k * blockDim.x;
-            a[k] = j < nvec ? acc4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            any[k] = a[k].x != 0.f || a[k].y != 0.f || a[k].z != 0.f || a[k].w != 0.f;
-            if (any[k]) t[k] = dst[j];
-        }
-#pragma unroll
-        for (int k = 0; k < kV; k++) {
-            if (!any[k]) continue;
-            const uint32_t j = j0 + k * blockDim.x;
-            t[k].x += a[k].x; t[k].y += a[k].y; t[k].z += a[k].z; t[k].w += a[k].w;
+    for (int k = 0; k < kV; k++) {
+        const uint32_t j = threadIdx.x + k * blockDim.x;
+        if (j >= nvec) continue;
+        const float4 a = acc4[j];
+        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
+            t[k].x += a.x; t[k].y += a.y; t[k].z += a.z; t[k].w += a.w;
             dst[j] = t[k];
         }
     }
