@@ -407,16 +407,20 @@ constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4
 template <int C>
 struct BinRecord { uint32_t cell; float v[C]; };
 
-// cells per bin: table / kBins for the power-of-two hashed tables; for a dense level (res^3 cells) the quotient rounded up to an even
-// number -- the last bins are then partly or wholly empty.
+// cells per bin: table / kBins for the power-of-two hashed tables; for a dense level (res^3 cells) the quotient rounded up to a
+// number of cells whose C floats fill whole float4s (C = 2: even, as before; C = 1: a multiple of four -- k_hash_bin_reduce zeroes,
+// accumulates and writes back whole quads) -- the last bins are then partly or wholly empty.
+template <int C>
 __device__ __forceinline__ uint32_t bin_width(const LevelInfo &li) {
+    constexpr uint32_t q = (C % 4 == 0) ? 1u : (C % 2 == 0) ? 2u : 4u;      // cells per float4 group
     const uint32_t w = (li.table + kBins - 1u) / kBins;
-    return (w + 1u) & ~1u;
+    return (w + q - 1u) / q * q;
 }
 
 __device__ int g_bin_dense = 1;      // HOLOSCENE_BIN_DENSE=0 (A/B): dense levels keep the wave-merged atomic path (set once by the launchers)
-__device__ __forceinline__ bool binned_level(const LevelInfo &li, int C, const void *ws) {
-    if (ws == nullptr || (size_t)bin_width(li) * C * sizeof(float) > kReduceLds) return false;
+template <int C>
+__device__ __forceinline__ bool binned_level(const LevelInfo &li, const void *ws) {
+    if (ws == nullptr || (size_t)bin_width<C>(li) * C * sizeof(float) > kReduceLds) return false;
     if (li.hashed) return (li.table & (li.table - 1u)) == 0u && li.table >= 64u * kBins;
     return g_bin_dense != 0 && li.table >= 32u * kBins;
 }
@@ -431,7 +435,7 @@ __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restr
     valid = wave_merge<D, C>(g, cache, valid);
     uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
     BinRecord<C> *records = reinterpret_cast<BinRecord<C> *>(reinterpret_cast<char *>(lay.scatter_ws) + HS_MAX_LEVELS * kBins * sizeof(uint32_t));
-    const uint32_t per_bin = bin_width(li);
+    const uint32_t per_bin = bin_width<C>(li);
     if (threadIdx.x < kBins) hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t cell[1 << D], rank[1 << D];
@@ -483,17 +487,17 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     extern __shared__ float acc[];
     const uint32_t level = blockIdx.y, bin = blockIdx.x;
     const LevelInfo li = level_info<D>(offsets, level, sc);
-    if (!binned_level(li, C, lay.scatter_ws)) return;
+    if (!binned_level<C>(li, lay.scatter_ws)) return;
     const uint32_t *counts = reinterpret_cast<const uint32_t *>(lay.scatter_ws);
     const BinRecord<C> *records = reinterpret_cast<const BinRecord<C> *>(reinterpret_cast<const char *>(lay.scatter_ws) +
                                                                           HS_MAX_LEVELS * kBins * sizeof(uint32_t)) +
                                   ((size_t)level * kBins + bin) * lay.scatter_cap;
     const uint32_t n = min(counts[level * kBins + bin], lay.scatter_cap);
     if (n == 0u) return;
-    const uint32_t per_bin = bin_width(li), first = bin * per_bin;
+    const uint32_t per_bin = bin_width<C>(li), first = bin * per_bin;
     if (first >= li.table) return;                               // (dense levels: bins past the end of the table hold nothing)
     const uint32_t nfl = min(per_bin, li.table - first) * C;     // floats of the table this bin covers
-    const uint32_t nvec = per_bin * C / 4;                       // per_bin is even: a whole number of float4
+    const uint32_t nvec = per_bin * C / 4;                       // bin_width: a whole number of float4
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
     // the table's current content of this thread's quads does not depend on the records: requested now, it arrives under the record
     // phase instead of costing a memory round trip (four serialised ones, when the loads were issued per touched quad) at the end of a
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
 #pragma unroll
         for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
-    if (binned_level(li, C, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
+    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
     else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             }
         }
     }
-    if (binned_level(li, C, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
+    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
     else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
 }
 

@@ -11,19 +11,33 @@ crosses the process boundary and the PCIe bus every iteration (holoscene_train.p
 that the reference's own draws reproduce its batches index for index -- tests/golden/ns_sampler.npz) and hands a batch over either as
 the dictionaries ``__getitem__`` + ``collate_fn`` produce (``next_batch``) or gathered by ONE launch straight into the training graph's
 static input block (``write_batch``; csrc/encode_ops.hip: hs_gather_rows).  Batches are drawn ahead into a ring, off the critical path,
-as the reference's workers do.  Loading the image files stays with the reference's ``NSDataset`` (``from_reference``).
+as the reference's workers do, and every slot is REDRAWN once it has been served (datasets/ring.py: host threads in the role of the
+DataLoader workers) -- a new frame and new permutations for every iteration, as ns_dataset.py:380-430 has it.  Loading the image files
+stays with the reference's ``NSDataset`` (``from_reference``).
 """
 import random
 
 import numpy as np
 import torch
 
+from .ring import BatchRing
+
+
+def rank_seed(seed, rank=None):
+    """Data-parallel ranks must not draw the same frames and pixels (an effective batch of 1/N): the stream of a rank is derived from
+    its rank the way Stage1Trainer derives its own (seed + 7919 (rank + 1)).  rank None: the process group's rank when one is alive."""
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return int(seed) + 7919 * int(rank) if rank else int(seed)
+
 
 class ResidentNSDataset:
     def __init__(self, rgb_images, depth_images, normal_images, mask_images, semantic_images, semantic_images_classes, intrinsics_all, pose_all,
-                 img_res, num_pixels, fix_length=0, device="cuda", ring=64, seed=0):
+                 img_res, num_pixels, fix_length=0, device="cuda", ring=64, seed=0, rank=None, workers=8):
         """*_images: per-frame flat tensors as NSDataset stores them ([H*W, C]; lists or stacked); semantic_images_classes: per frame the
-        sorted class ids present in it (ns_dataset.py:307-308)."""
+        sorted class ids present in it (ns_dataset.py:307-308).  seed / rank: every data-parallel rank draws its own stream (rank_seed);
+        workers: host threads refilling the ring (the reference's DataLoader runs 8 worker processes, holoscene_train.py:128)."""
         dev = self.device = torch.device(device)
         stack = lambda t: (torch.stack(list(t)) if not torch.is_tensor(t) else t).float()  # noqa: E731
         self.rgb, self.depth, self.normal, self.mask = (stack(t).to(dev) for t in (rgb_images, depth_images, normal_images, mask_images))
@@ -41,10 +55,13 @@ class ResidentNSDataset:
         # pixel lists per (frame, class): torch.nonzero(semantic_images[idx] == class) of :419-421, computed once
         segs_host = self.segs.reshape(self.n_images, -1).cpu()
         self._class_pixels = [[torch.nonzero(segs_host[f] == c).reshape(-1) for c in self.classes[f]] for f in range(self.n_images)]
+        seed = rank_seed(seed, rank)
         self._gen = torch.Generator().manual_seed(seed)
         self._py = random.Random(seed)
-        self._ring_len, self._ring, self._cursor = ring, [], 0
-        self._plans, self._const_done = {}, set()
+        self._epoch = []                # fix_length == 0: frames of the current epoch still to be served (a shuffled DataLoader epoch)
+        self._epoch_lock = __import__("threading").Lock()
+        self._ring = BatchRing(self._draw, num_pixels, dev, ring=ring, workers=workers, seed=seed)
+        self._plans = {}
 
     @classmethod
     def from_reference(cls, ds, num_pixels, device="cuda", **kw):
@@ -56,9 +73,10 @@ class ResidentNSDataset:
         return self.n_images if self.fix_length == 0 else self.fix_length
 
     # ------------------------------------------------------------------ the sampling rule
-    def sample_indices(self, frame, draws=None):
+    def sample_indices(self, frame, draws=None, gen=None):
         """Pixel indices of one batch of `frame` (host tensor, int64), ns_dataset.py:409-430.  draws: optional iterator over the
         permutations ``torch.randperm`` returned in call order (one per class that has more pixels than its quota, then the uniform one)."""
+        gen = self._gen if gen is None else gen
         half = self.sampling_size // 2
         n_cls = len(self.classes[frame])
         per_class = half // n_cls
@@ -70,7 +88,7 @@ class ResidentNSDataset:
                 p = torch.as_tensor(next(it)).long()
                 assert p.numel() == n, "injected permutation has the wrong length"
                 return p
-            return torch.randperm(n, generator=self._gen)
+            return torch.randperm(n, generator=gen)
 
         chosen = []
         for i, pix in enumerate(self._class_pixels[frame]):
@@ -81,10 +99,23 @@ class ResidentNSDataset:
         chosen.append(perm(self.total_pixels)[: self.sampling_size - half])
         return torch.cat(chosen)
 
-    def pick_frame(self, idx=None):
-        if self.fix_length != 0 or idx is None:      # :382-383
-            return self._py.randint(0, self.n_images - 1)
-        return int(idx)
+    def pick_frame(self, idx=None, py=None):
+        """fix_length != 0: a random frame per item (:382-383).  fix_length == 0: the DataLoader hands out the frames of a shuffled
+        epoch (holoscene_train.py:124-127, shuffle=True) -- every frame once before any repeats."""
+        py = self._py if py is None else py
+        if self.fix_length != 0:
+            return py.randint(0, self.n_images - 1)
+        if idx is not None:
+            return int(idx)
+        with self._epoch_lock:
+            if not self._epoch:
+                self._epoch = list(range(self.n_images))
+                py.shuffle(self._epoch)
+            return self._epoch.pop()
+
+    def _draw(self, gen, py):
+        f = self.pick_frame(py=py)
+        return f, self.sample_indices(f, gen=gen)
 
     # ------------------------------------------------------------------ batches
     def get(self, frame, sampling_idx):
@@ -95,33 +126,32 @@ class ResidentNSDataset:
               "normal": self.normal[frame][idx][None], "segs": self.segs[frame][idx][None]}
         return torch.tensor([frame]), sample, gt
 
-    def _fill_ring(self):
-        while len(self._ring) < self._ring_len:
-            f = self.pick_frame()
-            idx = self.sample_indices(f)
-            self._ring.append((f, idx.to(self.device), torch.tensor([f], dtype=torch.int64).to(self.device)))
-
     def next_batch(self):
-        self._fill_ring()
-        frame, idx, _ = self._ring[self._cursor % self._ring_len]
-        self._cursor += 1
-        return self.get(frame, idx)
+        s = self._ring.acquire()
+        out = self.get(s.frame, s.idx[:s.count])
+        self._ring.release(s)
+        return out
 
     def write_batch(self, dst_input, dst_gt):
         """The next ring batch gathered straight into existing buffers (the training graph's static input block) by one launch."""
         from ..hashencoder import backend as _be
-        self._fill_ring()
-        slot = self._cursor % self._ring_len
-        self._cursor += 1
-        frame, idx, fidx = self._ring[slot]
-        if idx.numel() != dst_input["uv"].shape[1]:
-            raise RuntimeError(f"batch of {idx.numel()} rays (a class of frame {frame} has fewer pixels than its quota, ns_dataset.py:422-427) "
-                               f"does not fit the static block of {dst_input['uv'].shape[1]}: use next_batch() / the eager path for such scenes")
-        tag = dst_input["uv"].data_ptr()
-        plan = self._plans.get((slot, tag))
-        if plan is None:
-            plan = self._plans[(slot, tag)] = _be._backend.gather_plan([
-                (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
-                (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),
-                (self.mask[frame], dst_gt["mask"], idx), (self.segs[frame], dst_gt["segs"], idx)])
-        _be._backend.gather_rows(plan)
+        s = self._ring.acquire()
+        try:
+            if s.count != dst_input["uv"].shape[1]:
+                raise RuntimeError(f"batch of {s.count} rays (a class of frame {s.frame} has fewer pixels than its quota, ns_dataset.py:422-427) "
+                                   f"does not fit the static block of {dst_input['uv'].shape[1]}: use next_batch() / the eager path for such scenes")
+            # the launch plan holds pointers only: the slot's index tensors are static (their CONTENT is redrawn), the per-frame
+            # sources depend on the frame the slot currently holds
+            key = (s.i, s.frame, dst_input["uv"].data_ptr())
+            plan = self._plans.get(key)
+            if plan is None:
+                if len(self._plans) >= 4096:      # (slot, frame) pairs of a long scene: the cache is a convenience, not state
+                    self._plans.clear()
+                frame, idx, fidx = s.frame, s.idx, s.fidx
+                plan = self._plans[key] = _be._backend.gather_plan([
+                    (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
+                    (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),
+                    (self.mask[frame], dst_gt["mask"], idx), (self.segs[frame], dst_gt["segs"], idx)])
+            _be._backend.gather_rows(plan)
+        finally:
+            self._ring.release(s)

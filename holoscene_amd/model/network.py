@@ -228,7 +228,7 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     M = 4 * B
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
-    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L * C == 32 and D == 3 and F_in == 71
+    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L == 16 and C == 2 and D == 3 and F_in == 71   # the kernel hard-codes the stock 16 x 2 grid
     fuse_split = wave and split is not None and TRUNK_SPLIT_FUSED      # the kernel writes the split outputs itself: no Y at all
     Y = None if fuse_split else torch.empty(M, d_out, device=dev, dtype=torch.float32)
     bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
@@ -246,7 +246,7 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     if TRUNK_FWD_IMPL not in ("wave", "tile"):
         raise RuntimeError(f"unknown HOLOSCENE_TRUNK_FWD_IMPL={TRUNK_FWD_IMPL!r}")
     X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
-    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L * C == 32 and D == 3   # k_trunk_fwd assembles its input rows itself
+    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L == 16 and C == 2 and D == 3   # k_trunk_fwd assembles its input rows itself
     if not build_in_kernel:
         _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
     w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
@@ -843,9 +843,15 @@ class ObjectImplicitNetworkGrid(nn.Module):
     def _fused_trunk_supported(self, x):
         lins = self._lins()
         return (self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None
-                and self.embedder.multires == 6 and self.grid_feature_dim == 32 and lins[0].out_features == 256
+                and self.embedder.multires == 6 and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].out_features == 256
                 and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features <= 64
                 and not any(l in self.skip_in for l in range(3)))
+
+    def _stock_grid(self):
+        """The fused MLP kernels address hash features as 16 levels x 2 channels (csrc/sdf_mlp2.hip, trunk_mlp2.hip: no L / C arguments);
+        any other split of the 32 features (8 x 4, 32 x 1) takes the library-GEMM path."""
+        enc = self.encoding
+        return getattr(enc, "num_levels", None) == 16 and getattr(enc, "level_dim", None) == 2 and getattr(enc, "input_dim", 3) == 3
 
     def _fused_sdf_supported(self, x):
         return not torch.is_grad_enabled() and self._fused_trunk_supported(x)

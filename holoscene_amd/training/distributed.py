@@ -45,8 +45,9 @@ def reduce_scatter_sum(out_shard, full, world_size, rank, group=None):
     CPU tests cover exactly the indexing the RCCL branch uses."""
     n = out_shard.numel()
     if dist.get_backend(group) == "gloo":
-        for r in range(world_size):
-            dist.reduce(full[r * n:(r + 1) * n], dst=r, op=dist.ReduceOp.SUM, group=group)    # only dst's slice is defined afterwards
+        for r in range(world_size):     # `dst` is a GLOBAL rank: translate the group-local index when a sub-group is used
+            dst = r if group is None else dist.get_global_rank(group, r)
+            dist.reduce(full[r * n:(r + 1) * n], dst=dst, op=dist.ReduceOp.SUM, group=group)    # only dst's slice is defined afterwards
         out_shard.copy_(full[rank * n:(rank + 1) * n])
     else:
         dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)

@@ -5,11 +5,14 @@ circle of radius 0.7 in the z=0 plane looking at the origin; instance mask = K v
 rgb ~ U[0,1], depth ~ U[0.1,1], unit normals from N(0,I), mask = 1.  Pixel batches follow the
 reference's class-balanced rule (datasets/ns_dataset.py:409-430): half of the rays split evenly over
 the classes present (background takes the remainder), the other half uniform over the image.
-Everything is generated once and kept resident in HBM; a ring of pre-drawn pixel batches stands in
-for the reference's DataLoader workers.
+The frames are generated once and kept resident in HBM; the pixel batches are drawn ahead into a ring
+that host threads refill behind the consumer (datasets/ring.py -- the reference's 8 DataLoader workers):
+every iteration sees a new frame pick and new permutations, as ns_dataset.py:380-430 has it.
 """
 import numpy as np
 import torch
+
+from ..datasets.ring import BatchRing
 
 
 def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
@@ -26,7 +29,7 @@ def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
 
 
 class SyntheticScene:
-    def __init__(self, num_rays, num_classes, img_res=(512, 512), num_frames=8, ring=64, seed=1234, device="cuda"):
+    def __init__(self, num_rays, num_classes, img_res=(512, 512), num_frames=8, ring=64, seed=1234, device="cuda", workers=8, redraw=True):
         self.R, self.K = num_rays, num_classes
         self.H, self.W = img_res
         self.F = num_frames
@@ -48,15 +51,12 @@ class SyntheticScene:
         ys, xs = torch.meshgrid(torch.arange(self.H), torch.arange(self.W), indexing="ij")
         self.uv_all = torch.stack([xs, ys], -1).reshape(npix, 2).float().to(self.device)
         self._class_pixels = [torch.nonzero(self.segs.cpu().reshape(-1) == c).reshape(-1) for c in range(num_classes)]
-        self._ring = [self._draw(g) for _ in range(ring)]
-        self._ring_dev = [(f, idx.to(self.device)) for f, idx in self._ring]
-        self._cursor = 0
+        self._ring = BatchRing(self._draw, num_rays, self.device, ring=ring, workers=workers, seed=seed, redraw=redraw)
         self._plans, self._const_done = {}, set()
-        self._frame_idx = [torch.tensor([f], dtype=torch.int64).to(self.device) for f, _ in self._ring]   # made here: no host->device copy (= sync) per step
 
-    def _draw(self, g):
+    def _draw(self, g, py):
         """One (frame, pixel-index) batch, ns_dataset.py:383, 409-430."""
-        frame = int(self.rng.randint(0, self.F))
+        frame = py.randint(0, self.F - 1)
         half = self.R // 2
         per_class = half // self.K
         n_bg = half - per_class * (self.K - 1)
@@ -70,30 +70,34 @@ class SyntheticScene:
         return frame, torch.cat(chosen)
 
     def next_batch(self):
-        frame, idx = self._ring_dev[self._cursor % len(self._ring_dev)]
-        self._cursor += 1
+        s = self._ring.acquire()
+        frame, idx = s.frame, s.idx[:s.count]
         model_input = {"uv": self.uv_all[idx][None], "intrinsics": self.intrinsics, "pose": self.poses[frame][None]}
         gt = {"rgb": self.rgb[frame][idx][None], "depth": self.depth[frame][idx][None], "normal": self.normal[frame][idx][None],
               "mask": torch.ones(1, idx.numel(), 1, device=self.device), "segs": self.segs[idx][None]}
+        self._ring.release(s)
         return torch.tensor([frame]), model_input, gt
 
     def write_batch(self, dst_input, dst_gt):
         """next_batch() written straight into existing buffers (the training graph's static input block) by ONE gather launch
         (csrc/encode_ops.hip: hs_gather_rows) instead of six indexing launches plus the copies into the block.  Same ring, same
-        cursor: interleaving next_batch() and write_batch() walks the same sequence of batches."""
+        cursor: interleaving next_batch() and write_batch() walks the same sequence of batches.  The launch plan of a (slot, frame)
+        pair holds pointers only -- the slot's index tensor is static, its content is redrawn after every use."""
         from ..hashencoder import backend as _be
-        slot = self._cursor % len(self._ring_dev)
-        self._cursor += 1
-        tag = dst_input["uv"].data_ptr()
-        plan = self._plans.get((slot, tag))
-        if plan is None:
-            frame, idx = self._ring_dev[slot]
-            fidx = self._frame_idx[slot]
-            plan = self._plans[(slot, tag)] = _be._backend.gather_plan([
-                (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
-                (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
-        if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
-            dst_input["intrinsics"].copy_(self.intrinsics)
-            dst_gt["mask"].fill_(1.0)
-            self._const_done.add(tag)
-        _be._backend.gather_rows(plan)
+        s = self._ring.acquire()
+        try:
+            tag = dst_input["uv"].data_ptr()
+            key = (s.i, s.frame, tag)
+            plan = self._plans.get(key)
+            if plan is None:
+                frame, idx, fidx = s.frame, s.idx, s.fidx
+                plan = self._plans[key] = _be._backend.gather_plan([
+                    (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
+                    (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
+            if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
+                dst_input["intrinsics"].copy_(self.intrinsics)
+                dst_gt["mask"].fill_(1.0)
+                self._const_done.add(tag)
+            _be._backend.gather_rows(plan)
+        finally:
+            self._ring.release(s)

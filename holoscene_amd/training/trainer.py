@@ -174,7 +174,7 @@ class Stage1Trainer:
         """Start of an iteration body (before the forward pass, so that the producers of the tables' gradients are counted):
         advance the optimiser state once and ask to be told when each table's gradient is final."""
         self._early_done = ()
-        if self._overlap:
+        if self._overlap and not self.freeze_parameters:
             self.flat.tick()
             for s_, t in enumerate(self._early_tables()):
                 t._hs_scatter_watch.arm(lambda s_=s_: self._exchange_early_segment(s_))
@@ -198,6 +198,8 @@ class Stage1Trainer:
 
     # ------------------------------------------------------------------ eager path
     def _exchange_and_step(self):
+        if self.freeze_parameters:      # tests: gradients only -- no exchange, no Adam step, no step / learning-rate tick
+            return
         if self.flat is not None:
             if self.dp:
                 self._finish_exchange()
@@ -252,22 +254,25 @@ class Stage1Trainer:
     def _update_in_body(self):
         """Tail of a captured iteration body: the Adam step (single process), or -- when the collectives are capturable -- the
         whole data-parallel exchange; otherwise the exchange follows the replay (`_after_replay`)."""
+        if self.freeze_parameters:
+            return
         if not self.dp:
-            if not self.freeze_parameters:
-                self.flat.step()
+            self.flat.step()
         elif self._overlap:
             self._finish_exchange()
 
     def _after_replay(self):
-        if self.dp and not self._overlap:
+        if self.dp and not self._overlap and not self.freeze_parameters:
             dist_util.exchange_and_step_flat(self.flat, self.world_size, zero1=self.zero1)
 
     # ------------------------------------------------------------------ whole-iteration graph
     def _capture_mode(self):
-        """With a process group alive, its watchdog thread polls events of in-flight collectives (cudaEventQuery / hipEventQuery) --
-        a call that is illegal for ANY thread while some stream captures in "global" mode and would invalidate the capture.  The
-        captured region itself contains no collective, so thread-local capture checking is the right scope for N > 1."""
-        return "thread_local" if self.dp else "global"
+        """Thread-local capture checking.  Other threads of this process make calls that are illegal for ANY thread while some
+        stream captures in "global" mode and would invalidate the capture: a process group's watchdog polls the events of in-flight
+        collectives (hipEventQuery), the refill threads of a device-resident dataset wait for `consumed` events and enqueue
+        host->device copies (datasets/ring.py).  None of them touches the capturing stream, so the capturing thread is the right
+        scope of the check."""
+        return "thread_local"
 
     def _full_graph_ok(self):
         """Rays, sampler (device-side loop control), render, loss, backward and Adam in ONE graph: possible whenever the sampler

@@ -231,7 +231,7 @@ def test_graph_training_reduces_loss():
     tr = Stage1Trainer(stock_conf(num_rays=256, S=32, d_out=4, num_levels=8, end_size=256, logmap=14, beta=0.05), device=DEV,
                        optimizer="flat", graph=True)
     benchmark_model_state(tr.model, 0.05)
-    scene = SyntheticScene(256, 4, img_res=(64, 64), num_frames=1, ring=1, device=DEV)
+    scene = SyntheticScene(256, 4, img_res=(64, 64), num_frames=1, ring=1, device=DEV, redraw=False)   # overfit ONE batch
     losses = []
     for _ in range(40):
         idx, mi, gt = scene.next_batch()
@@ -1229,6 +1229,20 @@ def test_resident_ns_dataset_gather_equals_indexed_batches():
             assert torch.equal(dst_gt[k], v), k
         done += 1
     assert done >= 8
+
+
+def test_resident_ns_dataset_equals_the_references_batches_on_the_device():
+    """SURVEY 8f rank 4 on the MI355X: the HBM-resident frames, indexed on the device with the reference's own permutation draws,
+    give the reference's batches (datasets/ns_dataset.py:409-453; fixture ns_sampler, incl. its ragged batch)."""
+    from test_dataset_cpu import check_batches_equal_reference
+    check_batches_equal_reference(DEV)
+
+
+def test_resident_ns_dataset_ring_is_refilled_by_its_worker_threads():
+    """The device ring is redrawn behind the consumer by host threads (datasets/ring.py): no batch served twice, deterministic per
+    seed, distinct per rank."""
+    from test_dataset_cpu import check_ring_is_redrawn
+    check_ring_is_redrawn(DEV, workers=3)
 
 
 @pytest.mark.parametrize("name", ["object_sdf_fg", "object_sdf_bg"])
