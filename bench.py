@@ -139,6 +139,36 @@ def _work_adam(a, k):
     return 0, 7 * 4 * (a[5] - a[4])
 
 
+def _work_scatter_plain(a, k):
+    B, C, L = a[4], a[6], a[7]       # bwd(grad, inputs, offsets, grad_embeddings, B, D, C, L, ...): read-modify-write of 8 corners per level
+    return 0, B * (2 * L * 8 * C * 4 + L * C * 4 + 12)
+
+
+def _work_wgrad(a, k):
+    fl = by = 0
+    for A, Bm in a[0]:
+        fl += 2 * A.shape[0] * A.shape[1] * Bm.shape[1]
+        by += A.numel() * 2 + Bm.numel() * 2
+    return fl, by
+
+
+def _work_trunk_bwd3(a, k):
+    M = int(k.get("M", 0)) or a[0].shape[0]
+    K = _K_OBJECTS[0] or 32
+    # recomputed forward (layers 0, 1) + data-gradient chain + three weight gradients, unpadded shapes
+    fwd01 = 2 * (K_IN * 256 + 256 * 256)
+    chain = 2 * (256 * K + 256 * 256 + K_IN * 256)
+    wgr = 2 * (256 * K + 256 * 256 + K_IN * 256)
+    return M * (fwd01 + chain + wgr), M * (80 * 2 + 32 * 2) + (M // 4) * (128 + 384)
+
+
+def _work_bmm(a, k):
+    A, Bm = a[0], a[1]
+    S, m, kk = A.shape
+    n = Bm.shape[2]
+    return 2 * S * m * kk * n, (A.numel() + Bm.numel()) * A.element_size() + S * m * n * A.element_size()
+
+
 _K_OBJECTS = [0]
 # backend entry point -> (kernel label, work model returning (algorithmic FLOPs, algorithmic bytes) of one call)
 TIMED = {
@@ -158,7 +188,30 @@ TIMED = {
     "sampler_draw_steps": ("k_sampler_draw (final draw + realised loop state)", None),
     "composite_fwd": ("k_composite_fwd", None),
     "composite_bwd": ("k_composite_bwd", None),
+    "bwd": ("hs_hash_bwd (colour-table scatter: k_hash_bwd_scatter + k_hash_bin_reduce)", _work_scatter_plain),
+    "wgrad_rows": ("k_wgrad_rows (weight gradients of a backward stage, split-M, one launch)", _work_wgrad),
+    "sum_slices": ("k_sum_slices (fp32 sums of the split-M partials)", None),
+    "trunk_split_bwd": ("k_trunk_split_bwd (cotangent image of the trunk outputs)", None),
+    "trunk_split_fwd": ("k_trunk_split_fwd", None),
+    "pack_bf16": ("k_pack_bf16 (bf16 operand images of the fp32 master weights)", None),
+    "sdf_mlp2_pack": ("k_sdf_pack2 (fragment-order weight images)", None),
+    "weight_norm_fwd": ("k_weight_norm<fwd>", None),
+    "weight_norm_bwd": ("k_weight_norm<bwd>", None),
+    "copy_many": ("k_copy_many (small gradients -> flat buffer)", None),
+    "gather_rows": ("k_gather_rows (pixel batch from the HBM-resident frames)", None),
+    "render_points": ("k_render_points", None),
+    "ray_setup": ("k_ray_setup", None),
+    "sampler_final": ("k_sampler_final", None),
+    "sampler_pick": ("k_sampler_pick", None),
+    "loss_stage1": ("k_loss_ray_local + k_loss_rays + k_loss_eikonal (hs_loss_stage1)", None),
+    "bg_smooth_loss": ("k_bg_smooth", None),
+    "adam_tick": ("k_adam_tick", None),
+    "softplus_tangent_fwd": ("k_softplus_tangent_fwd", None),
+    "softplus_tangent_bwd": ("k_softplus_tangent_bwd", None),
+    "softplus_tangent_bwd_h": ("k_softplus_tangent_bwd_h", None),
+    "trunk_mlp3_bwd": ("k_trunk_bwd3 (trunk backward: recompute + data-gradient chain + all three weight gradients in one kernel)", _work_trunk_bwd3),
 }
+LIBRARY_GEMM = "library GEMMs (hipBLASLt through torch.bmm: weight gradients not taken by k_wgrad_rows)"
 
 
 class KernelTimers:
@@ -189,22 +242,37 @@ class KernelTimers:
                 return r
 
             setattr(self.cls, n, staticmethod(timed))
+        # the library GEMMs of the iteration (weight gradients that stay with hipBLASLt) all go through torch.bmm
+        self._bmm = torch.bmm
+        self.records[LIBRARY_GEMM] = []
+
+        def timed_bmm(*a, **k):
+            if not self.enabled:
+                return self._bmm(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self._bmm(*a, **k)
+            e.record()
+            self.records[LIBRARY_GEMM].append((s, e, _work_bmm(a, k)))
+            return r
+        torch.bmm = timed_bmm
         return self
 
     def __exit__(self, *exc):
         for n, raw in self._raw.items():
             setattr(self.cls, n, raw)
+        torch.bmm = self._bmm
 
     def summary(self, iterations):
         out = []
-        for n in self.names:
+        for n in self.names + [LIBRARY_GEMM]:
             rec = self.records[n]
             if not rec:
                 continue
             us = [s.elapsed_time(e) * 1e3 for s, e, _ in rec]
             flops, nbytes = sum(w[0] for _, _, w in rec), sum(w[1] for _, _, w in rec)
             tot = sum(us)
-            d = {"kernel": TIMED[n][0], "calls_per_iter": round(len(rec) / iterations, 2), "avg_us": round(tot / len(rec), 2),
+            d = {"kernel": TIMED[n][0] if n in TIMED else n, "calls_per_iter": round(len(rec) / iterations, 2), "avg_us": round(tot / len(rec), 2),
                  "us_per_iter": round(tot / iterations, 1)}
             if flops:
                 d["tflops"] = round(flops / (tot * 1e-6) / 1e12, 1)
@@ -320,14 +388,21 @@ def main():
     rounds_seen.clear()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # per-step GPU time stamps: no sync inside the loop
+    is_bg = []
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        is_bg.append(bool(tr.model.wants_background(tr.iter_step)))      # every render_bg_iter-th iteration also renders the 32 x 32 patch
         step()
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    raw_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    per_step = sorted(raw_step)
+    reg = [t for t, b in zip(raw_step, is_bg) if not b]
+    bgs = [t for t, b in zip(raw_step, is_bg) if b]
+    iteration_kinds = {"regular": {"count": len(reg), "ms_mean": round(sum(reg) / max(1, len(reg)), 3)},
+                       "background_patch": {"count": len(bgs), "ms_mean": round(sum(bgs) / max(1, len(bgs)), 3) if bgs else None}}
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -336,29 +411,55 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.rays * world * args.steps / elapsed
 
-    # ---- N > 1: how long the one exchange per iteration (reduce-scatter -> shard Adam -> all-gather) is exposed after the graph
+    # ---- N > 1: what the one exchange per iteration (reduce-scatter -> shard Adam -> all-gather, per segment) costs.  Collectives
+    # captured inside the iteration graph cannot be bracketed by events, so the SAME process times, 20 steps each: the serial form
+    # (whole exchange after the graph) and no exchange at all (a single-process trainer on this rank's GPU); exposed = form - none.
     exchange_ms = None
     exchange_form = None
+    exchange_cmp = None
+    rccl_world = None
     if world > 1:
-        exchange_form = ("in-graph: colour-table segment (reduce-scatter, shard Adam, all-gather) on a side stream under the trunk backward, "
-                         "remaining segment at the end of the backward pass" if tr._overlap else "serial, after the iteration graph")
-    if world > 1 and not tr._overlap:     # (captured collectives cannot be bracketed by events; the driver's N=1 line is the comparison)
-        ev = []
-        orig_x = dist_util.exchange_and_step_flat
+        exchange_form = ("in-graph: each hash table's segment (reduce-scatter, shard Adam, all-gather) on a side stream as soon as its gradient is "
+                         "final, remaining segment at the end of the backward pass" if tr._overlap else "serial, after the iteration graph")
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl_world = int(ones.item())                   # from a collective's RESULT, not from get_world_size()
 
-        def timed_exchange(*a, **k):
-            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_.record()
-            r_ = orig_x(*a, **k)
-            e_.record()
-            ev.append((s_, e_))
-            return r_
-        dist_util.exchange_and_step_flat = timed_exchange
-        for _ in range(10):
-            step()
-        barrier()
-        dist_util.exchange_and_step_flat = orig_x
-        exchange_ms = round(sum(s_.elapsed_time(e_) for s_, e_ in ev) / max(1, len(ev)), 3)
+        def timed_steps(trn, n=20, warm=12):
+            for _ in range(warm):
+                trn.train_step_resident(scene)
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                trn.train_step_resident(scene)
+            barrier()
+            el = time.perf_counter() - t_
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            return float(tt) / n * 1e3
+
+        def variant(ws, exchange):
+            t_ = Stage1Trainer(conf, device=dev, world_size=ws, rank=rank if ws > 1 else 0, seed=42, optimizer=args.optimizer,
+                               graph=(not args.no_graph) and args.optimizer == "flat", exchange=exchange)
+            benchmark_model_state(t_.model, args.beta)
+            if ws > 1:
+                dist_util.broadcast_parameters(t_.model)
+            ms = timed_steps(t_)
+            form = "overlap" if getattr(t_, "_overlap", False) else ("serial" if ws > 1 else "none")
+            del t_
+            return ms, form
+        if args.optimizer == "flat":
+            here_ms = timed_steps(tr, warm=0)
+            other_ms, other_form = variant(world, "serial" if tr._overlap else "overlap")
+            none_ms, _ = variant(1, None)
+            mine = "overlap" if tr._overlap else "serial"
+            exchange_cmp = {"steps": 20, f"{mine}_ms_per_step": round(here_ms, 3), f"{other_form}_ms_per_step" if other_form != mine else "other_form_unavailable": round(other_ms, 3),
+                            "no_exchange_ms_per_step": round(none_ms, 3),
+                            "note": "same process, 20 steps each, max over ranks; no_exchange = a world-size-1 trainer on this rank's GPU"}
+            exchange_ms = round(here_ms - none_ms, 3)
+            exchange_cmp[f"exposed_{mine}_ms"] = exchange_ms
+            if other_form != mine:
+                exchange_cmp[f"exposed_{other_form}_ms"] = round(other_ms - none_ms, 3)
     # ---- rooflines.  Kernels inside a replayed HIP graph cannot be bracketed by events, so the same iteration is run eagerly a few
     # times right after the timed region and every launch of the hand-written kernels is timed with HIP events on the launching
     # stream.  Work models: SURVEY 8(d)'s ALGORITHMIC bytes / FLOPs on the unpadded layer shapes (71-wide trunk input, K objects).
@@ -429,6 +530,8 @@ def main():
         "note": "SURVEY 8(d) formulas at the realised sampler rounds, divided by the median step time of the timed region"}
     roofline["eager_iteration_us"] = round(e0.elapsed_time(e1) * 1e3 / max(1, args.roofline_steps), 1)
     roofline["timed_kernels_us_per_iter"] = round(sum(d["us_per_iter"] for d in kernels), 1)
+    regular_us = (iteration_kinds["regular"]["ms_mean"] or median_ms) * 1e3
+    roofline["timed_fraction_of_regular_iteration"] = round(roofline["timed_kernels_us_per_iter"] / regular_us, 3)
     # ---- SURVEY 8(d)'s second reported point: beta = 0.1 (1 sampler round; no sample has an exactly-zero cotangent, so the
     # scatter kernels issue every atomic).  Same code path, shorter run, reported beside the headline value.
     second = None
@@ -481,7 +584,7 @@ def main():
         line = {
             "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
+            "ms_per_step_median": round(median_ms, 3), "iteration_kinds": iteration_kinds, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
                                    f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
@@ -498,9 +601,10 @@ def main():
         if fp32_point is not None:
             line["config"]["fp32_point"] = fp32_point
         if world > 1:
-            line["config"]["rccl_world_size"] = torch.distributed.get_world_size()
+            line["config"]["rccl_world_size"] = rccl_world
             line["config"]["exchange"] = exchange_form
             line["config"]["exchange_ms_exposed"] = exchange_ms
+            line["config"]["exchange_comparison"] = exchange_cmp
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line))

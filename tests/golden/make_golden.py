@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import hash_oracle  # noqa: E402
-from helpers import stock_hash_table  # noqa: E402
+from helpers import stock_hash_table, seeded_table, TABLE_KEYS, TABLE_SAMPLE_STRIDE, table_digest  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- import shims
@@ -136,7 +136,10 @@ class DrawLog:
 # confs/replica/room_0/replica_room_0.conf (width 256, feature 256, 16 levels, base 16 -> 2048) with a small hash table so the
 # fixture stays small: those are the shapes the fused matrix-core kernels of the product are built for.
 SHAPES = {"tiny": dict(L=4, base=4, end=32, logmap=10, width=64, feat=32),
-          "stock": dict(L=16, base=16, end=2048, logmap=12, width=256, feat=256)}
+          "stock": dict(L=16, base=16, end=2048, logmap=12, width=256, feat=256),
+          # BASELINE configs[1] as it is benchmarked: the full 2^19-entry tables (48.8 MB each).  A fixture of this shape stores its tables
+          # as seeds (+ digest) and every table-sized result as a digest: strided row sample + per-level sums (helpers.table_digest)
+          "full": dict(L=16, base=16, end=2048, logmap=19, width=256, feat=256)}
 
 
 def shape_meta(shape):
@@ -227,15 +230,34 @@ def distinct_objects(model, K, g):
         l2.bias[:K] += 0.15 * torch.randn(K, generator=g)
 
 
-def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, seed, res=64, adam_steps=2, shape="tiny", distinct=False):
+def split_tables(prefix, d, out, offsets):
+    """to_np for a dict that may hold the two hash tables: those go in as digests (the initial state, which the tests regenerate from
+    its seed, with a sparser sample)."""
+    small = {k: v for k, v in d.items() if k not in TABLE_KEYS}
+    to_np(prefix, small, out)
+    stride = TABLE_SAMPLE_STRIDE * (64 if prefix == "state." else 1)
+    for k in TABLE_KEYS:
+        if k in d and d[k] is not None:
+            for kk, vv in table_digest(d[k].detach(), offsets, stride).items():
+                out[f"{prefix}{k}#{kk}"] = vv
+
+
+def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, seed, res=64, adam_steps=2, shape="tiny", distinct=False,
+                  emb_scale=2e-2):
     torch.manual_seed(seed)
     np.random.seed(seed)
     conf = small_conf(K, S, beta, **SHAPES[shape])
     model = Net(conf=conf, graph_node_dict=None, num_images=4)
     model.train()
-    perturb(model, seed + 1)
+    perturb(model, seed + 1, emb_scale=emb_scale)
     if distinct:
         distinct_objects(model, K, torch.Generator().manual_seed(seed + 5))
+    compact = shape == "full"
+    offsets = model.implicit_network.encoding.offsets.numpy().astype(np.int64)
+    if compact:     # tables regenerated from a seed by the tests (helpers.load_full) instead of stored
+        with torch.no_grad():
+            for i, enc in enumerate((model.implicit_network.encoding, model.implicit_network.color_encoding)):
+                enc.embeddings.copy_(seeded_table(seed * 10 + i, enc.embeddings.shape[0], emb_scale))
     loss_fn = Loss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, smooth_weight=0.005, depth_weight=0.5, normal_l1_weight=0.05,
                    normal_cos_weight=0.05, semantic_loss="torch.nn.MSELoss", use_obj_opacity=True, semantic_weight=5.0,
                    reg_vio_weight=0.01, bg_reg_weight=0.01, depth_type="marigold")
@@ -243,7 +265,11 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
     pose = look_at_pose(eye)
     rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.iter_step": iter_step, "meta.call_reg": int(call_reg), "meta.res": res,
            **shape_meta(shape)}
-    to_np("state.", model.state_dict(), rec)
+    if compact:
+        rec["meta.table_seed"], rec["meta.emb_scale"] = seed * 10, np.float64(emb_scale)
+        split_tables("state.", model.state_dict(), rec, offsets)
+    else:
+        to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(uv=uv, pose=pose, intrinsics=intr), rec)
     to_np("gt.", gt, rec)
     lr, lr_grid = 5e-4, 5e-4 * 20
@@ -281,16 +307,17 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
                 rec[f"rand.{k}"] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
             to_np("out.", {k: v for k, v in out.items() if torch.is_tensor(v)}, rec)
             to_np("loss.", lo, rec)
-            to_np("grad.", {k: p.grad for k, p in model.named_parameters() if p.grad is not None}, rec)
+            grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+            split_tables("grad.", grads, rec, offsets) if compact else to_np("grad.", grads, rec)
             rec["meta.has_bg"] = int("bg_depth_values" in out)
             # sampler round count is not exposed by the reference; recover it from the merged sample count
         opt.step()
         if step == 0:
-            to_np("adam1.", dict(model.named_parameters()), rec)
+            split_tables("adam1.", dict(model.named_parameters()), rec, offsets) if compact else to_np("adam1.", dict(model.named_parameters()), rec)
         break  # later Adam steps need fresh draws; one step pins the optimiser arithmetic
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **rec)
-    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  loss={float(lo['loss']):.6f}  N={out['z_vals'].shape[1]}")
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  loss={float(lo['loss']):.6f}  N={out['z_vals'].shape[1]}  rounds={rec['meta.rounds']}")
 
 
 def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shape="tiny"):
@@ -309,9 +336,35 @@ def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shap
     calls = []
     orig = model.implicit_network.get_sdf_vals
     model.implicit_network.get_sdf_vals = lambda p: (calls.append(p.shape[0]), orig(p))[1]
+    # per-round intermediates of Algorithm 1 -- well-conditioned quantities that pin the update kernel far tighter than final depths can:
+    # the merged sample set and its SDF values, d* (Theorem 1), the error bound at beta0, beta after the line search.  Taken by
+    # observing the arguments of get_error_bound (:182-188, 1 + beta_iters calls per round) and of the density call that follows the
+    # search (:193); the reference's source is not touched.
+    sm = model.ray_sampler
+    rounds_log = []
+    orig_eb, orig_dens = sm.get_error_bound, model.density.forward
+
+    def eb(beta, mdl, sdf, z_vals, dists, d_star):
+        out = orig_eb(beta, mdl, sdf, z_vals, dists, d_star)
+        if not rounds_log or rounds_log[-1]["calls"] == 1 + sm.beta_iters:
+            rounds_log.append({"calls": 0, "z": z_vals.detach().clone(), "sdf": sdf.reshape(z_vals.shape).detach().clone(),
+                               "d_star": d_star.detach().clone(), "err0": out.detach().clone()})
+        rounds_log[-1]["calls"] += 1
+        return out
+
+    def dens(sdf, beta=None):
+        if beta is not None and rounds_log and "beta" not in rounds_log[-1] and rounds_log[-1]["calls"] == 1 + sm.beta_iters:
+            rounds_log[-1]["beta"] = beta.reshape(-1).detach().clone()
+        return orig_dens(sdf, beta=beta)
+    sm.get_error_bound, model.density.forward = eb, dens
     with DrawLog() as log:
         z, z_eik = model.ray_sampler.get_z_vals(d, o, model)
+    sm.get_error_bound, model.density.forward = orig_eb, orig_dens
     rec = {"meta.K": K, "meta.S": S, "meta.R": R, "meta.train": int(train), "meta.rounds": len(calls), **shape_meta(shape)}
+    assert len(rounds_log) == len(calls), (len(rounds_log), len(calls))
+    for i, rl in enumerate(rounds_log):
+        for k in ("z", "sdf", "d_star", "err0", "beta"):
+            rec[f"round{i}.{k}"] = rl[k].numpy().copy()
     to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(ray_dirs=d, cam_loc=o), rec)
     names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
@@ -761,6 +814,14 @@ def main():
     if sel("stock_steps3_k32"):
         run_three_steps(Net, Loss, "stock_steps3_k32", K=32, S=16, R=24, beta=0.05, eye=(0.0, 0.1, 0.6), seed=150, shape="stock",
                         distinct=True)
+    # ---- BASELINE sizes (the configuration bench.py times): 1 024 rays x 128 samples, K = 32, L = 16, T = 2^19, background patch and
+    # collision term on; one more at configs[4]'s 2 048 x 192
+    if sel("full_c1"):
+        run_iteration(Net, Loss, "full_c1", K=32, S=128, R=1024, beta=0.01, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=310,
+                      res=512, shape="full", distinct=True)
+    if sel("full_c4"):
+        run_iteration(Net, Loss, "full_c4", K=32, S=192, R=2048, beta=0.01, eye=(0.0, 0.1, 0.6), iter_step=3, call_reg=False, seed=320,
+                      res=512, shape="full", distinct=True)
     for K in (21, 32):
         if sel(f"stock_net_k{K}"):
             run_network(Net, f"stock_net_k{K}", K=K, seed=140 + K, B=160, shape="stock")

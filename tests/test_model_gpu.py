@@ -61,24 +61,32 @@ def test_iteration(name):
         assert rel < 2e-2, (k, rel)
 
 
-def test_full_size_iteration_properties():
-    """BASELINE config 2 (1024 rays x 128 samples, K=32, 16-level grid): structural invariants."""
+@pytest.mark.parametrize("path", ["bf16_graph", "fp32_torch"])
+def test_full_size_iteration_properties(path):
+    """BASELINE config 2 (1024 rays x 128 samples, K=32, 16-level grid): structural invariants -- on the BENCHMARKED path (bf16 MLP
+    operands, flat buffers, the whole-iteration HIP graph: what bench.py replays) and on the fp32 / torch.optim path."""
     from holoscene_amd.training.synthetic import SyntheticScene
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
-    tr = Stage1Trainer(stock_conf(beta=0.001), device=DEV, optimizer="torch")
+    if path == "bf16_graph":
+        tr = Stage1Trainer(stock_conf(beta=0.001, mlp_precision="bf16"), device=DEV, optimizer="flat", graph=True)
+    else:
+        tr = Stage1Trainer(stock_conf(beta=0.001), device=DEV, optimizer="torch")
     benchmark_model_state(tr.model, 0.001)
     scene = SyntheticScene(1024, 32, device=DEV)
     idx, mi, gt = scene.next_batch()
     before = tr.model.implicit_network.encoding.embeddings.detach().clone()
     out, lo = tr.train_step(idx, mi, gt)
+    torch.cuda.synchronize()
+    if path == "bf16_graph":
+        assert ("full", True, False) in tr._graphs, "the step must have gone through the whole-iteration graph"
     z = out["z_vals"]
     assert z.shape == (1024, 98)
     assert bool((z[:, 1:] >= z[:, :-1]).all()), "depths must be sorted"
     assert float(z.min()) >= 0.0 and float(z.max()) <= 3.5 + 1e-6
     w = out["weights"]
-    assert bool((w >= -1e-6).all()) and bool((w.sum(-1) <= 1 + 1e-4).all()), "compositing weights form a sub-probability"
+    assert bool((w >= -1e-6).all()) and bool((w.sum(-1) <= 1 + (1e-3 if path == "bf16_graph" else 1e-4)).all()), "compositing weights form a sub-probability"
     assert out["grad_theta"].shape[0] == (32 + 1) * 4 * 1024 // 2
-    assert 1 <= tr.model.ray_sampler.last_rounds <= 5
+    assert 1 <= int(tr.model.ray_sampler.last_rounds) <= 5
     assert torch.isfinite(lo["loss"]) and "bg_depth_values" in out  # iteration 0 renders the background patch
     after = tr.model.implicit_network.encoding.embeddings.detach()
     assert float((after - before).abs().max()) > 0, "Adam must have moved the geometry grid"
@@ -672,6 +680,95 @@ def test_fused_mfma_appearance_vs_gemm_path(B):
         # quantities deep in the chain (d/d normals, table); the criterion is therefore relative to the established path
         assert rel < 0.1, (n, err, scale, rel)
         assert rel <= 1.5 * grel + 1e-3, (n, rel, grel)
+
+
+def _encode_relu_masks(layers, Bn):
+    """bool [Bn, 256] sign tensors of (hc, r0, r1) -> the ballot words hs_appearance_fwd leaves for the backward kernel (the inverse of the
+    decoding in test_appearance_relu_masks_equal_saved_signs)."""
+    ntiles = (Bn + 127) // 128
+    wave, k, lane = np.meshgrid(np.arange(8), np.arange(64), np.arange(64), indexing="ij")
+    nq, ph, j, pt, q, nt = wave & 3, wave >> 2, k & 3, (k >> 2) & 1, (k >> 3) & 3, k >> 5
+    row = ph * 64 + pt * 32 + (lane & 31)
+    neuron = nq * 64 + nt * 32 + q * 8 + 4 * (lane >> 5) + j
+    words = np.zeros((ntiles, 3, 8, 64), dtype=np.uint64)
+    shifts = np.arange(64, dtype=np.uint64)
+    for layer, m in enumerate(layers):
+        full = np.zeros((ntiles * 128, 256), dtype=bool)
+        full[:Bn] = m.cpu().numpy()
+        for tile in range(ntiles):
+            bits = full[tile * 128:(tile + 1) * 128][row, neuron].astype(np.uint64)        # [wave, k, lane]
+            words[tile, layer] = (bits << shifts).sum(-1, dtype=np.uint64)
+    return torch.from_numpy(words.view(np.int64).reshape(-1))
+
+
+@pytest.mark.parametrize("B", [25088, 1000])
+def test_fused_appearance_backward_on_fp32_relu_masks_is_tight(B, monkeypatch):
+    """Where the bf16 colour branch loses its 3-7 % of gradient parity (tools/exp/bf16_colour_branch_ab.py): ReLU units whose fp32
+    pre-activation lies within the bf16 rounding error of zero (7e-4 of the mask bits) switch their whole gradient on or off -- a
+    relative-L2 effect of sqrt(fraction) -- while bf16-stored cotangents and bf16 per-slice partials add nothing measurable.  So the
+    SHARP check of k_appear_bwd + k_wgrad_rows is on the masks of the fp32 forward: with those fed to the backward kernel (its ballot
+    words overwritten) every gradient must agree with fp32 autograd ~10x more tightly than on its own masks -- a dropped 5 % term
+    cannot hide in this bound."""
+    from holoscene_amd.model import network as N
+    from holoscene_amd.hashencoder import backend as Bk
+    torch.manual_seed(B + 1)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=5, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.5, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    rn = N.RenderingNetwork(256, "idr", 9, 3, [256, 256], weight_norm=True, multires_view=4, multires_point=4, multires_normal=4).to(DEV)
+    with torch.no_grad():
+        net.color_encoding.embeddings.uniform_(-0.5, 0.5)
+    pts = torch.rand(B, 3, device=DEV) * 2.4 - 1.2
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    nrm = (torch.randn(B, 3, device=DEV) * 0.7).requires_grad_(True)
+    cot = torch.randn(B, 3, device=DEV) * 0.05
+    mlp, enc = net.color_grid_feature_map_mlp, net.color_encoding
+    params = [enc.embeddings, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias] + [p for l in (rn.lin0, rn.lin1, rn.lin2)
+                                                                                          for p in (l.weight_v, l.weight_g, l.bias)]
+    names = ["table", "c0.w", "c0.b", "c1.w", "c1.b"] + [f"r{i}.{n}" for i in range(3) for n in ("v", "g", "bias")]
+    # fp32 forward, layer by layer, for the masks
+    net.set_mlp_precision("fp32")
+    rn.set_mlp_precision("fp32")
+    with torch.no_grad():
+        feat = enc(pts / net.divide_factor)
+        hc = torch.relu(feat @ mlp[0].weight.t() + mlp[0].bias)
+        fv = hc @ mlp[2].weight.t() + mlp[2].bias
+        emb = rn.embedview_fn
+        x = torch.cat([emb(pts), emb(dirs), emb(nrm.detach()), fv], -1)
+        r0 = torch.relu(x @ rn.lin0.weight.t() + rn.lin0.bias)
+        r1 = torch.relu(r0 @ rn.lin1.weight.t() + rn.lin1.bias)
+    words32 = _encode_relu_masks([hc > 0, r0 > 0, r1 > 0], B).to(DEV)
+    rgb = rn(pts, nrm, dirs, net._color_features(pts))
+    ref = [g.float() for g in torch.autograd.grad((rgb * cot).sum(), [nrm] + params)]
+
+    def fused(swap):
+        net.set_mlp_precision("bf16")
+        rn.set_mlp_precision("bf16")
+        be = Bk._backend
+        raw = be.appearance_bwd
+        if swap:
+            def with_fp32_masks(*a, **k):
+                a = list(a)
+                assert a[-1] is not None and a[-1].numel() == words32.numel()
+                a[-1] = words32
+                return raw(*a, **k)
+            monkeypatch.setattr(type(be), "appearance_bwd", staticmethod(with_fp32_masks))
+        rgb = N._fused_appearance.apply(pts, dirs, nrm, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                                        float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, rn.lin0.weight,
+                                        rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias)
+        out = [g.float() for g in torch.autograd.grad((rgb * cot).sum(), [nrm] + params)]
+        if swap:
+            monkeypatch.setattr(type(be), "appearance_bwd", staticmethod(raw))
+        return out
+
+    own, aligned = fused(False), fused(True)
+    worst_own = worst_al = 0.0
+    for a, o, b, n in zip(aligned, own, ref, ["d_normals"] + names):
+        ra = float((a - b).norm() / (b.norm() + 1e-20))
+        ro = float((o - b).norm() / (b.norm() + 1e-20))
+        print(f"PARITY appearance-bwd {n:10s} relL2 vs fp32: own bf16 masks {ro:.3e} | fp32 masks {ra:.3e}")
+        worst_own, worst_al = max(worst_own, ro), max(worst_al, ra)
+        assert ra < 1.2e-2, (n, ra)
+    assert worst_al < 0.5 * worst_own, (worst_al, worst_own)
 
 
 def _full_graph_trainer(beta, freeze, rays=256):

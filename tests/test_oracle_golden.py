@@ -172,3 +172,42 @@ def test_iteration_matches_reference(name):
     torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15).step()
     for k, v in section(rec, "adam1.").items():
         close(params[k].detach(), v, 1e-5, 1e-6, "adam1." + k)
+
+
+@pytest.mark.parametrize("name", ["sampler_1", "sampler_4", "stock_sampler_0"])
+def test_oracle_sampler_round_intermediates(name):
+    """The oracle's d* (Theorem 1), error bound (ray_sampler.py:450-458) and line search against the reference's per-round
+    intermediates (fixture keys round{i}.*: merged set, SDF, d*, bound at beta0, beta after the search)."""
+    import torch
+    from helpers import load, oracle_cfg, section
+    from oracle.stage1_oracle import Stage1Oracle
+    rec = load(name)
+    orc = Stage1Oracle(oracle_cfg(rec), section(rec, "state."))
+    c = orc.cfg
+    beta0 = orc.beta().detach()
+    beta = None
+    for r in range(int(rec["meta.rounds"])):
+        z, sdf, d_ref, e_ref, b_ref = (torch.from_numpy(rec[f"round{r}.{k}"]) for k in ("z", "sdf", "d_star", "err0", "beta"))
+        dists = z[:, 1:] - z[:, :-1]
+        if r == 0:
+            beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(c.eps + 1.0)))) * (dists ** 2).sum(-1))
+        a, b, cc = dists, sdf[:, :-1].abs(), sdf[:, 1:].abs()
+        first, second = a ** 2 + b ** 2 <= cc ** 2, a ** 2 + cc ** 2 <= b ** 2
+        s_ = (a + b + cc) / 2
+        heron = 2.0 * torch.sqrt(s_ * (s_ - a) * (s_ - b) * (s_ - cc)) / a
+        d_star = torch.where(first, b, torch.zeros_like(a))
+        d_star = torch.where(second, cc, d_star)
+        d_star = torch.where(~first & ~second & (b + cc - a > 0), heron, d_star)
+        d_star = (sdf[:, 1:].sign() * sdf[:, :-1].sign() == 1) * d_star
+        assert torch.allclose(d_star, d_ref, rtol=1e-6, atol=1e-9), r
+        err = orc.error_bound(beta0, sdf.reshape(-1, 1), z, dists, d_ref)
+        assert torch.allclose(err, e_ref, rtol=1e-5, atol=1e-7), r
+        beta = torch.where(err <= c.eps, beta0.expand_as(beta), beta)
+        lo, hi = beta0.expand_as(beta).clone(), beta.clone()
+        for _ in range(c.beta_iters):
+            mid = (lo + hi) / 2
+            e = orc.error_bound(mid[:, None], sdf.reshape(-1, 1), z, dists, d_ref)
+            hi = torch.where(e <= c.eps, mid, hi)
+            lo = torch.where(e > c.eps, mid, lo)
+        assert torch.allclose(hi, b_ref, rtol=1e-6, atol=0), r
+        beta = b_ref.clone()
