@@ -10,17 +10,17 @@ crosses the process boundary and the PCIe bus every iteration (holoscene_train.p
 ``ResidentNSDataset`` holds the same tensors on the device, applies the same rule (``sample_indices``; every permutation injectable so
 that the reference's own draws reproduce its batches index for index -- tests/golden/ns_sampler.npz) and hands a batch over either as
 the dictionaries ``__getitem__`` + ``collate_fn`` produce (``next_batch``) or gathered by ONE launch straight into the training graph's
-static input block (``write_batch``; csrc/encode_ops.hip: hs_gather_rows).  Batches are drawn ahead into a ring, off the critical path,
-as the reference's workers do, and every slot is REDRAWN once it has been served (datasets/ring.py: host threads in the role of the
-DataLoader workers) -- a new frame and new permutations for every iteration, as ns_dataset.py:380-430 has it.  Loading the image files
-stays with the reference's ``NSDataset`` (``from_reference``).
+static input block (``write_batch``; csrc/encode_ops.hip: hs_gather_rows).  Every batch is a NEW draw -- a new frame and new random pixel
+subsets per iteration, as ns_dataset.py:380-430 has it -- made by one launch on the training stream (datasets/pixel_sampler.py,
+csrc/batch_ops.hip: hs_draw_pixels), where the reference spends ~4.5 ms of host time per batch in DataLoader workers.  Loading the image
+files stays with the reference's ``NSDataset`` (``from_reference``).
 """
 import random
 
 import numpy as np
 import torch
 
-from .ring import BatchRing
+from .pixel_sampler import PixelSampler
 
 
 def rank_seed(seed, rank=None):
@@ -34,10 +34,9 @@ def rank_seed(seed, rank=None):
 
 class ResidentNSDataset:
     def __init__(self, rgb_images, depth_images, normal_images, mask_images, semantic_images, semantic_images_classes, intrinsics_all, pose_all,
-                 img_res, num_pixels, fix_length=0, device="cuda", ring=64, seed=0, rank=None, workers=8):
+                 img_res, num_pixels, fix_length=0, device="cuda", seed=0, rank=None):
         """*_images: per-frame flat tensors as NSDataset stores them ([H*W, C]; lists or stacked); semantic_images_classes: per frame the
-        sorted class ids present in it (ns_dataset.py:307-308).  seed / rank: every data-parallel rank draws its own stream (rank_seed);
-        workers: host threads refilling the ring (the reference's DataLoader runs 8 worker processes, holoscene_train.py:128)."""
+        sorted class ids present in it (ns_dataset.py:307-308).  seed / rank: every data-parallel rank draws its own stream (rank_seed)."""
         dev = self.device = torch.device(device)
         stack = lambda t: (torch.stack(list(t)) if not torch.is_tensor(t) else t).float()  # noqa: E731
         self.rgb, self.depth, self.normal, self.mask = (stack(t).to(dev) for t in (rgb_images, depth_images, normal_images, mask_images))
@@ -59,8 +58,8 @@ class ResidentNSDataset:
         self._gen = torch.Generator().manual_seed(seed)
         self._py = random.Random(seed)
         self._epoch = []                # fix_length == 0: frames of the current epoch still to be served (a shuffled DataLoader epoch)
-        self._epoch_lock = __import__("threading").Lock()
-        self._ring = BatchRing(self._draw, num_pixels, dev, ring=ring, workers=workers, seed=seed)
+        self._sampler = PixelSampler(self._class_pixels, self.total_pixels, num_pixels, dev, seed=seed)
+        self._fidx = torch.zeros(1, dtype=torch.int64, device=dev)       # static: frame index of the batch being served
         self._plans = {}
 
     @classmethod
@@ -73,31 +72,10 @@ class ResidentNSDataset:
         return self.n_images if self.fix_length == 0 else self.fix_length
 
     # ------------------------------------------------------------------ the sampling rule
-    def sample_indices(self, frame, draws=None, gen=None):
+    def sample_indices(self, frame, draws=None):
         """Pixel indices of one batch of `frame` (host tensor, int64), ns_dataset.py:409-430.  draws: optional iterator over the
         permutations ``torch.randperm`` returned in call order (one per class that has more pixels than its quota, then the uniform one)."""
-        gen = self._gen if gen is None else gen
-        half = self.sampling_size // 2
-        n_cls = len(self.classes[frame])
-        per_class = half // n_cls
-        n_bg = half - per_class * (n_cls - 1)
-        it = iter(draws) if draws is not None else None
-
-        def perm(n):
-            if it is not None:
-                p = torch.as_tensor(next(it)).long()
-                assert p.numel() == n, "injected permutation has the wrong length"
-                return p
-            return torch.randperm(n, generator=gen)
-
-        chosen = []
-        for i, pix in enumerate(self._class_pixels[frame]):
-            want = n_bg if i == 0 else per_class
-            if len(pix) > want:
-                pix = pix[perm(len(pix))[:want]]
-            chosen.append(pix)
-        chosen.append(perm(self.total_pixels)[: self.sampling_size - half])
-        return torch.cat(chosen)
+        return self._sampler.host_indices(frame, draws)
 
     def pick_frame(self, idx=None, py=None):
         """fix_length != 0: a random frame per item (:382-383).  fix_length == 0: the DataLoader hands out the frames of a shuffled
@@ -107,15 +85,10 @@ class ResidentNSDataset:
             return py.randint(0, self.n_images - 1)
         if idx is not None:
             return int(idx)
-        with self._epoch_lock:
-            if not self._epoch:
-                self._epoch = list(range(self.n_images))
-                py.shuffle(self._epoch)
-            return self._epoch.pop()
-
-    def _draw(self, gen, py):
-        f = self.pick_frame(py=py)
-        return f, self.sample_indices(f, gen=gen)
+        if not self._epoch:
+            self._epoch = list(range(self.n_images))
+            py.shuffle(self._epoch)
+        return self._epoch.pop()
 
     # ------------------------------------------------------------------ batches
     def get(self, frame, sampling_idx):
@@ -127,31 +100,28 @@ class ResidentNSDataset:
         return torch.tensor([frame]), sample, gt
 
     def next_batch(self):
-        s = self._ring.acquire()
-        out = self.get(s.frame, s.idx[:s.count])
-        self._ring.release(s)
-        return out
+        frame = self.pick_frame()
+        idx, n = self._sampler.draw(frame)
+        return self.get(frame, idx[:n])
 
     def write_batch(self, dst_input, dst_gt):
-        """The next ring batch gathered straight into existing buffers (the training graph's static input block) by one launch."""
+        """The next batch gathered straight into existing buffers (the training graph's static input block): one launch for the draw,
+        one for the gather."""
         from ..hashencoder import backend as _be
-        s = self._ring.acquire()
-        try:
-            if s.count != dst_input["uv"].shape[1]:
-                raise RuntimeError(f"batch of {s.count} rays (a class of frame {s.frame} has fewer pixels than its quota, ns_dataset.py:422-427) "
-                                   f"does not fit the static block of {dst_input['uv'].shape[1]}: use next_batch() / the eager path for such scenes")
-            # the launch plan holds pointers only: the slot's index tensors are static (their CONTENT is redrawn), the per-frame
-            # sources depend on the frame the slot currently holds
-            key = (s.i, s.frame, dst_input["uv"].data_ptr())
-            plan = self._plans.get(key)
-            if plan is None:
-                if len(self._plans) >= 4096:      # (slot, frame) pairs of a long scene: the cache is a convenience, not state
-                    self._plans.clear()
-                frame, idx, fidx = s.frame, s.idx, s.fidx
-                plan = self._plans[key] = _be._backend.gather_plan([
-                    (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
-                    (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),
-                    (self.mask[frame], dst_gt["mask"], idx), (self.segs[frame], dst_gt["segs"], idx)])
-            _be._backend.gather_rows(plan)
-        finally:
-            self._ring.release(s)
+        frame = self.pick_frame()
+        n = self._sampler.count(frame)
+        if n != dst_input["uv"].shape[1]:
+            self._sampler.skip()
+            raise RuntimeError(f"batch of {n} rays (a class of frame {frame} has fewer pixels than its quota, ns_dataset.py:422-427) "
+                               f"does not fit the static block of {dst_input['uv'].shape[1]}: use next_batch() / the eager path for such scenes")
+        idx, _ = self._sampler.draw(frame)
+        # the launch plan holds pointers only: the index tensor is static (its CONTENT is redrawn), the image sources depend on the frame
+        key = (frame, dst_input["uv"].data_ptr())
+        plan = self._plans.get(key)
+        if plan is None:
+            fidx = torch.tensor([frame], dtype=torch.int64).to(self.device)
+            plan = self._plans[key] = _be._backend.gather_plan([
+                (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
+                (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),
+                (self.mask[frame], dst_gt["mask"], idx), (self.segs[frame], dst_gt["segs"], idx)])
+        _be._backend.gather_rows(plan)

@@ -1,0 +1,93 @@
+"""The class-balanced pixel draw of one training batch (reference: NSDataset.__getitem__, datasets/ns_dataset.py:409-430).
+
+The reference draws a dozen ``torch.randperm`` per batch in 8 DataLoader worker processes (training/holoscene_train.py:124-129): ~4.5 ms
+of host time per batch at 512 x 512 pixels and 32 classes, twice a whole training iteration here.  On a CUDA device the draw is ONE
+launch on the training stream instead (csrc/batch_ops.hip: hs_draw_pixels) -- per class a uniformly random subset of its pixel list,
+then the uniform half -- written into a static index tensor that the batch gather reads through a cached launch plan.  No host
+threads, no ring, no host->device copies; (seed, counter) names a batch, so two samplers with one seed serve one sequence.  A new
+draw per iteration, as the reference has it -- nothing is ever served twice.
+
+On a CPU device (tests) the same rule runs on the host with a torch.Generator.  The reference's own permutations stay injectable
+(`host_indices(frame, draws=...)`) for the parity fixtures.
+"""
+import torch
+
+
+class PixelSampler:
+    def __init__(self, class_pixels, total_pixels, num_pixels, device, seed=0):
+        """class_pixels: per frame, the list of int64 host tensors `torch.nonzero(semantic == class)` for the classes present in that
+        frame, background first (ns_dataset.py:419-421)."""
+        self.device = torch.device(device)
+        self.R, self.total = int(num_pixels), int(total_pixels)
+        self._host = class_pixels
+        self._gen = torch.Generator().manual_seed(int(seed))
+        self._seed, self._counter = int(seed), 0
+        self.half = self.R // 2
+        self._frames = None
+        self.idx = torch.zeros(self.R, dtype=torch.int64, device=self.device)      # static: the gather plans point at it
+
+    def quotas(self, frame):
+        n_cls = len(self._host[frame])
+        per_class = self.half // n_cls
+        return n_cls, per_class, self.half - per_class * (n_cls - 1)
+
+    def count(self, frame):
+        """Rays the rule yields for `frame` (< num_pixels when a class has fewer pixels than its quota, ns_dataset.py:422-427)."""
+        n_cls, per_class, n_bg = self.quotas(frame)
+        return sum(min(len(p), n_bg if i == 0 else per_class) for i, p in enumerate(self._host[frame])) + (self.R - self.half)
+
+    # ------------------------------------------------------------------ host rule (CPU device, injected draws)
+    def host_indices(self, frame, draws=None, gen=None):
+        """Pixel indices of one batch of `frame` (host tensor, int64).  draws: optional iterator over the permutations ``torch.randperm``
+        returned in the reference, in call order (one per class that has more pixels than its quota, then the uniform one)."""
+        gen = self._gen if gen is None else gen
+        n_cls, per_class, n_bg = self.quotas(frame)
+        it = iter(draws) if draws is not None else None
+
+        def perm(n):
+            if it is not None:
+                p = torch.as_tensor(next(it)).long()
+                assert p.numel() == n, "injected permutation has the wrong length"
+                return p
+            return torch.randperm(n, generator=gen)
+
+        chosen = []
+        for i, pix in enumerate(self._host[frame]):
+            want = n_bg if i == 0 else per_class
+            if len(pix) > want:
+                pix = pix[perm(len(pix))[:want]]
+            chosen.append(pix)
+        chosen.append(perm(self.total)[: self.R - self.half])
+        return torch.cat(chosen)
+
+    # ------------------------------------------------------------------ device rule
+    def _device_frames(self):
+        if self._frames is None:
+            self._frames = []
+            for f, lists in enumerate(self._host):
+                n_cls, per_class, n_bg = self.quotas(f)
+                sizes = [len(p) for p in lists]
+                ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int32)
+                takes = [min(s, n_bg if i == 0 else per_class) for i, s in enumerate(sizes)] + [self.R - self.half]
+                off = torch.tensor([0] + list(torch.tensor(takes).cumsum(0).tolist()), dtype=torch.int32)
+                pix = torch.cat([p.reshape(-1) for p in lists]).to(torch.int32)
+                self._frames.append((ptr.to(self.device), pix.to(self.device), off.to(self.device), int(off[-1])))
+        return self._frames
+
+    def skip(self):
+        """Advance the stream by one batch without drawing it (a batch the caller refuses keeps the sequence of the others)."""
+        self._counter += 1
+
+    def draw(self, frame):
+        """The next batch of `frame` -> (static int64 index tensor, number of valid entries).  On CUDA the indices are written by one
+        launch on the current stream (the previous batch's readers are ahead of it in stream order)."""
+        if self.device.type != "cuda":
+            idx = self.host_indices(frame)
+            self.idx[:idx.numel()] = idx
+            return self.idx, int(idx.numel())
+        from ..hashencoder import backend as _be
+        ptr, pix, off, n = self._device_frames()[frame]
+        n_cls, per_class, n_bg = self.quotas(frame)
+        self._counter += 1
+        _be._backend.draw_pixels(ptr, pix, off, n_cls, per_class, n_bg, self.R - self.half, self.total, self._seed, self._counter, self.idx)
+        return self.idx, n

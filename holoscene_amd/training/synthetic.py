@@ -5,14 +5,17 @@ circle of radius 0.7 in the z=0 plane looking at the origin; instance mask = K v
 rgb ~ U[0,1], depth ~ U[0.1,1], unit normals from N(0,I), mask = 1.  Pixel batches follow the
 reference's class-balanced rule (datasets/ns_dataset.py:409-430): half of the rays split evenly over
 the classes present (background takes the remainder), the other half uniform over the image.
-The frames are generated once and kept resident in HBM; the pixel batches are drawn ahead into a ring
-that host threads refill behind the consumer (datasets/ring.py -- the reference's 8 DataLoader workers):
-every iteration sees a new frame pick and new permutations, as ns_dataset.py:380-430 has it.
+The frames are generated once and kept resident in HBM; every iteration draws a new frame and new random
+pixel subsets, as ns_dataset.py:380-430 has it -- by one launch on the training stream
+(datasets/pixel_sampler.py, csrc/batch_ops.hip: hs_draw_pixels; the reference's 8 DataLoader workers spend
+~4.5 ms of host time per batch on it).
 """
+import random
+
 import numpy as np
 import torch
 
-from ..datasets.ring import BatchRing
+from ..datasets.pixel_sampler import PixelSampler
 
 
 def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
@@ -29,7 +32,8 @@ def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
 
 
 class SyntheticScene:
-    def __init__(self, num_rays, num_classes, img_res=(512, 512), num_frames=8, ring=64, seed=1234, device="cuda", workers=8, redraw=True):
+    def __init__(self, num_rays, num_classes, img_res=(512, 512), num_frames=8, ring=64, seed=1234, device="cuda", redraw=True):
+        """ring / redraw=False: tests that overfit a FIXED set of `ring` batches (drawn once, replayed for ever)."""
         self.R, self.K = num_rays, num_classes
         self.H, self.W = img_res
         self.F = num_frames
@@ -51,53 +55,52 @@ class SyntheticScene:
         ys, xs = torch.meshgrid(torch.arange(self.H), torch.arange(self.W), indexing="ij")
         self.uv_all = torch.stack([xs, ys], -1).reshape(npix, 2).float().to(self.device)
         self._class_pixels = [torch.nonzero(self.segs.cpu().reshape(-1) == c).reshape(-1) for c in range(num_classes)]
-        self._ring = BatchRing(self._draw, num_rays, self.device, ring=ring, workers=workers, seed=seed, redraw=redraw)
+        self._sampler = PixelSampler([self._class_pixels] * num_frames, npix, num_rays, self.device, seed=seed)
+        self._py = random.Random(seed)
         self._plans, self._const_done = {}, set()
+        self._fixed, self._cursor = None, 0
+        if not redraw:      # a fixed set of batches, drawn once on the host
+            g2 = torch.Generator().manual_seed(seed)
+            self._fixed = []
+            for _ in range(ring):
+                f = self._py.randint(0, self.F - 1)
+                self._fixed.append((f, self._sampler.host_indices(f, gen=g2).to(self.device)))
 
-    def _draw(self, g, py):
-        """One (frame, pixel-index) batch, ns_dataset.py:383, 409-430."""
-        frame = py.randint(0, self.F - 1)
-        half = self.R // 2
-        per_class = half // self.K
-        n_bg = half - per_class * (self.K - 1)
-        chosen = []
-        for c, pix in enumerate(self._class_pixels):
-            want = n_bg if c == 0 else per_class
-            if len(pix) > want:
-                pix = pix[torch.randperm(len(pix), generator=g)[:want]]
-            chosen.append(pix)
-        chosen.append(torch.randperm(self.H * self.W, generator=g)[: self.R - half])
-        return frame, torch.cat(chosen)
+    def _next(self):
+        """(frame, static index tensor) of the next batch."""
+        if self._fixed is not None:
+            f, idx = self._fixed[self._cursor % len(self._fixed)]
+            self._cursor += 1
+            self._sampler.idx.copy_(idx)
+            return f, self._sampler.idx
+        f = self._py.randint(0, self.F - 1)     # ns_dataset.py:383
+        idx, _ = self._sampler.draw(f)
+        return f, idx
 
     def next_batch(self):
-        s = self._ring.acquire()
-        frame, idx = s.frame, s.idx[:s.count]
+        frame, idx = self._next()
         model_input = {"uv": self.uv_all[idx][None], "intrinsics": self.intrinsics, "pose": self.poses[frame][None]}
         gt = {"rgb": self.rgb[frame][idx][None], "depth": self.depth[frame][idx][None], "normal": self.normal[frame][idx][None],
               "mask": torch.ones(1, idx.numel(), 1, device=self.device), "segs": self.segs[idx][None]}
-        self._ring.release(s)
         return torch.tensor([frame]), model_input, gt
 
     def write_batch(self, dst_input, dst_gt):
-        """next_batch() written straight into existing buffers (the training graph's static input block) by ONE gather launch
-        (csrc/encode_ops.hip: hs_gather_rows) instead of six indexing launches plus the copies into the block.  Same ring, same
-        cursor: interleaving next_batch() and write_batch() walks the same sequence of batches.  The launch plan of a (slot, frame)
-        pair holds pointers only -- the slot's index tensor is static, its content is redrawn after every use."""
+        """next_batch() written straight into existing buffers (the training graph's static input block): one launch draws the pixel
+        indices (hs_draw_pixels), one gathers the rows (csrc/encode_ops.hip: hs_gather_rows) -- instead of six indexing launches plus
+        the copies into the block.  Same generator state, same counter: interleaving next_batch() and write_batch() walks the same
+        sequence of batches.  The launch plan of a frame holds pointers only -- the index tensor is static, its content is redrawn."""
         from ..hashencoder import backend as _be
-        s = self._ring.acquire()
-        try:
-            tag = dst_input["uv"].data_ptr()
-            key = (s.i, s.frame, tag)
-            plan = self._plans.get(key)
-            if plan is None:
-                frame, idx, fidx = s.frame, s.idx, s.fidx
-                plan = self._plans[key] = _be._backend.gather_plan([
-                    (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
-                    (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
-            if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
-                dst_input["intrinsics"].copy_(self.intrinsics)
-                dst_gt["mask"].fill_(1.0)
-                self._const_done.add(tag)
-            _be._backend.gather_rows(plan)
-        finally:
-            self._ring.release(s)
+        frame, idx = self._next()
+        tag = dst_input["uv"].data_ptr()
+        key = (frame, tag)
+        plan = self._plans.get(key)
+        if plan is None:
+            fidx = torch.tensor([frame], dtype=torch.int64).to(self.device)
+            plan = self._plans[key] = _be._backend.gather_plan([
+                (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
+                (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
+        if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
+            dst_input["intrinsics"].copy_(self.intrinsics)
+            dst_gt["mask"].fill_(1.0)
+            self._const_done.add(tag)
+        _be._backend.gather_rows(plan)

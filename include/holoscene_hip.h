@@ -487,6 +487,18 @@ typedef struct hsGatherJob {
 } hsGatherJob;
 int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
 
+/* The pixel draw of one training batch (datasets/ns_dataset.py:409-430: NSDataset.__getitem__'s class-balanced rule, there a dozen
+ * torch.randperm calls per batch in DataLoader worker processes) as ONE launch.  The frame's pixels grouped by instance class in CSR
+ * form: class_ptr [n_cls + 1] offsets into class_pix (pixel indices, class 0 = background first).  Class c contributes
+ * min(size_c, quota_c) pixels, quota_0 = n_bg, quota_c = per_class -- a uniformly random subset when the class is larger than its
+ * quota, all of it otherwise --, followed by n_uniform distinct pixels drawn uniformly from [0, total_pixels).  out_off [n_cls + 2]:
+ * where each class's share (and, last but one, the uniform share) starts in `out` (int64 [sum of the shares]); the caller computes it
+ * from the class sizes, which it knows.  (seed, counter) name the batch: the same pair gives the same batch on every run.
+ * Every quota must be <= HS_DRAW_MAX_WANT. */
+#define HS_DRAW_MAX_WANT 4096
+int hs_draw_pixels(const int32_t *class_ptr, const int32_t *class_pix, const int32_t *out_off, int32_t n_cls, int32_t per_class, int32_t n_bg,
+                   int32_t n_uniform, int32_t total_pixels, uint64_t seed, uint64_t counter, int64_t *out, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation

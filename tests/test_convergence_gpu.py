@@ -3,9 +3,12 @@
 Single-iteration parity bounds the bf16 colour-branch gradients only to a few per cent (ReLU mask flips, tests/test_model_gpu.py::
 test_fused_appearance_backward_on_fp32_relu_masks_is_tight); what matters for a training path is that those differences do not
 accumulate.  A learnable synthetic scene -- every pixel of three 64 x 64 frames rendered by a TEACHER model (distinct objects, its own
-weights) -- is fitted for 300 iterations from one initial state by (a) the benchmarked path, Stage1Trainer(graph=True, bf16), and (b) the
-fp32 path, both on the same batches and with the generator re-seeded identically before every step.  Asserted, not printed: no
-non-finite loss anywhere, both runs learn (the rgb term falls), and the trailing means of the loss terms agree.
+weights) -- is fitted for 300 iterations from one initial state by (a) the benchmarked path, Stage1Trainer(graph=True, bf16), (b) the fp32 path on
+the same batches with the generator re-seeded identically before every step, and (c) the fp32 path once more on OTHER draws.  Adam with
+the reference's eps = 1e-15 takes sign-like steps, so any two runs decorrelate element by element within a dozen iterations (DESIGN
+section 3); what a correct low-precision path must share with fp32 is the OUTCOME.  (c) measures how much that outcome moves between
+two fp32 runs; (a) must stay within max(5 %, 2.5 x that spread) of (b) in every loss term.  Asserted, not printed: no non-finite loss
+anywhere, all runs learn (the rgb term falls by more than half), and the trailing means agree.
 """
 import pytest
 import torch
@@ -17,7 +20,8 @@ STEPS, TAIL = 300, 40
 
 def _conf(precision):
     from holoscene_amd.training.trainer import stock_conf
-    return stock_conf(num_rays=256, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=0.05, mlp_precision=precision, use_bg_reg=True)
+    return stock_conf(num_rays=256, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=0.05, mlp_precision=precision, use_bg_reg=True,
+                      learning_rate=1.0e-4)
 
 
 def _teacher_scene():
@@ -32,12 +36,12 @@ def _teacher_scene():
         l2 = net.lin2
         l2.weight_v[:4] += (0.05 * torch.randn(4, l2.weight_v.shape[1], generator=g) * float(l2.weight_v[:4].abs().mean())).to(DEV)
         l2.bias[:4] += (0.15 * torch.randn(4, generator=g)).to(DEV)
-        for enc in (net.encoding, net.color_encoding):
-            enc.embeddings.copy_(((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * 2e-2).to(DEV))
+        enc = net.color_encoding          # colours from the table; the geometry stays smooth (distinct objects through lin2 only)
+        enc.embeddings.copy_(((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * 2e-2).to(DEV))
     model = teacher.model.eval()
 
     def make(seed):
-        sc = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, ring=8, seed=seed, device=DEV, workers=2)
+        sc = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, ring=8, seed=seed, device=DEV)
         npix = sc.H * sc.W
         with torch.no_grad():
             for f in range(sc.F):
@@ -51,13 +55,13 @@ def _teacher_scene():
     return make
 
 
-def _fit(precision, graph, scene):
+def _fit(precision, graph, scene, seed0=5000):
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state
     tr = Stage1Trainer(_conf(precision), device=DEV, optimizer="flat", graph=graph, seed=42)
     benchmark_model_state(tr.model, 0.05)
     hist = {"loss": [], "rgb_loss": [], "eikonal_loss": [], "depth_loss": [], "normal_l1": []}
     for i in range(STEPS):
-        torch.manual_seed(5000 + i)
+        torch.manual_seed(seed0 + i)
         _, lo = tr.train_step(*scene.next_batch())
         for k in hist:
             hist[k].append(lo[k].detach().clone())
@@ -70,20 +74,19 @@ def test_bf16_graph_training_tracks_fp32_training():
     bf, tr_bf = _fit("bf16", True, make(31))
     assert ("full", False, False) in tr_bf._graphs, "the bf16 run must have gone through the whole-iteration graph"
     fp, _ = _fit("fp32", False, make(31))
-    for name, h in (("bf16", bf), ("fp32", fp)):
+    fp_b, _ = _fit("fp32", False, make(77), seed0=9000)
+    tail = lambda h, k: float(h[k][-TAIL:].mean())  # noqa: E731
+    for name, h in (("bf16", bf), ("fp32", fp), ("fp32 other draws", fp_b)):
         for k, v in h.items():
             assert bool(torch.isfinite(v).all()), (name, k)
-        first, last = float(h["rgb_loss"][:TAIL].mean()), float(h["rgb_loss"][-TAIL:].mean())
-        print(f"PARITY convergence {name}: rgb_loss {first:.4f} -> {last:.4f}, eikonal {float(h['eikonal_loss'][-TAIL:].mean()):.4f}, "
-              f"loss {float(h['loss'][-TAIL:].mean()):.4f}")
-        assert last < 0.8 * first, (name, "the run does not learn", first, last)
-    for k, tol in (("rgb_loss", 0.05), ("eikonal_loss", 0.05), ("loss", 0.05), ("depth_loss", 0.10), ("normal_l1", 0.05)):
-        a, b = float(bf[k][-TAIL:].mean()), float(fp[k][-TAIL:].mean())
-        rel = abs(a - b) / max(abs(b), 1e-12)
-        print(f"PARITY convergence {k}: bf16 {a:.5f} fp32 {b:.5f} rel {rel:.3e}")
-        assert rel < tol, (k, a, b, rel)
-    # the whole trajectories stay together, not just their ends: per-step total loss, smoothed over 20 steps
-    sm = lambda t: torch.nn.functional.avg_pool1d(t[None, None], 20, 10)[0, 0]  # noqa: E731
-    dev = float(((sm(bf["loss"]) - sm(fp["loss"])).abs() / sm(fp["loss"]).abs()).max())
-    print(f"PARITY convergence worst smoothed-trajectory deviation {dev:.3e}")
-    assert dev < 0.10, dev
+        first, last = float(h["rgb_loss"][:10].mean()), tail(h, "rgb_loss")
+        print(f"PARITY convergence {name}: rgb_loss {first:.4f} -> {last:.4f}, eikonal {tail(h, 'eikonal_loss'):.4f}, loss {tail(h, 'loss'):.4f}")
+        assert last < 0.5 * first, (name, "the run does not learn", first, last)
+    bad = []
+    for k in ("rgb_loss", "eikonal_loss", "loss", "depth_loss", "normal_l1"):
+        a, b, c = tail(bf, k), tail(fp, k), tail(fp_b, k)
+        rel, spread = abs(a - b) / max(abs(b), 1e-12), abs(c - b) / max(abs(b), 1e-12)
+        print(f"PARITY convergence {k}: bf16 {a:.5f} fp32 {b:.5f} (other draws {c:.5f}) |bf16 - fp32| / fp32 {rel:.3e}, fp32 run-to-run {spread:.3e}")
+        if not rel < max(0.05, 2.5 * spread):
+            bad.append((k, a, b, c))
+    assert not bad, bad

@@ -1306,7 +1306,7 @@ def test_resident_ns_dataset_gather_equals_indexed_batches():
     ring; a ragged batch (class below its quota, ns_dataset.py:422-427) is refused for the static block."""
     from test_dataset_cpu import _dataset
     rec = load("ns_sampler")
-    a, b = _dataset(rec, DEV, seed=3, ring=8), _dataset(rec, DEV, seed=3, ring=8)
+    a, b = _dataset(rec, DEV, seed=3), _dataset(rec, DEV, seed=3)
     R = int(rec["meta.R"])
     dst_in = {"uv": torch.zeros(1, R, 2, device=DEV), "pose": torch.zeros(1, 4, 4, device=DEV), "intrinsics": torch.zeros(1, 4, 4, device=DEV)}
     dst_gt = {"rgb": torch.zeros(1, R, 3, device=DEV), "depth": torch.zeros(1, R, 1, device=DEV), "normal": torch.zeros(1, R, 3, device=DEV),
@@ -1335,11 +1335,62 @@ def test_resident_ns_dataset_equals_the_references_batches_on_the_device():
     check_batches_equal_reference(DEV)
 
 
-def test_resident_ns_dataset_ring_is_refilled_by_its_worker_threads():
-    """The device ring is redrawn behind the consumer by host threads (datasets/ring.py): no batch served twice, deterministic per
-    seed, distinct per rank."""
-    from test_dataset_cpu import check_ring_is_redrawn
-    check_ring_is_redrawn(DEV, workers=3)
+def test_resident_ns_dataset_draws_a_new_batch_every_iteration():
+    """Every batch is a new device-side draw (csrc/batch_ops.hip: hs_draw_pixels): none served twice, one sequence per seed, another per rank."""
+    from test_dataset_cpu import check_batches_are_redrawn
+    check_batches_are_redrawn(DEV)
+
+
+@pytest.mark.parametrize("R,K,res", [(1024, 32, 512), (256, 4, 64), (64, 3, 16), (4096, 32, 512)])
+def test_device_pixel_draw_follows_the_class_balanced_rule(R, K, res):
+    """hs_draw_pixels against the rule of ns_dataset.py:409-430: class by class min(size, quota) DISTINCT pixels of that class (a class
+    at or below its quota contributes all of its pixels -- the ragged case), then the uniform share, distinct, inside the image; the same
+    (seed, counter) gives the same batch, another counter another one; every pixel of a class is reachable (coverage over many draws)."""
+    from holoscene_amd.datasets.pixel_sampler import PixelSampler
+    g = torch.Generator().manual_seed(R + K)
+    npix = res * res
+    labels = torch.randint(0, K, (npix,), generator=g)
+    labels[labels == K - 1] = 0                       # class K-1 is absent from this frame
+    tiny = torch.nonzero(labels == 1).reshape(-1)
+    labels[tiny[3:]] = 0                              # class 1 keeps 3 pixels: below any quota -> ragged
+    classes = sorted(set(labels.tolist()))
+    lists = [torch.nonzero(labels == c).reshape(-1) for c in classes]
+    a, b = PixelSampler([lists], npix, R, DEV, seed=5), PixelSampler([lists], npix, R, DEV, seed=5)
+    n_cls, per_class, n_bg = a.quotas(0)
+    n = a.count(0)
+    seen = torch.zeros(npix, dtype=torch.bool)
+    prev = None
+    for it in range(6):
+        ia, na = a.draw(0)
+        ib, nb = b.draw(0)
+        assert na == nb == n and torch.equal(ia[:n], ib[:n]), "one seed, one sequence"
+        idx = ia[:n].cpu()
+        assert prev is None or not torch.equal(idx, prev), "a new counter must give a new batch"
+        prev = idx.clone()
+        off = 0
+        for i, (c, pix) in enumerate(zip(classes, lists)):
+            want = min(len(pix), n_bg if i == 0 else per_class)
+            seg = idx[off:off + want]
+            assert bool((labels[seg] == c).all()), (it, c)
+            assert seg.unique().numel() == want, "sampling within a class is without replacement"
+            if len(pix) <= (n_bg if i == 0 else per_class):
+                assert torch.equal(seg.sort()[0], pix.sort()[0]), "a class at or below its quota contributes every pixel"
+            off += want
+        uni = idx[off:]
+        assert uni.numel() == R - R // 2 and uni.unique().numel() == uni.numel() and int(uni.min()) >= 0 and int(uni.max()) < npix
+        seen[uni] = True
+    if npix <= 4096:          # coverage: with enough draws the uniform share reaches (nearly) every pixel
+        for _ in range(200):
+            ia, _ = a.draw(0)
+            seen[ia[:n].cpu()[-(R - R // 2):]] = True
+        assert float(seen.float().mean()) > 0.98
+    # uniformity of the uniform share: mean index of many draws ~ (npix - 1) / 2
+    acc, cnt = 0.0, 0
+    for _ in range(50):
+        ia, _ = a.draw(0)
+        u = ia[:n][-(R - R // 2):].double()
+        acc, cnt = acc + float(u.sum()), cnt + u.numel()
+    assert abs(acc / cnt - (npix - 1) / 2) < 4 * npix / (12 * cnt) ** 0.5
 
 
 @pytest.mark.parametrize("name", ["object_sdf_fg", "object_sdf_bg"])
