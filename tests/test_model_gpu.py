@@ -766,9 +766,11 @@ def test_fused_appearance_backward_on_fp32_relu_masks_is_tight(B, monkeypatch):
         ra = float((a - b).norm() / (b.norm() + 1e-20))
         ro = float((o - b).norm() / (b.norm() + 1e-20))
         print(f"PARITY appearance-bwd {n:10s} relL2 vs fp32: own bf16 masks {ro:.3e} | fp32 masks {ra:.3e}")
-        worst_own, worst_al = max(worst_own, ro), max(worst_al, ra)
-        assert ra < 1.2e-2, (n, ra)
-    assert worst_al < 0.5 * worst_own, (worst_al, worst_own)
+        if not n.startswith("r2."):       # (the output layer sits behind no mask: both columns are the same number, pure bf16 rounding)
+            worst_own, worst_al = max(worst_own, ro), max(worst_al, ra)
+        # measured: 2.7e-3 .. 5.6e-3 behind the masks (6.8e-2 on the kernel's own masks); output layer up to 2.0e-2 at B = 1000
+        assert ra < (3e-2 if n.startswith("r2.") else 1.2e-2), (n, ra)
+    assert worst_al < 0.2 * worst_own, (worst_al, worst_own)
 
 
 def _full_graph_trainer(beta, freeze, rays=256):
