@@ -1,0 +1,782 @@
+// holoscene_amd/csrc/trunk_rr.hip -- the SDF trunk of the RENDERED samples in reverse-over-reverse form, "wave tile" kernels (gfx950).
+//
+// What the rendered samples need from the trunk (model/network.py:273-301: ObjectImplicitNetworkGrid.get_outputs) is the K per-object
+// SDFs, their minimum and ONE gradient, d min / dx -- which the reference takes by reverse mode (autograd.grad(..., create_graph=True),
+// :293-299) and differentiates once more in loss.backward().  The value+Jacobian kernels (trunk_mlp2.hip, sdf_mlp.hip: k_trunk_bwd)
+// carry three input tangents beside the value instead -- 4 rows per sample through every layer, forward and backward, which also yields
+// all K gradients, but only the 4 R Eikonal points need those (network.py:212-254).  Here the samples go the reference's way, in closed
+// form (tools/exp/rr_trunk_math.py checks the formulas against autograd's double backward in float64):
+//
+//   forward   a0 = W0 xt + b0, h0 = sp(a0);  a1 = W1 h0 + b1, h1 = sp(a1);  y = W2 h1 + b2;  k* = argmin y            (k_rr_fwd_value)
+//             u1 = W2[k*], v1 = u1 s1;  u0 = W1^T v1, v0 = u0 s0;  ux = W0^T v0;  d min/dx = E^T ux                    (k_rr_fwd_grad)
+//   backward  ux~ = E g~;  v0~ = W0 ux~;  u0~ = v0~ s0, a0' = v0~ u0 s0';  v1~ = W1 u0~;  u1~ = v1~ s1, a1' = v1~ u1 s1'    (k_rr_bwd_grad)
+//             h1~ = W2^T y~;  a1~ = a1' + h1~ s1;  h0~ = W1^T a1~;  a0~ = a0' + h0~ s0;  xt~ = W0^T a0~                      (k_rr_bwd_value)
+//   weights   dW1 = a1~^T h0 + v1^T u0~,  dW0 = a0~^T xt + v0^T ux~,  dW2 = y~^T h1 + onehot(k*)^T u1~                        (wgrad_pairs.hip)
+//
+// with s = sigmoid(100 a) = 1 - exp(-100 h), s' = 100 s (1 - s), E = d xt / dx (positional encoding + hash dy_dx): 6 row-passes of the
+// MLP per sample instead of 12, on rows that are SAMPLES (100 352 at the stock size) instead of value+tangent quadruples (417 792).
+// Two kernel skeletons, each the structure of sdf_mlp2.hip (a wave owns 32 samples end to end, activations stay in registers as the next
+// product's B fragments, the 256 x 256 matrix LDS-resident in fragment order, the narrow one streamed from L2):
+//   "down"  W0 (L2) -> W1 (LDS) [-> W2 (LDS)]      k_rr_fwd_value, k_rr_bwd_grad
+//   "up"    [W2^T (LDS) ->] W1^T (LDS) -> W0^T (L2)    k_rr_fwd_grad, k_rr_bwd_value
+// Activations that cross kernels are stored TILE-PACKED ("TP"): [tile of 32 samples][k-step 0..15][lane 0..63] x 16 bytes = exactly
+// the four packed words lane (sample, half) holds for that k-step -- one coalesced 1 KB wave access per k-step in every producer and
+// consumer, no layout conversion anywhere (the weight-gradient kernel scatters the 8-byte runs into its row-major LDS tiles).
+#include "wave_tile.h"
+
+namespace {
+
+constexpr int XS = 3;                       // 32-slot tiles of the transposed input product (96 slots: 48 per lane half)
+constexpr int kW0TF = HS * XS * 64 * 8;     // bf16 elements of the W0^T image   [16 k-steps][3 tiles][64 lanes] x 8
+constexpr int kW2TF = 2 * NT * 64 * 8;      //                    W2^T image   [2 k-steps][8 tiles][64 lanes] x 8
+constexpr float kC = 144.269504f;           // 100 log2(e)
+
+// slot sigma (0..47) of lane half hh of the transposed input product <-> reference input column (wave_tile.h: input_column), -1 = padding
+__host__ __device__ inline int slot_column(int hh, int sigma) { return sigma < 40 ? input_column(hh, sigma) : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------- packing
+// W1^T, W0^T (slot order), W2^T as fragment images, W2 as an fp32 gather table [32][256]
+__global__ __launch_bounds__(256) void k_rr_pack(const float *__restrict__ W0, int ld0, const float *__restrict__ W1, const float *__restrict__ W2, int d_out,
+                                                 uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf, uint16_t *__restrict__ W2Tf,
+                                                 float *__restrict__ W2tab) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    constexpr int n1 = HS * NT * 64, n0 = HS * XS * 64, n2 = 2 * NT * 64, nt = 32 * 256 / 4;
+    float v[8];
+    uint16_t *dst;
+    if (idx < n1) {
+        const int s = idx / (NT * 64), mt = (idx / 64) % NT, lane = idx & 63, m = 32 * mt + (lane & 31), kh = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = W1[(size_t)(16 * s + 8 * (e >> 2) + 4 * kh + (e & 3)) * 256 + m];
+        dst = W1Tf + (size_t)idx * 8;
+    } else if (idx < n1 + n0) {
+        const int i = idx - n1, s = i / (XS * 64), t = (i / 64) % XS, lane = i & 63, m = lane & 31, kh = lane >> 5;
+        const int q = m >> 3, hh = (m >> 2) & 1, j = m & 3, col = slot_column(hh, 16 * t + 4 * q + j);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = col >= 0 ? W0[(size_t)(16 * s + 8 * (e >> 2) + 4 * kh + (e & 3)) * ld0 + col] : 0.f;
+        dst = W0Tf + (size_t)i * 8;
+    } else if (idx < n1 + n0 + n2) {
+        const int i = idx - n1 - n0, s = i / (NT * 64), ntile = (i / 64) % NT, lane = i & 63, m = 32 * ntile + (lane & 31), kh = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int obj = 16 * s + 8 * kh + e;
+            v[e] = obj < d_out ? W2[(size_t)obj * 256 + m] : 0.f;
+        }
+        dst = W2Tf + (size_t)i * 8;
+    } else if (idx < n1 + n0 + n2 + nt) {
+        const int i = idx - n1 - n0 - n2, k = (4 * i) / 256, n = (4 * i) % 256;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < d_out) o = *reinterpret_cast<const float4 *>(W2 + (size_t)k * 256 + n);
+        *reinterpret_cast<float4 *>(W2tab + 4 * i) = o;
+        return;
+    } else {
+        return;
+    }
+    uint4 pk;
+    pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
+    *reinterpret_cast<uint4 *>(dst) = pk;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- small helpers
+__device__ __forceinline__ float softplus100(float v) {      // torch.nn.Softplus(beta=100): linear above 100 v = 20
+    const float e = __builtin_amdgcn_exp2f(fminf(v * kC, 28.8539008f));
+    const float lg = __builtin_amdgcn_logf(1.f + e) * (0.69314718f * 0.01f);
+    return fmaxf(v, lg);
+}
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// s = sigmoid(100 a) from the stored h = softplus100(a): exp(-100 h) = 1 - s
+__device__ __forceinline__ float sig_of_h(float h) { return 1.f - __builtin_amdgcn_exp2f(-kC * h); }
+
+__device__ __forceinline__ uint4 tp_load(const uint16_t *__restrict__ T, int64_t tile, int s, int lane) {
+    return *reinterpret_cast<const uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8);
+}
+__device__ __forceinline__ void tp_store(uint16_t *__restrict__ T, int64_t tile, int s, int lane, const uint32_t *w4, bool ok) {
+    uint4 v = ok ? make_uint4(w4[0], w4[1], w4[2], w4[3]) : make_uint4(0u, 0u, 0u, 0u);      // rows past the end hold zeros: the weight gradients sum whole tiles
+    *reinterpret_cast<uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8) = v;
+}
+__device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// resident image by LDS-DMA (sdf_mlp2.hip), `bytes` a multiple of kWaves KB
+__device__ __forceinline__ void dma_fill(const void *src, void *dst, int bytes, int wave, int lane) {
+    const int chunks = bytes / 1024;
+    for (int c = wave; c < chunks; c += kWaves)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)src + (size_t)c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)((char *)dst + (size_t)c * 1024), 16, 0, 0);
+}
+
+// The derivative factors E[col][d] of this lane's 40 input columns are functions of x and dy_dx; both directions (d min / dx = E^T ux in
+// the forward, ux~ = E g~ in the backward) walk them in input_column order: j < 18 positional encoding (octave 3 hh + j / 6; sin
+// components, then cos), 18..33 hash level 8 hh + (j - 18) / 2, 34..36 the raw coordinate (half 0 only).
+struct EFac {
+    float pe[18];          // d (sin | cos)(f x_d) / d x_d of this lane's three octaves: f cos / -f sin  (one component each: column j <-> d = j % 3)
+    float2 dy[8][3];       // jac_scale * dy_dx[level 8 hh + i][sample][d][c]
+};
+__device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const float *__restrict__ dydx, int64_t gp, int64_t n, int hh, float jac_scale, bool ok) {
+    EFac E;
+    const int64_t b = ok ? gp : 0;
+    const float xs[3] = {x[b * 3], x[b * 3 + 1], x[b * 3 + 2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float f = hh ? (float)(8 << k) : (float)(1 << k);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float sn, cs;
+            __sincosf(xs[d] * f, &sn, &cs);
+            E.pe[6 * k + d] = f * cs;
+            E.pe[6 * k + 3 + d] = -f * sn;
+        }
+    }
+    const float *dp = dydx + ((size_t)(8 * hh) * n + b) * 6;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float2 t = *reinterpret_cast<const float2 *>(dp + (size_t)i * n * 6 + 2 * d);
+            E.dy[i][d] = make_float2(t.x * jac_scale, t.y * jac_scale);
+        }
+    return E;
+}
+
+// ================================================================================================================ "down" kernels
+// ---------------------------------------------------------------------------------------------------------------- forward, values
+// sdf_mlp2.hip's structure with plain-domain Softplus; H0 / H1 leave tile-packed, the assembled inputs as Xp [n, 80] (trunk_mlp2.hip's column order)
+__global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
+                                                                const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
+                                                                const float *__restrict__ biasg, int d_out, uint16_t *__restrict__ H0t,
+                                                                uint16_t *__restrict__ H1t, uint16_t *__restrict__ Xp, float *__restrict__ sdf_raw,
+                                                                float *__restrict__ sdf, int64_t *__restrict__ idx, uint16_t *__restrict__ onehot,
+                                                                int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *W1l = lds;
+    uint16_t *W2l = lds + kW1F;
+    float *bias = reinterpret_cast<float *>(W2l + kW2F);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+    dma_fill(W1f, W1l, (kW1F + kW2F) * 2, wave, lane);
+    for (int i = threadIdx.x; i < kBias; i += kThreadsW) bias[i] = biasg[i];
+    __syncthreads();
+    bool resident = false;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const bf16x8 *W0v = reinterpret_cast<const bf16x8 *>(W0f) + lane;
+    const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
+    const bf16x8 *W2v = reinterpret_cast<const bf16x8 *>(W2l) + lane;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int64_t gp = tile * kRows + row;
+        const bool ok = gp < n;
+        uint32_t hin[4 * K0S];
+        {
+            float v[40];
+            const float x0 = ok ? x[gp * 3] : 0.f, x1 = ok ? x[gp * 3 + 1] : 0.f, x2 = ok ? x[gp * 3 + 2] : 0.f;
+            const float xs[3] = {x0, x1, x2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float f = h ? (float)(8 << k) : (float)(1 << k);
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float sn, cs;
+                    __sincosf(xs[d] * f, &sn, &cs);
+                    v[6 * k + d] = sn;
+                    v[6 * k + 3 + d] = cs;
+                }
+            }
+            const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * 32 + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 t = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[18 + 4 * i] = t.x; v[19 + 4 * i] = t.y; v[20 + 4 * i] = t.z; v[21 + 4 * i] = t.w;
+            }
+            v[34] = h ? 0.f : x0; v[35] = h ? 0.f : x1; v[36] = h ? 0.f : x2;
+            v[37] = v[38] = v[39] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 40; j += 2) hin[j >> 1] = ok ? pack2(v[j], v[j + 1]) : 0u;
+            if (ok) {
+                uint4 *xp = reinterpret_cast<uint4 *>(Xp + gp * 80 + 40 * h);
+#pragma unroll
+                for (int i = 0; i < 5; i++) xp[i] = make_uint4(hin[4 * i], hin[4 * i + 1], hin[4 * i + 2], hin[4 * i + 3]);
+            }
+        }
+        uint32_t h0p[64], h1p[64];
+        f32x16 acc[2][2];
+        // slices 0..15 of an epilogue: Softplus + pack of one register pair; 16..19: the four k-steps of the finished quarter leave as TP
+        auto epi = [&](auto slc, f32x16 (&src)[2], uint32_t *hp, int q_done, uint16_t *T) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 16) {
+                const int r = 2 * (sl & 7);
+                hp[16 * q_done + 8 * (sl >> 3) + (sl & 7)] = anchor(pack2(softplus100(src[sl >> 3][r]), softplus100(src[sl >> 3][r + 1])));
+            } else {
+                tp_store(T, tile, 4 * q_done + (sl - 16), lane, hp + 16 * q_done + 4 * (sl - 16), ok);
+            }
+        };
+        {
+            bf16x8 w0[2][2 * K0S];
+            uint32_t zoff = 0;
+            asm volatile("" : "+v"(zoff));
+            const bf16x8 *W0q = W0v + zoff;
+#define HS_W0_FETCH(q) do { _Pragma("unroll") for (int s_ = 0; s_ < K0S; s_++) { \
+        w0[(q) & 1][2 * s_] = W0q[(size_t)(s_ * NT + 2 * (q)) * 64]; w0[(q) & 1][2 * s_ + 1] = W0q[(size_t)(s_ * NT + 2 * (q) + 1) * 64]; } } while (0)
+            HS_W0_FETCH(0);
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                init_acc(acc[q & 1][0], bias + 32 * (2 * q), h);
+                init_acc(acc[q & 1][1], bias + 32 * (2 * q + 1), h);
+                if constexpr (q < 3) HS_W0_FETCH(q + 1);
+                auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
+                if constexpr (q == 0) phase2<K0S, 1, K0S, 20, false>(acc[0], hin, f0, [](auto) {});
+                else phase2<K0S, 1, K0S, 20, true>(acc[q & 1], hin, f0, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h0p, q - 1, H0t); });
+            });
+#undef HS_W0_FETCH
+        }
+        if (!resident) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            resident = true;
+        }
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            init_acc(acc[q & 1][0], bias + 256 + 32 * (2 * q), h);
+            init_acc(acc[q & 1][1], bias + 256 + 32 * (2 * q + 1), h);
+            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
+            if constexpr (q == 0) phase2<HS, 2, 8, 20, true>(acc[0], h0p, f1, [&](auto slc) { epi(slc, acc[1], h0p, 3, H0t); });
+            else phase2<HS, 2, HS, 20, true>(acc[q & 1], h0p, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h1p, q - 1, H1t); });
+        });
+        f32x16 y;
+        {
+            f32x16 &y0 = acc[0][0], &y1 = acc[0][1];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { y0[i] = 0.f; y1[i] = 0.f; }
+            auto f2 = [&](int s, int j) { return W2v[(size_t)(2 * s + j) * 64]; };
+            bf16x8 ring[3][2];
+            static_for<2>([&](auto sc) { constexpr int s = decltype(sc)::value; ring[s][0] = f2(s, 0); ring[s][1] = f2(s, 1); });
+            static_for<HS / 2>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s + 2 < HS / 2) { ring[(s + 2) % 3][0] = f2(s + 2, 0); ring[(s + 2) % 3][1] = f2(s + 2, 1); }
+                if constexpr (s < 5)       // layer 1's last quarter (k-steps 12..15 of this product) in the shadow of k-steps 0..9
+                    static_for<4>([&](auto jc) { epi(std::integral_constant<int, 4 * s + decltype(jc)::value>{}, acc[1], h1p, 3, H1t); });
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][0], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int i = 0; i < 16; i++) y[i] = y0[i] + y1[i];
+        }
+        // ---- the K SDFs of the sample, their minimum and its index (lowest among equals): 16 outputs per lane half, one shuffle across the halves
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int nn = 8 * (i >> 2) + 4 * h + (i & 3);
+            y[i] += bias[512 + nn];
+            if (nn < d_out && y[i] < best) { best = y[i]; bi = nn; }
+        }
+        {
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (ok) {
+            float *dst = sdf_raw + gp * d_out;
+            uint16_t *oh = onehot + gp * 32;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int n0 = 8 * q + 4 * h;
+                if ((d_out & 3) == 0) {
+                    if (n0 < d_out) *reinterpret_cast<float4 *>(dst + n0) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (n0 + j < d_out) dst[n0 + j] = y[4 * q + j];
+                }
+                uint2 o;      // bf16 1.0 = 0x3f80
+                o.x = (bi == n0 ? 0x3f80u : 0u) | (bi == n0 + 1 ? 0x3f800000u : 0u);
+                o.y = (bi == n0 + 2 ? 0x3f80u : 0u) | (bi == n0 + 3 ? 0x3f800000u : 0u);
+                *reinterpret_cast<uint2 *>(oh + n0) = o;
+            }
+            if (h == 0) { sdf[gp] = best; idx[gp] = bi; }
+        }
+    }
+    if (!resident) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward, gradient part
+// ux~ = E g~ as the "input layer" of a down pass WITHOUT biases; the epilogues multiply by the derivative factors of the saved activations
+__global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__restrict__ x, const float *__restrict__ dydx, const float *__restrict__ g_grad,
+                                                               const float *__restrict__ uxh, const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ W2tab, const uint16_t *__restrict__ W0f,
+                                                               const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ H0t,
+                                                               const uint16_t *__restrict__ H1t, const uint16_t *__restrict__ U0t,
+                                                               uint16_t *__restrict__ U0bt, uint16_t *__restrict__ A0pt, uint16_t *__restrict__ A1pt,
+                                                               uint16_t *__restrict__ U1bt, uint16_t *__restrict__ UXb, float *__restrict__ g_dydx,
+                                                               float jac_scale, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *W1l = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+    dma_fill(W1f, W1l, kW1F * 2, wave, lane);
+    bool resident = false;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const bf16x8 *W0v = reinterpret_cast<const bf16x8 *>(W0f) + lane;
+    const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int64_t gp = tile * kRows + row;
+        const bool ok = gp < n;
+        const int64_t b = ok ? gp : 0;
+        const int bi = (int)idx[b];
+        const float g[3] = {ok ? g_grad[b * 3] : 0.f, ok ? g_grad[b * 3 + 1] : 0.f, ok ? g_grad[b * 3 + 2] : 0.f};
+        uint32_t hin[4 * K0S];
+        {
+            const EFac E = load_efac(x, dydx, gp, n, h, jac_scale, ok);
+            float v[40];
+#pragma unroll
+            for (int j = 0; j < 18; j++) v[j] = E.pe[j] * g[j % 3];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v[18 + 2 * i] = E.dy[i][0].x * g[0] + E.dy[i][1].x * g[1] + E.dy[i][2].x * g[2];
+                v[19 + 2 * i] = E.dy[i][0].y * g[0] + E.dy[i][1].y * g[1] + E.dy[i][2].y * g[2];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) v[34 + d] = h ? 0.f : g[d];
+            v[37] = v[38] = v[39] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 40; j += 2) hin[j >> 1] = ok ? pack2(v[j], v[j + 1]) : 0u;
+            if (ok) {
+                uint4 *xp = reinterpret_cast<uint4 *>(UXb + gp * 80 + 40 * h);
+#pragma unroll
+                for (int i = 0; i < 5; i++) xp[i] = make_uint4(hin[4 * i], hin[4 * i + 1], hin[4 * i + 2], hin[4 * i + 3]);
+                // cotangent of dy_dx: rank one, jac_scale * ux[level, c] * g~[d]  (the reference's second-backward cotangent, hashgrid.py:87-101)
+                const float4 *up = reinterpret_cast<const float4 *>(uxh + gp * 32 + 16 * h);
+                float u[16];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const float4 t = up[i]; u[4 * i] = t.x; u[4 * i + 1] = t.y; u[4 * i + 2] = t.z; u[4 * i + 3] = t.w; }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float2 *dp = reinterpret_cast<float2 *>(g_dydx + ((size_t)(8 * h + i) * n + gp) * 6);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) dp[d] = make_float2(jac_scale * u[2 * i] * g[d], jac_scale * u[2 * i + 1] * g[d]);
+                }
+            }
+        }
+        uint32_t u0p[64], scratch[16];
+        f32x16 acc[2][2];
+        // epilogue of layer 0's finished quarter qd: acc = v0~ ; u0~ = v0~ s0 (next product's input, and TP), a0' = v0~ u0 s0' (TP)
+        uint4 hw[4], uw[4];
+        auto load0 = [&](int qd) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { hw[i] = tp_load(H0t, tile, 4 * qd + i, lane); uw[i] = tp_load(U0t, tile, 4 * qd + i, lane); }
+        };
+        auto epi0 = [&](auto slc, f32x16 (&src)[2], int qd) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 16) {
+                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;                 // tile t of the quarter, word p of its 8-word block = k-step 2 t + (p >> 2)
+                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3), uwd = word_of(uw[2 * t + (p >> 2)], p & 3);
+                const float sa = sig_of_h(lo_bf(hwd)), sb = sig_of_h(hi_bf(hwd));
+                const float va = src[t][r], vb = src[t][r + 1];
+                u0p[16 * qd + 8 * t + p] = anchor(pack2(va * sa, vb * sb));
+                scratch[8 * t + p] = anchor(pack2(va * lo_bf(uwd) * (100.f * sa * (1.f - sa)), vb * hi_bf(uwd) * (100.f * sb * (1.f - sb))));
+            } else if constexpr (sl < 20) {
+                tp_store(U0bt, tile, 4 * qd + (sl - 16), lane, u0p + 16 * qd + 4 * (sl - 16), ok);
+            } else {
+                tp_store(A0pt, tile, 4 * qd + (sl - 20), lane, scratch + 4 * (sl - 20), ok);
+            }
+        };
+        {
+            bf16x8 w0[2][2 * K0S];
+            uint32_t zoff = 0;
+            asm volatile("" : "+v"(zoff));
+            const bf16x8 *W0q = W0v + zoff;
+#define HS_W0_FETCH(q) do { _Pragma("unroll") for (int s_ = 0; s_ < K0S; s_++) { \
+        w0[(q) & 1][2 * s_] = W0q[(size_t)(s_ * NT + 2 * (q)) * 64]; w0[(q) & 1][2 * s_ + 1] = W0q[(size_t)(s_ * NT + 2 * (q) + 1) * 64]; } } while (0)
+            HS_W0_FETCH(0);
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (q < 3) HS_W0_FETCH(q + 1);
+                if constexpr (q > 0) load0(q - 1);
+                auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
+                if constexpr (q == 0) phase2<K0S, 1, K0S, 24, false, true>(acc[0], hin, f0, [](auto) {});
+                else phase2<K0S, 1, K0S, 24, true, true>(acc[q & 1], hin, f0, [&](auto slc) { epi0(slc, acc[(q & 1) ^ 1], q - 1); });
+            });
+#undef HS_W0_FETCH
+        }
+        if (!resident) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            resident = true;
+        }
+        // epilogue of layer 1's finished quarter: acc = v1~ ; u1~ = v1~ s1 (TP), a1' = v1~ u1 s1' (TP), u1 = W2[k*] gathered
+        uint32_t s1w[16];
+        auto epi1 = [&](auto slc, f32x16 (&src)[2], int qd) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 16) {
+                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
+                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
+                const float sa = sig_of_h(lo_bf(hwd)), sb = sig_of_h(hi_bf(hwd));
+                const int nn = 32 * (2 * qd + t) + 8 * (r >> 2) + 4 * h + (r & 3);
+                const float2 u1 = *reinterpret_cast<const float2 *>(W2tab + (size_t)bi * 256 + nn);
+                const float va = src[t][r], vb = src[t][r + 1];
+                s1w[8 * t + p] = anchor(pack2(va * sa, vb * sb));
+                scratch[8 * t + p] = anchor(pack2(va * u1.x * (100.f * sa * (1.f - sa)), vb * u1.y * (100.f * sb * (1.f - sb))));
+            } else if constexpr (sl < 20) {
+                tp_store(U1bt, tile, 4 * qd + (sl - 16), lane, s1w + 4 * (sl - 16), ok);
+            } else {
+                tp_store(A1pt, tile, 4 * qd + (sl - 20), lane, scratch + 4 * (sl - 20), ok);
+            }
+        };
+        auto load1 = [&](int qd) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) hw[i] = tp_load(H1t, tile, 4 * qd + i, lane);
+        };
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
+            if constexpr (q == 0) {
+                load0(3);
+                phase2<HS, 2, 8, 24, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 3); });
+            } else {
+                load1(q - 1);
+                phase2<HS, 2, HS, 24, true, true>(acc[q & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(q & 1) ^ 1], q - 1); });
+            }
+        });
+        load1(3);
+        static_for<24>([&](auto slc) { epi1(slc, acc[1], 3); });
+    }
+    if (!resident) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ================================================================================================================ "up" kernels
+// W0^T product: 16 k-steps x 3 slot tiles, fragments from L2 (48 KB image), AH k-steps ahead of their MFMAs; `side(s)` runs in the shadow of k-step s
+template <int AH, class SideFn>
+__device__ __forceinline__ void up_input_product(const bf16x8 *__restrict__ W0Tv, const uint32_t *vp, f32x16 &o0, f32x16 &o1, f32x16 &o2, SideFn side) {
+    bf16x8 ring[AH + 1][XS];
+    static_for<AH>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        static_for<XS>([&](auto tc) { constexpr int t = decltype(tc)::value; ring[s][t] = W0Tv[(size_t)(s * XS + t) * 64]; });
+    });
+    static_for<HS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + AH < HS)
+            static_for<XS>([&](auto tc) { constexpr int t = decltype(tc)::value; ring[(s + AH) % (AH + 1)][t] = W0Tv[(size_t)((s + AH) * XS + t) * 64]; });
+        side(sc);
+        const bf16x8 bfrag = frag_of(vp + 4 * s);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (s == 0) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][0], bfrag, zero, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][1], bfrag, zero, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][2], bfrag, zero, 0, 0, 0);
+        } else {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AH + 1)][0], bfrag, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AH + 1)][1], bfrag, o1, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AH + 1)][2], bfrag, o2, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+constexpr int kUpAhead = 3;
+
+// slot sigma (0..47) of this lane half sits in accumulator (sigma >> 4), register (sigma & 15)
+#define HS_SLOT(o0, o1, o2, sigma) ((sigma) < 16 ? o0[(sigma) & 15] : (sigma) < 32 ? o1[(sigma) & 15] : o2[(sigma) & 15])
+
+// ---------------------------------------------------------------------------------------------------------------- forward, gradient chain
+__global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__restrict__ x, const float *__restrict__ dydx, const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ W2tab, const uint16_t *__restrict__ W1Tf,
+                                                               const uint16_t *__restrict__ W0Tf, const uint16_t *__restrict__ H0t,
+                                                               const uint16_t *__restrict__ H1t, uint16_t *__restrict__ U0t, uint16_t *__restrict__ V1t,
+                                                               uint16_t *__restrict__ V0t, float *__restrict__ grad, float *__restrict__ uxh,
+                                                               float jac_scale, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *W1l = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+    dma_fill(W1Tf, W1l, kW1F * 2, wave, lane);
+    bool resident = false;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
+    const bf16x8 *W0Tv = reinterpret_cast<const bf16x8 *>(W0Tf) + lane;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int64_t gp = tile * kRows + row;
+        const bool ok = gp < n;
+        const int bi = (int)idx[ok ? gp : 0];
+        // ---- v1 = W2[k*] * s1 in B-fragment order (k-step s: neurons 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3)
+        uint32_t vin[64];
+        {
+            const float *wrow = W2tab + (size_t)bi * 256 + 4 * h;
+#pragma unroll
+            for (int s = 0; s < HS; s++) {
+                const uint4 hw = tp_load(H1t, tile, s, lane);
+                const float4 ua = *reinterpret_cast<const float4 *>(wrow + 16 * s), ub = *reinterpret_cast<const float4 *>(wrow + 16 * s + 8);
+                vin[4 * s] = pack2(ua.x * sig_of_h(lo_bf(hw.x)), ua.y * sig_of_h(hi_bf(hw.x)));
+                vin[4 * s + 1] = pack2(ua.z * sig_of_h(lo_bf(hw.y)), ua.w * sig_of_h(hi_bf(hw.y)));
+                vin[4 * s + 2] = pack2(ub.x * sig_of_h(lo_bf(hw.z)), ub.y * sig_of_h(hi_bf(hw.z)));
+                vin[4 * s + 3] = pack2(ub.z * sig_of_h(lo_bf(hw.w)), ub.w * sig_of_h(hi_bf(hw.w)));
+                tp_store(V1t, tile, s, lane, vin + 4 * s, ok);
+            }
+        }
+        if (!resident) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            resident = true;
+        }
+        uint32_t v0p[64], uw8[16];
+        f32x16 acc[2][2];
+        uint4 hw[4];
+        auto load0 = [&](int qd) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) hw[i] = tp_load(H0t, tile, 4 * qd + i, lane);
+        };
+        // finished quarter qd of u0 = W1^T v1: u0 leaves as TP, v0 = u0 s0 is the next product's input (and TP, for the weight gradient)
+        auto epi = [&](auto slc, f32x16 (&src)[2], int qd) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 16) {
+                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
+                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
+                const float ua = src[t][r], ub = src[t][r + 1];
+                uw8[8 * t + p] = anchor(pack2(ua, ub));
+                v0p[16 * qd + 8 * t + p] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
+            } else if constexpr (sl < 20) {
+                tp_store(U0t, tile, 4 * qd + (sl - 16), lane, uw8 + 4 * (sl - 16), ok);
+            } else {
+                tp_store(V0t, tile, 4 * qd + (sl - 20), lane, v0p + 16 * qd + 4 * (sl - 20), ok);
+            }
+        };
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
+            if constexpr (q == 0) phase2<HS, 2, HS, 24, false, true>(acc[0], vin, f1, [](auto) {});
+            else {
+                load0(q - 1);
+                phase2<HS, 2, HS, 24, true, true>(acc[q & 1], vin, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], q - 1); });
+            }
+        });
+        // ---- ux = W0^T v0 (the last quarter's epilogue in the shadow of k-steps 0..7, which only need quarters 0..1)
+        load0(3);
+        f32x16 &o0 = acc[0][0], &o1 = acc[0][1];
+        f32x16 o2;
+        up_input_product<kUpAhead>(W0Tv, v0p, o0, o1, o2, [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s < 8) static_for<3>([&](auto jc) { epi(std::integral_constant<int, 3 * s + decltype(jc)::value>{}, acc[1], 3); });
+        });
+        // ---- d min / dx = E^T ux over this half's 37 columns, the other half's share by one shuffle; the hash columns of ux are kept
+        //      for the backward pass (cotangent of dy_dx)
+        const EFac E = load_efac(x, dydx, gp, n, h, jac_scale, ok);
+        float gd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 18; j++) gd[j % 3] += E.pe[j] * HS_SLOT(o0, o1, o2, j);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) gd[d] += E.dy[i][d].x * HS_SLOT(o0, o1, o2, 18 + 2 * i) + E.dy[i][d].y * HS_SLOT(o0, o1, o2, 19 + 2 * i);
+        if (h == 0) { gd[0] += HS_SLOT(o0, o1, o2, 34); gd[1] += HS_SLOT(o0, o1, o2, 35); gd[2] += HS_SLOT(o0, o1, o2, 36); }
+#pragma unroll
+        for (int d = 0; d < 3; d++) gd[d] += __shfl_xor(gd[d], 32);
+        if (ok) {
+            if (h == 0) { grad[gp * 3] = gd[0]; grad[gp * 3 + 1] = gd[1]; grad[gp * 3 + 2] = gd[2]; }
+            float4 *up = reinterpret_cast<float4 *>(uxh + gp * 32 + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                up[i] = make_float4(HS_SLOT(o0, o1, o2, 18 + 4 * i), HS_SLOT(o0, o1, o2, 19 + 4 * i), HS_SLOT(o0, o1, o2, 20 + 4 * i), HS_SLOT(o0, o1, o2, 21 + 4 * i));
+        }
+    }
+    if (!resident) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward, value part
+// PRIME: the gradient part ran (a0', a1' exist); without it (no cotangent on d min / dx) they are zero
+template <bool PRIME>
+__global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *__restrict__ gy, const uint16_t *__restrict__ W2Tf,
+                                                                const uint16_t *__restrict__ W1Tf, const uint16_t *__restrict__ W0Tf,
+                                                                const uint16_t *__restrict__ H0t, const uint16_t *__restrict__ H1t,
+                                                                const uint16_t *__restrict__ A0pt, const uint16_t *__restrict__ A1pt,
+                                                                uint16_t *__restrict__ A0t, uint16_t *__restrict__ A1t, float *__restrict__ g_feat,
+                                                                int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t *W1l = lds;
+    uint16_t *W2l = lds + kW1F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
+    dma_fill(W1Tf, W1l, kW1F * 2, wave, lane);
+    dma_fill(W2Tf, W2l, kW2TF * 2, wave, lane);
+    bool resident = false;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
+    const bf16x8 *W2v = reinterpret_cast<const bf16x8 *>(W2l) + lane;
+    const bf16x8 *W0Tv = reinterpret_cast<const bf16x8 *>(W0Tf) + lane;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        const int64_t gp = tile * kRows + row;
+        const bool ok = gp < n;
+        // B fragments of the output cotangent: k-step s = objects 16 s + 8 h + 0..7 of this sample
+        uint32_t gin[8];
+        {
+            const uint4 a = ok ? *reinterpret_cast<const uint4 *>(gy + gp * 32 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 b = ok ? *reinterpret_cast<const uint4 *>(gy + gp * 32 + 16 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            gin[0] = a.x; gin[1] = a.y; gin[2] = a.z; gin[3] = a.w; gin[4] = b.x; gin[5] = b.y; gin[6] = b.z; gin[7] = b.w;
+        }
+        if (!resident) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            resident = true;
+        }
+        uint32_t a1p[64], a0p[64];
+        f32x16 acc[2][2];
+        uint4 hw[4], pw[4];
+        auto load = [&](const uint16_t *H, const uint16_t *P, int qd) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                hw[i] = tp_load(H, tile, 4 * qd + i, lane);
+                if constexpr (PRIME) pw[i] = tp_load(P, tile, 4 * qd + i, lane);
+            }
+        };
+        // a~ = a' + h~ s for the finished quarter qd: next product's input and TP (weight gradient)
+        auto epi = [&](auto slc, f32x16 (&src)[2], uint32_t *ap, uint16_t *T, int qd) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 16) {
+                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
+                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
+                float va = src[t][r] * sig_of_h(lo_bf(hwd)), vb = src[t][r + 1] * sig_of_h(hi_bf(hwd));
+                if constexpr (PRIME) {
+                    const uint32_t pwd = word_of(pw[2 * t + (p >> 2)], p & 3);
+                    va += lo_bf(pwd);
+                    vb += hi_bf(pwd);
+                }
+                ap[16 * qd + 8 * t + p] = anchor(pack2(va, vb));
+            } else {
+                tp_store(T, tile, 4 * qd + (sl - 16), lane, ap + 16 * qd + 4 * (sl - 16), ok);
+            }
+        };
+        // ---- h1~ = W2^T y~ (K = 32: two k-steps per tile), quarter by quarter, each followed by its epilogue
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            load(H1t, A1pt, q);
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 (&cur)[2] = acc[q & 1];
+            static_for<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(0 * NT + 2 * q + j) * 64], frag_of(gin), zero, 0, 0, 0);
+                cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(1 * NT + 2 * q + j) * 64], frag_of(gin + 4), cur[j], 0, 0, 0);
+            });
+            static_for<20>([&](auto slc) { epi(slc, cur, a1p, A1t, q); });
+        });
+        // ---- h0~ = W1^T a1~
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
+            if constexpr (q == 0) phase2<HS, 2, HS, 20, false, true>(acc[0], a1p, f1, [](auto) {});
+            else {
+                load(H0t, A0pt, q - 1);
+                phase2<HS, 2, HS, 20, true, true>(acc[q & 1], a1p, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], a0p, A0t, q - 1); });
+            }
+        });
+        // ---- xt~ = W0^T a0~; only the hash-feature slots are wanted (x is a constant): g_feat [L, n, 2], level-major
+        load(H0t, A0pt, 3);
+        f32x16 &o0 = acc[0][0], &o1 = acc[0][1];
+        f32x16 o2;
+        up_input_product<kUpAhead>(W0Tv, a0p, o0, o1, o2, [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s < 10) static_for<2>([&](auto jc) { epi(std::integral_constant<int, 2 * s + decltype(jc)::value>{}, acc[1], a0p, A0t, 3); });
+        });
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                *reinterpret_cast<float2 *>(g_feat + ((size_t)(8 * h + i) * n + gp) * 2) = make_float2(HS_SLOT(o0, o1, o2, 18 + 2 * i), HS_SLOT(o0, o1, o2, 19 + 2 * i));
+        }
+    }
+    if (!resident) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hs_trunk_rr_pack_bytes(int32_t which) {
+    switch (which) {
+        case 0: return (int64_t)kW1F * 2;        /* W1^T image */
+        case 1: return (int64_t)kW0TF * 2;       /* W0^T image */
+        case 2: return (int64_t)kW2TF * 2;       /* W2^T image */
+        case 3: return (int64_t)32 * 256 * 4;    /* W2 gather table */
+        default: return -1;
+    }
+}
+
+int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
+                     void *stream) {
+    if (d_out < 1 || d_out > 32 || ld0 < 71) return HS_ERR_ARG;
+    if (!W0 || !W1 || !W2 || !W1Tf || !W0Tf || !W2Tf || !W2tab) return HS_ERR_NULL;
+    const int slots = HS * NT * 64 + HS * XS * 64 + 2 * NT * 64 + 32 * 256 / 4;
+    k_rr_pack<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(W0, ld0, W1, W2, d_out, (uint16_t *)W1Tf, (uint16_t *)W0Tf, (uint16_t *)W2Tf, W2tab);
+    return wt_check_launch();
+}
+
+static int rr_grid(int64_t n) {
+    const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
+    return (int)(want < 256 ? want : 256);
+}
+
+int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
+                          void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream) {
+    if (d_out < 1 || d_out > 32) return HS_ERR_ARG;
+    if (n == 0) return HS_OK;
+    if (!x || !feat || !W0f || !W1f || !W2f || !bias || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx || !onehot) return HS_ERR_NULL;
+    if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
+    const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    k_rr_fwd_value<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                    (uint16_t *)H0t, (uint16_t *)H1t, (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, n);
+    return wt_check_launch();
+}
+
+int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
+                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, void *stream) {
+    if (n == 0) return HS_OK;
+    if (!x || !dydx || !idx || !W2tab || !W1Tf || !W0Tf || !H0t || !H1t || !U0t || !V1t || !V0t || !grad || !uxh) return HS_ERR_NULL;
+    const size_t lds = (size_t)kW1F * sizeof(uint16_t);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    k_rr_fwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, idx, W2tab, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, (const uint16_t *)H0t,
+                                                                   (const uint16_t *)H1t, (uint16_t *)U0t, (uint16_t *)V1t, (uint16_t *)V0t, grad, uxh, jac_scale, n);
+    return wt_check_launch();
+}
+
+int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad, const float *uxh, const int64_t *idx, const float *W2tab, const void *W0f,
+                         const void *W1f, const void *H0t, const void *H1t, const void *U0t, void *U0bt, void *A0pt, void *A1pt, void *U1bt, void *UXb,
+                         float *g_dydx, float jac_scale, int64_t n, void *stream) {
+    if (n == 0) return HS_OK;
+    if (!x || !dydx || !g_grad || !uxh || !idx || !W2tab || !W0f || !W1f || !H0t || !H1t || !U0t || !U0bt || !A0pt || !A1pt || !U1bt || !UXb || !g_dydx)
+        return HS_ERR_NULL;
+    const size_t lds = (size_t)kW1F * sizeof(uint16_t);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_bwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    k_rr_bwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, g_grad, uxh, idx, W2tab, (const uint16_t *)W0f, (const uint16_t *)W1f,
+                                                                   (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)U0t, (uint16_t *)U0bt,
+                                                                   (uint16_t *)A0pt, (uint16_t *)A1pt, (uint16_t *)U1bt, (uint16_t *)UXb, g_dydx, jac_scale, n);
+    return wt_check_launch();
+}
+
+int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t, const void *A0pt,
+                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, void *stream) {
+    if (n == 0) return HS_OK;
+    if (!gy || !W2Tf || !W1Tf || !W0Tf || !H0t || !H1t || !A0t || !A1t || !g_feat || (!A0pt) != (!A1pt)) return HS_ERR_NULL;
+    const size_t lds = (size_t)(kW1F + kW2TF) * sizeof(uint16_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)k_rr_bwd_value<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_rr_bwd_value<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (A0pt)
+        k_rr_bwd_value<true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
+                                                                              (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)A0pt, (const uint16_t *)A1pt,
+                                                                              (uint16_t *)A0t, (uint16_t *)A1t, g_feat, n);
+    else
+        k_rr_bwd_value<false><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
+                                                                               (const uint16_t *)H0t, (const uint16_t *)H1t, nullptr, nullptr, (uint16_t *)A0t, (uint16_t *)A1t,
+                                                                               g_feat, n);
+    return wt_check_launch();
+}
+
+}  // extern "C"

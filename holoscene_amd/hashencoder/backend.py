@@ -59,6 +59,11 @@ class hsWnJob(ctypes.Structure):
                 ("gg", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
 
 
+class hsWgradPairJob(ctypes.Structure):
+    _fields_ = [("A0", ctypes.c_void_p), ("B0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("B1", ctypes.c_void_p), ("part", ctypes.c_void_p),
+                ("M", ctypes.c_int64), ("rows", ctypes.c_int64), ("kind", ctypes.c_int32), ("slices", ctypes.c_int32)]
+
+
 class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
@@ -99,7 +104,8 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels"]
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs"]
 
 
 def _check(rc, what):
@@ -540,6 +546,88 @@ class _HipBackend:
         _check(lib.hs_draw_pixels(_dev(class_ptr, "class_ptr", i32), _dev(class_pix, "class_pix", i32), _dev(out_off, "out_off", i32), int(n_cls),
                                   int(per_class), int(n_bg), int(n_uniform), int(total_pixels), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
                                   ctypes.c_uint64(int(counter)), _dev(out, "out", torch.int64), _stream()), "hs_draw_pixels")
+
+    # ---- reverse-over-reverse trunk of the rendered samples (csrc/trunk_rr.hip, csrc/wgrad_pairs.hip)
+    @staticmethod
+    def tp_rows(n):
+        """Rows a tile-packed activation tensor holds for n samples (whole 32-row tiles)."""
+        return 32 * ((int(n) + 31) // 32)
+
+    @staticmethod
+    def trunk_rr_pack(W0, W1, W2, d_out):
+        """fp32 effective matrices -> (W1Tf, W0Tf, W2Tf, W2tab): fragment images of the transposed matrices + the fp32 gather table of W2."""
+        lib = load_library()
+        lib.hs_trunk_rr_pack_bytes.restype = ctypes.c_int64
+        dev, bf = W0.device, torch.bfloat16
+        n = [int(lib.hs_trunk_rr_pack_bytes(i)) for i in range(4)]
+        W1Tf, W0Tf, W2Tf = (torch.empty(n[i] // 2, device=dev, dtype=bf) for i in range(3))
+        W2tab = torch.empty(n[3] // 4, device=dev)
+        if W0.stride(1) != 1 or W0.stride(0) < 71:
+            raise RuntimeError("trunk_rr_pack: W0 must be row-major with at least 71 columns")
+        _check(lib.hs_trunk_rr_pack(_dev(W0, "W0"), int(W0.stride(0)), _dev(W1, "W1"), _dev(W2, "W2"), int(d_out), _dev(W1Tf, "W1Tf", bf),
+                                    _dev(W0Tf, "W0Tf", bf), _dev(W2Tf, "W2Tf", bf), _dev(W2tab, "W2tab"), _stream()), "hs_trunk_rr_pack")
+        return W1Tf, W0Tf, W2Tf, W2tab
+
+    @staticmethod
+    def trunk_rr_fwd_value(x, feat, packed, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot):
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, W2f, bias = packed
+        _check(lib.hs_trunk_rr_fwd_value(_dev(x, "x"), _dev(feat, "feat"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
+                                         int(d_out), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(Xp, "Xp", bf), _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"),
+                                         _dev(idx, "idx", torch.int64), _dev(onehot, "onehot", bf), ctypes.c_int64(x.shape[0]), _stream()), "hs_trunk_rr_fwd_value")
+
+    @staticmethod
+    def trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac_scale):
+        lib = load_library()
+        bf = torch.bfloat16
+        W1Tf, W0Tf, _, W2tab = rr
+        _check(lib.hs_trunk_rr_fwd_grad(_dev(x, "x"), _dev(dydx, "dydx"), _dev(idx, "idx", torch.int64), _dev(W2tab, "W2tab"), _dev(W1Tf, "W1Tf", bf),
+                                        _dev(W0Tf, "W0Tf", bf), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(U0t, "U0t", bf), _dev(V1t, "V1t", bf),
+                                        _dev(V0t, "V0t", bf), _dev(grad, "grad"), _dev(uxh, "uxh"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]),
+                                        _stream()), "hs_trunk_rr_fwd_grad")
+
+    @staticmethod
+    def trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac_scale):
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, _, _ = packed
+        _check(lib.hs_trunk_rr_bwd_grad(_dev(x, "x"), _dev(dydx, "dydx"), _dev(g_grad, "g_grad"), _dev(uxh, "uxh"), _dev(idx, "idx", torch.int64),
+                                        _dev(rr[3], "W2tab"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf),
+                                        _dev(U0t, "U0t", bf), _dev(U0bt, "U0bt", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(U1bt, "U1bt", bf),
+                                        _dev(UXb, "UXb", bf), _dev(g_dydx, "g_dydx"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]), _stream()),
+               "hs_trunk_rr_bwd_grad")
+
+    @staticmethod
+    def trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n):
+        lib = load_library()
+        bf = torch.bfloat16
+        W1Tf, W0Tf, W2Tf, _ = rr
+        _check(lib.hs_trunk_rr_bwd_value(_dev(gy, "gy", bf), _dev(W2Tf, "W2Tf", bf), _dev(W1Tf, "W1Tf", bf), _dev(W0Tf, "W0Tf", bf), _dev(H0t, "H0t", bf),
+                                         _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf), _dev(A1t, "A1t", bf),
+                                         _dev(g_feat, "g_feat"), ctypes.c_int64(n), _stream()), "hs_trunk_rr_bwd_value")
+
+    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2}
+
+    @staticmethod
+    def wgrad_pairs(jobs, n):
+        """jobs: [((NA, W), slices, (A0, B0), (A1, B1) or None)] over n samples -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80),
+        all in one launch (csrc/wgrad_pairs.hip)."""
+        lib = load_library()
+        bf = torch.bfloat16
+        M = _HipBackend.tp_rows(n)
+        arr = (hsWgradPairJob * len(jobs))()
+        outs = []
+        for a, (shape, slices, p0, p1) in zip(arr, jobs):
+            NA, W = shape
+            MB = 128 if W == 80 else W
+            part = torch.empty(slices, NA, MB, device=p0[0].device, dtype=bf)
+            a.A0, a.B0 = _dev(p0[0], "A0", bf).value, _dev(p0[1], "B0", bf).value
+            a.A1, a.B1 = (_dev(p1[0], "A1", bf).value, _dev(p1[1], "B1", bf).value) if p1 is not None else (None, None)
+            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, int(n), _HipBackend.WGP_KINDS[shape], int(slices)
+            outs.append(part)
+        _check(lib.hs_wgrad_pairs(arr, len(jobs), _stream()), "hs_wgrad_pairs")
+        return outs
 
     WGRAD_SHAPES = ((256, 256), (256, 128), (32, 256))
 

@@ -487,6 +487,48 @@ typedef struct hsGatherJob {
 } hsGatherJob;
 int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
 
+/* ------------------------------------------------------------------ reverse-over-reverse trunk of the rendered samples (csrc/trunk_rr.hip)
+ *
+ * ObjectImplicitNetworkGrid.get_outputs (model/network.py:273-301) for the rendered samples -- K per-object SDFs, their minimum, its
+ * index and d min / dx -- and its double backward (the reference: autograd.grad(create_graph=True) :293-299, then loss.backward()), in
+ * closed form on rows that are SAMPLES: see the header of csrc/trunk_rr.hip for the equations.  bf16 operands, fp32 accumulation.
+ * "TP" = tile-packed activation tensor: [ceil(n / 32)][16][64] x 8 bf16 (lane (sample, half)'s four packed words of every k-step);
+ * rows past n are written as zeros.  Images: W0f / W1f / W2f / bias from hs_sdf_mlp2_pack(log2_domain = 0); W1Tf / W0Tf / W2Tf / W2tab
+ * from hs_trunk_rr_pack (sizes: hs_trunk_rr_pack_bytes(0..3)).
+ *   fwd_value: x [n,3], feat [n,32] (point-major)  ->  H0t, H1t (TP), Xp [n,80] bf16 (hs_trunk_mlp2_input_column order), sdf_raw [n,K],
+ *              sdf [n], idx [n] (arg-min, lowest among equals), onehot [n,32] bf16 (1 at idx)
+ *   fwd_grad:  dydx [L=16, n, 6] as hs_hash_fwd wrote it  ->  U0t, V1t, V0t (TP), grad [n,3] = d min / dx, uxh [n,32] (hash columns of ux)
+ *   bwd_grad:  g_grad [n,3]  ->  U0bt, A0pt, A1pt, U1bt (TP), UXb [n,80] bf16, g_dydx [16, n, 6] (cotangent of dy_dx, for hs_hash_bwd_jac)
+ *   bwd_value: gy [n,32] bf16 (cotangent of the K outputs, the minimum's folded in at idx); A0pt / A1pt NULL when bwd_grad did not run
+ *              ->  A0t, A1t (TP), g_feat [16, n, 2] (cotangent of the hash features, level-major) */
+int64_t hs_trunk_rr_pack_bytes(int32_t which);
+int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
+                     void *stream);
+int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
+                          void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
+int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
+                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, void *stream);
+int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad, const float *uxh, const int64_t *idx, const float *W2tab, const void *W0f,
+                         const void *W1f, const void *H0t, const void *H1t, const void *U0t, void *U0bt, void *A0pt, void *A1pt, void *U1bt, void *UXb,
+                         float *g_dydx, float jac_scale, int64_t n, void *stream);
+int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t, const void *A0pt,
+                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, void *stream);
+
+/* Weight gradients of that formulation: part[slice] = sum over the job's one or two operand pairs of A^T B over the slice's rows
+ * (csrc/wgrad_pairs.hip).  kind: HS_WGP_256x256 (A, B tile-packed), HS_WGP_256x80 (A tile-packed, B row-major [rows, 80]; result
+ * [256, 128], columns >= 80 zero), HS_WGP_32x256 (A row-major [rows, 32], B tile-packed).  M = 32 * number of tiles (a multiple of
+ * 32 * slices), rows <= M the valid rows of the row-major operands; part: bf16 [slices, NA, MB]. */
+#define HS_WGP_256x256 0
+#define HS_WGP_256x80 1
+#define HS_WGP_32x256 2
+typedef struct hsWgradPairJob {
+    const void *A0, *B0, *A1, *B1;      /* second pair optional (both NULL) */
+    void *part;
+    int64_t M, rows;
+    int32_t kind, slices;
+} hsWgradPairJob;
+int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream);
+
 /* The pixel draw of one training batch (datasets/ns_dataset.py:409-430: NSDataset.__getitem__'s class-balanced rule, there a dozen
  * torch.randperm calls per batch in DataLoader worker processes) as ONE launch.  The frame's pixels grouped by instance class in CSR
  * form: class_ptr [n_cls + 1] offsets into class_pix (pixel indices, class 0 = background first).  Class c contributes

