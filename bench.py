@@ -162,6 +162,42 @@ def _work_trunk_bwd3(a, k):
     return M * (fwd01 + chain + wgr), M * (80 * 2 + 32 * 2) + (M // 4) * (128 + 384)
 
 
+def _rr_n(a):
+    return a[0].shape[0]
+
+
+def _work_rr_fwd_value(a, k):
+    n, K = a[0].shape[0], a[3]
+    return n * trunk_flops_per_row(K), n * (12 + 128 + 2 * 512 + 160 + 4 * K + 12 + 64)
+
+
+def _work_rr_fwd_grad(a, k):
+    n = a[0].shape[0]
+    return n * 2 * (256 * 256 + K_IN * 256), n * (12 + 384 + 8 + 2 * 512 + 3 * 512 + 12 + 128)
+
+
+def _work_rr_bwd_grad(a, k):
+    n = a[0].shape[0]
+    return n * 2 * (K_IN * 256 + 256 * 256), n * (12 + 384 + 12 + 128 + 8 + 3 * 512 + 4 * 512 + 160 + 384)
+
+
+def _work_rr_bwd_value(a, k):
+    n, K = a[9], _K_OBJECTS[0] or 32
+    prime = a[4] is not None
+    return n * 2 * (256 * K + 256 * 256 + K_IN * 256), n * (64 + (4 if prime else 2) * 512 + 2 * 512 + 128)
+
+
+def _work_wgrad_pairs(a, k):
+    fl = by = 0
+    n = a[1]
+    for (NA, W), _s, p0, p1 in a[0]:
+        for pr in (p0, p1):
+            if pr is not None:
+                fl += 2 * n * NA * W
+                by += n * (NA + W) * 2
+    return fl, by
+
+
 def _work_bmm(a, k):
     A, Bm = a[0], a[1]
     S, m, kk = A.shape
@@ -209,7 +245,12 @@ TIMED = {
     "softplus_tangent_fwd": ("k_softplus_tangent_fwd", None),
     "softplus_tangent_bwd": ("k_softplus_tangent_bwd", None),
     "softplus_tangent_bwd_h": ("k_softplus_tangent_bwd_h", None),
-    "trunk_mlp3_bwd": ("k_trunk_bwd3 (trunk backward: recompute + data-gradient chain + all three weight gradients in one kernel)", _work_trunk_bwd3),
+    "trunk_rr_fwd_value": ("k_rr_fwd_value (rendered samples, reverse-over-reverse trunk: values, min, arg-min)", _work_rr_fwd_value),
+    "trunk_rr_fwd_grad": ("k_rr_fwd_grad (d min / dx by one reverse pass: W1^T, W0^T, E^T)", _work_rr_fwd_grad),
+    "trunk_rr_bwd_grad": ("k_rr_bwd_grad (double backward, gradient part: E, W0, W1)", _work_rr_bwd_grad),
+    "trunk_rr_bwd_value": ("k_rr_bwd_value (double backward, value part: W2^T, W1^T, W0^T)", _work_rr_bwd_value),
+    "wgrad_pairs": ("k_wgrad_pairs (trunk weight gradients: three pair-accumulating products on tile-packed operands, one launch)", _work_wgrad_pairs),
+    "trunk_rr_pack": ("k_rr_pack (transposed fragment images)", None),
 }
 LIBRARY_GEMM = "library GEMMs (hipBLASLt through torch.bmm: weight gradients not taken by k_wgrad_rows)"
 

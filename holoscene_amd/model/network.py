@@ -392,6 +392,138 @@ class _fused_trunk_render(torch.autograd.Function):
         return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
 
+# How the rendered samples go through the trunk: "rr" = reverse-over-reverse (csrc/trunk_rr.hip: rows are samples; value pass + one
+# reverse pass for d min / dx, closed-form double backward), "jac" = the value+Jacobian rows of _fused_trunk_render for every point
+# (4 rows per sample; what the Eikonal points, which need all K gradients, always use)
+TRUNK_MODE = os.environ.get("HOLOSCENE_TRUNK_MODE", "rr")
+
+
+def _rr_slices(n):
+    """Row slices of the three weight-gradient jobs of an rr backward pass (csrc/wgrad_pairs.hip): a slice is a whole number of 32-row
+    tiles, the jobs together should fill the chip once (256 workgroups), the 256 x 256 job -- two tile-packed pairs, the most bytes --
+    gets the finest cut."""
+    tiles = (n + 31) // 32
+    divs = [d for d in range(1, min(tiles, 128) + 1) if tiles % d == 0]
+    fine = max(divs)
+    coarse = max(d for d in divs if d <= max(1, (256 - fine) // 2)) if fine < 256 else fine
+    return fine, coarse, coarse
+
+
+def _tp_colsum(T):
+    """Column sums of a tile-packed activation tensor -> [256] fp32 in neuron order (bias gradients)."""
+    t = T.view(-1, 16, 2, 32, 2, 4).float().sum((0, 3))         # [s, h, e >> 2, e & 3]
+    return t.permute(0, 2, 1, 3).reshape(256)                    # neuron = 16 s + 8 (e >> 2) + 4 h + (e & 3)
+
+
+class _rr_trunk_main(torch.autograd.Function):
+    """The trunk of the rendered samples, reverse-over-reverse (module docstring of csrc/trunk_rr.hip): x [n,3] (constant), hash table and
+    the three effective weight matrices / biases -> sdf_raw [n,K], sdf [n,1] (min over objects), idx [n,1] (arg-min), gradients [n,3]
+    (d min / dx) -- the first four outputs of _fused_trunk_render, same values, a quarter of the rows in every kernel."""
+
+    @staticmethod
+    def forward(ctx, x, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+        ctx.set_materialize_grads(False)
+        be = _be._backend
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        x = x.contiguous().float()
+        if x01 is None:
+            x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+        n, dev, bf = x.shape[0], x.device, torch.bfloat16
+        L, C, K = offsets.shape[0] - 1, embeddings.shape[1], W2.shape[0]
+        feat = torch.empty(n, L * C, device=dev)
+        dydx = torch.empty(L, n, 3 * C, device=dev)
+        be.fwd(x01, embeddings, offsets, feat, n, 3, C, L, S, Hres, dydx)
+        jac = 0.5 / divide_factor
+        f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
+        packed = be.sdf_mlp2_pack(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2, b2.detach().float().contiguous(), K,
+                                  log2_domain=False)
+        rr = be.trunk_rr_pack(f0, f1, f2, K)
+        M = be.tp_rows(n)
+        tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
+        H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
+        Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty(n, 32, device=dev, dtype=bf)
+        sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(n, 1, device=dev, dtype=torch.int64)
+        grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
+        be.trunk_rr_fwd_value(x, feat, packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot)
+        be.trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac)
+        if ctx.needs_input_grad[1]:
+            _be.expect_scatter(ctx.table)
+        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr)
+        ctx.cfg = (n, L, C, K, S, Hres, jac)
+        ctx.mark_non_differentiable(idx)
+        return sdf_raw, sdf, idx, grad
+
+    @staticmethod
+    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad):
+        be = _be._backend
+        x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, W0f, W1f, W2f, bias, W1Tf, W0Tf, W2Tf, W2tab = ctx.saved_tensors
+        packed, rr = (W0f, W1f, W2f, bias), (W1Tf, W0Tf, W2Tf, W2tab)
+        n, L, C, K, S, Hres, jac = ctx.cfg
+        dev, bf = x.device, torch.bfloat16
+        M = be.tp_rows(n)
+        tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
+        # cotangent of the K outputs, the minimum's folded in at its index
+        gy32 = torch.zeros(n, 32, device=dev)
+        if g_raw is not None:
+            gy32[:, :K] = g_raw
+        if g_sdf is not None:
+            gy32.scatter_add_(1, idx, g_sdf.reshape(n, 1).float())
+        gy = gy32.to(bf)
+        need_table, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[6]
+        A0t, A1t = tp(), tp()
+        g_feat = torch.empty(L, n, C, device=dev)
+        g_dydx = None
+        if g_grad is not None:
+            U0bt, A0pt, A1pt, U1bt = tp(), tp(), tp(), tp()
+            UXb = torch.empty(n, 80, device=dev, dtype=bf)
+            g_dydx = torch.empty(L, n, 3 * C, device=dev)
+            be.trunk_rr_bwd_grad(x, dydx, g_grad.contiguous().float(), uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac)
+            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n)
+        else:
+            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n)
+        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
+        if need_w:
+            s1, s0, s2 = _rr_slices(n)
+            second = g_grad is not None
+            parts = be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
+                                    ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
+                                    ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)], n)
+            gW1, gW0p, gW2p = be.sum_slices(parts)
+            gW0 = gW0p[:, :80].index_select(1, _xp_columns(dev))
+            gW2 = gW2p[:K]
+            gb0, gb1, gb2 = _tp_colsum(A0t), _tp_colsum(A1t), gy32.sum(0)[:K]
+        g_emb = None
+        if need_table:
+            table = ctx.table
+            inplace = _be.accumulates_into_grad(table)
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, n, 3, C, L, S, Hres,
+                       ws=be.scatter_workspace(n, 3, C, L, dev) if n >= _BIN_MIN_POINTS else None, level_major=True)
+            if inplace:
+                _be.scatter_done(table)
+            g_emb = None if inplace else target
+        return None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
+
+
+def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+    """_fused_trunk_render's seven outputs.  TRUNK_MODE == "rr": the n_main rendered samples through the reverse-over-reverse kernels,
+    the Eikonal points (all K gradients) through the value+Jacobian ones; otherwise everything through the latter."""
+    B, K = x.shape[0], W2.shape[0]
+    if not (TRUNK_MODE == "rr" and n_main > 0 and K <= 32 and nfreq == 6 and offsets.shape[0] - 1 == 16 and embeddings.shape[1] == 2
+            and W0.shape[1] == 71):
+        if TRUNK_MODE not in ("rr", "jac"):
+            raise RuntimeError(f"unknown HOLOSCENE_TRUNK_MODE={TRUNK_MODE!r}")
+        return _fused_trunk_render.apply(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
+    sdf_raw, sdf, idx, grad = _rr_trunk_main.apply(x[:n_main], embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2,
+                                                   None if x01 is None else x01[:n_main])
+    if B == n_main:
+        empty = torch.empty(0, device=x.device)
+        return sdf_raw, sdf, idx, grad, empty.reshape(0, K), empty.reshape(0, 1), empty.reshape(0, 3)
+    _, _, idx_e, _, y_eik, min_eik, gtheta = _fused_trunk_render.apply(x[n_main:], 0, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1,
+                                                                      W2, b2, None if x01 is None else x01[n_main:])
+    return sdf_raw, sdf, torch.cat([idx, idx_e], 0), grad, y_eik, min_eik, gtheta
+
+
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
 # bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
 APPEARANCE_IMPL = os.environ.get("HOLOSCENE_APPEARANCE_IMPL", "mfma")
@@ -1654,7 +1786,7 @@ class HoloSceneNetwork(nn.Module):
             enc = net.encoding
             l0, l1, l2 = net._lins()
             trunk_W = W0, W1, W2 = effective_weights([l0, l1, l2])
-            sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = _fused_trunk_render.apply(
+            sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = trunk_render(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
         else:
@@ -1736,7 +1868,7 @@ class HoloSceneNetwork(nn.Module):
                 enc = net.encoding
                 l0, l1, l2 = net._lins()
                 W0, W1, W2 = trunk_W if trunk_W is not None else effective_weights([l0, l1, l2])   # the main pass's normalised weights
-                raw_b, sdf_b, _, grad_b, _, _, _ = _fused_trunk_render.apply(
+                raw_b, sdf_b, _, grad_b, _, _, _ = trunk_render(
                     xb, B0, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                     net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, xb01)
                 beta, unused_rgb = self.density.get_beta(), grad_b.detach()     # (the colour slot of the kernel is not needed here)

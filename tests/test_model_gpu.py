@@ -809,11 +809,16 @@ def test_fused_background_smoothness_vs_torch_formulation(density, monkeypatch):
             close(g_h, g_t, 1e-5, 1e-7, name)
 
 
-def test_fused_background_pass_vs_torch_formulation(monkeypatch):
+@pytest.mark.parametrize("trunk_mode", ["jac", "rr"])
+def test_fused_background_pass_vs_torch_formulation(trunk_mode, monkeypatch):
     """render()'s background-surface pass through the main pass's kernels (trunk + split, compositing twice) vs the whole-tensor
     formulation on the same bf16 trunk: label map, depth and normal map of the 32x32 patch, and the gradient of a scalar of them
-    with respect to the geometry hash table and the trunk weights."""
+    with respect to the geometry hash table and the trunk weights.  trunk_mode "jac": both sides run the value+Jacobian kernels (same
+    arithmetic: tight bounds); "rr" (the default): the fused side takes d min / dx by the reverse-over-reverse kernels -- another
+    order of bf16 roundings, so bf16-level bounds."""
     from holoscene_amd.model import network as N
+    monkeypatch.setattr(N, "TRUNK_MODE", trunk_mode)
+    tight = trunk_mode == "jac"
     tr, scene = _full_graph_trainer(0.01, True)
     model = tr.model.train()
     _, ins, _ = scene.next_batch()
@@ -833,14 +838,15 @@ def test_fused_background_pass_vs_torch_formulation(monkeypatch):
         grads = torch.autograd.grad(val, params, allow_unused=True)
         res[impl] = (out["bg_mask"], out["bg_depth_values"].detach(), out["bg_normal_map"].detach(), grads)
     a, b = res["hip"], res["torch"]
-    assert float((a[0] != b[0]).float().mean()) <= 0.01          # argmax labels: ties aside, identical
-    close(a[1], b[1], 1e-4, 1e-5, "bg depth")
-    close(a[2], b[2], 1e-4, 1e-5, "bg normal map")
+    assert float((a[0] != b[0]).float().mean()) <= (0.01 if tight else 0.03)          # argmax labels: ties aside, identical
+    close(a[1], b[1], 1e-4 if tight else 5e-3, 1e-5 if tight else 5e-3, "bg depth")
+    close(a[2], b[2], 1e-4 if tight else 1e-2, 1e-5 if tight else 3e-2, "bg normal map")       # rr: measured max 1.3e-2
     for ga, gb, p in zip(a[3], b[3], params):
         assert (ga is None) == (gb is None)
         if ga is not None:
             rel = float((ga - gb).norm() / gb.norm().clamp(min=1e-20))
-            assert rel < 2e-2, (tuple(p.shape), rel)       # bf16 cotangent images on both sides (split kernel vs autograd chain)
+            print(f"PARITY bg pass {trunk_mode} grad {tuple(p.shape)} relL2 {rel:.3e}")
+            assert rel < (2e-2 if tight else 6e-2), (tuple(p.shape), rel)       # bf16 cotangent images on both sides (split kernel vs autograd chain)
 
 
 def test_resident_batch_gather_equals_indexed_batches():
