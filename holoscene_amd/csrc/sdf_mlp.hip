@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                                                          uint16_t *__restrict__ gA1, uint16_t *__restrict__ gA0, float *__restrict__ gb1,
                                                          float *__restrict__ gb0, const uint16_t *__restrict__ W0t, float *__restrict__ g_feat,
                                                          float *__restrict__ g_dydx, int L, int C, float jac_scale, int64_t M,
-                                                         float *__restrict__ gb2, float *__restrict__ dW2_part) {
+                                                         float *__restrict__ gb2, float *__restrict__ dW2_part, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *H = lds;
     uint16_t *Wc = lds + (size_t)BM * HP;
@@ -639,24 +639,24 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
                 constexpr int P = BM / 4;
                 for (int idx = threadIdx.x; idx < P * NFEAT; idx += kThreads) {          // [L, B, 2]: 2 P floats per level
                     const int l = idx / (2 * P), rem = idx % (2 * P), pt = rem >> 1, c = rem & 1;
-                    if (pb + pt < Bp) g_feat[((size_t)l * Bp + pb + pt) * 2 + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * 2 + c] << 16);
+                    if (pb + pt < Bp) g_feat[((size_t)l * ld + pb + pt) * 2 + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * 2 + c] << 16);
                 }
                 for (int idx = threadIdx.x; idx < (NFEAT / 2) * P * 6; idx += kThreads) {  // [L, B, 3, 2]: 6 P floats per level
                     const int l = idx / (6 * P), rem = idx % (6 * P), pt = rem / 6, dc = rem % 6, d = dc >> 1, c = dc & 1;
                     if (pb + pt < Bp)
-                        g_dydx[((size_t)l * Bp + pb + pt) * 6 + dc] = jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * 2 + c] << 16);
+                        g_dydx[((size_t)l * ld + pb + pt) * 6 + dc] = jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * 2 + c] << 16);
                 }
             } else {
             for (int idx = threadIdx.x; idx < (BM / 4) * LC; idx += kThreads) {   // level-major [L, B, C]
                 const int l = idx / ((BM / 4) * C), rem = idx - l * ((BM / 4) * C), pt = rem / C, c = rem - pt * C;
                 if (pb + pt < Bp)
-                    g_feat[((size_t)l * Bp + pb + pt) * C + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * C + c] << 16);
+                    g_feat[((size_t)l * ld + pb + pt) * C + c] = __uint_as_float((uint32_t)H[(size_t)(4 * pt) * HP + NPE + l * C + c] << 16);
             }
             const int run = (BM / 4) * 3 * C;
             for (int idx = threadIdx.x; idx < L * run; idx += kThreads) {
                 const int l = idx / run, rem = idx - l * run, pt = rem / (3 * C), dc = rem - pt * (3 * C), d = dc / C, c = dc - d * C;
                 if (pb + pt < Bp)
-                    g_dydx[((size_t)l * Bp + pb + pt) * (3 * C) + dc] =
+                    g_dydx[((size_t)l * ld + pb + pt) * (3 * C) + dc] =
                         jac_scale * __uint_as_float((uint32_t)H[(size_t)(4 * pt + 1 + d) * HP + NPE + l * C + c] << 16);
             }
             }
@@ -752,8 +752,9 @@ int32_t hs_trunk_bwd_parts(int64_t M) {
 
 int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void *H0, const void *W2t, const void *W1t, void *gA1, void *gA0,
                      float *gb1, float *gb0, const void *W0t, float *g_feat, float *g_dydx, int32_t L, int32_t C, float jac_scale, int64_t M,
-                     float *gb2, float *dW2_part, void *stream) {
-    if ((g_pitch != 32 && g_pitch != 64) || (M & 3)) return HS_ERR_ARG;
+                     float *gb2, float *dW2_part, int64_t ld, void *stream) {
+    if ((g_pitch != 32 && g_pitch != 64) || (M & 3) || (ld != 0 && ld < (M >> 2))) return HS_ERR_ARG;
+    if (ld == 0) ld = M >> 2;       /* points per level of the g_feat / g_dydx buffers (>= M / 4 when they hold more points than this call's) */
     if (M == 0) return HS_OK;
     if (W0t && (L < 1 || C < 1 || L * C != NFEAT)) return HS_ERR_ARG;
     if (!g || !H1 || !H0 || !W2t || !W1t || !gA1 || !gA0 || (W0t && (!g_feat || !g_dydx))) return HS_ERR_NULL;
@@ -765,12 +766,12 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
         static bool attr1 = false;
         if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part, ld);
     } else {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
-                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part);
+                                                      (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part, ld);
     }
     return check_launch();
 }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
                                                               const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f,
                                                               const uint16_t *__restrict__ W2f, const float *__restrict__ biasg, int d_out,
                                                               uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y,
-                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp) {
+                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
         Raw r;
         r.xs[0] = x[b * 3]; r.xs[1] = x[b * 3 + 1]; r.xs[2] = x[b * 3 + 2];
         // eight levels 8h..8h+7: features (value row, [B,32] point-major) or dy_dx[level][b][d][c] (tangent row d, [L,B,3C])
-        const float *fp = t == 0 ? feat + b * 32 + 16 * h : dydx + ((int64_t)(8 * h) * Bp + b) * 6 + 2 * (t - 1);
-        const int64_t fstride = t == 0 ? 2 : Bp * 6;
+        const float *fp = t == 0 ? feat + b * 32 + 16 * h : dydx + ((int64_t)(8 * h) * ld + b) * 6 + 2 * (t - 1);      // ld: points per level of dy_dx
+        const int64_t fstride = t == 0 ? 2 : ld * 6;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.f[i] = *reinterpret_cast<const float2 *>(fp + i * fstride);
         return r;
@@ -443,8 +443,9 @@ int32_t hs_trunk_mlp2_input_column(int32_t c) {
 }
 
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, void *stream) {
-    if (d_out < 1 || d_out > 32 || (M & 3)) return HS_ERR_ARG;
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, void *stream) {
+    if (d_out < 1 || d_out > 32 || (M & 3) || (ld != 0 && ld < (M >> 2))) return HS_ERR_ARG;
+    if (ld == 0) ld = M >> 2;
     if (M == 0) return HS_OK;
     if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !H0 || !H1 || (!Y && !split) || !Xp) return HS_ERR_NULL;
     hsTrunkSplit sp = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -468,10 +469,10 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     const int grid = (int)(want < 256 ? want : 256);
     if (split)
         k_trunk_fwd2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld);
     else
         k_trunk_fwd2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld);
     return wt_check_launch();
 }
 

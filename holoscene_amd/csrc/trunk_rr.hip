@@ -111,7 +111,7 @@ struct EFac {
     float pe[18];          // d (sin | cos)(f x_d) / d x_d of this lane's three octaves: f cos / -f sin  (one component each: column j <-> d = j % 3)
     float2 dy[8][3];       // jac_scale * dy_dx[level 8 hh + i][sample][d][c]
 };
-__device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const float *__restrict__ dydx, int64_t gp, int64_t n, int hh, float jac_scale, bool ok) {
+__device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const float *__restrict__ dydx, int64_t gp, int64_t ld, int hh, float jac_scale, bool ok) {
     EFac E;
     const int64_t b = ok ? gp : 0;
     const float xs[3] = {x[b * 3], x[b * 3 + 1], x[b * 3 + 2]};
@@ -126,12 +126,12 @@ __device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const flo
             E.pe[6 * k + 3 + d] = -f * sn;
         }
     }
-    const float *dp = dydx + ((size_t)(8 * hh) * n + b) * 6;
+    const float *dp = dydx + ((size_t)(8 * hh) * ld + b) * 6;
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const float2 t = *reinterpret_cast<const float2 *>(dp + (size_t)i * n * 6 + 2 * d);
+            const float2 t = *reinterpret_cast<const float2 *>(dp + (size_t)i * ld * 6 + 2 * d);
             E.dy[i][d] = make_float2(t.x * jac_scale, t.y * jac_scale);
         }
     return E;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                                                                const uint16_t *__restrict__ H1t, const uint16_t *__restrict__ U0t,
                                                                uint16_t *__restrict__ U0bt, uint16_t *__restrict__ A0pt, uint16_t *__restrict__ A1pt,
                                                                uint16_t *__restrict__ U1bt, uint16_t *__restrict__ UXb, float *__restrict__ g_dydx,
-                                                               float jac_scale, int64_t n) {
+                                                               float jac_scale, int64_t n, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
         const float g[3] = {ok ? g_grad[b * 3] : 0.f, ok ? g_grad[b * 3 + 1] : 0.f, ok ? g_grad[b * 3 + 2] : 0.f};
         uint32_t hin[4 * K0S];
         {
-            const EFac E = load_efac(x, dydx, gp, n, h, jac_scale, ok);
+            const EFac E = load_efac(x, dydx, gp, ld, h, jac_scale, ok);
             float v[40];
 #pragma unroll
             for (int j = 0; j < 18; j++) v[j] = E.pe[j] * g[j % 3];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                 for (int i = 0; i < 4; i++) { const float4 t = up[i]; u[4 * i] = t.x; u[4 * i + 1] = t.y; u[4 * i + 2] = t.z; u[4 * i + 3] = t.w; }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    float2 *dp = reinterpret_cast<float2 *>(g_dydx + ((size_t)(8 * h + i) * n + gp) * 6);
+                    float2 *dp = reinterpret_cast<float2 *>(g_dydx + ((size_t)(8 * h + i) * ld + gp) * 6);
 #pragma unroll
                     for (int d = 0; d < 3; d++) dp[d] = make_float2(jac_scale * u[2 * i] * g[d], jac_scale * u[2 * i + 1] * g[d]);
                 }
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
                                                                const uint16_t *__restrict__ W0Tf, const uint16_t *__restrict__ H0t,
                                                                const uint16_t *__restrict__ H1t, uint16_t *__restrict__ U0t, uint16_t *__restrict__ V1t,
                                                                uint16_t *__restrict__ V0t, float *__restrict__ grad, float *__restrict__ uxh,
-                                                               float jac_scale, int64_t n) {
+                                                               float jac_scale, int64_t n, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 31, h = lane >> 5;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
         });
         // ---- d min / dx = E^T ux over this half's 37 columns, the other half's share by one shuffle; the hash columns of ux are kept
         //      for the backward pass (cotangent of dy_dx)
-        const EFac E = load_efac(x, dydx, gp, n, h, jac_scale, ok);
+        const EFac E = load_efac(x, dydx, gp, ld, h, jac_scale, ok);
         float gd[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 18; j++) gd[j % 3] += E.pe[j] * HS_SLOT(o0, o1, o2, j);
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
                                                                 const uint16_t *__restrict__ H0t, const uint16_t *__restrict__ H1t,
                                                                 const uint16_t *__restrict__ A0pt, const uint16_t *__restrict__ A1pt,
                                                                 uint16_t *__restrict__ A0t, uint16_t *__restrict__ A1t, float *__restrict__ g_feat,
-                                                                int64_t n) {
+                                                                int64_t n, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
         if (ok) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                *reinterpret_cast<float2 *>(g_feat + ((size_t)(8 * h + i) * n + gp) * 2) = make_float2(HS_SLOT(o0, o1, o2, 18 + 2 * i), HS_SLOT(o0, o1, o2, 19 + 2 * i));
+                *reinterpret_cast<float2 *>(g_feat + ((size_t)(8 * h + i) * ld + gp) * 2) = make_float2(HS_SLOT(o0, o1, o2, 18 + 2 * i), HS_SLOT(o0, o1, o2, 19 + 2 * i));
         }
     }
     if (!resident) {
@@ -731,21 +731,25 @@ int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, co
 }
 
 int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
-                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, void *stream) {
+                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld, void *stream) {
     if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
     if (!x || !dydx || !idx || !W2tab || !W1Tf || !W0Tf || !H0t || !H1t || !U0t || !V1t || !V0t || !grad || !uxh) return HS_ERR_NULL;
     const size_t lds = (size_t)kW1F * sizeof(uint16_t);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     k_rr_fwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, idx, W2tab, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, (const uint16_t *)H0t,
-                                                                   (const uint16_t *)H1t, (uint16_t *)U0t, (uint16_t *)V1t, (uint16_t *)V0t, grad, uxh, jac_scale, n);
+                                                                   (const uint16_t *)H1t, (uint16_t *)U0t, (uint16_t *)V1t, (uint16_t *)V0t, grad, uxh, jac_scale, n, ld);
     return wt_check_launch();
 }
 
 int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad, const float *uxh, const int64_t *idx, const float *W2tab, const void *W0f,
                          const void *W1f, const void *H0t, const void *H1t, const void *U0t, void *U0bt, void *A0pt, void *A1pt, void *U1bt, void *UXb,
-                         float *g_dydx, float jac_scale, int64_t n, void *stream) {
+                         float *g_dydx, float jac_scale, int64_t n, int64_t ld, void *stream) {
     if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
     if (!x || !dydx || !g_grad || !uxh || !idx || !W2tab || !W0f || !W1f || !H0t || !H1t || !U0t || !U0bt || !A0pt || !A1pt || !U1bt || !UXb || !g_dydx)
         return HS_ERR_NULL;
     const size_t lds = (size_t)kW1F * sizeof(uint16_t);
@@ -753,13 +757,15 @@ int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad,
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_bwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     k_rr_bwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, g_grad, uxh, idx, W2tab, (const uint16_t *)W0f, (const uint16_t *)W1f,
                                                                    (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)U0t, (uint16_t *)U0bt,
-                                                                   (uint16_t *)A0pt, (uint16_t *)A1pt, (uint16_t *)U1bt, (uint16_t *)UXb, g_dydx, jac_scale, n);
+                                                                   (uint16_t *)A0pt, (uint16_t *)A1pt, (uint16_t *)U1bt, (uint16_t *)UXb, g_dydx, jac_scale, n, ld);
     return wt_check_launch();
 }
 
 int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t, const void *A0pt,
-                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, void *stream) {
+                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, int64_t ld, void *stream) {
     if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
     if (!gy || !W2Tf || !W1Tf || !W0Tf || !H0t || !H1t || !A0t || !A1t || !g_feat || (!A0pt) != (!A1pt)) return HS_ERR_NULL;
     const size_t lds = (size_t)(kW1F + kW2TF) * sizeof(uint16_t);
     static bool attr = false;
@@ -771,11 +777,11 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
     if (A0pt)
         k_rr_bwd_value<true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
                                                                               (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)A0pt, (const uint16_t *)A1pt,
-                                                                              (uint16_t *)A0t, (uint16_t *)A1t, g_feat, n);
+                                                                              (uint16_t *)A0t, (uint16_t *)A1t, g_feat, n, ld);
     else
         k_rr_bwd_value<false><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
                                                                                (const uint16_t *)H0t, (const uint16_t *)H1t, nullptr, nullptr, (uint16_t *)A0t, (uint16_t *)A1t,
-                                                                               g_feat, n);
+                                                                               g_feat, n, ld);
     return wt_check_launch();
 }
 

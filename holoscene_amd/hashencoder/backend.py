@@ -125,6 +125,12 @@ def _dev(t, name, dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _dev_at(t, name, elem_offset, dtype=torch.float32):
+    """_dev(t) advanced by elem_offset elements (a sub-range of a level-major buffer: the kernels take a level stride `ld`)."""
+    p = _dev(t, name, dtype)
+    return None if p is None else ctypes.c_void_p(p.value + int(elem_offset) * t.element_size())
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -453,9 +459,9 @@ class _HipBackend:
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
 
     @staticmethod
-    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None):
+    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None, ld=0, off=0):
         """split = (n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta): the kernel writes hs_trunk_split_fwd's outputs itself and
-        Y (then None) is never stored."""
+        Y (then None) is never stored.  ld / off: dydx is a [L, ld, 6] buffer whose points [off, off + M / 4) are this call's."""
         lib = load_library()
         bf = torch.bfloat16
         W0f, W1f, W2f, bias = packed
@@ -465,10 +471,10 @@ class _HipBackend:
             opt = lambda t, name, dt=torch.float32: _dev(t, name, dt).value if t is not None and t.numel() else None   # noqa: E731
             sp = hsTrunkSplit(int(n_main), opt(sdf_raw, "sdf_raw"), opt(sdf, "sdf"), _dev(idx, "idx", torch.int64).value, opt(grad, "grad"),
                               opt(y_eik, "y_eik"), opt(min_eik, "min_eik"), opt(gtheta, "grad_theta"))
-        _check(lib.hs_trunk_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
+        _check(lib.hs_trunk_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev_at(dydx, "dydx", off * 6), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
                                      _dev(bias, "bias"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y") if Y is not None else None,
                                      _dev(Xp, "Xp", bf), ctypes.c_int64(H0.shape[0]), ctypes.c_float(jac_scale),
-                                     ctypes.byref(sp) if sp is not None else None, _stream()), "hs_trunk_mlp2_fwd")
+                                     ctypes.byref(sp) if sp is not None else None, ctypes.c_int64(ld), _stream()), "hs_trunk_mlp2_fwd")
 
     @staticmethod
     def trunk_mlp2_columns():
@@ -578,34 +584,34 @@ class _HipBackend:
                                          _dev(idx, "idx", torch.int64), _dev(onehot, "onehot", bf), ctypes.c_int64(x.shape[0]), _stream()), "hs_trunk_rr_fwd_value")
 
     @staticmethod
-    def trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac_scale):
+    def trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac_scale, ld=0):
         lib = load_library()
         bf = torch.bfloat16
         W1Tf, W0Tf, _, W2tab = rr
         _check(lib.hs_trunk_rr_fwd_grad(_dev(x, "x"), _dev(dydx, "dydx"), _dev(idx, "idx", torch.int64), _dev(W2tab, "W2tab"), _dev(W1Tf, "W1Tf", bf),
                                         _dev(W0Tf, "W0Tf", bf), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(U0t, "U0t", bf), _dev(V1t, "V1t", bf),
                                         _dev(V0t, "V0t", bf), _dev(grad, "grad"), _dev(uxh, "uxh"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]),
-                                        _stream()), "hs_trunk_rr_fwd_grad")
+                                        ctypes.c_int64(ld), _stream()), "hs_trunk_rr_fwd_grad")
 
     @staticmethod
-    def trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac_scale):
+    def trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac_scale, ld=0):
         lib = load_library()
         bf = torch.bfloat16
         W0f, W1f, _, _ = packed
         _check(lib.hs_trunk_rr_bwd_grad(_dev(x, "x"), _dev(dydx, "dydx"), _dev(g_grad, "g_grad"), _dev(uxh, "uxh"), _dev(idx, "idx", torch.int64),
                                         _dev(rr[3], "W2tab"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf),
                                         _dev(U0t, "U0t", bf), _dev(U0bt, "U0bt", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(U1bt, "U1bt", bf),
-                                        _dev(UXb, "UXb", bf), _dev(g_dydx, "g_dydx"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]), _stream()),
-               "hs_trunk_rr_bwd_grad")
+                                        _dev(UXb, "UXb", bf), _dev(g_dydx, "g_dydx"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]), ctypes.c_int64(ld),
+                                        _stream()), "hs_trunk_rr_bwd_grad")
 
     @staticmethod
-    def trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n):
+    def trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=0):
         lib = load_library()
         bf = torch.bfloat16
         W1Tf, W0Tf, W2Tf, _ = rr
         _check(lib.hs_trunk_rr_bwd_value(_dev(gy, "gy", bf), _dev(W2Tf, "W2Tf", bf), _dev(W1Tf, "W1Tf", bf), _dev(W0Tf, "W0Tf", bf), _dev(H0t, "H0t", bf),
                                          _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf), _dev(A1t, "A1t", bf),
-                                         _dev(g_feat, "g_feat"), ctypes.c_int64(n), _stream()), "hs_trunk_rr_bwd_value")
+                                         _dev(g_feat, "g_feat"), ctypes.c_int64(n), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_bwd_value")
 
     WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2}
 
@@ -741,16 +747,18 @@ class _HipBackend:
 
     @staticmethod
     def trunk_mlp_bwd(g, H1, H0, W2t, W1t, gA1, gA0, gb1, gb0, W0t=None, g_feat=None, g_dydx=None, L=0, C=0, jac_scale=0.0, gb2=None,
-                      dW2_part=None):
-        """dW2_part: optional fp32 [trunk_bwd_parts(M), g.shape[1], 256] receiving per-workgroup slices of g^T . H1."""
+                      dW2_part=None, ld=0, off=0):
+        """dW2_part: optional fp32 [trunk_bwd_parts(M), g.shape[1], 256] receiving per-workgroup slices of g^T . H1.
+        ld / off: g_feat / g_dydx are [L, ld, .] buffers whose points [off, off + M / 4) this call writes."""
         lib = load_library()
         bf = torch.bfloat16
         if dW2_part is not None and tuple(dW2_part.shape) != (_HipBackend.trunk_bwd_parts(g.shape[0]), g.shape[-1], 256):
             raise RuntimeError("trunk_mlp_bwd: dW2_part has the wrong shape")
         _check(lib.hs_trunk_mlp_bwd(_dev(g, "g", bf), g.shape[-1], _dev(H1, "H1", bf), _dev(H0, "H0", bf), _dev(W2t, "W2t", bf),
                                     _dev(W1t, "W1t", bf), _dev(gA1, "gA1", bf), _dev(gA0, "gA0", bf), _dev(gb1, "gb1"), _dev(gb0, "gb0"),
-                                    _dev(W0t, "W0t", bf), _dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), L, C, ctypes.c_float(jac_scale),
-                                    ctypes.c_int64(g.shape[0]), _dev(gb2, "gb2"), _dev(dW2_part, "dW2_part"), _stream()), "hs_trunk_mlp_bwd")
+                                    _dev(W0t, "W0t", bf), _dev_at(g_feat, "g_feat", off * C), _dev_at(g_dydx, "g_dydx", off * 3 * C), L, C,
+                                    ctypes.c_float(jac_scale), ctypes.c_int64(g.shape[0]), _dev(gb2, "gb2"), _dev(dW2_part, "dW2_part"),
+                                    ctypes.c_int64(ld), _stream()), "hs_trunk_mlp_bwd")
 
     @staticmethod
     def trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta):

@@ -415,24 +415,26 @@ def _tp_colsum(T):
     return t.permute(0, 2, 1, 3).reshape(256)                    # neuron = 16 s + 8 (e >> 2) + 4 h + (e & 3)
 
 
-class _rr_trunk_main(torch.autograd.Function):
-    """The trunk of the rendered samples, reverse-over-reverse (module docstring of csrc/trunk_rr.hip): x [n,3] (constant), hash table and
-    the three effective weight matrices / biases -> sdf_raw [n,K], sdf [n,1] (min over objects), idx [n,1] (arg-min), gradients [n,3]
-    (d min / dx) -- the first four outputs of _fused_trunk_render, same values, a quarter of the rows in every kernel."""
+class _trunk_render_rr(torch.autograd.Function):
+    """_fused_trunk_render with the n_main rendered samples on the reverse-over-reverse kernels (csrc/trunk_rr.hip: rows are samples) and
+    the Eikonal points, which need all K gradients, on the value+Jacobian ones (4 rows per point) -- ONE hash gather for all points in the
+    forward, ONE table scatter in the backward (both kernel families read / write their own point range of the level-major buffers
+    through a level stride).  Same seven outputs, same values."""
 
     @staticmethod
-    def forward(ctx, x, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
+    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
         ctx.set_materialize_grads(False)
         be = _be._backend
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
         x = x.contiguous().float()
         if x01 is None:
             x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
-        n, dev, bf = x.shape[0], x.device, torch.bfloat16
+        B, n, dev, bf = x.shape[0], int(n_main), x.device, torch.bfloat16
+        Be = B - n
         L, C, K = offsets.shape[0] - 1, embeddings.shape[1], W2.shape[0]
-        feat = torch.empty(n, L * C, device=dev)
-        dydx = torch.empty(L, n, 3 * C, device=dev)
-        be.fwd(x01, embeddings, offsets, feat, n, 3, C, L, S, Hres, dydx)
+        feat = torch.empty(B, L * C, device=dev)
+        dydx = torch.empty(L, B, 3 * C, device=dev)
+        be.fwd(x01, embeddings, offsets, feat, B, 3, C, L, S, Hres, dydx)
         jac = 0.5 / divide_factor
         f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
         packed = be.sdf_mlp2_pack(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2, b2.detach().float().contiguous(), K,
@@ -442,86 +444,115 @@ class _rr_trunk_main(torch.autograd.Function):
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
         Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty(n, 32, device=dev, dtype=bf)
-        sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(n, 1, device=dev, dtype=torch.int64)
+        sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(B, 1, device=dev, dtype=torch.int64)
         grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
-        be.trunk_rr_fwd_value(x, feat, packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot)
-        be.trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac)
-        if ctx.needs_input_grad[1]:
+        be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
+        be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
+        y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
+        eik = ()
+        if Be > 0:      # value + three tangent rows per Eikonal point (csrc/trunk_mlp2.hip), same weight images
+            Me = 4 * Be
+            H0e, H1e, Xpe = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 80, device=dev, dtype=bf)
+            w1t, w2t, w0t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 32, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)
+            be.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, K, True), (f0, w0t, 0, 0, W0.shape[1], 256, True)])
+            be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
+                              split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n)
+            eik = (H0e, H1e, Xpe, w0t, w1t, w2t)
+        if ctx.needs_input_grad[2]:
             _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr)
-        ctx.cfg = (n, L, C, K, S, Hres, jac)
+        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik)
+        ctx.cfg = (B, n, L, C, K, S, Hres, jac, W0.shape[1])
         ctx.mark_non_differentiable(idx)
-        return sdf_raw, sdf, idx, grad
+        return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
 
     @staticmethod
-    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad):
+    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_mineik, g_theta):
         be = _be._backend
-        x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, W0f, W1f, W2f, bias, W1Tf, W0Tf, W2Tf, W2tab = ctx.saved_tensors
+        sv = ctx.saved_tensors
+        x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, W0f, W1f, W2f, bias, W1Tf, W0Tf, W2Tf, W2tab = sv[:22]
         packed, rr = (W0f, W1f, W2f, bias), (W1Tf, W0Tf, W2Tf, W2tab)
-        n, L, C, K, S, Hres, jac = ctx.cfg
+        B, n, L, C, K, S, Hres, jac, F_in = ctx.cfg
+        Be = B - n
         dev, bf = x.device, torch.bfloat16
+        need_table, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[7]
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g_feat = torch.empty(L, B, C, device=dev)
+        g_dydx = torch.empty(L, B, 3 * C, device=dev)
+        # ---- rendered samples: cotangent of the K outputs with the minimum's folded in at its index, then the two rr kernels
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
-        # cotangent of the K outputs, the minimum's folded in at its index
         gy32 = torch.zeros(n, 32, device=dev)
         if g_raw is not None:
             gy32[:, :K] = g_raw
         if g_sdf is not None:
-            gy32.scatter_add_(1, idx, g_sdf.reshape(n, 1).float())
+            gy32.scatter_add_(1, idx[:n], g_sdf.reshape(n, 1).float())
         gy = gy32.to(bf)
-        need_table, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[6]
         A0t, A1t = tp(), tp()
-        g_feat = torch.empty(L, n, C, device=dev)
-        g_dydx = None
-        if g_grad is not None:
+        second = g_grad is not None
+        if second:
             U0bt, A0pt, A1pt, U1bt = tp(), tp(), tp(), tp()
             UXb = torch.empty(n, 80, device=dev, dtype=bf)
-            g_dydx = torch.empty(L, n, 3 * C, device=dev)
-            be.trunk_rr_bwd_grad(x, dydx, g_grad.contiguous().float(), uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac)
-            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n)
+            be.trunk_rr_bwd_grad(x[:n], dydx, c(g_grad), uxh, idx[:n], rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac, ld=B)
+            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
         else:
-            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n)
+            g_dydx[:, :n].zero_()
+            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
         gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
+        stacks = []
         if need_w:
             s1, s0, s2 = _rr_slices(n)
-            second = g_grad is not None
-            parts = be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
-                                    ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                                    ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)], n)
-            gW1, gW0p, gW2p = be.sum_slices(parts)
-            gW0 = gW0p[:, :80].index_select(1, _xp_columns(dev))
-            gW2 = gW2p[:K]
+            stacks = be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
+                                     ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
+                                     ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)], n)
             gb0, gb1, gb2 = _tp_colsum(A0t), _tp_colsum(A1t), gy32.sum(0)[:K]
+        # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
+        eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
+        e_parts, eW = [], None
+        if eik_live:
+            H0e, H1e, Xpe, w0t, w1t, w2t = sv[22:]
+            Me = 4 * Be
+            g_img = torch.empty(Me, 32, device=dev, dtype=bf)
+            be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
+            gA1, gA0 = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf)
+            gbz = torch.zeros(2 * 256 + 32, device=dev)
+            w2_part = torch.empty(be.trunk_bwd_parts(Me), 32, 256, device=dev) if need_w else None
+            be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,
+                             gb2=gbz[512:] if need_w else None, dW2_part=w2_part, ld=B, off=n)
+            if need_w:
+                eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])      # dW1, dW0 (80 own-order columns), dW2 [32, 256]
+        elif Be > 0:
+            g_feat[:, n:].zero_()
+            g_dydx[:, n:].zero_()
+        if need_w:
+            gW1, gW0p, gW2p = be.sum_slices(stacks)
+            gW0p = gW0p[:, :80]
+            if eW is not None:
+                gW1, gW0p, gW2p = gW1 + eW[0], gW0p + eW[1], gW2p + eW[2]
+                gb1, gb0, gb2 = gb1 + gbz[:256], gb0 + gbz[256:512], gb2 + gbz[512:512 + K]
+            gW0 = gW0p.index_select(1, _xp_columns(dev))
+            gW2 = gW2p[:K]
         g_emb = None
-        if need_table:
+        if need_table:      # one value+Jacobian scatter for all B points
             table = ctx.table
             inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, n, 3, C, L, S, Hres,
-                       ws=be.scatter_workspace(n, 3, C, L, dev) if n >= _BIN_MIN_POINTS else None, level_major=True)
+            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, 3, C, L, S, Hres,
+                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
             if inplace:
                 _be.scatter_done(table)
             g_emb = None if inplace else target
-        return None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
+        return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
 
 def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
-    """_fused_trunk_render's seven outputs.  TRUNK_MODE == "rr": the n_main rendered samples through the reverse-over-reverse kernels,
-    the Eikonal points (all K gradients) through the value+Jacobian ones; otherwise everything through the latter."""
-    B, K = x.shape[0], W2.shape[0]
-    if not (TRUNK_MODE == "rr" and n_main > 0 and K <= 32 and nfreq == 6 and offsets.shape[0] - 1 == 16 and embeddings.shape[1] == 2
-            and W0.shape[1] == 71):
-        if TRUNK_MODE not in ("rr", "jac"):
-            raise RuntimeError(f"unknown HOLOSCENE_TRUNK_MODE={TRUNK_MODE!r}")
-        return _fused_trunk_render.apply(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
-    sdf_raw, sdf, idx, grad = _rr_trunk_main.apply(x[:n_main], embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2,
-                                                   None if x01 is None else x01[:n_main])
-    if B == n_main:
-        empty = torch.empty(0, device=x.device)
-        return sdf_raw, sdf, idx, grad, empty.reshape(0, K), empty.reshape(0, 1), empty.reshape(0, 3)
-    _, _, idx_e, _, y_eik, min_eik, gtheta = _fused_trunk_render.apply(x[n_main:], 0, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1,
-                                                                      W2, b2, None if x01 is None else x01[n_main:])
-    return sdf_raw, sdf, torch.cat([idx, idx_e], 0), grad, y_eik, min_eik, gtheta
+    """_fused_trunk_render's seven outputs; TRUNK_MODE == "rr" (and the stock shapes): the rendered samples through the
+    reverse-over-reverse kernels (_trunk_render_rr)."""
+    K = W2.shape[0]
+    if TRUNK_MODE == "rr" and n_main > 0 and K <= 32 and nfreq == 6 and offsets.shape[0] - 1 == 16 and embeddings.shape[1] == 2 and W0.shape[1] == 71:
+        return _trunk_render_rr.apply(x, n_main, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01)
+    if TRUNK_MODE not in ("rr", "jac"):
+        raise RuntimeError(f"unknown HOLOSCENE_TRUNK_MODE={TRUNK_MODE!r}")
+    return _fused_trunk_render.apply(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
 
 
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in

@@ -348,8 +348,9 @@ typedef struct hsTrunkSplit {
     float *grad_theta;     /* [(K+1) Be, 3] */
 } hsTrunkSplit;
 int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
+/* (hs_trunk_mlp2_fwd: ld = points per level of dydx; 0 = M / 4) */
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, void *stream);
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, void *stream);
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);
@@ -380,6 +381,7 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
                      int64_t M, float *gb2 /* [g_pitch] fp32 (+=): column sums of g's value rows = last layer's bias gradient, or NULL */,
                      float *dW2_part /* NULL, or [hs_trunk_bwd_parts(M), g_pitch, 256] fp32: per-workgroup slices of the last layer's weight
                                         gradient g^T . H1 (sum them with hs_sum_slices, src_f32 = 1; rows >= d_out are zero) */,
+                     int64_t ld /* points per level of the g_feat / g_dydx buffers; 0 = M / 4 (> M / 4: the buffers also hold other points) */,
                      void *stream);
 int32_t hs_trunk_bwd_parts(int64_t M);   /* number of slices hs_trunk_mlp_bwd writes into dW2_part */
 
@@ -507,12 +509,12 @@ int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float 
 int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                           void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
 int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
-                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, void *stream);
+                         const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld, void *stream);
 int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad, const float *uxh, const int64_t *idx, const float *W2tab, const void *W0f,
                          const void *W1f, const void *H0t, const void *H1t, const void *U0t, void *U0bt, void *A0pt, void *A1pt, void *U1bt, void *UXb,
-                         float *g_dydx, float jac_scale, int64_t n, void *stream);
+                         float *g_dydx, float jac_scale, int64_t n, int64_t ld, void *stream);
 int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t, const void *A0pt,
-                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, void *stream);
+                          const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, int64_t ld, void *stream);
 
 /* Weight gradients of that formulation: part[slice] = sum over the job's one or two operand pairs of A^T B over the slice's rows
  * (csrc/wgrad_pairs.hip).  kind: HS_WGP_256x256 (A, B tile-packed), HS_WGP_256x80 (A tile-packed, B row-major [rows, 80]; result
