@@ -190,11 +190,13 @@ def _work_rr_bwd_value(a, k):
 def _work_wgrad_pairs(a, k):
     fl = by = 0
     n = a[1]
-    for (NA, W), _s, p0, p1 in a[0]:
+    for job in a[0]:
+        (NA, W), p0, p1 = job[0][:2], job[2], job[3]
+        rows = job[4] if len(job) > 4 else n
         for pr in (p0, p1):
             if pr is not None:
-                fl += 2 * n * NA * W
-                by += n * (NA + W) * 2
+                fl += 2 * rows * NA * W
+                by += rows * (NA + W) * 2
     return fl, by
 
 

@@ -137,9 +137,54 @@ __device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const flo
     return E;
 }
 
+// ================================================================================================================ tile machinery
+// One PHASE = the k-steps of ONE 32-neuron tile (one accumulator) with, in their shadow, slices of the previous tile's epilogue -- the
+// single-tile form of wave_tile.h's phase2: half the accumulator and epilogue-staging registers of a quarter phase.  These kernels move
+// 0.3-0.4 GB each for ~20 GFLOP: what they need registers for is loads in flight, not MFMA operands (a quarter-phase version spilled 40-80
+// registers and ran at 1.5-3 TB/s).  A fragments `frag(s)` travel AHEAD k-steps in front of their MFMA.
+template <int KS, int AHEAD, int E, int NSL, bool EPI, bool ZERO_C, class FragFn, class EpiFn>
+__device__ __forceinline__ void phase1r(f32x16 &cur, const uint32_t *bin, FragFn frag, EpiFn epi) {
+    bf16x8 ring[AHEAD + 1];
+    static_for<(AHEAD < KS ? AHEAD : KS)>([&](auto sc) { constexpr int s = decltype(sc)::value; ring[s] = frag(s); });
+    static_for<KS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + AHEAD < KS) ring[(s + AHEAD) % (AHEAD + 1)] = frag(s + AHEAD);
+        const bf16x8 b = frag_of(bin + 4 * s);
+        if constexpr (ZERO_C && s == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)], b, zero, 0, 0, 0);
+        } else {
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % (AHEAD + 1)], b, cur, 0, 0, 0);
+        }
+        if constexpr (EPI && s < E) {
+            constexpr int lo = (s * NSL) / E, hi = ((s + 1) * NSL) / E;
+            static_for<hi - lo>([&](auto jc) { epi(std::integral_constant<int, lo + decltype(jc)::value>{}); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// the two TP pieces (k-steps 2 nt, 2 nt + 1) that hold tile nt's 8 words of this lane
+struct TilePair { uint4 a, b; };
+__device__ __forceinline__ TilePair tp_load_tile(const uint16_t *__restrict__ T, int64_t tile, int nt, int lane) {
+    TilePair r;
+    r.a = tp_load(T, tile, 2 * nt, lane);
+    r.b = tp_load(T, tile, 2 * nt + 1, lane);
+    return r;
+}
+// The loads of a phase's saved activations are `const __restrict__` and would otherwise be scheduled to the top of the tile (all 8 tiles of
+// two tensors = 128 registers in flight: 60-70 spills).  An index the compiler cannot see through, produced where the request belongs,
+// keeps each one there (volatile asm statements keep their order relative to the epilogues' anchors).
+__device__ __forceinline__ int64_t here(int64_t tile) {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return tile + z;
+}
+__device__ __forceinline__ uint32_t tile_word(const TilePair &t, int p) { return p < 4 ? word_of(t.a, p) : word_of(t.b, p - 4); }   // p = 0..7
+
 // ================================================================================================================ "down" kernels
 // ---------------------------------------------------------------------------------------------------------------- forward, values
-// sdf_mlp2.hip's structure with plain-domain Softplus; H0 / H1 leave tile-packed, the assembled inputs as Xp [n, 80] (trunk_mlp2.hip's column order)
+// sdf_mlp2.hip's function with plain-domain Softplus; H0 / H1 leave tile-packed, the assembled inputs as Xp [n, 80] (trunk_mlp2.hip's column order)
 __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
                                                                 const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
                                                                 const float *__restrict__ biasg, int d_out, uint16_t *__restrict__ H0t,
@@ -195,64 +240,61 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__re
             }
         }
         uint32_t h0p[64], h1p[64];
-        f32x16 acc[2][2];
-        // slices 0..15 of an epilogue: Softplus + pack of one register pair; 16..19: the four k-steps of the finished quarter leave as TP
-        auto epi = [&](auto slc, f32x16 (&src)[2], uint32_t *hp, int q_done, uint16_t *T) {
+        f32x16 acc[2];
+        // epilogue of finished tile nd: slices 0..7 Softplus + pack of one register pair, 8..9 its two k-steps leave as TP
+        auto epi = [&](auto slc, const f32x16 &src, uint32_t *hp, int nd, uint16_t *T) {
             constexpr int sl = decltype(slc)::value;
-            if constexpr (sl < 16) {
-                const int r = 2 * (sl & 7);
-                hp[16 * q_done + 8 * (sl >> 3) + (sl & 7)] = anchor(pack2(softplus100(src[sl >> 3][r]), softplus100(src[sl >> 3][r + 1])));
-            } else {
-                tp_store(T, tile, 4 * q_done + (sl - 16), lane, hp + 16 * q_done + 4 * (sl - 16), ok);
-            }
+            if constexpr (sl < 8) hp[8 * nd + sl] = anchor(pack2(softplus100(src[2 * sl]), softplus100(src[2 * sl + 1])));
+            else tp_store(T, tile, 2 * nd + (sl - 8), lane, hp + 8 * nd + 4 * (sl - 8), ok);
         };
         {
-            bf16x8 w0[2][2 * K0S];
+            bf16x8 w0[3][K0S];
             uint32_t zoff = 0;
             asm volatile("" : "+v"(zoff));
             const bf16x8 *W0q = W0v + zoff;
-#define HS_W0_FETCH(q) do { _Pragma("unroll") for (int s_ = 0; s_ < K0S; s_++) { \
-        w0[(q) & 1][2 * s_] = W0q[(size_t)(s_ * NT + 2 * (q)) * 64]; w0[(q) & 1][2 * s_ + 1] = W0q[(size_t)(s_ * NT + 2 * (q) + 1) * 64]; } } while (0)
-            HS_W0_FETCH(0);
-            static_for<4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                init_acc(acc[q & 1][0], bias + 32 * (2 * q), h);
-                init_acc(acc[q & 1][1], bias + 32 * (2 * q + 1), h);
-                if constexpr (q < 3) HS_W0_FETCH(q + 1);
-                auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
-                if constexpr (q == 0) phase2<K0S, 1, K0S, 20, false>(acc[0], hin, f0, [](auto) {});
-                else phase2<K0S, 1, K0S, 20, true>(acc[q & 1], hin, f0, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h0p, q - 1, H0t); });
+            static_for<K0S>([&](auto sc) { constexpr int s = decltype(sc)::value; w0[0][s] = W0q[(size_t)(s * NT + 0) * 64]; w0[1][s] = W0q[(size_t)(s * NT + 1) * 64]; });
+            static_for<NT>([&](auto nc) {
+                constexpr int nt = decltype(nc)::value;
+                init_acc(acc[nt & 1], bias + 32 * nt, h);
+                if constexpr (nt + 2 < NT)
+                    static_for<K0S>([&](auto sc) { constexpr int s = decltype(sc)::value; w0[(nt + 2) % 3][s] = W0q[(size_t)(s * NT + nt + 2) * 64]; });
+                auto f0 = [&](int s) { return w0[nt % 3][s]; };
+                if constexpr (nt == 0) phase1r<K0S, 0, K0S, 10, false, false>(acc[0], hin, f0, [](auto) {});
+                else phase1r<K0S, 0, K0S, 10, true, false>(acc[nt & 1], hin, f0, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], h0p, nt - 1, H0t); });
             });
-#undef HS_W0_FETCH
         }
         if (!resident) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             resident = true;
         }
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            init_acc(acc[q & 1][0], bias + 256 + 32 * (2 * q), h);
-            init_acc(acc[q & 1][1], bias + 256 + 32 * (2 * q + 1), h);
-            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
-            if constexpr (q == 0) phase2<HS, 2, 8, 20, true>(acc[0], h0p, f1, [&](auto slc) { epi(slc, acc[1], h0p, 3, H0t); });
-            else phase2<HS, 2, HS, 20, true>(acc[q & 1], h0p, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h1p, q - 1, H1t); });
+        static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            init_acc(acc[nt & 1], bias + 256 + 32 * nt, h);
+            auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
+            // tile 0 also finishes layer 0's last tile (its words are k-steps 14, 15 of this product) within the first 10 k-steps
+            if constexpr (nt == 0) phase1r<HS, 2, 10, 10, true, false>(acc[0], h0p, f1, [&](auto slc) { epi(slc, acc[1], h0p, 7, H0t); });
+            else phase1r<HS, 2, HS, 10, true, false>(acc[nt & 1], h0p, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], h1p, nt - 1, H1t); });
         });
         f32x16 y;
         {
-            f32x16 &y0 = acc[0][0], &y1 = acc[0][1];
-#pragma unroll
-            for (int i = 0; i < 16; i++) { y0[i] = 0.f; y1[i] = 0.f; }
+            // layer 1's tile 7 sits in acc[1]; layer 2 on two fresh partial accumulators (even / odd k-steps), tile 7's epilogue in the shadow of k-steps 0..9
+            f32x16 y0, y1;
             auto f2 = [&](int s, int j) { return W2v[(size_t)(2 * s + j) * 64]; };
             bf16x8 ring[3][2];
             static_for<2>([&](auto sc) { constexpr int s = decltype(sc)::value; ring[s][0] = f2(s, 0); ring[s][1] = f2(s, 1); });
             static_for<HS / 2>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (s + 2 < HS / 2) { ring[(s + 2) % 3][0] = f2(s + 2, 0); ring[(s + 2) % 3][1] = f2(s + 2, 1); }
-                if constexpr (s < 5)       // layer 1's last quarter (k-steps 12..15 of this product) in the shadow of k-steps 0..9
-                    static_for<4>([&](auto jc) { epi(std::integral_constant<int, 4 * s + decltype(jc)::value>{}, acc[1], h1p, 3, H1t); });
-                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][0], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
-                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                if constexpr (s < 5) static_for<2>([&](auto jc) { epi(std::integral_constant<int, 2 * s + decltype(jc)::value>{}, acc[1], h1p, 7, H1t); });
+                if constexpr (s == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][0], frag_of(h1p), zero, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][1], frag_of(h1p + 4), zero, 0, 0, 0);
+                } else {
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][0], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
 #pragma unroll
@@ -356,88 +398,72 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                 }
             }
         }
-        uint32_t u0p[64], scratch[16];
-        f32x16 acc[2][2];
-        // epilogue of layer 0's finished quarter qd: acc = v0~ ; u0~ = v0~ s0 (next product's input, and TP), a0' = v0~ u0 s0' (TP)
-        uint4 hw[4], uw[4];
-        auto load0 = [&](int qd) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { hw[i] = tp_load(H0t, tile, 4 * qd + i, lane); uw[i] = tp_load(U0t, tile, 4 * qd + i, lane); }
-        };
-        auto epi0 = [&](auto slc, f32x16 (&src)[2], int qd) {
+        uint32_t u0p[64], wa[8], wb[8];
+        f32x16 acc[2];
+        TilePair hw[2], uw[2];          // saved activations of the tile whose epilogue runs next / the one after (requested a phase ahead)
+        // layer 0, finished tile nd: acc = v0~ ; u0~ = v0~ s0 (next product's input, and TP), a0' = v0~ u0 s0' (TP)
+        auto epi0 = [&](auto slc, const f32x16 &src, int nd) {
             constexpr int sl = decltype(slc)::value;
-            if constexpr (sl < 16) {
-                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;                 // tile t of the quarter, word p of its 8-word block = k-step 2 t + (p >> 2)
-                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3), uwd = word_of(uw[2 * t + (p >> 2)], p & 3);
+            if constexpr (sl < 8) {
+                const uint32_t hwd = tile_word(hw[nd & 1], sl), uwd = tile_word(uw[nd & 1], sl);
                 const float sa = sig_of_h(lo_bf(hwd)), sb = sig_of_h(hi_bf(hwd));
-                const float va = src[t][r], vb = src[t][r + 1];
-                u0p[16 * qd + 8 * t + p] = anchor(pack2(va * sa, vb * sb));
-                scratch[8 * t + p] = anchor(pack2(va * lo_bf(uwd) * (100.f * sa * (1.f - sa)), vb * hi_bf(uwd) * (100.f * sb * (1.f - sb))));
-            } else if constexpr (sl < 20) {
-                tp_store(U0bt, tile, 4 * qd + (sl - 16), lane, u0p + 16 * qd + 4 * (sl - 16), ok);
+                const float va = src[2 * sl], vb = src[2 * sl + 1];
+                u0p[8 * nd + sl] = anchor(pack2(va * sa, vb * sb));
+                wa[sl] = anchor(pack2(va * lo_bf(uwd) * (100.f * sa * (1.f - sa)), vb * hi_bf(uwd) * (100.f * sb * (1.f - sb))));
+            } else if constexpr (sl < 10) {
+                tp_store(U0bt, tile, 2 * nd + (sl - 8), lane, u0p + 8 * nd + 4 * (sl - 8), ok);
             } else {
-                tp_store(A0pt, tile, 4 * qd + (sl - 20), lane, scratch + 4 * (sl - 20), ok);
+                tp_store(A0pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
             }
         };
         {
-            bf16x8 w0[2][2 * K0S];
+            bf16x8 w0[3][K0S];
             uint32_t zoff = 0;
             asm volatile("" : "+v"(zoff));
             const bf16x8 *W0q = W0v + zoff;
-#define HS_W0_FETCH(q) do { _Pragma("unroll") for (int s_ = 0; s_ < K0S; s_++) { \
-        w0[(q) & 1][2 * s_] = W0q[(size_t)(s_ * NT + 2 * (q)) * 64]; w0[(q) & 1][2 * s_ + 1] = W0q[(size_t)(s_ * NT + 2 * (q) + 1) * 64]; } } while (0)
-            HS_W0_FETCH(0);
-            static_for<4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                if constexpr (q < 3) HS_W0_FETCH(q + 1);
-                if constexpr (q > 0) load0(q - 1);
-                auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
-                if constexpr (q == 0) phase2<K0S, 1, K0S, 24, false, true>(acc[0], hin, f0, [](auto) {});
-                else phase2<K0S, 1, K0S, 24, true, true>(acc[q & 1], hin, f0, [&](auto slc) { epi0(slc, acc[(q & 1) ^ 1], q - 1); });
+            static_for<K0S>([&](auto sc) { constexpr int s = decltype(sc)::value; w0[0][s] = W0q[(size_t)(s * NT + 0) * 64]; w0[1][s] = W0q[(size_t)(s * NT + 1) * 64]; });
+            static_for<NT>([&](auto nc) {
+                constexpr int nt = decltype(nc)::value;
+                if constexpr (nt + 2 < NT)
+                    static_for<K0S>([&](auto sc) { constexpr int s = decltype(sc)::value; w0[(nt + 2) % 3][s] = W0q[(size_t)(s * NT + nt + 2) * 64]; });
+                // tile nt's saved activations are consumed by its epilogue in phase nt + 1 (buffer nt & 1; phase nt's epilogue reads the other one)
+                { const int64_t tl = here(tile); hw[nt & 1] = tp_load_tile(H0t, tl, nt, lane); uw[nt & 1] = tp_load_tile(U0t, tl, nt, lane); }
+                auto f0 = [&](int s) { return w0[nt % 3][s]; };
+                if constexpr (nt == 0) phase1r<K0S, 0, K0S, 12, false, true>(acc[0], hin, f0, [](auto) {});
+                else phase1r<K0S, 0, K0S, 12, true, true>(acc[nt & 1], hin, f0, [&](auto slc) { epi0(slc, acc[(nt & 1) ^ 1], nt - 1); });
             });
-#undef HS_W0_FETCH
         }
         if (!resident) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             resident = true;
         }
-        // epilogue of layer 1's finished quarter: acc = v1~ ; u1~ = v1~ s1 (TP), a1' = v1~ u1 s1' (TP), u1 = W2[k*] gathered
-        uint32_t s1w[16];
-        auto epi1 = [&](auto slc, f32x16 (&src)[2], int qd) {
+        // layer 1, finished tile nd: acc = v1~ ; u1~ = v1~ s1 (TP), a1' = v1~ u1 s1' (TP), u1 = W2[k*] gathered
+        TilePair h1w[2];
+        auto epi1 = [&](auto slc, const f32x16 &src, int nd) {
             constexpr int sl = decltype(slc)::value;
-            if constexpr (sl < 16) {
-                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
-                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
+            if constexpr (sl < 8) {
+                const uint32_t hwd = tile_word(h1w[nd & 1], sl);
                 const float sa = sig_of_h(lo_bf(hwd)), sb = sig_of_h(hi_bf(hwd));
-                const int nn = 32 * (2 * qd + t) + 8 * (r >> 2) + 4 * h + (r & 3);
+                const int nn = 32 * nd + 8 * (sl >> 1) + 4 * h + 2 * (sl & 1);
                 const float2 u1 = *reinterpret_cast<const float2 *>(W2tab + (size_t)bi * 256 + nn);
-                const float va = src[t][r], vb = src[t][r + 1];
-                s1w[8 * t + p] = anchor(pack2(va * sa, vb * sb));
-                scratch[8 * t + p] = anchor(pack2(va * u1.x * (100.f * sa * (1.f - sa)), vb * u1.y * (100.f * sb * (1.f - sb))));
-            } else if constexpr (sl < 20) {
-                tp_store(U1bt, tile, 4 * qd + (sl - 16), lane, s1w + 4 * (sl - 16), ok);
+                const float va = src[2 * sl], vb = src[2 * sl + 1];
+                wb[sl] = anchor(pack2(va * sa, vb * sb));
+                wa[sl] = anchor(pack2(va * u1.x * (100.f * sa * (1.f - sa)), vb * u1.y * (100.f * sb * (1.f - sb))));
+            } else if constexpr (sl < 10) {
+                tp_store(U1bt, tile, 2 * nd + (sl - 8), lane, wb + 4 * (sl - 8), ok);
             } else {
-                tp_store(A1pt, tile, 4 * qd + (sl - 20), lane, scratch + 4 * (sl - 20), ok);
+                tp_store(A1pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
             }
         };
-        auto load1 = [&](int qd) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) hw[i] = tp_load(H1t, tile, 4 * qd + i, lane);
-        };
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
-            if constexpr (q == 0) {
-                load0(3);
-                phase2<HS, 2, 8, 24, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 3); });
-            } else {
-                load1(q - 1);
-                phase2<HS, 2, HS, 24, true, true>(acc[q & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(q & 1) ^ 1], q - 1); });
-            }
+        static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
+            h1w[nt & 1] = tp_load_tile(H1t, here(tile), nt, lane);
+            if constexpr (nt == 0) phase1r<HS, 2, 10, 12, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 7); });
+            else phase1r<HS, 2, HS, 12, true, true>(acc[nt & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(nt & 1) ^ 1], nt - 1); });
         });
-        load1(3);
-        static_for<24>([&](auto slc) { epi1(slc, acc[1], 3); });
+        static_for<12>([&](auto slc) { epi1(slc, acc[1], 7); });
     }
     if (!resident) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -497,68 +523,71 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int bi = (int)idx[ok ? gp : 0];
-        // ---- v1 = W2[k*] * s1 in B-fragment order (k-step s: neurons 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3)
+        // ---- v1 = W2[k*] * s1 in B-fragment order (k-step s: neurons 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3); eight H1 pieces in flight
         uint32_t vin[64];
         {
             const float *wrow = W2tab + (size_t)bi * 256 + 4 * h;
+            static_for<2>([&](auto hc) {
+                constexpr int half = decltype(hc)::value;
+                uint4 hwv[8];
 #pragma unroll
-            for (int s = 0; s < HS; s++) {
-                const uint4 hw = tp_load(H1t, tile, s, lane);
-                const float4 ua = *reinterpret_cast<const float4 *>(wrow + 16 * s), ub = *reinterpret_cast<const float4 *>(wrow + 16 * s + 8);
-                vin[4 * s] = pack2(ua.x * sig_of_h(lo_bf(hw.x)), ua.y * sig_of_h(hi_bf(hw.x)));
-                vin[4 * s + 1] = pack2(ua.z * sig_of_h(lo_bf(hw.y)), ua.w * sig_of_h(hi_bf(hw.y)));
-                vin[4 * s + 2] = pack2(ub.x * sig_of_h(lo_bf(hw.z)), ub.y * sig_of_h(hi_bf(hw.z)));
-                vin[4 * s + 3] = pack2(ub.z * sig_of_h(lo_bf(hw.w)), ub.w * sig_of_h(hi_bf(hw.w)));
-                tp_store(V1t, tile, s, lane, vin + 4 * s, ok);
-            }
+                for (int i = 0; i < 8; i++) hwv[i] = tp_load(H1t, here(tile), 8 * half + i, lane);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int s = 8 * half + i;
+                    const uint4 hw = hwv[i];
+                    const float4 ua = *reinterpret_cast<const float4 *>(wrow + 16 * s), ub = *reinterpret_cast<const float4 *>(wrow + 16 * s + 8);
+                    vin[4 * s] = pack2(ua.x * sig_of_h(lo_bf(hw.x)), ua.y * sig_of_h(hi_bf(hw.x)));
+                    vin[4 * s + 1] = pack2(ua.z * sig_of_h(lo_bf(hw.y)), ua.w * sig_of_h(hi_bf(hw.y)));
+                    vin[4 * s + 2] = pack2(ub.x * sig_of_h(lo_bf(hw.z)), ub.y * sig_of_h(hi_bf(hw.z)));
+                    vin[4 * s + 3] = pack2(ub.z * sig_of_h(lo_bf(hw.w)), ub.w * sig_of_h(hi_bf(hw.w)));
+                    tp_store(V1t, tile, s, lane, vin + 4 * s, ok);
+                }
+            });
         }
         if (!resident) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             resident = true;
         }
-        uint32_t v0p[64], uw8[16];
-        f32x16 acc[2][2];
-        uint4 hw[4];
-        auto load0 = [&](int qd) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) hw[i] = tp_load(H0t, tile, 4 * qd + i, lane);
-        };
-        // finished quarter qd of u0 = W1^T v1: u0 leaves as TP, v0 = u0 s0 is the next product's input (and TP, for the weight gradient)
-        auto epi = [&](auto slc, f32x16 (&src)[2], int qd) {
+        uint32_t v0p[64], uw8[8];
+        f32x16 acc[2];
+        TilePair hw[2];
+        // finished tile nd of u0 = W1^T v1: u0 leaves as TP, v0 = u0 s0 is the next product's input (and TP, for the weight gradient)
+        auto epi = [&](auto slc, const f32x16 &src, int nd) {
             constexpr int sl = decltype(slc)::value;
-            if constexpr (sl < 16) {
-                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
-                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
-                const float ua = src[t][r], ub = src[t][r + 1];
-                uw8[8 * t + p] = anchor(pack2(ua, ub));
-                v0p[16 * qd + 8 * t + p] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
-            } else if constexpr (sl < 20) {
-                tp_store(U0t, tile, 4 * qd + (sl - 16), lane, uw8 + 4 * (sl - 16), ok);
+            if constexpr (sl < 8) {
+                const uint32_t hwd = tile_word(hw[nd & 1], sl);
+                const float ua = src[2 * sl], ub = src[2 * sl + 1];
+                uw8[sl] = anchor(pack2(ua, ub));
+                v0p[8 * nd + sl] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
+            } else if constexpr (sl < 10) {
+                tp_store(U0t, tile, 2 * nd + (sl - 8), lane, uw8 + 4 * (sl - 8), ok);
             } else {
-                tp_store(V0t, tile, 4 * qd + (sl - 20), lane, v0p + 16 * qd + 4 * (sl - 20), ok);
+                tp_store(V0t, tile, 2 * nd + (sl - 10), lane, v0p + 8 * nd + 4 * (sl - 10), ok);
             }
         };
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
-            if constexpr (q == 0) phase2<HS, 2, HS, 24, false, true>(acc[0], vin, f1, [](auto) {});
-            else {
-                load0(q - 1);
-                phase2<HS, 2, HS, 24, true, true>(acc[q & 1], vin, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], q - 1); });
-            }
+        static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
+            hw[nt & 1] = tp_load_tile(H0t, here(tile), nt, lane);        // consumed by tile nt's epilogue, in phase nt + 1
+            if constexpr (nt == 0) phase1r<HS, 2, HS, 12, false, true>(acc[0], vin, f1, [](auto) {});
+            else phase1r<HS, 2, HS, 12, true, true>(acc[nt & 1], vin, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], nt - 1); });
         });
-        // ---- ux = W0^T v0 (the last quarter's epilogue in the shadow of k-steps 0..7, which only need quarters 0..1)
-        load0(3);
-        f32x16 &o0 = acc[0][0], &o1 = acc[0][1];
-        f32x16 o2;
-        up_input_product<kUpAhead>(W0Tv, v0p, o0, o1, o2, [&](auto sc) {
+        // ---- ux = W0^T v0 (tile 7's epilogue -- k-steps 14, 15 of this product -- in the shadow of k-steps 0..11)
+        f32x16 &o0 = acc[0];
+        f32x16 o1, o2;
+        uint32_t zw = 0;
+        asm volatile("" : "+v"(zw));         // opaque zero: the (tile-invariant) fragment loads stay inside the tile loop, at this point
+        up_input_product<kUpAhead>(W0Tv + zw, v0p, o0, o1, o2, [&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if constexpr (s < 8) static_for<3>([&](auto jc) { epi(std::integral_constant<int, 3 * s + decltype(jc)::value>{}, acc[1], 3); });
+            if constexpr (s < 12) epi(sc, acc[1], 7);
         });
         // ---- d min / dx = E^T ux over this half's 37 columns, the other half's share by one shuffle; the hash columns of ux are kept
-        //      for the backward pass (cotangent of dy_dx)
-        const EFac E = load_efac(x, dydx, gp, ld, h, jac_scale, ok);
+        //      for the backward pass (cotangent of dy_dx).  (Opaque offset: the loads must not be hoisted above the products.)
+        int64_t gpo = gp;
+        asm volatile("" : "+v"(gpo));
+        const EFac E = load_efac(x, dydx, gpo, ld, h, jac_scale, ok);
         float gd[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 18; j++) gd[j % 3] += E.pe[j] * HS_SLOT(o0, o1, o2, j);
@@ -613,68 +642,63 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
             const uint4 b = ok ? *reinterpret_cast<const uint4 *>(gy + gp * 32 + 16 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
             gin[0] = a.x; gin[1] = a.y; gin[2] = a.z; gin[3] = a.w; gin[4] = b.x; gin[5] = b.y; gin[6] = b.z; gin[7] = b.w;
         }
+        uint32_t a1p[64], a0p[64];
+        f32x16 acc[2];
+        TilePair hw[2], pw[2];
+        auto load = [&](const uint16_t *H, const uint16_t *P, int nd) {
+            const int64_t tl = here(tile);
+            hw[nd & 1] = tp_load_tile(H, tl, nd, lane);
+            if constexpr (PRIME) pw[nd & 1] = tp_load_tile(P, tl, nd, lane);
+        };
+        // a~ = a' + h~ s for the finished tile nd: next product's input and TP (weight gradient)
+        auto epi = [&](auto slc, const f32x16 &src, uint32_t *ap, uint16_t *T, int nd) {
+            constexpr int sl = decltype(slc)::value;
+            if constexpr (sl < 8) {
+                const uint32_t hwd = tile_word(hw[nd & 1], sl);
+                float va = src[2 * sl] * sig_of_h(lo_bf(hwd)), vb = src[2 * sl + 1] * sig_of_h(hi_bf(hwd));
+                if constexpr (PRIME) {
+                    const uint32_t pwd = tile_word(pw[nd & 1], sl);
+                    va += lo_bf(pwd);
+                    vb += hi_bf(pwd);
+                }
+                ap[8 * nd + sl] = anchor(pack2(va, vb));
+            } else {
+                tp_store(T, tile, 2 * nd + (sl - 8), lane, ap + 8 * nd + 4 * (sl - 8), ok);
+            }
+        };
+        load(H1t, A1pt, 0);
+        load(H1t, A1pt, 1);
         if (!resident) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             resident = true;
         }
-        uint32_t a1p[64], a0p[64];
-        f32x16 acc[2][2];
-        uint4 hw[4], pw[4];
-        auto load = [&](const uint16_t *H, const uint16_t *P, int qd) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                hw[i] = tp_load(H, tile, 4 * qd + i, lane);
-                if constexpr (PRIME) pw[i] = tp_load(P, tile, 4 * qd + i, lane);
-            }
-        };
-        // a~ = a' + h~ s for the finished quarter qd: next product's input and TP (weight gradient)
-        auto epi = [&](auto slc, f32x16 (&src)[2], uint32_t *ap, uint16_t *T, int qd) {
-            constexpr int sl = decltype(slc)::value;
-            if constexpr (sl < 16) {
-                constexpr int t = sl >> 3, p = sl & 7, r = 2 * p;
-                const uint32_t hwd = word_of(hw[2 * t + (p >> 2)], p & 3);
-                float va = src[t][r] * sig_of_h(lo_bf(hwd)), vb = src[t][r + 1] * sig_of_h(hi_bf(hwd));
-                if constexpr (PRIME) {
-                    const uint32_t pwd = word_of(pw[2 * t + (p >> 2)], p & 3);
-                    va += lo_bf(pwd);
-                    vb += hi_bf(pwd);
-                }
-                ap[16 * qd + 8 * t + p] = anchor(pack2(va, vb));
-            } else {
-                tp_store(T, tile, 4 * qd + (sl - 16), lane, ap + 16 * qd + 4 * (sl - 16), ok);
-            }
-        };
-        // ---- h1~ = W2^T y~ (K = 32: two k-steps per tile), quarter by quarter, each followed by its epilogue
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            load(H1t, A1pt, q);
+        // ---- h1~ = W2^T y~ (K = 32: two k-steps per tile), tile by tile, each followed by its epilogue; saved activations two tiles ahead
+        static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 (&cur)[2] = acc[q & 1];
-            static_for<2>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(0 * NT + 2 * q + j) * 64], frag_of(gin), zero, 0, 0, 0);
-                cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(1 * NT + 2 * q + j) * 64], frag_of(gin + 4), cur[j], 0, 0, 0);
-            });
-            static_for<20>([&](auto slc) { epi(slc, cur, a1p, A1t, q); });
+            f32x16 &cur = acc[nt & 1];
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(0 * NT + nt) * 64], frag_of(gin), zero, 0, 0, 0);
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(1 * NT + nt) * 64], frag_of(gin + 4), cur, 0, 0, 0);
+            static_for<10>([&](auto slc) { epi(slc, cur, a1p, A1t, nt); });
+            if constexpr (nt + 2 < NT) load(H1t, A1pt, nt + 2);
         });
         // ---- h0~ = W1^T a1~
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
-            if constexpr (q == 0) phase2<HS, 2, HS, 20, false, true>(acc[0], a1p, f1, [](auto) {});
-            else {
-                load(H0t, A0pt, q - 1);
-                phase2<HS, 2, HS, 20, true, true>(acc[q & 1], a1p, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], a0p, A0t, q - 1); });
-            }
+        static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
+            load(H0t, A0pt, nt);        // consumed by tile nt's epilogue, in phase nt + 1
+            if constexpr (nt == 0) phase1r<HS, 2, HS, 10, false, true>(acc[0], a1p, f1, [](auto) {});
+            else phase1r<HS, 2, HS, 10, true, true>(acc[nt & 1], a1p, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], a0p, A0t, nt - 1); });
         });
-        // ---- xt~ = W0^T a0~; only the hash-feature slots are wanted (x is a constant): g_feat [L, n, 2], level-major
-        load(H0t, A0pt, 3);
-        f32x16 &o0 = acc[0][0], &o1 = acc[0][1];
-        f32x16 o2;
-        up_input_product<kUpAhead>(W0Tv, a0p, o0, o1, o2, [&](auto sc) {
+        // ---- xt~ = W0^T a0~; only the hash-feature slots are wanted (x is a constant): g_feat [L, ld, 2], level-major
+        f32x16 &o0 = acc[0];
+        f32x16 o1, o2;
+        uint32_t zw = 0;
+        asm volatile("" : "+v"(zw));         // opaque zero: the (tile-invariant) fragment loads stay inside the tile loop, at this point
+        up_input_product<kUpAhead>(W0Tv + zw, a0p, o0, o1, o2, [&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if constexpr (s < 10) static_for<2>([&](auto jc) { epi(std::integral_constant<int, 2 * s + decltype(jc)::value>{}, acc[1], a0p, A0t, 3); });
+            if constexpr (s < 10) epi(sc, acc[1], a0p, A0t, 7);
         });
         if (ok) {
 #pragma unroll
@@ -686,6 +710,28 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- output cotangent image
+// gy [n, 32] bf16 = g_raw (K columns, zero beyond) with the minimum's cotangent added at its index; gb2 [32] += its column sums (fp32)
+__global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
+                                               uint16_t *__restrict__ gy, float *__restrict__ gb2, int64_t n) {
+    __shared__ float colsum[32];
+    if (threadIdx.x < 32) colsum[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int col = threadIdx.x & 31, rsub = threadIdx.x >> 5;          // 8 rows per pass
+    float acc = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 8 + rsub; r < n; r += (int64_t)gridDim.x * 8) {
+        float v = (g_raw && col < K) ? g_raw[r * K + col] : 0.f;
+        if (g_sdf && (int)idx[r] == col) v += g_sdf[r];
+        acc += v;
+        const uint32_t u = __float_as_uint(v);
+        gy[r * 32 + col] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    atomicAdd(&colsum[col], acc);
+    __syncthreads();
+    if (threadIdx.x < 32 && gb2) unsafeAtomicAdd(gb2 + threadIdx.x, colsum[threadIdx.x]);
 }
 
 }  // namespace
@@ -714,6 +760,15 @@ int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float 
 static int rr_grid(int64_t n) {
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     return (int)(want < 256 ? want : 256);
+}
+
+int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2, int64_t n, void *stream) {
+    if (K < 1 || K > 32) return HS_ERR_ARG;
+    if (n == 0) return HS_OK;
+    if (!gy || (g_sdf && !idx)) return HS_ERR_NULL;
+    const int64_t want = (n + 63) / 64;
+    k_rr_gy<<<(int)(want < 1024 ? want : 1024), 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2, n);
+    return wt_check_launch();
 }
 
 int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,

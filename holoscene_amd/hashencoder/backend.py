@@ -104,7 +104,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs"]
 
 
@@ -560,6 +560,12 @@ class _HipBackend:
         return 32 * ((int(n) + 31) // 32)
 
     @staticmethod
+    def trunk_rr_gy(g_raw, g_sdf, idx, K, gy, gb2):
+        lib = load_library()
+        _check(lib.hs_trunk_rr_gy(_dev(g_raw, "g_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), int(K), _dev(gy, "gy", torch.bfloat16),
+                                  _dev(gb2, "gb2"), ctypes.c_int64(gy.shape[0]), _stream()), "hs_trunk_rr_gy")
+
+    @staticmethod
     def trunk_rr_pack(W0, W1, W2, d_out):
         """fp32 effective matrices -> (W1Tf, W0Tf, W2Tf, W2tab): fragment images of the transposed matrices + the fp32 gather table of W2."""
         lib = load_library()
@@ -613,24 +619,30 @@ class _HipBackend:
                                          _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf), _dev(A1t, "A1t", bf),
                                          _dev(g_feat, "g_feat"), ctypes.c_int64(n), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_bwd_value")
 
-    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2}
+    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2, (256, 256, "rm"): 3, (256, 80, "rm"): 4}
 
     @staticmethod
-    def wgrad_pairs(jobs, n):
-        """jobs: [((NA, W), slices, (A0, B0), (A1, B1) or None)] over n samples -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80),
-        all in one launch (csrc/wgrad_pairs.hip)."""
+    def wgrad_pairs(jobs, n, outs_into=None):
+        """jobs: [((NA, W[, "rm"]), slices, (A0, B0), (A1, B1) or None[, rows])] -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80), all
+        in one launch (csrc/wgrad_pairs.hip).  Tile-packed operands cover n samples; "rm" jobs (both operands row-major) name their own
+        row count (a multiple of 32 * slices).  outs_into: optional per-job destination tensors (e.g. slices of one stack, so that several
+        jobs' partials are summed together by one hs_sum_slices job)."""
         lib = load_library()
         bf = torch.bfloat16
-        M = _HipBackend.tp_rows(n)
         arr = (hsWgradPairJob * len(jobs))()
         outs = []
-        for a, (shape, slices, p0, p1) in zip(arr, jobs):
-            NA, W = shape
+        for a, job in zip(arr, jobs):
+            shape, slices, p0, p1 = job[:4]
+            rows = int(job[4]) if len(job) > 4 else int(n)
+            M = _HipBackend.tp_rows(rows)
+            NA, W = shape[:2]
             MB = 128 if W == 80 else W
-            part = torch.empty(slices, NA, MB, device=p0[0].device, dtype=bf)
+            part = outs_into[len(outs)] if outs_into is not None and outs_into[len(outs)] is not None else torch.empty(slices, NA, MB, device=p0[0].device, dtype=bf)
+            if tuple(part.shape) != (slices, NA, MB) or part.dtype != bf or not part.is_contiguous():
+                raise RuntimeError("wgrad_pairs: destination must be a contiguous bf16 [slices, NA, MB] tensor")
             a.A0, a.B0 = _dev(p0[0], "A0", bf).value, _dev(p0[1], "B0", bf).value
             a.A1, a.B1 = (_dev(p1[0], "A1", bf).value, _dev(p1[1], "B1", bf).value) if p1 is not None else (None, None)
-            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, int(n), _HipBackend.WGP_KINDS[shape], int(slices)
+            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[shape], int(slices)
             outs.append(part)
         _check(lib.hs_wgrad_pairs(arr, len(jobs), _stream()), "hs_wgrad_pairs")
         return outs

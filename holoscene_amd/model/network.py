@@ -398,21 +398,27 @@ class _fused_trunk_render(torch.autograd.Function):
 TRUNK_MODE = os.environ.get("HOLOSCENE_TRUNK_MODE", "rr")
 
 
-def _rr_slices(n):
+def _rr_slices(n, budget=256):
     """Row slices of the three weight-gradient jobs of an rr backward pass (csrc/wgrad_pairs.hip): a slice is a whole number of 32-row
-    tiles, the jobs together should fill the chip once (256 workgroups), the 256 x 256 job -- two tile-packed pairs, the most bytes --
-    gets the finest cut."""
+    tiles, the jobs together should fill the chip once (`budget` workgroups), the 256 x 256 job -- two tile-packed pairs, the most
+    bytes -- gets the finest cut."""
     tiles = (n + 31) // 32
-    divs = [d for d in range(1, min(tiles, 128) + 1) if tiles % d == 0]
+    divs = [d for d in range(1, min(tiles, budget // 2) + 1) if tiles % d == 0]
     fine = max(divs)
-    coarse = max(d for d in divs if d <= max(1, (256 - fine) // 2)) if fine < 256 else fine
+    coarse = max(d for d in divs if d <= max(1, (budget - fine) // 2))
     return fine, coarse, coarse
+
+
+def _rows_slices(rows, cap):
+    """Largest slice count <= cap that cuts `rows` row-major rows into whole 32-row tiles."""
+    tiles = rows // 32
+    return max(d for d in range(1, max(1, min(tiles, cap)) + 1) if tiles % d == 0)
 
 
 def _tp_colsum(T):
     """Column sums of a tile-packed activation tensor -> [256] fp32 in neuron order (bias gradients)."""
-    t = T.view(-1, 16, 2, 32, 2, 4).float().sum((0, 3))         # [s, h, e >> 2, e & 3]
-    return t.permute(0, 2, 1, 3).reshape(256)                    # neuron = 16 s + 8 (e >> 2) + 4 h + (e & 3)
+    t = T.view(-1, 16, 2, 32, 2, 4).sum((0, 3), dtype=torch.float32)       # [s, h, e >> 2, e & 3]; fp32 accumulation, no fp32 copy
+    return t.permute(0, 2, 1, 3).reshape(256)                               # neuron = 16 s + 8 (e >> 2) + 4 h + (e & 3)
 
 
 class _trunk_render_rr(torch.autograd.Function):
@@ -481,12 +487,9 @@ class _trunk_render_rr(torch.autograd.Function):
         # ---- rendered samples: cotangent of the K outputs with the minimum's folded in at its index, then the two rr kernels
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
-        gy32 = torch.zeros(n, 32, device=dev)
-        if g_raw is not None:
-            gy32[:, :K] = g_raw
-        if g_sdf is not None:
-            gy32.scatter_add_(1, idx[:n], g_sdf.reshape(n, 1).float())
-        gy = gy32.to(bf)
+        gy = torch.empty(n, 32, device=dev, dtype=bf)
+        gbz = torch.zeros(2 * 256 + 32, device=dev)         # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
+        be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gbz[512:] if need_w else None)
         A0t, A1t = tp(), tp()
         second = g_grad is not None
         if second:
@@ -497,38 +500,46 @@ class _trunk_render_rr(torch.autograd.Function):
         else:
             g_dydx[:, :n].zero_()
             be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
-        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
-        stacks = []
-        if need_w:
-            s1, s0, s2 = _rr_slices(n)
-            stacks = be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
-                                     ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                                     ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)], n)
-            gb0, gb1, gb2 = _tp_colsum(A0t), _tp_colsum(A1t), gy32.sum(0)[:K]
         # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
         eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
-        e_parts, eW = [], None
+        w2_part = None
+        eik_jobs = []
         if eik_live:
             H0e, H1e, Xpe, w0t, w1t, w2t = sv[22:]
             Me = 4 * Be
             g_img = torch.empty(Me, 32, device=dev, dtype=bf)
             be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
             gA1, gA0 = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf)
-            gbz = torch.zeros(2 * 256 + 32, device=dev)
             w2_part = torch.empty(be.trunk_bwd_parts(Me), 32, 256, device=dev) if need_w else None
             be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,
                              gb2=gbz[512:] if need_w else None, dW2_part=w2_part, ld=B, off=n)
-            if need_w:
-                eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])      # dW1, dW0 (80 own-order columns), dW2 [32, 256]
+            if need_w and Me % 32 == 0:
+                se = _rows_slices(Me, 16)
+                eik_jobs = [((256, 256, "rm"), se, (gA1, H0e), None, Me), ((256, 80, "rm"), se, (gA0, Xpe), None, Me)]
         elif Be > 0:
             g_feat[:, n:].zero_()
             g_dydx[:, n:].zero_()
-        if need_w:
-            gW1, gW0p, gW2p = be.sum_slices(stacks)
-            gW0p = gW0p[:, :80]
-            if eW is not None:
-                gW1, gW0p, gW2p = gW1 + eW[0], gW0p + eW[1], gW2p + eW[2]
-                gb1, gb0, gb2 = gb1 + gbz[:256], gb0 + gbz[256:512], gb2 + gbz[512:512 + K]
+        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
+        if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
+            s1, s0, s2 = _rr_slices(n, 256 - sum(j[1] for j in eik_jobs))
+            se = eik_jobs[0][1] if eik_jobs else 0
+            # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix
+            st1, st0 = torch.empty(s1 + se, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se, 256, 128, device=dev, dtype=bf)
+            st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
+            be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
+                            ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
+                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)] + eik_jobs, n,
+                           outs_into=[st1[:s1], st0[:s0], st2] + ([st1[s1:], st0[s0:]] if eik_jobs else []))
+            if eik_live and not eik_jobs:
+                eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
+                sums = be.sum_slices([st1, st0, st2])
+                gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
+            else:
+                sums = be.sum_slices([st1, st0, st2] + ([w2_part] if eik_live else []))
+                gW1, gW0p, gW2p = sums[0], sums[1][:, :80], sums[2]
+                if eik_live:
+                    gW2p = gW2p + sums[3]
+            gb1, gb0, gb2 = gbz[:256] + _tp_colsum(A1t), gbz[256:512] + _tp_colsum(A0t), gbz[512:512 + K]
             gW0 = gW0p.index_select(1, _xp_columns(dev))
             gW2 = gW2p[:K]
         g_emb = None

@@ -503,6 +503,8 @@ int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
  *   bwd_grad:  g_grad [n,3]  ->  U0bt, A0pt, A1pt, U1bt (TP), UXb [n,80] bf16, g_dydx [16, n, 6] (cotangent of dy_dx, for hs_hash_bwd_jac)
  *   bwd_value: gy [n,32] bf16 (cotangent of the K outputs, the minimum's folded in at idx); A0pt / A1pt NULL when bwd_grad did not run
  *              ->  A0t, A1t (TP), g_feat [16, n, 2] (cotangent of the hash features, level-major) */
+/* gy [n,32] bf16 = g_raw [n,K] (NULL = zeros) with g_sdf [n] (NULL = none) added at column idx[n]; gb2 [32] fp32 (+=, NULL = skip): its column sums */
+int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2, int64_t n, void *stream);
 int64_t hs_trunk_rr_pack_bytes(int32_t which);
 int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
                      void *stream);
@@ -523,6 +525,8 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
 #define HS_WGP_256x256 0
 #define HS_WGP_256x80 1
 #define HS_WGP_32x256 2
+#define HS_WGP_256x256_RM 3     /* as HS_WGP_256x256 / _256x80 with BOTH operands row-major ([rows, 256] / [rows, 80]) */
+#define HS_WGP_256x80_RM 4
 typedef struct hsWgradPairJob {
     const void *A0, *B0, *A1, *B1;      /* second pair optional (both NULL) */
     void *part;
