@@ -714,24 +714,42 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
 
 
 // ---------------------------------------------------------------------------------------------------------------- output cotangent image
-// gy [n, 32] bf16 = g_raw (K columns, zero beyond) with the minimum's cotangent added at its index; gb2 [32] += its column sums (fp32)
+// gy [n, 32] bf16 = g_raw (K columns, zero beyond) with the minimum's cotangent added at its index; gb2_part [blocks, 32] = per-block column
+// sums in fp32 (the last layer's bias gradient = their sum: no same-address atomics).  Thread = (column, row residue mod 8), four rows in flight.
 __global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
-                                               uint16_t *__restrict__ gy, float *__restrict__ gb2, int64_t n) {
-    __shared__ float colsum[32];
-    if (threadIdx.x < 32) colsum[threadIdx.x] = 0.f;
-    __syncthreads();
-    const int col = threadIdx.x & 31, rsub = threadIdx.x >> 5;          // 8 rows per pass
+                                               uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n) {
+    __shared__ float part[8][32];
+    const int col = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
     float acc = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * 8 + rsub; r < n; r += (int64_t)gridDim.x * 8) {
-        float v = (g_raw && col < K) ? g_raw[r * K + col] : 0.f;
-        if (g_sdf && (int)idx[r] == col) v += g_sdf[r];
-        acc += v;
-        const uint32_t u = __float_as_uint(v);
-        gy[r * 32 + col] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    for (int64_t r = r0 + rsub; r < r1; r += 32) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t rr = r + 8 * u;
+            const bool in = rr < r1;
+            v[u] = (in && g_raw && col < K) ? g_raw[rr * K + col] : 0.f;
+            if (in && g_sdf && (int)idx[rr] == col) v[u] += g_sdf[rr];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t rr = r + 8 * u;
+            if (rr < r1) {
+                acc += v[u];
+                const uint32_t w = __float_as_uint(v[u]);
+                gy[rr * 32 + col] = (uint16_t)((w + 0x7fffu + ((w >> 16) & 1u)) >> 16);
+            }
+        }
     }
-    atomicAdd(&colsum[col], acc);
+    part[rsub][col] = acc;
     __syncthreads();
-    if (threadIdx.x < 32 && gb2) unsafeAtomicAdd(gb2 + threadIdx.x, colsum[threadIdx.x]);
+    if (threadIdx.x < 32 && gb2_part) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t += part[i][threadIdx.x];
+        gb2_part[(size_t)blockIdx.x * 32 + threadIdx.x] = t;
+    }
 }
 
 }  // namespace
@@ -762,12 +780,11 @@ static int rr_grid(int64_t n) {
     return (int)(want < 256 ? want : 256);
 }
 
-int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2, int64_t n, void *stream) {
+int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, void *stream) {
     if (K < 1 || K > 32) return HS_ERR_ARG;
     if (n == 0) return HS_OK;
     if (!gy || (g_sdf && !idx)) return HS_ERR_NULL;
-    const int64_t want = (n + 63) / 64;
-    k_rr_gy<<<(int)(want < 1024 ? want : 1024), 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2, n);
+    k_rr_gy<<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);
     return wt_check_launch();
 }
 

@@ -102,12 +102,20 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
     const int64_t rows = job.M / S, row_begin = (int64_t)slice * rows, row_end = row_begin + rows;
     // row-major operands hold job.rows valid rows (<= M = whole 32-row tiles); tile-packed ones are zero-filled beyond them by their producers
     const int64_t end_a = ATP ? row_end : (row_end < job.rows ? row_end : job.rows), end_b = BTP ? row_end : (row_end < job.rows ? row_end : job.rows);
-    if constexpr (WB < MB) {        // the padding columns of both B tiles: zero once, never written again
-        for (int i = threadIdx.x; i < 2 * RCP * (MB - WB); i += kThreadsP) {
-            const int buf = i / (RCP * (MB - WB)), r = (i / (MB - WB)) % RCP, cidx = i % (MB - WB);
-            Bbuf[buf][(size_t)r * PB + WB + cidx] = 0;
+    if constexpr (WB < MB) {        // the padding columns of both B tiles: zero once; column WB becomes the ONES column below, the rest is never written again
+        const int wz = job.B0 ? MB - WB : MB;           // (a job without B data: the whole tile)
+        const int c0 = job.B0 ? WB : 0;
+        for (int i = threadIdx.x; i < 2 * RCP * wz; i += kThreadsP) {
+            const int buf = i / (RCP * wz), r = (i / wz) % RCP, cidx = i % wz;
+            Bbuf[buf][(size_t)r * PB + c0 + cidx] = 0;
         }
     }
+    // job.ones: during the FIRST pair column WB of the B tile holds 1 -> column WB of the result = column sums of that pair's A operand
+    // (a bias gradient for free: the rows are streaming through anyway)
+    auto ones_column = [&](uint16_t *Bt, bool first_pair) {
+        if constexpr (WB < MB)
+            if (job.ones && threadIdx.x < RCP) Bt[(size_t)threadIdx.x * PB + WB] = first_pair ? (uint16_t)0x3f80 : (uint16_t)0;
+    };
     f32x16 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; a++)
@@ -147,22 +155,25 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
     int64_t r0;
     operands(0, A, B, r0);
     ChunkP<NA> ca = load_chunk_p<NA, ATP>(A, r0, end_a);
-    ChunkP<WB> cb = load_chunk_p<WB, BTP>(B, r0, end_b);
+    ChunkP<WB> cb;
+    if (B) cb = load_chunk_p<WB, BTP>(B, r0, end_b);
     __syncthreads();        // (the padding zeros above)
     store_chunk_p<NA, NA, ATP>(Abuf[0], ca);
-    store_chunk_p<WB, MB, BTP>(Bbuf[0], cb);
+    if (B) store_chunk_p<WB, MB, BTP>(Bbuf[0], cb);
+    ones_column(Bbuf[0], true);
     __syncthreads();
     for (int64_t c = 0; c < total; c++) {
         const int cur = (int)(c & 1);
         if (c + 1 < total) {
             operands(c + 1, A, B, r0);
             ca = load_chunk_p<NA, ATP>(A, r0, end_a);
-            cb = load_chunk_p<WB, BTP>(B, r0, end_b);
+            if (B) cb = load_chunk_p<WB, BTP>(B, r0, end_b);
         }
         multiply(cur);
         if (c + 1 < total) {
             store_chunk_p<NA, NA, ATP>(Abuf[cur ^ 1], ca);
-            store_chunk_p<WB, MB, BTP>(Bbuf[cur ^ 1], cb);
+            if (B) store_chunk_p<WB, MB, BTP>(Bbuf[cur ^ 1], cb);
+            ones_column(Bbuf[cur ^ 1], c + 1 < nchunks);
         }
         __syncthreads();
     }
@@ -209,7 +220,8 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
         if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_256x80_RM) return HS_ERR_ARG;
         // a slice is a whole number of 32-row tiles: the tile-packed operands are addressed by tile
         if (j.slices < 1 || j.M < j.slices || (j.M % j.slices) != 0 || ((j.M / j.slices) % 32) != 0 || j.rows < 0 || j.rows > j.M) return HS_ERR_ARG;
-        if (!j.A0 || !j.B0 || !j.part || (!j.A1) != (!j.B1)) return HS_ERR_NULL;
+        const bool no_b = !j.B0 && j.ones && (j.kind == HS_WGP_256x80 || j.kind == HS_WGP_256x80_RM) && !j.A1;     /* column sums only */
+        if (!j.A0 || (!j.B0 && !no_b) || !j.part || (!j.A1) != (!j.B1)) return HS_ERR_NULL;
         pj.j[i] = j;
         pj.first[i + 1] = pj.first[i] + j.slices;
     }

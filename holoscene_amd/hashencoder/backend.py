@@ -61,7 +61,8 @@ class hsWnJob(ctypes.Structure):
 
 class hsWgradPairJob(ctypes.Structure):
     _fields_ = [("A0", ctypes.c_void_p), ("B0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("B1", ctypes.c_void_p), ("part", ctypes.c_void_p),
-                ("M", ctypes.c_int64), ("rows", ctypes.c_int64), ("kind", ctypes.c_int32), ("slices", ctypes.c_int32)]
+                ("M", ctypes.c_int64), ("rows", ctypes.c_int64), ("kind", ctypes.c_int32), ("slices", ctypes.c_int32), ("ones", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class hsGatherJob(ctypes.Structure):
@@ -559,11 +560,16 @@ class _HipBackend:
         """Rows a tile-packed activation tensor holds for n samples (whole 32-row tiles)."""
         return 32 * ((int(n) + 31) // 32)
 
+    RR_GY_BLOCKS = 512
+
     @staticmethod
-    def trunk_rr_gy(g_raw, g_sdf, idx, K, gy, gb2):
+    def trunk_rr_gy(g_raw, g_sdf, idx, K, gy, gb2_part):
+        """gb2_part: None or fp32 [RR_GY_BLOCKS, 32] (per-block column sums of gy)."""
         lib = load_library()
+        if gb2_part is not None and tuple(gb2_part.shape) != (_HipBackend.RR_GY_BLOCKS, 32):
+            raise RuntimeError("trunk_rr_gy: gb2_part must be [RR_GY_BLOCKS, 32]")
         _check(lib.hs_trunk_rr_gy(_dev(g_raw, "g_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), int(K), _dev(gy, "gy", torch.bfloat16),
-                                  _dev(gb2, "gb2"), ctypes.c_int64(gy.shape[0]), _stream()), "hs_trunk_rr_gy")
+                                  _dev(gb2_part, "gb2_part"), ctypes.c_int64(gy.shape[0]), _stream()), "hs_trunk_rr_gy")
 
     @staticmethod
     def trunk_rr_pack(W0, W1, W2, d_out):
@@ -623,7 +629,8 @@ class _HipBackend:
 
     @staticmethod
     def wgrad_pairs(jobs, n, outs_into=None):
-        """jobs: [((NA, W[, "rm"]), slices, (A0, B0), (A1, B1) or None[, rows])] -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80), all
+        """jobs: [((NA, W[, "rm"][, "ones"]), slices, (A0, B0), (A1, B1) or None[, rows])] -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80;
+        "ones": column 80 of the result = column sums of A0, B0 may then be None), all
         in one launch (csrc/wgrad_pairs.hip).  Tile-packed operands cover n samples; "rm" jobs (both operands row-major) name their own
         row count (a multiple of 32 * slices).  outs_into: optional per-job destination tensors (e.g. slices of one stack, so that several
         jobs' partials are summed together by one hs_sum_slices job)."""
@@ -640,9 +647,10 @@ class _HipBackend:
             part = outs_into[len(outs)] if outs_into is not None and outs_into[len(outs)] is not None else torch.empty(slices, NA, MB, device=p0[0].device, dtype=bf)
             if tuple(part.shape) != (slices, NA, MB) or part.dtype != bf or not part.is_contiguous():
                 raise RuntimeError("wgrad_pairs: destination must be a contiguous bf16 [slices, NA, MB] tensor")
-            a.A0, a.B0 = _dev(p0[0], "A0", bf).value, _dev(p0[1], "B0", bf).value
+            a.ones = int("ones" in shape)
+            a.A0, a.B0 = _dev(p0[0], "A0", bf).value, (_dev(p0[1], "B0", bf).value if p0[1] is not None else None)
             a.A1, a.B1 = (_dev(p1[0], "A1", bf).value, _dev(p1[1], "B1", bf).value) if p1 is not None else (None, None)
-            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[shape], int(slices)
+            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[tuple(t for t in shape if t != "ones")], int(slices)
             outs.append(part)
         _check(lib.hs_wgrad_pairs(arr, len(jobs), _stream()), "hs_wgrad_pairs")
         return outs

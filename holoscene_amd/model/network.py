@@ -489,7 +489,8 @@ class _trunk_render_rr(torch.autograd.Function):
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         gy = torch.empty(n, 32, device=dev, dtype=bf)
         gbz = torch.zeros(2 * 256 + 32, device=dev)         # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
-        be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gbz[512:] if need_w else None)
+        gb2_part = torch.empty(be.RR_GY_BLOCKS, 32, device=dev) if need_w else None
+        be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
         A0t, A1t = tp(), tp()
         second = g_grad is not None
         if second:
@@ -521,25 +522,28 @@ class _trunk_render_rr(torch.autograd.Function):
             g_dydx[:, n:].zero_()
         gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
         if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
-            s1, s0, s2 = _rr_slices(n, 256 - sum(j[1] for j in eik_jobs))
+            sb = _rows_slices(be.tp_rows(n), 24)         # the b1 column-sum job (reads a1~ once more: one eighth of the pass's bytes)
+            s1, s0, s2 = _rr_slices(n, 256 - sb - sum(j[1] for j in eik_jobs))
             se = eik_jobs[0][1] if eik_jobs else 0
-            # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix
+            # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
+            # samples ride along as a ONES column of the B tile (column 80 of the 256 x 80 results)
             st1, st0 = torch.empty(s1 + se, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se, 256, 128, device=dev, dtype=bf)
-            st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
+            st2, stb = torch.empty(s2, 32, 256, device=dev, dtype=bf), torch.empty(sb, 256, 128, device=dev, dtype=bf)
             be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
-                            ((256, 80), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)] + eik_jobs, n,
-                           outs_into=[st1[:s1], st0[:s0], st2] + ([st1[s1:], st0[s0:]] if eik_jobs else []))
+                            ((256, 80, "ones"), s0, (A0t, Xp), (V0t, UXb) if second else None),
+                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None),
+                            ((256, 80, "ones"), sb, (A1t, None), None)] + eik_jobs, n,
+                           outs_into=[st1[:s1], st0[:s0], st2, stb] + ([st1[s1:], st0[s0:]] if eik_jobs else []))
             if eik_live and not eik_jobs:
                 eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
-                sums = be.sum_slices([st1, st0, st2])
+                sums = be.sum_slices([st1, st0, st2, stb])
                 gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
             else:
-                sums = be.sum_slices([st1, st0, st2] + ([w2_part] if eik_live else []))
+                sums = be.sum_slices([st1, st0, st2, stb] + ([w2_part] if eik_live else []))
                 gW1, gW0p, gW2p = sums[0], sums[1][:, :80], sums[2]
                 if eik_live:
-                    gW2p = gW2p + sums[3]
-            gb1, gb0, gb2 = gbz[:256] + _tp_colsum(A1t), gbz[256:512] + _tp_colsum(A0t), gbz[512:512 + K]
+                    gW2p = gW2p + sums[4]
+            gb1, gb0, gb2 = gbz[:256] + sums[3][:, 80], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
             gW0 = gW0p.index_select(1, _xp_columns(dev))
             gW2 = gW2p[:K]
         g_emb = None

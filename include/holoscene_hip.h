@@ -503,8 +503,10 @@ int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
  *   bwd_grad:  g_grad [n,3]  ->  U0bt, A0pt, A1pt, U1bt (TP), UXb [n,80] bf16, g_dydx [16, n, 6] (cotangent of dy_dx, for hs_hash_bwd_jac)
  *   bwd_value: gy [n,32] bf16 (cotangent of the K outputs, the minimum's folded in at idx); A0pt / A1pt NULL when bwd_grad did not run
  *              ->  A0t, A1t (TP), g_feat [16, n, 2] (cotangent of the hash features, level-major) */
-/* gy [n,32] bf16 = g_raw [n,K] (NULL = zeros) with g_sdf [n] (NULL = none) added at column idx[n]; gb2 [32] fp32 (+=, NULL = skip): its column sums */
-int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2, int64_t n, void *stream);
+/* gy [n,32] bf16 = g_raw [n,K] (NULL = zeros) with g_sdf [n] (NULL = none) added at column idx[n]; gb2_part [HS_RR_GY_BLOCKS, 32] fp32 (NULL =
+ * skip): per-block column sums of gy (their sum = the last layer's bias gradient) */
+#define HS_RR_GY_BLOCKS 512
+int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, void *stream);
 int64_t hs_trunk_rr_pack_bytes(int32_t which);
 int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
                      void *stream);
@@ -532,6 +534,8 @@ typedef struct hsWgradPairJob {
     void *part;
     int64_t M, rows;
     int32_t kind, slices;
+    int32_t ones;       /* HS_WGP_256x80 / _RM: column 80 of the result = column sums of A0 (a bias gradient); with B0 == NULL nothing else */
+    int32_t reserved;
 } hsWgradPairJob;
 int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream);
 
