@@ -820,7 +820,7 @@ def main():
         run_iteration(Net, Loss, "full_c1", K=32, S=128, R=1024, beta=0.01, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=310,
                       res=512, shape="full", distinct=True)
     if sel("full_c4"):
-        run_iteration(Net, Loss, "full_c4", K=32, S=192, R=2048, beta=0.01, eye=(0.0, 0.1, 0.6), iter_step=3, call_reg=False, seed=320,
+        run_iteration(Net, Loss, "full_c4", K=32, S=192, R=2048, beta=0.03, eye=(0.7, 0.0, 0.1), iter_step=3, call_reg=False, seed=320,
                       res=512, shape="full", distinct=True)
     for K in (21, 32):
         if sel(f"stock_net_k{K}"):
