@@ -145,6 +145,15 @@ __device__ __forceinline__ Vec<C> load_entry(const float *__restrict__ p) {
     return r;
 }
 
+// Batched-over-grids launches (hsHashLayout::grid_id): point b reads / updates the table of grid grid_id[b], which starts
+// grid_id[b] * grid_stride entries after `embeddings`; every grid has the same level geometry (`offsets`).
+__device__ __forceinline__ uint32_t grid_of(const hsHashLayout &lay, uint32_t b, bool inb = true) {
+    return (lay.grid_id != nullptr && inb) ? (uint32_t)lay.grid_id[b] : 0u;
+}
+__device__ __forceinline__ size_t grid_entry0(const hsHashLayout &lay, uint32_t gid, const LevelInfo &li) {
+    return (size_t)gid * (size_t)lay.grid_stride + (size_t)li.offset;
+}
+
 // ------------------------------------------------------------------------------------ forward
 template <int D, int C, bool DYDX>
 __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__ x, const float *__restrict__ emb,
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
     const uint32_t b = chunk * kThreads + threadIdx.x;
     if (b >= B) return;
     const LevelInfo li = level_info<D>(offsets, level, sc);
-    const float *__restrict__ grid = emb + (size_t)li.offset * C;
+    const float *__restrict__ grid = emb + grid_entry0(lay, grid_of(lay, b), li) * C;
     float *o = out + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
     float *j = DYDX ? dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride : nullptr;
 
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
     const uint32_t t = chunk * kThreads + threadIdx.x, b = t >> 1, xb = t & 1u;
     if (b >= B) return;                      // both lanes of a pair leave together
     const LevelInfo li = level_info<D>(offsets, level, sc);
-    const float *__restrict__ grid = emb + (size_t)li.offset * C;
+    const float *__restrict__ grid = emb + grid_entry0(lay, grid_of(lay, b), li) * C;
     float *o = out + (int64_t)level * lay.level_stride + (int64_t)b * lay.point_stride;
     float *jo = DYDX ? dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride : nullptr;
     uint32_t g[D];
@@ -341,9 +350,10 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
 // All 64 lanes must call this (inactive lanes pass valid=false).
 // Returns whether this lane ends a run (and now holds the run's sums in `cache`).
 template <int D, int C>
-__device__ __forceinline__ bool wave_merge(const uint32_t g[D], float cache[(1 << D) * C], bool valid) {
+__device__ __forceinline__ bool wave_merge(const uint32_t g[D], float cache[(1 << D) * C], bool valid, uint32_t key = 0u) {
     const int lane = threadIdx.x & 63;
     bool same_prev = valid && lane > 0;
+    same_prev = same_prev && ((uint32_t)__shfl_up(key, 1) == key);     // (batched launches: the same cell of ANOTHER grid is another cell)
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const uint32_t pg = __shfl_up(valid ? g[d] : 0xffffffffu, 1);
@@ -370,8 +380,8 @@ __device__ __forceinline__ bool wave_merge(const uint32_t g[D], float cache[(1 <
 
 template <int D, int C>
 __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const LevelInfo &li, const uint32_t g[D], float cache[(1 << D) * C],
-                                             bool valid) {
-    if (!wave_merge<D, C>(g, cache, valid)) return;
+                                             bool valid, uint32_t key = 0u) {
+    if (!wave_merge<D, C>(g, cache, valid, key)) return;
 #pragma unroll
     for (int corner = 0; corner < (1 << D); corner++) {
         uint32_t gl[D];
@@ -587,8 +597,9 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
 #pragma unroll
         for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
-    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
-    else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
+    const uint32_t gid = grid_of(lay, b, b < B);
+    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);      // (never with grid_id: the launchers refuse)
+    else scatter_cell<D, C>(gemb + grid_entry0(lay, gid, li) * C, li, g, cache, valid, gid);
 }
 
 // ------------------------------------------------------------------------------------ first backward: d/dx
@@ -676,7 +687,8 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict_
 #pragma unroll
         for (int d = 0; d < D; d++) g[d] = 0xffffffffu;
     }
-    scatter_cell<D, C>(g2emb + (size_t)li.offset * C, li, g, cache, valid);
+    const uint32_t gid = grid_of(lay, b, inb);
+    scatter_cell<D, C>(g2emb + grid_entry0(lay, gid, li) * C, li, g, cache, valid, gid);
 }
 
 // ------------------------------------------------------------------------------------ value+Jacobian backward
@@ -743,8 +755,9 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             }
         }
     }
-    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);
-    else scatter_cell<D, C>(gemb + (size_t)li.offset * C, li, g, cache, valid);
+    const uint32_t gid = grid_of(lay, b, b < B);
+    if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);      // (never with grid_id: the launchers refuse)
+    else scatter_cell<D, C>(gemb + grid_entry0(lay, gid, li) * C, li, g, cache, valid, gid);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -765,6 +778,8 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.gate.b = nullptr;
     lay.scatter_ws = nullptr;
     lay.scatter_cap = 0;
+    lay.grid_id = nullptr;
+    lay.grid_stride = 0;
     return lay;
 }
 
@@ -816,6 +831,7 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
     if (B == 0) return HS_OK;  // empty batches carry NULL data pointers
     if (!inputs || !embeddings || !offsets || !outputs || !layout) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
+    if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);
@@ -845,6 +861,7 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
     if (!grad || !inputs || !offsets || !layout) return HS_ERR_NULL;
     if (grad_inputs && !dy_dx) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
+    if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     hipStream_t st = (hipStream_t)stream;
@@ -873,6 +890,7 @@ int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets,
     if (B == 0 || (!grad_grad && !grad2_embeddings)) return HS_OK;
     if (!grad || !inputs || !offsets || !dy_dx || !grad_grad_inputs || !layout) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
+    if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);
@@ -890,6 +908,7 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     if (B == 0 || (!g_feat && !g_dydx)) return HS_OK;
     if (!inputs || !offsets || !grad_embeddings || !layout) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
+    if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);

@@ -28,7 +28,7 @@ class hsGate(ctypes.Structure):
 class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
-                ("scatter_cap", ctypes.c_uint32)]
+                ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -69,7 +69,7 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _gate(gate):
@@ -215,8 +215,16 @@ class _HipBackend:
 
     # ---- strided / selective variants (include/holoscene_hip.h section 2); point-major features, level-major dy_dx
     @staticmethod
-    def _layout(B, D, C, L, gate=None, ws=None, level_major=False):
-        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0)
+    def _layout(B, D, C, L, gate=None, ws=None, level_major=False, grids=None):
+        """grids: None, or (grid_id int32 [B], entries per grid): a batched-over-grids launch (hsHashLayout::grid_id)."""
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0)
+        if grids is not None:
+            if ws is not None:
+                raise ValueError("the binned scatter holds the records of ONE table: no scatter work space with grids=")
+            gid, stride = grids
+            if gid.numel() != B:
+                raise ValueError("grid_id: one entry per point")
+            lay.grid_id, lay.grid_stride = _dev(gid, "grid_id", torch.int32).value, int(stride)
         if level_major:      # features [L, B, C]: consecutive lanes (points) write consecutive 4C-byte entries
             lay.level_stride, lay.point_stride = B * C, C
         if ws is not None:
@@ -238,34 +246,34 @@ class _HipBackend:
         return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
 
     @classmethod
-    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False):
+    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False, grids=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, gate, level_major=level_major)
+        lay = cls._layout(B, D, C, L, gate, level_major=level_major, grids=grids)
         _check(lib.hs_hash_fwd(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
                                _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), ctypes.byref(lay),
                                _stream()), "hs_hash_fwd")
 
     @classmethod
-    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False):
+    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False, grids=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major)
+        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
         _check(lib.hs_hash_bwd(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
                                _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
                                _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay), _stream()), "hs_hash_bwd")
 
     @classmethod
-    def bwd2(cls, grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings):
+    def bwd2(cls, grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, grids=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L)
+        lay = cls._layout(B, D, C, L, grids=grids)
         _check(lib.hs_hash_bwd2(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32), B, D, C, L,
                                 ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), _dev(grad_grad_inputs, "grad_grad_inputs"),
                                 _dev(grad_grad, "grad_grad"), _dev(grad2_embeddings, "grad2_embeddings"), ctypes.byref(lay),
                                 _stream()), "hs_hash_bwd2")
 
     @classmethod
-    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False):
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None):
         lib = load_library()
-        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major)
+        lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")

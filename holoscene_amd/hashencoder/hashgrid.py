@@ -137,3 +137,83 @@ class HashEncoder(nn.Module):
         inputs = inputs.view(-1, self.input_dim)
         outputs = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
         return outputs.view(prefix_shape + [self.output_dim])
+
+
+# ------------------------------------------------------------------------------------ many grids, one launch
+class _hash_encode_grids(Function):
+    """Points of N grids with the same level geometry in ONE launch (hsHashLayout::grid_id): point b looks up table
+    ``embeddings[grid_id[b]]``.  Returns the features [B, L*C] and, with ``jacobian=True``, dy_dx [L, B, D*C] as a second
+    DIFFERENTIABLE-IN-THE-TABLE output (the value+Jacobian formulation of this package: no gradient flows to the inputs, as in
+    hashgrid.py:101).  backward: one fused value+Jacobian scatter into the stacked table gradient."""
+
+    @staticmethod
+    def forward(ctx, inputs, grid_id, embeddings, offsets, per_level_scale, base_resolution, jacobian=False):
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        if ctx.needs_input_grad[2]:
+            _be.expect_scatter(ctx.table)
+        inputs = inputs.contiguous()
+        grid_id = grid_id.contiguous()
+        G, T, C = embeddings.shape
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        S, H = float(np.log2(per_level_scale)), int(base_resolution)
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=inputs.dtype)
+        dy_dx = torch.empty(L, B, D * C, device=inputs.device, dtype=inputs.dtype) if jacobian else None
+        _be._backend.fwd(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, grids=(grid_id, T))
+        ctx.save_for_backward(inputs, grid_id, embeddings, offsets)
+        ctx.dims = (B, D, C, L, S, H, T)
+        if not jacobian:
+            return outputs
+        return outputs, dy_dx
+
+    @staticmethod
+    def backward(ctx, g_feat, g_dydx=None):
+        inputs, grid_id, embeddings, offsets = ctx.saved_tensors
+        B, D, C, L, S, H, T = ctx.dims
+        g_emb = None
+        if ctx.needs_input_grad[2]:
+            table = ctx.table
+            inplace = _be.accumulates_into_grad(table)
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(), inputs, offsets,
+                                 target, B, D, C, L, S, H, grids=(grid_id, T))
+            g_emb = None if inplace else target
+            if inplace:
+                _be.scatter_done(table)
+        return None, None, g_emb, None, None, None, None
+
+
+hash_encode_grids = _hash_encode_grids.apply
+
+
+class BatchedHashEncoder(nn.Module):
+    """``num_grids`` HashEncoders of one geometry behind ONE stacked table [G, T, C] -- the per-object grids of
+    SingleObjectImplicitNetworkGrid (model/network.py:1880-1883: every object constructs the same HashEncoder) evaluated together.
+    ``forward(inputs, grid_id)`` = ``HashEncoder.forward`` of grid ``grid_id[b]`` on point b, bit for bit."""
+
+    def __init__(self, num_grids, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None):
+        super().__init__()
+        one = HashEncoder(input_dim, num_levels, level_dim, per_level_scale, base_resolution, log2_hashmap_size, desired_resolution)
+        self.num_grids, self.input_dim, self.num_levels, self.level_dim = num_grids, input_dim, num_levels, level_dim
+        self.per_level_scale, self.base_resolution, self.output_dim = one.per_level_scale, base_resolution, one.output_dim
+        self.register_buffer("offsets", one.offsets.clone())
+        self.embeddings = nn.Parameter(torch.empty(num_grids, one.embeddings.shape[0], level_dim).uniform_(-1e-4, 1e-4))
+
+    @classmethod
+    def from_encoders(cls, encoders):
+        """Stack existing HashEncoders (copies their tables)."""
+        e0 = encoders[0]
+        self = cls(len(encoders), e0.input_dim, e0.num_levels, e0.level_dim, e0.per_level_scale, e0.base_resolution, e0.log2_hashmap_size)
+        self.to(e0.embeddings.device)
+        with torch.no_grad():
+            for g, e in enumerate(encoders):
+                if not torch.equal(e.offsets.cpu(), self.offsets.cpu()):
+                    raise ValueError("grids of different level geometry cannot share a launch")
+                self.embeddings[g].copy_(e.embeddings)
+        return self
+
+    def forward(self, inputs, grid_id, size=1, jacobian=False):
+        """inputs [B, D] in [-size, size], grid_id int32 [B] -> features [B, L*C] (and dy_dx [L, B, D*C] w.r.t. the [0,1] coordinate)."""
+        x01 = ((inputs + size) / (2 * size)).view(-1, self.input_dim)
+        return hash_encode_grids(x01, grid_id.to(torch.int32), self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, jacobian)

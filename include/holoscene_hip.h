@@ -105,6 +105,11 @@ typedef struct hsHashLayout {
     hsGate gate;               /* honoured by hs_hash_fwd only */
     void *scatter_ws;          /* NULL, or work space of hs_hash_scatter_ws_bytes() bytes: hs_hash_bwd / hs_hash_bwd_jac then scatter */
     uint32_t scatter_cap;      /* the hashed levels through per-bin record lists + an LDS reduction instead of global atomics     */
+    /* Batched-over-grids launches (ONE launch for the points of N per-object grids, model/network.py:1835-2032 holds one
+     * HashEncoder per object): NULL, or grid_id[b] in [0, N) for every point; grid g's table starts g * grid_stride ENTRIES
+     * (of C floats) after `embeddings` / `grad_embeddings`, all grids share `offsets`.  Needs scatter_ws == NULL. */
+    const int32_t *grid_id;
+    int64_t grid_stride;
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */

@@ -292,3 +292,99 @@ def test_binned_scatter_vs_oracle(cfg, cap):
     be.bwd_jac(gpm, g_dydx, xd, od, a, B, 3, 2, L, S, base, ws=ws)
     be.bwd_jac(gpm, g_dydx, xd, od, b, B, 3, 2, L, S, base)
     assert (a - b).abs().max() <= 4e-6 * np.sqrt(B) * float(b.abs().max())
+
+
+# ------------------------------------------------------------------------------------ many grids in one launch (hsHashLayout::grid_id)
+@pytest.mark.parametrize("order", ["mixed", "sorted"])
+@pytest.mark.parametrize("cfg", [dict(L=8, base=16, end=256, logmap=13, B=3001, G=5, C=2), dict(L=16, base=16, end=2048, logmap=19, B=12000, G=3, C=2),
+                                 dict(L=6, base=8, end=96, logmap=11, B=2000, G=4, C=4)])
+def test_batched_grids_vs_oracle_per_grid(cfg, order):
+    """Points of G grids of one geometry in ONE launch each for forward(+dy_dx), scatter, second backward and the value+Jacobian
+    scatter: every point's result is the ORACLE's on its own grid's table (forward bit-exact); the same cell of two grids in
+    neighbouring lanes must not be merged (ray-like runs of equal points, alternating grids, are part of the batch)."""
+    g = torch.Generator().manual_seed(11)
+    L, base, G, C, B = cfg["L"], cfg["base"], cfg["G"], cfg["C"], cfg["B"]
+    pls = hash_oracle.per_level_scale_for(base, cfg["end"], L)
+    offs = torch.from_numpy(hash_oracle.level_offsets(L, base, pls, cfg["logmap"]))
+    T = int(offs[-1])
+    emb = torch.rand(G, T, C, generator=g) * 2 - 1
+    x = torch.rand(B, 3, generator=g) * 1.1 - 0.05
+    x[64:192] = x[64:65]                                         # 128 lanes on ONE cell ...
+    gid = torch.randint(0, G, (B,), generator=g, dtype=torch.int32)
+    gid[64:192] = (torch.arange(128) // 3 % G).to(torch.int32)  # ... in runs of three lanes per grid
+    if order == "sorted":
+        gid, perm = torch.sort(gid, stable=True)
+        x = x[perm]
+    S = float(np.log2(pls))
+    dev = "cuda"
+    xd, ed, od, gd = x.to(dev), emb.to(dev), offs.to(dev), gid.to(dev)
+    out = torch.empty(B, L * C, device=dev)
+    dydx = torch.empty(L, B, 3 * C, device=dev)
+    _be().fwd(xd, ed, od, out, B, 3, C, L, S, base, dydx, grids=(gd, T))
+    out_v = torch.empty_like(out)
+    _be().fwd(xd, ed, od, out_v, B, 3, C, L, S, base, None, grids=(gd, T))
+    assert torch.equal(out_v, out)
+    grad = torch.randn(L, B, C, generator=g)
+    gpm = grad.permute(1, 0, 2).reshape(B, -1).contiguous().to(dev)
+    ggx = torch.randn(B, 3, generator=g)
+    gj = torch.randn(L, B, 3 * C, generator=g)                  # an arbitrary Jacobian cotangent
+    ge = torch.zeros_like(ed)
+    gx = torch.empty_like(xd)
+    _be().bwd(gpm, xd, od, ge, B, 3, C, L, S, base, dydx, gx, grids=(gd, T))
+    g2 = torch.zeros_like(ed)
+    gg = torch.empty_like(gpm)
+    if C >= 2:
+        _be().bwd2(gpm, xd, od, B, 3, C, L, S, base, dydx, ggx.to(dev), gg, g2, grids=(gd, T))
+    gjac = torch.zeros_like(ed)
+    _be().bwd_jac(gpm, gj.to(dev), xd, od, gjac, B, 3, C, L, S, base, grids=(gd, T))
+    for k in range(G):
+        sel = (gid == k).nonzero().flatten()
+        n = sel.numel()
+        ref_out, ref_dydx = hash_oracle.fwd(x[sel], emb[k], offs, S, base, True)
+        assert torch.equal(out.cpu()[sel], ref_out.permute(1, 0, 2).reshape(n, -1)), f"grid {k}: forward must be bit-exact"
+        assert torch.equal(dydx.cpu()[:, sel], ref_dydx.view(n, L, 3 * C).permute(1, 0, 2)), f"grid {k}: dy_dx must be bit-exact"
+        ref_gx, ref_ge = hash_oracle.bwd(grad[:, sel].contiguous(), x[sel], emb[k], offs, S, base, True, ref_dydx)
+        assert torch.equal(gx.cpu()[sel], ref_gx)
+        assert (ge.cpu()[k] - ref_ge).abs().max() <= 2e-6 * np.sqrt(n) * float(ref_ge.abs().max()), f"grid {k}: scatter"
+        if C >= 2:
+            ref_gg, ref_g2 = hash_oracle.bwd2(grad[:, sel].contiguous(), x[sel], emb[k], offs, S, base, ref_dydx, ggx[sel])
+            assert torch.equal(gg.cpu()[sel], ref_gg.permute(1, 0, 2).reshape(n, -1))
+            assert (g2.cpu()[k] - ref_g2).abs().max() <= 2e-6 * np.sqrt(n) * float(ref_g2.abs().max()), f"grid {k}: second backward"
+        # value+Jacobian scatter == the single-grid launch on this grid's points (itself oracle-checked in test_model_gpu / stock fixtures)
+        one = torch.zeros(T, C, device=dev)
+        sd = sel.to(dev)
+        _be().bwd_jac(gpm[sd].contiguous(), gj.to(dev)[:, sd].contiguous(), xd[sd].contiguous(), od, one, n, 3, C, L, S, base)
+        assert (gjac[k] - one).abs().max() <= 2e-6 * np.sqrt(n) * float(one.abs().max()), f"grid {k}: value+Jacobian scatter"
+
+
+def test_batched_grids_module_and_refusals():
+    """BatchedHashEncoder == the HashEncoders it was stacked from, gradient included; the binned scatter refuses grid ids."""
+    from holoscene_amd.hashencoder import HashEncoder
+    from holoscene_amd.hashencoder.hashgrid import BatchedHashEncoder
+    torch.manual_seed(3)
+    encs = [HashEncoder(num_levels=8, base_resolution=8, log2_hashmap_size=12, desired_resolution=128).cuda() for _ in range(4)]
+    for e in encs:
+        e.embeddings.data.uniform_(-1, 1)
+    bank = BatchedHashEncoder.from_encoders(encs)
+    B = 4099
+    x = torch.rand(B, 3, device="cuda") * 2 - 1
+    gid = torch.randint(0, 4, (B,), device="cuda", dtype=torch.int32)
+    y = bank(x, gid)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    for k, e in enumerate(encs):
+        sel = gid == k
+        yk = e(x[sel])
+        assert torch.equal(yk, y[sel])
+        (yk * w[sel]).sum().backward()
+        assert (bank.embeddings.grad[k] - e.embeddings.grad).abs().max() <= 1e-5 * float(e.embeddings.grad.abs().max())
+    ws = _be().scatter_workspace(B, 3, 2, 8, "cuda")
+    if ws is not None:
+        with pytest.raises(ValueError):
+            _be().bwd_jac(w, None, x, bank.offsets, torch.zeros_like(bank.embeddings), B, 3, 2, 8, 1.0, 8, ws=ws, grids=(gid, 10))
+    lay = _be()._layout(B, 3, 2, 8, grids=(gid, 0))           # a zero stride is refused by the library itself
+    from holoscene_amd.hashencoder import backend
+    import ctypes
+    rc = backend.load_library().hs_hash_fwd(backend._dev(x, "x"), backend._dev(bank.embeddings.data, "e"), backend._dev(bank.offsets, "o", torch.int32),
+                                            backend._dev(y.detach(), "y"), B, 3, 2, 8, ctypes.c_float(1.0), 8, None, ctypes.byref(lay), None)
+    assert rc != 0
