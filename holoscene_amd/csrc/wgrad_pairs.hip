@@ -99,7 +99,10 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
     uint16_t *Bbuf[2] = {lds + RCP * PA, lds + 2 * RCP * PA + RCP * PB};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave % WN, wm = wave / WN;
-    const int64_t rows = job.M / S, row_begin = (int64_t)slice * rows, row_end = row_begin + rows;
+    // slice = ceil(tiles / S) whole 32-row tiles; the last slices may be short or empty (their partial is then all zero): the caller cuts
+    // every job of a launch in proportion to its BYTES, not to a divisor of its tile count
+    const int64_t rows = ((job.M / 32 + S - 1) / S) * 32, row_begin = (int64_t)slice * rows;
+    const int64_t row_end = row_begin + rows < job.M ? row_begin + rows : job.M;
     // row-major operands hold job.rows valid rows (<= M = whole 32-row tiles); tile-packed ones are zero-filled beyond them by their producers
     const int64_t end_a = ATP ? row_end : (row_end < job.rows ? row_end : job.rows), end_b = BTP ? row_end : (row_end < job.rows ? row_end : job.rows);
     if constexpr (WB < MB) {        // the padding columns of both B tiles: zero once; column WB becomes the ONES column below, the rest is never written again
@@ -142,7 +145,7 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
         }
     };
     // chunk sequence: all chunks of pair 0, then all chunks of pair 1 (when present) -- one pipeline, one chunk in flight ahead
-    const int64_t nchunks = (rows + RCP - 1) / RCP;
+    const int64_t nchunks = row_end > row_begin ? (row_end - row_begin + RCP - 1) / RCP : 0;
     const int npairs = job.A1 ? 2 : 1;
     const int64_t total = nchunks * npairs;
     auto operands = [&](int64_t c, const uint16_t *&A, const uint16_t *&B, int64_t &r0) {
@@ -219,7 +222,7 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
         const hsWgradPairJob &j = jobs[i];
         if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_256x80_RM) return HS_ERR_ARG;
         // a slice is a whole number of 32-row tiles: the tile-packed operands are addressed by tile
-        if (j.slices < 1 || j.M < j.slices || (j.M % j.slices) != 0 || ((j.M / j.slices) % 32) != 0 || j.rows < 0 || j.rows > j.M) return HS_ERR_ARG;
+        if (j.slices < 1 || j.M < 32 || (j.M % 32) != 0 || j.rows < 0 || j.rows > j.M) return HS_ERR_ARG;
         const bool no_b = !j.B0 && j.ones && (j.kind == HS_WGP_256x80 || j.kind == HS_WGP_256x80_RM) && !j.A1;     /* column sums only */
         if (!j.A0 || (!j.B0 && !no_b) || !j.part || (!j.A1) != (!j.B1)) return HS_ERR_NULL;
         pj.j[i] = j;

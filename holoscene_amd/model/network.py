@@ -409,6 +409,29 @@ def _rr_slices(n, budget=256):
     return fine, coarse, coarse
 
 
+_PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432}      # bytes of one operand pair per 32-row tile
+
+
+def _pair_slices(jobs, budget=256):
+    """Slice counts for the jobs of ONE hs_wgrad_pairs launch: a workgroup streams its slice at a fixed rate (one workgroup per CU, the
+    launch lasts as long as its largest slice), so every job is cut in proportion to its BYTES and the counts add up to the chip.
+    jobs: [(shape, tiles, pairs, has_B)] -> [slices]."""
+    cost = []
+    for shape, tiles, pairs, has_b in jobs:
+        per = _PAIR_TILE_BYTES[tuple(shape[:2])] if has_b else 64 * shape[0]
+        cost.append(float(per * pairs * tiles))
+    total = sum(cost)
+    want = [max(1, min(t, int(c / total * budget))) for c, (_, t, _, _) in zip(cost, jobs)]
+    spare = budget - sum(want)
+    while spare > 0:          # hand the remaining workgroups to whoever has the most bytes per slice
+        i = max(range(len(jobs)), key=lambda k: cost[k] / want[k] if want[k] < jobs[k][1] else 0.0)
+        if want[i] >= jobs[i][1]:
+            break
+        want[i] += 1
+        spare -= 1
+    return want
+
+
 def _rows_slices(rows, cap):
     """Largest slice count <= cap that cuts `rows` row-major rows into whole 32-row tiles."""
     tiles = rows // 32
@@ -515,19 +538,22 @@ class _trunk_render_rr(torch.autograd.Function):
             be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,
                              gb2=gbz[512:] if need_w else None, dW2_part=w2_part, ld=B, off=n)
             if need_w and Me % 32 == 0:
-                se = _rows_slices(Me, 16)
-                eik_jobs = [((256, 256, "rm"), se, (gA1, H0e), None, Me), ((256, 80, "rm"), se, (gA0, Xpe), None, Me)]
+                eik_jobs = [((256, 256, "rm"), 0, (gA1, H0e), None, Me), ((256, 80, "rm"), 0, (gA0, Xpe), None, Me)]
         elif Be > 0:
             g_feat[:, n:].zero_()
             g_dydx[:, n:].zero_()
         gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
         if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
-            sb = _rows_slices(be.tp_rows(n), 24)         # the b1 column-sum job (reads a1~ once more: one eighth of the pass's bytes)
-            s1, s0, s2 = _rr_slices(n, 256 - sb - sum(j[1] for j in eik_jobs))
-            se = eik_jobs[0][1] if eik_jobs else 0
+            T, npair = be.tp_rows(n) // 32, 2 if second else 1
+            # (the b1 column-sum job reads a1~ once more: one eighth of the pass's bytes)
+            cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True), ((256, 80), T, 1, False)]
+                               + [(j[0], Me // 32, 1, True) for j in eik_jobs])
+            s1, s0, s2, sb = cut[:4]
+            se1, se0 = cut[4:] if eik_jobs else (0, 0)
+            eik_jobs = [(j[0], sl) + tuple(j[2:]) for j, sl in zip(eik_jobs, (se1, se0))]
             # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
             # samples ride along as a ONES column of the B tile (column 80 of the 256 x 80 results)
-            st1, st0 = torch.empty(s1 + se, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se, 256, 128, device=dev, dtype=bf)
+            st1, st0 = torch.empty(s1 + se1, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se0, 256, 128, device=dev, dtype=bf)
             st2, stb = torch.empty(s2, 32, 256, device=dev, dtype=bf), torch.empty(sb, 256, 128, device=dev, dtype=bf)
             be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
                             ((256, 80, "ones"), s0, (A0t, Xp), (V0t, UXb) if second else None),

@@ -527,8 +527,9 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
 
 /* Weight gradients of that formulation: part[slice] = sum over the job's one or two operand pairs of A^T B over the slice's rows
  * (csrc/wgrad_pairs.hip).  kind: HS_WGP_256x256 (A, B tile-packed), HS_WGP_256x80 (A tile-packed, B row-major [rows, 80]; result
- * [256, 128], columns >= 80 zero), HS_WGP_32x256 (A row-major [rows, 32], B tile-packed).  M = 32 * number of tiles (a multiple of
- * 32 * slices), rows <= M the valid rows of the row-major operands; part: bf16 [slices, NA, MB]. */
+ * [256, 128], columns >= 80 zero), HS_WGP_32x256 (A row-major [rows, 32], B tile-packed).  M = 32 * number of tiles; a slice is
+ * ceil(tiles / slices) whole tiles, the last slices may be short or empty (their partial is then zero); rows <= M the valid rows of
+ * the row-major operands; part: bf16 [slices, NA, MB]. */
 #define HS_WGP_256x256 0
 #define HS_WGP_256x80 1
 #define HS_WGP_32x256 2

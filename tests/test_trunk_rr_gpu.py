@@ -119,3 +119,9 @@ def test_rr_kernels_vs_torch_restatement(n, K):
     assert e["dW1"] < 1e-2 and e["dW0"] < 1e-2 and e["dW2"] < 1e-2 and e["dW0 pad"] == 0, e
     single = be.wgrad_pairs([((256, 256), S, (A1t, H0t), None)], n)[0].float().sum(0)
     assert rel_l2(single, A1d.t() @ f3["h0"]) < 1e-2
+    # ragged cuts (slice = ceil(tiles / S) tiles; short and EMPTY trailing slices write zero partials), a different count per job
+    for cuts in [(3, 5, 7), (tiles - 1 if tiles > 2 else 1, 2, max(1, tiles // 2 + 1))]:
+        parts = be.wgrad_pairs([((256, 256), cuts[0], (A1t, H0t), (V1t, U0bt)), ((256, 80), cuts[1], (A0t, Xp), (V0t, UXb)),
+                                ((32, 256), cuts[2], (gy, H1t), (onehot, U1bt))], n)
+        r1, r0, r2 = (p.float().sum(0) for p in parts)
+        assert rel_l2(r1, want1) < 1e-2 and rel_l2(r0[:, :80], want0) < 1e-2 and rel_l2(r2, want2) < 1e-2, cuts
