@@ -65,11 +65,44 @@ class hsWgradPairJob(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class hsAsmTerm(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("col_map", ctypes.c_void_p), ("ld", ctypes.c_int64), ("red_stride", ctypes.c_int64), ("col0", ctypes.c_int32),
+                ("red", ctypes.c_int32)]
+
+
+class hsAsmJob(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("dst_ld", ctypes.c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("n_terms", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("term", hsAsmTerm * 3)]
+
+
 class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
 ABI_VERSION = 4
+
+# Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
+# together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
+# requests inside an iteration is the same every time, so a captured graph sees the same addresses as its warm-up passes.
+_ZERO_POOL = {"buf": None, "pos": 0}
+
+
+def set_zero_pool(buf):
+    """buf: fp32 device tensor that the caller has just zeroed (training/flat.py: FlatAdam.zero_grad), or None to switch the pool off."""
+    _ZERO_POOL["buf"], _ZERO_POOL["pos"] = buf, 0
+
+
+def zeros_small(n, device):
+    """n zero floats: from the pool when one is armed on that device and has room, else a fresh torch.zeros."""
+    buf, pos = _ZERO_POOL["buf"], _ZERO_POOL["pos"]
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    if buf is not None and buf.device == d and pos + n <= buf.numel():
+        _ZERO_POOL["pos"] = pos + (n + 3) // 4 * 4
+        return buf[pos:pos + n]
+    return torch.zeros(n, device=device)
+
 
 
 def _gate(gate):
@@ -106,7 +139,7 @@ def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
-            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs"]
+            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift"]
 
 
 def _check(rc, what):
@@ -664,6 +697,44 @@ class _HipBackend:
         return outs
 
     WGRAD_SHAPES = ((256, 256), (256, 128), (32, 256))
+
+    @staticmethod
+    def assemble(jobs):
+        """jobs: [((rows, cols), [term, ...])] with term = (src fp32 tensor, ld, col0 or int32 column-map tensor[, red, red_stride]) ->
+        fp32 tensors [rows, cols] (1-D when rows == 1... no: always [rows, cols]) = the sums of the terms, all in one launch
+        (hs_assemble, csrc/small_ops.hip).  The element (r, c) of a term is src.flat[r * ld + col(c) (+ k * red_stride, summed over k < red)]."""
+        lib = load_library()
+        outs, keep = [], []
+        for k0 in range(0, len(jobs), 8):
+            grp = jobs[k0:k0 + 8]
+            arr = (hsAsmJob * len(grp))()
+            for a, ((rows, cols), terms) in zip(arr, grp):
+                dev = terms[0][0].device
+                out = torch.empty(rows, cols, device=dev, dtype=torch.float32)
+                a.dst, a.dst_ld, a.rows, a.cols, a.n_terms = out.data_ptr(), cols, rows, cols, len(terms)
+                for t, term in zip(a.term, terms):
+                    src, ld, col = term[:3]
+                    t.src, t.ld = _dev(src, "assemble source").value, int(ld)
+                    if torch.is_tensor(col):
+                        t.col_map, t.col0 = _dev(col, "column map", torch.int32).value, 0
+                        keep.append(col)
+                    else:
+                        t.col_map, t.col0 = None, int(col)
+                    t.red, t.red_stride = (int(term[3]), int(term[4])) if len(term) > 3 else (1, 0)
+                outs.append(out)
+            _check(lib.hs_assemble(arr, len(grp), _stream()), "hs_assemble")
+        return outs
+
+    @staticmethod
+    def abs_shift(x, shift=None, gy=None):
+        """forward (gy is None): |x| + shift[0]; backward: gy * sgn(x) (hs_abs_shift)."""
+        lib = load_library()
+        out = torch.empty_like(x)
+        if gy is None:
+            _check(lib.hs_abs_shift(_dev(x, "x"), _dev(shift, "shift"), _dev(out, "y"), None, None, x.numel(), _stream()), "hs_abs_shift")
+        else:
+            _check(lib.hs_abs_shift(_dev(x, "x"), None, None, _dev(gy, "gy"), _dev(out, "gx"), x.numel(), _stream()), "hs_abs_shift")
+        return out
 
     @staticmethod
     def wgrad_rows(pairs, slices):

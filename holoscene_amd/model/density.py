@@ -10,6 +10,29 @@ def laplace_density(sdf, beta):
     return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
 
 
+class _abs_shift(torch.autograd.Function):
+    """|beta| + beta_min and its backward as one launch each (csrc/small_ops.hip) -- autograd's abs, add / sgn, mul are four ~5 us
+    launches inside the replayed training graph for one float."""
+
+    @staticmethod
+    def forward(ctx, beta, beta_min):
+        from ..hashencoder.backend import _backend
+        ctx.save_for_backward(beta)
+        return _backend.abs_shift(beta.detach().contiguous(), beta_min)
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hashencoder.backend import _backend
+        (beta,) = ctx.saved_tensors
+        return _backend.abs_shift(beta.detach().contiguous(), gy=g.contiguous().float()), None
+
+
+def _beta(beta, beta_min):
+    if beta.is_cuda and beta.dtype == torch.float32:
+        return _abs_shift.apply(beta, beta_min)
+    return beta.abs() + beta_min
+
+
 class Density(nn.Module):
     def __init__(self, params_init={}):
         super().__init__()
@@ -35,13 +58,13 @@ class LaplaceDensity(Density):
     def get_beta(self):
         if self._shared is not None:
             return self._shared
-        return self.beta.abs() + self.beta_min
+        return _beta(self.beta, self.beta_min)
 
     @contextlib.contextmanager
     def shared_beta(self):
         """Within the block every get_beta() returns ONE tensor evaluated on entry (with its autograd history): an iteration asks
         for beta in the sampler, the background sampler and the renderer, and the parameter cannot change in between."""
-        self._shared = self.beta.abs() + self.beta_min
+        self._shared = _beta(self.beta, self.beta_min)
         try:
             yield self._shared
         finally:

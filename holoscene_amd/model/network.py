@@ -170,6 +170,63 @@ def _xp_columns(dev):
     return _XP_COLUMNS[key]
 
 
+class _Outputs(dict):
+    """render()'s output dictionary.  An entry registered with defer() is evaluated on first access (or when the dictionary is
+    enumerated): per-sample products nobody reads during training then cost no launch in the replayed iteration."""
+
+    def defer(self, key, fn):
+        self.__dict__.setdefault("_deferred", {})[key] = fn
+
+    def _pending(self):
+        return self.__dict__.get("_deferred", {})
+
+    def __missing__(self, key):
+        fn = self._pending().pop(key, None)
+        if fn is None:
+            raise KeyError(key)
+        self[key] = v = fn()
+        return v
+
+    def _materialise(self):
+        for k in list(self._pending()):
+            self[k]
+        return self
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._pending()
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return dict.keys(self._materialise())
+
+    def items(self):
+        return dict.items(self._materialise())
+
+    def values(self):
+        return dict.values(self._materialise())
+
+    def __iter__(self):
+        return dict.__iter__(self._materialise())
+
+    def __len__(self):
+        return dict.__len__(self._materialise())
+
+    def pop(self, key, *default):
+        if key in self._pending():
+            self._pending().pop(key)
+            return None
+        return dict.pop(self, key, *default)
+
+
+def _xp_columns32(dev):
+    key = "i32:" + str(dev)
+    if key not in _XP_COLUMNS:
+        _XP_COLUMNS[key] = _xp_columns(dev).to(torch.int32)
+    return _XP_COLUMNS[key]
+
+
 def _wgrad_rows(g, x):
     """g^T @ x over M rows as a split-M batched GEMM (see _linear_rows) -> fp32 [g.shape[1], x.shape[1]]."""
     M = x.shape[0]
@@ -272,7 +329,7 @@ def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
     gA1 = torch.empty(M, 256, device=dev, dtype=bf)
     gA0 = torch.empty(M, 256, device=dev, dtype=bf)
     KP = g.shape[1]
-    gbz = torch.zeros(2 * 256 + KP, device=dev)      # one zero-fill for the three bias-gradient accumulators
+    gbz = _be.zeros_small(2 * 256 + KP, dev)         # one zero-fill for the three bias-gradient accumulators
     gb1, gb0, gb2k = gbz[:256], gbz[256:512], gbz[512:]
     g_feat = g_dydx = None
     if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
@@ -511,7 +568,7 @@ class _trunk_render_rr(torch.autograd.Function):
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         gy = torch.empty(n, 32, device=dev, dtype=bf)
-        gbz = torch.zeros(2 * 256 + 32, device=dev)         # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
+        gbz = _be.zeros_small(2 * 256 + 32, dev)            # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
         gb2_part = torch.empty(be.RR_GY_BLOCKS, 32, device=dev) if need_w else None
         be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
         A0t, A1t = tp(), tp()
@@ -567,11 +624,18 @@ class _trunk_render_rr(torch.autograd.Function):
             else:
                 sums = be.sum_slices([st1, st0, st2, stb] + ([w2_part] if eik_live else []))
                 gW1, gW0p, gW2p = sums[0], sums[1][:, :80], sums[2]
-                if eik_live:
-                    gW2p = gW2p + sums[4]
-            gb1, gb0, gb2 = gbz[:256] + sums[3][:, 80], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
-            gW0 = gW0p.index_select(1, _xp_columns(dev))
-            gW2 = gW2p[:K]
+            if eik_live and not eik_jobs:
+                gb1, gb0, gb2 = gbz[:256] + sums[3][:, 80], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
+                gW0 = gW0p.index_select(1, _xp_columns(dev))
+                gW2 = gW2p[:K]
+            else:   # the column selection of dW0, dW2 of both point families, the three bias gradients: one launch (csrc/small_ops.hip)
+                gW0, gW2, gb1, gb0, gb2 = be.assemble([
+                    ((256, F_in), [(sums[1], 128, _xp_columns32(dev))]),
+                    ((K, 256), [(sums[2], 256, 0)] + ([(sums[4], 256, 0)] if eik_live else [])),
+                    ((256, 1), [(gbz, 1, 0), (sums[3], 128, 80)]),
+                    ((256, 1), [(gbz, 1, 256), (sums[1], 128, 80)]),
+                    ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
+                gb1, gb0, gb2 = gb1.view(-1), gb0.view(-1), gb2.view(-1)
         g_emb = None
         if need_table:      # one value+Jacobian scatter for all B points
             table = ctx.table
@@ -656,7 +720,7 @@ class _fused_appearance(torch.autograd.Function):
         gy, gA_r1, gA_r0, g_fv, gA_hc = new(32), new(256), new(256), new(256), new(256)
         d_normals = torch.empty(B, 3, device=dev)
         g_featc = torch.empty(L, B, C, device=dev)
-        gb = torch.zeros(5, 256, device=dev)
+        gb = _be.zeros_small(5 * 256, dev).view(5, 256)
         W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
         be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb, ctx.masks)
         need_w = ctx.needs_input_grad[8]
@@ -1893,7 +1957,7 @@ class HoloSceneNetwork(nn.Module):
         if self.white_bkgd:
             rgb_values = rgb_values + (1.0 - torch.sum(weights, -1)[..., None]) * self.bg_color.unsqueeze(0)
 
-        output = {
+        output = _Outputs({
             "rgb": rgb,
             "semantic_values": semantic_values,
             "object_opacity": object_opacity,
@@ -1902,9 +1966,9 @@ class HoloSceneNetwork(nn.Module):
             "z_vals": z_vals,
             "sdf": sdf.reshape(z_vals.shape),
             "weights": weights,
-        }
+        })
 
-        output["depth_vals"] = z_vals * depth_scale
+        output.defer("depth_vals", lambda: z_vals * depth_scale)     # nothing in training reads it: evaluated on first access
         if self.training:
             # replaces gradient() + get_sdf_raw() + get_sdf_vals() on the Eikonal set (network.py:856-863)
             if gtheta is not None:      # already stacked by the split kernel

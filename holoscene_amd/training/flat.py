@@ -26,6 +26,8 @@ from ..hashencoder import backend as _be
 
 
 class FlatAdam:
+    ZERO_POOL = 8192        # floats of zeroed scratch behind the gradients (backend.zeros_small: bias-gradient accumulators of the backward kernels)
+
     def __init__(self, model, lr, lr_factor_for_grid, decay_rate, decay_steps, betas=(0.9, 0.99), eps=1e-15, world_size=1, rank=0,
                  shard_moments=False, early_params=None):
         """shard_moments (ZeRO-1): this rank stores the Adam moments of its own 1/world_size slice (of every segment) only; the
@@ -57,7 +59,8 @@ class FlatAdam:
             cuts.append(self.padded)
         self.segments = list(zip(cuts[:-1], cuts[1:]))
         self.flat_p = torch.zeros(self.padded, device=dev)
-        self.flat_g = torch.zeros(self.padded, device=dev)
+        self._g_alloc = torch.zeros(self.padded + self.ZERO_POOL, device=dev)     # gradients | pool of small zeroed accumulators (backend.zeros_small)
+        self.flat_g = self._g_alloc[:self.padded]
         self.shards = [(b + rank * ((e - b) // world_size), b + (rank + 1) * ((e - b) // world_size)) for b, e in self.segments]
         self.shard_moments = bool(shard_moments) and world_size > 1
         # moment storage: full length, or this rank's slices of the segments back to back; mv_bases[s] = flat index that
@@ -104,7 +107,8 @@ class FlatAdam:
         """One memset; the hash tables keep their gradient views attached (the scatter kernels accumulate into them in
         place), the ~30 small MLP tensors are detached so that autograd hands over each gradient tensor as is instead of
         launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy."""
-        self.flat_g.zero_()
+        self._g_alloc.zero_()
+        _be.set_zero_pool(self._g_alloc[self.padded:])
         for p, _ in self.small:
             p.grad = None
 
@@ -113,6 +117,7 @@ class FlatAdam:
         iteration is updated with a zero gradient (its moments decay, its momentum still moves it), whereas torch.optim.Adam after
         `zero_grad(set_to_none=True)` -- the reference's loop -- skips it.  Stage 1 uses every parameter in every iteration, so the
         two agree there; a model with conditionally used parameters is told once."""
+        _be.set_zero_pool(None)         # the backward pass this pool served is over
         src = [p.grad for p, _ in self.small if p.grad is not None]
         dst = [v for p, v in self.small if p.grad is not None]
         if len(src) != len(self.small) and not getattr(self, "_warned_missing_grad", False):

@@ -471,6 +471,31 @@ typedef struct hsSumJob {
 } hsSumJob;
 int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream);
 
+/* Small fp32 matrices assembled in ONE launch (csrc/small_ops.hip):
+ *   dst[r * dst_ld + c] = sum over terms t of  sum_{k < red_t} src_t[k * red_stride_t + r * ld_t + (col_map_t ? col_map_t[c] : col0_t + c)]
+ * for r < rows, c < cols -- bias gradient = accumulator + a column of a partial-sum matrix, weight gradient = a column selection of the
+ * padded result, a column sum of per-workgroup partials (red > 1) ... what autograd would spend one ~5 us launch per operator on. */
+#define HS_ASM_MAX_JOBS 8
+#define HS_ASM_MAX_TERMS 3
+typedef struct hsAsmTerm {
+    const float *src;
+    const int32_t *col_map;    /* NULL: columns col0 .. col0 + cols - 1 */
+    int64_t ld;                /* row stride of src (0: every row reads the same source row) */
+    int64_t red_stride;
+    int32_t col0;
+    int32_t red;               /* >= 1: number of source blocks summed */
+} hsAsmTerm;
+typedef struct hsAsmJob {
+    float *dst;
+    int64_t dst_ld;
+    int32_t rows, cols, n_terms, reserved;
+    hsAsmTerm term[HS_ASM_MAX_TERMS];
+} hsAsmJob;
+int hs_assemble(const hsAsmJob *jobs, int32_t n_jobs, void *stream);
+
+/* LaplaceDensity.get_beta (model/density.py:28-30): y = |x| + shift[0] (y != NULL) and / or its backward gx = gy * sgn(x) (gx != NULL). */
+int hs_abs_shift(const float *x, const float *shift, float *y, const float *gy, float *gx, int32_t n, void *stream);
+
 /* Weight normalisation of several layers in one launch (nn.utils.weight_norm with dim = 0, model/network.py:158-159):
  * forward  W[r,:] = g[r] * v[r,:] / ||v[r,:]||;   backward (gW given)  gg[r] = <gW[r,:], v[r,:]> / ||v[r,:]||,
  * gv[r,:] = g[r]/||v[r,:]|| * (gW[r,:] - v[r,:] * <gW[r,:], v[r,:]> / ||v[r,:]||^2).  All fp32, row-major [rows, cols]. */
