@@ -494,7 +494,8 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
                                                       float far_cap, float bound, float eps, float *__restrict__ ray_dirs,
                                                       float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
                                                       float *__restrict__ beta_init, int R, float divide_factor, float *__restrict__ x,
-                                                      float *__restrict__ x01, float offset_shift, float *__restrict__ rot_out) {
+                                                      float *__restrict__ x01, float offset_shift, float *__restrict__ rot_out,
+                                                      float *__restrict__ beta_work) {
     extern __shared__ float lds[];  // [S] stratified depths of this ray
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
@@ -565,7 +566,11 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
     float acc = 0.f;
     for (int i = lane; i + 1 < S; i += kWave) { const float dd = lds[i + 1] - lds[i]; acc += dd * dd; }
     acc = wave_sum(acc);
-    if (lane == 0) beta_init[r] = sqrtf((1.0f / (4.0f * logf(eps + 1.0f))) * acc);
+    if (lane == 0) {
+        const float b = sqrtf((1.0f / (4.0f * logf(eps + 1.0f))) * acc);
+        beta_init[r] = b;
+        if (beta_work) beta_work[r] = b;      // the sampler's working copy (its update kernels overwrite it round by round)
+    }
 }
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
@@ -679,13 +684,14 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 float divide_factor, float *x, float *x01, float offset_shift, float *rot_out, void *stream) {
+                 float divide_factor, float *x, float *x01, float offset_shift, float *rot_out, float *beta_work, void *stream) {
     if (R <= 0) return HS_OK;
     if (S < 2 || S > 4096) return HS_ERR_ARG;
     if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
     if (x && (!x01 || divide_factor == 0.f)) return HS_ERR_ARG;
     k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
-                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift, rot_out);
+                                                                                 ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift, rot_out,
+                                                                                 beta_work);
     return check_launch();
 }
 

@@ -92,13 +92,21 @@ def set_zero_pool(buf):
     _ZERO_POOL["buf"], _ZERO_POOL["pos"] = buf, 0
 
 
+def _pool_device(device):
+    d = torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+
+
+def zero_pool_armed(device, n=1):
+    """Whether zeros_small(n, device) would be served from the pool (i.e. without a fill launch)."""
+    buf = _ZERO_POOL["buf"]
+    return buf is not None and buf.device == _pool_device(device) and _ZERO_POOL["pos"] + n <= buf.numel()
+
+
 def zeros_small(n, device):
     """n zero floats: from the pool when one is armed on that device and has room, else a fresh torch.zeros."""
     buf, pos = _ZERO_POOL["buf"], _ZERO_POOL["pos"]
-    d = torch.device(device)
-    if d.type == "cuda" and d.index is None:
-        d = torch.device("cuda", torch.cuda.current_device())
-    if buf is not None and buf.device == d and pos + n <= buf.numel():
+    if buf is not None and buf.device == _pool_device(device) and pos + n <= buf.numel():
         _ZERO_POOL["pos"] = pos + (n + 3) // 4 * 4
         return buf[pos:pos + n]
     return torch.zeros(n, device=device)
@@ -386,13 +394,14 @@ class _HipBackend:
 
     @staticmethod
     def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init,
-                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0, rot_out=None):
+                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0, rot_out=None, beta_work=None):
         lib = load_library()
         _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
                                 _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
                                 ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
                                 _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], ctypes.c_float(divide_factor), _dev(x, "x"),
-                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _dev(rot_out, "rot_out"), _stream()), "hs_ray_setup")
+                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _dev(rot_out, "rot_out"), _dev(beta_work, "beta_work"), _stream()),
+               "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)
     @staticmethod
@@ -701,17 +710,26 @@ class _HipBackend:
     @staticmethod
     def assemble(jobs):
         """jobs: [((rows, cols), [term, ...])] with term = (src fp32 tensor, ld, col0 or int32 column-map tensor[, red, red_stride]) ->
-        fp32 tensors [rows, cols] (1-D when rows == 1... no: always [rows, cols]) = the sums of the terms, all in one launch
+        fp32 tensors [rows, cols] = the sums of the terms (a job may name its destination: ((rows, cols), terms, (matrix, col0)) writes that
+        column window of an existing fp32 matrix and returns the matrix), all in one launch
         (hs_assemble, csrc/small_ops.hip).  The element (r, c) of a term is src.flat[r * ld + col(c) (+ k * red_stride, summed over k < red)]."""
         lib = load_library()
         outs, keep = [], []
         for k0 in range(0, len(jobs), 8):
             grp = jobs[k0:k0 + 8]
             arr = (hsAsmJob * len(grp))()
-            for a, ((rows, cols), terms) in zip(arr, grp):
+            for a, job in zip(arr, grp):
+                (rows, cols), terms = job[:2]
                 dev = terms[0][0].device
-                out = torch.empty(rows, cols, device=dev, dtype=torch.float32)
-                a.dst, a.dst_ld, a.rows, a.cols, a.n_terms = out.data_ptr(), cols, rows, cols, len(terms)
+                if len(job) > 2:        # (tensor [rows, >= col0 + cols] fp32 contiguous, col0): a column window of an existing matrix
+                    out, c0 = job[2]
+                    if out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 2 or out.shape[0] != rows or c0 + cols > out.shape[1]:
+                        raise RuntimeError("assemble: destination window outside its matrix")
+                    a.dst, a.dst_ld = out.data_ptr() + 4 * int(c0), out.shape[1]
+                else:
+                    out = torch.empty(rows, cols, device=dev, dtype=torch.float32)
+                    a.dst, a.dst_ld = out.data_ptr(), cols
+                a.rows, a.cols, a.n_terms = rows, cols, len(terms)
                 for t, term in zip(a.term, terms):
                     src, ld, col = term[:3]
                     t.src, t.ld = _dev(src, "assemble source").value, int(ld)

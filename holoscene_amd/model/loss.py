@@ -48,6 +48,7 @@ class _fused_core_loss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, depth, nmap, opac, g1, g2, sdf, rgb_gt, depth_gt, n_gt, gt_mask, segs, weights):
+        ctx.set_materialize_grads(False)     # (the seven logging terms would otherwise reach backward as a zero-FILLED tensor: one launch)
         w_rgb, w_depth, w_l1, w_cos, w_opac, w_eik, w_smooth = weights
         dev = rgb.device
         R = rgb.shape[0]
@@ -77,6 +78,8 @@ class _fused_core_loss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_terms):
+        if g is None:
+            return (None,) * 13
         one = _ONE.get(str(g.device))
         if one is not None and g.data_ptr() == one.data_ptr():    # the root cotangent 1.0 (unit_cotangent): the stored gradients are the answer
             grads = tuple(ctx.saved_tensors)

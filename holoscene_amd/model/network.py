@@ -729,8 +729,15 @@ class _fused_appearance(torch.autograd.Function):
             w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many([(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)])
             gWr2 = w_r2[:3]
             gbr2 = gb[4, :3]
-            gWr0 = torch.cat([w_r0x[:, 32:113], w_r0f], 1)
-            gWc0 = w_c0[:, :32]
+            if w_r0x.is_cuda and w_r0x.dtype == torch.float32 and w_r0x.is_contiguous() and w_r0f.is_contiguous() and w_c0.is_contiguous():
+                # the two halves of dWr0 side by side and dWc0's 32 real columns: one launch instead of a concatenation and a strided copy
+                gWr0 = torch.empty(w_r0x.shape[0], 81 + w_r0f.shape[1], device=dev)
+                _, _, gWc0 = be.assemble([((w_r0x.shape[0], 81), [(w_r0x, w_r0x.shape[1], 32)], (gWr0, 0)),
+                                          ((w_r0f.shape[0], w_r0f.shape[1]), [(w_r0f, w_r0f.shape[1], 0)], (gWr0, 81)),
+                                          ((w_c0.shape[0], 32), [(w_c0, w_c0.shape[1], 0)])])
+            else:
+                gWr0 = torch.cat([w_r0x[:, 32:113], w_r0f], 1)
+                gWc0 = w_c0[:, :32]
         g_emb = None
         if ctx.needs_input_grad[3]:
             table = ctx.table
@@ -1814,18 +1821,21 @@ class HoloSceneNetwork(nn.Module):
             t_rand = torch.rand(R, S, device=dev)
         out = {"ray_dirs": torch.empty(R, 3, device=dev), "cam_loc": torch.empty(R, 3, device=dev), "depth_scale": torch.empty(R, 1, device=dev),
                "z0": torch.empty(R, S, device=dev), "beta_init": torch.empty(R, device=dev),
+               "beta_work": torch.empty(R, device=dev),      # a second copy for the sampler to iterate on (taken by the first sample() call)
                "x0": torch.empty(R * S, 3, device=dev), "x0_grid": torch.empty(R * S, 3, device=dev),   # positions of z0: the sampler's first sweep
                "rot": torch.empty(3, 3, device=dev)}          # pose[0, :3, :3]^T, written by the kernel
         _be._backend.ray_setup(uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
                                pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
                                None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
                                float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
-                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift, out["rot"])
+                               out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift, out["rot"],
+                               beta_work=out["beta_work"])
         return out
 
     def sample(self, rays, rng=None, idx=None):
         return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng, z0=rays.get("z0"),
-                                           beta_init=rays.get("beta_init"), x0=(rays["x0"], rays["x0_grid"]) if "x0" in rays else None)
+                                           beta_init=rays.get("beta_init"), x0=(rays["x0"], rays["x0_grid"]) if "x0" in rays else None,
+                                           beta_work=rays.pop("beta_work", None))
 
     def wants_background(self, iter_step):
         return bool(self.use_bg_reg and iter_step % self.render_bg_iter == 0)

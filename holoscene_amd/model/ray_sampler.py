@@ -181,12 +181,13 @@ class ErrorBoundSampler(RaySampler):
         return net.get_multi_object_sdf_vals(points, idx)
 
     @torch.no_grad()
-    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None, z0=None, beta_init=None, x0=None):
+    def get_z_vals(self, ray_dirs, cam_loc, model, idx=None, rng=None, z0=None, beta_init=None, x0=None, beta_work=None):
         """z0 / beta_init (/ x0 = positions (x, x01) of z0): optionally the first uniform depths and Lemma-2 beta already produced
-        by the fused ray-setup kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference."""
+        by the fused ray-setup kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference.
+        beta_work: a copy of beta_init this call may overwrite (its per-ray beta state), saving the clone."""
         if SAMPLER_IMPL == "hip":
             if ray_dirs.is_cuda and self.device_control_ok(model, idx):
-                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init, x0)
+                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init, x0, beta_work=beta_work)
             return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
         if SAMPLER_IMPL != "torch":
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
@@ -285,7 +286,7 @@ class ErrorBoundSampler(RaySampler):
         return z_out, z_eik
 
 
-    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, x0=None, bounds=None):
+    def _get_z_vals_device(self, ray_dirs, cam_loc, model, idx, rng, z0=None, beta_init=None, x0=None, bounds=None, beta_work=None):
         """Algorithm 1 with device-side loop control: max_total_iters unrolled rounds of gated kernels, zero host syncs."""
         be = _be._backend
         dev = ray_dirs.device
@@ -300,15 +301,23 @@ class ErrorBoundSampler(RaySampler):
             d0 = z0[:, 1:] - z0[:, :-1]
             beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (d0 ** 2.0).sum(-1)).contiguous()
         else:
-            beta = beta_init.clone()
+            beta = beta_work if beta_work is not None else beta_init.clone()
         nr = self.max_total_iters
         if self._ctl_init is None or self._ctl_init.device != dev or self._ctl_init.numel() != (nr + 1) * 4 + nr:
             init = torch.zeros((nr + 1) * 4 + nr)            # [nr+1] hsSamplerCtl slots (slot r+1 = state after round r) | [nr] per-round max beta
             init[:4] = torch.tensor([1.0, 0.5, 0.0, 0.0])     # slot 0: {running, half, m = 0, rounds = 0}
             self._ctl_init = init.to(dev)
-        state = self._ctl_init.clone()                        # one copy initialises the control slots and zeroes the max-beta cells
-        ctl, beta_max_all = state[:(nr + 1) * 4].view(nr + 1, 4), state[(nr + 1) * 4:]
-        ci = ctl.view(torch.int32)
+        if FUSE_DRAW and _be.zero_pool_armed(dev, nr):
+            # no control slots between the rounds in this form (below): slot 0 is only ever read -- the constant itself serves --, the end
+            # state is written whole, and the per-round maxima come zeroed from the iteration's accumulator pool: no copy launch
+            ctl = None
+            ctl_first, ctl_last = self._ctl_init[:4], torch.empty(4, device=dev)
+            beta_max_all = _be.zeros_small(nr, dev)
+        else:
+            state = self._ctl_init.clone()                    # one copy initialises the control slots and zeroes the max-beta cells
+            ctl, beta_max_all = state[:(nr + 1) * 4].view(nr + 1, 4), state[(nr + 1) * 4:]
+            ctl_first, ctl_last = ctl[0], ctl[nr]
+        ci = None if ctl is None else ctl.view(torch.int32)
         z = torch.empty(R, ld, device=dev)
         sdf = torch.empty(R, ld, device=dev)
         cam = (cam_loc.expand(R, 3) if cam_loc.shape[0] != R else cam_loc).contiguous()
@@ -345,7 +354,7 @@ class ErrorBoundSampler(RaySampler):
                 else:
                     be.sampler_update(z, sdf, r * S, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1],
                                       gate=gate)
-            be.sampler_draw_steps(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[0], ctl[nr], beta_max_all, beta0, S, nr, nr)
+            be.sampler_draw_steps(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl_first, ctl_last, beta_max_all, beta0, S, nr, nr)
         else:
             for r in range(nr):
                 gate, m_dev = (ctl[r, 0:1], ctl[r, 1:2]), ci[r, 2:3]
@@ -358,7 +367,7 @@ class ErrorBoundSampler(RaySampler):
                     be.sampler_draw_step(z, sdf, beta, 0, float(self.add_tiny), None, S, samples, ctl[r], ctl[r + 1], beta_max_all[r:r + 1], beta0, S,
                                          nr, cam, dirs, df, x, x01)
             be.sampler_draw_step(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[nr - 1], ctl[nr], beta_max_all[nr - 1:nr], beta0, S, nr)
-        ctl_end = ctl[nr]
+        ctl_end = ctl_last
         pick = None
         if self.N_samples_extra > 0:
             if "perm" in rng:   # explicit permutation of the (then host-known) merged set: parity tests
@@ -384,7 +393,7 @@ class ErrorBoundSampler(RaySampler):
         be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u,
                          near_rays=None if bounds is None else bounds[0], far_rays=None if bounds is None else bounds[1])
         net.invalidate_packed_weights()
-        self._rounds = ci[nr, 3:4]
+        self._rounds = ctl_last.view(torch.int32)[3:4]
         return z_out, z_eik
 
     def _get_z_vals_torch(self, ray_dirs, cam_loc, model, idx, rng, z0=None, bounds=None):

@@ -220,7 +220,9 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
                  float divide_factor, float *x /* or NULL */, float *x01,
                  float offset_shift /* added to ray_offset: 0, or -0.5 when ray_offset holds raw U[0,1) draws */,
-                 float *rot_out /* NULL, or [3,3]: the world-to-camera rotation pose[:3,:3]^T (network.py:917) */, void *stream);
+                 float *rot_out /* NULL, or [3,3]: the world-to-camera rotation pose[:3,:3]^T (network.py:917) */,
+                 float *beta_work /* NULL, or [R]: a second copy of beta_init -- the sampler's working state, which its update kernels overwrite */,
+                 void *stream);
 
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
