@@ -332,15 +332,17 @@ class KernelTimers:
 
 
 def cpu_baseline(seconds):
-    """all host threads (the headline cpu_baseline object) + the reference's own setting, torch.set_num_threads(1)
-    (training/holoscene_train.py:46), reported inside it as "one_thread"."""
+    """The CPU oracle timed twice -- the reference's own setting, torch.set_num_threads(1) (training/holoscene_train.py:46), and all host
+    threads -- and the FASTER of the two reported as the baseline (`cores` = the threads it used; at configs[0]'s size the per-op thread
+    fan-out costs more than it gains, so that is normally the one-thread run); the other run rides along as "other_setting"."""
     n_all = torch.get_num_threads()
     torch.set_num_threads(1)
     one = _cpu_baseline_run(seconds * 0.4)
     torch.set_num_threads(n_all)
-    out = _cpu_baseline_run(seconds * 0.6)
-    out["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
-    return out
+    many = _cpu_baseline_run(seconds * 0.6)
+    best, other = (one, many) if one["value"] >= many["value"] else (many, one)
+    best["other_setting"] = {"value": other["value"], "unit": other["unit"], "cores": other["cores"], "sample": other["sample"]}
+    return best
 
 
 def _cpu_baseline_run(seconds):
@@ -563,7 +565,7 @@ def main():
         + 7 * 4 * n_params + 4 * n_params
     dom = kernels[0] if kernels else None
     traffic, traffic_src = None, None
-    for cand in ("r02", "r01"):
+    for cand in ("r03", "r02", "r01"):
         pmc_file = os.path.join(ROOT, "profiles", cand, "pmc_traffic.json")
         if os.path.exists(pmc_file):
             pm = json.load(open(pmc_file))
