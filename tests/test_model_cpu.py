@@ -153,3 +153,40 @@ def test_per_object_networks_match_reference(name):
     background (bg) initialisation."""
     from object_helpers import check_object_model
     check_object_model(load(name), "cpu", strict=True)
+
+
+# ------------------------------------------------------------------------------------ host logic added in round 3
+def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
+    """_pair_slices: the jobs of one hs_wgrad_pairs launch get workgroups in proportion to their bytes, the counts add up to the budget,
+    no job gets more slices than it has tiles, and no slice is more than ~15 % above the mean load."""
+    import math
+    from holoscene_amd.model.network import _PAIR_TILE_BYTES, _pair_slices
+    for T, Te, npair in [(3136, 512, 2), (3136, 512, 1), (12288, 1024, 2), (40, 8, 2), (3, 1, 2)]:
+        jobs = [((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True), ((256, 80), T, 1, False),
+                ((256, 256, "rm"), Te, 1, True), ((256, 80, "rm"), Te, 1, True)]
+        cut = _pair_slices(jobs)
+        assert all(1 <= c <= j[1] for c, j in zip(cut, jobs))
+        total_tiles = sum(j[1] for j in jobs)
+        assert sum(cut) == min(256, total_tiles)
+        if T >= 3136:
+            per = [(_PAIR_TILE_BYTES[tuple(j[0][:2])] if j[3] else 64 * j[0][0]) * j[2] for j in jobs]
+            load = [math.ceil(j[1] / c) * p for j, c, p in zip(jobs, cut, per)]
+            mean = sum(j[1] * p for j, p in zip(jobs, per)) / 256
+            assert max(load) <= 1.15 * mean, (cut, load, mean)
+
+
+def test_render_outputs_defer_entries_until_read():
+    from holoscene_amd.model.network import _Outputs
+    calls = []
+    o = _Outputs({"a": 1})
+    o.defer("b", lambda: calls.append(1) or 2)
+    assert "b" in o and not calls                  # membership does not evaluate
+    assert o["a"] == 1 and not calls
+    assert o["b"] == 2 and calls == [1] and o["b"] == 2 and calls == [1]      # once
+    o.defer("c", lambda: 3)
+    assert sorted(o.keys()) == ["a", "b", "c"] and dict(o) == {"a": 1, "b": 2, "c": 3} and len(o) == 3
+    o.defer("d", lambda: 4)
+    assert o.pop("d") is None and "d" not in o      # dropped unevaluated
+    assert o.get("zz", 7) == 7
+    with pytest.raises(KeyError):
+        o["zz"]
