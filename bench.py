@@ -194,7 +194,9 @@ def _work_wgrad_pairs(a, k):
         (NA, W), p0, p1 = job[0][:2], job[2], job[3]
         rows = job[4] if len(job) > 4 else n
         for pr in (p0, p1):
-            if pr is not None:
+            if pr is not None and pr[1] is None:      # column sums of A only (a bias gradient)
+                by += rows * NA * 2
+            elif pr is not None:
                 fl += 2 * rows * NA * W
                 by += rows * (NA + W) * 2
     return fl, by
@@ -251,7 +253,7 @@ TIMED = {
     "trunk_rr_fwd_grad": ("k_rr_fwd_grad (d min / dx by one reverse pass: W1^T, W0^T, E^T)", _work_rr_fwd_grad),
     "trunk_rr_bwd_grad": ("k_rr_bwd_grad (double backward, gradient part: E, W0, W1)", _work_rr_bwd_grad),
     "trunk_rr_bwd_value": ("k_rr_bwd_value (double backward, value part: W2^T, W1^T, W0^T)", _work_rr_bwd_value),
-    "wgrad_pairs": ("k_wgrad_pairs (trunk weight gradients: three pair-accumulating products on tile-packed operands, one launch)", _work_wgrad_pairs),
+    "wgrad_pairs": ("k_wgrad_pairs (weight gradients: all products of the trunk backward in one launch, all of the appearance backward in another; slices cut by bytes)", _work_wgrad_pairs),
     "trunk_rr_pack": ("k_rr_pack (transposed fragment images)", None),
 }
 LIBRARY_GEMM = "library GEMMs (hipBLASLt through torch.bmm: weight gradients not taken by k_wgrad_rows)"

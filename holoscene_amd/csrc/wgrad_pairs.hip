@@ -205,6 +205,8 @@ __global__ __launch_bounds__(kThreadsP) void k_wgrad_pairs(PairJobs jobs) {
     else if (job.kind == HS_WGP_32x256) pair_slice<32, 256, 256, false, true>(job, slice, S, lds);        // y~^T h1 + onehot^T u1~ (A row-major [M, 32])
     else if (job.kind == HS_WGP_256x256_RM) pair_slice<256, 256, 256, false, false>(job, slice, S, lds);  // row-major operands (the value+Jacobian rows
     else if (job.kind == HS_WGP_256x80_RM) pair_slice<256, 128, 80, false, false>(job, slice, S, lds);    //  of the Eikonal points: gA1^T H0, gA0^T Xp)
+    else if (job.kind == HS_WGP_256x128_RM) pair_slice<256, 128, 128, false, false>(job, slice, S, lds);  // the appearance branch's products (row-major
+    else if (job.kind == HS_WGP_32x256_RM) pair_slice<32, 256, 256, false, false>(job, slice, S, lds);    //  activations): gA^T xin, gy^T r1
 }
 
 }  // namespace
@@ -220,7 +222,7 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
     pj.first[0] = 0;
     for (int i = 0; i < n_jobs; i++) {
         const hsWgradPairJob &j = jobs[i];
-        if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_256x80_RM) return HS_ERR_ARG;
+        if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_32x256_RM) return HS_ERR_ARG;
         // a slice is a whole number of 32-row tiles: the tile-packed operands are addressed by tile
         if (j.slices < 1 || j.M < 32 || (j.M % 32) != 0 || j.rows < 0 || j.rows > j.M) return HS_ERR_ARG;
         const bool no_b = !j.B0 && j.ones && (j.kind == HS_WGP_256x80 || j.kind == HS_WGP_256x80_RM) && !j.A1;     /* column sums only */

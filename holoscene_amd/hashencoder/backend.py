@@ -675,7 +675,7 @@ class _HipBackend:
                                          _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf), _dev(A1t, "A1t", bf),
                                          _dev(g_feat, "g_feat"), ctypes.c_int64(n), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_bwd_value")
 
-    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2, (256, 256, "rm"): 3, (256, 80, "rm"): 4}
+    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2, (256, 256, "rm"): 3, (256, 80, "rm"): 4, (256, 128, "rm"): 5, (32, 256, "rm"): 6}
 
     @staticmethod
     def wgrad_pairs(jobs, n, outs_into=None):

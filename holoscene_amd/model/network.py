@@ -466,7 +466,7 @@ def _rr_slices(n, budget=256):
     return fine, coarse, coarse
 
 
-_PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432}      # bytes of one operand pair per 32-row tile
+_PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432, (256, 128): 24576}      # bytes of one operand pair per 32-row tile
 
 
 def _pair_slices(jobs, budget=256):
@@ -670,6 +670,11 @@ APPEARANCE_RELU_MASKS = os.environ.get("HOLOSCENE_APPEARANCE_RELU_MASKS", "1") !
 BG_IMPL = os.environ.get("HOLOSCENE_BG_IMPL", "hip")
 
 
+# weight gradients of the appearance branch: "pairs" = six row-major jobs of one hs_wgrad_pairs launch (byte-proportional slices),
+# "rows" = hs_wgrad_rows (csrc/wgrad.hip: 128 equal slices per product)
+APPEARANCE_WGRAD = os.environ.get("HOLOSCENE_APPEARANCE_WGRAD", "pairs")
+
+
 class _fused_appearance(torch.autograd.Function):
     """(points, view dirs, normals, colour hash table, colour-MLP and rendering-MLP weights) -> rgb [B,3].
 
@@ -726,7 +731,15 @@ class _fused_appearance(torch.autograd.Function):
         need_w = ctx.needs_input_grad[8]
         gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbr2 = None
         if need_w:
-            w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many([(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)])
+            prods = [(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)]
+            if APPEARANCE_WGRAD == "pairs" and B % 32 == 0 and xin.shape[1] == 128 and all(t.is_contiguous() for pr in prods for t in pr):
+                # the six products as single-pair row-major jobs of ONE hs_wgrad_pairs launch: 256 workgroups, slices cut by bytes (12.2)
+                shapes = [(a.shape[1], b.shape[1], "rm") for a, b in prods]
+                cut = _pair_slices([(sh, B // 32, 1, True) for sh in shapes])
+                stacks = be.wgrad_pairs([(sh, c, pr, None, B) for sh, c, pr in zip(shapes, cut, prods)], B)
+                w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = be.sum_slices(stacks)
+            else:
+                w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many(prods)
             gWr2 = w_r2[:3]
             gbr2 = gb[4, :3]
             if w_r0x.is_cuda and w_r0x.dtype == torch.float32 and w_r0x.is_contiguous() and w_r0f.is_contiguous() and w_c0.is_contiguous():

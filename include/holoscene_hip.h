@@ -562,6 +562,8 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
 #define HS_WGP_32x256 2
 #define HS_WGP_256x256_RM 3     /* as HS_WGP_256x256 / _256x80 with BOTH operands row-major ([rows, 256] / [rows, 80]) */
 #define HS_WGP_256x80_RM 4
+#define HS_WGP_256x128_RM 5     /* A [rows, 256], B [rows, 128], both row-major */
+#define HS_WGP_32x256_RM 6      /* A [rows, 32],  B [rows, 256], both row-major */
 typedef struct hsWgradPairJob {
     const void *A0, *B0, *A1, *B1;      /* second pair optional (both NULL) */
     void *part;
