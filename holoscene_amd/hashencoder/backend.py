@@ -147,7 +147,8 @@ def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
-            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift"]
+            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
+            "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_pack_t", "hs_appearance2_bwd"]
 
 
 def _check(rc, what):
@@ -802,6 +803,51 @@ class _HipBackend:
             outs.append(out)
         _check(lib.hs_sum_slices(arr, len(partials), _stream()), "hs_sum_slices")
         return outs
+
+    # ---- colour branch, wave-tile form (csrc/appearance2.hip)
+    @staticmethod
+    def appearance2_pack(wc0, wc1, wr0, wr1, wr2, biases):
+        """fp32 effective matrices + (bc0, bc1, br0, br1, br2) -> dict of fragment images (stream, R2f, bias)."""
+        lib = load_library()
+        lib.hs_appearance2_pack_bytes.restype = ctypes.c_int64
+        dev = wc0.device
+        nb = [int(lib.hs_appearance2_pack_bytes(i)) for i in range(3)]
+        P = {"stream": torch.empty(nb[0], device=dev, dtype=torch.uint8), "R2f": torch.empty(nb[1], device=dev, dtype=torch.uint8),
+             "bias": torch.empty(nb[2] // 4, device=dev)}
+        keep = [t.detach().float().contiguous() for t in (wc0, wc1, wr0, wr1, wr2) + tuple(biases)]
+        _check(lib.hs_appearance2_pack(*[_dev(t, "w") for t in keep[:2]], _dev(keep[2], "wr0"), keep[2].shape[1], _dev(keep[3], "wr1"), _dev(keep[4], "wr2"),
+                                       *[_dev(t, "b") for t in keep[5:]], _dev(P["stream"], "stream", torch.uint8), _dev(P["R2f"], "R2f", torch.uint8),
+                                       _dev(P["bias"], "bias"), _stream()), "hs_appearance2_pack")
+        return P
+
+    @staticmethod
+    def appearance2_packT(wc0, wc1, wr0, wr1, wr2):
+        """fp32 effective matrices -> the transposed fragment image of the backward kernel (uint8 tensor)."""
+        lib = load_library()
+        lib.hs_appearance2_pack_t_bytes.restype = ctypes.c_int64
+        keep = [t.detach().float().contiguous() for t in (wc0, wc1, wr0, wr1, wr2)]
+        img = torch.empty(int(lib.hs_appearance2_pack_t_bytes()), device=wc0.device, dtype=torch.uint8)
+        _check(lib.hs_appearance2_pack_t(_dev(keep[0], "wc0"), _dev(keep[1], "wc1"), _dev(keep[2], "wr0"), keep[2].shape[1], _dev(keep[3], "wr1"),
+                                        _dev(keep[4], "wr2"), _dev(img, "streamT", torch.uint8), _stream()), "hs_appearance2_pack_t")
+        return img
+
+    @staticmethod
+    def appearance2_bwd(g_rgb, rgb, normals, masks, streamT, gy, GR1t, GR0t, GFVt, GHCt, d_normals, g_featc, gb2):
+        lib = load_library()
+        bf = torch.bfloat16
+        _check(lib.hs_appearance2_bwd(_dev(g_rgb, "g_rgb"), _dev(rgb, "rgb"), _dev(normals, "normals"), _dev(masks, "masks", torch.int32),
+                                      _dev(streamT, "streamT", torch.uint8), _dev(gy, "gy", bf), _dev(GR1t, "GR1t", bf), _dev(GR0t, "GR0t", bf),
+                                      _dev(GFVt, "GFVt", bf), _dev(GHCt, "GHCt", bf), _dev(d_normals, "d_normals"), _dev(g_featc, "g_featc"),
+                                      _dev(gb2, "gb2"), ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance2_bwd")
+
+    @staticmethod
+    def appearance2_fwd(featc, points, dirs, normals, P, XAt, HCt, FVt, R0t, R1t, masks, rgb):
+        lib = load_library()
+        bf, u8 = torch.bfloat16, torch.uint8
+        _check(lib.hs_appearance2_fwd(_dev(featc, "featc"), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
+                                      _dev(P["stream"], "stream", u8), _dev(P["R2f"], "R2f", u8), _dev(P["bias"], "bias"),
+                                      _dev(XAt, "XAt", bf), _dev(HCt, "HCt", bf), _dev(FVt, "FVt", bf), _dev(R0t, "R0t", bf), _dev(R1t, "R1t", bf),
+                                      _dev(masks, "masks", torch.int32), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]), _stream()), "hs_appearance2_fwd")
 
     @staticmethod
     def appearance_mask_words(B):

@@ -433,6 +433,30 @@ int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals
                       void *g_fv, void *gA_hc, float *d_normals, float *g_featc, float *gbias, int64_t B,
                       const uint64_t *relu_masks /* NULL: the masks are taken from r1, r0, hc; else those three may be NULL */, void *stream);
 
+/* ------------------------------------------------------------------ 7c. the colour branch in wave-tile form (csrc/appearance2.hip)
+ * Same function as hs_appearance_fwd / _bwd; a wave owns 32 samples through all five layers, the workgroup shares a pipeline of weight
+ * chunks through LDS.  Weights as FRAGMENT images built by hs_appearance2_pack from the fp32 effective matrices (Wc0 [256,32], Wc1
+ * [256,256], Wr0 [256,ldr0 >= 337], Wr1 [256,256], Wr2 [>=3,256]): buffers of hs_appearance2_pack_bytes(0: streamed image, 1: R2f,
+ * 2: bias block) bytes.  featc [16,n,2] fp32 level-major; points, dirs, normals [n,3].  Kept for the backward pass and the weight
+ * gradients, all TILE-PACKED (section 11): XAt [tiles][8 k-steps][64] x 16 B = [colour features | encodings] in the kernel's slot order
+ * (hs_appearance2_enc_column), HCt, FVt, R0t, R1t [tiles][16][64] x 16 B; masks [tiles][3][64][4] uint32 = the ReLU signs of hc, r0, r1.
+ * rgb [n,3]. */
+int64_t hs_appearance2_pack_bytes(int32_t which);
+int hs_appearance2_enc_column(int32_t half, int32_t slot);     /* encoded-input column (0..80) of slot 0..47 of lane half 0/1, -1 = padding */
+int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, const float *bc0,
+                        const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias, void *stream);
+int hs_appearance2_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *stream_image, const void *R2f,
+                       const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, void *stream);
+/* Backward data path of the same: the transposed fragment image (hs_appearance2_pack_t_bytes() bytes, built by hs_appearance2_pack_t from the same
+ * fp32 matrices), the forward pass's masks and rgb.  Outputs: gy [n,32] bf16 row-major (cotangent of the pre-sigmoid outputs, columns 0..2),
+ * GR1t, GR0t, GFVt, GHCt tile-packed (pre-activation cotangents of r1, r0, the feature vector, hc), d_normals [n,3], g_featc [16,n,2] fp32
+ * (level-major), gb2 [ceil(n / 32), 4] = per-tile partial sums of the last layer's bias gradient (columns 0..2; may be NULL).  The other bias gradients are column sums of the tile-packed
+ * cotangents: hs_wgrad_pairs produces them beside the weight gradients (hsWgradPairJob::colsum). */
+int64_t hs_appearance2_pack_t_bytes(void);
+int hs_appearance2_pack_t(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, void *streamT_image, void *stream);
+int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normals, const uint32_t *masks, const void *streamT_image, void *gy, void *GR1t,
+                       void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, void *stream);
+
 /* fp32 master matrices -> bf16 operand images in ONE launch: dst [dst_rows, dst_cols] (row-major bf16) receives the
  * [rows, cols] block of src (leading dimension ld) starting at (row0, col0) -- or, with transpose != 0, its transpose
  * (dst[r][c] = src[row0+c][col0+r]) -- zero-padded to the destination shape. */
