@@ -130,6 +130,16 @@ def _work_appear_bwd(a, k):
     return B * (CF + RN), B * (12 + 2 * (3 * 256) + 2 * (5 * 256) + 128 + 12)
 
 
+def _work_appear2_fwd(a, k):      # in: colour features, point / dir / normal; out: assembled inputs (8 k-steps), four layer outputs, masks, rgb
+    B = a[1].shape[0]
+    return B * (CF + RN), B * (128 + 36 + 2 * (128 + 4 * 256) + 48 + 12)
+
+
+def _work_appear2_bwd(a, k):      # in: cotangent, rgb, normals, masks; out: y~ [32], four cotangents, d normals, d colour features
+    B = a[0].shape[0]
+    return B * (CF + RN), B * (12 + 12 + 12 + 48 + 2 * (32 + 4 * 256) + 12 + 128)
+
+
 def _work_scatter(a, k):
     B, C, L = a[5], a[7], a[8]
     return 0, B * (2 * L * 8 * C * 4 + L * C * 4 + L * 3 * C * 4 + 12)
@@ -220,6 +230,9 @@ TIMED = {
     "trunk_mlp_bwd": ("k_trunk_bwd (trunk data-gradient chain + last-layer wgrad)", _work_trunk_bwd),
     "appearance_fwd": ("k_appear_fwd (colour-feature MLP + rendering network)", _work_appear_fwd),
     "appearance_bwd": ("k_appear_bwd", _work_appear_bwd),
+    "appearance2_fwd": ("k_appear2_fwd (colour-feature MLP + rendering network, wave-tile form: weight chunks shared through LDS)", _work_appear2_fwd),
+    "appearance2_bwd": ("k_appear2_bwd (its data-gradient chain; reads the ReLU masks only)", _work_appear2_bwd),
+    "appearance2_pack": ("k_appear2_pack (fragment images of the colour branch, forward + transposed)", None),
     "bwd_jac": ("hs_hash_bwd_jac (table scatter: k_hash_bwd_jac + k_hash_bin_reduce)", _work_scatter),
     "adam_flat": ("k_adam_flat", _work_adam),
     "sampler_update": ("k_sampler_update", None),

@@ -64,12 +64,12 @@ __host__ __device__ inline int enc_column(int h, int j) {
 
 // ---------------------------------------------------------------------------------------------------------------- weight images
 // fp32 effective matrices -> the streamed image (kStreamBytes), W_R2's fragments (one tile, resident) and the bias block
-__global__ __launch_bounds__(256) void k_appear2_pack(const float *__restrict__ Wc0, const float *__restrict__ Wc1, const float *__restrict__ Wr0, int ldr0,
-                                                      const float *__restrict__ Wr1, const float *__restrict__ Wr2, const float *__restrict__ bc0,
-                                                      const float *__restrict__ bc1, const float *__restrict__ br0, const float *__restrict__ br1,
-                                                      const float *__restrict__ br2, uint16_t *__restrict__ stream, uint16_t *__restrict__ R2f,
-                                                      float *__restrict__ bias) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment slot per thread
+constexpr int kPackSlots = kStreamBytes / 16 + HS * 64 + kA2Bias;      // slots of the forward images (one thread each)
+__device__ __forceinline__ void pack_slot(int idx, const float *__restrict__ Wc0, const float *__restrict__ Wc1, const float *__restrict__ Wr0, int ldr0,
+                                          const float *__restrict__ Wr1, const float *__restrict__ Wr2, const float *__restrict__ bc0,
+                                          const float *__restrict__ bc1, const float *__restrict__ br0, const float *__restrict__ br1,
+                                          const float *__restrict__ br2, uint16_t *__restrict__ stream, uint16_t *__restrict__ R2f,
+                                          float *__restrict__ bias) {
     constexpr int nstream = kStreamBytes / 16, nr2 = HS * 64;
     float v[8];
     uint16_t *dst;
@@ -120,9 +120,8 @@ __global__ __launch_bounds__(256) void k_appear2_pack(const float *__restrict__ 
 
 // the transposed image for the backward pass (kStreamTBytes): every product is D[input unit][sample] = sum_k W[k][input unit] g[k][sample], i.e. the A
 // operand is W^T with the OUTPUT unit k of the layer as the reduction index, permuted like every 256-deep reduction (wave_tile.h)
-__global__ __launch_bounds__(256) void k_appear2_packT(const float *__restrict__ Wc0, const float *__restrict__ Wc1, const float *__restrict__ Wr0, int ldr0,
-                                                       const float *__restrict__ Wr1, const float *__restrict__ Wr2, uint16_t *__restrict__ streamT) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_t_slot(int idx, const float *__restrict__ Wc0, const float *__restrict__ Wc1, const float *__restrict__ Wr0, int ldr0,
+                                            const float *__restrict__ Wr1, const float *__restrict__ Wr2, uint16_t *__restrict__ streamT) {
     if (idx >= kStreamTBytes / 16) return;
     const int byte = idx * 16, lane = idx & 63, m = lane & 31, h = lane >> 5;
     auto kperm = [&](int s, int e) { return 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); };
@@ -155,6 +154,17 @@ __global__ __launch_bounds__(256) void k_appear2_packT(const float *__restrict__
     uint4 pk;
     pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
     *reinterpret_cast<uint4 *>(streamT + (size_t)idx * 8) = pk;
+}
+
+// both images in one launch (streamT may be NULL: forward only)
+__global__ __launch_bounds__(256) void k_appear2_pack(const float *__restrict__ Wc0, const float *__restrict__ Wc1, const float *__restrict__ Wr0, int ldr0,
+                                                      const float *__restrict__ Wr1, const float *__restrict__ Wr2, const float *__restrict__ bc0,
+                                                      const float *__restrict__ bc1, const float *__restrict__ br0, const float *__restrict__ br1,
+                                                      const float *__restrict__ br2, uint16_t *__restrict__ stream, uint16_t *__restrict__ R2f,
+                                                      float *__restrict__ bias, uint16_t *__restrict__ streamT) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment slot per thread
+    if (idx < kPackSlots) pack_slot(idx, Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, bc0, bc1, br0, br1, br2, stream, R2f, bias);
+    else if (streamT != nullptr) pack_t_slot(idx - kPackSlots, Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, streamT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- helpers
@@ -673,12 +683,13 @@ int64_t hs_appearance2_pack_bytes(int32_t which) {
 int hs_appearance2_enc_column(int32_t h, int32_t j) { return (h < 0 || h > 1 || j < 0 || j >= 48) ? -1 : enc_column(h, j); }
 
 int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, const float *bc0,
-                        const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias, void *stream) {
+                        const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias,
+                        void *streamT_image, void *stream) {
     if (ldr0 < 337) return HS_ERR_ARG;
     if (!Wc0 || !Wc1 || !Wr0 || !Wr1 || !Wr2 || !bc0 || !bc1 || !br0 || !br1 || !br2 || !stream_image || !R2f || !bias) return HS_ERR_NULL;
-    const int slots = kStreamBytes / 16 + HS * 64 + kA2Bias;
+    const int slots = kPackSlots + (streamT_image ? kStreamTBytes / 16 : 0);
     k_appear2_pack<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)stream_image,
-                                                                       (uint16_t *)R2f, bias);
+                                                                       (uint16_t *)R2f, bias, (uint16_t *)streamT_image);
     return wt_check_launch();
 }
 
@@ -698,13 +709,6 @@ int hs_appearance2_fwd(const float *featc, const float *points, const float *dir
 }
 
 int64_t hs_appearance2_pack_t_bytes(void) { return (int64_t)kStreamTBytes; }
-
-int hs_appearance2_pack_t(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, void *streamT_image, void *stream) {
-    if (ldr0 < 337) return HS_ERR_ARG;
-    if (!Wc0 || !Wc1 || !Wr0 || !Wr1 || !Wr2 || !streamT_image) return HS_ERR_NULL;
-    k_appear2_packT<<<(kStreamTBytes / 16 + 255) / 256, 256, 0, (hipStream_t)stream>>>(Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, (uint16_t *)streamT_image);
-    return wt_check_launch();
-}
 
 int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normals, const uint32_t *masks, const void *streamT_image, void *gy, void *GR1t,
                        void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, void *stream) {

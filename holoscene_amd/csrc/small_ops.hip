@@ -32,8 +32,15 @@ __global__ __launch_bounds__(256) void k_assemble(AsmJobs jobs) {
             const hsAsmTerm &tm = jb.term[t];
             const float *p = tm.src + (int64_t)r * tm.ld + (tm.col_map ? tm.col_map[c] : tm.col0 + c);
             float s = 0.f;
-            if (wide) {
-                for (int k = lane; k < tm.red; k += 64) s += p[(int64_t)k * tm.red_stride];
+            if (wide) {       // eight independent loads in flight per lane (a plain loop is one dependent-latency load at a time: 22 us for 3 136 blocks)
+                float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int k = lane;
+                for (; k + 7 * 64 < tm.red; k += 8 * 64) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s8[u] += p[(int64_t)(k + 64 * u) * tm.red_stride];
+                }
+                for (; k < tm.red; k += 64) s8[0] += p[(int64_t)k * tm.red_stride];
+                s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
             } else {
                 for (int k = 0; k < tm.red; k++) s += p[(int64_t)k * tm.red_stride];
             }

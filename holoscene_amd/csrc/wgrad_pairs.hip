@@ -47,7 +47,8 @@ __device__ __forceinline__ uint16_t f2bf16p(float f) {
 // one 64-row chunk of an operand of logical width W (LDS tile width WT >= W): 16 bytes per thread and pass
 template <int W> struct ChunkP { uint4 v[(RCP * (W / 8) + kThreadsP - 1) / kThreadsP]; };
 
-// TP: W must be 256.  Piece index within the chunk = (tile 0..1, k-step, lane): contiguous in memory, exactly like a row-major chunk
+// TP: W / 16 k-steps per tile (256: the trunk's and the colour branch's activations, 128: the colour branch's assembled inputs).  Piece index
+// within the chunk = (tile 0..1, k-step, lane): contiguous in memory, exactly like a row-major chunk
 template <int W, bool TP>
 __device__ __forceinline__ ChunkP<W> load_chunk_p(const uint16_t *__restrict__ src, int64_t row0, int64_t row_end) {      // rows >= row_end read as zero
     ChunkP<W> c;
@@ -57,7 +58,7 @@ __device__ __forceinline__ ChunkP<W> load_chunk_p(const uint16_t *__restrict__ s
         const int idx = threadIdx.x + i * kThreadsP;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if constexpr (TP) {
-            const int row = 32 * (idx >> 10) + (idx & 31);       // piece (tile, s, lane): lane & 31 = row within the tile
+            const int row = 32 * (idx / (4 * W)) + (idx & 31);   // piece (tile, s, lane): 4 W pieces per tile, lane & 31 = row within the tile
             if (idx < N && row0 + row < row_end) v = *reinterpret_cast<const uint4 *>(src + (size_t)row0 * W + (size_t)idx * 8);
         } else {
             const int row = idx / SEG, seg = idx - row * SEG;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void store_chunk_p(uint16_t *lds, const ChunkP<W> &c)
         const int idx = threadIdx.x + i * kThreadsP;
         if (idx >= N) continue;
         if constexpr (TP) {
-            const int tile = idx >> 10, s = (idx >> 6) & 15, lane = idx & 63, row = 32 * tile + (lane & 31), h = lane >> 5;
+            const int tile = idx / (4 * W), s = (idx >> 6) % (W / 16), lane = idx & 63, row = 32 * tile + (lane & 31), h = lane >> 5;
             uint16_t *dst = lds + (size_t)row * P + 16 * s + 4 * h;        // neurons 16 s + 4 h + 0..3 | 16 s + 8 + 4 h + 0..3
             *reinterpret_cast<uint2 *>(dst) = make_uint2(c.v[i].x, c.v[i].y);
             *reinterpret_cast<uint2 *>(dst + 8) = make_uint2(c.v[i].z, c.v[i].w);
@@ -126,10 +127,18 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
         for (int b = 0; b < TM; b++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
+    // job.colsum: column sums of the FIRST pair's A operand (a bias gradient) beside the product -- one more MFMA per A fragment against
+    // an all-ones B fragment, on the waves of column group 0 (the rows are streaming through anyway; the kernel is bound by their bytes)
+    const bool want_cs = job.colsum != nullptr && wm == 0;
+    f32x16 accs[TN];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) accs[a][i] = 0.f;
     const int L16 = lane & 15, cg = (lane >> 4) & 1, rg = lane >> 5;
     const uint32_t a_off = (uint32_t)(((rg * 8 + (L16 >> 2)) * PA + wn * TN * 32 + 16 * cg + 4 * (L16 & 3)) * 2);
     const uint32_t b_off = (uint32_t)(((rg * 8 + (L16 >> 2)) * PB + wm * TM * 32 + 16 * cg + 4 * (L16 & 3)) * 2);
-    auto multiply = [&](int cur) {
+    auto multiply = [&](int cur, bool first_pair) {
         const uint32_t abase = lds_addr_p(Abuf[cur]) + a_off, bbase = lds_addr_p(Bbuf[cur]) + b_off;
 #pragma unroll
         for (int ks = 0; ks < RCP / 16; ks++) {
@@ -142,6 +151,13 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
             for (int a = 0; a < TN; a++)
 #pragma unroll
                 for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            if (want_cs && first_pair) {
+                const uint32_t one2 = 0x3f803f80u;      // bf16 1.0 twice
+                const uint32_t w4[4] = {one2, one2, one2, one2};
+                const bf16x8 ones = *reinterpret_cast<const bf16x8 *>(w4);
+#pragma unroll
+                for (int a = 0; a < TN; a++) accs[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], ones, accs[a], 0, 0, 0);
+            }
         }
     };
     // chunk sequence: all chunks of pair 0, then all chunks of pair 1 (when present) -- one pipeline, one chunk in flight ahead
@@ -172,13 +188,20 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
             ca = load_chunk_p<NA, ATP>(A, r0, end_a);
             if (B) cb = load_chunk_p<WB, BTP>(B, r0, end_b);
         }
-        multiply(cur);
+        multiply(cur, c < nchunks);
         if (c + 1 < total) {
             store_chunk_p<NA, NA, ATP>(Abuf[cur ^ 1], ca);
             if (B) store_chunk_p<WB, MB, BTP>(Bbuf[cur ^ 1], cb);
             ones_column(Bbuf[cur ^ 1], c + 1 < nchunks);
         }
         __syncthreads();
+    }
+    if (want_cs && (lane & 31) == 0) {      // every column of the ones product holds the sum: lanes 0 and 32 write their 16 rows each
+        float *cs = job.colsum + (size_t)slice * NA;
+#pragma unroll
+        for (int a = 0; a < TN; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cs[(wn * TN + a) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = accs[a][r];
     }
     uint16_t *dst = reinterpret_cast<uint16_t *>(job.part) + (size_t)slice * NA * MB;
 #pragma unroll
@@ -207,6 +230,7 @@ __global__ __launch_bounds__(kThreadsP) void k_wgrad_pairs(PairJobs jobs) {
     else if (job.kind == HS_WGP_256x80_RM) pair_slice<256, 128, 80, false, false>(job, slice, S, lds);    //  of the Eikonal points: gA1^T H0, gA0^T Xp)
     else if (job.kind == HS_WGP_256x128_RM) pair_slice<256, 128, 128, false, false>(job, slice, S, lds);  // the appearance branch's products (row-major
     else if (job.kind == HS_WGP_32x256_RM) pair_slice<32, 256, 256, false, false>(job, slice, S, lds);    //  activations): gA^T xin, gy^T r1
+    else if (job.kind == HS_WGP_256x128_TP) pair_slice<256, 128, 128, true, true>(job, slice, S, lds);    // colour branch, wave-tile form: cotangent^T [features | encodings]
 }
 
 }  // namespace
@@ -222,7 +246,8 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
     pj.first[0] = 0;
     for (int i = 0; i < n_jobs; i++) {
         const hsWgradPairJob &j = jobs[i];
-        if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_32x256_RM) return HS_ERR_ARG;
+        if (j.kind < HS_WGP_256x256 || j.kind > HS_WGP_256x128_TP) return HS_ERR_ARG;
+        if (j.colsum && j.kind == HS_WGP_32x256) return HS_ERR_ARG;      // column sums: the 256-row results only
         // a slice is a whole number of 32-row tiles: the tile-packed operands are addressed by tile
         if (j.slices < 1 || j.M < 32 || (j.M % 32) != 0 || j.rows < 0 || j.rows > j.M) return HS_ERR_ARG;
         const bool no_b = !j.B0 && j.ones && (j.kind == HS_WGP_256x80 || j.kind == HS_WGP_256x80_RM) && !j.A1;     /* column sums only */

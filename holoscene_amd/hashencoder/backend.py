@@ -62,7 +62,7 @@ class hsWnJob(ctypes.Structure):
 class hsWgradPairJob(ctypes.Structure):
     _fields_ = [("A0", ctypes.c_void_p), ("B0", ctypes.c_void_p), ("A1", ctypes.c_void_p), ("B1", ctypes.c_void_p), ("part", ctypes.c_void_p),
                 ("M", ctypes.c_int64), ("rows", ctypes.c_int64), ("kind", ctypes.c_int32), ("slices", ctypes.c_int32), ("ones", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("colsum", ctypes.c_void_p)]
 
 
 class hsAsmTerm(ctypes.Structure):
@@ -148,7 +148,7 @@ def dir_symbols():
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
-            "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_pack_t", "hs_appearance2_bwd"]
+            "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd"]
 
 
 def _check(rc, what):
@@ -676,15 +676,16 @@ class _HipBackend:
                                          _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf), _dev(A1t, "A1t", bf),
                                          _dev(g_feat, "g_feat"), ctypes.c_int64(n), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_bwd_value")
 
-    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2, (256, 256, "rm"): 3, (256, 80, "rm"): 4, (256, 128, "rm"): 5, (32, 256, "rm"): 6}
+    WGP_KINDS = {(256, 256): 0, (256, 80): 1, (32, 256): 2, (256, 256, "rm"): 3, (256, 80, "rm"): 4, (256, 128, "rm"): 5, (32, 256, "rm"): 6, (256, 128, "tp"): 7}
 
     @staticmethod
-    def wgrad_pairs(jobs, n, outs_into=None):
+    def wgrad_pairs(jobs, n, outs_into=None, colsum_out=None):
         """jobs: [((NA, W[, "rm"][, "ones"]), slices, (A0, B0), (A1, B1) or None[, rows])] -> bf16 partial stacks [slices, NA, MB] (MB = 128 for W = 80;
         "ones": column 80 of the result = column sums of A0, B0 may then be None), all
         in one launch (csrc/wgrad_pairs.hip).  Tile-packed operands cover n samples; "rm" jobs (both operands row-major) name their own
         row count (a multiple of 32 * slices).  outs_into: optional per-job destination tensors (e.g. slices of one stack, so that several
-        jobs' partials are summed together by one hs_sum_slices job)."""
+        jobs' partials are summed together by one hs_sum_slices job).  A shape tagged "colsum" also yields the per-slice column sums of A0
+        (fp32 [slices, NA], appended to the list colsum_out; None for the other jobs)."""
         lib = load_library()
         bf = torch.bfloat16
         arr = (hsWgradPairJob * len(jobs))()
@@ -699,9 +700,13 @@ class _HipBackend:
             if tuple(part.shape) != (slices, NA, MB) or part.dtype != bf or not part.is_contiguous():
                 raise RuntimeError("wgrad_pairs: destination must be a contiguous bf16 [slices, NA, MB] tensor")
             a.ones = int("ones" in shape)
+            cs = torch.empty(slices, NA, device=p0[0].device, dtype=torch.float32) if "colsum" in shape else None      # per-slice column sums of A0
+            a.colsum = None if cs is None else cs.data_ptr()
+            if colsum_out is not None:
+                colsum_out.append(cs)
             a.A0, a.B0 = _dev(p0[0], "A0", bf).value, (_dev(p0[1], "B0", bf).value if p0[1] is not None else None)
             a.A1, a.B1 = (_dev(p1[0], "A1", bf).value, _dev(p1[1], "B1", bf).value) if p1 is not None else (None, None)
-            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[tuple(t for t in shape if t != "ones")], int(slices)
+            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[tuple(t for t in shape if t not in ("ones", "colsum"))], int(slices)
             outs.append(part)
         _check(lib.hs_wgrad_pairs(arr, len(jobs), _stream()), "hs_wgrad_pairs")
         return outs
@@ -806,30 +811,22 @@ class _HipBackend:
 
     # ---- colour branch, wave-tile form (csrc/appearance2.hip)
     @staticmethod
-    def appearance2_pack(wc0, wc1, wr0, wr1, wr2, biases):
-        """fp32 effective matrices + (bc0, bc1, br0, br1, br2) -> dict of fragment images (stream, R2f, bias)."""
+    def appearance2_pack(wc0, wc1, wr0, wr1, wr2, biases, transposed=True):
+        """fp32 effective matrices + (bc0, bc1, br0, br1, br2) -> dict of fragment images (stream, R2f, bias, streamT: the backward kernel's
+        transposed image, None without `transposed`), one launch."""
         lib = load_library()
         lib.hs_appearance2_pack_bytes.restype = ctypes.c_int64
         dev = wc0.device
         nb = [int(lib.hs_appearance2_pack_bytes(i)) for i in range(3)]
+        lib.hs_appearance2_pack_t_bytes.restype = ctypes.c_int64
         P = {"stream": torch.empty(nb[0], device=dev, dtype=torch.uint8), "R2f": torch.empty(nb[1], device=dev, dtype=torch.uint8),
-             "bias": torch.empty(nb[2] // 4, device=dev)}
+             "bias": torch.empty(nb[2] // 4, device=dev),
+             "streamT": torch.empty(int(lib.hs_appearance2_pack_t_bytes()), device=dev, dtype=torch.uint8) if transposed else None}
         keep = [t.detach().float().contiguous() for t in (wc0, wc1, wr0, wr1, wr2) + tuple(biases)]
         _check(lib.hs_appearance2_pack(*[_dev(t, "w") for t in keep[:2]], _dev(keep[2], "wr0"), keep[2].shape[1], _dev(keep[3], "wr1"), _dev(keep[4], "wr2"),
                                        *[_dev(t, "b") for t in keep[5:]], _dev(P["stream"], "stream", torch.uint8), _dev(P["R2f"], "R2f", torch.uint8),
-                                       _dev(P["bias"], "bias"), _stream()), "hs_appearance2_pack")
+                                       _dev(P["bias"], "bias"), _dev(P["streamT"], "streamT", torch.uint8), _stream()), "hs_appearance2_pack")
         return P
-
-    @staticmethod
-    def appearance2_packT(wc0, wc1, wr0, wr1, wr2):
-        """fp32 effective matrices -> the transposed fragment image of the backward kernel (uint8 tensor)."""
-        lib = load_library()
-        lib.hs_appearance2_pack_t_bytes.restype = ctypes.c_int64
-        keep = [t.detach().float().contiguous() for t in (wc0, wc1, wr0, wr1, wr2)]
-        img = torch.empty(int(lib.hs_appearance2_pack_t_bytes()), device=wc0.device, dtype=torch.uint8)
-        _check(lib.hs_appearance2_pack_t(_dev(keep[0], "wc0"), _dev(keep[1], "wc1"), _dev(keep[2], "wr0"), keep[2].shape[1], _dev(keep[3], "wr1"),
-                                        _dev(keep[4], "wr2"), _dev(img, "streamT", torch.uint8), _stream()), "hs_appearance2_pack_t")
-        return img
 
     @staticmethod
     def appearance2_bwd(g_rgb, rgb, normals, masks, streamT, gy, GR1t, GR0t, GFVt, GHCt, d_normals, g_featc, gb2):

@@ -764,6 +764,129 @@ class _fused_appearance(torch.autograd.Function):
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
 
 
+# form of the fused colour branch: "wave" = csrc/appearance2.hip (a wave owns 32 samples through all five layers, weight chunks shared
+# through LDS, tile-packed saved activations, the weight gradients on hs_wgrad_pairs' tile-packed kinds), "tile" = csrc/appearance_mlp.hip
+# (128-point workgroup tiles; row-major saved activations)
+APPEARANCE_FORM = os.environ.get("HOLOSCENE_APPEARANCE_FORM", "wave")
+_XA_COLS = {}
+
+
+def _xa_columns(dev):
+    """Position, in the 128-wide weight-gradient result against hs_appearance2_fwd's assembled-input image, of (a) the 81 encoded inputs of
+    the rendering network and (b) the 32 colour features (int32 device tensors).  Logical column of (k-step s, lane half h, element e) of a
+    tile-packed operand = 16 s + 8 (e >> 2) + 4 h + (e & 3) (csrc/wgrad_pairs.hip: store_chunk_p); k-steps 0, 1 hold the colour features
+    (feature 16 h + 8 s + e), k-steps 2..7 the encoding slots 8 (s - 2) + e of half h."""
+    key = str(dev)
+    if key not in _XA_COLS:
+        lib = _be.load_library()
+        L = lambda s_, h, e: 16 * s_ + 8 * (e >> 2) + 4 * h + (e & 3)  # noqa: E731
+        enc = [-1] * 81
+        for h in range(2):
+            for j in range(48):
+                c = int(lib.hs_appearance2_enc_column(h, j))
+                if c >= 0:
+                    enc[c] = L(2 + j // 8, h, j % 8)
+        assert min(enc) >= 0
+        fc = [L((f % 16) // 8, f // 16, f % 8) for f in range(32)]
+        _XA_COLS[key] = (torch.tensor(enc, dtype=torch.int32, device=dev), torch.tensor(fc, dtype=torch.int32, device=dev))
+    return _XA_COLS[key]
+
+
+class _fused_appearance_wave(torch.autograd.Function):
+    """_fused_appearance on the wave-tile kernels (csrc/appearance2.hip): same inputs, same result, same gradients.
+
+    forward: colour hash gather -> hs_appearance2_fwd; kept: the four layer outputs and the assembled inputs TILE-PACKED, the ReLU signs
+    as bit masks, rgb.  backward: hs_appearance2_bwd (reads the masks only) -> the four cotangents tile-packed -> ONE hs_wgrad_pairs launch
+    for the six weight gradients and the four bias gradients (column sums) -> one slice sum, one assembly -> colour-table scatter."""
+
+    @staticmethod
+    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
+        ctx.set_materialize_grads(False)
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        if ctx.needs_input_grad[3]:
+            _be.expect_scatter(ctx.table)
+        be = _be._backend
+        points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
+        if x01 is None:
+            x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
+        B = points.shape[0]
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        dev, bf = points.device, torch.bfloat16
+        featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for the consumer
+        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
+        mats = (Wc0, Wc1, Wr0, Wr1, Wr2)
+        need_bwd = any(ctx.needs_input_grad)
+        P = be.appearance2_pack(*mats, (bc0, bc1, br0, br1, br2), transposed=need_bwd)
+        sT = P["streamT"]
+        tiles = (B + 31) // 32
+        tp = lambda ks: torch.empty(tiles * ks * 512, device=dev, dtype=bf)  # noqa: E731
+        XAt, HCt, FVt, R0t, R1t = tp(8), tp(16), tp(16), tp(16), tp(16)
+        masks = torch.empty(tiles * 3 * 256, device=dev, dtype=torch.int32)
+        rgb = torch.empty(B, 3, device=dev)
+        be.appearance2_fwd(featc, points, dirs, normals, P, XAt, HCt, FVt, R0t, R1t, masks, rgb)
+        if need_bwd:
+            ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT)
+        ctx.cfg = (B, C, L, S, Hres, Wr0.shape[1])
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        if g_rgb is None:
+            return (None,) * 19
+        x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT = ctx.saved_tensors
+        B, C, L, S, Hres, ldr0 = ctx.cfg
+        be = _be._backend
+        dev, bf = rgb.device, torch.bfloat16
+        tiles = (B + 31) // 32
+        tp = lambda: torch.empty(tiles * 16 * 512, device=dev, dtype=bf)  # noqa: E731
+        gy = torch.empty(B, 32, device=dev, dtype=bf)
+        GR1, GR0, GFV, GHC = tp(), tp(), tp(), tp()
+        d_normals = torch.empty(B, 3, device=dev)
+        g_featc = torch.empty(L, B, C, device=dev)
+        need_w = ctx.needs_input_grad[8]
+        gb2 = torch.empty(tiles, 4, device=dev) if need_w else None
+        be.appearance2_bwd(g_rgb.contiguous().float(), rgb, normals, masks, sT, gy, GR1, GR0, GFV, GHC, d_normals, g_featc, gb2)
+        gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbc0 = gbc1 = gbr0 = gbr1 = gbr2 = None
+        if need_w:
+            # six products, four of them with the column sums of their cotangent (= the bias gradients) riding along; slices cut by bytes
+            shapes = [(32, 256), (256, 256, "colsum"), (256, 128, "tp", "colsum"), (256, 256), (256, 256, "colsum"), (256, 128, "tp", "colsum")]
+            prods = [(gy, R1t), (GR1, R0t), (GR0, XAt), (GR0, FVt), (GFV, HCt), (GHC, XAt)]
+            cut = _pair_slices([(sh, tiles, 1, True) for sh in shapes])
+            cs = []
+            stacks = be.wgrad_pairs([(sh, c_, pr, None, B) for sh, c_, pr in zip(shapes, cut, prods)], B, colsum_out=cs)
+            sums = be.sum_slices(stacks + [t for t in cs if t is not None])
+            w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0, s_br1, s_br0, s_bc1, s_bc0 = sums
+            enc_cols, fc_cols = _xa_columns(dev)
+            gWr0 = torch.empty(256, ldr0, device=dev)
+            _, _, gWc0, gbr2 = be.assemble([((256, 81), [(w_r0x, 128, enc_cols)], (gWr0, 0)),
+                                            ((256, ldr0 - 81), [(w_r0f, 256, 0)], (gWr0, 81)),
+                                            ((256, 32), [(w_c0, 128, fc_cols)]),
+                                            ((1, 3), [(gb2, 0, 0, tiles, 4)])])
+            gWr2, gbr2 = w_r2[:3], gbr2.view(-1)
+            gbr1, gbr0, gbc1, gbc0 = s_br1, s_br0, s_bc1, s_bc0
+        g_emb = None
+        if ctx.needs_input_grad[3]:
+            table = ctx.table
+            inplace = _be.accumulates_into_grad(table)
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
+                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
+            g_emb = None if inplace else target
+            if inplace:
+                _be.scatter_done(table)
+        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gbc0, gWc1, gbc1, gWr0, gbr0, gWr1, gbr1, gWr2, gbr2, None)
+
+
+def fused_appearance(*args):
+    """The fused colour branch in the selected form (APPEARANCE_FORM)."""
+    Wr0 = args[12]
+    if APPEARANCE_FORM == "wave" and args[0].is_cuda and args[0].shape[0] > 0 and Wr0.shape[1] == 337:
+        return _fused_appearance_wave.apply(*args)
+    if APPEARANCE_FORM not in ("wave", "tile"):
+        raise RuntimeError(f"unknown HOLOSCENE_APPEARANCE_FORM={APPEARANCE_FORM!r}")
+    return _fused_appearance.apply(*args)
+
+
 class _render_input(torch.autograd.Function):
     """[posenc(points), posenc(view_dirs), posenc(normals), feature_vectors] in one kernel; the backward returns
     the gradients of the two differentiable inputs (normals, feature_vectors)."""
@@ -1530,7 +1653,7 @@ class HoloSceneNetwork(nn.Module):
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
-            return _fused_appearance.apply(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
+            return fused_appearance(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
                                            int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
                                            mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias, R2, rn.lin2.bias, x01)
         return self.rendering_network(points_flat, gradients, dirs_flat, net._color_features(points_flat), indices)

@@ -444,16 +444,16 @@ int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals
 int64_t hs_appearance2_pack_bytes(int32_t which);
 int hs_appearance2_enc_column(int32_t half, int32_t slot);     /* encoded-input column (0..80) of slot 0..47 of lane half 0/1, -1 = padding */
 int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, const float *bc0,
-                        const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias, void *stream);
+                        const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias,
+                        void *streamT_image /* NULL, or hs_appearance2_pack_t_bytes() bytes: the transposed image of the backward kernel */, void *stream);
 int hs_appearance2_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *stream_image, const void *R2f,
                        const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, void *stream);
-/* Backward data path of the same: the transposed fragment image (hs_appearance2_pack_t_bytes() bytes, built by hs_appearance2_pack_t from the same
- * fp32 matrices), the forward pass's masks and rgb.  Outputs: gy [n,32] bf16 row-major (cotangent of the pre-sigmoid outputs, columns 0..2),
+/* Backward data path of the same: the transposed fragment image (hs_appearance2_pack_t_bytes() bytes, built by hs_appearance2_pack), the forward
+ * pass's masks and rgb.  Outputs: gy [n,32] bf16 row-major (cotangent of the pre-sigmoid outputs, columns 0..2),
  * GR1t, GR0t, GFVt, GHCt tile-packed (pre-activation cotangents of r1, r0, the feature vector, hc), d_normals [n,3], g_featc [16,n,2] fp32
  * (level-major), gb2 [ceil(n / 32), 4] = per-tile partial sums of the last layer's bias gradient (columns 0..2; may be NULL).  The other bias gradients are column sums of the tile-packed
  * cotangents: hs_wgrad_pairs produces them beside the weight gradients (hsWgradPairJob::colsum). */
 int64_t hs_appearance2_pack_t_bytes(void);
-int hs_appearance2_pack_t(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, void *streamT_image, void *stream);
 int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normals, const uint32_t *masks, const void *streamT_image, void *gy, void *GR1t,
                        void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, void *stream);
 
@@ -588,6 +588,7 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
 #define HS_WGP_256x80_RM 4
 #define HS_WGP_256x128_RM 5     /* A [rows, 256], B [rows, 128], both row-major */
 #define HS_WGP_32x256_RM 6      /* A [rows, 32],  B [rows, 256], both row-major */
+#define HS_WGP_256x128_TP 7     /* A tile-packed (16 k-steps), B tile-packed with 8 k-steps (hs_appearance2_fwd's assembled inputs) */
 typedef struct hsWgradPairJob {
     const void *A0, *B0, *A1, *B1;      /* second pair optional (both NULL) */
     void *part;
@@ -595,6 +596,7 @@ typedef struct hsWgradPairJob {
     int32_t kind, slices;
     int32_t ones;       /* HS_WGP_256x80 / _RM: column 80 of the result = column sums of A0 (a bias gradient); with B0 == NULL nothing else */
     int32_t reserved;
+    float *colsum;      /* NULL, or fp32 [slices, NA]: per-slice column sums of A0 (kinds with a 256-row result: one more bias gradient per job) */
 } hsWgradPairJob;
 int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream);
 

@@ -1,5 +1,5 @@
 set -e
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03p
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03q
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-fp32-point --steps 60 --roofline-steps 2 > $OUT/bench.log 2>&1 || true

@@ -633,8 +633,9 @@ def test_fused_draw_step_equals_separate_launches():
             assert (out2 != -7.0).all() == (mode == 1 or running)
 
 
+@pytest.mark.parametrize("form", ["wave", "tile"])
 @pytest.mark.parametrize("B", [25088, 1000, 37])
-def test_fused_mfma_appearance_vs_gemm_path(B):
+def test_fused_mfma_appearance_vs_gemm_path(B, form):
     """k_appear_fwd / k_appear_bwd (+ hs_pack_bf16) vs (a) the library-GEMM bf16 path and (b) the fp32 path on the same weights:
     rgb, d/d normals and the gradient of every parameter (colour table, colour MLP, rendering MLP).  bf16 operand rounding:
     relative L2 error against fp32 below 0.1 and not worse than 1.5x that of the established bf16 (library GEMM) path."""
@@ -657,10 +658,11 @@ def test_fused_mfma_appearance_vs_gemm_path(B):
     def run(prec, fused):
         net.set_mlp_precision(prec)
         rn.set_mlp_precision(prec)
-        if fused:
-            rgb = N._fused_appearance.apply(pts, dirs, nrm, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
-                                            float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, rn.lin0.weight,
-                                            rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias)
+        if fused:      # both forms of the fused colour branch: csrc/appearance2.hip (wave tiles) and csrc/appearance_mlp.hip (workgroup tiles)
+            fn = N._fused_appearance_wave if form == "wave" else N._fused_appearance
+            rgb = fn.apply(pts, dirs, nrm, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                           float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, rn.lin0.weight,
+                           rn.lin0.bias, rn.lin1.weight, rn.lin1.bias, rn.lin2.weight, rn.lin2.bias)
         else:
             rgb = rn(pts, nrm, dirs, net._color_features(pts))
         gr = torch.autograd.grad((rgb * cot).sum(), [nrm] + params)

@@ -69,7 +69,7 @@ def run(n):
     d_n, g_fc, gb = torch.empty(n, 3, device=dev), torch.empty(16, n, 2, device=dev), torch.zeros(5, 256, device=dev)
     oldb = lambda: be.appearance_bwd(g_rgb, rgb, normals, r1, r0, hc, Wt, gy, gA_r1, gA_r0, g_fv, gA_hc, d_n, g_fc, gb, None)  # noqa: E731
     oldb()
-    sT = be.appearance2_packT(wc0, wc1, wr0, wr1, wr2)
+    sT = P["streamT"]
     gy2 = new(n, 32)
     GR1, GR0, GFV, GHC = tp(16), tp(16), tp(16), tp(16)
     d_n2, g_fc2, gb2 = torch.empty(n, 3, device=dev), torch.empty(16, n, 2, device=dev), torch.zeros(tiles, 4, device=dev)
