@@ -602,37 +602,36 @@ class _trunk_render_rr(torch.autograd.Function):
         gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
         if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
             T, npair = be.tp_rows(n) // 32, 2 if second else 1
-            # (the b1 column-sum job reads a1~ once more: one eighth of the pass's bytes)
-            cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True), ((256, 80), T, 1, False)]
+            cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True)]
                                + [(j[0], Me // 32, 1, True) for j in eik_jobs])
-            s1, s0, s2, sb = cut[:4]
-            se1, se0 = cut[4:] if eik_jobs else (0, 0)
+            s1, s0, s2 = cut[:3]
+            se1, se0 = cut[3:] if eik_jobs else (0, 0)
             eik_jobs = [(j[0], sl) + tuple(j[2:]) for j, sl in zip(eik_jobs, (se1, se0))]
             # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
-            # samples ride along as a ONES column of the B tile (column 80 of the 256 x 80 results)
+            # samples ride along: db0 as a ONES column of the B tile (column 80 of the 256 x 80 result), db1 as the column sums of a1~ from
+            # one more MFMA per fragment of the 256 x 256 job (hsWgradPairJob::colsum)
             st1, st0 = torch.empty(s1 + se1, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se0, 256, 128, device=dev, dtype=bf)
-            st2, stb = torch.empty(s2, 32, 256, device=dev, dtype=bf), torch.empty(sb, 256, 128, device=dev, dtype=bf)
-            be.wgrad_pairs([((256, 256), s1, (A1t, H0t), (V1t, U0bt) if second else None),
+            st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
+            cs = []
+            be.wgrad_pairs([((256, 256, "colsum"), s1, (A1t, H0t), (V1t, U0bt) if second else None),
                             ((256, 80, "ones"), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None),
-                            ((256, 80, "ones"), sb, (A1t, None), None)] + eik_jobs, n,
-                           outs_into=[st1[:s1], st0[:s0], st2, stb] + ([st1[s1:], st0[s0:]] if eik_jobs else []))
+                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)] + eik_jobs, n,
+                           outs_into=[st1[:s1], st0[:s0], st2] + ([st1[s1:], st0[s0:]] if eik_jobs else []), colsum_out=cs)
+            csb1 = cs[0]        # [s1, 256] fp32
             if eik_live and not eik_jobs:
                 eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
-                sums = be.sum_slices([st1, st0, st2, stb])
+                sums = be.sum_slices([st1, st0, st2, csb1])
                 gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
-            else:
-                sums = be.sum_slices([st1, st0, st2, stb] + ([w2_part] if eik_live else []))
-                gW1, gW0p, gW2p = sums[0], sums[1][:, :80], sums[2]
-            if eik_live and not eik_jobs:
-                gb1, gb0, gb2 = gbz[:256] + sums[3][:, 80], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
+                gb1, gb0, gb2 = gbz[:256] + sums[3], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
                 gW0 = gW0p.index_select(1, _xp_columns(dev))
                 gW2 = gW2p[:K]
             else:   # the column selection of dW0, dW2 of both point families, the three bias gradients: one launch (csrc/small_ops.hip)
+                sums = be.sum_slices([st1, st0, st2, csb1] + ([w2_part] if eik_live else []))
+                gW1 = sums[0]
                 gW0, gW2, gb1, gb0, gb2 = be.assemble([
                     ((256, F_in), [(sums[1], 128, _xp_columns32(dev))]),
                     ((K, 256), [(sums[2], 256, 0)] + ([(sums[4], 256, 0)] if eik_live else [])),
-                    ((256, 1), [(gbz, 1, 0), (sums[3], 128, 80)]),
+                    ((256, 1), [(gbz, 1, 0), (sums[3], 1, 0)]),
                     ((256, 1), [(gbz, 1, 256), (sums[1], 128, 80)]),
                     ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
                 gb1, gb0, gb2 = gb1.view(-1), gb0.view(-1), gb2.view(-1)
