@@ -257,10 +257,14 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
     for (int i = threadIdx.x; i < kA2Bias; i += kThreadsW) bias[i] = biasg[i];
     const int64_t ntiles = (n + kRows - 1) / kRows, nst = (ntiles + kWaves - 1) / kWaves;
     const bf16x8 *R2v = reinterpret_cast<const bf16x8 *>(R2l) + lane;
-    for (int64_t st = blockIdx.x; st < nst; st += gridDim.x) {
-        const int64_t tile = st * kWaves + wave;
-        const bool live = tile < ntiles;                  // wave-uniform: a wave without a tile still serves the pipeline (DMA share, barriers)
-        const bool more = st + gridDim.x < nst;           // workgroup-uniform
+    // workgroup b owns the contiguous tiles [b T / G, (b + 1) T / G) (trunk_rr.hip: tile_begin): at the stock size 12 or 13 -- a round of
+    // eight waves and a round of four or five, each alone on its SIMD
+    const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    (void)nst;
+    for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
+        const int64_t tile = r0 + wave;
+        const bool live = tile < wt1;                     // wave-uniform: a wave without a tile still serves the pipeline (DMA share, barriers)
+        const bool more = r0 + kWaves < wt1;              // workgroup-uniform
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int64_t b = ok ? gp : 0;
@@ -276,6 +280,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
             par ^= 1;
             return base;
         };
+        if (!live) {      // nothing to compute: keep the chunk pipeline turning for the others
+            static_for<kChunks>([&](auto jc) { (void)chunk_begin(jc); });
+            continue;
+        }
         // ---- this lane's inputs: 16 colour features (levels 8 h .. 8 h + 7) and its 48 encoding slots (rows past the end: zeros)
         uint32_t fcw[8], pew[24];
         {
@@ -459,10 +467,12 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
     int par = 0;
     dma_chunk(streamT, lds2, kChunkTOff[0], kChunkTBytes[0], 0, wave, lane);
     const int64_t ntiles = (n + kRows - 1) / kRows, nst = (ntiles + kWaves - 1) / kWaves;
-    for (int64_t st = blockIdx.x; st < nst; st += gridDim.x) {
-        const int64_t tile = st * kWaves + wave;
-        const bool live = tile < ntiles;
-        const bool more = st + gridDim.x < nst;
+    const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    (void)nst;
+    for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
+        const int64_t tile = r0 + wave;
+        const bool live = tile < wt1;
+        const bool more = r0 + kWaves < wt1;
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int64_t b = ok ? gp : 0;
@@ -476,6 +486,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
             par ^= 1;
             return base;
         };
+        if (!live) {
+            static_for<kChunksT>([&](auto jc) { (void)chunk_begin(jc); });
+            continue;
+        }
         // ---- the ReLU signs of this lane's 3 x 128 activations, and the cotangent of the three pre-sigmoid outputs (lane half 0 holds k = 0..3)
         uint32_t mk[3][4];
         {

@@ -138,6 +138,11 @@ __device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const flo
 }
 
 // ================================================================================================================ tile machinery
+// Workgroup b owns the CONTIGUOUS tiles [b T / G, (b + 1) T / G): at the stock size 3 136 tiles on 256 workgroups are 12 or 13 each -- one
+// round of all eight waves and one of four or five, a wave alone on its SIMD -- instead of two full rounds on 136 compute units while 120
+// stand idle (the strided assignment: 392 super-tiles of eight on 256 workgroups).
+__device__ __forceinline__ int64_t tile_begin(int64_t ntiles) { return ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x; }
+__device__ __forceinline__ int64_t tile_end(int64_t ntiles) { return ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x; }
 // One PHASE = the k-steps of ONE 32-neuron tile (one accumulator) with, in their shadow, slices of the previous tile's epilogue -- the
 // single-tile form of wave_tile.h's phase2: half the accumulator and epilogue-staging registers of a quarter phase.  These kernels move
 // 0.3-0.4 GB each for ~20 GFLOP: what they need registers for is loads in flight, not MFMA operands (a quarter-phase version spilled 40-80
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__re
     const bf16x8 *W0v = reinterpret_cast<const bf16x8 *>(W0f) + lane;
     const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
     const bf16x8 *W2v = reinterpret_cast<const bf16x8 *>(W2l) + lane;
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+    for (int64_t tile = tile_begin(ntiles) + wave, tile_e = tile_end(ntiles); tile < tile_e; tile += kWaves) {
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         uint32_t hin[4 * K0S];
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
     const int64_t ntiles = (n + kRows - 1) / kRows;
     const bf16x8 *W0v = reinterpret_cast<const bf16x8 *>(W0f) + lane;
     const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+    for (int64_t tile = tile_begin(ntiles) + wave, tile_e = tile_end(ntiles); tile < tile_e; tile += kWaves) {
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int64_t b = ok ? gp : 0;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
     const int64_t ntiles = (n + kRows - 1) / kRows;
     const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
     const bf16x8 *W0Tv = reinterpret_cast<const bf16x8 *>(W0Tf) + lane;
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+    for (int64_t tile = tile_begin(ntiles) + wave, tile_e = tile_end(ntiles); tile < tile_e; tile += kWaves) {
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int bi = (int)idx[ok ? gp : 0];
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
     const bf16x8 *W1v = reinterpret_cast<const bf16x8 *>(W1l) + lane;
     const bf16x8 *W2v = reinterpret_cast<const bf16x8 *>(W2l) + lane;
     const bf16x8 *W0Tv = reinterpret_cast<const bf16x8 *>(W0Tf) + lane;
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+    for (int64_t tile = tile_begin(ntiles) + wave, tile_e = tile_end(ntiles); tile < tile_e; tile += kWaves) {
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         // B fragments of the output cotangent: k-step s = objects 16 s + 8 h + 0..7 of this sample
