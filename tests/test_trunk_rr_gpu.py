@@ -125,3 +125,18 @@ def test_rr_kernels_vs_torch_restatement(n, K):
                                 ((32, 256), cuts[2], (gy, H1t), (onehot, U1bt))], n)
         r1, r0, r2 = (p.float().sum(0) for p in parts)
         assert rel_l2(r1, want1) < 1e-2 and rel_l2(r0[:, :80], want0) < 1e-2 and rel_l2(r2, want2) < 1e-2, cuts
+    # column sums of the first pair's A operand beside the product (hsWgradPairJob::colsum: the bias gradients of a backward pass), with and
+    # without a second pair; an 8-k-step tile-packed B operand (the colour branch's assembled inputs: kind 256 x 128 "tp")
+    for second in (True, False):
+        cs = []
+        parts = be.wgrad_pairs([((256, 256, "colsum"), 5, (A1t, H0t), (V1t, U0bt) if second else None)], n, colsum_out=cs)
+        assert rel_l2(parts[0].float().sum(0), want1 if second else A1d.t() @ f3["h0"]) < 1e-2
+        assert cs[0].shape == (5, 256) and rel_l2(cs[0].sum(0), A1d.sum(0)) < 2e-3, "column sums of A0 only (fp32 accumulation of bf16 values)"
+    g = torch.Generator().manual_seed(9)
+    xa = (torch.randn(M, 128, generator=g) * 0.5).to(DEV)
+    xa[n:] = 0
+    XAt = xa.view(tiles, 32, 8, 2, 2, 4).permute(0, 2, 4, 1, 3, 5).contiguous().to(torch.bfloat16).view(-1)   # [tile, s, h, row, e >> 2, e & 3]
+    xa_bf = xa.to(torch.bfloat16).float()
+    cs = []
+    parts = be.wgrad_pairs([((256, 128, "tp", "colsum"), 7, (A0t, XAt), None)], n, colsum_out=cs)
+    assert rel_l2(parts[0].float().sum(0), A0d.t() @ xa_bf[:n]) < 1e-2 and rel_l2(cs[0].sum(0), A0d.sum(0)) < 2e-3
