@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kThreadsP = 512, kWavesP = 8;
 constexpr int RCP = 64;             // rows per chunk (two 32-row tiles of a tile-packed operand)
-constexpr int PADP = 8;
+constexpr int PADP = 24;           // row pitch of the LDS tiles = width + 24 elements = 140 words = 12 mod 64 banks: the 4-row x 16-word transposed fragment reads collide two-way instead of four-way (+ 8: SQ_LDS_BANK_CONFLICT was 7 x SQ_ACTIVE_INST_LDS), the 8-byte tile-packed stores two-way (125 -> 120 us per launch; an XOR swizzle without padding, conflict-free on paper for both, measured 133 us: its address arithmetic costs more than the conflicts)
 
 struct PairJobs { hsWgradPairJob j[HS_WGRAD_MAX_JOBS]; int32_t first[HS_WGRAD_MAX_JOBS + 1]; int32_t n; };
 

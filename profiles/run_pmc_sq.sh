@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for fn in glob.glob('/tmp/pmc_${TAG}_*/*counter_collection.csv'):
     for r in csv.DictReader(open(fn)):
         k = r['Kernel_Name']
-        if not any(t in k for t in ('k_sdf_mlp', 'k_sdf_mlp2', 'k_trunk_fwd', 'k_trunk_bwd', 'k_appear_fwd', 'k_appear_bwd', 'k_hash_fwd', 'k_hash_bwd_jac', 'k_hash_bin_reduce', 'k_sampler_update', 'k_composite')):
+        if not any(t in k for t in ('k_sdf_mlp', 'k_sdf_mlp2', 'k_trunk_fwd', 'k_trunk_bwd', 'k_appear', 'k_rr_', 'k_wgrad', 'k_hash_fwd', 'k_hash_bwd_jac', 'k_hash_bin_reduce', 'k_sampler_update', 'k_composite')):
             continue
         k = k.replace('void ', '', 1).replace('(anonymous namespace)::', '').split('(')[0]
         a = agg[k][r['Counter_Name']]
