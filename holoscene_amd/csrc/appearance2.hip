@@ -178,16 +178,6 @@ __device__ __forceinline__ void tp_store_n(uint16_t *__restrict__ T, int64_t til
     *reinterpret_cast<uint4 *>(T + ((size_t)tile * ksteps + s) * 512 + lo) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 }
 
-// accumulator initialisation from the bias block through an opaque LDS base (wave_tile.h: lds_base -- written as bias[const + lane part] every
-// one of the 128 distinct addresses of a tile becomes a loop-invariant VGPR)
-__device__ __forceinline__ void init_acc_b(f32x16 &acc, uint32_t bias_base, int float_off) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const f32x4 bq = lds_at<f32x4>(bias_base, (uint32_t)(float_off + 8 * q) * 4u);
-        acc[4 * q + 0] = bq[0]; acc[4 * q + 1] = bq[1]; acc[4 * q + 2] = bq[2]; acc[4 * q + 3] = bq[3];
-    }
-}
-
 // resident image by LDS-DMA (sdf_mlp2.hip), `bytes` a multiple of 1 KB
 __device__ __forceinline__ void dma_fill2(const void *src, void *dst, int bytes, int wave, int lane) {
     const int chunks = bytes / 1024;

@@ -195,6 +195,16 @@ template <typename T> __device__ __forceinline__ T lds_at(uint32_t base, uint32_
     return *(__attribute__((address_space(3))) const T *)(uintptr_t)(base + byte_off);
 }
 
+// accumulator initialisation from the bias block through an opaque LDS base (wave_tile.h: lds_base -- written as bias[const + lane part] every
+// one of the 128 distinct addresses of a tile becomes a loop-invariant VGPR)
+__device__ __forceinline__ void init_acc_b(f32x16 &acc, uint32_t bias_base, int float_off) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x4 bq = lds_at<f32x4>(bias_base, (uint32_t)(float_off + 8 * q) * 4u);
+        acc[4 * q + 0] = bq[0]; acc[4 * q + 1] = bq[1]; acc[4 * q + 2] = bq[2]; acc[4 * q + 3] = bq[3];
+    }
+}
+
 // an empty volatile asm on a freshly computed value pins its computation HERE: the optimiser otherwise sinks an epilogue to the use of
 // its result many MFMAs later, out of the MFMA shadow it was placed in (measured: layer 1's epilogues piled up in front of layer 2)
 __device__ __forceinline__ uint32_t anchor(uint32_t w) {
