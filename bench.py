@@ -438,7 +438,10 @@ def main():
     def step():
         tr.train_step_resident(scene)    # batch gathered from the HBM-resident frames straight into the graph's input block
         r_ = tr.model.ray_sampler._rounds       # int, or a device tensor (device-controlled sampler): no sync inside the loop
-        rounds_seen.append(r_.clone() if torch.is_tensor(r_) else r_)
+        step.calls += 1
+        if step.calls % 8 == 0 or not torch.is_tensor(r_):      # (a device tensor is the graph's static cell: sampled by a 4-byte copy every 8th step)
+            rounds_seen.append(r_.clone() if torch.is_tensor(r_) else r_)
+    step.calls = 0
 
     def barrier():
         if world > 1:
@@ -459,6 +462,9 @@ def main():
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    if not rounds_seen:      # a run shorter than the sampling period: the last iteration's count
+        r_ = tr.model.ray_sampler._rounds
+        rounds_seen.append(r_.clone() if torch.is_tensor(r_) else r_)
     raw_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     per_step = sorted(raw_step)
     reg = [t for t, b in zip(raw_step, is_bg) if not b]
@@ -569,7 +575,7 @@ def main():
             n_roof += 1
         kt.enabled = False
         kernels = kt.summary(max(n_roof, 1))
-    rounds_mean = sum(int(r_) for r_ in rounds_seen[:args.steps]) / max(1, args.steps)
+    rounds_mean = sum(int(r_) for r_ in rounds_seen) / max(1, len(rounds_seen))
     N_pts = args.samples // 2 + args.samples // 4 + 2
     R, S, K = args.rays, args.samples, args.objects
     n_params = tr.flat.numel if tr.flat is not None else sum(p.numel() for p in tr.model.parameters())    # (--optimizer torch has no flat buffers)

@@ -18,11 +18,6 @@
 
 namespace {
 
-#ifdef HS_A2_NOLDS
-#define HS_A2_S(s) 0
-#else
-#define HS_A2_S(s) (s)
-#endif
 #ifndef HS_A2_LA
 #define HS_A2_LA 2
 #endif
@@ -245,12 +240,11 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
     dma_chunk(stream, lds2, kChunkOff[0], kChunkBytes[0], 0, wave, lane);
     dma_fill2(R2f, R2l, kW2F * 2, wave, lane);
     for (int i = threadIdx.x; i < kA2Bias; i += kThreadsW) bias[i] = biasg[i];
-    const int64_t ntiles = (n + kRows - 1) / kRows, nst = (ntiles + kWaves - 1) / kWaves;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
     const bf16x8 *R2v = reinterpret_cast<const bf16x8 *>(R2l) + lane;
     // workgroup b owns the contiguous tiles [b T / G, (b + 1) T / G) (trunk_rr.hip: tile_begin): at the stock size 12 or 13 -- a round of
     // eight waves and a round of four or five, each alone on its SIMD
     const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
-    (void)nst;
     for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
         const int64_t tile = r0 + wave;
         const bool live = tile < wt1;                     // wave-uniform: a wave without a tile still serves the pipeline (DMA share, barriers)
@@ -339,8 +333,6 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        auto IC = [](auto v) { return v; };
-        (void)IC;
         // ---- colour MLP layer 0: 32 -> 256, ReLU (chunk 0: all eight tiles, two k-steps each)
         mk[0] = mk[1] = mk[2] = mk[3] = 0u;
         {
@@ -456,9 +448,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 31, h = lane >> 5;
     int par = 0;
     dma_chunk(streamT, lds2, kChunkTOff[0], kChunkTBytes[0], 0, wave, lane);
-    const int64_t ntiles = (n + kRows - 1) / kRows, nst = (ntiles + kWaves - 1) / kWaves;
+    const int64_t ntiles = (n + kRows - 1) / kRows;
     const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
-    (void)nst;
     for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
         const int64_t tile = r0 + wave;
         const bool live = tile < wt1;

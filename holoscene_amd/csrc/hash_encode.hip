@@ -505,7 +505,11 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     const uint32_t n = min(counts[level * kBins + bin], lay.scatter_cap);
     if (n == 0u) return;
     const uint32_t per_bin = bin_width<C>(li), first = bin * per_bin;
-    if (first >= li.table) return;                               // (dense levels: bins past the end of the table hold nothing)
+    if (first >= li.table) {                                     // (dense levels: bins past the end of the table hold nothing)
+        __syncthreads();
+        if (threadIdx.x == 0) const_cast<uint32_t *>(counts)[level * kBins + bin] = 0u;
+        return;
+    }
     const uint32_t nfl = min(per_bin, li.table - first) * C;     // floats of the table this bin covers
     const uint32_t nvec = per_bin * C / 4;                       // bin_width: a whole number of float4
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
@@ -525,6 +529,9 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     }
     for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    // everybody has read this bin's count: leave it at zero for the next scatter through this work space (hsHashLayout::ws_clean: the
+    // clearing launch in front of every scatter was 5 us of a ~85 us stage, twice per iteration)
+    if (threadIdx.x == 0) const_cast<uint32_t *>(counts)[level * kBins + bin] = 0u;
     // records: independent loads, four in flight per thread before the first LDS atomic (eight cost an occupancy step: 74 registers,
     // 104 vs 101 us per scatter)
     uint32_t i = threadIdx.x;
@@ -780,6 +787,7 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.scatter_cap = 0;
     lay.grid_id = nullptr;
     lay.grid_stride = 0;
+    lay.ws_clean = 0;
     return lay;
 }
 
@@ -868,7 +876,7 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
     if (grad_embeddings) {
         const LevelScales sc = make_scales(L, S, H);
         apply_bin_dense_switch();
-    if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
+    if (lay.scatter_ws && !lay.ws_clean) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
         dispatch_dc(D, C, [&](auto d, auto c) {
             k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
                 grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
@@ -914,7 +922,7 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     const LevelScales sc = make_scales(L, S, H);
     hipStream_t st = (hipStream_t)stream;
     apply_bin_dense_switch();
-    if (lay.scatter_ws) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
+    if (lay.scatter_ws && !lay.ws_clean) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
     dispatch_dc(D, C, [&](auto d, auto c) {
         k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
             g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);

@@ -50,13 +50,11 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 // Ray-local heavy parts, one wave per ray: the foreground flag (does the SDF change sign along the ray, loss.py:313-315: N
 // values) and the opacity BCE with its gradient (K values).  The single-workgroup kernel below used to walk both per thread
 // (1 024 threads striding 392-byte rows on ONE CU: 100 us); here they are coalesced wave reads spread over the chip.
-__global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
-                                                         const float *__restrict__ gt_mask, int R, int N, int K, float w_opac,
-                                                         float *__restrict__ fg, float *__restrict__ bce, float *__restrict__ g_opac,
-                                                         float *__restrict__ zero2) {
+__device__ __forceinline__ void ray_local_block(int block, const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
+                                                const float *__restrict__ gt_mask, int R, int N, int K, float w_opac, float *__restrict__ fg,
+                                                float *__restrict__ bce, float *__restrict__ g_opac) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0.f;   // k_loss_eikonal's accumulators (launched after this kernel)
+    const int r = block * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     bool pos = false, neg = false;
     for (int i = lane; i < N; i += 64) {
@@ -82,6 +80,12 @@ __global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void k_loss_ray_local(const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
+                                                         const float *__restrict__ gt_mask, int R, int N, int K, float w_opac,
+                                                         float *__restrict__ fg, float *__restrict__ bce, float *__restrict__ g_opac) {
+    ray_local_block(blockIdx.x, sdf, opac, segs, gt_mask, R, N, K, w_opac, fg, bce, g_opac);
+}
+
 // out[0..4] = rgb, depth, normal_l1, normal_cos, opacity losses (unweighted).  acc2 != NULL (hs_loss_stage1: k_loss_eikonal has
 // run): also out[5..6] = eikonal, smooth (= acc2 / H) and out[7] = the weighted total of all seven terms.
 __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ rgb, const float *__restrict__ rgb_gt, const float *__restrict__ depth,
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
                                                       const float *__restrict__ n_gt, const float *__restrict__ fg,
                                                       const float *__restrict__ bce, int R, int K, float w_rgb, float w_depth,
                                                       float w_l1, float w_cos, float *__restrict__ out, float *__restrict__ g_rgb,
-                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap, const float *__restrict__ acc2, float invH,
+                                                      float *__restrict__ g_depth, float *__restrict__ g_nmap, const float *__restrict__ acc2, int nparts, float invH,
                                                       float w_opac, float w_eik, float w_smooth) {
     __shared__ float scratch[kBlock / 64];
     const float invR = 1.f / (float)R;
@@ -163,10 +167,16 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
         const float dq = ((2.f * p * E - D - Bs * tt) - q * ddet) / det;
         g_depth[r] = w_depth * 2.f * invR * (c * res * w + S1 * dw + S0 * dq);
     }
+    float se_ = 0.f, ss_ = 0.f;      // the Eikonal blocks' partial sums (acc2 [nparts][2]), added up by wave 0 in a fixed order
+    if (acc2 && threadIdx.x < 64) {
+        for (int i = threadIdx.x; i < nparts; i += 64) { se_ += acc2[2 * i]; ss_ += acc2[2 * i + 1]; }
+        se_ = wave_sum(se_);
+        ss_ = wave_sum(ss_);
+    }
     if (threadIdx.x == 0) {
         out[0] = Lrgb; out[1] = Ld; out[2] = Ll1; out[3] = Lcos; out[4] = Lop;
         if (acc2) {
-            const float Le = acc2[0] * invH, Ls = acc2[1] * invH;
+            const float Le = se_ * invH, Ls = ss_ * invH;
             out[5] = Le; out[6] = Ls;
             out[7] = w_rgb * Lrgb + w_depth * Ld + w_l1 * Ll1 + w_cos * Lcos + w_opac * Lop + w_eik * Le + w_smooth * Ls;
         }
@@ -185,12 +195,14 @@ __device__ __forceinline__ Unit unit(const float g[3], float eps) {
 }
 
 // acc[0] += sum (|g1|-1)^2, acc[1] += sum |n1-n2|  (the host divides by H); gradients carry 1/H and the weights
-__global__ __launch_bounds__(256) void k_loss_eikonal(const float *__restrict__ g1, const float *__restrict__ g2, int64_t H, float w_eik, float w_smooth,
-                                                       float *__restrict__ acc, float *__restrict__ d_g1, float *__restrict__ d_g2) {
+// part != NULL: this block's two sums go to part[2 block], part[2 block + 1] (summed by k_loss_rays: deterministic) instead of into acc by atomics
+__device__ __forceinline__ void eikonal_block(int block, int nblocks, const float *__restrict__ g1, const float *__restrict__ g2, int64_t H, float w_eik,
+                                              float w_smooth, float *__restrict__ acc, float *__restrict__ part, float *__restrict__ d_g1,
+                                              float *__restrict__ d_g2) {
     __shared__ float scratch[4];
     const float invH = 1.f / (float)H;
     float s_e = 0.f, s_s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < H; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < H; i += (int64_t)nblocks * 256) {
         const float a[3] = {g1[3 * i], g1[3 * i + 1], g1[3 * i + 2]};
         const float b[3] = {g2[3 * i], g2[3 * i + 1], g2[3 * i + 2]};
         const Unit ua = unit(a, 1e-5f), ub = unit(b, 1e-5f);
@@ -218,11 +230,35 @@ __global__ __launch_bounds__(256) void k_loss_eikonal(const float *__restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { scratch[wave] = s_e; }
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(acc, scratch[0] + scratch[1] + scratch[2] + scratch[3]);
+    if (threadIdx.x == 0) {
+        const float v = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        if (part) part[2 * block] = v;
+        else unsafeAtomicAdd(acc, v);
+    }
     __syncthreads();
     if (lane == 0) { scratch[wave] = s_s; }
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(acc + 1, scratch[0] + scratch[1] + scratch[2] + scratch[3]);
+    if (threadIdx.x == 0) {
+        const float v = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        if (part) part[2 * block + 1] = v;
+        else unsafeAtomicAdd(acc + 1, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_loss_eikonal(const float *__restrict__ g1, const float *__restrict__ g2, int64_t H, float w_eik, float w_smooth,
+                                                       float *__restrict__ acc, float *__restrict__ d_g1, float *__restrict__ d_g2) {
+    eikonal_block(blockIdx.x, gridDim.x, g1, g2, H, w_eik, w_smooth, acc, nullptr, d_g1, d_g2);
+}
+
+// hs_loss_stage1's first launch: the ray-local blocks and the Eikonal blocks are independent -- one launch for both (a launch costs ~5 us
+// in the replayed iteration whatever its size)
+__global__ __launch_bounds__(256) void k_loss_local(const float *__restrict__ sdf, const float *__restrict__ opac, const int64_t *__restrict__ segs,
+                                                     const float *__restrict__ gt_mask, int R, int N, int K, float w_opac, float *__restrict__ fg,
+                                                     float *__restrict__ bce, float *__restrict__ g_opac, int nb_local, const float *__restrict__ g1,
+                                                     const float *__restrict__ g2, int64_t H, float w_eik, float w_smooth, float *__restrict__ part,
+                                                     float *__restrict__ d_g1, float *__restrict__ d_g2) {
+    if ((int)blockIdx.x < nb_local) ray_local_block(blockIdx.x, sdf, opac, segs, gt_mask, R, N, K, w_opac, fg, bce, g_opac);
+    else eikonal_block((int)blockIdx.x - nb_local, (int)gridDim.x - nb_local, g1, g2, H, w_eik, w_smooth, nullptr, part, d_g1, d_g2);
 }
 
 // Background-surface smoothness (model/loss.py:519-547 compute_grad_error on the depth and on the three normal channels of the
@@ -295,9 +331,9 @@ int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, cons
     if (!rgb || !rgb_gt || !depth || !depth_gt || !normal_map || !normal_gt || !gt_mask || !sdf || !opacity || !segs || !out5 || !g_rgb || !g_depth ||
         !g_normal_map || !g_opacity || !scratch)
         return HS_ERR_NULL;
-    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w_opac, scratch, scratch + R, g_opacity, nullptr);
+    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w_opac, scratch, scratch + R, g_opacity);
     k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, scratch, scratch + R, R, K, w_rgb, w_depth, w_l1,
-                                                        w_cos, out5, g_rgb, g_depth, g_normal_map, nullptr, 0.f, 0.f, 0.f, 0.f);
+                                                        w_cos, out5, g_rgb, g_depth, g_normal_map, nullptr, 0, 0.f, 0.f, 0.f, 0.f);
     return check_launch();
 }
 
@@ -310,12 +346,13 @@ int hs_loss_stage1(const float *rgb, const float *rgb_gt, const float *depth, co
         !g_rgb || !g_depth || !g_normal_map || !g_opacity || !d_g1 || !d_g2 || !scratch)
         return HS_ERR_NULL;
     const float *w = weights7;   // rgb, depth, normal_l1, normal_cos, opacity, eikonal, smooth
-    float *acc2 = scratch + 2 * (size_t)R;
-    k_loss_ray_local<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w[4], scratch, scratch + R, g_opacity, acc2);
+    float *part = scratch + 2 * (size_t)R;      // [HS_LOSS_EIK_BLOCKS][2]: per-block sums of the Eikonal / smoothness terms
     const int64_t want = (H + 255) / 256;
-    k_loss_eikonal<<<(int)(want < 2048 ? want : 2048), 256, 0, (hipStream_t)stream>>>(g1, g2, H, w[5], w[6], acc2, d_g1, d_g2);
+    const int nb_local = (R + 3) / 4, nb_eik = (int)(want < HS_LOSS_EIK_BLOCKS ? want : HS_LOSS_EIK_BLOCKS);
+    k_loss_local<<<nb_local + nb_eik, 256, 0, (hipStream_t)stream>>>(sdf, opacity, segs, gt_mask, R, N, K, w[4], scratch, scratch + R, g_opacity, nb_local, g1, g2,
+                                                                     H, w[5], w[6], part, d_g1, d_g2);
     k_loss_rays<<<1, kBlock, 0, (hipStream_t)stream>>>(rgb, rgb_gt, depth, depth_gt, normal_map, normal_gt, scratch, scratch + R, R, K, w[0], w[1], w[2], w[3],
-                                                        out8, g_rgb, g_depth, g_normal_map, acc2, 1.f / (float)H, w[4], w[5], w[6]);
+                                                        out8, g_rgb, g_depth, g_normal_map, part, nb_eik, 1.f / (float)H, w[4], w[5], w[6]);
     return check_launch();
 }
 

@@ -28,7 +28,7 @@ class hsGate(ctypes.Structure):
 class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
-                ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64)]
+                ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64), ("ws_clean", ctypes.c_int32)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -85,6 +85,7 @@ ABI_VERSION = 4
 # together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
 # requests inside an iteration is the same every time, so a captured graph sees the same addresses as its warm-up passes.
 _ZERO_POOL = {"buf": None, "pos": 0}
+_SCATTER_WS = {}
 
 
 def set_zero_pool(buf):
@@ -259,7 +260,7 @@ class _HipBackend:
     @staticmethod
     def _layout(B, D, C, L, gate=None, ws=None, level_major=False, grids=None):
         """grids: None, or (grid_id int32 [B], entries per grid): a batched-over-grids launch (hsHashLayout::grid_id)."""
-        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0)
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0)
         if grids is not None:
             if ws is not None:
                 raise ValueError("the binned scatter holds the records of ONE table: no scatter work space with grids=")
@@ -270,8 +271,9 @@ class _HipBackend:
         if level_major:      # features [L, B, C]: consecutive lanes (points) write consecutive 4C-byte entries
             lay.level_stride, lay.point_stride = B * C, C
         if ws is not None:
-            buf, cap = ws
+            buf, cap = ws[:2]
             lay.scatter_ws, lay.scatter_cap = _dev(buf, "scatter_ws", torch.uint8).value, cap
+            lay.ws_clean = int(len(ws) > 2 and bool(ws[2]))
         return lay
 
     @staticmethod
@@ -285,7 +287,16 @@ class _HipBackend:
         n = lib.hs_hash_scatter_ws_bytes(B, D, C, L, ctypes.byref(cap))
         if n < 0:
             raise RuntimeError(f"hs_hash_scatter_ws_bytes: {n}")
-        return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
+        # one PERSISTENT work space per shape and device, zero-filled once: the reduce kernel returns the bin counters to zero, so a scatter
+        # through it needs no clearing launch (third element: hsHashLayout::ws_clean).  Scatters on one stream use it one after the other; it is
+        # created eagerly (the warm-up passes of a captured iteration), never inside a capture
+        key = (int(B), int(D), int(C), int(L), str(torch.device(device)))
+        hit = _SCATTER_WS.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
+            hit = _SCATTER_WS[key] = (torch.zeros(n, device=device, dtype=torch.uint8), int(cap.value), True)
+        return hit
 
     @classmethod
     def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False, grids=None):
@@ -991,7 +1002,7 @@ class _HipBackend:
         R, N = sdf.shape
         K = opac.shape[1]
         w = (ctypes.c_float * 7)(*[float(x) for x in weights7])
-        scratch = torch.empty(2 * R + 2, device=rgb.device)
+        scratch = torch.empty(2 * R + 2 * 256, device=rgb.device)      # HS_LOSS_EIK_BLOCKS
         _check(lib.hs_loss_stage1(_dev(rgb, "rgb"), _dev(rgb_gt, "rgb_gt"), _dev(depth, "depth"), _dev(depth_gt, "depth_gt"), _dev(nmap, "normal_map"),
                                   _dev(n_gt, "normal_gt"), _dev(gt_mask, "gt_mask"), _dev(sdf, "sdf"), _dev(opac, "opacity"),
                                   _dev(segs, "segs", torch.int64), R, N, K, _dev(g1, "g1"), _dev(g2, "g2"), ctypes.c_int64(g1.shape[0]), w,

@@ -110,6 +110,8 @@ typedef struct hsHashLayout {
      * (of C floats) after `embeddings` / `grad_embeddings`, all grids share `offsets`.  Needs scatter_ws == NULL. */
     const int32_t *grid_id;
     int64_t grid_stride;
+    int32_t ws_clean;          /* != 0: the caller guarantees that the counters at the head of scatter_ws are zero -- as a fresh zero-filled work
+                                * space has them and as every hs_hash_bwd / hs_hash_bwd_jac leaves them -- so the clearing launch is skipped */
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */
@@ -650,7 +652,8 @@ int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, cons
 int hs_loss_eikonal(const float *g1, const float *g2, int64_t H, float w_eik, float w_smooth, float *acc2, float *d_g1, float *d_g2, void *stream);
 /* Both of the above plus the weighted total (loss.py:325-334, 655-657) as three launches with no host-side glue:
  * weights7 (HOST array) = weights of {rgb, depth, normal_l1, normal_cos, opacity, eikonal, smooth};
- * out8 = the seven unweighted terms in that order, then sum_i weights7[i] * term_i.  scratch [2R + 2] (needs no initialisation). */
+ * out8 = the seven unweighted terms in that order, then sum_i weights7[i] * term_i.  scratch [2R + 2 * HS_LOSS_EIK_BLOCKS] (needs no initialisation). */
+#define HS_LOSS_EIK_BLOCKS 256
 int hs_loss_stage1(const float *rgb, const float *rgb_gt, const float *depth, const float *depth_gt, const float *normal_map, const float *normal_gt,
                    const float *gt_mask, const float *sdf, const float *opacity, const int64_t *segs, int32_t R, int32_t N, int32_t K, const float *g1,
                    const float *g2, int64_t H, const float *weights7, float *out8, float *g_rgb, float *g_depth, float *g_normal_map, float *g_opacity,
