@@ -268,6 +268,7 @@ TIMED = {
     "trunk_rr_bwd_value": ("k_rr_bwd_value (double backward, value part: W2^T, W1^T, W0^T)", _work_rr_bwd_value),
     "wgrad_pairs": ("k_wgrad_pairs (weight gradients: all products of the trunk backward in one launch, all of the appearance backward in another; slices cut by bytes)", _work_wgrad_pairs),
     "trunk_rr_pack": ("k_rr_pack (transposed fragment images)", None),
+    "trunk_pack_all": ("k_trunk_pack_all (every weight image of a trunk training pass, one launch)", None),
 }
 LIBRARY_GEMM = "library GEMMs (hipBLASLt through torch.bmm: weight gradients not taken by k_wgrad_rows)"
 

@@ -36,10 +36,10 @@ __host__ __device__ inline int slot_column(int hh, int sigma) { return sigma < 4
 
 // ---------------------------------------------------------------------------------------------------------------- packing
 // W1^T, W0^T (slot order), W2^T as fragment images, W2 as an fp32 gather table [32][256]
-__global__ __launch_bounds__(256) void k_rr_pack(const float *__restrict__ W0, int ld0, const float *__restrict__ W1, const float *__restrict__ W2, int d_out,
-                                                 uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf, uint16_t *__restrict__ W2Tf,
-                                                 float *__restrict__ W2tab) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+constexpr int kRrPackSlots = HS * NT * 64 + HS * XS * 64 + 2 * NT * 64 + 32 * 256 / 4;
+__device__ __forceinline__ void rr_pack_slot(int idx, const float *__restrict__ W0, int ld0, const float *__restrict__ W1, const float *__restrict__ W2, int d_out,
+                                             uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf, uint16_t *__restrict__ W2Tf,
+                                             float *__restrict__ W2tab) {
     constexpr int n1 = HS * NT * 64, n0 = HS * XS * 64, n2 = 2 * NT * 64, nt = 32 * 256 / 4;
     float v[8];
     uint16_t *dst;
@@ -70,6 +70,52 @@ __global__ __launch_bounds__(256) void k_rr_pack(const float *__restrict__ W0, i
         return;
     } else {
         return;
+    }
+    uint4 pk;
+    pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
+    *reinterpret_cast<uint4 *>(dst) = pk;
+}
+
+__global__ __launch_bounds__(256) void k_rr_pack(const float *__restrict__ W0, int ld0, const float *__restrict__ W1, const float *__restrict__ W2, int d_out,
+                                                 uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf, uint16_t *__restrict__ W2Tf,
+                                                 float *__restrict__ W2tab) {
+    rr_pack_slot(blockIdx.x * 256 + threadIdx.x, W0, ld0, W1, W2, d_out, W1Tf, W0Tf, W2Tf, W2tab);
+}
+
+// Every weight image a training pass of the trunk needs, in ONE launch: the plain-domain fragment images + bias block (sdf_mlp2.hip's packing
+// with act = 1), the transposed fragment images above, and -- for the value+Jacobian backward of the Eikonal points (sdf_mlp.hip: k_trunk_bwd)
+// -- the row-major bf16 transposes W1^T [256,256], W2^T [256,32] (columns >= d_out zero), W0^T [256,256] (rows >= f_in zero).  Three
+// launches of ~5 us before; a dispatch costs that whatever it does.
+constexpr int kTransSlots = (256 * 256 + 256 * 32 + 256 * 256) / 8;
+__global__ __launch_bounds__(256) void k_trunk_pack_all(const float *__restrict__ W0, int ld0, int f_in, const float *__restrict__ b0, const float *__restrict__ W1,
+                                                        const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
+                                                        uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
+                                                        float *__restrict__ bias, uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf,
+                                                        uint16_t *__restrict__ W2Tf, float *__restrict__ W2tab, uint16_t *__restrict__ w1t,
+                                                        uint16_t *__restrict__ w2t, uint16_t *__restrict__ w0t) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < kSdfPackSlots) { sdf_pack2_slot(idx, W0, ld0, b0, W1, b1, W2, b2, d_out, W0f, W1f, W2f, bias, 1.f); return; }
+    idx -= kSdfPackSlots;
+    if (idx < kRrPackSlots) { rr_pack_slot(idx, W0, ld0, W1, W2, d_out, W1Tf, W0Tf, W2Tf, W2tab); return; }
+    idx -= kRrPackSlots;
+    if (w1t == nullptr || idx >= kTransSlots) return;
+    float v[8];
+    uint16_t *dst;
+    if (idx < 256 * 32) {                          // W1^T
+        const int r = idx >> 5, c = (idx & 31) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = W1[(size_t)(c + e) * 256 + r];
+        dst = w1t + (size_t)r * 256 + c;
+    } else if (idx < 256 * 32 + 256 * 4) {         // W2^T, padded to 32 columns
+        const int i = idx - 256 * 32, r = i >> 2, c = (i & 3) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = c + e < d_out ? W2[(size_t)(c + e) * 256 + r] : 0.f;
+        dst = w2t + (size_t)r * 32 + c;
+    } else {                                       // W0^T, padded to 256 rows
+        const int i = idx - 256 * 32 - 256 * 4, r = i >> 5, c = (i & 31) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = r < f_in ? W0[(size_t)(c + e) * ld0 + r] : 0.f;
+        dst = w0t + (size_t)r * 256 + c;
     }
     uint4 pk;
     pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
@@ -775,8 +821,21 @@ int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float 
                      void *stream) {
     if (d_out < 1 || d_out > 32 || ld0 < 71) return HS_ERR_ARG;
     if (!W0 || !W1 || !W2 || !W1Tf || !W0Tf || !W2Tf || !W2tab) return HS_ERR_NULL;
-    const int slots = HS * NT * 64 + HS * XS * 64 + 2 * NT * 64 + 32 * 256 / 4;
+    const int slots = kRrPackSlots;
     k_rr_pack<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(W0, ld0, W1, W2, d_out, (uint16_t *)W1Tf, (uint16_t *)W0Tf, (uint16_t *)W2Tf, W2tab);
+    return wt_check_launch();
+}
+
+int hs_trunk_pack_all(const float *W0, int32_t ld0, int32_t f_in, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
+                      void *W0f, void *W1f, void *W2f, float *bias, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab, void *w1t, void *w2t, void *w0t,
+                      void *stream) {
+    if (d_out < 1 || d_out > 32 || ld0 < 71 || f_in < 1 || f_in > 256 || f_in > ld0) return HS_ERR_ARG;
+    if (!W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !W0f || !W1f || !W2f || !bias || !W1Tf || !W0Tf || !W2Tf || !W2tab) return HS_ERR_NULL;
+    if ((w1t != nullptr) != (w2t != nullptr) || (w1t != nullptr) != (w0t != nullptr)) return HS_ERR_NULL;
+    const int slots = kSdfPackSlots + kRrPackSlots + (w1t ? kTransSlots : 0);
+    k_trunk_pack_all<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(W0, ld0, f_in, b0, W1, b1, W2, b2, d_out, (uint16_t *)W0f, (uint16_t *)W1f, (uint16_t *)W2f,
+                                                                         bias, (uint16_t *)W1Tf, (uint16_t *)W0Tf, (uint16_t *)W2Tf, W2tab, (uint16_t *)w1t,
+                                                                         (uint16_t *)w2t, (uint16_t *)w0t);
     return wt_check_launch();
 }
 

@@ -57,13 +57,13 @@ __host__ __device__ inline int input_column(int h, int j) {
 
 // ---------------------------------------------------------------------------------------------------------------- weight packing
 // fp32 effective (weight-normalised) matrices, row-major [out][in] -> bf16 fragment images + the bias block
-__global__ __launch_bounds__(256) void k_sdf_pack2(const float *__restrict__ W0, int ld0, const float *__restrict__ b0, const float *__restrict__ W1,
-                                                   const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
-                                                   uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
-                                                   float *__restrict__ bias, float act) {
+constexpr int kSdfPackSlots = K0S * NT * 64 + HS * NT * 64 + HS * 64 + kBias;      // one thread per 16-byte fragment slot / bias entry
+__device__ __forceinline__ void sdf_pack2_slot(int idx, const float *__restrict__ W0, int ld0, const float *__restrict__ b0, const float *__restrict__ W1,
+                                               const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
+                                               uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
+                                               float *__restrict__ bias, float act) {
     // act: factor folded into W0 and the hidden biases (its inverse into W2): 100 log2(e) for the inference kernel's log2-domain
     // softplus, 1 for the training kernel (which stores plain-domain activations for the backward pass)
-    const int idx = blockIdx.x * 256 + threadIdx.x;      // one 16-byte fragment slot per thread
     constexpr int n0 = K0S * NT * 64, n1 = HS * NT * 64, n2 = HS * 64;
     float v[8];
     uint16_t *dst;
@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void k_sdf_pack2(const float *__restrict__ W0,
     uint4 pk;
     pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]); pk.z = pack2(v[4], v[5]); pk.w = pack2(v[6], v[7]);
     *reinterpret_cast<uint4 *>(dst) = pk;
+}
+
+__global__ __launch_bounds__(256) void k_sdf_pack2(const float *__restrict__ W0, int ld0, const float *__restrict__ b0, const float *__restrict__ W1,
+                                                   const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
+                                                   uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
+                                                   float *__restrict__ bias, float act) {
+    sdf_pack2_slot(blockIdx.x * 256 + threadIdx.x, W0, ld0, b0, W1, b1, W2, b2, d_out, W0f, W1f, W2f, bias, act);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- tile machinery

@@ -148,7 +148,7 @@ def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
-            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
+            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd"]
 
 
@@ -647,6 +647,28 @@ class _HipBackend:
         _check(lib.hs_trunk_rr_pack(_dev(W0, "W0"), int(W0.stride(0)), _dev(W1, "W1"), _dev(W2, "W2"), int(d_out), _dev(W1Tf, "W1Tf", bf),
                                     _dev(W0Tf, "W0Tf", bf), _dev(W2Tf, "W2Tf", bf), _dev(W2tab, "W2tab"), _stream()), "hs_trunk_rr_pack")
         return W1Tf, W0Tf, W2Tf, W2tab
+
+    @staticmethod
+    def trunk_pack_all(W0, b0, W1, b1, W2, b2, d_out, transposes):
+        """sdf_mlp2_pack(log2_domain=False) + trunk_rr_pack (+ the row-major bf16 transposes w1t, w2t, w0t when `transposes`) in ONE launch
+        -> (packed, rr, (w1t, w2t, w0t) or None)."""
+        lib = load_library()
+        lib.hs_sdf_mlp2_pack_bytes.restype = ctypes.c_int64
+        lib.hs_trunk_rr_pack_bytes.restype = ctypes.c_int64
+        dev, bf = W0.device, torch.bfloat16
+        n = [int(lib.hs_sdf_mlp2_pack_bytes(i)) // 2 for i in range(3)]
+        w12 = torch.empty(n[1] + n[2], device=dev, dtype=bf)
+        packed = (torch.empty(n[0], device=dev, dtype=bf), w12[:n[1]], w12[n[1]:], torch.empty(int(lib.hs_sdf_mlp2_pack_bytes(3)) // 4, device=dev))
+        m = [int(lib.hs_trunk_rr_pack_bytes(i)) for i in range(4)]
+        rr = tuple(torch.empty(m[i] // 2, device=dev, dtype=bf) for i in range(3)) + (torch.empty(m[3] // 4, device=dev),)
+        tr = (torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 32, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)) if transposes else None
+        if W0.stride(1) != 1 or W0.stride(0) < 71:
+            raise RuntimeError("trunk_pack_all: W0 must be row-major with at least 71 columns")
+        _check(lib.hs_trunk_pack_all(_dev(W0, "W0"), int(W0.stride(0)), int(W0.shape[1]), _dev(b0, "b0"), _dev(W1, "W1"), _dev(b1, "b1"), _dev(W2, "W2"),
+                                     _dev(b2, "b2"), int(d_out), *[_dev(t, "frag", bf) for t in packed[:3]], _dev(packed[3], "bias"),
+                                     *[_dev(t, "frag", bf) for t in rr[:3]], _dev(rr[3], "W2tab"),
+                                     *([_dev(t, "transpose", bf) for t in tr] if tr else [None, None, None]), _stream()), "hs_trunk_pack_all")
+        return packed, rr, tr
 
     @staticmethod
     def trunk_rr_fwd_value(x, feat, packed, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot):

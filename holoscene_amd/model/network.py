@@ -523,9 +523,9 @@ class _trunk_render_rr(torch.autograd.Function):
         be.fwd(x01, embeddings, offsets, feat, B, 3, C, L, S, Hres, dydx)
         jac = 0.5 / divide_factor
         f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-        packed = be.sdf_mlp2_pack(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2, b2.detach().float().contiguous(), K,
-                                  log2_domain=False)
-        rr = be.trunk_rr_pack(f0, f1, f2, K)
+        # every weight image of this pass -- fragment images, their transposes, the Eikonal points' row-major transposes -- in one launch
+        packed, rr, trans = be.trunk_pack_all(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2,
+                                              b2.detach().float().contiguous(), K, transposes=Be > 0)
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
@@ -539,8 +539,7 @@ class _trunk_render_rr(torch.autograd.Function):
         if Be > 0:      # value + three tangent rows per Eikonal point (csrc/trunk_mlp2.hip), same weight images
             Me = 4 * Be
             H0e, H1e, Xpe = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 80, device=dev, dtype=bf)
-            w1t, w2t, w0t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 32, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)
-            be.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, K, True), (f0, w0t, 0, 0, W0.shape[1], 256, True)])
+            w1t, w2t, w0t = trans
             be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
                               split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n)
             eik = (H0e, H1e, Xpe, w0t, w1t, w2t)

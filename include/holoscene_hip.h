@@ -568,6 +568,12 @@ int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, i
 int64_t hs_trunk_rr_pack_bytes(int32_t which);
 int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
                      void *stream);
+/* hs_sdf_mlp2_pack (plain-domain images: log2_domain = 0) + hs_trunk_rr_pack + the three row-major bf16 transposes the value+Jacobian backward of
+ * the Eikonal points reads (w1t [256,256] = W1^T, w2t [256,32] = W2^T zero-padded, w0t [256,256] = W0^T with rows >= f_in zero; all three NULL
+ * = skip) in ONE launch: what a training pass of the trunk needs from its fp32 effective matrices. */
+int hs_trunk_pack_all(const float *W0, int32_t ld0, int32_t f_in, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
+                      void *W0f, void *W1f, void *W2f, float *bias, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab, void *w1t, void *w2t, void *w0t,
+                      void *stream);
 int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                           void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
 int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
