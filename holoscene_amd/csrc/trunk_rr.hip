@@ -159,6 +159,7 @@ struct EFac {
 };
 __device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const float *__restrict__ dydx, int64_t gp, int64_t ld, int hh, float jac_scale, bool ok) {
     EFac E;
+    asm volatile("" : "+v"(hh));        // opaque: the frequency factors and level offsets are otherwise per-lane loop invariants, kept (and spilled) across the tile loop
     const int64_t b = ok ? gp : 0;
     const float xs[3] = {x[b * 3], x[b * 3 + 1], x[b * 3 + 2]};
 #pragma unroll
@@ -366,11 +367,15 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__re
             if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
         if (ok) {
+            // (opaque lane half: written as 8 q + 4 h the eight 64-bit store offsets are loop invariants the compiler keeps in registers it does
+            // not have -- and a scratch reload waits on the vector-memory counter, i.e. for every activation store in front of it)
+            int hq = h;
+            asm volatile("" : "+v"(hq));
             float *dst = sdf_raw + gp * d_out;
             uint16_t *oh = onehot + gp * 32;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int n0 = 8 * q + 4 * h;
+                const int n0 = 8 * q + 4 * hq;
                 if ((d_out & 3) == 0) {
                     if (n0 < d_out) *reinterpret_cast<float4 *>(dst + n0) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
                 } else {
@@ -490,14 +495,19 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
             resident = true;
         }
         // layer 1, finished tile nd: acc = v1~ ; u1~ = v1~ s1 (TP), a1' = v1~ u1 s1' (TP), u1 = W2[k*] gathered
+        // u1 of a tile (eight neurons of W2's arg-min row per lane) is requested a phase ahead beside the saved activations: a load that is
+        // issued and consumed inside an epilogue slice makes the slice wait for EVERY vector-memory operation before it -- the counter retires
+        // in order -- including the stores of the slices just before (measured: 70 full drains per tile in this kernel)
         TilePair h1w[2];
+        float4 u1w[2][4];
+        const float *u1row = W2tab + (size_t)bi * 256 + 4 * h;
         auto epi1 = [&](auto slc, const f32x16 &src, int nd) {
             constexpr int sl = decltype(slc)::value;
             if constexpr (sl < 8) {
                 const uint32_t hwd = tile_word(h1w[nd & 1], sl);
                 const float sa = sig_of_h(lo_bf(hwd)), sb = sig_of_h(hi_bf(hwd));
-                const int nn = 32 * nd + 8 * (sl >> 1) + 4 * h + 2 * (sl & 1);
-                const float2 u1 = *reinterpret_cast<const float2 *>(W2tab + (size_t)bi * 256 + nn);
+                const float4 uq = u1w[nd & 1][sl >> 1];        // neurons 32 nd + 8 (sl >> 1) + 4 h + 0..3
+                const float2 u1 = (sl & 1) ? make_float2(uq.z, uq.w) : make_float2(uq.x, uq.y);
                 const float va = src[2 * sl], vb = src[2 * sl + 1];
                 wb[sl] = anchor(pack2(va * sa, vb * sb));
                 wa[sl] = anchor(pack2(va * u1.x * (100.f * sa * (1.f - sa)), vb * u1.y * (100.f * sb * (1.f - sb))));
@@ -511,6 +521,11 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
             constexpr int nt = decltype(nc)::value;
             auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
             h1w[nt & 1] = tp_load_tile(H1t, here(tile), nt, lane);
+            {
+                const float *ur = u1row + here(0) + 32 * nt;
+#pragma unroll
+                for (int q = 0; q < 4; q++) u1w[nt & 1][q] = *reinterpret_cast<const float4 *>(ur + 8 * q);
+            }
             if constexpr (nt == 0) phase1r<HS, 2, 10, 12, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 7); });
             else phase1r<HS, 2, HS, 12, true, true>(acc[nt & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(nt & 1) ^ 1], nt - 1); });
         });
@@ -803,6 +818,338 @@ __global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, 
     }
 }
 
+// ================================================================================================================ fused forward
+// k_rr_fwd_value + k_rr_fwd_grad in ONE kernel per tile: the activations the gradient pass needs (h0, h1 of the SAME samples) are still in the
+// wave's registers when the value pass ends, so they are not read back (102 MB), and v1 = u1 . s1, v0 = u0 . s0 overwrite them in place.  Two
+// 256 x 256 matrices (W1, W1^T) cannot both be LDS-resident: the workgroup shares the weight pipeline of appearance2.hip -- seven chunks of
+// whole neuron tiles cycling through two 64 KB LDS buffers by LDS-DMA, the eight waves meeting once per chunk -- which also frees the
+// registers of the streamed-weight rings, so the value layers run in QUARTER phases (two accumulator chains) like sdf_mlp2.hip.
+constexpr int kFBuf = 4 * 16 * 1024;
+constexpr int kW2Rows = 16 * 1024, kW2Pitch = 1024 + 16;      // chunk 3: W2 fragments | 32 fp32 rows of W2, padded against bank conflicts
+#ifndef HS_FA
+#define HS_FA 2
+#endif
+#ifndef HS_COUNTED
+#define HS_COUNTED 1
+#endif
+constexpr bool kCountedWait = HS_COUNTED;
+constexpr int kFA = HS_FA;      // k-steps a weight fragment is read from LDS ahead of its MFMAs
+// the 1 KB pieces (tile nt0 + ntl, k-step s) of a [k-step][tile] fragment image -> LDS [ntl][s], dealt round-robin to the eight waves
+__device__ __forceinline__ void dma_tiles(const uint16_t *__restrict__ img, char *dst, int ks, int ntot, int nt0, int ntn, int wave, int lane) {
+    uint32_t lo = (uint32_t)lane * 16u;       // opaque: the request addresses are loop invariants the compiler would keep (and spill)
+    asm volatile("" : "+v"(lo));
+    const char *src = reinterpret_cast<const char *>(img);
+    for (int p = wave; p < ntn * ks; p += kWaves) {
+        const int ntl = p / ks, s_ = p - ntl * ks;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)(s_ * ntot + nt0 + ntl) * 1024 + lo),
+                                         (__attribute__((address_space(3))) void *)(dst + (size_t)p * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict__ x, const float *__restrict__ feat, const float *__restrict__ dydx,
+                                                          const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
+                                                          const float *__restrict__ biasg, const float *__restrict__ W2tab,
+                                                          const uint16_t *__restrict__ W1Tf, const uint16_t *__restrict__ W0Tf, int d_out,
+                                                          uint16_t *__restrict__ H0t, uint16_t *__restrict__ H1t, uint16_t *__restrict__ Xp,
+                                                          float *__restrict__ sdf_raw, float *__restrict__ sdf, int64_t *__restrict__ idx,
+                                                          uint16_t *__restrict__ onehot, uint16_t *__restrict__ U0t, uint16_t *__restrict__ V1t,
+                                                          uint16_t *__restrict__ V0t, float *__restrict__ grad, float *__restrict__ uxh, float jac_scale,
+                                                          int64_t n, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) char ldsf[];
+    float *bias = reinterpret_cast<float *>(ldsf + 2 * kFBuf);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 31, h = lane >> 5;
+    int par = 0;
+    // chunk J of a super-tile: 0 W0 (8 tiles x 5 k-steps), 1-2 W1 (4 tiles each), 3 W2, 4-5 W1^T, 6 W0^T (3 slot tiles)
+    auto request = [&](int J, int buf) {
+        char *dst = ldsf + buf * kFBuf;
+        if (J == 0) dma_tiles(W0f, dst, K0S, NT, 0, NT, wave, lane);
+        else if (J == 1 || J == 2) dma_tiles(W1f, dst, HS, NT, 4 * (J - 1), 4, wave, lane);
+        else if (J == 3) {       // W2 (16 KB) and, behind it, the fp32 rows of W2 the gradient chain starts from (32 rows at a pitch of 1 KB + 16 B)
+            dma_tiles(W2f, dst, HS, 1, 0, 1, wave, lane);
+            uint32_t lo = (uint32_t)lane * 16u;
+            asm volatile("" : "+v"(lo));
+            for (int p = wave; p < 32; p += kWaves)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(W2tab) + (size_t)p * 1024 + lo),
+                                                 (__attribute__((address_space(3))) void *)(dst + kW2Rows + (size_t)p * kW2Pitch), 16, 0, 0);
+        }
+        else if (J == 4 || J == 5) dma_tiles(W1Tf, dst, HS, NT, 4 * (J - 4), 4, wave, lane);
+        else dma_tiles(W0Tf, dst, HS, XS, 0, XS, wave, lane);
+    };
+    request(0, 0);
+    for (int i = threadIdx.x; i < kBias; i += kThreadsW) bias[i] = biasg[i];
+    __syncthreads();        // the bias block (the chunk barriers below are bare barrier instructions)
+    const int64_t ntiles = (n + kRows - 1) / kRows;
+    const int64_t wt0 = tile_begin(ntiles), wt1 = tile_end(ntiles);
+    for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
+        const int64_t tile = r0 + wave;
+        const bool live = tile < wt1;
+        const bool more = r0 + kWaves < wt1;
+        const int64_t gp = tile * kRows + row;
+        const bool ok = live && gp < n;
+        // Chunk J must have landed.  The vector-memory counter retires in issue order and counts this wave's activation stores too: waiting
+        // for zero would drain every store of the phase before (a round trip to L2 per chunk); kAfter[J] is a lower bound of the vector-memory
+        // instructions a LIVE wave issues between the requests of chunk J and this point, so that many may still be in flight.
+        auto chunk_begin = [&](auto jc, auto livec) -> char * {
+            constexpr int J = decltype(jc)::value;
+            constexpr bool counted = decltype(livec)::value && kCountedWait;
+            if constexpr (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (J == 0) { if (r0 == wt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); }
+            else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (J == 2 || J == 3 || J == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (J == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // (bare: __syncthreads() brings a workgroup fence, for which the compiler waits for vmcnt(0) anyway)
+            if constexpr (J + 1 < 7) request(J + 1, par ^ 1);
+            else if (more) request(0, par ^ 1);
+            asm volatile("" ::: "memory");      // no store of the coming phase is scheduled ahead of the requests
+            char *base = ldsf + par * kFBuf;
+            par ^= 1;
+            return base;
+        };
+        if (!live) {
+            static_for<7>([&](auto jc) { (void)chunk_begin(jc, std::false_type{}); });
+            continue;
+        }
+        // ---- inputs (k_rr_fwd_value)
+        uint32_t hin[4 * K0S];
+        {
+            float v[40];
+            const float x0 = ok ? x[gp * 3] : 0.f, x1 = ok ? x[gp * 3 + 1] : 0.f, x2 = ok ? x[gp * 3 + 2] : 0.f;
+            const float xs[3] = {x0, x1, x2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float f = h ? (float)(8 << k) : (float)(1 << k);
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float sn, cs;
+                    __sincosf(xs[d] * f, &sn, &cs);
+                    v[6 * k + d] = sn;
+                    v[6 * k + 3 + d] = cs;
+                }
+            }
+            const float4 *fp = reinterpret_cast<const float4 *>(feat + (ok ? gp : 0) * 32 + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 t = ok ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[18 + 4 * i] = t.x; v[19 + 4 * i] = t.y; v[20 + 4 * i] = t.z; v[21 + 4 * i] = t.w;
+            }
+            v[34] = h ? 0.f : x0; v[35] = h ? 0.f : x1; v[36] = h ? 0.f : x2;
+            v[37] = v[38] = v[39] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 40; j += 2) hin[j >> 1] = ok ? pack2(v[j], v[j + 1]) : 0u;
+            if (ok) {
+                uint4 *xp = reinterpret_cast<uint4 *>(Xp + gp * 80 + 40 * h);
+#pragma unroll
+                for (int i = 0; i < 5; i++) xp[i] = make_uint4(hin[4 * i], hin[4 * i + 1], hin[4 * i + 2], hin[4 * i + 3]);
+            }
+        }
+        const uint32_t bias_b = lds_base(bias, 16 * h);
+        uint32_t h0p[64], h1p[64];          // h0 -> (in place) v0;  h1 -> (in place) v1
+        f32x16 acc[2][2];
+        // epilogue of a finished quarter qd of a value layer: slices 0..15 Softplus + pack of one register pair, 16..19 its four k-steps leave
+        auto epi = [&](auto slc, const f32x16 (&src)[2], uint32_t *hp, auto qdc, uint16_t *T) {
+            constexpr int sl = decltype(slc)::value, qd = decltype(qdc)::value;
+            if constexpr (sl < 16) {
+                constexpr int j = sl >> 3, r = sl & 7, nd = 2 * qd + j;
+                hp[8 * nd + r] = anchor(pack2(softplus100(src[j][2 * r]), softplus100(src[j][2 * r + 1])));
+            } else {
+                constexpr int ks = 4 * qd + (sl - 16);
+                tp_store(T, here(tile), ks, lane, hp + 4 * ks, ok);
+            }
+        };
+        // ---- layer 0 (chunk 0)
+        {
+            char *cb = chunk_begin(std::integral_constant<int, 0>{}, std::true_type{});
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                init_acc_b(acc[q & 1][0], relaunder(bias_b), 32 * (2 * q));
+                init_acc_b(acc[q & 1][1], relaunder(bias_b), 32 * (2 * q + 1));
+                const uint32_t ab = lds_base(cb + 2 * q * K0S * 1024, lane * 16);
+                auto f0 = [&](int s_, int j) { return lds_at<bf16x8>(ab, (j * K0S + s_) * 1024); };
+                if constexpr (q == 0) phase2<K0S, kFA, K0S, 20, false>(acc[0], hin, f0, [](auto) {});
+                else phase2<K0S, kFA, K0S, 20, true>(acc[q & 1], hin, f0, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h0p, std::integral_constant<int, q - 1>{}, H0t); });
+            });
+        }
+        // ---- layer 1 (chunks 1, 2); quarter 0 finishes layer 0's quarter 3 within its first 10 k-steps
+        {
+            char *cb = nullptr;
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 1 + q / 2>{}, std::true_type{});
+                init_acc_b(acc[q & 1][0], relaunder(bias_b), 256 + 32 * (2 * q));
+                init_acc_b(acc[q & 1][1], relaunder(bias_b), 256 + 32 * (2 * q + 1));
+                const uint32_t ab = lds_base(cb + 2 * (q % 2) * HS * 1024, lane * 16);
+                auto f1 = [&](int s_, int j) { return lds_at<bf16x8>(ab, (j * HS + s_) * 1024); };
+                if constexpr (q == 0) phase2<HS, kFA, 10, 20, true>(acc[0], h0p, f1, [&](auto slc) { epi(slc, acc[1], h0p, std::integral_constant<int, 3>{}, H0t); });
+                else phase2<HS, kFA, HS, 20, true>(acc[q & 1], h0p, f1, [&](auto slc) { epi(slc, acc[(q & 1) ^ 1], h1p, std::integral_constant<int, q - 1>{}, H1t); });
+            });
+        }
+        // ---- layer 2 (chunk 3): two partial accumulators, layer 1's quarter 3 in the shadow of k-steps 0..9; then the K SDFs, minimum, arg-min
+        int bi = 0x7fffffff;
+        char *cb3;
+        {
+            char *cb = cb3 = chunk_begin(std::integral_constant<int, 3>{}, std::true_type{});
+            const uint32_t ab = lds_base(cb, lane * 16);
+            f32x16 y0, y1, y;
+            bf16x8 ring[3][2];
+            auto f2 = [&](int s_, int j) { return lds_at<bf16x8>(ab, (2 * s_ + j) * 1024); };
+            static_for<2>([&](auto sc) { constexpr int s_ = decltype(sc)::value; ring[s_][0] = f2(s_, 0); ring[s_][1] = f2(s_, 1); });
+            static_for<HS / 2>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                if constexpr (s_ + 2 < HS / 2) { ring[(s_ + 2) % 3][0] = f2(s_ + 2, 0); ring[(s_ + 2) % 3][1] = f2(s_ + 2, 1); }
+                if constexpr (s_ < 5) static_for<4>([&](auto jc) { epi(std::integral_constant<int, 4 * s_ + decltype(jc)::value>{}, acc[1], h1p, std::integral_constant<int, 3>{}, H1t); });
+                if constexpr (s_ == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][0], frag_of(h1p), zero, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][1], frag_of(h1p + 4), zero, 0, 0, 0);
+                } else {
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s_ % 3][0], frag_of(h1p + 4 * (2 * s_)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s_ % 3][1], frag_of(h1p + 4 * (2 * s_ + 1)), y1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            float best = INFINITY;
+            int hq2 = h;        // opaque: sixteen "nn < d_out" lane masks and as many LDS addresses are loop invariants otherwise (kept, and spilled)
+            asm volatile("" : "+v"(hq2));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bq = lds_at<f32x4>(relaunder(bias_b), (uint32_t)(512 + 8 * q) * 4u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = 4 * q + j, nn = 8 * q + 4 * hq2 + j;
+                    y[i] = y0[i] + y1[i] + bq[j];
+                    if (nn < d_out && y[i] < best) { best = y[i]; bi = nn; }
+                }
+            }
+            {
+                const float ob = __shfl_xor(best, 32);
+                const int oi = __shfl_xor(bi, 32);
+                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (ok) {
+                const int64_t gq = here(gp);
+                int hq = h;         // (opaque, as in k_rr_fwd_value)
+                asm volatile("" : "+v"(hq));
+                float *dst = sdf_raw + gq * d_out;
+                uint16_t *oh = onehot + gq * 32;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n0 = 8 * q + 4 * hq;
+                    if ((d_out & 3) == 0) {
+                        if (n0 < d_out) *reinterpret_cast<float4 *>(dst + n0) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (n0 + j < d_out) dst[n0 + j] = y[4 * q + j];
+                    }
+                    uint2 o;      // bf16 1.0 = 0x3f80
+                    o.x = (bi == n0 ? 0x3f80u : 0u) | (bi == n0 + 1 ? 0x3f800000u : 0u);
+                    o.y = (bi == n0 + 2 ? 0x3f80u : 0u) | (bi == n0 + 3 ? 0x3f800000u : 0u);
+                    *reinterpret_cast<uint2 *>(oh + n0) = o;
+                }
+                if (h == 0) { sdf[gq] = best; idx[gq] = bi; }
+            }
+        }
+        // ---- v1 = W2[k*] . s1 over h1, in place (k-step s: neurons 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3).  The sample's row of W2 is read from
+        //      LDS (it came with chunk 3), not from global memory: the vector-memory counter retires in order, so a global load issued behind
+        //      the activation stores of the k-step before is not "there" until those stores have been acknowledged -- sixteen store round
+        //      trips per tile in the two-kernel form's k_rr_fwd_grad
+        {
+            const uint32_t wl = lds_base(cb3 + kW2Rows + (size_t)(ok ? bi : 0) * kW2Pitch, 16 * h);
+            static_for<HS>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                const f32x4 ua = lds_at<f32x4>(wl, 64 * s_), ub = lds_at<f32x4>(wl, 64 * s_ + 32);
+                const uint32_t w0 = h1p[4 * s_], w1 = h1p[4 * s_ + 1], w2 = h1p[4 * s_ + 2], w3 = h1p[4 * s_ + 3];
+                h1p[4 * s_] = pack2(ua[0] * sig_of_h(lo_bf(w0)), ua[1] * sig_of_h(hi_bf(w0)));
+                h1p[4 * s_ + 1] = pack2(ua[2] * sig_of_h(lo_bf(w1)), ua[3] * sig_of_h(hi_bf(w1)));
+                h1p[4 * s_ + 2] = pack2(ub[0] * sig_of_h(lo_bf(w2)), ub[1] * sig_of_h(hi_bf(w2)));
+                h1p[4 * s_ + 3] = pack2(ub[2] * sig_of_h(lo_bf(w3)), ub[3] * sig_of_h(hi_bf(w3)));
+                tp_store(V1t, here(tile), s_, lane, h1p + 4 * s_, ok);
+            });
+        }
+        // ---- u0 = W1^T v1 (chunks 4, 5) in quarter phases; a finished quarter leaves as u0 (TP) and, times s0 of h0, as v0 IN PLACE of h0 (TP)
+        // 24 slices of a finished quarter qd, per k-step t of it: four packs (u0 word, v0 word in place of h0's), the u0 store, the v0 store
+        uint32_t uw[4];
+        auto epu = [&](auto slc, const f32x16 (&src)[2], auto qdc) {
+            constexpr int sl = decltype(slc)::value, qd = decltype(qdc)::value, t = sl / 6, w = sl % 6;
+            if constexpr (w < 4) {
+                constexpr int j = t >> 1, r = 4 * (t & 1) + w, nd = 2 * qd + j;
+                const uint32_t hwd = h0p[8 * nd + r];
+                const float ua = src[j][2 * r], ub = src[j][2 * r + 1];
+                uw[w] = anchor(pack2(ua, ub));
+                h0p[8 * nd + r] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
+            } else if constexpr (w == 4) {
+                tp_store(U0t, here(tile), 4 * qd + t, lane, uw, ok);
+            } else {
+                tp_store(V0t, here(tile), 4 * qd + t, lane, h0p + 4 * (4 * qd + t), ok);
+            }
+        };
+        {
+            char *cb = nullptr;
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 4 + q / 2>{}, std::true_type{});
+                const uint32_t ab = lds_base(cb + 2 * (q % 2) * HS * 1024, lane * 16);
+                auto f1 = [&](int s_, int j) { return lds_at<bf16x8>(ab, (j * HS + s_) * 1024); };
+                if constexpr (q == 0) phase2<HS, kFA, HS, 24, false, true>(acc[0], h1p, f1, [](auto) {});
+                else phase2<HS, kFA, HS, 24, true, true>(acc[q & 1], h1p, f1, [&](auto slc) { epu(slc, acc[(q & 1) ^ 1], std::integral_constant<int, q - 1>{}); });
+            });
+        }
+        // ---- ux = W0^T v0 (chunk 6: three slot tiles, three accumulator chains); u0's quarter 3 (v0 k-steps 12..15) in the shadow of k-steps 0..11
+        f32x16 o0, o1, o2;
+        {
+            char *cb = chunk_begin(std::integral_constant<int, 6>{}, std::true_type{});
+            const uint32_t ab = lds_base(cb, lane * 16);
+            bf16x8 ring[3][XS];
+            static_for<2>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                static_for<XS>([&](auto tc) { constexpr int t = decltype(tc)::value; ring[s_][t] = lds_at<bf16x8>(ab, (t * HS + s_) * 1024); });
+            });
+            static_for<HS>([&](auto sc) {
+                constexpr int s_ = decltype(sc)::value;
+                if constexpr (s_ + 2 < HS)
+                    static_for<XS>([&](auto tc) { constexpr int t = decltype(tc)::value; ring[(s_ + 2) % 3][t] = lds_at<bf16x8>(ab, (t * HS + s_ + 2) * 1024); });
+                if constexpr (s_ < 12) static_for<2>([&](auto jc) { epu(std::integral_constant<int, 2 * s_ + decltype(jc)::value>{}, acc[1], std::integral_constant<int, 3>{}); });
+                const bf16x8 bfrag = frag_of(h0p + 4 * s_);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (s_ == 0) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][0], bfrag, zero, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][1], bfrag, zero, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0][2], bfrag, zero, 0, 0, 0);
+                } else {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s_ % 3][0], bfrag, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s_ % 3][1], bfrag, o1, 0, 0, 0);
+                    o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s_ % 3][2], bfrag, o2, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- d min / dx = E^T ux (k_rr_fwd_grad's tail)
+        {
+            int64_t gpo = ok ? gp : 0;
+            asm volatile("" : "+v"(gpo));
+            const EFac E = load_efac(x, dydx, gpo, ld, h, jac_scale, ok);
+            float gd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 18; j++) gd[j % 3] += E.pe[j] * HS_SLOT(o0, o1, o2, j);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) gd[d] += E.dy[i][d].x * HS_SLOT(o0, o1, o2, 18 + 2 * i) + E.dy[i][d].y * HS_SLOT(o0, o1, o2, 19 + 2 * i);
+            if (h == 0) { gd[0] += HS_SLOT(o0, o1, o2, 34); gd[1] += HS_SLOT(o0, o1, o2, 35); gd[2] += HS_SLOT(o0, o1, o2, 36); }
+#pragma unroll
+            for (int d = 0; d < 3; d++) gd[d] += __shfl_xor(gd[d], 32);
+            if (ok) {
+                if (h == 0) { grad[gpo * 3] = gd[0]; grad[gpo * 3 + 1] = gd[1]; grad[gpo * 3 + 2] = gd[2]; }
+                float4 *up = reinterpret_cast<float4 *>(uxh + gpo * 32 + 16 * h);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    up[i] = make_float4(HS_SLOT(o0, o1, o2, 18 + 4 * i), HS_SLOT(o0, o1, o2, 19 + 4 * i), HS_SLOT(o0, o1, o2, 20 + 4 * i), HS_SLOT(o0, o1, o2, 21 + 4 * i));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -863,6 +1210,27 @@ int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, co
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     k_rr_fwd_value<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                     (uint16_t *)H0t, (uint16_t *)H1t, (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, n);
+    return wt_check_launch();
+}
+
+int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                    const float *W2tab, const void *W1Tf, const void *W0Tf, int32_t d_out, void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf,
+                    int64_t *idx, void *onehot, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld,
+                    void *stream) {
+    if (d_out < 1 || d_out > 32) return HS_ERR_ARG;
+    if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
+    if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !W2tab || !W1Tf || !W0Tf || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx || !onehot || !U0t ||
+        !V1t || !V0t || !grad || !uxh)
+        return HS_ERR_NULL;
+    const size_t lds = 2 * (size_t)kFBuf + kBias * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    k_rr_fwd<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, W2tab,
+                                                               (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, d_out, (uint16_t *)H0t, (uint16_t *)H1t,
+                                                               (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, (uint16_t *)U0t, (uint16_t *)V1t,
+                                                               (uint16_t *)V0t, grad, uxh, jac_scale, n, ld);
     return wt_check_launch();
 }
 

@@ -148,7 +148,7 @@ def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
-            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
+            "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd"]
 
 
@@ -690,6 +690,19 @@ class _HipBackend:
                                         ctypes.c_int64(ld), _stream()), "hs_trunk_rr_fwd_grad")
 
     @staticmethod
+    def trunk_rr_fwd(x, feat, dydx, packed, rr, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot, U0t, V1t, V0t, grad, uxh, jac_scale, ld=0):
+        """trunk_rr_fwd_value + trunk_rr_fwd_grad in one launch (csrc/trunk_rr.hip: k_rr_fwd)."""
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, W2f, bias = packed
+        W1Tf, W0Tf, _, W2tab = rr
+        _check(lib.hs_trunk_rr_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
+                                   _dev(bias, "bias"), _dev(W2tab, "W2tab"), _dev(W1Tf, "W1Tf", bf), _dev(W0Tf, "W0Tf", bf), int(d_out), _dev(H0t, "H0t", bf),
+                                   _dev(H1t, "H1t", bf), _dev(Xp, "Xp", bf), _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"), _dev(idx, "idx", torch.int64),
+                                   _dev(onehot, "onehot", bf), _dev(U0t, "U0t", bf), _dev(V1t, "V1t", bf), _dev(V0t, "V0t", bf), _dev(grad, "grad"),
+                                   _dev(uxh, "uxh"), ctypes.c_float(jac_scale), ctypes.c_int64(x.shape[0]), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_fwd")
+
+    @staticmethod
     def trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac_scale, ld=0):
         lib = load_library()
         bf = torch.bfloat16
@@ -733,13 +746,14 @@ class _HipBackend:
             if tuple(part.shape) != (slices, NA, MB) or part.dtype != bf or not part.is_contiguous():
                 raise RuntimeError("wgrad_pairs: destination must be a contiguous bf16 [slices, NA, MB] tensor")
             a.ones = int("ones" in shape)
+            a.reserved = int("reg" in shape) + 2 * int("consecutive" in shape)       # (tests: the two forms of the row stream against each other)
             cs = torch.empty(slices, NA, device=p0[0].device, dtype=torch.float32) if "colsum" in shape else None      # per-slice column sums of A0
             a.colsum = None if cs is None else cs.data_ptr()
             if colsum_out is not None:
                 colsum_out.append(cs)
             a.A0, a.B0 = _dev(p0[0], "A0", bf).value, (_dev(p0[1], "B0", bf).value if p0[1] is not None else None)
             a.A1, a.B1 = (_dev(p1[0], "A1", bf).value, _dev(p1[1], "B1", bf).value) if p1 is not None else (None, None)
-            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[tuple(t for t in shape if t not in ("ones", "colsum"))], int(slices)
+            a.part, a.M, a.rows, a.kind, a.slices = part.data_ptr(), M, rows, _HipBackend.WGP_KINDS[tuple(t for t in shape if t not in ("ones", "colsum", "reg", "consecutive"))], int(slices)
             outs.append(part)
         _check(lib.hs_wgrad_pairs(arr, len(jobs), _stream()), "hs_wgrad_pairs")
         return outs

@@ -466,6 +466,7 @@ def _rr_slices(n, budget=256):
     return fine, coarse, coarse
 
 
+_PAIR_REG_COST = float(os.environ.get("HOLOSCENE_PAIR_REG_COST", "1.5"))
 _PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432, (256, 128): 24576}      # bytes of one operand pair per 32-row tile
 
 
@@ -476,7 +477,9 @@ def _pair_slices(jobs, budget=256):
     cost = []
     for shape, tiles, pairs, has_b in jobs:
         per = _PAIR_TILE_BYTES[tuple(shape[:2])] if has_b else 64 * shape[0]
-        cost.append(float(per * pairs * tiles))
+        # row-major-only jobs stay on the kernel's register-staged form, which streams ~1.4x slower per byte than the LDS-DMA form
+        # (3.3 against 4.6 TB/s measured, tools/exp/wgrad_cold_time.py): lighter slices, or they are the launch's tail
+        cost.append(float(per * pairs * tiles) * (_PAIR_REG_COST if "rm" in shape else 1.0))
     total = sum(cost)
     want = [max(1, min(t, int(c / total * budget))) for c, (_, t, _, _) in zip(cost, jobs)]
     spare = budget - sum(want)
@@ -532,8 +535,11 @@ class _trunk_render_rr(torch.autograd.Function):
         Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty(n, 32, device=dev, dtype=bf)
         sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(B, 1, device=dev, dtype=torch.int64)
         grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
-        be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
-        be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
+        if RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
+            be.trunk_rr_fwd(x[:n], feat[:n], dydx, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
+        else:
+            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
+            be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
         eik = ()
         if Be > 0:      # value + three tangent rows per Eikonal point (csrc/trunk_mlp2.hip), same weight images
@@ -607,31 +613,31 @@ class _trunk_render_rr(torch.autograd.Function):
             se1, se0 = cut[3:] if eik_jobs else (0, 0)
             eik_jobs = [(j[0], sl) + tuple(j[2:]) for j, sl in zip(eik_jobs, (se1, se0))]
             # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
-            # samples ride along: db0 as a ONES column of the B tile (column 80 of the 256 x 80 result), db1 as the column sums of a1~ from
-            # one more MFMA per fragment of the 256 x 256 job (hsWgradPairJob::colsum)
+            # samples ride along: db0, db1 as the column sums of a0~, a1~ from one more MFMA per fragment of the jobs that stream them
+            # (hsWgradPairJob::colsum)
             st1, st0 = torch.empty(s1 + se1, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se0, 256, 128, device=dev, dtype=bf)
             st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
             cs = []
             be.wgrad_pairs([((256, 256, "colsum"), s1, (A1t, H0t), (V1t, U0bt) if second else None),
-                            ((256, 80, "ones"), s0, (A0t, Xp), (V0t, UXb) if second else None),
+                            ((256, 80, "colsum"), s0, (A0t, Xp), (V0t, UXb) if second else None),
                             ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)] + eik_jobs, n,
                            outs_into=[st1[:s1], st0[:s0], st2] + ([st1[s1:], st0[s0:]] if eik_jobs else []), colsum_out=cs)
-            csb1 = cs[0]        # [s1, 256] fp32
+            csb1, csb0 = cs[0], cs[1]        # [s1, 256], [s0, 256] fp32
             if eik_live and not eik_jobs:
                 eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
-                sums = be.sum_slices([st1, st0, st2, csb1])
+                sums = be.sum_slices([st1, st0, st2, csb1, csb0])
                 gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
-                gb1, gb0, gb2 = gbz[:256] + sums[3], gbz[256:512] + sums[1][:, 80], gbz[512:512 + K] + gb2_part.sum(0)[:K]
+                gb1, gb0, gb2 = gbz[:256] + sums[3], gbz[256:512] + sums[4], gbz[512:512 + K] + gb2_part.sum(0)[:K]
                 gW0 = gW0p.index_select(1, _xp_columns(dev))
                 gW2 = gW2p[:K]
             else:   # the column selection of dW0, dW2 of both point families, the three bias gradients: one launch (csrc/small_ops.hip)
-                sums = be.sum_slices([st1, st0, st2, csb1] + ([w2_part] if eik_live else []))
+                sums = be.sum_slices([st1, st0, st2, csb1, csb0] + ([w2_part] if eik_live else []))
                 gW1 = sums[0]
                 gW0, gW2, gb1, gb0, gb2 = be.assemble([
                     ((256, F_in), [(sums[1], 128, _xp_columns32(dev))]),
-                    ((K, 256), [(sums[2], 256, 0)] + ([(sums[4], 256, 0)] if eik_live else [])),
+                    ((K, 256), [(sums[2], 256, 0)] + ([(sums[5], 256, 0)] if eik_live else [])),
                     ((256, 1), [(gbz, 1, 0), (sums[3], 1, 0)]),
-                    ((256, 1), [(gbz, 1, 256), (sums[1], 128, 80)]),
+                    ((256, 1), [(gbz, 1, 256), (sums[4], 1, 0)]),
                     ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
                 gb1, gb0, gb2 = gb1.view(-1), gb0.view(-1), gb2.view(-1)
         g_emb = None
@@ -671,6 +677,9 @@ BG_IMPL = os.environ.get("HOLOSCENE_BG_IMPL", "hip")
 # weight gradients of the appearance branch: "pairs" = six row-major jobs of one hs_wgrad_pairs launch (byte-proportional slices),
 # "rows" = hs_wgrad_rows (csrc/wgrad.hip: 128 equal slices per product)
 APPEARANCE_WGRAD = os.environ.get("HOLOSCENE_APPEARANCE_WGRAD", "pairs")
+# "fused": k_rr_fwd, the value and the gradient chain of a sample tile in one kernel (bit-identical outputs; 107-112 us against 52 + 70 for
+# the pair, same box, alternating runs); "split": k_rr_fwd_value then k_rr_fwd_grad
+RR_FORWARD = os.environ.get("HOLOSCENE_RR_FORWARD", "fused")
 
 
 class _fused_appearance(torch.autograd.Function):

@@ -547,6 +547,15 @@ typedef struct hsGatherJob {
 } hsGatherJob;
 int hs_gather_rows(const hsGatherJob *jobs, int32_t n_jobs, void *stream);
 
+/* hs_trunk_rr_fwd_value + hs_trunk_rr_fwd_grad of the same samples in one launch (arguments as in those two; H0t / H1t are outputs only).
+ * The activations stay in registers between the two chains; the five weight images cycle through LDS in chunks shared by the workgroup.
+ * Replaces the same reference lines as the pair: model/network.py:ObjectImplicitNetworkGrid.forward + gradient (autograd.grad of the
+ * minimum SDF), instant-sdf trunk. */
+int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                    const float *W2tab, const void *W1Tf, const void *W0Tf, int32_t d_out, void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf,
+                    int64_t *idx, void *onehot, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld,
+                    void *stream);
+
 /* ------------------------------------------------------------------ reverse-over-reverse trunk of the rendered samples (csrc/trunk_rr.hip)
  *
  * ObjectImplicitNetworkGrid.get_outputs (model/network.py:273-301) for the rendered samples -- K per-object SDFs, their minimum, its
@@ -603,9 +612,14 @@ typedef struct hsWgradPairJob {
     int64_t M, rows;
     int32_t kind, slices;
     int32_t ones;       /* HS_WGP_256x80 / _RM: column 80 of the result = column sums of A0 (a bias gradient); with B0 == NULL nothing else */
-    int32_t reserved;
+    int32_t reserved;   /* bit 0: keep this job on the register-staged form; bit 1: consecutive tiles per slice in the LDS-DMA form (see below) */
     float *colsum;      /* NULL, or fp32 [slices, NA]: per-slice column sums of A0 (kinds with a 256-row result: one more bias gradient per job) */
 } hsWgradPairJob;
+/* Two forms of the row stream: kinds 0, 1, 2, 7 (at least one tile-packed operand) bring their rows in by LDS-DMA, four 32-row stages in
+ * LDS, three in flight; there a ROW-MAJOR operand's rows in [rows, M) are read as copies of row rows - 1 -- its partner in the pair is
+ * tile-packed, zero in those rows, so they contribute nothing; slice s sums tiles s, s + slices, s + 2 slices, ... (with reserved bit 1:
+ * ceil(tiles / slices) consecutive tiles, as the register form does).  The row-major-only kinds, jobs with `ones`, jobs with reserved bit 0 and
+ * every job under HOLOSCENE_WGRAD_DMA=0 stage 64-row chunks through registers (rows >= `rows` read as zero). */
 int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream);
 
 /* The pixel draw of one training batch (datasets/ns_dataset.py:409-430: NSDataset.__getitem__'s class-balanced rule, there a dozen

@@ -157,7 +157,7 @@ def test_per_object_networks_match_reference(name):
 
 # ------------------------------------------------------------------------------------ host logic added in round 3
 def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
-    """_pair_slices: the jobs of one hs_wgrad_pairs launch get workgroups in proportion to their bytes, the counts add up to the budget,
+    """_pair_slices: the jobs of one hs_wgrad_pairs launch get workgroups in proportion to their (costed) bytes, the counts add up to the budget,
     no job gets more slices than it has tiles, and no slice is more than ~15 % above the mean load."""
     import math
     from holoscene_amd.model.network import _PAIR_TILE_BYTES, _pair_slices
@@ -169,7 +169,8 @@ def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
         total_tiles = sum(j[1] for j in jobs)
         assert sum(cut) == min(256, total_tiles)
         if T >= 3136:
-            per = [(_PAIR_TILE_BYTES[tuple(j[0][:2])] if j[3] else 64 * j[0][0]) * j[2] for j in jobs]
+            from holoscene_amd.model.network import _PAIR_REG_COST        # row-major-only jobs: the slower register-staged form, costed per byte
+            per = [(_PAIR_TILE_BYTES[tuple(j[0][:2])] if j[3] else 64 * j[0][0]) * j[2] * (_PAIR_REG_COST if "rm" in j[0] else 1.0) for j in jobs]
             load = [math.ceil(j[1] / c) * p for j, c, p in zip(jobs, cut, per)]
             mean = sum(j[1] * p for j, p in zip(jobs, per)) / 256
             assert max(load) <= 1.15 * mean, (cut, load, mean)

@@ -72,6 +72,16 @@ def test_rr_kernels_vs_torch_restatement(n, K):
          "uxh": rel(uxh, f2["uxh"]), "grad": rel(grad, f2["grad"])}
     print("PARITY rr fwd_grad", e)
     assert max(e.values()) < 1.5e-2, e
+    # ---- the two chains in one launch (k_rr_fwd): the same arithmetic in the same order, so every output is bit-identical to the pair's
+    F = {k: tp() for k in ("H0t", "H1t", "U0t", "V1t", "V0t")}
+    Xp2, onehot2 = torch.zeros(n, 80, device=DEV, dtype=bf), torch.zeros(n, 32, device=DEV, dtype=bf)
+    raw2, sdf2, idx2 = torch.empty(n, K, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64)
+    grad2, uxh2 = torch.empty(n, 3, device=DEV), torch.empty(n, 32, device=DEV)
+    be.trunk_rr_fwd(x, feat, dydx, packed, rr, K, F["H0t"], F["H1t"], Xp2, raw2, sdf2, idx2, onehot2, F["U0t"], F["V1t"], F["V0t"], grad2, uxh2, jac)
+    pairs = {"H0t": (F["H0t"], H0t), "H1t": (F["H1t"], H1t), "U0t": (F["U0t"], U0t), "V1t": (F["V1t"], V1t), "V0t": (F["V0t"], V0t), "Xp": (Xp2, Xp),
+             "onehot": (onehot2, onehot), "sdf_raw": (raw2, sdf_raw), "sdf": (sdf2, sdf), "idx": (idx2, idx), "grad": (grad2, grad), "uxh": (uxh2, uxh)}
+    diff = [k for k, (a, b) in pairs.items() if not torch.equal(a.view(torch.int16) if a.dtype == bf else a, b.view(torch.int16) if b.dtype == bf else b)]
+    assert not diff, f"fused forward differs from the two-kernel forward in {diff}"
     # ---- backward
     g = torch.Generator().manual_seed(5)
     g_grad = torch.randn(n, 3, generator=g).to(DEV)
@@ -132,6 +142,16 @@ def test_rr_kernels_vs_torch_restatement(n, K):
         parts = be.wgrad_pairs([((256, 256, "colsum"), 5, (A1t, H0t), (V1t, U0bt) if second else None)], n, colsum_out=cs)
         assert rel_l2(parts[0].float().sum(0), want1 if second else A1d.t() @ f3["h0"]) < 1e-2
         assert cs[0].shape == (5, 256) and rel_l2(cs[0].sum(0), A1d.sum(0)) < 2e-3, "column sums of A0 only (fp32 accumulation of bf16 values)"
+    # the two forms of the row stream (LDS-DMA stages / register-staged chunks) add the same products in the same order: equal partials
+    for cuts in [(4, 3, 2), (tiles, tiles, tiles)]:
+        both = []
+        for tag in (("consecutive",), ("reg",)):
+            cs = []
+            parts = be.wgrad_pairs([((256, 256, "colsum") + tag, cuts[0], (A1t, H0t), (V1t, U0bt)), ((256, 80, "colsum") + tag, cuts[1], (A0t, Xp), (V0t, UXb)),
+                                    ((32, 256) + tag, cuts[2], (gy, H1t), (onehot, U1bt))], n, colsum_out=cs)
+            both.append([p.float() for p in parts] + [c for c in cs if c is not None])
+        for a, b in zip(*both):
+            assert rel_l2(a.sum(0), b.sum(0)) < 1e-5 and torch.equal(a, b), "LDS-DMA form differs from the register form"
     g = torch.Generator().manual_seed(9)
     xa = (torch.randn(M, 128, generator=g) * 0.5).to(DEV)
     xa[n:] = 0
@@ -140,3 +160,6 @@ def test_rr_kernels_vs_torch_restatement(n, K):
     cs = []
     parts = be.wgrad_pairs([((256, 128, "tp", "colsum"), 7, (A0t, XAt), None)], n, colsum_out=cs)
     assert rel_l2(parts[0].float().sum(0), A0d.t() @ xa_bf[:n]) < 1e-2 and rel_l2(cs[0].sum(0), A0d.sum(0)) < 2e-3
+    reg = be.wgrad_pairs([((256, 128, "tp", "reg"), 7, (A0t, XAt), None)], n)
+    con = be.wgrad_pairs([((256, 128, "tp", "consecutive"), 7, (A0t, XAt), None)], n)
+    assert torch.equal(reg[0], con[0]) and rel_l2(reg[0].float().sum(0), parts[0].float().sum(0)) < 6e-3      # (bf16 partials, another cut)
