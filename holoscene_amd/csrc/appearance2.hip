@@ -240,11 +240,12 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
     dma_chunk(stream, lds2, kChunkOff[0], kChunkBytes[0], 0, wave, lane);
     dma_fill2(R2f, R2l, kW2F * 2, wave, lane);
     for (int i = threadIdx.x; i < kA2Bias; i += kThreadsW) bias[i] = biasg[i];
+    __syncthreads();        // the bias block, the resident last layer (the chunk barriers below are bare barrier instructions)
     const int64_t ntiles = (n + kRows - 1) / kRows;
     const bf16x8 *R2v = reinterpret_cast<const bf16x8 *>(R2l) + lane;
     // workgroup b owns the contiguous tiles [b T / G, (b + 1) T / G) (trunk_rr.hip: tile_begin): at the stock size 12 or 13 -- a round of
     // eight waves and a round of four or five, each alone on its SIMD
-    const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    const int64_t wt0 = uniform64(ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x), wt1 = uniform64(ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x);
     for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
         const int64_t tile = r0 + wave;
         const bool live = tile < wt1;                     // wave-uniform: a wave without a tile still serves the pipeline (DMA share, barriers)
@@ -254,18 +255,28 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
         const int64_t b = ok ? gp : 0;
         // the barrier that publishes chunk J (everybody's DMA share has landed) is also the point after which nobody reads the OTHER buffer
         // any more: the next chunk is requested into it at once and lands under this chunk's products.  Returns the LDS base of chunk J.
-        auto chunk_begin = [&](auto jc) -> char * {
+        // The wait: the vector-memory counter retires in issue order and counts this wave's activation stores too, so waiting for zero would
+        // also wait out every store of the phase just finished; kAfterF[J] = the vector-memory instructions a LIVE wave issues for certain
+        // between the request of chunk J and this point (the tile-packed stores of the epilogues in between), which may stay in flight.
+        // The barrier is the bare instruction: __syncthreads() carries a workgroup fence, for which the compiler drains the counter anyway.
+        auto chunk_begin = [&](auto jc, auto livec) -> char * {
             constexpr int J = decltype(jc)::value;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (!decltype(livec)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (J == 0) { if (r0 == wt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+            else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (J == 2 || J == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if constexpr (J == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if constexpr (J + 1 < kChunks) dma_chunk(stream, lds2, kChunkOff[J + 1], kChunkBytes[J + 1], par ^ 1, wave, lane);
             else if (more) dma_chunk(stream, lds2, kChunkOff[0], kChunkBytes[0], par ^ 1, wave, lane);
+            asm volatile("" ::: "memory");      // no store of the coming phase is scheduled ahead of the requests
             char *base = lds2 + par * kBufBytes;
             par ^= 1;
             return base;
         };
         if (!live) {      // nothing to compute: keep the chunk pipeline turning for the others
-            static_for<kChunks>([&](auto jc) { (void)chunk_begin(jc); });
+            static_for<kChunks>([&](auto jc) { (void)chunk_begin(jc, std::false_type{}); });
             continue;
         }
         // ---- this lane's inputs: 16 colour features (levels 8 h .. 8 h + 7) and its 48 encoding slots (rows past the end: zeros)
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
         // ---- colour MLP layer 0: 32 -> 256, ReLU (chunk 0: all eight tiles, two k-steps each)
         mk[0] = mk[1] = mk[2] = mk[3] = 0u;
         {
-            char *cb = chunk_begin(std::integral_constant<int, 0>{});
+            char *cb = chunk_begin(std::integral_constant<int, 0>{}, std::true_type{});
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 init_acc_b(acc[q & 1][0], relaunder(bias_b), 32 * (2 * q));
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
             char *cb = nullptr;
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 1 + q / 2>{});
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 1 + q / 2>{}, std::true_type{});
                 init_acc_b(acc[q & 1][0], relaunder(bias_b), 256 + 32 * (2 * q));
                 init_acc_b(acc[q & 1][1], relaunder(bias_b), 256 + 32 * (2 * q + 1));
                 const uint32_t ab = lds_base(cb + 2 * (q % 2) * kBigTile, lane * 16);
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
         mk[0] = mk[1] = mk[2] = mk[3] = 0u;
         static_for<4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            char *cb = chunk_begin(std::integral_constant<int, 3 + q>{});
+            char *cb = chunk_begin(std::integral_constant<int, 3 + q>{}, std::true_type{});
             init_acc_b(acc[q & 1][0], relaunder(bias_b), 512 + 32 * (2 * q));
             init_acc_b(acc[q & 1][1], relaunder(bias_b), 512 + 32 * (2 * q + 1));
             const uint32_t ab = lds_base(cb, lane * 16);
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
             char *cb = nullptr;
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 7 + q / 2>{});
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 7 + q / 2>{}, std::true_type{});
                 init_acc_b(acc[q & 1][0], relaunder(bias_b), 768 + 32 * (2 * q));
                 init_acc_b(acc[q & 1][1], relaunder(bias_b), 768 + 32 * (2 * q + 1));
                 const uint32_t ab = lds_base(cb + 2 * (q % 2) * kBigTile, lane * 16);
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
     int par = 0;
     dma_chunk(streamT, lds2, kChunkTOff[0], kChunkTBytes[0], 0, wave, lane);
     const int64_t ntiles = (n + kRows - 1) / kRows;
-    const int64_t wt0 = ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x, wt1 = ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    const int64_t wt0 = uniform64(ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x), wt1 = uniform64(ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x);
     for (int64_t r0 = wt0; r0 < wt1; r0 += kWaves) {
         const int64_t tile = r0 + wave;
         const bool live = tile < wt1;
@@ -457,20 +468,28 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         const int64_t b = ok ? gp : 0;
-        auto chunk_begin = [&](auto jc) -> char * {
+        // (counted wait + bare barrier, as in the forward kernel: the tile-packed stores issued since chunk J's request may stay in flight)
+        auto chunk_begin = [&](auto jc, auto livec) -> char * {
             constexpr int J = decltype(jc)::value;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (!decltype(livec)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (J == 0) { if (r0 == wt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+            else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (J == 6 || J == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if constexpr (J + 1 < kChunksT) dma_chunk(streamT, lds2, kChunkTOff[J + 1], kChunkTBytes[J + 1], par ^ 1, wave, lane);
             else if (more) dma_chunk(streamT, lds2, kChunkTOff[0], kChunkTBytes[0], par ^ 1, wave, lane);
+            asm volatile("" ::: "memory");
             char *base = lds2 + par * kBufBytes;
             par ^= 1;
             return base;
         };
         if (!live) {
-            static_for<kChunksT>([&](auto jc) { (void)chunk_begin(jc); });
+            static_for<kChunksT>([&](auto jc) { (void)chunk_begin(jc, std::false_type{}); });
             continue;
         }
+        // (the normal itself, for d normals below: requested here, ahead of the tile's stores -- a load issued behind them waits for them)
+        const float nx[3] = {normals[b * 3], normals[b * 3 + 1], normals[b * 3 + 2]};
         // ---- the ReLU signs of this lane's 3 x 128 activations, and the cotangent of the three pre-sigmoid outputs (lane half 0 holds k = 0..3)
         uint32_t mk[3][4];
         {
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         using LN_ = std::integral_constant<int, -1>;
         // ---- r1~ = (Wr2^T y~) . [r1 > 0]: one k-step per quarter (chunk 0)
         {
-            char *cb = chunk_begin(std::integral_constant<int, 0>{});
+            char *cb = chunk_begin(std::integral_constant<int, 0>{}, std::true_type{});
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 zero2(acc[q & 1]);
@@ -556,7 +575,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
             char *cb = nullptr;
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 1 + q / 2>{});
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 1 + q / 2>{}, std::true_type{});
                 zero2(acc[q & 1]);
                 const uint32_t ab = lds_base(cb + 2 * (q % 2) * kBigTile, lane * 16);
                 auto af = [&](int s, int j) { return lds_at<bf16x8>(ab, j * kBigTile + s * 1024); };
@@ -570,7 +589,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
             char *cb = nullptr;
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 3 + q / 2>{});
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 3 + q / 2>{}, std::true_type{});
                 zero2(acc[q & 1]);
                 const uint32_t ab = lds_base(cb + 2 * (q % 2) * kBigTile, lane * 16);
                 auto af = [&](int s, int j) { return lds_at<bf16x8>(ab, j * kBigTile + s * 1024); };
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         }
         f32x16 en;       // enc~ of the 27 encoded-normal inputs: register r <-> input 8 (r >> 2) + 4 h + (r & 3)
         {
-            char *cb = chunk_begin(std::integral_constant<int, 5>{});
+            char *cb = chunk_begin(std::integral_constant<int, 5>{}, std::true_type{});
 #pragma unroll
             for (int i = 0; i < 16; i++) en[i] = 0.f;
             const uint32_t ab = lds_base(cb, lane * 16);
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
             char *cb = nullptr;
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 6 + q / 2>{});
+                if constexpr (q % 2 == 0) cb = chunk_begin(std::integral_constant<int, 6 + q / 2>{}, std::true_type{});
                 zero2(acc[q & 1]);
                 const uint32_t ab = lds_base(cb + 2 * (q % 2) * kBigTile, lane * 16);
                 auto af = [&](int s, int j) { return lds_at<bf16x8>(ab, j * kBigTile + s * 1024); };
@@ -613,7 +632,6 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         }
         {   // d normals[d] = sum over the normal's 27 encoded inputs c of (d enc_c / d n_d) enc~_c: c < 3 the coordinate itself, c = 3 + 6 k + comp:
             // sin (comp < 3) / cos (comp >= 3) of 2^k n_(comp % 3)
-            const float nx[3] = {normals[b * 3], normals[b * 3 + 1], normals[b * 3 + 2]};
             float dn[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         }
         // ---- featc~ = Wc0^T hc~ (chunk 8, one tile): hc~'s last quarter in the shadow of its first k-steps; register r <-> colour feature 16 h + r
         {
-            char *cb = chunk_begin(std::integral_constant<int, 8>{});
+            char *cb = chunk_begin(std::integral_constant<int, 8>{}, std::true_type{});
             f32x16 fc;
 #pragma unroll
             for (int i = 0; i < 16; i++) fc[i] = 0.f;

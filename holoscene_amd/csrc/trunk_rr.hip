@@ -188,8 +188,8 @@ __device__ __forceinline__ EFac load_efac(const float *__restrict__ x, const flo
 // Workgroup b owns the CONTIGUOUS tiles [b T / G, (b + 1) T / G): at the stock size 3 136 tiles on 256 workgroups are 12 or 13 each -- one
 // round of all eight waves and one of four or five, a wave alone on its SIMD -- instead of two full rounds on 136 compute units while 120
 // stand idle (the strided assignment: 392 super-tiles of eight on 256 workgroups).
-__device__ __forceinline__ int64_t tile_begin(int64_t ntiles) { return ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x; }
-__device__ __forceinline__ int64_t tile_end(int64_t ntiles) { return ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x; }
+__device__ __forceinline__ int64_t tile_begin(int64_t ntiles) { return uniform64(ntiles * (int64_t)blockIdx.x / (int64_t)gridDim.x); }
+__device__ __forceinline__ int64_t tile_end(int64_t ntiles) { return uniform64(ntiles * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x); }
 // One PHASE = the k-steps of ONE 32-neuron tile (one accumulator) with, in their shadow, slices of the previous tile's epilogue -- the
 // single-tile form of wave_tile.h's phase2: half the accumulator and epilogue-staging registers of a quarter phase.  These kernels move
 // 0.3-0.4 GB each for ~20 GFLOP: what they need registers for is loads in flight, not MFMA operands (a quarter-phase version spilled 40-80

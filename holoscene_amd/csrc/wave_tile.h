@@ -202,6 +202,13 @@ template <typename T> __device__ __forceinline__ T lds_at(uint32_t base, uint32_
     return *(__attribute__((address_space(3))) const T *)(uintptr_t)(base + byte_off);
 }
 
+// a workgroup-uniform 64-bit value into scalar registers (the 64-bit division behind a tile range runs on the vector ALU: without this
+// the loop bounds live in -- and are spilled from -- vector registers)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // accumulator initialisation from the bias block through an opaque LDS base (wave_tile.h: lds_base -- written as bias[const + lane part] every
 // one of the 128 distinct addresses of a tile becomes a loop-invariant VGPR)
 __device__ __forceinline__ void init_acc_b(f32x16 &acc, uint32_t bias_base, int float_off) {
