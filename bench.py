@@ -186,6 +186,14 @@ def _work_rr_fwd_grad(a, k):
     return n * 2 * (256 * 256 + K_IN * 256), n * (12 + 384 + 8 + 2 * 512 + 3 * 512 + 12 + 128)
 
 
+def _work_rr_fwd(a, k):
+    # both chains of a sample in one launch: the pair's work without the 2 x 512 bytes of h0, h1 the gradient kernel reads back
+    n, K = a[0].shape[0], a[5]
+    f0, b0 = _work_rr_fwd_value((a[0], a[1], a[3], K), k)
+    f1, b1 = _work_rr_fwd_grad((a[0],), k)
+    return f0 + f1, b0 + b1 - n * (2 * 512 + 12 + 8)
+
+
 def _work_rr_bwd_grad(a, k):
     n = a[0].shape[0]
     return n * 2 * (K_IN * 256 + 256 * 256), n * (12 + 384 + 12 + 128 + 8 + 3 * 512 + 4 * 512 + 160 + 384)
@@ -263,6 +271,7 @@ TIMED = {
     "softplus_tangent_bwd": ("k_softplus_tangent_bwd", None),
     "softplus_tangent_bwd_h": ("k_softplus_tangent_bwd_h", None),
     "trunk_rr_fwd_value": ("k_rr_fwd_value (rendered samples, reverse-over-reverse trunk: values, min, arg-min)", _work_rr_fwd_value),
+    "trunk_rr_fwd": ("k_rr_fwd (rendered samples: values, min, arg-min and d min / dx, both chains of a tile in one kernel)", _work_rr_fwd),
     "trunk_rr_fwd_grad": ("k_rr_fwd_grad (d min / dx by one reverse pass: W1^T, W0^T, E^T)", _work_rr_fwd_grad),
     "trunk_rr_bwd_grad": ("k_rr_bwd_grad (double backward, gradient part: E, W0, W1)", _work_rr_bwd_grad),
     "trunk_rr_bwd_value": ("k_rr_bwd_value (double backward, value part: W2^T, W1^T, W0^T)", _work_rr_bwd_value),
