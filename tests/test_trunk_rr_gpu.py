@@ -163,3 +163,24 @@ def test_rr_kernels_vs_torch_restatement(n, K):
     reg = be.wgrad_pairs([((256, 128, "tp", "reg"), 7, (A0t, XAt), None)], n)
     con = be.wgrad_pairs([((256, 128, "tp", "consecutive"), 7, (A0t, XAt), None)], n)
     assert torch.equal(reg[0], con[0]) and rel_l2(reg[0].float().sum(0), parts[0].float().sum(0)) < 6e-3      # (bf16 partials, another cut)
+
+
+@pytest.mark.parametrize("n,K", [(1000, 32), (4099, 5), (64, 12)])
+def test_rr_output_cotangent_image(n, K):
+    """hs_trunk_rr_gy: gy = bf16(g_raw + g_sdf at the arg-min column), zero beyond K; per-block column sums add up to the bias gradient;
+    either cotangent may be absent."""
+    from holoscene_amd.hashencoder.backend import _backend as be
+    g = torch.Generator().manual_seed(n + K)
+    g_raw, g_sdf = torch.randn(n, K, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    idx = torch.randint(0, K, (n,), generator=g).to(DEV)
+    for raw, sdf in ((g_raw, g_sdf), (g_raw, None), (None, g_sdf)):
+        gy = torch.full((n, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+        part = torch.full((be.RR_GY_BLOCKS, 32), 7.0, device=DEV)
+        be.trunk_rr_gy(raw, sdf, idx, K, gy, part)
+        want = torch.zeros(n, 32, device=DEV)
+        if raw is not None:
+            want[:, :K] = raw
+        if sdf is not None:
+            want[torch.arange(n, device=DEV), idx] += sdf
+        assert torch.equal(gy, want.to(torch.bfloat16)), "gy is the bf16 rounding of the fp32 sum"
+        assert torch.allclose(part.sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
