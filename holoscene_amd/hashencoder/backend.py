@@ -149,7 +149,7 @@ def dir_symbols():
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
             "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
-            "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd"]
+            "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
 
 def _check(rc, what):
@@ -855,6 +855,35 @@ class _HipBackend:
             outs.append(out)
         _check(lib.hs_sum_slices(arr, len(partials), _stream()), "hs_sum_slices")
         return outs
+
+    # ---- fp32 products as split-bf16 MFMA sums (csrc/gemm_split.hip)
+    @staticmethod
+    def gemm_split_nt(a, b, bias=None, planes=3):
+        """a [M, K] . b [N, K]^T (+ bias [N]) -> fp32 [M, N]; fp32 operands, rows may be strided (stride(1) == 1)."""
+        lib = load_library()
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+            raise RuntimeError("gemm_split_nt: fp32 [M, K] x [N, K] expected")
+        a = a if a.stride(1) == 1 or a.shape[1] == 1 else a.contiguous()
+        b = b if b.stride(1) == 1 or b.shape[1] == 1 else b.contiguous()
+        M, K, N = a.shape[0], a.shape[1], b.shape[0]
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        _check(lib.hs_gemm_split_nt(ctypes.c_void_p(a.data_ptr()), ctypes.c_int64(max(a.stride(0), K)), ctypes.c_void_p(b.data_ptr()), ctypes.c_int64(max(b.stride(0), K)),
+                                    _dev(out, "out"), ctypes.c_int64(N), _dev(bias, "bias"), ctypes.c_int64(M), int(N), int(K), int(planes), _stream()), "hs_gemm_split_nt")
+        return out
+
+    @staticmethod
+    def gemm_split_tn(a, b, slices, planes=3):
+        """per-slice a [m, N]^T . b [m, K] -> fp32 partials [slices, N, K] (sum over dim 0 = a^T b)."""
+        lib = load_library()
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+            raise RuntimeError("gemm_split_tn: fp32 [M, N], [M, K] expected")
+        a = a if a.stride(1) == 1 else a.contiguous()
+        b = b if b.stride(1) == 1 else b.contiguous()
+        M, N, K = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty(slices, N, K, device=a.device, dtype=torch.float32)
+        _check(lib.hs_gemm_split_tn(ctypes.c_void_p(a.data_ptr()), ctypes.c_int64(max(a.stride(0), N)), ctypes.c_void_p(b.data_ptr()), ctypes.c_int64(max(b.stride(0), K)),
+                                    _dev(out, "out"), ctypes.c_int64(M), int(N), int(K), int(slices), int(planes), _stream()), "hs_gemm_split_tn")
+        return out
 
     # ---- colour branch, wave-tile form (csrc/appearance2.hip)
     @staticmethod

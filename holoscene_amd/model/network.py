@@ -927,6 +927,13 @@ def _split_rows(M):
     return 1
 
 
+# fp32 GEMMs of the fp32 configuration: "lib" = the library's (fp32 MFMA), "split3" / "split2" = csrc/gemm_split.hip with three / two bf16
+# planes per operand (three: the accuracy of an fp32 GEMM, measured 1.1-1.2x the library on the 256-wide layers; two: 16 mantissa
+# bits per operand, 1.4-1.6x)
+FP32_GEMM_PLANES = {"lib": 0, "split3": 3, "split2": 2}[os.environ.get("HOLOSCENE_FP32_GEMM", "lib")]
+_SPLIT_MIN_ROWS = 4096
+
+
 class _linear_rows(torch.autograd.Function):
     """y = x @ W^T (+ bias) for x [M, in] with very large M.
 
@@ -949,6 +956,11 @@ class _linear_rows(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.bf16 = bf16
+        ctx.split = 0
+        if not bf16 and FP32_GEMM_PLANES and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= _SPLIT_MIN_ROWS:
+            # fp32 operands as sums of bf16 planes on the bf16 matrix cores (csrc/gemm_split.hip): three planes = an fp32 GEMM's accuracy
+            ctx.split = FP32_GEMM_PLANES
+            return _be._backend.gemm_split_nt(x, w.detach().float(), None if bias is None else bias.detach().float().contiguous(), planes=ctx.split)
         if bias is not None:
             return torch.addmm(bias.to(w.dtype), x, w.t())   # bias rides the GEMM epilogue (no separate pass over [M, out])
         return x @ w.t()
@@ -961,6 +973,18 @@ class _linear_rows(torch.autograd.Function):
             g = g.to(torch.bfloat16)
         M = x.shape[0]
         S = _split_rows(M)
+        if ctx.split:
+            be = _be._backend
+            g = g.float()
+            gx = be.gemm_split_nt(g, w.detach().float().t().contiguous(), planes=ctx.split) if ctx.needs_input_grad[0] else None
+            gw = gb = None
+            if ctx.needs_input_grad[1]:
+                tiles = ((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128)
+                Sg = max(1, min(M // 256, 1024 // tiles))
+                gw = be.sum_slices([be.gemm_split_tn(g, x, Sg, planes=ctx.split)])[0]
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = g.view(S, M // S, -1).sum(1, dtype=torch.float32).sum(0) if S > 1 else g.sum(0, dtype=torch.float32)
+            return gx, gw, gb, None
         gx = g @ w if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1]:

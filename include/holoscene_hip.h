@@ -622,6 +622,18 @@ typedef struct hsWgradPairJob {
  * every job under HOLOSCENE_WGRAD_DMA=0 stage 64-row chunks through registers (rows >= `rows` read as zero). */
 int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream);
 
+/* fp32 matrix products on the bf16 matrix cores (csrc/gemm_split.hip): each fp32 operand is split into `planes` bf16 planes (3: 24 mantissa
+ * bits, the accuracy of an fp32 FMA chain, six plane products; 2: 16 bits, relative error ~1e-5, three) and the plane products are
+ * accumulated in fp32.  The reference trains in fp32 (training/holoscene_train.py:45; nn.Linear = torch.addmm on fp32 operands): these two
+ * replace the library GEMMs behind model/network.py's `_linear_rows` in the fp32 configuration.
+ *   hs_gemm_split_nt:  C [M, N] (ldc) = A [M, K] (lda) . B [N, K]^T (ldb) + bias [N] (NULL = none)          -- y = x W^T + b;  g W via B = W^T
+ *   hs_gemm_split_tn:  C_parts [slices, N, K] = per-slice A [m, N]^T . B [m, K] over ceil(M / slices) rows   -- dW = g^T x as split-M partials
+ * All matrices row-major fp32; any M, N, K >= 0 (edges are masked; 16-byte-aligned rows take vector loads). */
+int hs_gemm_split_nt(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias, int64_t M, int32_t N, int32_t K,
+                     int32_t planes, void *stream);
+int hs_gemm_split_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C_parts, int64_t M, int32_t N, int32_t K, int32_t slices, int32_t planes,
+                     void *stream);
+
 /* The pixel draw of one training batch (datasets/ns_dataset.py:409-430: NSDataset.__getitem__'s class-balanced rule, there a dozen
  * torch.randperm calls per batch in DataLoader worker processes) as ONE launch.  The frame's pixels grouped by instance class in CSR
  * form: class_ptr [n_cls + 1] offsets into class_pix (pixel indices, class 0 = background first).  Class c contributes
