@@ -653,6 +653,126 @@ class _trunk_render_rr(torch.autograd.Function):
         return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
 
+# The fp32 configuration's trunk of the RENDERED samples.  "rr": the reverse-over-reverse formulation of _trunk_render_rr in fp32 torch
+# arithmetic (rows are samples: value pass, one reverse pass for d min / dx, closed-form backward of both: 16 sample-row GEMMs instead of
+# the 36 of four value+Jacobian rows per point); "jac": every point through sdf_and_jacobian (the Eikonal points always do: all K gradients)
+# (measured equal: 10.5 against 10.4 ms per fp32 iteration -- the 20 fewer GEMMs are paid back in eager elementwise launches -- so the
+# established form stays the default)
+FP32_TRUNK = os.environ.get("HOLOSCENE_FP32_TRUNK", "jac")
+
+
+def _posenc6(x):
+    out = [x]
+    for k in range(6):
+        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    return torch.cat(out, -1)
+
+
+class _trunk_rr32(torch.autograd.Function):
+    """x [n, 3] (constant), hash table, effective weights (W0 [256, 71], W1 [256, 256], W2 [K, 256]) -> sdf_raw [n, K], sdf [n, 1], idx [n, 1],
+    gradients [n, 3] = d min_k sdf_k / dx.  Same function as ObjectImplicitNetworkGrid.forward + gradient on the minimum
+    (model/network.py:169-210, 293-299 of the reference), all arithmetic fp32:
+        value:     xt = [posenc(x) | hash(x)], a0 = W0 xt + b0, h0 = softplus100(a0), a1 = W1 h0 + b1, h1 = softplus100(a1), y = W2 h1 + b2
+        gradient:  v1 = W2[k*] . s1, u0 = W1^T v1, v0 = u0 . s0, ux = W0^T v0, grad = E^T ux     (s = sigmoid(100 a), E = d xt / dx)
+    and the backward of both in closed form (tests/rr_reference.py states the same formulas for the bf16 kernels; checked against
+    autograd's double backward in tools/exp/rr_trunk_math.py)."""
+
+    @staticmethod
+    def forward(ctx, x, x01, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2):
+        ctx.set_materialize_grads(False)
+        be = _be._backend
+        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        x = x.contiguous().float()
+        if x01 is None:
+            x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
+        n, dev = x.shape[0], x.device
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        feat, dydx = torch.empty(n, L * C, device=dev), torch.empty(L, n, 3 * C, device=dev)
+        be.fwd(x01, embeddings, offsets, feat, n, 3, C, L, S, Hres, dydx)
+        jac = 0.5 / divide_factor
+        W0, W1, W2 = W0.detach().float(), W1.detach().float(), W2.detach().float()
+        fr = torch.exp2(torch.arange(6, device=dev, dtype=torch.float32)).view(1, 6, 1)      # (device-side: this runs under graph capture)
+        ang = x.view(n, 1, 3) * fr                                       # [n, 6, 3]
+        sn, cs = torch.sin(ang), torch.cos(ang)
+        xt = torch.cat([x, torch.cat([sn, cs], -1).reshape(n, 36), feat, x.new_zeros(n, 9)], -1)      # [x | sin f0 x, cos f0 x | ... | hash | 0]: 80 columns
+        dpe = torch.cat([fr * cs, -fr * sn], -1).reshape(n, 36)          # d posenc / d x, in xt's column order (column 3 + 6 k + 3 t + d <-> x_d)
+        W0p = F.pad(W0, (0, 9))                             # [256, 80]: the library's kernels for 71 columns run at a tenth of the rate
+        a0 = torch.addmm(b0.detach().float(), xt, W0p.t())
+        h0 = F.softplus(a0, beta=100)
+        s0 = torch.sigmoid_(a0.mul_(100.0))                 # in place: a0 is not needed again
+        a1 = torch.addmm(b1.detach().float(), h0, W1.t())
+        h1 = F.softplus(a1, beta=100)
+        s1 = torch.sigmoid_(a1.mul_(100.0))
+        y = torch.addmm(b2.detach().float(), h1, W2.t())
+        sdf, idx = y.min(-1, keepdim=True)
+        v1 = W2[idx.view(-1)] * s1
+        u0 = v1 @ W1
+        v0 = u0 * s0
+        ux = v0 @ W0p                                       # [n, 80]
+        dy = dydx.view(L, n, 3, C)
+        uxh = ux[:, 39:71].contiguous()
+        # (sums written as products + reductions: einsum turns them into n batched 3 x 32 GEMMs, 1.35 ms each)
+        grad = ux[:, 0:3] + (dpe * ux[:, 3:39]).view(n, 12, 3).sum(1) + jac * (dy * uxh.view(n, L, 1, C).transpose(0, 1)).sum((0, 3))
+        if ctx.needs_input_grad[2]:
+            _be.expect_scatter(ctx.table)
+        ctx.save_for_backward(x01, embeddings, offsets, dydx, idx, xt, h0, h1, s0, s1, u0, v1, v0, uxh, W0p, W1, W2, dpe)
+        ctx.cfg = (n, L, C, S, Hres, jac)
+        ctx.mark_non_differentiable(idx)
+        return y, sdf, idx, grad
+
+    @staticmethod
+    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad):
+        x01, embeddings, offsets, dydx, idx, xt, h0, h1, s0, s1, u0, v1, v0, uxh, W0p, W1, W2, dpe = ctx.saved_tensors
+        n, L, C, S, Hres, jac = ctx.cfg
+        be = _be._backend
+        dev = x01.device
+        K = W2.shape[0]
+        gy = torch.zeros(n, K, device=dev) if g_raw is None else g_raw.float().clone()
+        if g_sdf is not None:
+            gy.scatter_add_(1, idx, g_sdf.float().reshape(n, 1))
+        need_w, need_table = ctx.needs_input_grad[7], ctx.needs_input_grad[2]
+        a0p = a1p = g_dydx = None
+        if g_grad is not None:
+            g = g_grad.float()
+            dy = dydx.view(L, n, 3, C)
+            uxb = torch.cat([g, (dpe.view(n, 12, 3) * g.view(n, 1, 3)).reshape(n, 36),
+                             jac * (dy * g.view(1, n, 3, 1)).sum(2).transpose(0, 1).reshape(n, L * C), g.new_zeros(n, 9)], -1)          # E g~  [n, 80]
+            v0b = uxb @ W0p.t()
+            u0b = v0b * s0
+            a0p = v0b * u0 * (100.0 * s0 * (1.0 - s0))
+            v1b = u0b @ W1.t()
+            u1b = v1b * s1
+            a1p = v1b * W2[idx.view(-1)] * (100.0 * s1 * (1.0 - s1))
+            # cotangent of dy_dx: rank one, jac * ux[level, c] * g~[d]  ([L, n, 3 C] = [level][sample][d * C + c])
+            g_dydx = (jac * uxh.reshape(n, L, 1, C) * g.reshape(n, 1, 3, 1)).permute(1, 0, 2, 3).reshape(L, n, 3 * C).contiguous()
+        h1b = gy @ W2
+        a1 = h1b * s1 if a1p is None else a1p + h1b * s1
+        h0b = a1 @ W1
+        a0 = h0b * s0 if a0p is None else a0p + h0b * s0
+        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
+        if need_w:
+            gW1, gW0, gW2 = _wgrad_rows(a1, h0), _wgrad_rows(a0, xt), _wgrad_rows(gy, h1)
+            if g_grad is not None:
+                onehot = F.one_hot(idx.view(-1), K).float()
+                gW1, gW0, gW2 = gW1 + _wgrad_rows(v1, u0b), gW0 + _wgrad_rows(v0, uxb), gW2 + _wgrad_rows(onehot, u1b)
+            gW0 = gW0[:, :71]
+            gb0, gb1, gb2 = a0.sum(0), a1.sum(0), gy.sum(0)
+        g_emb = None
+        if need_table:
+            g_feat = (a0 @ W0p[:, 39:71].contiguous()).reshape(n, L, C).permute(1, 0, 2).contiguous()         # level-major [L, n, C]
+            if g_dydx is None:
+                g_dydx = torch.zeros(L, n, 3 * C, device=dev)
+            table = ctx.table
+            inplace = _be.accumulates_into_grad(table)
+            target = table.grad if inplace else torch.zeros_like(embeddings)
+            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, n, 3, C, L, S, Hres,
+                       ws=be.scatter_workspace(n, 3, C, L, dev) if n >= _BIN_MIN_POINTS else None, level_major=True)
+            if inplace:
+                _be.scatter_done(table)
+            g_emb = None if inplace else target
+        return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
+
+
 def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
     """_fused_trunk_render's seven outputs; TRUNK_MODE == "rr" (and the stock shapes): the rendered samples through the
     reverse-over-reverse kernels (_trunk_render_rr)."""
@@ -1287,6 +1407,13 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return (self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None
                 and self.embedder.multires == 6 and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].out_features == 256
                 and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features <= 64
+                and not any(l in self.skip_in for l in range(3)))
+
+    def _rr32_supported(self, x):
+        """fp32 trunk of the stock shape (71 -> 256 -> 256 -> K, softplus 100, no skip, 16 x 2 hash features, 6 frequencies) on the device"""
+        lins = self._lins()
+        return (not self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None and self.embedder.multires == 6
+                and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].in_features == 71 and lins[2].out_features == self.d_out
                 and not any(l in self.skip_in for l in range(3)))
 
     def _stock_grid(self):
@@ -2102,6 +2229,20 @@ class HoloSceneNetwork(nn.Module):
             sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = trunk_render(
                 x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
+        elif FP32_TRUNK == "rr" and net._rr32_supported(x_all) and n_main > 0:
+            # fp32: the rendered samples by the reverse-over-reverse closed form (rows = samples), the Eikonal points by value+Jacobian rows
+            enc = net.encoding
+            l0, l1, l2 = net._lins()
+            W0, W1, W2 = effective_weights([l0, l1, l2])
+            sdf_raw, sdf, idx_min, gradients = _trunk_rr32.apply(
+                x_all[:n_main].detach(), None if x01_all is None else x01_all[:n_main], enc.embeddings, enc.offsets,
+                float(np.log2(enc.per_level_scale)), int(enc.base_resolution), float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias)
+            if x_all.shape[0] > n_main:
+                y_eik, J_eik = net.sdf_and_jacobian(x_all[n_main:])
+                y_eik, J_eik = y_eik[:, :net.d_out], J_eik[:, :net.d_out]
+            else:
+                y_eik, J_eik = sdf_raw[:0], sdf_raw.new_zeros(0, net.d_out, 3)
+            min_eik = gtheta = None
         else:
             y_all, J_all = net.sdf_and_jacobian(x_all)
             y_all, J_all = y_all[:, :net.d_out], J_all[:, :net.d_out]
