@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -213,24 +214,36 @@ __global__ __launch_bounds__(BLOCK) void k_composite_fwd(const float *__restrict
         }
     }
     __syncthreads();
-    for (int j = i; j < C; j += BLOCK) {  // column sums -> outputs
-        if (j == 4) continue;            // folded into the depth column
-        if (rot && (j == 6 || j == 7)) continue;   // the thread of column 5 sums all three normal components and rotates them
-        float acc = 0.f, acc_w = 0.f, acc1 = 0.f, acc2 = 0.f;
-        for (int n = 0; n < N; n++) {
-            acc += contrib[(size_t)n * CP + j];
-            if (j == 3) acc_w += contrib[(size_t)n * CP + 4];
-            if (rot && j == 5) { acc1 += contrib[(size_t)n * CP + 6]; acc2 += contrib[(size_t)n * CP + 7]; }
+    // column sums -> outputs.  A wave sums a column ACROSS its lanes (lane = sample, two samples per lane beyond 64; the odd pitch keeps the
+    // reads conflict-free), the waves of the block taking the columns in turn -- one thread per column walked its N samples as a chain of
+    // N dependent LDS reads (98 of them, on 72 of the block's threads: half of this kernel's time).  The sums land in LDS; a last short
+    // phase turns them into the outputs.
+    {
+        const int lane = i & 63, wave = i >> 6;
+        constexpr int NW = BLOCK / 64;
+        float *colsum = rawS;                 // C floats behind the contribution matrix (the staging area is not in use: stage == 0)
+        for (int j = wave; j < C; j += NW) {
+            float v = 0.f;
+            for (int n = lane; n < N; n += 64) v += contrib[(size_t)n * CP + j];
+            v = hs_wave::sum(v);
+            if (lane == 0) colsum[j] = v;
         }
-        if (j < 3) rgb_out[3 * r + j] = acc;
-        else if (j == 3) depth_out[r] = depth_scale[r] * (acc / (acc_w + 1e-8f));
-        else if (rot && j == 5) {     // world -> camera frame (network.py:917-918: rot @ normal_map^T)
+        __syncthreads();
+        for (int j = i; j < C; j += BLOCK) {
+            if (j == 4) continue;            // folded into the depth column
+            if (rot && (j == 6 || j == 7)) continue;   // the thread of column 5 rotates all three normal components
+            const float acc = colsum[j];
+            if (j < 3) rgb_out[3 * r + j] = acc;
+            else if (j == 3) depth_out[r] = depth_scale[r] * (acc / (colsum[4] + 1e-8f));
+            else if (rot && j == 5) {     // world -> camera frame (network.py:917-918: rot @ normal_map^T)
+                const float acc1 = colsum[6], acc2 = colsum[7];
 #pragma unroll
-            for (int a = 0; a < 3; a++) normal_out[3 * r + a] = rot[3 * a] * acc + rot[3 * a + 1] * acc1 + rot[3 * a + 2] * acc2;
+                for (int a = 0; a < 3; a++) normal_out[3 * r + a] = rot[3 * a] * acc + rot[3 * a + 1] * acc1 + rot[3 * a + 2] * acc2;
+            }
+            else if (j < 8) normal_out[3 * r + (j - 5)] = acc;
+            else if (j < 8 + K) sem_out[(size_t)r * K + (j - 8)] = acc;
+            else opac_out[(size_t)r * K + (j - 8 - K)] = acc;
         }
-        else if (j < 8) normal_out[3 * r + (j - 5)] = acc;
-        else if (j < 8 + K) sem_out[(size_t)r * K + (j - 8)] = acc;
-        else opac_out[(size_t)r * K + (j - 8 - K)] = acc;
     }
 }
 
@@ -367,7 +380,7 @@ int hs_composite_fwd(const float *z, const float *sdf, const float *raw, const f
     if (N < 1 || N > 256 || K < 1 || K > 256) return HS_ERR_ARG;
     if (!z || !sdf || !raw || !rgb || !g || !beta || !depth_scale || !weights || !rgb_out || !depth_out || !normal_out || !sem_out || !opac_out)
         return HS_ERR_NULL;
-    size_t lds = (4 + (size_t)N * ((8 + 2 * K) | 1)) * sizeof(float);
+    size_t lds = (4 + (size_t)N * ((8 + 2 * K) | 1) + (8 + 2 * (size_t)K)) * sizeof(float);      // scratch | contributions [N][C | 1] | column sums [C]
     if (lds > 64 * 1024) return HS_ERR_ARG;  // per-sample contribution matrix (odd row pitch) must fit the default dynamic-LDS window
     // (staging the per-object SDF block as the backward does was slower here: 33 -> 47 us -- with the 28 KB contribution matrix the
     //  extra 13 KB cost a workgroup per CU)
