@@ -184,3 +184,32 @@ def test_rr_output_cotangent_image(n, K):
             want[torch.arange(n, device=DEV), idx] += sdf
         assert torch.equal(gy, want.to(torch.bfloat16)), "gy is the bf16 rounding of the fp32 sum"
         assert torch.allclose(part.sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_fused_forward_equals_the_pair_at_the_benchmarked_size():
+    """k_rr_fwd's chunk pipeline (counted vector-memory waits, bare barriers, two rounds of tiles per workgroup) at 100 352 samples:
+    every output bit-identical to k_rr_fwd_value + k_rr_fwd_grad, five runs in a row (a race in the pipeline would show as a run
+    that differs)."""
+    from holoscene_amd.hashencoder.backend import _backend as be
+    n, K = 100352, 32
+    x, feat, dydx, W = _problem(n, K, 11)
+    W0, b0, W1, b1, W2, b2 = W
+    bf = torch.bfloat16
+    packed = be.sdf_mlp2_pack(W0, b0, W1, b1, W2, b2, K, log2_domain=False)
+    rr = be.trunk_rr_pack(W0, W1, W2, K)
+    M = be.tp_rows(n)
+
+    def buffers():
+        tp = lambda: torch.full((M * 256,), 7.0, device=DEV, dtype=bf)  # noqa: E731
+        return dict(H0t=tp(), H1t=tp(), U0t=tp(), V1t=tp(), V0t=tp(), Xp=torch.zeros(n, 80, device=DEV, dtype=bf), onehot=torch.zeros(n, 32, device=DEV, dtype=bf),
+                    raw=torch.empty(n, K, device=DEV), sdf=torch.empty(n, device=DEV), idx=torch.empty(n, device=DEV, dtype=torch.int64),
+                    grad=torch.empty(n, 3, device=DEV), uxh=torch.empty(n, 32, device=DEV))
+    a = buffers()
+    be.trunk_rr_fwd_value(x, feat, packed, K, a["H0t"], a["H1t"], a["Xp"], a["raw"], a["sdf"], a["idx"], a["onehot"])
+    be.trunk_rr_fwd_grad(x, dydx, a["idx"], rr, a["H0t"], a["H1t"], a["U0t"], a["V1t"], a["V0t"], a["grad"], a["uxh"], 0.5)
+    for run in range(5):
+        b = buffers()
+        be.trunk_rr_fwd(x, feat, dydx, packed, rr, K, b["H0t"], b["H1t"], b["Xp"], b["raw"], b["sdf"], b["idx"], b["onehot"], b["U0t"], b["V1t"], b["V0t"],
+                        b["grad"], b["uxh"], 0.5)
+        diff = [k for k in a if not torch.equal(a[k].view(torch.int16) if a[k].dtype == bf else a[k], b[k].view(torch.int16) if b[k].dtype == bf else b[k])]
+        assert not diff, f"run {run}: fused forward differs from the pair in {diff}"
