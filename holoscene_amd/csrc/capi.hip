@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int hs_abi_version(void) { return 4; }
+int hs_abi_version(void) { return 5; }
 
 const char *hs_target_arch(void) { return "gfx950"; }
 

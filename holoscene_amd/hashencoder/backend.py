@@ -79,7 +79,7 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
 # together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
