@@ -260,8 +260,12 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
     float w[D], dw[D];
     if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
         if (xb == 0) {
+            if (!DYDX && lay.out_bf16) {
+                o[0] = 0.f;             // (one zero word)
+            } else {
 #pragma unroll
-            for (int c = 0; c < C; c++) o[c] = 0.f;
+                for (int c = 0; c < C; c++) o[c] = 0.f;
+            }
             if (DYDX) {
 #pragma unroll
                 for (int i = 0; i < D * C; i++) jo[i] = 0.f;
@@ -293,7 +297,14 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restr
     }
     if (xb == 0) {
         if constexpr (C == 2) {
-            *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
+            if (!DYDX && lay.out_bf16) {       // one word per (point, level): both channels as bf16 (hsHashLayout::out_bf16)
+                typedef float f2_t __attribute__((ext_vector_type(2)));
+                typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+                const f2_t v = {acc[0], acc[1]};
+                *reinterpret_cast<uint32_t *>(o) = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+            } else {
+                *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < C; c++) o[c] = acc[c];
@@ -788,6 +799,7 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.grid_id = nullptr;
     lay.grid_stride = 0;
     lay.ws_clean = 0;
+    lay.out_bf16 = 0;
     return lay;
 }
 
@@ -841,6 +853,7 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
     hsHashLayout lay = *layout;
     if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
+    if (lay.out_bf16 && (C != 2 || D != 3 || dy_dx || !pair_forward())) return HS_ERR_ARG;     // the packed-word output: the pair kernel's value form only
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
     const LevelScales sc = make_scales(L, S, H);
     hipStream_t st = (hipStream_t)stream;

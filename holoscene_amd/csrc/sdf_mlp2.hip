@@ -111,7 +111,15 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                     v[6 * k + 3 + d] = cs;
                 }
             }
-            if (feat_level_major) {      // feat [16, B, 2]
+            uint32_t fw[8];
+            if (feat_level_major == 2) {     // feat: uint32 [16, B], the two channels of a level as bf16 (hs_hash_fwd, hsHashLayout::out_bf16):
+                                             // the words ARE this lane's feature inputs (levels 8 h .. 8 h + 7), no conversion
+                const uint32_t *fl = reinterpret_cast<const uint32_t *>(feat) + (size_t)(8 * h) * B + (ok ? gp : 0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) fw[i] = ok ? fl[(size_t)i * B] : 0u;
+#pragma unroll
+                for (int j = 18; j < 34; j++) v[j] = 0.f;
+            } else if (feat_level_major) {      // feat [16, B, 2]
                 const float2 *fl = reinterpret_cast<const float2 *>(feat) + (size_t)(8 * h) * B + (ok ? gp : 0);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -131,6 +139,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
             v[37] = v[38] = v[39] = 0.f;
 #pragma unroll
             for (int j = 0; j < 40; j += 2) hin[j >> 1] = pack2(v[j], v[j + 1]);
+            if (feat_level_major == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) hin[9 + i] = fw[i];
+            }
         }
         HS_STAMP(1);
         // ---- nine phases: layer 0 quarters 0-3 (weights from L2 in fragment order: one coalesced 1 KB load per wave and fragment,

@@ -28,7 +28,8 @@ class hsGate(ctypes.Structure):
 class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
-                ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64), ("ws_clean", ctypes.c_int32)]
+                ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64), ("ws_clean", ctypes.c_int32),
+                ("out_bf16", ctypes.c_int32)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -260,7 +261,7 @@ class _HipBackend:
     @staticmethod
     def _layout(B, D, C, L, gate=None, ws=None, level_major=False, grids=None):
         """grids: None, or (grid_id int32 [B], entries per grid): a batched-over-grids launch (hsHashLayout::grid_id)."""
-        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0)
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0, 0)
         if grids is not None:
             if ws is not None:
                 raise ValueError("the binned scatter holds the records of ONE table: no scatter work space with grids=")
@@ -299,12 +300,18 @@ class _HipBackend:
         return hit
 
     @classmethod
-    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False, grids=None):
+    def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False, grids=None, out_bf16=False):
+        """out_bf16: outputs is an int32 [L, B] tensor that receives one word per (level, point) = both channels as bf16 (C == 2, no dy_dx):
+        the form hs_sdf_mlp2_fwd(feat_level_major=2) consumes -- half the bytes of the fp32 features, written and read."""
         lib = load_library()
         lay = cls._layout(B, D, C, L, gate, level_major=level_major, grids=grids)
+        if out_bf16:
+            if C != 2 or dy_dx is not None or outputs.dtype != torch.int32 or tuple(outputs.shape) != (L, B):
+                raise RuntimeError("hash fwd out_bf16: int32 [L, B] outputs, C == 2, no dy_dx")
+            lay.out_bf16, lay.level_stride, lay.point_stride = 1, B, 1
         _check(lib.hs_hash_fwd(_dev(inputs, "inputs"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32),
-                               _dev(outputs, "outputs"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), ctypes.byref(lay),
-                               _stream()), "hs_hash_fwd")
+                               _dev(outputs, "outputs", torch.int32 if out_bf16 else torch.float32), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
+                               ctypes.byref(lay), _stream()), "hs_hash_fwd")
 
     @classmethod
     def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False, grids=None):
@@ -517,7 +524,8 @@ class _HipBackend:
                 mask |= 1 << int(k)
             select = -1
         W0f, W1f, W2f, bias = packed
-        _check(lib.hs_sdf_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
+        # feat_level_major: False = fp32 [B, 32]; True = fp32 [16, B, 2]; 2 = int32 [16, B], a level's two channels as bf16 (fwd(out_bf16=True))
+        _check(lib.hs_sdf_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat", torch.int32 if int(feat_level_major) == 2 else torch.float32), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
                                    d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
 

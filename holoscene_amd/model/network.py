@@ -1050,6 +1050,8 @@ def _split_rows(M):
 # fp32 GEMMs of the fp32 configuration: "lib" = the library's (fp32 MFMA), "split3" / "split2" = csrc/gemm_split.hip with three / two bf16
 # planes per operand (three: the accuracy of an fp32 GEMM, measured 1.1-1.2x the library on the 256-wide layers; two: 16 mantissa
 # bits per operand, 1.4-1.6x)
+# the sampler's hash features between the gather and the SDF trunk kernel as bf16 words (identical results, half the bytes) / as fp32
+SDF_FEAT_BF16 = os.environ.get("HOLOSCENE_SDF_FEAT_BF16", "1") != "0"
 FP32_GEMM_PLANES = {"lib": 0, "split3": 3, "split2": 2}[os.environ.get("HOLOSCENE_FP32_GEMM", "lib")]
 _SPLIT_MIN_ROWS = 4096
 
@@ -1458,6 +1460,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return self._packed_cache2
 
     def _sdf_mlp(self, x, feat, d_out, select, out, raw, gate, lm):
+        # lm: False = fp32 [B, 32], True = fp32 [16, B, 2], 2 = int32 [16, B] bf16 words (wave-tile kernel only)
         """The fused SDF trunk on already gathered hash features: wave-tile kernel for d_out <= 32, workgroup-tile kernel otherwise."""
         be = _be._backend
         if SDF_MLP_IMPL == "wave" and d_out <= 32:
@@ -1512,12 +1515,20 @@ class ObjectImplicitNetworkGrid(nn.Module):
         # level-major features [L, R*S, C]: the gather kernel's stores become fully coalesced (point-major 8-byte pieces at a
         # 128-byte stride were written 4x, PMC WRITE_SIZE 66 MB for 17 MB), and the MFMA kernel reads 8-byte runs per level
         lm = L == 16 and C == 2
-        feat = torch.empty((L, R * S, C) if lm else (R * S, L * C), device=dev)
-        be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
-               gate=gate, level_major=lm)
         d_out = self._lins()[2].out_features
+        # ... and as bf16 words [L, R*S] when the wave-tile trunk kernel follows: it rounds the features to bf16 anyway (same rounding:
+        # identical results), so the gather writes and the trunk reads half the bytes
+        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= 32 and enc.embeddings.shape[1] == 2
+        if words:
+            feat = torch.empty(L, R * S, device=dev, dtype=torch.int32)
+            be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+                   gate=gate, level_major=True, out_bf16=True)
+        else:
+            feat = torch.empty((L, R * S, C) if lm else (R * S, L * C), device=dev)
+            be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+                   gate=gate, level_major=lm)
         out = torch.empty(R, S, device=dev)
-        self._sdf_mlp(x, feat, d_out, select, out, None, gate, lm)
+        self._sdf_mlp(x, feat, d_out, select, out, None, gate, 2 if words else lm)
         return out
 
     def sdf_and_jacobian(self, x):

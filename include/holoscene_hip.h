@@ -112,6 +112,9 @@ typedef struct hsHashLayout {
     int64_t grid_stride;
     int32_t ws_clean;          /* != 0: the caller guarantees that the counters at the head of scatter_ws are zero -- as a fresh zero-filled work
                                 * space has them and as every hs_hash_bwd / hs_hash_bwd_jac leaves them -- so the clearing launch is skipped */
+    int32_t out_bf16;          /* hs_hash_fwd, C == 2, D == 3, dy_dx == NULL only: `outputs` receives ONE 32-bit word per (point, level) = the two
+                                * channels rounded to bf16 (round to nearest even, channel 0 in the low half) -- exactly what the SDF trunk kernel
+                                * makes of the fp32 features, at half the bytes both ways (hs_sdf_mlp2_fwd: feat_bf16); the strides count words */
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */
@@ -360,6 +363,8 @@ int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
 /* (hs_trunk_mlp2_fwd: ld = points per level of dydx; 0 = M / 4) */
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
                       int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, void *stream);
+/* (hs_sdf_mlp2_fwd: feat_level_major 0 = fp32 [B, 32]; 1 = fp32 [16, B, 2]; 2 = `feat` points at uint32 [16, B], each word a level's two
+ * channels as bf16 -- what hs_hash_fwd writes with hsHashLayout::out_bf16; results identical to the fp32 forms, which round the same way) */
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);
