@@ -75,7 +75,8 @@ G_BYTES = 16 * 8 * 2 * 4                        # hash gather per point and grid
 def _work_hash_fwd(a, k):
     B, C, L, D = a[4], a[6], a[7], a[5]
     dydx = a[10] if len(a) > 10 else k.get("dy_dx")
-    return 0, B * (L * 8 * C * 4 + 4 * D + L * C * 4 + (L * D * C * 4 if dydx is not None else 0))
+    feat_bytes = L * C * (2 if k.get("out_bf16") else 4)        # the features leave as bf16 words in the sampler sweeps (hsHashLayout::out_bf16)
+    return 0, B * (L * 8 * C * 4 + 4 * D + feat_bytes + (L * D * C * 4 if dydx is not None else 0))
 
 
 def _work_sdf_mlp(a, k):
@@ -85,7 +86,8 @@ def _work_sdf_mlp(a, k):
 
 def _work_sdf_mlp2(a, k):
     B, K = a[0].shape[0], a[3]
-    return B * trunk_flops_per_row(K), B * (12 + 128 + 4)
+    feat = 64 if int(k.get("feat_level_major", 0)) == 2 else 128        # feature bytes per point: bf16 words / fp32
+    return B * trunk_flops_per_row(K), B * (12 + feat + 4)
 
 
 def _work_trunk_fwd(a, k):
