@@ -747,11 +747,20 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
             for (int c = 0; c < C; c++) cache[corner * C + c] = wt * gv[c];
         }
     }
-    if (valid && g_dydx) {
-        const float *gj = g_dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
+    const bool rank1 = lay.r1_ux != nullptr && b < lay.r1_n;
+    if (valid && (rank1 || g_dydx)) {
         float G[D * C];
+        if (rank1) {        // (scale * ux[level, c]) * g[d]: the product hs_trunk_rr_bwd_grad would have stored, same order of operations
+            const float *ux = lay.r1_ux + ((size_t)b * L + level) * C, *gg = lay.r1_g + (size_t)b * D;
 #pragma unroll
-        for (int i = 0; i < D * C; i++) G[i] = gj[i];
+            for (int d = 0; d < D; d++)
+#pragma unroll
+                for (int c = 0; c < C; c++) G[d * C + c] = lay.r1_scale * ux[c] * gg[d];
+        } else {
+            const float *gj = g_dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride;
+#pragma unroll
+            for (int i = 0; i < D * C; i++) G[i] = gj[i];
+        }
 #pragma unroll
         for (int gd = 0; gd < D; gd++) {
 #pragma unroll
@@ -800,6 +809,9 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.grid_stride = 0;
     lay.ws_clean = 0;
     lay.out_bf16 = 0;
+    lay.r1_ux = lay.r1_g = nullptr;
+    lay.r1_n = 0;
+    lay.r1_scale = 0.f;
     return lay;
 }
 
@@ -926,9 +938,11 @@ int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets,
 int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
-    if (B == 0 || (!g_feat && !g_dydx)) return HS_OK;
-    if (!inputs || !offsets || !grad_embeddings || !layout) return HS_ERR_NULL;
+    if (!layout) return HS_ERR_NULL;
+    if (B == 0 || (!g_feat && !g_dydx && !layout->r1_ux)) return HS_OK;
+    if (!inputs || !offsets || !grad_embeddings) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
+    if (lay.r1_ux && (!lay.r1_g || lay.r1_n > B)) return HS_ERR_ARG;
     if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     const uint32_t n_chunks = (B + kThreads - 1) / kThreads;

@@ -442,15 +442,17 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
 #pragma unroll
                 for (int i = 0; i < 5; i++) xp[i] = make_uint4(hin[4 * i], hin[4 * i + 1], hin[4 * i + 2], hin[4 * i + 3]);
                 // cotangent of dy_dx: rank one, jac_scale * ux[level, c] * g~[d]  (the reference's second-backward cotangent, hashgrid.py:87-101)
-                const float4 *up = reinterpret_cast<const float4 *>(uxh + gp * 32 + 16 * h);
-                float u[16];
+                if (g_dydx != nullptr) {      // (NULL: the consumer takes the rank-one form itself -- hsHashLayout::r1_ux -- from uxh and g~)
+                    const float4 *up = reinterpret_cast<const float4 *>(uxh + gp * 32 + 16 * h);
+                    float u[16];
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const float4 t = up[i]; u[4 * i] = t.x; u[4 * i + 1] = t.y; u[4 * i + 2] = t.z; u[4 * i + 3] = t.w; }
+                    for (int i = 0; i < 4; i++) { const float4 t = up[i]; u[4 * i] = t.x; u[4 * i + 1] = t.y; u[4 * i + 2] = t.z; u[4 * i + 3] = t.w; }
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float2 *dp = reinterpret_cast<float2 *>(g_dydx + ((size_t)(8 * h + i) * ld + gp) * 6);
+                    for (int i = 0; i < 8; i++) {
+                        float2 *dp = reinterpret_cast<float2 *>(g_dydx + ((size_t)(8 * h + i) * ld + gp) * 6);
 #pragma unroll
-                    for (int d = 0; d < 3; d++) dp[d] = make_float2(jac_scale * u[2 * i] * g[d], jac_scale * u[2 * i + 1] * g[d]);
+                        for (int d = 0; d < 3; d++) dp[d] = make_float2(jac_scale * u[2 * i] * g[d], jac_scale * u[2 * i + 1] * g[d]);
+                    }
                 }
             }
         }
@@ -1264,7 +1266,7 @@ int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad,
     if (n == 0) return HS_OK;
     if (ld == 0) ld = n;
     if (ld < n) return HS_ERR_ARG;
-    if (!x || !dydx || !g_grad || !uxh || !idx || !W2tab || !W0f || !W1f || !H0t || !H1t || !U0t || !U0bt || !A0pt || !A1pt || !U1bt || !UXb || !g_dydx)
+    if (!x || !dydx || !g_grad || !uxh || !idx || !W2tab || !W0f || !W1f || !H0t || !H1t || !U0t || !U0bt || !A0pt || !A1pt || !U1bt || !UXb)       /* g_dydx may be NULL */
         return HS_ERR_NULL;
     const size_t lds = (size_t)kW1F * sizeof(uint16_t);
     static bool attr = false;

@@ -29,7 +29,7 @@ class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
                 ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64), ("ws_clean", ctypes.c_int32),
-                ("out_bf16", ctypes.c_int32)]
+                ("out_bf16", ctypes.c_int32), ("r1_ux", ctypes.c_void_p), ("r1_g", ctypes.c_void_p), ("r1_n", ctypes.c_uint32), ("r1_scale", ctypes.c_float)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -261,7 +261,7 @@ class _HipBackend:
     @staticmethod
     def _layout(B, D, C, L, gate=None, ws=None, level_major=False, grids=None):
         """grids: None, or (grid_id int32 [B], entries per grid): a batched-over-grids launch (hsHashLayout::grid_id)."""
-        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0, 0)
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0, 0, None, None, 0, 0.0)
         if grids is not None:
             if ws is not None:
                 raise ValueError("the binned scatter holds the records of ONE table: no scatter work space with grids=")
@@ -331,9 +331,16 @@ class _HipBackend:
                                 _stream()), "hs_hash_bwd2")
 
     @classmethod
-    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None):
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None, rank1=None):
+        """rank1: None, or (ux fp32 [n, L*C], g fp32 [n, D], scale): the dy_dx cotangent of the first n points is (scale * ux[b, l*C + c]) * g[b, d]
+        and is formed inside the kernel; those rows of g_dydx are not read (g_dydx may be None when n == B)."""
         lib = load_library()
         lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
+        if rank1 is not None:
+            ux, g1, scale = rank1
+            if ux.shape[0] != g1.shape[0] or ux.shape[0] > B or ux.shape[1] != L * C or g1.shape[1] != D:
+                raise RuntimeError("bwd_jac rank1: ux [n, L*C], g [n, D], n <= B")
+            lay.r1_ux, lay.r1_g, lay.r1_n, lay.r1_scale = _dev(ux, "rank1 ux").value, _dev(g1, "rank1 g").value, int(ux.shape[0]), float(scale)
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")

@@ -581,9 +581,14 @@ class _trunk_render_rr(torch.autograd.Function):
         if second:
             U0bt, A0pt, A1pt, U1bt = tp(), tp(), tp(), tp()
             UXb = torch.empty(n, 80, device=dev, dtype=bf)
-            be.trunk_rr_bwd_grad(x[:n], dydx, c(g_grad), uxh, idx[:n], rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, g_dydx, jac, ld=B)
+            # (the samples' dy_dx cotangent is rank one -- jac * ux[level, c] * g~[d] --: the table scatter forms it itself from uxh and g~
+            #  (hsHashLayout::r1_ux) instead of this kernel writing and that one reading 24 B x 16 levels per sample)
+            gg = c(g_grad)
+            rank1 = (uxh, gg, jac) if need_table else None
+            be.trunk_rr_bwd_grad(x[:n], dydx, gg, uxh, idx[:n], rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, None, jac, ld=B)
             be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
         else:
+            rank1 = None
             g_dydx[:, :n].zero_()
             be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
         # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
@@ -646,7 +651,7 @@ class _trunk_render_rr(torch.autograd.Function):
             inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
             be.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, 3, C, L, S, Hres,
-                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
+                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rank1=rank1)
             if inplace:
                 _be.scatter_done(table)
             g_emb = None if inplace else target

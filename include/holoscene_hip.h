@@ -115,6 +115,13 @@ typedef struct hsHashLayout {
     int32_t out_bf16;          /* hs_hash_fwd, C == 2, D == 3, dy_dx == NULL only: `outputs` receives ONE 32-bit word per (point, level) = the two
                                 * channels rounded to bf16 (round to nearest even, channel 0 in the low half) -- exactly what the SDF trunk kernel
                                 * makes of the fp32 features, at half the bytes both ways (hs_sdf_mlp2_fwd: feat_bf16); the strides count words */
+    /* hs_hash_bwd_jac only: NULL, or the dy_dx cotangent of points b < r1_n in RANK-ONE form -- g_dydx[l][b][d * C + c] =
+     * (r1_scale * r1_ux[b * L * C + l * C + c]) * r1_g[b * D + d] -- instead of being read from `g_dydx` (those rows of g_dydx are then
+     * not touched: the reverse-over-reverse trunk's cotangent is exactly this product, hs_trunk_rr_bwd_grad need not write 24 B x L per
+     * sample and this kernel need not read them) */
+    const float *r1_ux, *r1_g;
+    uint32_t r1_n;
+    float r1_scale;
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */
@@ -592,6 +599,8 @@ int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, co
                           void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
 int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
                          const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld, void *stream);
+/* (hs_trunk_rr_bwd_grad: g_dydx may be NULL -- its content is the rank-one product jac_scale * uxh[b, level * 2 + c] * g_grad[b, d], which
+ * hs_hash_bwd_jac can form itself: hsHashLayout::r1_ux) */
 int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad, const float *uxh, const int64_t *idx, const float *W2tab, const void *W0f,
                          const void *W1f, const void *H0t, const void *H1t, const void *U0t, void *U0bt, void *A0pt, void *A1pt, void *U1bt, void *UXb,
                          float *g_dydx, float jac_scale, int64_t n, int64_t ld, void *stream);

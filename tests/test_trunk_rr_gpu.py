@@ -97,6 +97,22 @@ def test_rr_kernels_vs_torch_restatement(n, K):
          "u1b": rel(R.tp_decode(U1bt, n), ref["u1b"]), "a1p": rel(R.tp_decode(A1pt, n), ref["a1p"]), "g_dydx": rel(g_dydx, ref["g_dydx"])}
     print("PARITY rr bwd_grad", e)
     assert max(e.values()) < 2e-2, e
+    # the dy_dx cotangent is rank one: a table scatter given (uxh, g~, jac) forms it itself and must give what it gives on the stored tensor,
+    # bit for bit (hsHashLayout::r1_ux); with g_dydx = NULL the kernel leaves the tensor alone
+    T = 1 << 14
+    offs = torch.arange(17, device=DEV, dtype=torch.int32) * T
+    x01 = ((x + 1) / 2).contiguous()
+    g_feat_lm = torch.randn(16, n, 2, device=DEV)
+    tabs = [torch.zeros(16 * T, 2, device=DEV) for _ in range(2)]
+    be.bwd_jac(g_feat_lm, g_dydx, x01, offs, tabs[0], n, 3, 2, 16, 0.45, 16, level_major=True)
+    be.bwd_jac(g_feat_lm, None, x01, offs, tabs[1], n, 3, 2, 16, 0.45, 16, level_major=True, rank1=(uxh, g_grad, jac))
+    # (atomic accumulation order differs between launches: compare to rounding, and the cotangent itself exactly)
+    assert rel_l2(tabs[1], tabs[0]) < 1e-5
+    want_dydx = (jac * uxh.view(n, 16, 1, 2) * g_grad.view(n, 1, 3, 1)).permute(1, 0, 2, 3).reshape(16, n, 6)
+    assert torch.equal(g_dydx, want_dydx), "the stored cotangent is the rank-one product"
+    untouched = torch.full((16, n, 6), 5.0, device=DEV)
+    be.trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, tp(), tp(), tp(), tp(), torch.zeros(n, 80, device=DEV, dtype=bf), None, jac)
+    assert float(untouched.min()) == 5.0
     gy = torch.zeros(n, 32, device=DEV, dtype=bf)
     gy[:, :K] = g_y.to(bf)
     g_feat = torch.empty(16, n, 2, device=DEV)
