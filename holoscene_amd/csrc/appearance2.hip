@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
                                                                const uint16_t *__restrict__ R2f, const float *__restrict__ biasg,
                                                                uint16_t *__restrict__ XAt, uint16_t *__restrict__ HCt, uint16_t *__restrict__ FVt,
                                                                uint16_t *__restrict__ R0t, uint16_t *__restrict__ R1t, uint32_t *__restrict__ masks,
-                                                               float *__restrict__ rgb, int64_t n) {
+                                                               float *__restrict__ rgb, int64_t n, int featc_words) {
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     uint16_t *R2l = reinterpret_cast<uint16_t *>(lds2 + 2 * kBufBytes);
     float *bias = reinterpret_cast<float *>(lds2 + 2 * kBufBytes + kW2F * 2);
@@ -282,11 +282,17 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
         // ---- this lane's inputs: 16 colour features (levels 8 h .. 8 h + 7) and its 48 encoding slots (rows past the end: zeros)
         uint32_t fcw[8], pew[24];
         {
-            const float2 *fl = reinterpret_cast<const float2 *>(featc) + (size_t)(8 * h) * n + b;     // featc [16, n, 2]
+            if (featc_words) {        // featc: uint32 [16, n], a level's two channels as bf16 (hs_hash_fwd, hsHashLayout::out_bf16): the words themselves
+                const uint32_t *fl = reinterpret_cast<const uint32_t *>(featc) + (size_t)(8 * h) * n + b;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float2 t = fl[(size_t)i * n];
-                fcw[i] = ok ? pack2(t.x, t.y) : 0u;
+                for (int i = 0; i < 8; i++) fcw[i] = ok ? fl[(size_t)i * n] : 0u;
+            } else {
+                const float2 *fl = reinterpret_cast<const float2 *>(featc) + (size_t)(8 * h) * n + b;     // featc [16, n, 2]
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float2 t = fl[(size_t)i * n];
+                    fcw[i] = ok ? pack2(t.x, t.y) : 0u;
+                }
             }
             const float *src[3] = {points, dirs, normals};
             float raw[9];
@@ -707,7 +713,8 @@ int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, in
 }
 
 int hs_appearance2_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *stream_image, const void *R2f,
-                       const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, void *stream) {
+                       const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, int32_t featc_words,
+                       void *stream) {
     if (n < 0) return HS_ERR_ARG;
     if (n == 0) return HS_OK;
     if (!featc || !points || !dirs || !normals || !stream_image || !R2f || !bias || !XAt || !HCt || !FVt || !R0t || !R1t || !masks || !rgb) return HS_ERR_NULL;
@@ -717,7 +724,7 @@ int hs_appearance2_fwd(const float *featc, const float *points, const float *dir
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     k_appear2_fwd<<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
         featc, points, dirs, normals, (const char *)stream_image, (const uint16_t *)R2f, bias, (uint16_t *)XAt, (uint16_t *)HCt, (uint16_t *)FVt, (uint16_t *)R0t,
-        (uint16_t *)R1t, masks, rgb, n);
+        (uint16_t *)R1t, masks, rgb, n, featc_words);
     return wt_check_launch();
 }
 

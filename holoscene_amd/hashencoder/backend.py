@@ -930,12 +930,14 @@ class _HipBackend:
 
     @staticmethod
     def appearance2_fwd(featc, points, dirs, normals, P, XAt, HCt, FVt, R0t, R1t, masks, rgb):
+        """featc: fp32 [16, n, 2], or int32 [16, n] bf16 words (fwd(out_bf16=True))."""
         lib = load_library()
         bf, u8 = torch.bfloat16, torch.uint8
-        _check(lib.hs_appearance2_fwd(_dev(featc, "featc"), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
+        words = featc.dtype == torch.int32
+        _check(lib.hs_appearance2_fwd(_dev(featc, "featc", torch.int32 if words else torch.float32), _dev(points, "points"), _dev(dirs, "dirs"), _dev(normals, "normals"),
                                       _dev(P["stream"], "stream", u8), _dev(P["R2f"], "R2f", u8), _dev(P["bias"], "bias"),
                                       _dev(XAt, "XAt", bf), _dev(HCt, "HCt", bf), _dev(FVt, "FVt", bf), _dev(R0t, "R0t", bf), _dev(R1t, "R1t", bf),
-                                      _dev(masks, "masks", torch.int32), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]), _stream()), "hs_appearance2_fwd")
+                                      _dev(masks, "masks", torch.int32), _dev(rgb, "rgb"), ctypes.c_int64(points.shape[0]), int(words), _stream()), "hs_appearance2_fwd")
 
     @staticmethod
     def appearance_mask_words(B):

@@ -944,8 +944,12 @@ class _fused_appearance_wave(torch.autograd.Function):
         B = points.shape[0]
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
         dev, bf = points.device, torch.bfloat16
-        featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for the consumer
-        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
+        if SDF_FEAT_BF16 and C == 2:      # bf16 words [L, B]: the kernel rounds the features to bf16 anyway (same rounding), half the bytes both ways
+            featc = torch.empty(L, B, device=dev, dtype=torch.int32)
+            be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True, out_bf16=True)
+        else:
+            featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for the consumer
+            be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
         mats = (Wc0, Wc1, Wr0, Wr1, Wr2)
         need_bwd = any(ctx.needs_input_grad)
         P = be.appearance2_pack(*mats, (bc0, bc1, br0, br1, br2), transposed=need_bwd)

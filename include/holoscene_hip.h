@@ -460,8 +460,9 @@ int hs_appearance2_enc_column(int32_t half, int32_t slot);     /* encoded-input 
 int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0, const float *Wr1, const float *Wr2, const float *bc0,
                         const float *bc1, const float *br0, const float *br1, const float *br2, void *stream_image, void *R2f, float *bias,
                         void *streamT_image /* NULL, or hs_appearance2_pack_t_bytes() bytes: the transposed image of the backward kernel */, void *stream);
+/* (hs_appearance2_fwd: featc_words != 0: `featc` points at uint32 [16, n], a level's two channels as bf16 -- hsHashLayout::out_bf16) */
 int hs_appearance2_fwd(const float *featc, const float *points, const float *dirs, const float *normals, const void *stream_image, const void *R2f,
-                       const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, void *stream);
+                       const float *bias, void *XAt, void *HCt, void *FVt, void *R0t, void *R1t, uint32_t *masks, float *rgb, int64_t n, int32_t featc_words, void *stream);
 /* Backward data path of the same: the transposed fragment image (hs_appearance2_pack_t_bytes() bytes, built by hs_appearance2_pack), the forward
  * pass's masks and rgb.  Outputs: gy [n,32] bf16 row-major (cotangent of the pre-sigmoid outputs, columns 0..2),
  * GR1t, GR0t, GFVt, GHCt tile-packed (pre-activation cotangents of r1, r0, the feature vector, hc), d_normals [n,3], g_featc [16,n,2] fp32
