@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kThreadsP) void k_wgrad_pairs(PairJobs jobs) {
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first[j + 1]) j++;
     const hsWgradPairJob &job = jobs.j[j];
     const int slice = blockIdx.x - jobs.first[j], S = job.slices;
-    if (jobs.dma && !job.ones && !(job.reserved & 1)) {       // the all-tile-packed and the mixed kinds: rows by LDS-DMA (row-major-only kinds and the ones column: register form)
+    if (jobs.dma && !job.ones && !(job.reserved & 1) && job.rows > 0) {      // (rows == 0: a row-major operand has no row to clamp to)       // the all-tile-packed and the mixed kinds: rows by LDS-DMA (row-major-only kinds and the ones column: register form)
         char *ldsc = reinterpret_cast<char *>(lds);
         if (job.kind == HS_WGP_256x256) { pair_slice_dma<256, 256, 256, true, true>(job, slice, S, ldsc); return; }
         if (job.kind == HS_WGP_256x80) { pair_slice_dma<256, 128, 80, true, false>(job, slice, S, ldsc); return; }
