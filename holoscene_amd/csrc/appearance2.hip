@@ -14,6 +14,7 @@
 // the signs only.
 //
 //   forward   hc = relu(Wc0 f + bc0);  fv = Wc1 hc + bc1;  r0 = relu(Wr0 [enc | fv] + br0);  r1 = relu(Wr1 r0 + br1);  rgb = sigmoid(Wr2 r1 + br2)
+#include "launch_util.h"
 #include "wave_tile.h"
 
 namespace {
@@ -719,8 +720,8 @@ int hs_appearance2_fwd(const float *featc, const float *points, const float *dir
     if (n == 0) return HS_OK;
     if (!featc || !points || !dirs || !normals || !stream_image || !R2f || !bias || !XAt || !HCt || !FVt || !R0t || !R1t || !masks || !rgb) return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kBufBytes + (size_t)kW2F * 2 + kA2Bias * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear2_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_appear2_fwd, (int)lds);
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     k_appear2_fwd<<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
         featc, points, dirs, normals, (const char *)stream_image, (const uint16_t *)R2f, bias, (uint16_t *)XAt, (uint16_t *)HCt, (uint16_t *)FVt, (uint16_t *)R0t,
@@ -736,8 +737,8 @@ int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normal
     if (n == 0) return HS_OK;
     if (!g_rgb || !rgb || !normals || !masks || !streamT_image || !gy || !GR1t || !GR0t || !GFVt || !GHCt || !d_normals || !g_featc) return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kBufBytes;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear2_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_appear2_bwd, (int)lds);
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     k_appear2_bwd<<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
         g_rgb, rgb, normals, masks, (const char *)streamT_image, (uint16_t *)gy, (uint16_t *)GR1t, (uint16_t *)GR0t, (uint16_t *)GFVt, (uint16_t *)GHCt, d_normals,

@@ -13,6 +13,7 @@
 //
 //   k_appear_fwd : featc, points, dirs, normals -> rgb;  keeps xin = [featc | posenc] , hc, fv, r0, r1 (bf16)
 //   k_appear_bwd : d rgb -> g_y, gA_r1, gA_r0, g_fv, gA_hc (bf16), d normals, d featc (fp32), bias gradients
+#include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <math.h>
@@ -515,8 +516,8 @@ int hs_appearance_fwd(const float *featc, const float *points, const float *dirs
     if (!featc || !points || !dirs || !normals || !Wc0 || !Wc1 || !Wr0f || !Wr0p || !Wr1 || !Wr2 || !bc0 || !bc1 || !br0 || !br1 || !br2 || !xin ||
         !hc || !fv || !r0 || !r1 || !rgb)
         return HS_ERR_NULL;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFwd); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_appear_fwd, (int)kLdsFwd);
     const int64_t ntiles = (B + BM - 1) / BM;
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     k_appear_fwd<<<grid, kThreads, kLdsFwd, (hipStream_t)stream>>>(
@@ -532,8 +533,8 @@ int hs_appearance_bwd(const float *g_rgb, const float *rgb, const float *normals
     if (!g_rgb || !rgb || !normals || (!relu_masks && (!r1 || !r0 || !hc)) || !Wr2t || !Wr1t || !Wr0ft || !Wr0nt || !Wc1t || !Wc0t || !gy || !gA_r1 || !gA_r0 || !g_fv ||
         !gA_hc || !d_normals || !g_featc)
         return HS_ERR_NULL;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_appear_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBwd); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_appear_bwd, (int)kLdsBwd);
     const int64_t ntiles = (B + BM - 1) / BM;
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     k_appear_bwd<<<grid, kThreads, kLdsBwd, (hipStream_t)stream>>>(

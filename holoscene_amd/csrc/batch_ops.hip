@@ -118,8 +118,8 @@ int hs_draw_pixels(const int32_t *class_ptr, const int32_t *class_pix, const int
     while (want_max < (uint32_t)(want > 1 ? want : 1)) want_max <<= 1;      // the sort pads to a power of two
     const uint32_t cap = 4 * want_max;                                       // load factor <= 1/4
     const size_t lds = ((size_t)cap + 4 * (size_t)want_max) * sizeof(uint32_t);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_draw_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * (size_t)HS_DRAW_MAX_WANT * sizeof(uint32_t))); attr = true; }
+    // (per call, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and the call is cheap)
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_draw_pixels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * (size_t)HS_DRAW_MAX_WANT * sizeof(uint32_t)));
     k_draw_pixels<<<n_cls + 1, kDrawThreads, lds, (hipStream_t)stream>>>(class_ptr, class_pix, out_off, n_cls, per_class, n_bg, n_uniform, total_pixels,
                                                                       seed, counter, out, cap, want_max);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;

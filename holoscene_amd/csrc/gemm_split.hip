@@ -11,6 +11,7 @@
 // Workgroup = 4 waves = one 128 x 128 tile of C (a wave: 64 x 64, four accumulators); the reduction runs in chunks of 32 through LDS: fp32 from
 // global memory (next chunk requested before this chunk's products), split in registers, planes stored as bf16 tiles; fragments by
 // ds_read_b128 (NT: the reduction index is contiguous) or by gfx950's transposing ds_read_b64_tr_b16 (TN: it is the row index).
+#include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(kT) void k_gemm_split(const float *__restrict__ A, 
 template <int P, bool TN> int launch(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias, int64_t I, int J, int64_t R,
                                      int slices, hipStream_t stream) {
     const size_t lds = 2 * (size_t)P * (TN ? RC * PTN : BT * PNT) * sizeof(uint16_t);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_gemm_split<P, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_gemm_split<P, TN>, (int)lds);
     const int tiles_j = (J + BT - 1) / BT;
     const int64_t tiles_i = (I + BT - 1) / BT;
     if (tiles_i * tiles_j > 0x7fffffff) return HS_ERR_ARG;

@@ -22,6 +22,7 @@
 //   one k-step ahead; weight chunks stream L2 -> registers -> LDS one chunk ahead.
 //   Measured history (131 072 points, MI355X): 276 us (libm sinf/cosf staging) -> 132 us (hardware sincos) ->
 //   see DESIGN.md for the current figure.
+#include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <math.h>
@@ -707,13 +708,13 @@ int hs_sdf_mlp_fwd(const float *x, const float *feat, const void *W0, const floa
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);  // one workgroup per CU (111 KB LDS), tiles strided across the grid
     hipStream_t st = (hipStream_t)stream;
     if (d_out <= 32) {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        static hsLdsAttrOnce attr1;
+        attr1.set((const void *)k_sdf_mlp<1>, (int)lds);
         k_sdf_mlp<1><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select, select_mask,
                                                    out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     } else {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+        static hsLdsAttrOnce attr2;
+        attr2.set((const void *)k_sdf_mlp<2>, (int)lds);
         k_sdf_mlp<2><<<grid, kThreads, lds, st>>>(x, feat, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2, d_out, select, select_mask,
                                                    out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr}, feat_level_major);
     }
@@ -732,13 +733,13 @@ int hs_trunk_mlp_fwd(const void *X, const void *W0, const float *b0, const void 
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);
     hipStream_t st = (hipStream_t)stream;
     if (d_out <= 32) {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        static hsLdsAttrOnce attr1;
+        attr1.set((const void *)k_trunk_fwd<1>, (int)lds);
         k_trunk_fwd<1><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
                                                      d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M, x, feat, dydx, (uint16_t *)Xout, L, C, jac_scale);
     } else {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+        static hsLdsAttrOnce attr2;
+        attr2.set((const void *)k_trunk_fwd<2>, (int)lds);
         k_trunk_fwd<2><<<grid, kThreads, lds, st>>>((const uint16_t *)X, (const uint16_t *)W0, b0, (const uint16_t *)W1, b1, (const uint16_t *)W2, b2,
                                                      d_out, (uint16_t *)H0, (uint16_t *)H1, Y, M, x, feat, dydx, (uint16_t *)Xout, L, C, jac_scale);
     }
@@ -763,13 +764,13 @@ int hs_trunk_mlp_bwd(const void *g, int32_t g_pitch, const void *H1, const void 
     const int grid = (int)(ntiles < kGridCap ? ntiles : kGridCap);   // == hs_trunk_bwd_parts(M)
     hipStream_t st = (hipStream_t)stream;
     if (g_pitch == 32) {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        static hsLdsAttrOnce attr1;
+        attr1.set((const void *)k_trunk_bwd<32>, (int)lds);
         k_trunk_bwd<32><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
                                                       (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part, ld);
     } else {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void *)k_trunk_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+        static hsLdsAttrOnce attr2;
+        attr2.set((const void *)k_trunk_bwd<64>, (int)lds);
         k_trunk_bwd<64><<<grid, kThreads, lds, st>>>((const uint16_t *)g, (const uint16_t *)H1, (const uint16_t *)H0, (const uint16_t *)W2t,
                                                       (const uint16_t *)W1t, (uint16_t *)gA1, (uint16_t *)gA0, gb1, gb0, (const uint16_t *)W0t, g_feat, g_dydx, L, C, jac_scale, M, gb2, dW2_part, ld);
     }

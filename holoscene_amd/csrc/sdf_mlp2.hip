@@ -21,6 +21,7 @@
 //
 // Softplus(beta = 100) is evaluated in the scaled domain of sdf_mlp.hip (t = 100 log2(e) v: log2(1 + 2^t)), the biases initialise
 // the accumulators.  d_out <= 32 (one output tile); wider heads keep the workgroup-tile kernel.
+#include "launch_util.h"
 #include "wave_tile.h"
 
 #ifdef HS_SDF2_PROFILE     // tools/exp/sdf2_prof.hip: per-phase s_memtime stamps of a steady-state wave tile
@@ -288,8 +289,8 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     if (!x || !feat || !W0f || !W1f || !W2f || !bias || !out_min) return HS_ERR_NULL;
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;   // the resident image is copied in one sweep: W2f directly behind W1f
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_sdf_mlp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_sdf_mlp2, (int)lds);
     const int64_t ntiles = (B + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);      // one workgroup per CU (146 KB of LDS), wave tiles strided across the grid

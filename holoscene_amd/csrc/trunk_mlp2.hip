@@ -18,6 +18,7 @@
 //     lane, halving the store instructions (the epilogue store tail is issue-bound);
 //   * the assembled input rows leave as Xp [M,80] bf16 in the kernel's own column order (lane (row, h) writes its 40 values as one
 //     80-byte run): the first layer's weight gradient is taken against Xp and un-permuted on the host side (71 columns).
+#include "launch_util.h"
 #include "wave_tile.h"
 
 #ifdef HS_TRUNK2_PROFILE     // tools/exp/trunk2_prof.hip: per-phase s_memtime stamps of a wave tile
@@ -458,12 +459,9 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     }
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)k_trunk_fwd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_trunk_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static hsLdsAttrOnce attr_a, attr_b;
+    attr_a.set((const void *)k_trunk_fwd2<false>, (int)lds);
+    attr_b.set((const void *)k_trunk_fwd2<true>, (int)lds);
     const int64_t ntiles = (M + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);

@@ -22,6 +22,7 @@
 // Activations that cross kernels are stored TILE-PACKED ("TP"): [tile of 32 samples][k-step 0..15][lane 0..63] x 16 bytes = exactly
 // the four packed words lane (sample, half) holds for that k-step -- one coalesced 1 KB wave access per k-step in every producer and
 // consumer, no layout conversion anywhere (the weight-gradient kernel scatters the 8-byte runs into its row-major LDS tiles).
+#include "launch_util.h"
 #include "wave_tile.h"
 
 namespace {
@@ -1218,8 +1219,8 @@ int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, co
     if (!x || !feat || !W0f || !W1f || !W2f || !bias || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx || !onehot) return HS_ERR_NULL;
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_value, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_rr_fwd_value, (int)lds);
     k_rr_fwd_value<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                     (uint16_t *)H0t, (uint16_t *)H1t, (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, n);
     return wt_check_launch();
@@ -1237,8 +1238,8 @@ int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const 
         !V1t || !V0t || !grad || !uxh)
         return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kFBuf + kBias * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_rr_fwd, (int)lds);
     k_rr_fwd<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, W2tab,
                                                                (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, d_out, (uint16_t *)H0t, (uint16_t *)H1t,
                                                                (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, (uint16_t *)U0t, (uint16_t *)V1t,
@@ -1253,8 +1254,8 @@ int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, 
     if (ld < n) return HS_ERR_ARG;
     if (!x || !dydx || !idx || !W2tab || !W1Tf || !W0Tf || !H0t || !H1t || !U0t || !V1t || !V0t || !grad || !uxh) return HS_ERR_NULL;
     const size_t lds = (size_t)kW1F * sizeof(uint16_t);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_fwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_rr_fwd_grad, (int)lds);
     k_rr_fwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, idx, W2tab, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, (const uint16_t *)H0t,
                                                                    (const uint16_t *)H1t, (uint16_t *)U0t, (uint16_t *)V1t, (uint16_t *)V0t, grad, uxh, jac_scale, n, ld);
     return wt_check_launch();
@@ -1269,8 +1270,8 @@ int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad,
     if (!x || !dydx || !g_grad || !uxh || !idx || !W2tab || !W0f || !W1f || !H0t || !H1t || !U0t || !U0bt || !A0pt || !A1pt || !U1bt || !UXb)       /* g_dydx may be NULL */
         return HS_ERR_NULL;
     const size_t lds = (size_t)kW1F * sizeof(uint16_t);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_rr_bwd_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_rr_bwd_grad, (int)lds);
     k_rr_bwd_grad<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, dydx, g_grad, uxh, idx, W2tab, (const uint16_t *)W0f, (const uint16_t *)W1f,
                                                                    (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)U0t, (uint16_t *)U0bt,
                                                                    (uint16_t *)A0pt, (uint16_t *)A1pt, (uint16_t *)U1bt, (uint16_t *)UXb, g_dydx, jac_scale, n, ld);
@@ -1284,12 +1285,9 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
     if (ld < n) return HS_ERR_ARG;
     if (!gy || !W2Tf || !W1Tf || !W0Tf || !H0t || !H1t || !A0t || !A1t || !g_feat || (!A0pt) != (!A1pt)) return HS_ERR_NULL;
     const size_t lds = (size_t)(kW1F + kW2TF) * sizeof(uint16_t);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)k_rr_bwd_value<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_rr_bwd_value<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static hsLdsAttrOnce attr_a, attr_b;
+    attr_a.set((const void *)k_rr_bwd_value<true>, (int)lds);
+    attr_b.set((const void *)k_rr_bwd_value<false>, (int)lds);
     if (A0pt)
         k_rr_bwd_value<true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
                                                                               (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)A0pt, (const uint16_t *)A1pt,

@@ -9,6 +9,7 @@
 // and keeps the whole result of its slice in registers (256 x 256 fp32 = 128 VGPRs per wave, 8 waves).  The operands run along the ROWS
 // of row-major tiles, which is what gfx950's transposing LDS read delivers (`ds_read_b64_tr_b16`, sdf_mlp.hip: tr_frag).
 // Partial results leave as bf16 slices [S, NA, MB] (the same rounding the library's bf16 bmm output had); hs_sum_slices adds them in fp32.
+#include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -189,8 +190,8 @@ int hs_wgrad_rows(const hsWgradJob *jobs, int32_t n_jobs, int32_t slices, void *
         wj.j[i] = j;
     }
     const size_t lds = 2 * (size_t)RC * ((256 + PADG) + (256 + PADG)) * sizeof(uint16_t);      // two chunks of the widest operand pair
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_wgrad_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_wgrad_rows, (int)lds);
     k_wgrad_rows<<<n_jobs * slices, kThreadsG, lds, (hipStream_t)stream>>>(wj, slices);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
 }

@@ -9,6 +9,7 @@
 //     lane (row, half)'s two runs of four neurons of one k-step, dropped into the row-major LDS tile as two 8-byte writes.
 // Result shapes: 256 x 256, 256 x 128 (B = [M, 80]: columns 80..127 of the LDS tile stay zero), 32 x 256.  Partials leave as bf16
 // slices [S, NA, MB] like wgrad.hip's; hs_sum_slices adds them in fp32.
+#include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -422,8 +423,8 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
     }
     const size_t lds_reg = 2 * (size_t)RCP * ((256 + PADP) + (256 + PADP)) * sizeof(uint16_t), lds_dma = (size_t)kLdsD;
     const size_t lds = lds_reg > lds_dma ? lds_reg : lds_dma;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_wgrad_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_wgrad_pairs, (int)lds);
     k_wgrad_pairs<<<pj.first[n_jobs], kThreadsP, lds, (hipStream_t)stream>>>(pj);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
 }

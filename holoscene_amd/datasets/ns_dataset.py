@@ -25,7 +25,9 @@ from .pixel_sampler import PixelSampler
 
 def rank_seed(seed, rank=None):
     """Data-parallel ranks must not draw the same frames and pixels (an effective batch of 1/N): the stream of a rank is derived from
-    its rank the way Stage1Trainer derives its own (seed + 7919 (rank + 1)).  rank None: the process group's rank when one is alive."""
+    its rank: seed + 7919 rank, i.e. rank 0 keeps the bare seed (a single process and rank 0 of a job read the same batches).
+    (Stage1Trainer reseeds the MODEL's draws with seed + 7919 (rank + 1) after the common initialisation; the two streams are unrelated.)
+    rank None: the process group's rank when one is alive."""
     if rank is None:
         import torch.distributed as dist
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
@@ -59,7 +61,7 @@ class ResidentNSDataset:
         self._py = random.Random(seed)
         self._epoch = []                # fix_length == 0: frames of the current epoch still to be served (a shuffled DataLoader epoch)
         self._sampler = PixelSampler(self._class_pixels, self.total_pixels, num_pixels, dev, seed=seed)
-        self._fidx = torch.zeros(1, dtype=torch.int64, device=dev)       # static: frame index of the batch being served
+        self._fidx = torch.arange(self.n_images, dtype=torch.int64, device=dev)      # per-frame index rows for write_batch's gather plans (no host->device copy in the loop)
         self._plans = {}
 
     @classmethod
@@ -119,7 +121,7 @@ class ResidentNSDataset:
         key = (frame, dst_input["uv"].data_ptr())
         plan = self._plans.get(key)
         if plan is None:
-            fidx = torch.tensor([frame], dtype=torch.int64).to(self.device)
+            fidx = self._fidx[frame:frame + 1]
             plan = self._plans[key] = _be._backend.gather_plan([
                 (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
                 (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),

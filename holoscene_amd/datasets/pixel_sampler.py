@@ -89,5 +89,10 @@ class PixelSampler:
         ptr, pix, off, n = self._device_frames()[frame]
         n_cls, per_class, n_bg = self.quotas(frame)
         self._counter += 1
+        if max(n_bg, per_class, self.R - self.half) > _be.DRAW_MAX_WANT:
+            # a quota beyond the kernel's LDS hash set (num_pixels > 2 x HS_DRAW_MAX_WANT): the host rule + one copy, as on CPU
+            idx = self.host_indices(frame)
+            self.idx[:idx.numel()].copy_(idx, non_blocking=True)
+            return self.idx, int(idx.numel())
         _be._backend.draw_pixels(ptr, pix, off, n_cls, per_class, n_bg, self.R - self.half, self.total, self._seed, self._counter, self.idx)
         return self.idx, n

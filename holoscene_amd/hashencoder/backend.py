@@ -183,6 +183,7 @@ def _stream():
 SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
 # Scatter the hashed levels through per-bin record lists + an LDS reduction instead of global atomics (csrc/hash_encode.hip)
 SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
+DRAW_MAX_WANT = 4096     # include/holoscene_hip.h: HS_DRAW_MAX_WANT (largest per-class / uniform quota hs_draw_pixels takes)
 
 def accumulates_into_grad(table):
     """True for a hash table whose gradient lives in flat gradient storage (training/flat.py marks the parameter with
@@ -288,16 +289,37 @@ class _HipBackend:
         n = lib.hs_hash_scatter_ws_bytes(B, D, C, L, ctypes.byref(cap))
         if n < 0:
             raise RuntimeError(f"hs_hash_scatter_ws_bytes: {n}")
-        # one PERSISTENT work space per shape and device, zero-filled once: the reduce kernel returns the bin counters to zero, so a scatter
-        # through it needs no clearing launch (third element: hsHashLayout::ws_clean).  Scatters on one stream use it one after the other; it is
-        # created eagerly (the warm-up passes of a captured iteration), never inside a capture
-        key = (int(B), int(D), int(C), int(L), str(torch.device(device)))
+        # ONE persistent work space per (D, C, L, device), zero-filled once and sized for the largest batch seen so far, rounded up to a power
+        # of two (a smaller batch runs through the same buffer with the larger per-bin capacity: the kernels take the capacity from the
+        # layout, not from B) -- the eager path's batch size varies per frame, and one ~2.3 KB x B buffer per distinct B would pin memory
+        # until the process dies.  The reduce kernel returns the bin counters to zero, so a scatter through a CLEAN work space needs no
+        # clearing launch (third element -> hsHashLayout::ws_clean); that only holds while every scatter through it is ordered on one
+        # stream, so a call from another stream than the last one gets the clearing launch (and takes the buffer over).
+        # Created eagerly (the warm-up passes of a captured iteration), never inside a capture.
+        key = (int(D), int(C), int(L), str(torch.device(device)))
+        stream = int(torch.cuda.current_stream(device).cuda_stream)
         hit = _SCATTER_WS.get(key)
-        if hit is None:
+        if hit is None or hit["B"] < B:
             if torch.cuda.is_current_stream_capturing():
                 return torch.empty(n, device=device, dtype=torch.uint8), int(cap.value)
-            hit = _SCATTER_WS[key] = (torch.zeros(n, device=device, dtype=torch.uint8), int(cap.value), True)
-        return hit
+            Bcap = 1 << max(int(B) - 1, 1).bit_length()
+            n2 = lib.hs_hash_scatter_ws_bytes(Bcap, D, C, L, ctypes.byref(cap))
+            if n2 < 0:
+                raise RuntimeError(f"hs_hash_scatter_ws_bytes: {n2}")
+            _SCATTER_WS.pop(key, None)          # (the smaller buffer goes back to the allocator)
+            hit = _SCATTER_WS[key] = {"B": Bcap, "buf": torch.zeros(n2, device=device, dtype=torch.uint8), "cap": int(cap.value), "stream": stream}
+        # (stream None: the owner declared the device idle since the last use -- scatter_workspaces_idle(), the trainer after the
+        #  synchronize that ends its warm-up passes -- so whoever comes next, the capture stream included, finds the counters at zero)
+        clean = hit["stream"] is None or hit["stream"] == stream
+        hit["stream"] = stream
+        return hit["buf"], hit["cap"], clean
+
+    @staticmethod
+    def scatter_workspaces_idle():
+        """Declare that every scatter issued so far has completed (the caller has synchronised the device): the next scatter through a
+        cached work space may come from any stream without the clearing launch."""
+        for hit in _SCATTER_WS.values():
+            hit["stream"] = None
 
     @classmethod
     def fwd(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gate=None, level_major=False, grids=None, out_bf16=False):

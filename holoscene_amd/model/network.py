@@ -214,9 +214,9 @@ class _Outputs(dict):
         return dict.__len__(self._materialise())
 
     def pop(self, key, *default):
-        if key in self._pending():
-            self._pending().pop(key)
-            return None
+        fn = self._pending().pop(key, None)        # a deferred entry is evaluated by pop like by any other read (dict semantics)
+        if fn is not None:
+            return fn()
         return dict.pop(self, key, *default)
 
 

@@ -354,6 +354,7 @@ class Stage1Trainer:
             t.copy_(s0)
         self.model.implicit_network.invalidate_packed_weights()
         torch.cuda.synchronize()
+        _net._be._backend.scatter_workspaces_idle()      # the capture stream takes the scatter work spaces over without a clearing launch
         self._drain_collective_watchdog()
 
     def _drain_collective_watchdog(self):

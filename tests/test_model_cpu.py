@@ -187,7 +187,8 @@ def test_render_outputs_defer_entries_until_read():
     o.defer("c", lambda: 3)
     assert sorted(o.keys()) == ["a", "b", "c"] and dict(o) == {"a": 1, "b": 2, "c": 3} and len(o) == 3
     o.defer("d", lambda: 4)
-    assert o.pop("d") is None and "d" not in o      # dropped unevaluated
+    assert o.pop("d") == 4 and "d" not in o         # pop reads like any other access (dict semantics), then the entry is gone
+    assert o.pop("d", 9) == 9
     assert o.get("zz", 7) == 7
     with pytest.raises(KeyError):
         o["zz"]
