@@ -429,6 +429,7 @@ def main():
         # duplicate devices); the driver's multi-GPU runs use the default, RCCL
         be_name = os.environ.get("HS_BENCH_BACKEND", "nccl")
         if be_name == "nccl":
+            os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")      # the flight recorder the trainer waits on before a capture (trainer.py: _drain_collective_watchdog)
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(be_name)

@@ -16,6 +16,7 @@
 //   forward   hc = relu(Wc0 f + bc0);  fv = Wc1 hc + bc1;  r0 = relu(Wr0 [enc | fv] + br0);  r1 = relu(Wr1 r0 + br1);  rgb = sigmoid(Wr2 r1 + br2)
 #include "launch_util.h"
 #include "wave_tile.h"
+#include "trunk_pack.h"
 
 namespace {
 
@@ -161,6 +162,41 @@ __global__ __launch_bounds__(256) void k_appear2_pack(const float *__restrict__ 
     const int idx = blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment slot per thread
     if (idx < kPackSlots) pack_slot(idx, Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, bc0, bc1, br0, br1, br2, stream, R2f, bias);
     else if (streamT != nullptr) pack_t_slot(idx - kPackSlots, Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, streamT);
+}
+
+// Every weight image of a Stage-1 iteration -- the sampler sweeps' trunk images (log2-domain softplus, sdf_mlp2.hip), the training trunk's
+// (trunk_pack.h), the colour branch's (above) -- in ONE launch: they are functions of the same ~0.3 M weights, and the three separate
+// pack launches of an iteration cost ~5 us each whatever they do.
+struct PackIterArgs {
+    // trunk
+    const float *W0, *b0, *W1, *b1, *W2, *b2;
+    int32_t ld0, f_in, d_out;
+    uint16_t *sW0f, *sW1f, *sW2f; float *sbias;                                         // sampler images (NULL: none)
+    uint16_t *W0f, *W1f, *W2f; float *bias; uint16_t *W1Tf, *W0Tf, *W2Tf; float *W2tab;  // training images (NULL: none)
+    uint16_t *w1t, *w2t, *w0t;                                                          // + row-major transposes (NULL: none)
+    // colour branch (stream NULL: none)
+    const float *Wc0, *Wc1, *Wr0, *Wr1, *Wr2, *bc0, *bc1, *br0, *br1, *br2;
+    int32_t ldr0;
+    uint16_t *stream, *R2f; float *abias; uint16_t *streamT;
+};
+constexpr int kIterPackSlots = kSdfPackSlots + kTrunkPackSlots + kPackSlots + kStreamTBytes / 16;
+
+__global__ __launch_bounds__(256) void k_pack_iteration(PackIterArgs a) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < kSdfPackSlots) {
+        if (a.sW0f) sdf_pack2_slot(idx, a.W0, a.ld0, a.b0, a.W1, a.b1, a.W2, a.b2, a.d_out, a.sW0f, a.sW1f, a.sW2f, a.sbias, kAct);
+        return;
+    }
+    idx -= kSdfPackSlots;
+    if (idx < kTrunkPackSlots) {
+        if (a.W0f) trunk_pack_all_slot(idx, a.W0, a.ld0, a.f_in, a.b0, a.W1, a.b1, a.W2, a.b2, a.d_out, a.W0f, a.W1f, a.W2f, a.bias, a.W1Tf, a.W0Tf, a.W2Tf, a.W2tab,
+                                       a.w1t, a.w2t, a.w0t);
+        return;
+    }
+    idx -= kTrunkPackSlots;
+    if (!a.stream) return;
+    if (idx < kPackSlots) pack_slot(idx, a.Wc0, a.Wc1, a.Wr0, a.ldr0, a.Wr1, a.Wr2, a.bc0, a.bc1, a.br0, a.br1, a.br2, a.stream, a.R2f, a.abias);
+    else if (a.streamT != nullptr) pack_t_slot(idx - kPackSlots, a.Wc0, a.Wc1, a.Wr0, a.ldr0, a.Wr1, a.Wr2, a.streamT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- helpers
@@ -710,6 +746,36 @@ int hs_appearance2_pack(const float *Wc0, const float *Wc1, const float *Wr0, in
     const int slots = kPackSlots + (streamT_image ? kStreamTBytes / 16 : 0);
     k_appear2_pack<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(Wc0, Wc1, Wr0, ldr0, Wr1, Wr2, bc0, bc1, br0, br1, br2, (uint16_t *)stream_image,
                                                                        (uint16_t *)R2f, bias, (uint16_t *)streamT_image);
+    return wt_check_launch();
+}
+
+int hs_pack_iteration(const float *W0, int32_t ld0, int32_t f_in, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
+                      int32_t d_out, void *sW0f, void *sW1f, void *sW2f, float *sbias, void *W0f, void *W1f, void *W2f, float *bias, void *W1Tf, void *W0Tf,
+                      void *W2Tf, float *W2tab, void *w1t, void *w2t, void *w0t, const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0,
+                      const float *Wr1, const float *Wr2, const float *bc0, const float *bc1, const float *br0, const float *br1, const float *br2,
+                      void *stream_image, void *R2f, float *abias, void *streamT_image, void *stream) {
+    const bool trunk = sW0f || W0f, colour = stream_image != nullptr;
+    if (!trunk && !colour) return HS_OK;
+    if (trunk) {
+        if (d_out < 1 || d_out > 32 || ld0 < 71) return HS_ERR_ARG;
+        if (!W0 || !b0 || !W1 || !b1 || !W2 || !b2) return HS_ERR_NULL;
+        if (sW0f && (!sW1f || !sW2f || !sbias)) return HS_ERR_NULL;
+        if (W0f && (!W1f || !W2f || !bias || !W1Tf || !W0Tf || !W2Tf || !W2tab)) return HS_ERR_NULL;
+        if (w1t && (!W0f || !w2t || !w0t)) return HS_ERR_NULL;
+    }
+    if (colour) {
+        if (ldr0 < 337) return HS_ERR_ARG;
+        if (!Wc0 || !Wc1 || !Wr0 || !Wr1 || !Wr2 || !bc0 || !bc1 || !br0 || !br1 || !br2 || !R2f || !abias) return HS_ERR_NULL;
+    }
+    PackIterArgs a;
+    a.W0 = W0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ld0 = ld0; a.f_in = f_in; a.d_out = d_out;
+    a.sW0f = (uint16_t *)sW0f; a.sW1f = (uint16_t *)sW1f; a.sW2f = (uint16_t *)sW2f; a.sbias = sbias;
+    a.W0f = (uint16_t *)W0f; a.W1f = (uint16_t *)W1f; a.W2f = (uint16_t *)W2f; a.bias = bias;
+    a.W1Tf = (uint16_t *)W1Tf; a.W0Tf = (uint16_t *)W0Tf; a.W2Tf = (uint16_t *)W2Tf; a.W2tab = W2tab;
+    a.w1t = (uint16_t *)w1t; a.w2t = (uint16_t *)w2t; a.w0t = (uint16_t *)w0t;
+    a.Wc0 = Wc0; a.Wc1 = Wc1; a.Wr0 = Wr0; a.Wr1 = Wr1; a.Wr2 = Wr2; a.bc0 = bc0; a.bc1 = bc1; a.br0 = br0; a.br1 = br1; a.br2 = br2; a.ldr0 = ldr0;
+    a.stream = (uint16_t *)stream_image; a.R2f = (uint16_t *)R2f; a.abias = abias; a.streamT = (uint16_t *)streamT_image;
+    k_pack_iteration<<<(kIterPackSlots + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
     return wt_check_launch();
 }
 

@@ -14,44 +14,96 @@ namespace {
 
 struct AsmJobs { hsAsmJob j[HS_ASM_MAX_JOBS]; };
 
-// A job with a long reduction (a term with red >= 16: column sums over per-workgroup partials) gives every element a whole WAVE -- lane l
-// adds blocks l, l + 64, ..., the lanes meet by shuffles -- instead of one thread walking hundreds of dependent-latency loads (30 us for
-// 32 sums over 512 blocks); the other jobs keep one thread per element.
+__device__ __forceinline__ float bf16_at(const void *p, int64_t i) { return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(p)[i] << 16); }
+__device__ __forceinline__ float term_at(const hsAsmTerm &tm, int64_t i) { return tm.src_bf16 ? bf16_at(tm.src, i) : tm.src[i]; }
+
+// Two forms per job, chosen from its longest reduction:
+//   * GROUPED (red < 256 everywhere: the split-M partial stacks of the weight-gradient kernels, 6-130 slices): a workgroup = 32 units x 8
+//     slice groups; group y adds blocks y, y + 8, ... of its unit, the eight partial sums meet in LDS (appearance_mlp.hip: k_sum_slices'
+//     scheme -- one thread walking 128 slices is 128 dependent-latency loads).  A unit is a QUAD of four consecutive destination columns
+//     read with one 8- or 16-byte load per block when every term allows it (no column map, everything a multiple of four), else one element.
+//   * WIDE (a term with red >= 256: column sums over per-workgroup partials): a whole WAVE per element -- lane l adds blocks l, l + 64, ...,
+//     eight loads in flight, the lanes meet by shuffles (a plain loop is one dependent-latency load at a time: 22 us for 3 136 blocks).
 __global__ __launch_bounds__(256) void k_assemble(AsmJobs jobs) {
+    __shared__ float4 part[8][32];
     const hsAsmJob &jb = jobs.j[blockIdx.y];
     const int64_t total = (int64_t)jb.rows * jb.cols;
-    bool wide = false;
-    for (int t = 0; t < jb.n_terms; t++) wide = wide || jb.term[t].red >= 16;
-    const int lane = threadIdx.x & 63;
-    const int64_t first = wide ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * (wide ? 4 : 256);
-    for (int64_t i = first; i < total; i += step) {
-        const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
-        float v = 0.f;
-        for (int t = 0; t < jb.n_terms; t++) {
-            const hsAsmTerm &tm = jb.term[t];
-            const float *p = tm.src + (int64_t)r * tm.ld + (tm.col_map ? tm.col_map[c] : tm.col0 + c);
-            float s = 0.f;
-            if (wide) {       // eight independent loads in flight per lane (a plain loop is one dependent-latency load at a time: 22 us for 3 136 blocks)
+    bool wide = false, quads = (jb.cols & 3) == 0;
+    const bool dst_vec = (jb.dst_ld & 3) == 0 && (((uintptr_t)jb.dst) & 15) == 0;        // (a column window may start anywhere: scalar stores then)
+    for (int t = 0; t < jb.n_terms; t++) {
+        const hsAsmTerm &tm = jb.term[t];
+        wide = wide || tm.red >= 256;
+        quads = quads && !tm.col_map && (tm.col0 & 3) == 0 && (tm.ld & 3) == 0 && (tm.red_stride & 3) == 0 && (((uintptr_t)tm.src) & 15) == 0;
+    }
+    if (wide) {
+        const int lane = threadIdx.x & 63;
+        for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (int64_t)gridDim.x * 4) {
+            const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
+            float v = 0.f;
+            for (int t = 0; t < jb.n_terms; t++) {
+                const hsAsmTerm &tm = jb.term[t];
+                const int64_t at = (int64_t)r * tm.ld + (tm.col_map ? tm.col_map[c] : tm.col0 + c);
                 float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 int k = lane;
                 for (; k + 7 * 64 < tm.red; k += 8 * 64) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) s8[u] += p[(int64_t)(k + 64 * u) * tm.red_stride];
+                    for (int u = 0; u < 8; u++) s8[u] += term_at(tm, at + (int64_t)(k + 64 * u) * tm.red_stride);
                 }
-                for (; k < tm.red; k += 64) s8[0] += p[(int64_t)k * tm.red_stride];
-                s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-            } else {
-                for (int k = 0; k < tm.red; k++) s += p[(int64_t)k * tm.red_stride];
+                for (; k < tm.red; k += 64) s8[0] += term_at(tm, at + (int64_t)k * tm.red_stride);
+                v += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
             }
-            v += s;
-        }
-        if (wide) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane != 0) continue;
+            if (lane == 0) jb.dst[(int64_t)r * jb.dst_ld + c] = v;
         }
-        jb.dst[(int64_t)r * jb.dst_ld + c] = v;
+        return;
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t units = quads ? total >> 2 : total;
+    for (int64_t u0 = (int64_t)blockIdx.x * 32; u0 < units; u0 += (int64_t)gridDim.x * 32) {     // (workgroup-uniform bound: the barriers below are safe)
+        const int64_t u = u0 + tx;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int r = 0, c = 0;
+        if (u < units) {
+            const int64_t e = quads ? u << 2 : u;
+            r = (int)(e / jb.cols);
+            c = (int)(e - (int64_t)r * jb.cols);
+            for (int t = 0; t < jb.n_terms; t++) {
+                const hsAsmTerm &tm = jb.term[t];
+                const int64_t at = (int64_t)r * tm.ld + (tm.col_map ? tm.col_map[c] : tm.col0 + c);
+                if (quads) {
+                    if (tm.src_bf16) {
+#pragma unroll 4
+                        for (int k = ty; k < tm.red; k += 8) {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(tm.src) + at + (int64_t)k * tm.red_stride);
+                            a.x += __uint_as_float(v.x << 16); a.y += __uint_as_float(v.x & 0xffff0000u);
+                            a.z += __uint_as_float(v.y << 16); a.w += __uint_as_float(v.y & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll 4
+                        for (int k = ty; k < tm.red; k += 8) {
+                            const float4 v = *reinterpret_cast<const float4 *>(tm.src + at + (int64_t)k * tm.red_stride);
+                            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int k = ty; k < tm.red; k += 8) a.x += term_at(tm, at + (int64_t)k * tm.red_stride);
+                }
+            }
+        }
+        part[ty][tx] = a;
+        __syncthreads();
+        if (ty == 0 && u < units) {
+            float4 s4 = part[0][tx];
+#pragma unroll
+            for (int y = 1; y < 8; y++) { const float4 v = part[y][tx]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+            float *dst = jb.dst + (int64_t)r * jb.dst_ld + c;
+            if (quads && dst_vec) *reinterpret_cast<float4 *>(dst) = s4;
+            else if (quads) { dst[0] = s4.x; dst[1] = s4.y; dst[2] = s4.z; dst[3] = s4.w; }
+            else *dst = s4.x;
+        }
+        __syncthreads();
     }
 }
 
@@ -78,18 +130,18 @@ int hs_assemble(const hsAsmJob *jobs, int32_t n_jobs, void *stream) {
         const hsAsmJob &j = jobs[i];
         if (j.rows < 1 || j.cols < 1 || j.n_terms < 1 || j.n_terms > HS_ASM_MAX_TERMS || j.dst_ld < j.cols) return HS_ERR_ARG;
         if (!j.dst) return HS_ERR_NULL;
+        bool wide = false;
         for (int t = 0; t < j.n_terms; t++) {
             if (!j.term[t].src) return HS_ERR_NULL;
             if (j.term[t].red < 1) return HS_ERR_ARG;
+            wide = wide || j.term[t].red >= 256;
         }
         aj.j[i] = j;
-        int64_t n = (int64_t)j.rows * j.cols;
-        for (int t = 0; t < j.n_terms; t++)
-            if (j.term[t].red >= 16) { n *= 64; break; }       // a wave per element (k_assemble)
-        most = n > most ? n : most;
+        const int64_t n = (int64_t)j.rows * j.cols;
+        const int64_t blocks = wide ? (n + 3) / 4 : (n + 31) / 32;      // a wave per element / 32 units per workgroup (quads: a quarter of that is enough)
+        most = blocks > most ? blocks : most;
     }
-    const int64_t want = (most + 255) / 256;
-    k_assemble<<<dim3((unsigned)(want < 256 ? want : 256), n_jobs), 256, 0, (hipStream_t)stream>>>(aj);
+    k_assemble<<<dim3((unsigned)(most < 1024 ? most : 1024), n_jobs), 256, 0, (hipStream_t)stream>>>(aj);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
 }
 

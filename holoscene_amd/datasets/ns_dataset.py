@@ -107,8 +107,8 @@ class ResidentNSDataset:
         return self.get(frame, idx[:n])
 
     def write_batch(self, dst_input, dst_gt):
-        """The next batch gathered straight into existing buffers (the training graph's static input block): one launch for the draw,
-        one for the gather."""
+        """The next batch gathered straight into existing buffers (the training graph's static input block): one launch for the draw
+        and the gather together."""
         from ..hashencoder import backend as _be
         frame = self.pick_frame()
         n = self._sampler.count(frame)
@@ -116,7 +116,7 @@ class ResidentNSDataset:
             self._sampler.skip()
             raise RuntimeError(f"batch of {n} rays (a class of frame {frame} has fewer pixels than its quota, ns_dataset.py:422-427) "
                                f"does not fit the static block of {dst_input['uv'].shape[1]}: use next_batch() / the eager path for such scenes")
-        idx, _ = self._sampler.draw(frame)
+        idx = self._sampler.idx
         # the launch plan holds pointers only: the index tensor is static (its CONTENT is redrawn), the image sources depend on the frame
         key = (frame, dst_input["uv"].data_ptr())
         plan = self._plans.get(key)
@@ -126,4 +126,8 @@ class ResidentNSDataset:
                 (self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], fidx), (self.intrinsics_all, dst_input["intrinsics"], fidx),
                 (self.rgb[frame], dst_gt["rgb"], idx), (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx),
                 (self.mask[frame], dst_gt["mask"], idx), (self.segs[frame], dst_gt["segs"], idx)])
-        _be._backend.gather_rows(plan)
+        if self.device.type == "cuda":
+            self._sampler.draw(frame, gather=plan)      # pixel draw + row gather: one launch (csrc/batch_ops.hip: hs_draw_gather)
+        else:
+            self._sampler.draw(frame)
+            _be._backend.gather_rows(plan)

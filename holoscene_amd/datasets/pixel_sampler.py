@@ -78,9 +78,10 @@ class PixelSampler:
         """Advance the stream by one batch without drawing it (a batch the caller refuses keeps the sequence of the others)."""
         self._counter += 1
 
-    def draw(self, frame):
+    def draw(self, frame, gather=None):
         """The next batch of `frame` -> (static int64 index tensor, number of valid entries).  On CUDA the indices are written by one
-        launch on the current stream (the previous batch's readers are ahead of it in stream order)."""
+        launch on the current stream (the previous batch's readers are ahead of it in stream order); gather: a backend.gather_plan() whose
+        jobs are indexed by self.idx -- the rows of the batch are then gathered by the same launch (hs_draw_gather)."""
         if self.device.type != "cuda":
             idx = self.host_indices(frame)
             self.idx[:idx.numel()] = idx
@@ -89,10 +90,6 @@ class PixelSampler:
         ptr, pix, off, n = self._device_frames()[frame]
         n_cls, per_class, n_bg = self.quotas(frame)
         self._counter += 1
-        if max(n_bg, per_class, self.R - self.half) > _be.DRAW_MAX_WANT:
-            # a quota beyond the kernel's LDS hash set (num_pixels > 2 x HS_DRAW_MAX_WANT): the host rule + one copy, as on CPU
-            idx = self.host_indices(frame)
-            self.idx[:idx.numel()].copy_(idx, non_blocking=True)
-            return self.idx, int(idx.numel())
-        _be._backend.draw_pixels(ptr, pix, off, n_cls, per_class, n_bg, self.R - self.half, self.total, self._seed, self._counter, self.idx)
+        _be._backend.draw_pixels(ptr, pix, off, n_cls, per_class, n_bg, self.R - self.half, self.total, self._seed, self._counter, self.idx,
+                                 n_out=n, gather=gather)
         return self.idx, n

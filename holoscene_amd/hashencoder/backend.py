@@ -68,7 +68,7 @@ class hsWgradPairJob(ctypes.Structure):
 
 class hsAsmTerm(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("col_map", ctypes.c_void_p), ("ld", ctypes.c_int64), ("red_stride", ctypes.c_int64), ("col0", ctypes.c_int32),
-                ("red", ctypes.c_int32)]
+                ("red", ctypes.c_int32), ("src_bf16", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class hsAsmJob(ctypes.Structure):
@@ -80,7 +80,7 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
 # together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
@@ -148,7 +148,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -183,7 +183,6 @@ def _stream():
 SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
 # Scatter the hashed levels through per-bin record lists + an LDS reduction instead of global atomics (csrc/hash_encode.hip)
 SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
-DRAW_MAX_WANT = 4096     # include/holoscene_hip.h: HS_DRAW_MAX_WANT (largest per-class / uniform quota hs_draw_pixels takes)
 
 def accumulates_into_grad(table):
     """True for a hash table whose gradient lives in flat gradient storage (training/flat.py marks the parameter with
@@ -623,6 +622,41 @@ class _HipBackend:
         return outs
 
     @staticmethod
+    def iter_prologue(vs, gs, rng_pool=None, rng_state=None, beta=None, beta_min=None, adam=None):
+        """hs_iter_prologue: the weight-normalised matrices of (vs, gs), the pool of U[0, 1) draws, |beta| + beta_min and the optimiser tick in
+        one launch.  adam: None or (state uint8 tensor, beta1, beta2, gamma).  -> (Ws, beta_eff or None)"""
+        lib = load_library()
+        arr = (hsWnJob * max(len(vs), 1))()
+        outs = []
+        for a, v, g in zip(arr, vs, gs):
+            W = torch.empty_like(v)
+            a.v, a.g, a.W, a.rows, a.cols = _dev(v, "v").value, _dev(g, "g").value, _dev(W, "W").value, v.shape[0], v.shape[1]
+            outs.append(W)
+        beta_out = torch.empty_like(beta) if beta is not None else None
+        st, b1, b2, gamma = adam if adam is not None else (None, 0.0, 0.0, 1.0)
+        _check(lib.hs_iter_prologue(arr, len(vs), _dev(rng_pool, "rng_pool"), ctypes.c_int64(0 if rng_pool is None else rng_pool.numel()),
+                                    _dev(rng_state, "rng_state", torch.int64), _dev(beta, "beta"), _dev(beta_min, "beta_min"), _dev(beta_out, "beta_out"),
+                                    0 if beta is None else beta.numel(), _dev(st, "adam state", torch.uint8), ctypes.c_float(b1), ctypes.c_float(b2),
+                                    ctypes.c_double(gamma), _stream()), "hs_iter_prologue")
+        return outs, beta_out
+
+    @staticmethod
+    def iter_epilogue(vs, gs, gWs, outs, beta=None, g_beta_parts=(), g_beta_out=None):
+        """hs_iter_epilogue: weight-norm backward of every layer + beta's backward in one launch.  outs: [(gv, gg)] destinations (e.g. views of
+        the flat gradient buffer); g_beta_parts: up to four fp32 tensors of partial cotangents of |beta| + beta_min (all summed)."""
+        lib = load_library()
+        arr = (hsWnJob * max(len(vs), 1))()
+        for a, v, g, gW, (gv, gg) in zip(arr, vs, gs, gWs, outs):
+            a.v, a.g, a.gW = _dev(v, "v").value, _dev(g, "g").value, _dev(gW, "gW").value
+            a.gv, a.gg, a.rows, a.cols = _dev(gv, "gv").value, _dev(gg, "gg").value, v.shape[0], v.shape[1]
+        n_beta = 0 if beta is None else beta.numel()
+        parts = [t for t in g_beta_parts if t is not None and t.numel() > 0]
+        ptrs = (ctypes.c_void_p * max(len(parts), 1))(*[_dev(t, "g_beta part").value for t in parts])
+        lens = (ctypes.c_int32 * max(len(parts), 1))(*[t.numel() // max(n_beta, 1) for t in parts])
+        _check(lib.hs_iter_epilogue(arr, len(vs), _dev(beta, "beta"), ptrs, lens, len(parts), _dev(g_beta_out, "g_beta_out"), n_beta, _stream()),
+               "hs_iter_epilogue")
+
+    @staticmethod
     def gather_plan(jobs):
         """jobs: list of (src [rows, ...], dst [n, ...], idx int64 [n]) device tensors -> a reusable launch description of
         dst[i] = src[idx[i]] for all of them (hs_gather_rows).  The plan keeps the tensors alive; run it with gather_rows(plan)."""
@@ -644,14 +678,19 @@ class _HipBackend:
         _check(lib.hs_gather_rows(plan[0], plan[1], _stream()), "hs_gather_rows")
 
     @staticmethod
-    def draw_pixels(class_ptr, class_pix, out_off, n_cls, per_class, n_bg, n_uniform, total_pixels, seed, counter, out):
+    def draw_pixels(class_ptr, class_pix, out_off, n_cls, per_class, n_bg, n_uniform, total_pixels, seed, counter, out, n_out=None, gather=None):
         """One batch's pixel indices (hs_draw_pixels; include/holoscene_hip.h): class_ptr / class_pix / out_off int32 device tensors, out
-        int64 [R]."""
+        int64 [>= n_out].  gather: a gather_plan() whose jobs indexed by `out` are served in the same launch (hs_draw_gather)."""
         lib = load_library()
         i32 = torch.int32
-        _check(lib.hs_draw_pixels(_dev(class_ptr, "class_ptr", i32), _dev(class_pix, "class_pix", i32), _dev(out_off, "out_off", i32), int(n_cls),
-                                  int(per_class), int(n_bg), int(n_uniform), int(total_pixels), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
-                                  ctypes.c_uint64(int(counter)), _dev(out, "out", torch.int64), _stream()), "hs_draw_pixels")
+        n_out = int(out.numel() if n_out is None else n_out)
+        args = (_dev(class_ptr, "class_ptr", i32), _dev(class_pix, "class_pix", i32), _dev(out_off, "out_off", i32), int(n_cls), int(per_class),
+                int(n_bg), int(n_uniform), int(total_pixels), n_out, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_uint64(int(counter)),
+                _dev(out, "out", torch.int64))
+        if gather is None:
+            _check(lib.hs_draw_pixels(*args, _stream()), "hs_draw_pixels")
+        else:
+            _check(lib.hs_draw_gather(*args, gather[0], gather[1], _stream()), "hs_draw_gather")
 
     # ---- reverse-over-reverse trunk of the rendered samples (csrc/trunk_rr.hip, csrc/wgrad_pairs.hip)
     @staticmethod
@@ -706,6 +745,60 @@ class _HipBackend:
                                      *[_dev(t, "frag", bf) for t in rr[:3]], _dev(rr[3], "W2tab"),
                                      *([_dev(t, "transpose", bf) for t in tr] if tr else [None, None, None]), _stream()), "hs_trunk_pack_all")
         return packed, rr, tr
+
+    @staticmethod
+    def pack_iteration(trunk=None, colour=None):
+        """Every weight image of a Stage-1 iteration in one launch (hs_pack_iteration).
+        trunk: None or (W0, b0, W1, b1, W2, b2, d_out, sampler, training, transposes) -- fp32 effective matrices; the three flags say which
+        image families to build; colour: None or ((Wc0, Wc1, Wr0, Wr1, Wr2), (bc0, bc1, br0, br1, br2), transposed).
+        -> {"sdf": sdf_mlp2_pack's tuple | None, "trunk": trunk_pack_all's (packed, rr, tr) | None, "appear": appearance2_pack's dict | None}"""
+        lib = load_library()
+        for fn in (lib.hs_sdf_mlp2_pack_bytes, lib.hs_trunk_rr_pack_bytes, lib.hs_appearance2_pack_bytes, lib.hs_appearance2_pack_t_bytes):
+            fn.restype = ctypes.c_int64
+        bf, u8 = torch.bfloat16, torch.uint8
+        out = {"sdf": None, "trunk": None, "appear": None}
+        targs = [None, 0, 0, None, None, None, None, None, 0] + [None] * 15
+        keep = []
+        if trunk is not None:
+            W0, b0, W1, b1, W2, b2, d_out, sampler, training, transposes = trunk
+            dev = W0.device
+            if W0.stride(1) != 1 or W0.stride(0) < 71:
+                raise RuntimeError("pack_iteration: W0 must be row-major with at least 71 columns")
+            n = [int(lib.hs_sdf_mlp2_pack_bytes(i)) // 2 for i in range(3)]
+            nb = int(lib.hs_sdf_mlp2_pack_bytes(3)) // 4
+
+            def frag_set():
+                w12 = torch.empty(n[1] + n[2], device=dev, dtype=bf)      # W2f directly behind W1f: the kernels copy both in one sweep
+                return (torch.empty(n[0], device=dev, dtype=bf), w12[:n[1]], w12[n[1]:], torch.empty(nb, device=dev))
+
+            sp = frag_set() if sampler else (None,) * 4
+            packed = rr = tr = None
+            if training:
+                packed = frag_set()
+                m = [int(lib.hs_trunk_rr_pack_bytes(i)) for i in range(4)]
+                rr = tuple(torch.empty(m[i] // 2, device=dev, dtype=bf) for i in range(3)) + (torch.empty(m[3] // 4, device=dev),)
+                if transposes:
+                    tr = (torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 32, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf))
+            pk, r_, t_ = packed or (None,) * 4, rr or (None,) * 4, tr or (None,) * 3
+            targs = [_dev(W0, "W0"), int(W0.stride(0)), int(W0.shape[1]), _dev(b0, "b0"), _dev(W1, "W1"), _dev(b1, "b1"), _dev(W2, "W2"), _dev(b2, "b2"), int(d_out),
+                     *[_dev(t, "frag", bf) for t in sp[:3]], _dev(sp[3], "bias"), *[_dev(t, "frag", bf) for t in pk[:3]], _dev(pk[3], "bias"),
+                     *[_dev(t, "frag", bf) for t in r_[:3]], _dev(r_[3], "W2tab"), *[_dev(t, "transpose", bf) for t in t_]]
+            out["sdf"] = sp if sampler else None
+            out["trunk"] = (packed, rr, tr) if training else None
+        cargs = [None, None, None, 337] + [None] * 11
+        if colour is not None:
+            mats, biases, transposed = colour
+            dev = mats[0].device
+            nbs = [int(lib.hs_appearance2_pack_bytes(i)) for i in range(3)]
+            P = {"stream": torch.empty(nbs[0], device=dev, dtype=u8), "R2f": torch.empty(nbs[1], device=dev, dtype=u8), "bias": torch.empty(nbs[2] // 4, device=dev),
+                 "streamT": torch.empty(int(lib.hs_appearance2_pack_t_bytes()), device=dev, dtype=u8) if transposed else None}
+            keep = [t.detach().float().contiguous() for t in tuple(mats) + tuple(biases)]
+            cargs = [*[_dev(t, "w") for t in keep[:2]], _dev(keep[2], "wr0"), keep[2].shape[1], _dev(keep[3], "wr1"), _dev(keep[4], "wr2"),
+                     *[_dev(t, "b") for t in keep[5:]], _dev(P["stream"], "stream", u8), _dev(P["R2f"], "R2f", u8), _dev(P["bias"], "bias"),
+                     _dev(P["streamT"], "streamT", u8)]
+            out["appear"] = P
+        _check(lib.hs_pack_iteration(*targs, *cargs, _stream()), "hs_pack_iteration")
+        return out
 
     @staticmethod
     def trunk_rr_fwd_value(x, feat, packed, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot):
@@ -799,19 +892,25 @@ class _HipBackend:
 
     @staticmethod
     def assemble(jobs):
-        """jobs: [((rows, cols), [term, ...])] with term = (src fp32 tensor, ld, col0 or int32 column-map tensor[, red, red_stride]) ->
+        """jobs: [((rows, cols), [term, ...])] with term = (src fp32 or bf16 tensor, ld, col0 or int32 column-map tensor[, red, red_stride]) ->
         fp32 tensors [rows, cols] = the sums of the terms (a job may name its destination: ((rows, cols), terms, (matrix, col0)) writes that
         column window of an existing fp32 matrix and returns the matrix), all in one launch
-        (hs_assemble, csrc/small_ops.hip).  The element (r, c) of a term is src.flat[r * ld + col(c) (+ k * red_stride, summed over k < red)]."""
+        (hs_assemble, csrc/small_ops.hip).  The element (r, c) of a term is src.flat[r * ld + col(c) (+ k * red_stride, summed over k < red)];
+        a bf16 source is a stack of split-M weight-gradient partials [red, rows, ld]: its slice sum happens here too."""
         lib = load_library()
         outs, keep = [], []
-        for k0 in range(0, len(jobs), 8):
-            grp = jobs[k0:k0 + 8]
+        for k0 in range(0, len(jobs), 12):
+            grp = jobs[k0:k0 + 12]
             arr = (hsAsmJob * len(grp))()
             for a, job in zip(arr, grp):
                 (rows, cols), terms = job[:2]
                 dev = terms[0][0].device
-                if len(job) > 2:        # (tensor [rows, >= col0 + cols] fp32 contiguous, col0): a column window of an existing matrix
+                if len(job) > 2 and job[2][1] is None:      # (fp32 contiguous tensor of rows * cols elements, None): the whole result goes there
+                    out = job[2][0]
+                    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != rows * cols or not out.is_cuda:
+                        raise RuntimeError("assemble: destination tensor must hold rows * cols contiguous fp32 values")
+                    a.dst, a.dst_ld = out.data_ptr(), cols
+                elif len(job) > 2:        # (tensor [rows, >= col0 + cols] fp32 contiguous, col0): a column window of an existing matrix
                     out, c0 = job[2]
                     if out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 2 or out.shape[0] != rows or c0 + cols > out.shape[1]:
                         raise RuntimeError("assemble: destination window outside its matrix")
@@ -822,7 +921,7 @@ class _HipBackend:
                 a.rows, a.cols, a.n_terms = rows, cols, len(terms)
                 for t, term in zip(a.term, terms):
                     src, ld, col = term[:3]
-                    t.src, t.ld = _dev(src, "assemble source").value, int(ld)
+                    t.src, t.ld, t.src_bf16 = _dev(src, "assemble source", src.dtype if src.dtype == torch.bfloat16 else torch.float32).value, int(ld), int(src.dtype == torch.bfloat16)
                     if torch.is_tensor(col):
                         t.col_map, t.col0 = _dev(col, "column map", torch.int32).value, 0
                         keep.append(col)

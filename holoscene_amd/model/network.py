@@ -527,8 +527,12 @@ class _trunk_render_rr(torch.autograd.Function):
         jac = 0.5 / divide_factor
         f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
         # every weight image of this pass -- fragment images, their transposes, the Eikonal points' row-major transposes -- in one launch
-        packed, rr, trans = be.trunk_pack_all(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2,
-                                              b2.detach().float().contiguous(), K, transposes=Be > 0)
+        ip = _ITER_PACKS
+        if ip is not None and ip["trunk"] is not None and ip["trunk_key"] == (id(W0), id(W1), id(W2)) and (Be == 0 or ip["trunk"][2] is not None):
+            packed, rr, trans = ip["trunk"]       # packed at the top of the iteration, together with every other image (hs_pack_iteration)
+        else:
+            packed, rr, trans = be.trunk_pack_all(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2,
+                                                  b2.detach().float().contiguous(), K, transposes=Be > 0)
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
@@ -553,6 +557,7 @@ class _trunk_render_rr(torch.autograd.Function):
             _be.expect_scatter(ctx.table)
         ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik)
         ctx.cfg = (B, n, L, C, K, S, Hres, jac, W0.shape[1])
+        ctx.bias_dst = [flat_grad_view(b) for b in (b0, b1, b2)]     # bias gradients go straight into the flat gradient buffer when there is one
         ctx.mark_non_differentiable(idx)
         return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
 
@@ -635,16 +640,19 @@ class _trunk_render_rr(torch.autograd.Function):
                 gb1, gb0, gb2 = gbz[:256] + sums[3], gbz[256:512] + sums[4], gbz[512:512 + K] + gb2_part.sum(0)[:K]
                 gW0 = gW0p.index_select(1, _xp_columns(dev))
                 gW2 = gW2p[:K]
-            else:   # the column selection of dW0, dW2 of both point families, the three bias gradients: one launch (csrc/small_ops.hip)
-                sums = be.sum_slices([st1, st0, st2, csb1, csb0] + ([w2_part] if eik_live else []))
-                gW1 = sums[0]
-                gW0, gW2, gb1, gb0, gb2 = be.assemble([
-                    ((256, F_in), [(sums[1], 128, _xp_columns32(dev))]),
-                    ((K, 256), [(sums[2], 256, 0)] + ([(sums[5], 256, 0)] if eik_live else [])),
-                    ((256, 1), [(gbz, 1, 0), (sums[3], 1, 0)]),
-                    ((256, 1), [(gbz, 1, 256), (sums[4], 1, 0)]),
-                    ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
-                gb1, gb0, gb2 = gb1.view(-1), gb0.view(-1), gb2.view(-1)
+            else:
+                # the slice sums of every partial stack, the column selection of dW0 / dW2 of both point families and the three bias gradients
+                # (into the flat gradient buffer's views when the biases have them): ONE launch (csrc/small_ops.hip: hs_assemble on bf16 stacks)
+                d0, d1, d2 = ctx.bias_dst
+                dst = lambda d, shape: () if d is None or d.numel() != shape[0] * shape[1] else ((d, None),)  # noqa: E731
+                gW1, gW0, gW2, gb1, gb0, gb2 = be.assemble([
+                    ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
+                    ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
+                    ((K, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + ([(w2_part, 256, 0, w2_part.shape[0], 32 * 256)] if eik_live else [])),
+                    ((1, 256), [(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]) + dst(d1, (1, 256)),
+                    ((1, 256), [(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]) + dst(d0, (1, 256)),
+                    ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)]) + dst(d2, (1, K))])
+                gb1, gb0, gb2 = gb1.view(-1)[...], gb0.view(-1)[...], gb2.view(-1)[...]
         g_emb = None
         if need_table:      # one value+Jacobian scatter for all B points
             table = ctx.table
@@ -952,7 +960,11 @@ class _fused_appearance_wave(torch.autograd.Function):
             be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
         mats = (Wc0, Wc1, Wr0, Wr1, Wr2)
         need_bwd = any(ctx.needs_input_grad)
-        P = be.appearance2_pack(*mats, (bc0, bc1, br0, br1, br2), transposed=need_bwd)
+        ip = _ITER_PACKS
+        if ip is not None and ip["appear"] is not None and ip["appear_key"] == tuple(id(t) for t in mats) and (not need_bwd or ip["appear"]["streamT"] is not None):
+            P = ip["appear"]
+        else:
+            P = be.appearance2_pack(*mats, (bc0, bc1, br0, br1, br2), transposed=need_bwd)
         sT = P["streamT"]
         tiles = (B + 31) // 32
         tp = lambda ks: torch.empty(tiles * ks * 512, device=dev, dtype=bf)  # noqa: E731
@@ -963,6 +975,7 @@ class _fused_appearance_wave(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT)
         ctx.cfg = (B, C, L, S, Hres, Wr0.shape[1])
+        ctx.direct_dst = [flat_grad_view(t) for t in (Wc0, bc0, Wc1, bc1, br0, br1, br2)]      # plain parameters of this Function: gradients in place
         return rgb
 
     @staticmethod
@@ -1167,6 +1180,11 @@ class _composite(torch.autograd.Function):
         ctx.save_for_backward(z, sdf, raw, rgb, g, beta1, depth_scale)
         ctx.sem_scale = float(sem_scale)
         ctx.beta_shape = beta.shape
+        # inside iteration_prologue(): the per-ray partials d / d beta go to its relay (summed by hs_iter_epilogue), not through a sum launch
+        ctx.relay = None
+        if _BETA_RELAY is not None and _BETA_RELAY["key"] is beta and _BETA_RELAY["users"] < 3 and beta.requires_grad:
+            ctx.relay = _BETA_RELAY
+            _BETA_RELAY["users"] += 1
         ctx.mark_non_differentiable(trans)
         return weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out
 
@@ -1181,6 +1199,9 @@ class _composite(torch.autograd.Function):
         d_beta = torch.empty(z.shape[0], device=z.device) if ctx.needs_input_grad[5] else None   # per-ray partials
         _be._backend.composite_bwd(z, sdf, raw, rgb, g, beta1, depth_scale, ctx.sem_scale, c(g_w), c(g_rgb), c(g_depth), c(g_normal), c(g_sem),
                                    c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta, rot=ctx.rot)
+        if d_beta is not None and ctx.relay is not None:
+            ctx.relay["parts"].append(d_beta)
+            d_beta = None
         return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None, None
 
 
@@ -1252,6 +1273,104 @@ def shared_effective_weights(lins):
         yield
     finally:
         _SHARED_W = None
+
+
+# ---- the head and the tail of a training iteration as one launch each (csrc/iter_ops.hip)
+_ITER_PACKS = None      # armed by iteration_prologue(): every packed weight image of the iteration from ONE launch (hs_pack_iteration), keyed by the
+                        # identity of the effective matrices they were packed from -- the pack sites below take theirs from here when the keys match
+_BETA_RELAY = None      # armed by iteration_prologue(): {"key": beta_eff, "parts": [...]} -- _composite.backward leaves its per-ray partial
+                        # derivatives w.r.t. beta there instead of launching a sum; _iter_prologue.backward adds them up inside its one launch
+
+
+def flat_grad_view(p):
+    """The view of the flat gradient buffer that belongs to parameter p (training/flat.py), or None."""
+    v = getattr(p, "_hs_flat_view", None)
+    return v if v is not None and v.is_cuda else None
+
+
+class _iter_prologue(torch.autograd.Function):
+    """(beta, v0, g0, v1, g1, ...) -> (|beta| + beta_min, W0, W1, ...) and, on the side, the iteration's pool of U[0, 1) draws and the
+    optimiser tick: hs_iter_prologue.  Backward: hs_iter_epilogue -- every weight-norm backward, beta's backward and the sum of the
+    compositing kernels' per-ray partials in one launch, written straight into the flat gradient buffer's views when the parameters
+    have them (flat_grad_view): no multi-tensor copy afterwards."""
+
+    @staticmethod
+    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, *vg):
+        ctx.set_materialize_grads(False)
+        vs = [t.detach().float().contiguous() for t in vg[0::2]]
+        gs = [t.detach().float().contiguous() for t in vg[1::2]]
+        b = beta.detach().float().reshape(-1).contiguous()
+        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam)
+        ctx.save_for_backward(b, *vs, *gs)
+        ctx.n, ctx.relay, ctx.beta_shape = len(vs), relay, beta.shape
+        ctx.dsts = [flat_grad_view(t) for t in (beta,) + tuple(vg)]
+        return (beta_eff.view(beta.shape),) + tuple(Ws)
+
+    @staticmethod
+    def backward(ctx, g_beta, *gWs):
+        b = ctx.saved_tensors[0]
+        vs, gs = ctx.saved_tensors[1:1 + ctx.n], ctx.saved_tensors[1 + ctx.n:]
+        gWs = [torch.zeros_like(v) if gW is None else gW.contiguous().float() for v, gW in zip(vs, gWs)]
+        dst = ctx.dsts
+        fresh = lambda d, like: torch.empty_like(like) if d is None else d.view_as(like)[...]  # noqa: E731   (a NEW tensor object on the flat view: autograd may adopt it as .grad)
+        outs = [(fresh(dst[1 + 2 * i], v), fresh(dst[2 + 2 * i], g)) for i, (v, g) in enumerate(zip(vs, gs))]
+        parts = list(ctx.relay["parts"]) if ctx.relay is not None else []
+        if ctx.relay is not None:
+            ctx.relay["parts"].clear()
+        if g_beta is not None:
+            parts.append(g_beta.detach().float().reshape(-1).contiguous())
+        gb = None
+        if ctx.needs_input_grad[0] and parts:
+            gb = fresh(dst[0], b)
+            _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs, b, parts, gb)
+            gb = gb.view(ctx.beta_shape)
+        else:
+            _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs)
+        return (gb, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
+
+
+@contextlib.contextmanager
+def iteration_prologue(model, flat=None, rng_sizes=None):
+    """One launch for everything a Stage-1 iteration needs before its first ray: within the block model.density.get_beta() and
+    effective_weights() return the tensors evaluated here (as under density.shared_beta() + shared_effective_weights()), `flat`'s Adam
+    state is ticked (training/flat.py: FlatAdam -- its step() then skips the tick launch), and the block yields the `rng` dictionary of
+    model.draw_uniforms (views of one pool of U[0, 1) draws from the model's own device-resident Philox stream).  Enter with grad enabled."""
+    global _SHARED_W, _BETA_RELAY
+    lins = [l for l in model.weight_norm_layers() if isinstance(l, WNLinear) and l.weight_v.is_cuda]
+    dens = model.density
+    dev = dens.beta.device
+    if not lins or dev.type != "cuda" or dens.beta.dtype != torch.float32:
+        with dens.shared_beta(), shared_effective_weights(model.weight_norm_layers()):
+            yield None
+        return
+    pool = rng = None
+    if rng_sizes is not None:
+        total = sum(int(np.prod(v)) for v in rng_sizes.values())
+        pool = torch.empty(total, device=dev)
+    adam = None
+    if flat is not None and not flat._ticked:
+        adam = (flat.state, flat.betas[0], flat.betas[1], flat.gamma)
+    relay = {"key": None, "parts": [], "users": 0}
+    outs = _iter_prologue.apply(dens.beta, dens.beta_min, pool, model.rng_state(dev) if pool is not None else None, adam, relay,
+                                *[t for l in lins for t in (l.weight_v, l.weight_g)])
+    if adam is not None:
+        flat._ticked = True
+    beta_eff, Ws = outs[0], outs[1:]
+    relay["key"] = beta_eff
+    if pool is not None:
+        rng, off = {}, 0
+        for k, shp in rng_sizes.items():
+            n = int(np.prod(shp))
+            rng[k] = pool[off:off + n].view(shp)
+            off += n
+    global _ITER_PACKS
+    prev_w, prev_relay, prev_beta, prev_packs = _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS
+    _SHARED_W, _BETA_RELAY, dens._shared = {id(l): W for l, W in zip(lins, Ws)}, relay, beta_eff
+    _ITER_PACKS = model._pack_iteration()
+    try:
+        yield rng
+    finally:
+        _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS = prev_w, prev_relay, prev_beta, prev_packs
 
 
 def effective_weights(lins):
@@ -1460,6 +1579,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         """Fragment-order images for the wave-tile kernel (csrc/sdf_mlp2.hip), one pack launch per parameter state."""
         if getattr(self, "_packed_cache2", None) is not None:
             return self._packed_cache2
+        if _ITER_PACKS is not None and _ITER_PACKS.get("net") == id(self) and _ITER_PACKS["sdf"] is not None:
+            return _ITER_PACKS["sdf"]            # (not cached on the module: valid inside this iteration_prologue() only)
         l0, l1, l2 = self._lins()
         with torch.no_grad():
             f0, f1, f2 = effective_weights([l0, l1, l2])
@@ -2076,15 +2197,55 @@ class HoloSceneNetwork(nn.Module):
         return list(self.implicit_network._lins()) + [l for l in (getattr(rn, "lin0", None), getattr(rn, "lin1", None), getattr(rn, "lin2", None))
                                                        if l is not None]
 
+    def _pack_iteration(self):
+        """Inside iteration_prologue(): the fragment images of this iteration's weights for the sampler sweeps, the training trunk and the
+        colour branch from one launch -- None when the model does not run on the fused bf16 kernels (the pack sites then pack for themselves)."""
+        net, rn = self.implicit_network, self.rendering_network
+        probe = self.density.beta
+        if not (probe.is_cuda and TRUNK_IMPL == "mfma" and TRUNK_MODE == "rr" and RR_FORWARD == "fused" and SDF_MLP_IMPL == "wave" and APPEARANCE_IMPL == "mfma"
+                and APPEARANCE_FORM == "wave" and net._fused_trunk_supported(probe) and self._fused_appearance_supported(probe)):
+            return None
+        l0, l1, l2 = net._lins()
+        if l2.out_features != net.d_out or net.d_out > 32:
+            return None
+        with torch.no_grad():
+            W0, W1, W2 = effective_weights([l0, l1, l2])
+            R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
+            mlp = net.color_grid_feature_map_mlp
+            f = lambda t: t.detach().float().contiguous()  # noqa: E731
+            grad = torch.is_grad_enabled()
+            out = _be._backend.pack_iteration(
+                (f(W0), f(l0.bias), f(W1), f(l1.bias), f(W2), f(l2.bias), net.d_out, True, True, self.training),
+                ((mlp[0].weight, mlp[2].weight, R0, R1, R2), (mlp[0].bias, mlp[2].bias, rn.lin0.bias, rn.lin1.bias, rn.lin2.bias), grad))
+        out["net"] = id(net)
+        out["trunk_key"] = (id(W0), id(W1), id(W2))
+        out["appear_key"] = (id(mlp[0].weight), id(mlp[2].weight), id(R0), id(R1), id(R2))
+        return out
+
+    def uniform_sizes(self, num_rays):
+        """Names and shapes of the U[0, 1) draws of one training iteration (draw_uniforms / iteration_prologue)."""
+        sm = self.ray_sampler
+        R = num_rays
+        return {"ray_offset_u": (1, R, 2), "t_rand": (R, sm.N_samples_eval), "u_final": (R, sm.N_samples), "u_pick": (max(sm.N_samples_extra, 1),),
+                "eik_u": (R,), "eik_uniform_u": (R, 3), "eik_jitter": (2 * R, 3)}
+
+    def rng_state(self, device):
+        """Device-resident (seed, counter, scratch) of this model's Philox stream (hs_iter_prologue): seeded once from torch's default CPU
+        generator -- torch.manual_seed decides it, data-parallel ranks that reseed after the common initialisation get their own --, advanced
+        by every launch that draws from it."""
+        st = getattr(self, "_rng_state", None)
+        dev = torch.device(device)
+        if st is None or st.device.type != dev.type or (dev.index is not None and st.device.index != dev.index):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            st = self._rng_state = torch.tensor([seed, 0, 0], dtype=torch.int64).to(device)
+        return st
+
     def draw_uniforms(self, num_rays, device):
         """Every U[0,1) draw of one training iteration from ONE generator launch (the reference draws them where it needs them:
         network.py:773 ray offsets, ray_sampler.py:77 stratified jitter, :238 inverse-CDF draws, :269 extra samples, :279
         Eikonal pick, network.py:846-853 Eikonal points): an `rng` dict for prepare_rays / sample / render whose *_u entries are
         raw draws that the consuming kernels shift / scale / quantise themselves."""
-        sm = self.ray_sampler
-        R = num_rays
-        sizes = {"ray_offset_u": (1, R, 2), "t_rand": (R, sm.N_samples_eval), "u_final": (R, sm.N_samples), "u_pick": (max(sm.N_samples_extra, 1),),
-                 "eik_u": (R,), "eik_uniform_u": (R, 3), "eik_jitter": (2 * R, 3)}
+        sizes = self.uniform_sizes(num_rays)
         total = sum(int(np.prod(v)) for v in sizes.values())
         pool = torch.rand(total, device=device)
         rng, off = {}, 0

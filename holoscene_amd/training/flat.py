@@ -85,6 +85,7 @@ class FlatAdam:
             p.grad = self.flat_g[off:off + n].view_as(p)
             if i >= n_tables:
                 self.small.append((p, p.grad))
+                p._hs_flat_view = p.grad    # producers that can write a gradient in place do (model/network.py: flat_grad_view)
             else:
                 p._hs_flat_owner = True   # its gradient is consumed through gather_grads() only: the scatters write it in place
             if i < n_tables:
@@ -118,13 +119,15 @@ class FlatAdam:
         `zero_grad(set_to_none=True)` -- the reference's loop -- skips it.  Stage 1 uses every parameter in every iteration, so the
         two agree there; a model with conditionally used parameters is told once."""
         _be.set_zero_pool(None)         # the backward pass this pool served is over
-        src = [p.grad for p, _ in self.small if p.grad is not None]
-        dst = [v for p, v in self.small if p.grad is not None]
-        if len(src) != len(self.small) and not getattr(self, "_warned_missing_grad", False):
+        have = [(p.grad, v) for p, v in self.small if p.grad is not None]
+        if len(have) != len(self.small) and not getattr(self, "_warned_missing_grad", False):
             import warnings
             self._warned_missing_grad = True
-            warnings.warn(f"FlatAdam: {len(self.small) - len(src)} of {len(self.small)} small parameters received no gradient; the flat "
+            warnings.warn(f"FlatAdam: {len(self.small) - len(have)} of {len(self.small)} small parameters received no gradient; the flat "
                           "optimiser updates them with a zero gradient (torch.optim.Adam would skip them)")
+        # a producer that wrote its result straight into the view (hs_iter_epilogue, hs_assemble with a destination) needs no copy
+        src = [g for g, v in have if g.data_ptr() != v.data_ptr()]
+        dst = [v for g, v in have if g.data_ptr() != v.data_ptr()]
         if src:
             if src[0].is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in src):
                 _be._backend.copy_many(dst, src)        # one launch, one element per thread (the multi-tensor copy is 17 us here)

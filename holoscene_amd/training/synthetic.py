@@ -58,6 +58,7 @@ class SyntheticScene:
         self._sampler = PixelSampler([self._class_pixels] * num_frames, npix, num_rays, self.device, seed=seed)
         self._py = random.Random(seed)
         self._plans, self._const_done = {}, set()
+        self._fidx = torch.arange(num_frames, dtype=torch.int64, device=self.device)
         self._fixed, self._cursor = None, 0
         if not redraw:      # a fixed set of batches, drawn once on the host
             g2 = torch.Generator().manual_seed(seed)
@@ -85,17 +86,21 @@ class SyntheticScene:
         return torch.tensor([frame]), model_input, gt
 
     def write_batch(self, dst_input, dst_gt):
-        """next_batch() written straight into existing buffers (the training graph's static input block): one launch draws the pixel
-        indices (hs_draw_pixels), one gathers the rows (csrc/encode_ops.hip: hs_gather_rows) -- instead of six indexing launches plus
-        the copies into the block.  Same generator state, same counter: interleaving next_batch() and write_batch() walks the same
+        """next_batch() written straight into existing buffers (the training graph's static input block): ONE launch draws the pixel
+        indices and gathers their rows (csrc/batch_ops.hip: hs_draw_gather) -- instead of six indexing launches plus the copies into
+        the block.  Same generator state, same counter: interleaving next_batch() and write_batch() walks the same
         sequence of batches.  The launch plan of a frame holds pointers only -- the index tensor is static, its content is redrawn."""
         from ..hashencoder import backend as _be
-        frame, idx = self._next()
+        fused = self._fixed is None
+        if fused:
+            frame, idx = self._py.randint(0, self.F - 1), self._sampler.idx     # ns_dataset.py:383; the draw itself rides in the gather launch below
+        else:
+            frame, idx = self._next()
         tag = dst_input["uv"].data_ptr()
         key = (frame, tag)
         plan = self._plans.get(key)
         if plan is None:
-            fidx = torch.tensor([frame], dtype=torch.int64).to(self.device)
+            fidx = self._fidx[frame:frame + 1]
             plan = self._plans[key] = _be._backend.gather_plan([
                 (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
                 (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
@@ -103,4 +108,7 @@ class SyntheticScene:
             dst_input["intrinsics"].copy_(self.intrinsics)
             dst_gt["mask"].fill_(1.0)
             self._const_done.add(tag)
-        _be._backend.gather_rows(plan)
+        if fused:
+            self._sampler.draw(frame, gather=plan)      # pixel draw + row gather: one launch (csrc/batch_ops.hip: hs_draw_gather)
+        else:
+            _be._backend.gather_rows(plan)

@@ -286,10 +286,16 @@ class Stage1Trainer:
         self.flat.zero_grad()
         self._arm_early_exchange()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
-        with model.density.shared_beta(), _net.shared_effective_weights(model.weight_norm_layers()):
+        # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
+        # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
+        tick = self.flat if (self.flat is not None and not self.freeze_parameters and (not self.dp or self._overlap)) else None
+        sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1])
+        with _net.iteration_prologue(model, tick, sizes) as drawn:
             with torch.no_grad():
                 if "rng" in st:     # injected draws (static tensors the caller overwrites before each replay)
                     rng = st["rng"]
+                elif drawn is not None:
+                    rng = drawn
                 else:
                     rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
                 rays = model.prepare_rays(st["input"], rng)
@@ -358,17 +364,35 @@ class Stage1Trainer:
         self._drain_collective_watchdog()
 
     def _drain_collective_watchdog(self):
-        """Before a capture that will pull the process group's communication stream into capture mode: let the process group's watchdog
-        thread retire every EAGER collective it still tracks.  It polls their end events (hipEventQuery, every ~100 ms); on this stack a
-        query of an event whose stream has meanwhile entered capture fails with hipErrorCapturedEvent, the watchdog rethrows and the process
-        aborts (seen once in five runs of tests/test_distributed_gpu.py behind another GPU test: 'operation not permitted on an event last
-        recorded in a capturing stream' from ProcessGroupNCCL::Watchdog::runLoop).  The warm-up passes' collectives have completed by now
-        (synchronize above); three polling periods later the watchdog's list is empty."""
-        if self.dp:
-            import time
-            import torch.distributed as dist
-            if dist.is_initialized() and dist.get_backend() == "nccl":
-                time.sleep(0.35)
+        """Before a capture that will pull the process group's communication stream into capture mode: wait until the process group's
+        watchdog thread has RETIRED every eager collective it still tracks.  It polls their end events (hipEventQuery, every ~100 ms); on
+        this stack a query of an event whose stream has meanwhile entered capture fails with hipErrorCapturedEvent, the watchdog rethrows
+        and the process aborts (seen once in five runs of tests/test_distributed_gpu.py behind another GPU test: 'operation not permitted
+        on an event last recorded in a capturing stream' from ProcessGroupNCCL::Watchdog::runLoop).  The warm-up passes' collectives have
+        completed by now (synchronize above); what is left is the watchdog noticing.  That is observable: the process group's flight
+        recorder marks an entry `retired` when the watchdog drops it from its list (tools/exp/pg_retire_probe.py: 60-100 ms after
+        completion), so the wait is on that CONDITION -- the short sleeps only yield the GIL between polls.  Without a recorder
+        (TORCH_FR_BUFFER_SIZE=0 when the group was created: no entries) three polling periods of sleep remain the fallback."""
+        if not self.dp:
+            return
+        import time
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_backend() == "nccl"):
+            return
+        try:
+            import pickle
+            from torch._C._distributed_c10d import _dump_nccl_trace
+            deadline = time.monotonic() + 10.0
+            while time.monotonic() < deadline:
+                entries = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries", [])
+                if not entries:
+                    break                                   # recorder off: fall back
+                if all(e.get("retired", False) for e in entries):
+                    return
+                time.sleep(0.005)
+        except Exception:                                   # no flight recorder in this build
+            pass
+        time.sleep(0.35)
 
     def _train_step_full_graph(self, model_input, ground_truth, rng=None, depths=None):
         self.model.train()

@@ -516,15 +516,18 @@ int hs_sum_slices(const hsSumJob *jobs, int32_t n_jobs, void *stream);
  *   dst[r * dst_ld + c] = sum over terms t of  sum_{k < red_t} src_t[k * red_stride_t + r * ld_t + (col_map_t ? col_map_t[c] : col0_t + c)]
  * for r < rows, c < cols -- bias gradient = accumulator + a column of a partial-sum matrix, weight gradient = a column selection of the
  * padded result, a column sum of per-workgroup partials (red > 1) ... what autograd would spend one ~5 us launch per operator on. */
-#define HS_ASM_MAX_JOBS 8
+#define HS_ASM_MAX_JOBS 12
 #define HS_ASM_MAX_TERMS 3
 typedef struct hsAsmTerm {
-    const float *src;
+    const float *src;          /* fp32, or bf16 when src_bf16 (then ld / red_stride / col0 count bf16 elements) */
     const int32_t *col_map;    /* NULL: columns col0 .. col0 + cols - 1 */
     int64_t ld;                /* row stride of src (0: every row reads the same source row) */
     int64_t red_stride;
     int32_t col0;
-    int32_t red;               /* >= 1: number of source blocks summed */
+    int32_t red;               /* >= 1: number of source blocks summed (e.g. the slices of a split-M partial stack [red, rows, ld]) */
+    int32_t src_bf16;          /* 1: src holds bf16 (the weight-gradient kernels' partial stacks): the slice sum of hs_sum_slices and the column
+                                * selection / accumulation of its result in the same launch */
+    int32_t reserved;
 } hsAsmTerm;
 typedef struct hsAsmJob {
     float *dst;
@@ -546,6 +549,28 @@ typedef struct hsWnJob {
     int32_t rows, cols;
 } hsWnJob;
 int hs_weight_norm(const hsWnJob *jobs, int32_t n_jobs, int32_t backward, void *stream);
+
+/* Every weight image of a Stage-1 iteration in ONE launch: hs_sdf_mlp2_pack(log2_domain = 1) -> s* (the sampler sweeps), hs_trunk_pack_all ->
+ * W0f .. w0t (the training trunk), hs_appearance2_pack -> stream_image .. streamT_image (the colour branch); arguments as in those three.  A NULL
+ * first output of a group (sW0f, W0f, stream_image) leaves the group out; w1t / streamT_image NULL: no row-major transposes / no backward image. */
+int hs_pack_iteration(const float *W0, int32_t ld0, int32_t f_in, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
+                      int32_t d_out, void *sW0f, void *sW1f, void *sW2f, float *sbias, void *W0f, void *W1f, void *W2f, float *bias, void *W1Tf, void *W0Tf,
+                      void *W2Tf, float *W2tab, void *w1t, void *w2t, void *w0t, const float *Wc0, const float *Wc1, const float *Wr0, int32_t ldr0,
+                      const float *Wr1, const float *Wr2, const float *bc0, const float *bc1, const float *br0, const float *br1, const float *br2,
+                      void *stream_image, void *R2f, float *abias, void *streamT_image, void *stream);
+
+/* Head and tail of a training iteration, one launch each (csrc/iter_ops.hip).
+ * hs_iter_prologue: (a) the weight-norm FORWARD of `jobs` (as hs_weight_norm); (b) rng_pool[0..n_rng) <- U[0, 1) draws, Philox-4x32-10 keyed by
+ * rng_state[0] (seed) at counter rng_state[1]; the launch advances the counter (rng_state: three device uint64, [2] = scratch, zero between
+ * launches), so every replay of a captured graph draws a new pool -- replaces torch.rand's generator kernel + its two Philox-state fills
+ * (the reference draws where it needs them: network.py:785, 847-853, ray_sampler.py:79, 238, 269, 279); (c) beta_out = |beta| + beta_min[0]
+ * (model/density.py:28-30); (d) adam != NULL: hs_adam_tick's update of the optimiser state.  Any part may be empty.
+ * hs_iter_epilogue: the weight-norm BACKWARD of `jobs` + g_beta_out[i] = sgn(beta[i]) * (sum over up to 4 arrays [part_len[q], n_beta] of partial
+ * cotangents -- the per-ray partials the compositing backward leaves --), written where the caller points (the flat gradient buffer's views). */
+int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
+                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, void *stream);
+int hs_iter_epilogue(const hsWnJob *jobs, int32_t n_jobs, const float *beta, const float *const *g_beta_parts, const int32_t *part_len,
+                     int32_t n_parts, float *g_beta_out, int32_t n_beta, void *stream);
 
 /* Batch assembly from device-resident arrays: dst[i, :] = src[idx[i], :], rows of row_bytes (a multiple of 4) bytes, for up to
  * HS_GATHER_MAX_JOBS arrays in one launch -- the sampled-pixel gather of a training batch (datasets/scene_dataset.py:143-167:
@@ -656,10 +681,14 @@ int hs_gemm_split_tn(const float *A, int64_t lda, const float *B, int64_t ldb, f
  * quota, all of it otherwise --, followed by n_uniform distinct pixels drawn uniformly from [0, total_pixels).  out_off [n_cls + 2]:
  * where each class's share (and, last but one, the uniform share) starts in `out` (int64 [sum of the shares]); the caller computes it
  * from the class sizes, which it knows.  (seed, counter) name the batch: the same pair gives the same batch on every run.
- * Every quota must be <= HS_DRAW_MAX_WANT. */
-#define HS_DRAW_MAX_WANT 4096
+ * n_out = out_off[n_cls + 1] = the batch size (one thread per output position; any quota).
+ * hs_draw_gather: the same draw plus the batch's row gather (hs_gather_rows, section 8) in the same launch -- a job whose `idx` IS `out`
+ * gathers by the pixels just drawn (its n must equal n_out), any other job by its own index array. */
 int hs_draw_pixels(const int32_t *class_ptr, const int32_t *class_pix, const int32_t *out_off, int32_t n_cls, int32_t per_class, int32_t n_bg,
-                   int32_t n_uniform, int32_t total_pixels, uint64_t seed, uint64_t counter, int64_t *out, void *stream);
+                   int32_t n_uniform, int32_t total_pixels, int32_t n_out, uint64_t seed, uint64_t counter, int64_t *out, void *stream);
+int hs_draw_gather(const int32_t *class_ptr, const int32_t *class_pix, const int32_t *out_off, int32_t n_cls, int32_t per_class, int32_t n_bg,
+                   int32_t n_uniform, int32_t total_pixels, int32_t n_out, uint64_t seed, uint64_t counter, int64_t *out,
+                   const struct hsGatherJob *jobs, int32_t n_jobs, void *stream);
 
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *

@@ -50,6 +50,7 @@ def _worker(rank, world, port, backend, q, zero1, steps, share_gpu):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0 if share_gpu else rank)
     torch.cuda.set_device(dev)
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     dist.init_process_group(backend, rank=rank, world_size=world)
     from holoscene_amd.training.distributed import exchange_and_step_flat
     from holoscene_amd.training.flat import FlatAdam
@@ -139,6 +140,7 @@ def _trainer_worker(port, q):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from holoscene_amd.training.synthetic import SyntheticScene
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf

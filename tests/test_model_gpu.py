@@ -1037,13 +1037,18 @@ def test_whole_iteration_graph_matches_eager_execution(beta):
         idx, mi, gt = scene.next_batch()
         tr.train_step(idx, mi, gt)
         entry = tr._graphs[("full", key_iter == 0, False)]
-        torch.cuda.manual_seed(7)
+
+        def same_draws():       # torch's generator (background patch) and the model's own Philox stream (hs_iter_prologue) at one position
+            torch.cuda.manual_seed(7)
+            tr.model.rng_state(DEV)[1] = 7
+
+        same_draws()
         entry["graph"].replay()
         torch.cuda.synchronize()
         g_graph = tr.flat.flat_g.clone()
         out_graph = {k: v.clone() for k, v in entry["out"].items() if torch.is_tensor(v)}
         loss_graph, rounds_graph = float(entry["loss"]["loss"]), int(entry["rounds"])
-        torch.cuda.manual_seed(7)
+        same_draws()
         out_eager, loss_eager = tr._full_body(entry["static"], key_iter == 0, False)
         g_eager = tr.flat.flat_g.clone()
         assert rounds_graph == tr.model.ray_sampler.last_rounds and 1 <= rounds_graph <= 5

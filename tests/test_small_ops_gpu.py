@@ -64,3 +64,93 @@ def test_zero_pool_hands_out_untouched_zeros():
     assert c.numel() == 100 and float(c.abs().sum()) == 0 and float(b.abs().sum()) == 0
     backend.set_zero_pool(None)
     assert backend.zeros_small(4, "cuda").data_ptr() != pool.data_ptr()
+
+
+def test_iteration_prologue_and_epilogue_kernels():
+    """csrc/iter_ops.hip: weight norms, beta, the uniform pool and the optimiser tick in one launch (hs_iter_prologue) against their
+    whole-tensor formulations; the tail (hs_iter_epilogue) against autograd through torch._weight_norm and abs."""
+    from holoscene_amd.hashencoder import backend as be
+    g = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    shapes = [(256, 71), (256, 256), (32, 256), (3, 337)]
+    vs = [torch.randn(*s_, generator=g).to(dev) for s_ in shapes]
+    gs = [torch.rand(s_[0], 1, generator=g).add(0.5).to(dev) for s_ in shapes]
+    beta, beta_min = torch.tensor([-0.02], device=dev), torch.tensor([1e-4], device=dev)
+    n = 208928 + 3
+    pool = torch.full((n,), -1.0, device=dev)
+    rs = torch.tensor([1234567, 0, 0], dtype=torch.int64, device=dev)
+    st = be.hsAdamState()
+    st.step = 4
+    for i, v in enumerate((1e-2, 5e-4, 5e-4)):
+        st.lr0[i] = v
+    state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(dev)
+    ref_state = state.clone()
+    Ws, beta_eff = _be().iter_prologue(vs, gs, pool, rs, beta, beta_min, (state, 0.9, 0.99, 0.999))
+    for W, v, g_ in zip(Ws, vs, gs):
+        assert torch.allclose(W, torch._weight_norm(v, g_, 0), rtol=2e-6, atol=1e-7)
+    assert torch.equal(beta_eff, beta.abs() + beta_min)
+    _be().adam_tick(ref_state, 0.9, 0.99, 0.999)
+    assert torch.equal(state, ref_state)
+    assert rs.tolist() == [1234567, 1, 0]
+    first = pool.clone()
+    assert float(first.min()) >= 0.0 and float(first.max()) < 1.0
+    assert abs(float(first.mean()) - 0.5) < 4 * (1 / 12 / n) ** 0.5 and abs(float(first.var()) - 1 / 12) < 1e-3
+    assert first.unique().numel() > 0.98 * n      # 24-bit draws: ~0.6 % birthday collisions at this length
+    _be().iter_prologue([], [], pool, rs)
+    assert rs.tolist() == [1234567, 2, 0] and not torch.equal(pool, first)        # the next launch draws the next pool
+    rs2 = torch.tensor([1234567, 0, 0], dtype=torch.int64, device=dev)
+    pool2 = torch.empty(n, device=dev)
+    _be().iter_prologue([], [], pool2, rs2)
+    assert torch.equal(pool2, first)                                              # (seed, counter) name the pool
+    # ---- tail
+    gWs = [torch.randn_like(v) for v in vs]
+    vr = [v.clone().requires_grad_() for v in vs]
+    gr = [g_.clone().requires_grad_() for g_ in gs]
+    br = beta.clone().requires_grad_()
+    parts = [torch.randn(1024, device=dev), torch.randn(1, device=dev)]
+    loss = sum((torch._weight_norm(v, g_, 0) * gW).sum() for v, g_, gW in zip(vr, gr, gWs)) + (br.abs() + beta_min).sum() * sum(p.sum() for p in parts)
+    loss.backward()
+    outs = [(torch.empty_like(v), torch.empty_like(g_)) for v, g_ in zip(vs, gs)]
+    gb = torch.empty(1, device=dev)
+    _be().iter_epilogue(vs, gs, gWs, outs, beta, parts, gb)
+    for (gv, gg), v, g_ in zip(outs, vr, gr):
+        assert torch.allclose(gv, v.grad, rtol=1e-4, atol=1e-5) and torch.allclose(gg, g_.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gb, br.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_iteration_prologue_context_equals_the_separate_contexts():
+    """model/network.py: iteration_prologue() against density.shared_beta() + shared_effective_weights(): same beta, same matrices, same
+    parameter gradients -- written into the flat gradient buffer's views without a copy --, one optimiser tick."""
+    from holoscene_amd.model import network as net
+    from holoscene_amd.training.trainer import Stage1Trainer, stock_conf
+    tr = Stage1Trainer(stock_conf(beta=0.01, mlp_precision="bf16"), device="cuda", optimizer="flat", graph=False)
+    m, flat = tr.model, tr.flat
+    lins = m.weight_norm_layers()
+    coef = [torch.randn_like(l.weight_v) for l in lins]
+
+    def run(ctx):
+        flat.zero_grad()
+        with ctx as rng:
+            Ws = net.effective_weights(lins)
+            b = m.density.get_beta()
+            loss = sum((W * c).sum() for W, c in zip(Ws, coef)) + 7.0 * b
+            vals = [W.detach().clone() for W in Ws] + [b.detach().clone()]
+        loss.backward()
+        flat.gather_grads()
+        return vals, flat.flat_g.clone(), rng
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def old():
+        with m.density.shared_beta(), net.shared_effective_weights(lins):
+            yield None
+
+    v0, g0, _ = run(old())
+    step0 = flat.read_state().step
+    v1, g1, rng = run(net.iteration_prologue(m, flat, m.uniform_sizes(64)))
+    assert all(torch.equal(a, b) for a, b in zip(v0, v1))
+    assert torch.allclose(g0, g1, rtol=1e-6, atol=1e-8) and float(g1.abs().sum()) > 0
+    assert flat.read_state().step == step0 + 1 and flat._ticked
+    flat.end_update()
+    assert set(rng) == set(m.uniform_sizes(64)) and all(0.0 <= float(t.min()) and float(t.max()) < 1.0 for t in rng.values())

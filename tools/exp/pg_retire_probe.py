@@ -1,7 +1,8 @@
 """What does the process group's flight recorder say about eager collectives the watchdog still tracks?  (trainer.py: _drain_collective_watchdog)"""
 import os, pickle, time
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", os.environ.get("TBS", "2000"))
+if os.environ.get("TBS"):
+    os.environ["TORCH_FR_BUFFER_SIZE"] = os.environ["TBS"]      # unset: the build's default
 import torch, torch.distributed as dist
 dist.init_process_group("nccl", rank=0, world_size=1)
 x = torch.ones(1 << 20, device="cuda")
