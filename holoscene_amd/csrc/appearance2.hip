@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
                                                                const uint32_t *__restrict__ masks, const char *__restrict__ streamT,
                                                                uint16_t *__restrict__ gy_out, uint16_t *__restrict__ GR1t, uint16_t *__restrict__ GR0t,
                                                                uint16_t *__restrict__ GFVt, uint16_t *__restrict__ GHCt, float *__restrict__ d_normals,
-                                                               float *__restrict__ g_featc, float *__restrict__ gb2, int64_t n) {
+                                                               float *__restrict__ g_featc, float *__restrict__ gb2, int64_t n, int normals_add) {
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 31, h = lane >> 5;
     int par = 0;
@@ -696,7 +696,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
             }
 #pragma unroll
             for (int d = 0; d < 3; d++) dn[d] += __shfl_xor(dn[d], 32);
-            if (h == 0 && ok) { d_normals[gp * 3] = dn[0]; d_normals[gp * 3 + 1] = dn[1]; d_normals[gp * 3 + 2] = dn[2]; }
+            if (h == 0 && ok) {
+                if (normals_add) { dn[0] += d_normals[gp * 3]; dn[1] += d_normals[gp * 3 + 1]; dn[2] += d_normals[gp * 3 + 2]; }    // the other consumer's cotangent is there already
+                d_normals[gp * 3] = dn[0]; d_normals[gp * 3 + 1] = dn[1]; d_normals[gp * 3 + 2] = dn[2];
+            }
         }
         // ---- featc~ = Wc0^T hc~ (chunk 8, one tile): hc~'s last quarter in the shadow of its first k-steps; register r <-> colour feature 16 h + r
         {
@@ -798,7 +801,7 @@ int hs_appearance2_fwd(const float *featc, const float *points, const float *dir
 int64_t hs_appearance2_pack_t_bytes(void) { return (int64_t)kStreamTBytes; }
 
 int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normals, const uint32_t *masks, const void *streamT_image, void *gy, void *GR1t,
-                       void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, void *stream) {
+                       void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, int32_t normals_add, void *stream) {
     if (n < 0) return HS_ERR_ARG;
     if (n == 0) return HS_OK;
     if (!g_rgb || !rgb || !normals || !masks || !streamT_image || !gy || !GR1t || !GR0t || !GFVt || !GHCt || !d_normals || !g_featc) return HS_ERR_NULL;
@@ -808,7 +811,7 @@ int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normal
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     k_appear2_bwd<<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
         g_rgb, rgb, normals, masks, (const char *)streamT_image, (uint16_t *)gy, (uint16_t *)GR1t, (uint16_t *)GR0t, (uint16_t *)GFVt, (uint16_t *)GHCt, d_normals,
-        g_featc, gb2, n);
+        g_featc, gb2, n, normals_add);
     return wt_check_launch();
 }
 

@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int kDrawThreads = 256;
+constexpr int kDrawLdsCls = 510;
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {      // splitmix64 finaliser
     x += 0x9e3779b97f4a7c15ull;
@@ -62,17 +63,25 @@ struct DrawArgs {
 // the pixel that output position t of the batch holds (t < out_off[n_cls + 1]).  Segment by bisection over out_off (a linear walk is
 // n_cls dependent global loads: 17 us at 33 segments)
 __device__ __forceinline__ int64_t drawn_pixel(const DrawArgs &a, int32_t t) {
+    // the segment table through LDS when it fits (one load latency for the workgroup instead of log2(n_cls) dependent ones per thread)
+    __shared__ int32_t s_off[kDrawLdsCls + 2];
+    const bool staged = a.n_cls <= kDrawLdsCls;
+    if (staged) {
+        for (int i = threadIdx.x; i < a.n_cls + 2; i += kDrawThreads) s_off[i] = a.out_off[i];
+        __syncthreads();
+    }
+    const int32_t *off = staged ? s_off : a.out_off;
     int lo = 0, hi = a.n_cls;           // the largest c in [0, n_cls] with out_off[c] <= t (empty segments in front of it are skipped)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (a.out_off[mid] <= t) lo = mid; else hi = mid - 1;
+        if (off[mid] <= t) lo = mid; else hi = mid - 1;
     }
     const int c = lo;
     const bool uniform = c == a.n_cls;
     const int32_t first = uniform ? 0 : a.class_ptr[c];
     const int32_t n = uniform ? a.total_pixels : a.class_ptr[c + 1] - first;
     const int32_t quota = uniform ? a.n_uniform : (c == 0 ? a.n_bg : a.per_class);
-    const int32_t i = t - a.out_off[c];
+    const int32_t i = t - off[c];
     int32_t pos = i;            // n <= quota: the whole class (ns_dataset.py:422-427); never taken by the uniform half of a real image
     if (n > quota) pos = (int32_t)perm_index((uint32_t)i, (uint32_t)n, mix64(a.seed ^ mix64(a.counter * 0x100000001b3ull + (uint64_t)c)));
     return uniform ? (int64_t)pos : (int64_t)a.class_pix[first + pos];
@@ -80,7 +89,8 @@ __device__ __forceinline__ int64_t drawn_pixel(const DrawArgs &a, int32_t t) {
 
 __global__ __launch_bounds__(kDrawThreads) void k_draw_pixels(DrawArgs a, int32_t total) {
     const int32_t t = blockIdx.x * kDrawThreads + threadIdx.x;
-    if (t < total) a.out[t] = drawn_pixel(a, t);
+    const int64_t pix = drawn_pixel(a, t < total ? t : 0);       // (every thread: the segment table is staged by the whole workgroup)
+    if (t < total) a.out[t] = pix;
 }
 
 // the draw and the batch's row gather in one launch: dst_j[t, :] = src_j[pixel(t), :] for the jobs indexed by the drawn pixels (idx == out),
@@ -89,19 +99,38 @@ struct DrawGatherJobs { hsGatherJob j[HS_GATHER_MAX_JOBS]; int32_t n; };
 
 __global__ __launch_bounds__(kDrawThreads) void k_draw_gather(DrawArgs a, int32_t total, DrawGatherJobs jobs) {
     const int32_t t = blockIdx.x * kDrawThreads + threadIdx.x;
-    int64_t pix = 0;
-    if (t < total) {
-        pix = drawn_pixel(a, t);
-        a.out[t] = pix;
-    }
-    for (int q = 0; q < jobs.n; q++) {
+    const int64_t pix = drawn_pixel(a, t < total ? t : 0);       // (every thread: the segment table is staged by the whole workgroup)
+    if (t < total) a.out[t] = pix;
+    // rows of up to four words (every per-pixel array of a batch): ALL loads first, then the stores -- source and destination may alias as far as
+    // the compiler knows, so a load-store loop per job is one memory round trip after the other (17 us for six jobs)
+    uint32_t buf[HS_GATHER_MAX_JOBS][4];
+#pragma unroll
+    for (int q = 0; q < HS_GATHER_MAX_JOBS; q++) {
+        if (q >= jobs.n) break;
         const hsGatherJob jb = jobs.j[q];
-        if (t >= jb.n) continue;
         const int words = jb.row_bytes >> 2;
+        if (t >= jb.n || words > 4) continue;
         const int64_t r = jb.idx == a.out ? pix : jb.idx[t];
         const uint32_t *src = reinterpret_cast<const uint32_t *>(jb.src) + r * words;
+#pragma unroll
+        for (int w = 0; w < 4; w++) buf[q][w] = w < words ? src[w] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < HS_GATHER_MAX_JOBS; q++) {
+        if (q >= jobs.n) break;
+        const hsGatherJob jb = jobs.j[q];
+        const int words = jb.row_bytes >> 2;
+        if (t >= jb.n) continue;
         uint32_t *dst = reinterpret_cast<uint32_t *>(jb.dst) + (int64_t)t * words;
-        for (int w = 0; w < words; w++) dst[w] = src[w];
+        if (words <= 4) {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (w < words) dst[w] = buf[q][w];
+        } else {        // a long row (the frame's pose: one row per batch)
+            const int64_t r = jb.idx == a.out ? pix : jb.idx[t];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(jb.src) + r * words;
+            for (int w = 0; w < words; w++) dst[w] = src[w];
+        }
     }
 }
 

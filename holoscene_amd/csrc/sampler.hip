@@ -198,6 +198,20 @@ struct DrawExt {
     float divide_factor;
 };
 
+// The tail of Algorithm 1 in the SAME launch as the final draw (hs_sampler_tail): the extra-sample indices (k_sampler_pick's partial
+// Fisher-Yates shuffle, recomputed by every workgroup from the same draws: 32 dependent LDS steps against a 5 us launch) and the merge of
+// [drawn samples | near | far | z[pick]] into the sorted output row (k_sampler_final).  z_out == NULL: a plain draw.
+struct TailExt {
+    const float *u_pick;          // NULL: eval mode (torch.linspace(0, m - 1, n_extra).long()) unless pick_in
+    const int64_t *pick_in;       // explicit indices (parity tests inject the reference's permutation)
+    int n_extra;
+    float near, far;
+    const float *near_r, *far_r;
+    const int64_t *eik_idx;
+    const float *eik_u;
+    float *z_out, *z_eik;
+};
+
 // The draw itself, on a ray whose merged depths / SDF values are in LDS (z, sdf: m entries; cdf, pdf: scratch of m floats each; sc: 3 x
 // NT / 64 floats): shared by k_sampler_draw (which stages the ray first) and by the fused update + draw kernel (whose update phase
 // has just produced them).  All NT threads of the workgroup call it.
@@ -430,7 +444,7 @@ template <int kDraw>
 __global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict__ z_in, const float *__restrict__ sdf_in, int ld, int m,
                                                          const float *__restrict__ beta_in, int mode, float add_tiny, const float *__restrict__ u_in,
                                                          int n_out, float *__restrict__ out, int R, hsGate gate, const int32_t *__restrict__ m_dev,
-                                                         DrawExt ext) {
+                                                         DrawExt ext, TailExt tail) {
     extern __shared__ float lds[];
     if (ext.ctl_in) {
         hsSamplerCtl c = *ext.ctl_in;
@@ -456,6 +470,51 @@ __global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict_
     for (int i = lane; i < m; i += kDraw) { z[i] = zr[i]; sdf[i] = sr[i]; }
     __syncthreads();
     draw_phase<kDraw>(z, sdf, cdf, pdf, sc, m, beta_in[r], mode, add_tiny, u_in, n_out, out, r, lane, ext);
+    if (tail.z_out == nullptr) return;
+    // ---- tail: pick, merge, sort (the ray's merged depths are still in z; cdf / pdf / sdf are scratch from here on)
+    __syncthreads();          // every inverse-CDF read is done; the drawn depths (global, written by this workgroup) are visible to it
+    const int n_extra = tail.n_extra, n = n_out + 2 + n_extra;      // n <= s_new <= m (launcher)
+    int *idx = reinterpret_cast<int *>(cdf);                          // m ints
+    float *v = pdf, *sorted = sdf;                                    // n floats each
+    int *pk = reinterpret_cast<int *>(lds + 4 * m + 3 * 4);           // n_extra ints behind the draw's scratch (launcher sizes it)
+    if (n_extra > 0) {
+        if (tail.pick_in) {
+            for (int j = lane; j < n_extra; j += kDraw) pk[j] = (int)tail.pick_in[j];
+        } else if (tail.u_pick == nullptr) {
+            for (int j = lane; j < n_extra; j += kDraw) {
+                const float step = (float)(m - 1) / (float)(n_extra - 1 > 0 ? n_extra - 1 : 1);
+                const float t = j < n_extra / 2 ? step * (float)j : (float)(m - 1) - step * (float)(n_extra - 1 - j);
+                pk[j] = (int)t;
+            }
+        } else {
+            for (int i = lane; i < m; i += kDraw) idx[i] = i;
+            float *up = v;            // the draws through LDS: the shuffle below is a serial chain, a global load per step would be its whole cost
+            for (int j = lane; j < n_extra; j += kDraw) up[j] = tail.u_pick[j];
+            __syncthreads();
+            if (lane == 0) {
+                for (int j = 0; j < n_extra && j < m; j++) {
+                    int k = j + (int)(up[j] * (float)(m - j));
+                    k = k > m - 1 ? m - 1 : k;
+                    const int t = idx[j]; idx[j] = idx[k]; idx[k] = t;
+                    pk[j] = idx[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < n_out; i += kDraw) v[i] = out[(size_t)r * n_out + i];
+    if (lane == 0) { v[n_out] = tail.near_r ? tail.near_r[r] : tail.near; v[n_out + 1] = tail.far_r ? tail.far_r[r] : tail.far; }
+    for (int i = lane; i < n_extra; i += kDraw) v[n_out + 2 + i] = z[pk[i]];
+    __syncthreads();
+    for (int i = lane; i < n; i += kDraw) {  // rank sort (n ~ 100), k_sampler_final's
+        const float x = v[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (v[j] < x) || (v[j] == x && j < i);
+        sorted[rank] = x;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += kDraw) tail.z_out[(size_t)r * n + i] = sorted[i];
+    if (lane == 0 && tail.z_eik) tail.z_eik[r] = sorted[tail.eik_u ? min((int)(tail.eik_u[r] * (float)n), n - 1) : (int)tail.eik_idx[r]];
 }
 
 // ------------------------------------------------------------------------------------ final
@@ -576,9 +635,9 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
 template <typename... Args>
-void launch_draw(int R, int m_cap, hipStream_t st, Args... args) {
+void launch_draw(int R, int m_cap, int n_extra, hipStream_t st, Args... args) {
     static const int nt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_DRAW_THREADS"); const int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
-    const size_t lds = (4 * (size_t)m_cap + 3 * 4) * sizeof(float);
+    const size_t lds = (4 * (size_t)m_cap + 3 * 4 + (size_t)n_extra) * sizeof(float);
     if (nt == 64) k_sampler_draw<64><<<dim3(R), dim3(64), lds, st>>>(args...);
     else if (nt == 128) k_sampler_draw<128><<<dim3(R), dim3(128), lds, st>>>(args...);
     else k_sampler_draw<256><<<dim3(R), dim3(256), lds, st>>>(args...);
@@ -630,7 +689,7 @@ int hs_sampler_draw(const float *z, const float *sdf, int32_t ld, int32_t m, con
     if (!z || !sdf || !beta || !out) return HS_ERR_NULL;
     if (m_dev) m = ld;
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
-    launch_draw(R, m, (hipStream_t)stream, z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev, DrawExt{});
+    launch_draw(R, m, 0, (hipStream_t)stream, z, sdf, ld, m, beta, mode, add_tiny, u, n_out, out, R, gate ? *gate : hsGate{nullptr, nullptr}, m_dev, DrawExt{}, TailExt{});
     return check_launch();
 }
 
@@ -653,7 +712,23 @@ int hs_sampler_draw_steps(const float *z, const float *sdf, int32_t ld, const fl
     if (x && (!x01 || !cam_loc || !ray_dirs || divide_factor == 0.f)) return HS_ERR_NULL;
     if (ld < 2 || ld > HS_SAMPLER_MAX_M || (mode != 0 && mode != 1)) return HS_ERR_ARG;
     const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, n_steps, cam_loc, ray_dirs, x, x01, divide_factor};
-    launch_draw(R, ld, (hipStream_t)stream, z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R, hsGate{nullptr, nullptr}, (const int32_t *)nullptr, ext);
+    launch_draw(R, ld, 0, (hipStream_t)stream, z, sdf, ld, ld, beta, mode, add_tiny, u, n_out, out, R, hsGate{nullptr, nullptr}, (const int32_t *)nullptr, ext, TailExt{});
+    return check_launch();
+}
+
+int hs_sampler_tail(const float *z, const float *sdf, int32_t ld, const float *beta, float add_tiny, const float *u, int32_t n_out, float *out, int32_t R,
+                    const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0, int32_t s_new, int32_t max_rounds,
+                    int32_t n_steps, const float *u_pick, const int64_t *pick_in, int32_t n_extra, float near, float far, const float *near_rays,
+                    const float *far_rays, const int64_t *eik_idx, const float *eik_u, float *z_out, float *z_eik, void *stream) {
+    if (n_steps < 1 || n_extra < 0) return HS_ERR_ARG;
+    if (R <= 0 || n_out <= 0) return HS_OK;
+    if (!z || !sdf || !beta || !out || !ctl_in || !ctl_out || !beta_max || !beta0 || !z_out || (z_eik && !eik_idx && !eik_u)) return HS_ERR_NULL;
+    if (ctl_in == ctl_out) return HS_ERR_ARG;
+    // the merged row has at least s_new entries; the tail reuses two m-float scratch arrays for its n = n_out + 2 + n_extra values
+    if (ld < 2 || ld > HS_SAMPLER_MAX_M || n_out + 2 + n_extra > s_new || n_extra > s_new) return HS_ERR_ARG;
+    const DrawExt ext{ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, n_steps, nullptr, nullptr, nullptr, nullptr, 1.f};
+    const TailExt tail{u_pick, pick_in, n_extra, near, far, near_rays, far_rays, eik_idx, eik_u, z_out, z_eik};
+    launch_draw(R, ld, n_extra, (hipStream_t)stream, z, sdf, ld, ld, beta, 1, add_tiny, u, n_out, out, R, hsGate{nullptr, nullptr}, (const int32_t *)nullptr, ext, tail);
     return check_launch();
 }
 

@@ -105,6 +105,10 @@ def zero_pool_armed(device, n=1):
     return buf is not None and buf.device == _pool_device(device) and _ZERO_POOL["pos"] + n <= buf.numel()
 
 
+FLAT_CLAIMS = set()      # data pointers of the flat-gradient views a backward kernel has written since the optimiser's last zero_grad()
+                         # (model/network.py: flat_grad_target; cleared by training/flat.py: FlatAdam.zero_grad)
+
+
 def zeros_small(n, device):
     """n zero floats: from the pool when one is armed on that device and has room, else a fresh torch.zeros."""
     buf, pos = _ZERO_POOL["buf"], _ZERO_POOL["pos"]
@@ -148,7 +152,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -416,6 +420,18 @@ class _HipBackend:
                                          _dev(out, "out"), R, _dev(ctl_in, "ctl_in"), _dev(ctl_out, "ctl_out"), _dev(beta_max, "beta_max"),
                                          _dev(beta0, "beta0"), s_new, max_rounds, n_steps, None, None, ctypes.c_float(1.0), None, None, _stream()),
                "hs_sampler_draw_steps")
+
+    @staticmethod
+    def sampler_tail(z, sdf, beta, add_tiny, u, n_out, out, ctl_in, ctl_out, beta_max, beta0, s_new, max_rounds, n_steps, u_pick, pick_in, n_extra,
+                     near, far, eik_idx, z_out, z_eik, near_rays=None, far_rays=None, eik_u=None):
+        """sampler_draw_steps (final draw) + sampler_pick + sampler_final in one launch (hs_sampler_tail)."""
+        lib = load_library()
+        R, ld = z.shape
+        _check(lib.hs_sampler_tail(_dev(z, "z"), _dev(sdf, "sdf"), ld, _dev(beta, "beta"), ctypes.c_float(add_tiny), _dev(u, "u"), n_out, _dev(out, "out"), R,
+                                   _dev(ctl_in, "ctl_in"), _dev(ctl_out, "ctl_out"), _dev(beta_max, "beta_max"), _dev(beta0, "beta0"), s_new, max_rounds,
+                                   n_steps, _dev(u_pick, "u_pick"), _dev(pick_in, "pick", torch.int64), int(n_extra), ctypes.c_float(near),
+                                   ctypes.c_float(far), _dev(near_rays, "near_rays"), _dev(far_rays, "far_rays"), _dev(eik_idx, "eik_idx", torch.int64),
+                                   _dev(eik_u, "eik_u"), _dev(z_out, "z_out"), _dev(z_eik, "z_eik"), _stream()), "hs_sampler_tail")
 
     @staticmethod
     def sampler_step(ctl, beta_max, beta0, s_new, max_rounds):
@@ -1041,13 +1057,13 @@ class _HipBackend:
         return P
 
     @staticmethod
-    def appearance2_bwd(g_rgb, rgb, normals, masks, streamT, gy, GR1t, GR0t, GFVt, GHCt, d_normals, g_featc, gb2):
+    def appearance2_bwd(g_rgb, rgb, normals, masks, streamT, gy, GR1t, GR0t, GFVt, GHCt, d_normals, g_featc, gb2, normals_add=False):
         lib = load_library()
         bf = torch.bfloat16
         _check(lib.hs_appearance2_bwd(_dev(g_rgb, "g_rgb"), _dev(rgb, "rgb"), _dev(normals, "normals"), _dev(masks, "masks", torch.int32),
                                       _dev(streamT, "streamT", torch.uint8), _dev(gy, "gy", bf), _dev(GR1t, "GR1t", bf), _dev(GR0t, "GR0t", bf),
                                       _dev(GFVt, "GFVt", bf), _dev(GHCt, "GHCt", bf), _dev(d_normals, "d_normals"), _dev(g_featc, "g_featc"),
-                                      _dev(gb2, "gb2"), ctypes.c_int64(g_rgb.shape[0]), _stream()), "hs_appearance2_bwd")
+                                      _dev(gb2, "gb2"), ctypes.c_int64(g_rgb.shape[0]), int(bool(normals_add)), _stream()), "hs_appearance2_bwd")
 
     @staticmethod
     def appearance2_fwd(featc, points, dirs, normals, P, XAt, HCt, FVt, R0t, R1t, masks, rgb):

@@ -557,7 +557,7 @@ class _trunk_render_rr(torch.autograd.Function):
             _be.expect_scatter(ctx.table)
         ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik)
         ctx.cfg = (B, n, L, C, K, S, Hres, jac, W0.shape[1])
-        ctx.bias_dst = [flat_grad_view(b) for b in (b0, b1, b2)]     # bias gradients go straight into the flat gradient buffer when there is one
+        ctx.bias_params = (b0, b1, b2)       # their gradients go straight into the flat gradient buffer when there is one (flat_grad_target)
         ctx.mark_non_differentiable(idx)
         return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
 
@@ -643,16 +643,16 @@ class _trunk_render_rr(torch.autograd.Function):
             else:
                 # the slice sums of every partial stack, the column selection of dW0 / dW2 of both point families and the three bias gradients
                 # (into the flat gradient buffer's views when the biases have them): ONE launch (csrc/small_ops.hip: hs_assemble on bf16 stacks)
-                d0, d1, d2 = ctx.bias_dst
-                dst = lambda d, shape: () if d is None or d.numel() != shape[0] * shape[1] else ((d, None),)  # noqa: E731
+                p0, p1, p2 = ctx.bias_params
+                D1, D0, D2 = _DirectGrad(p1, (1, 256)), _DirectGrad(p0, (1, 256)), _DirectGrad(p2, (1, K))
                 gW1, gW0, gW2, gb1, gb0, gb2 = be.assemble([
                     ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
                     ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
                     ((K, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + ([(w2_part, 256, 0, w2_part.shape[0], 32 * 256)] if eik_live else [])),
-                    ((1, 256), [(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]) + dst(d1, (1, 256)),
-                    ((1, 256), [(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]) + dst(d0, (1, 256)),
-                    ((1, K), [(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)]) + dst(d2, (1, K))])
-                gb1, gb0, gb2 = gb1.view(-1)[...], gb0.view(-1)[...], gb2.view(-1)[...]
+                    D1.job([(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]),
+                    D0.job([(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]),
+                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
+                gb1, gb0, gb2 = D1.grad(gb1, (256,)), D0.grad(gb0, (256,)), D2.grad(gb2, (K,))
         g_emb = None
         if need_table:      # one value+Jacobian scatter for all B points
             table = ctx.table
@@ -975,7 +975,11 @@ class _fused_appearance_wave(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT)
         ctx.cfg = (B, C, L, S, Hres, Wr0.shape[1])
-        ctx.direct_dst = [flat_grad_view(t) for t in (Wc0, bc0, Wc1, bc1, br0, br1, br2)]      # plain parameters of this Function: gradients in place
+        ctx.direct_params = (Wc0, bc0, Wc1, bc1, br0, br1, br2)      # plain parameters of this Function: gradients in place (flat_grad_target)
+        ctx.nrelay = None
+        if _NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is None and ctx.needs_input_grad[2]:
+            _NORMALS_RELAY["key"] = ctx.nrelay_key = normals      # (the contiguous fp32 tensor itself when the caller's was one)
+            ctx.nrelay = _NORMALS_RELAY
         return rgb
 
     @staticmethod
@@ -990,11 +994,14 @@ class _fused_appearance_wave(torch.autograd.Function):
         tp = lambda: torch.empty(tiles * 16 * 512, device=dev, dtype=bf)  # noqa: E731
         gy = torch.empty(B, 32, device=dev, dtype=bf)
         GR1, GR0, GFV, GHC = tp(), tp(), tp(), tp()
-        d_normals = torch.empty(B, 3, device=dev)
         g_featc = torch.empty(L, B, C, device=dev)
         need_w = ctx.needs_input_grad[8]
         gb2 = torch.empty(tiles, 4, device=dev) if need_w else None
-        be.appearance2_bwd(g_rgb.contiguous().float(), rgb, normals, masks, sT, gy, GR1, GR0, GFV, GHC, d_normals, g_featc, gb2)
+        other = None
+        if ctx.nrelay is not None:        # the compositing backward's cotangent of the same normals: this kernel adds into it
+            other, ctx.nrelay["cot"] = ctx.nrelay["cot"], None
+        d_normals = other if other is not None else torch.empty(B, 3, device=dev)
+        be.appearance2_bwd(g_rgb.contiguous().float(), rgb, normals, masks, sT, gy, GR1, GR0, GFV, GHC, d_normals, g_featc, gb2, normals_add=other is not None)
         gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbc0 = gbc1 = gbr0 = gbr1 = gbr2 = None
         if need_w:
             # six products, four of them with the column sums of their cotangent (= the bias gradients) riding along; slices cut by bytes
@@ -1003,16 +1010,31 @@ class _fused_appearance_wave(torch.autograd.Function):
             cut = _pair_slices([(sh, tiles, 1, True) for sh in shapes])
             cs = []
             stacks = be.wgrad_pairs([(sh, c_, pr, None, B) for sh, c_, pr in zip(shapes, cut, prods)], B, colsum_out=cs)
-            sums = be.sum_slices(stacks + [t for t in cs if t is not None])
-            w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0, s_br1, s_br0, s_bc1, s_bc0 = sums
+            # slice sums of the six partial stacks and the four column-sum stacks, the column selections (encodings | features of Wr0, the 32
+            # colour features of Wc0) and the output layer's bias: ONE launch; plain parameters' gradients land in the flat buffer's views
+            k_r2, k_r1, k_r0x, k_r0f, k_c1, k_c0 = stacks
+            c_r1, c_r0, c_c1, c_c0 = cs[1], cs[2], cs[4], cs[5]
             enc_cols, fc_cols = _xa_columns(dev)
             gWr0 = torch.empty(256, ldr0, device=dev)
-            _, _, gWc0, gbr2 = be.assemble([((256, 81), [(w_r0x, 128, enc_cols)], (gWr0, 0)),
-                                            ((256, ldr0 - 81), [(w_r0f, 256, 0)], (gWr0, 81)),
-                                            ((256, 32), [(w_c0, 128, fc_cols)]),
-                                            ((1, 3), [(gb2, 0, 0, tiles, 4)])])
-            gWr2, gbr2 = w_r2[:3], gbr2.view(-1)
-            gbr1, gbr0, gbc1, gbc0 = s_br1, s_br0, s_bc1, s_bc0
+            pWc0, pbc0, pWc1, pbc1, pbr0, pbr1, pbr2 = ctx.direct_params
+            DWc1, DWc0 = _DirectGrad(pWc1, (256, 256)), _DirectGrad(pWc0, (256, 32))
+            Dbr1, Dbr0, Dbc1, Dbc0 = (_DirectGrad(p_, (1, 256)) for p_ in (pbr1, pbr0, pbc1, pbc0))
+            Dbr2 = _DirectGrad(pbr2, (1, 3))
+            stk = lambda t, ld, col: (t, ld, col, t.shape[0], t[0].numel())  # noqa: E731
+            out = be.assemble([((3, 256), [stk(k_r2, 256, 0)]),
+                               ((256, 256), [stk(k_r1, 256, 0)]),
+                               ((256, 81), [stk(k_r0x, 128, enc_cols)], (gWr0, 0)),
+                               ((256, ldr0 - 81), [stk(k_r0f, 256, 0)], (gWr0, 81)),
+                               DWc1.job([stk(k_c1, 256, 0)]),
+                               DWc0.job([stk(k_c0, 128, fc_cols)]),
+                               Dbr1.job([stk(c_r1, 0, 0)]),
+                               Dbr0.job([stk(c_r0, 0, 0)]),
+                               Dbc1.job([stk(c_c1, 0, 0)]),
+                               Dbc0.job([stk(c_c0, 0, 0)]),
+                               Dbr2.job([(gb2, 0, 0, tiles, 4)])])
+            gWr2, gWr1, _, _, gWc1, gWc0, gbr1, gbr0, gbc1, gbc0, gbr2 = out
+            gWc1, gWc0 = DWc1.grad(gWc1, (256, 256)), DWc0.grad(gWc0, (256, 32))
+            gbr1, gbr0, gbc1, gbc0, gbr2 = Dbr1.grad(gbr1, (256,)), Dbr0.grad(gbr0, (256,)), Dbc1.grad(gbc1, (256,)), Dbc0.grad(gbc0, (256,)), Dbr2.grad(gbr2, (3,))
         g_emb = None
         if ctx.needs_input_grad[3]:
             table = ctx.table
@@ -1181,6 +1203,9 @@ class _composite(torch.autograd.Function):
         ctx.sem_scale = float(sem_scale)
         ctx.beta_shape = beta.shape
         # inside iteration_prologue(): the per-ray partials d / d beta go to its relay (summed by hs_iter_epilogue), not through a sum launch
+        # ... and the normal map's cotangent w.r.t. the normals goes to the colour branch's backward kernel, their other consumer, which adds its
+        # own into the same buffer (no `grad += grad` launch): only when that Function registered exactly this tensor
+        ctx.nrelay = _NORMALS_RELAY if (_NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is g and ctx.needs_input_grad[4]) else None
         ctx.relay = None
         if _BETA_RELAY is not None and _BETA_RELAY["key"] is beta and _BETA_RELAY["users"] < 3 and beta.requires_grad:
             ctx.relay = _BETA_RELAY
@@ -1202,6 +1227,9 @@ class _composite(torch.autograd.Function):
         if d_beta is not None and ctx.relay is not None:
             ctx.relay["parts"].append(d_beta)
             d_beta = None
+        if d_g is not None and ctx.nrelay is not None:
+            ctx.nrelay["cot"] = d_g
+            d_g = None
         return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None, None
 
 
@@ -1278,6 +1306,8 @@ def shared_effective_weights(lins):
 # ---- the head and the tail of a training iteration as one launch each (csrc/iter_ops.hip)
 _ITER_PACKS = None      # armed by iteration_prologue(): every packed weight image of the iteration from ONE launch (hs_pack_iteration), keyed by the
                         # identity of the effective matrices they were packed from -- the pack sites below take theirs from here when the keys match
+_NORMALS_RELAY = None   # armed by iteration_prologue(): {"key": the normals tensor both the colour branch and the compositing kernel consume, "cot": ...} --
+                        # _composite.backward leaves the normal map's cotangent there and the colour branch's backward kernel adds its own into it
 _BETA_RELAY = None      # armed by iteration_prologue(): {"key": beta_eff, "parts": [...]} -- _composite.backward leaves its per-ray partial
                         # derivatives w.r.t. beta there instead of launching a sum; _iter_prologue.backward adds them up inside its one launch
 
@@ -1286,6 +1316,44 @@ def flat_grad_view(p):
     """The view of the flat gradient buffer that belongs to parameter p (training/flat.py), or None."""
     v = getattr(p, "_hs_flat_view", None)
     return v if v is not None and v.is_cuda else None
+
+
+def flat_grad_target(p):
+    """Where a backward kernel may put the gradient of parameter p without a copy afterwards: (view of the flat gradient buffer, first) --
+    first = this is the first producer since the optimiser's zero_grad(): it WRITES the view and hands it to autograd as the gradient
+    (adopted as p.grad without a copy); every later producer of the same backward pass (the background-patch iteration evaluates the trunk
+    twice) ACCUMULATES into it and hands autograd nothing.  (None, False): no flat view, or p.grad already holds something else."""
+    v = flat_grad_view(p)
+    if v is None:
+        return None, False
+    key = v.data_ptr()
+    if key in _be.FLAT_CLAIMS:
+        return v, False
+    if p.grad is None:
+        _be.FLAT_CLAIMS.add(key)
+        return v, True
+    return None, False
+
+
+class _DirectGrad:
+    """One hs_assemble job whose result is a parameter's gradient: into the flat view when there is one (flat_grad_target)."""
+
+    def __init__(self, p, shape):
+        self.shape = shape
+        self.d, self.first = flat_grad_target(p) if p is not None else (None, False)
+        if self.d is not None and self.d.numel() != shape[0] * shape[1]:
+            self.d, self.first = None, False
+
+    def job(self, terms):
+        if self.d is None:
+            return (self.shape, list(terms))
+        extra = [] if self.first else [(self.d, self.shape[1], 0)]        # later producers add to what is there
+        return (self.shape, list(terms) + extra, (self.d, None))
+
+    def grad(self, out, like_shape):
+        if self.d is None:
+            return out.view(like_shape)
+        return self.d.view(like_shape)[...] if self.first else None      # (a NEW tensor object on the view: autograd may adopt it as .grad)
 
 
 class _iter_prologue(torch.autograd.Function):
@@ -1303,7 +1371,7 @@ class _iter_prologue(torch.autograd.Function):
         Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam)
         ctx.save_for_backward(b, *vs, *gs)
         ctx.n, ctx.relay, ctx.beta_shape = len(vs), relay, beta.shape
-        ctx.dsts = [flat_grad_view(t) for t in (beta,) + tuple(vg)]
+        ctx.params = (beta,) + tuple(vg)
         return (beta_eff.view(beta.shape),) + tuple(Ws)
 
     @staticmethod
@@ -1311,7 +1379,8 @@ class _iter_prologue(torch.autograd.Function):
         b = ctx.saved_tensors[0]
         vs, gs = ctx.saved_tensors[1:1 + ctx.n], ctx.saved_tensors[1 + ctx.n:]
         gWs = [torch.zeros_like(v) if gW is None else gW.contiguous().float() for v, gW in zip(vs, gWs)]
-        dst = ctx.dsts
+        tg = [flat_grad_target(p) for p in ctx.params]
+        dst = [d if first else None for d, first in tg]         # this Function is the only producer of these gradients: write, or keep out of the view
         fresh = lambda d, like: torch.empty_like(like) if d is None else d.view_as(like)[...]  # noqa: E731   (a NEW tensor object on the flat view: autograd may adopt it as .grad)
         outs = [(fresh(dst[1 + 2 * i], v), fresh(dst[2 + 2 * i], g)) for i, (v, g) in enumerate(zip(vs, gs))]
         parts = list(ctx.relay["parts"]) if ctx.relay is not None else []
@@ -1363,14 +1432,15 @@ def iteration_prologue(model, flat=None, rng_sizes=None):
             n = int(np.prod(shp))
             rng[k] = pool[off:off + n].view(shp)
             off += n
-    global _ITER_PACKS
-    prev_w, prev_relay, prev_beta, prev_packs = _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS
+    global _ITER_PACKS, _NORMALS_RELAY
+    prev_w, prev_relay, prev_beta, prev_packs, prev_nrm = _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY
     _SHARED_W, _BETA_RELAY, dens._shared = {id(l): W for l, W in zip(lins, Ws)}, relay, beta_eff
     _ITER_PACKS = model._pack_iteration()
+    _NORMALS_RELAY = {"key": None, "cot": None}
     try:
         yield rng
     finally:
-        _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS = prev_w, prev_relay, prev_beta, prev_packs
+        _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY = prev_w, prev_relay, prev_beta, prev_packs, prev_nrm
 
 
 def effective_weights(lins):
@@ -2208,12 +2278,12 @@ class HoloSceneNetwork(nn.Module):
         l0, l1, l2 = net._lins()
         if l2.out_features != net.d_out or net.d_out > 32:
             return None
+        grad = torch.is_grad_enabled()          # (the colour branch's backward image only when a backward pass can follow)
         with torch.no_grad():
             W0, W1, W2 = effective_weights([l0, l1, l2])
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
             mlp = net.color_grid_feature_map_mlp
             f = lambda t: t.detach().float().contiguous()  # noqa: E731
-            grad = torch.is_grad_enabled()
             out = _be._backend.pack_iteration(
                 (f(W0), f(l0.bias), f(W1), f(l1.bias), f(W2), f(l2.bias), net.d_out, True, True, self.training),
                 ((mlp[0].weight, mlp[2].weight, R0, R1, R2), (mlp[0].bias, mlp[2].bias, rn.lin0.bias, rn.lin1.bias, rn.lin2.bias), grad))

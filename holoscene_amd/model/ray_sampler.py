@@ -35,6 +35,8 @@ CONTROL = os.environ.get("HOLOSCENE_SAMPLER_CONTROL", "device")
 # device-controlled loop: the next round's draw fused into the update launch, rounds gated on the previous round's max beta ("1"),
 # or one draw + control-step launch per round between control slots ("0")
 FUSE_DRAW = os.environ.get("HOLOSCENE_SAMPLER_FUSE_DRAW", "1") != "0"
+# ... and the tail -- final draw, extra-sample pick, merge / sort -- one launch instead of three (hs_sampler_tail); "0" restores the three
+FUSE_TAIL = os.environ.get("HOLOSCENE_SAMPLER_FUSE_TAIL", "1") != "0"
 
 
 def _rand(shape, device, cpu_rng):
@@ -354,8 +356,11 @@ class ErrorBoundSampler(RaySampler):
                 else:
                     be.sampler_update(z, sdf, r * S, samples, new_sdf, beta, beta0, float(self.eps), int(self.beta_iters), beta_max_all[r:r + 1],
                                       gate=gate)
-            be.sampler_draw_steps(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl_first, ctl_last, beta_max_all, beta0, S, nr, nr)
+            fuse_tail = FUSE_TAIL and n + 2 + self.N_samples_extra <= S
+            if not fuse_tail:
+                be.sampler_draw_steps(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl_first, ctl_last, beta_max_all, beta0, S, nr, nr)
         else:
+            fuse_tail = False
             for r in range(nr):
                 gate, m_dev = (ctl[r, 0:1], ctl[r, 1:2]), ci[r, 2:3]
                 new_sdf = net.sdf_at_points(x, x01, R, S, sel, gate=gate)
@@ -368,16 +373,16 @@ class ErrorBoundSampler(RaySampler):
                                          nr, cam, dirs, df, x, x01)
             be.sampler_draw_step(z, sdf, beta, 1, float(self.add_tiny), u, n, final, ctl[nr - 1], ctl[nr], beta_max_all[nr - 1:nr], beta0, S, nr)
         ctl_end = ctl_last
-        pick = None
+        pick = up = None
         if self.N_samples_extra > 0:
             if "perm" in rng:   # explicit permutation of the (then host-known) merged set: parity tests
                 pick = rng["perm"][: self.N_samples_extra].to(dev).long().contiguous()
             else:
-                pick = torch.empty(self.N_samples_extra, device=dev, dtype=torch.int64)
-                up = None
                 if model.training:
                     up = rng["u_pick"][: self.N_samples_extra].contiguous() if "u_pick" in rng else _rand((self.N_samples_extra,), dev, self.cpu_rng)
-                be.sampler_pick(ctl_end, up, self.N_samples_extra, pick)
+                if not fuse_tail:
+                    pick = torch.empty(self.N_samples_extra, device=dev, dtype=torch.int64)
+                    be.sampler_pick(ctl_end, up, self.N_samples_extra, pick)
         n_out = n + 2 + self.N_samples_extra
         eik_u = None
         if "eik_idx" in rng:
@@ -390,8 +395,12 @@ class ErrorBoundSampler(RaySampler):
             eik = torch.randint(n_out, (R,), device=dev)
         z_out = torch.empty(R, n_out, device=dev)
         z_eik = torch.empty(R, 1, device=dev)
-        be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u,
-                         near_rays=None if bounds is None else bounds[0], far_rays=None if bounds is None else bounds[1])
+        nb, fb = (None, None) if bounds is None else (bounds[0], bounds[1])
+        if fuse_tail:     # final draw + realised loop state + extra-sample pick + merge / sort: one launch (csrc/sampler.hip: hs_sampler_tail)
+            be.sampler_tail(z, sdf, beta, float(self.add_tiny), u, n, final, ctl_first, ctl_last, beta_max_all, beta0, S, nr, nr, up, pick,
+                            self.N_samples_extra, float(self.near), float(self.far), eik, z_out, z_eik, near_rays=nb, far_rays=fb, eik_u=eik_u)
+        else:
+            be.sampler_final(final, z, pick, float(self.near), float(self.far), eik, z_out, z_eik, eik_u=eik_u, near_rays=nb, far_rays=fb)
         net.invalidate_packed_weights()
         self._rounds = ctl_last.view(torch.int32)[3:4]
         return z_out, z_eik

@@ -110,6 +110,7 @@ class FlatAdam:
         launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy."""
         self._g_alloc.zero_()
         _be.set_zero_pool(self._g_alloc[self.padded:])
+        _be.FLAT_CLAIMS.clear()          # no view has been written yet: the first producer of each writes, later ones accumulate
         for p, _ in self.small:
             p.grad = None
 

@@ -206,6 +206,15 @@ int hs_sampler_draw_steps(const float *z, const float *sdf, int32_t ld, const fl
                           float *out, int32_t R, const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max /* [n_steps] */,
                           const float *beta0, int32_t s_new, int32_t max_rounds, int32_t n_steps, const float *cam_loc, const float *ray_dirs,
                           float divide_factor, float *x /* or NULL */, float *x01, void *stream);
+/* hs_sampler_draw_steps (mode 1: the final draw of Algorithm 1) + hs_sampler_pick + hs_sampler_final in ONE launch -- the whole tail of
+ * ErrorBoundSampler.get_z_vals (model/ray_sampler.py:224-280: final inverse-CDF draw, randperm(m)[:n_extra] / linspace extra samples,
+ * cat + sort with near / far, z_samples_eik).  out [R, n_out] receives the drawn depths, z_out [R, n_out + 2 + n_extra] the sorted row,
+ * z_eik [R] (optional) its eik_idx / eik_u-selected entry.  pick_in: explicit extra-sample indices (else drawn from u_pick, or the eval-mode
+ * linspace when that is NULL too).  Requires n_out + 2 + n_extra <= s_new. */
+int hs_sampler_tail(const float *z, const float *sdf, int32_t ld, const float *beta, float add_tiny, const float *u, int32_t n_out, float *out, int32_t R,
+                    const hsSamplerCtl *ctl_in, hsSamplerCtl *ctl_out, const float *beta_max, const float *beta0, int32_t s_new, int32_t max_rounds,
+                    int32_t n_steps, const float *u_pick, const int64_t *pick_in, int32_t n_extra, float near, float far, const float *near_rays,
+                    const float *far_rays, const int64_t *eik_idx, const float *eik_u, float *z_out, float *z_eik, void *stream);
 
 /* hs_sampler_update with the NEXT round's draw fused in (mode 0, u = linspace: ray_sampler.py:206-253 on the set just merged, with
  * the beta just found): out [R, n_out] next depths and, with x != NULL, their positions x / x01 [R*n_out,3] as hs_ray_points writes
@@ -467,10 +476,12 @@ int hs_appearance2_fwd(const float *featc, const float *points, const float *dir
  * pass's masks and rgb.  Outputs: gy [n,32] bf16 row-major (cotangent of the pre-sigmoid outputs, columns 0..2),
  * GR1t, GR0t, GFVt, GHCt tile-packed (pre-activation cotangents of r1, r0, the feature vector, hc), d_normals [n,3], g_featc [16,n,2] fp32
  * (level-major), gb2 [ceil(n / 32), 4] = per-tile partial sums of the last layer's bias gradient (columns 0..2; may be NULL).  The other bias gradients are column sums of the tile-packed
- * cotangents: hs_wgrad_pairs produces them beside the weight gradients (hsWgradPairJob::colsum). */
+ * cotangents: hs_wgrad_pairs produces them beside the weight gradients (hsWgradPairJob::colsum).  normals_add != 0: d_normals already holds the
+ * normals' cotangent from their other consumer (the compositing backward's normal map) and this kernel ADDS its own -- autograd's `grad += grad`
+ * launch for a tensor with two consumers, folded into the store. */
 int64_t hs_appearance2_pack_t_bytes(void);
 int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normals, const uint32_t *masks, const void *streamT_image, void *gy, void *GR1t,
-                       void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, void *stream);
+                       void *GR0t, void *GFVt, void *GHCt, float *d_normals, float *g_featc, float *gb2, int64_t n, int32_t normals_add, void *stream);
 
 /* fp32 master matrices -> bf16 operand images in ONE launch: dst [dst_rows, dst_cols] (row-major bf16) receives the
  * [rows, cols] block of src (leading dimension ld) starting at (row0, col0) -- or, with transpose != 0, its transpose

@@ -154,3 +154,34 @@ def test_iteration_prologue_context_equals_the_separate_contexts():
     assert flat.read_state().step == step0 + 1 and flat._ticked
     flat.end_update()
     assert set(rng) == set(m.uniform_sizes(64)) and all(0.0 <= float(t.min()) and float(t.max()) < 1.0 for t in rng.values())
+
+
+def test_assemble_sums_bf16_partial_stacks_in_the_same_launch():
+    """hs_assemble on the weight-gradient kernels' partial stacks (bf16 [slices, rows, ld]): slice sum + column selection / window /
+    accumulation in one launch == hs_sum_slices followed by the fp32 assembly; quads, scalar units, misaligned windows, wide reductions."""
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    bf = torch.bfloat16
+    st1 = torch.randn(98, 256, 256, generator=g).to(dev).to(bf)
+    st0 = torch.randn(64, 256, 128, generator=g).to(dev).to(bf)
+    st2 = torch.randn(55, 32, 256, generator=g).to(dev).to(bf)
+    w2p = torch.randn(300, 32, 256, generator=g).to(dev)
+    cs1 = torch.randn(98, 256, generator=g).to(dev)
+    acc = torch.randn(544, generator=g).to(dev)
+    cols = torch.randperm(80, generator=g)[:71].to(torch.int32).to(dev)
+    K = 21
+    win = torch.zeros(256, 337, device=dev)
+    flat = torch.zeros(256, device=dev)
+    out = _be().assemble([
+        ((256, 256), [(st1, 256, 0, 98, 65536)]),
+        ((256, 71), [(st0, 128, cols, 64, 256 * 128)]),
+        ((K, 256), [(st2, 256, 0, 55, 32 * 256), (w2p, 256, 0, 300, 32 * 256)]),
+        ((1, 256), [(acc, 0, 0), (cs1, 0, 0, 98, 256)], (flat, None)),
+        ((256, 256), [(st1, 256, 0, 98, 65536)], (win, 81)),
+        ((256, 81), [(st0, 128, 3, 64, 256 * 128)], (win, 0))])
+    s1, s0, s2 = st1.float().sum(0), st0.float().sum(0), st2.float().sum(0)
+    assert torch.allclose(out[0], s1, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(out[1], s0.index_select(1, cols.long()), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(out[2], s2[:K] + w2p.sum(0)[:K], rtol=1e-5, atol=2e-4)
+    assert out[3] is flat and torch.allclose(flat, acc[:256] + cs1.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(win[:, 81:], s1, rtol=1e-5, atol=1e-4) and torch.allclose(win[:, :81], s0[:, 3:84], rtol=1e-5, atol=1e-4)

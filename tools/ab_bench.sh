@@ -1,0 +1,11 @@
+#!/bin/bash
+# Same-box A/B of the default bench between this tree and a second checkout (default .ab_old = the previous round's HEAD, built in place):
+# alternating runs, medians of the regular iteration.   bash tools/ab_bench.sh [other_dir] [runs] [extra bench args]
+OTHER=${1:-.ab_old}; RUNS=${2:-3}; shift 2 2>/dev/null
+ARGS="--no-cpu-baseline --no-second-point --no-fp32-point --steps 200 --warmup 20 --roofline-steps 0 $@"
+cd ${GRAFT_REPO_ROOT:-.}
+for i in $(seq $RUNS); do
+  for d in $OTHER .; do
+    (cd $d && python bench.py $ARGS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$d', d['ms_per_step'], d.get('ms_per_step_median'), round(d['value']))")
+  done
+done
