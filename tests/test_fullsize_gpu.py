@@ -335,3 +335,159 @@ def test_full_size_rough_sdf_sampler_deviation_is_conditioning():
         chk(f"{prec} sampler kernels vs the oracle on the SAME SDF values: fraction outside bracket", own_out, 2.5e-3 if prec == "fp32" else 1e-2)
         chk(f"{prec}: ... relative to the product's deviation from the reference", own_off / max(ref_off, 1e-6), 0.5)
     chk.done()
+
+
+# ------------------------------------------------------------------------------------------------ bf16 gradients with the discontinuities aligned
+def _encode_relu_masks_wave(pre_list, B):
+    """fp32 pre-activations [B, 256] of the colour branch's three ReLU layers -> the mask words k_appear2_fwd writes (appearance2.hip: relu_pair,
+    store_mask): int32 [tiles, 3, 64 lanes, 4 words]; lane (h, row), neuron tile nd, register pair r cover neurons
+    32 nd + 8 (r >> 1) + 4 h + 2 (r & 1) (+1): bit 8 (nd & 1) + r (+16) of word nd >> 1; SET = unit off (negative, or -0)."""
+    tiles = (B + 31) // 32
+    out = np.zeros((tiles, 3, 64, 4), dtype=np.uint32)
+    for layer, pre in enumerate(pre_list):
+        p = pre.detach().float().cpu()
+        off = torch.zeros(tiles * 32, 256, dtype=torch.bool)
+        off[:B] = torch.signbit(p)                  # bf16(x) keeps the sign of x, incl. -0; a value rounding to +-0 keeps it too
+        off = off.view(tiles, 32, 256).numpy()
+        for h in range(2):
+            for nd in range(8):
+                for r in range(8):
+                    na = 32 * nd + 8 * (r >> 1) + 4 * h + 2 * (r & 1)
+                    bit = 8 * (nd & 1) + r
+                    out[:, layer, 32 * h:32 * h + 32, nd >> 1] |= (off[:, :, na].astype(np.uint32) << np.uint32(bit)) | \
+                                                                  (off[:, :, na + 1].astype(np.uint32) << np.uint32(bit + 16))
+    return torch.from_numpy(out.view(np.int32).reshape(-1).copy())
+
+
+def test_full_size_bf16_gradients_with_aligned_discontinuities(monkeypatch):
+    """What is left of the bf16 gradient error once the discontinuities are taken out.  At the benchmarked size the bf16 graph's MLP gradients
+    sit 0.5-5 % (relL2) and its table gradients 4-10 % (element-wise) from the reference's (test above): bounds a dropped term of a few per
+    cent would pass.  The diagnosis -- ReLU units of the colour branch and arg-min hand-overs of the K = 32 SDFs whose fp32 decision lies
+    within the bf16 rounding error of the threshold switch a whole sample's contribution -- is made testable here, on full_c1's state, points
+    (the reference's depths) and realistic cotangents, Function by Function against fp32 autograd through the same product modules:
+      * colour branch (k_appear2_fwd / _bwd, k_wgrad_pairs, hs_assemble, colour-table scatter): the fp32 forward's ReLU signs, encoded in the
+        kernel's own mask layout, replace the masks the bf16 forward wrote;
+      * trunk (k_rr_fwd / k_rr_bwd_*, k_trunk_fwd2 / k_trunk_bwd, k_wgrad_pairs, value+Jacobian scatter): samples whose bf16 arg-min differs
+        from the fp32 one get a zero cotangent on the outputs that depend on the arg-min (the minimum, its gradient) in BOTH runs.
+    Required: every MLP tensor of the colour branch within 1 % relL2 (measured 0.17-0.40 %: 4-7 % on the kernel's own masks), every trunk tensor
+    within 1.5 % (measured <= 1.02 %), every table level norm within 2 % (measured 0.2 %; element-wise the tables agree to 0.45 % / 0.53 % here,
+    against 4 % / 10 % in the end-to-end comparison above -- that remainder is not in the backward kernels: it is the bf16 SDF error, 5e-3,
+    entering the Laplace density through s / beta with beta = 0.01, i.e. the compositing weights the cotangents are built from)."""
+    from holoscene_amd.model import network as N
+    from holoscene_amd.hashencoder import backend as Bk
+    rec = load_full("full_c1")
+    model = build_model(rec, DEV).train()
+    net, rn = model.implicit_network, model.rendering_network
+    ins = _dev(section(rec, "in."))
+    dep = _dev(_reference_depths(rec))
+    rng = _dev(rand_dict(rec))
+    captured = {}
+    orig_rgb_at = model._rgb_at
+
+    def grab(points_flat, dirs_flat, gradients, indices=None, x01=None):
+        captured.update(pts=points_flat.detach(), dirs=dirs_flat.detach(), nrm=gradients.detach())
+        rgb = orig_rgb_at(points_flat, dirs_flat, gradients, indices, x01)
+        rgb.register_hook(lambda g: captured.__setitem__("g_rgb", g.detach().clone()))
+        return rgb
+    model._rgb_at = grab
+    sm = model.ray_sampler
+    sm.get_z_vals = lambda d, o, m, idx=None, **k: (dep["z_vals"], dep["z_eik"]) if idx is None else (dep["bg_z"], None)
+    out = model(ins, torch.tensor([0]), iter_step=3, rng=rng)       # (a regular iteration: no background patch)
+    out["iter_step"] = 3
+    lo = build_loss()(out, _dev(section(rec, "gt.")), call_reg=False)
+    lo["loss"].backward()
+    model.zero_grad(set_to_none=True)
+    pts, dirs, nrm0, cot = captured["pts"], captured["dirs"], captured["nrm"], captured["g_rgb"].reshape(-1, 3).contiguous()
+    B = pts.shape[0]
+    assert B == 1024 * 98
+    chk = Checker("full_c1 aligned")
+    rl2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))  # noqa: E731
+
+    def level_norm_err(a, b, offsets):
+        worst = 0.0
+        for lv, (s_, e_) in enumerate(zip(offsets[:-1], offsets[1:])):
+            nb = float(b[int(s_):int(e_)].double().norm())
+            if nb > 0:
+                worst = max(worst, abs(float(a[int(s_):int(e_)].double().norm()) - nb) / nb)
+        return worst
+    offsets = rec["aux.offsets"]
+    # ---------------------------------------------------------------- colour branch
+    mlp, enc = net.color_grid_feature_map_mlp, net.color_encoding
+    params = [enc.embeddings, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias] + [p for l in (rn.lin0, rn.lin1, rn.lin2)
+                                                                                          for p in (l.weight_v, l.weight_g, l.bias)]
+    names = ["colour table", "c0.w", "c0.b", "c1.w", "c1.b"] + [f"r{i}.{n}" for i in range(3) for n in ("v", "g", "bias")]
+    nrm = nrm0.clone().requires_grad_(True)
+    with torch.no_grad():
+        feat = enc(pts / net.divide_factor)
+        a_hc = feat @ mlp[0].weight.t() + mlp[0].bias
+        fv = torch.relu(a_hc) @ mlp[2].weight.t() + mlp[2].bias
+        emb = rn.embedview_fn
+        x = torch.cat([emb(pts), emb(dirs), emb(nrm0), fv], -1)
+        a_r0 = x @ rn.lin0.weight.t() + rn.lin0.bias
+        a_r1 = torch.relu(a_r0) @ rn.lin1.weight.t() + rn.lin1.bias
+    words32 = _encode_relu_masks_wave([a_hc, a_r0, a_r1], B).to(DEV)
+    rgb = rn(pts, nrm, dirs, net._color_features(pts))
+    ref = [g.float() for g in torch.autograd.grad((rgb * cot).sum(), [nrm] + params)]
+    net.set_mlp_precision("bf16")
+    rn.set_mlp_precision("bf16")
+    be = Bk._backend
+    raw_bwd = be.appearance2_bwd
+    flips = {}
+
+    def with_fp32_masks(g_rgb, rgb_, normals, masks, *a, **k):
+        flips["colour"] = float((masks.view(torch.int32) != words32).float().mean())
+        return raw_bwd(g_rgb, rgb_, normals, words32, *a, **k)
+    monkeypatch.setattr(type(be), "appearance2_bwd", staticmethod(with_fp32_masks))
+    R0, R1, R2 = N.effective_weights([rn.lin0, rn.lin1, rn.lin2])
+    rgb16 = N.fused_appearance(pts, dirs, nrm, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                               float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias,
+                               R2, rn.lin2.bias)
+    got = [g.float() for g in torch.autograd.grad((rgb16 * cot).sum(), [nrm] + params)]
+    monkeypatch.setattr(type(be), "appearance2_bwd", staticmethod(raw_bwd))
+    _report("full_c1 aligned colour branch: fraction of mask WORDS that differ between the bf16 and the fp32 forward", flips["colour"])
+    for a, b, n in zip(got, ref, ["d_normals"] + names):
+        if n == "colour table":
+            chk("colour table worst level-norm rel", level_norm_err(a, b, offsets), 2e-2)
+            _report("full_c1 aligned colour table relL2 (element-wise)", rl2(a, b))
+        else:
+            chk(f"colour {n} relL2", rl2(a, b), 1e-2)
+    # ---------------------------------------------------------------- trunk
+    net.set_mlp_precision("fp32")
+    genc = net.encoding
+    x_all = torch.cat([pts, (torch.rand(4096, 3, device=DEV) * 2 - 1)], 0).contiguous()
+    n_main, Be, K = B, 4096, net.d_out
+    l0, l1, l2 = net._lins()
+    tparams = [genc.embeddings] + [p for l in (l0, l1, l2) for p in (l.weight_v, l.weight_g, l.bias)]
+    tnames = ["geometry table"] + [f"lin{i}.{n}" for i in range(3) for n in ("v", "g", "bias")]
+    g = torch.Generator(device=DEV).manual_seed(7)
+    c_raw = torch.randn(n_main, K, device=DEV, generator=g) * 1e-3
+    c_sdf = torch.randn(n_main, 1, device=DEV, generator=g) * 1e-2
+    c_grad = torch.randn(n_main, 3, device=DEV, generator=g) * 1e-3
+    c_yeik = torch.randn(Be, K, device=DEV, generator=g) * 1e-3
+    c_theta = torch.randn(K * Be, 3, device=DEV, generator=g) * 1e-3          # the K per-object gradient rows (not the arg-min rows)
+    # fp32: value + Jacobian rows through the product's fp32 path
+    y, J = net.sdf_and_jacobian(x_all)
+    y, J = y[:, :K], J[:, :K]
+    sdf32, idx32 = y[:n_main].min(-1, keepdim=True)
+    # bf16 forward first (for its arg-min), without building a graph
+    net.set_mlp_precision("bf16")
+    W0, W1, W2 = N.effective_weights([l0, l1, l2])
+    args = (x_all, n_main, genc.embeddings, genc.offsets, float(np.log2(genc.per_level_scale)), int(genc.base_resolution), net.embedder.multires,
+            float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias)
+    raw16, sdf16, idx16, grad16, yeik16, mineik16, theta16 = N.trunk_render(*args)
+    same = (idx16[:n_main] == idx32).float()
+    _report("full_c1 aligned trunk: fraction of samples whose arg-min differs between bf16 and fp32", 1.0 - float(same.mean()))
+
+    def objective(raw, sdf, grad, yeik, theta_rows):
+        return (raw * c_raw).sum() + (sdf * c_sdf * same).sum() + (grad * c_grad * same).sum() + (yeik * c_yeik).sum() + (theta_rows * c_theta).sum()
+    grad32 = torch.gather(J[:n_main], 1, idx32.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+    theta32 = J[n_main:].transpose(0, 1).reshape(-1, 3)
+    tref = [t.float() for t in torch.autograd.grad(objective(y[:n_main], sdf32, grad32, y[n_main:], theta32), tparams)]
+    tgot = [t.float() for t in torch.autograd.grad(objective(raw16, sdf16, grad16, yeik16, theta16[:K * Be]), tparams)]
+    for a, b, n in zip(tgot, tref, tnames):
+        if n == "geometry table":
+            chk("geometry table worst level-norm rel", level_norm_err(a, b, offsets), 2e-2)
+            _report("full_c1 aligned geometry table relL2 (element-wise)", rl2(a, b))
+        else:
+            chk(f"trunk {n} relL2", rl2(a, b), 1.5e-2)       # measured 0.01-1.02 % (lin1.v, lin1.bias at 1.02 %; the other seven <= 0.92 %)
+    chk.done()
