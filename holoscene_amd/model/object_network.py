@@ -100,6 +100,10 @@ class SingleObjectImplicitNetworkGrid(nn.Module):
         inp = _trunk_input.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                                  self.embedder.multires if self.embedder is not None else 0, float(self.divide_factor), torch.float32,
                                  self._center.to(x.device), self.object_scale)                       # [B,4,71]
+        return self.rows_to_value_and_jacobian(inp)
+
+    def rows_to_value_and_jacobian(self, inp):
+        """The MLP on assembled value + tangent rows [B, 4, 71] (from _trunk_input, or from ObjectSDFNetworkSet's batched lookup)."""
         h = inp
         lins = self._lins()
         for lin in lins[:-1]:
@@ -141,13 +145,13 @@ class SingleObjectRenderingNetwork(RenderingNetwork):
 class ObjectSDFNetwork(nn.Module):
     N_EIK_POINTS = 2048     # network.py:2187
 
-    def __init__(self, center, scale, fg_bg, conf, implicit_kwargs=None):
-        """implicit_kwargs: optional constructor overrides of the implicit network (the reference hard-codes its defaults; the parity
-        fixture uses a small hash table)."""
+    def __init__(self, center, scale, fg_bg, conf, implicit_kwargs=None, rendering_kwargs=None):
+        """implicit_kwargs / rendering_kwargs: optional constructor overrides of the two networks (the reference hard-codes their defaults;
+        the parity fixtures use a small hash table, the eight-object one also narrow layers)."""
         super().__init__()
         self.scene_bounding_sphere = 1.0
         self.implicit_network = SingleObjectImplicitNetworkGrid(object_center=center, object_scale=scale, fg_bg=fg_bg, **(implicit_kwargs or {}))
-        self.rendering_network = SingleObjectRenderingNetwork()
+        self.rendering_network = SingleObjectRenderingNetwork(**(rendering_kwargs or {}))
         self.density = LaplaceDensity(**conf.get_config("density"))
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config("ray_sampler"))
 
@@ -164,7 +168,7 @@ class ObjectSDFNetwork(nn.Module):
         obj_density = self.density(sdf_raw).transpose(0, 1).reshape(-1, dists.shape[0], dists.shape[1])
         return (1 - torch.exp(-dists * obj_density)) * transmittance
 
-    def forward(self, ray_origins, ray_dirs, rng=None):
+    def forward(self, ray_origins, ray_dirs, rng=None, _defer=False):
         """rng: optional explicit draws {'t_rand','u_final','perm','eik_idx' (sampler), 'eik_uniform' [2048,3], 'eik_jitter' [2048+R,3]}."""
         rng = rng or {}
         cam_loc = ray_origins.reshape(-1, 3).contiguous()
@@ -183,7 +187,15 @@ class ObjectSDFNetwork(nn.Module):
         jitter = rng["eik_jitter"].to(dev) if "eik_jitter" in rng else torch.rand_like(eik)
         eik = torch.cat([eik, eik + (jitter - 0.5) * 0.01], 0)
         n_main = points_flat.shape[0]
-        y, J = net.value_and_jacobian(torch.cat([points_flat, eik], 0))
+        prep = (z_vals, points_flat, dirs_flat, torch.cat([points_flat, eik], 0), n_main)
+        if _defer:          # ObjectSDFNetworkSet: the value+Jacobian pass of all its objects shares one hash lookup
+            return prep
+        y, J = net.value_and_jacobian(prep[3])
+        return self._finish(prep, y, J)
+
+    def _finish(self, prep, y, J):
+        z_vals, points_flat, dirs_flat, _, n_main = prep
+        net, dev, N = self.implicit_network, z_vals.device, z_vals.shape[1]
         sdf, feature_vectors, gradients = y[:n_main, :net.d_out], y[:n_main, net.d_out:], J[:n_main].sum(dim=1)
         rgb_flat = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors)
         if z_vals.is_cuda and _net.COMPOSITE_IMPL == "hip":
@@ -201,3 +213,103 @@ class ObjectSDFNetwork(nn.Module):
         half = grad_theta.shape[0] // 2
         return {"object_opacity": object_opacity, "rgb_values": rgb_values, "depth_values": depth_values, "normal_map": normal_map,
                 "opacity": object_opacity, "grad_theta": grad_theta[:half], "grad_theta_nei": grad_theta[half:]}
+
+
+class _trunk_input_grids(torch.autograd.Function):
+    """_trunk_input for the points of SEVERAL objects at once: point b is looked up in table grid_id[b] of a stacked [G, T, C] table, in that
+    object's frame -- ONE batched-over-grids hash launch (csrc/hash_encode.hip: hsHashLayout::grid_id) instead of one per object, and ONE
+    fused value+Jacobian scatter on the way back."""
+
+    @staticmethod
+    def forward(ctx, x, grid_id, tables, offsets, S, H, nfreq, divide_factor, centers, scales):
+        be = _net._be._backend
+        x = x.contiguous()
+        gid = grid_id.long()
+        sc = scales.to(x.device)[gid].unsqueeze(1)                                  # per-point object scale
+        x01 = ((((x - centers.to(x.device)[gid]) / sc) / divide_factor + 1.0) / 2.0).contiguous()
+        B, D = x01.shape
+        G, T, C = tables.shape
+        L = offsets.shape[0] - 1
+        feat = torch.empty(B, L * C, device=x.device)
+        dydx = torch.empty(L, B, D * C, device=x.device)
+        flat = tables.detach().reshape(G * T, C)
+        be.fwd(x01, flat, offsets, feat, B, D, C, L, S, H, dydx, grids=(grid_id, T))
+        jac = (0.5 / (divide_factor * sc)).reshape(1, B, 1)                         # d x01 / d x differs per object
+        dydx.mul_(jac)
+        out = torch.empty(B, 4, 3 + 6 * nfreq + L * C, device=x.device)
+        be.trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, 1.0)
+        ctx.save_for_backward(x01, grid_id, tables, offsets, jac)
+        ctx.cfg = (B, D, C, L, S, H, nfreq, G, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, Gr):
+        be = _net._be._backend
+        x01, grid_id, tables, offsets, jac = ctx.saved_tensors
+        B, D, C, L, S, H, nfreq, G, T = ctx.cfg
+        if not ctx.needs_input_grad[2]:
+            return (None,) * 10
+        g_feat = torch.empty(B, L * C, device=Gr.device)
+        g_dydx = torch.empty(L, B, D * C, device=Gr.device)
+        be.trunk_input_bwd(Gr.contiguous(), g_feat, g_dydx, nfreq, L, C, 1.0)
+        g_dydx.mul_(jac)
+        target = torch.zeros(G * T, C, device=Gr.device)
+        be.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H, grids=(grid_id, T))
+        return None, None, target.view(G, T, C), None, None, None, None, None, None, None
+
+
+class ObjectSDFNetworkSet(nn.Module):
+    """Several ObjectSDFNetworks of one grid geometry evaluated together ("many small hash grids"): their tables live in
+    ONE stacked parameter [G, T, C] (every member's ``implicit_network.encoding.embeddings`` becomes a view of its slice, so the members keep
+    working on their own -- the samplers' SDF sweeps do), and a training pass gathers the value + Jacobian features of ALL objects' rendered and
+    Eikonal points with one batched-over-grids launch and scatters their table gradients with one (``_trunk_input_grids``).  Everything else
+    of a member's forward -- its sampler, its 71 -> 256 -> 256 -> 257 trunk on library GEMMs, rendering network, compositing -- is the
+    member's own code, so each object's outputs and gradients are those of ``ObjectSDFNetwork.forward`` on its rays.
+    (The reference's Stage-2 loop imports ObjectSDFNetwork and never constructs one, training/holoscene_train_post.py:58: the per-object
+    trunks stay on library GEMMs.)"""
+
+    def __init__(self, nets):
+        super().__init__()
+        self.nets = nn.ModuleList(nets)
+        encs = [n.implicit_network.encoding for n in nets]
+        e0 = encs[0]
+        for e in encs:
+            if not torch.equal(e.offsets.cpu(), e0.offsets.cpu()) or e.embeddings.shape != e0.embeddings.shape:
+                raise ValueError("the members' grids must share one level geometry")
+        self.tables = nn.Parameter(torch.stack([e.embeddings.detach() for e in encs]))
+        self._bind()
+
+    def _bind(self):
+        for g, n in enumerate(self.nets):       # the members' tables: views of the stacked parameter's storage (values shared, no copy)
+            n.implicit_network.encoding.embeddings.data = self.tables.data[g]
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._bind()
+        return out
+
+    def table_grads(self):
+        """Per member, the gradient of its table (a view of the stacked gradient)."""
+        return [None if self.tables.grad is None else self.tables.grad[g] for g in range(len(self.nets))]
+
+    def forward(self, ray_origins, ray_dirs, rngs=None):
+        """ray_origins / ray_dirs / rngs: one entry per member -> list of ObjectSDFNetwork.forward's output dictionaries."""
+        rngs = rngs or [None] * len(self.nets)
+        preps = [n(o, d, rng=r, _defer=True) for n, o, d, r in zip(self.nets, ray_origins, ray_dirs, rngs)]
+        xs = [p[3] for p in preps]
+        dev = xs[0].device
+        counts = [x.shape[0] for x in xs]
+        grid_id = torch.cat([torch.full((c,), g, dtype=torch.int32, device=dev) for g, c in enumerate(counts)])
+        nets = [n.implicit_network for n in self.nets]
+        n0, e0 = nets[0], nets[0].encoding
+        centers = torch.stack([n._center.to(dev) for n in nets])
+        scales = torch.tensor([float(n.object_scale) for n in nets], device=dev)
+        inp = _trunk_input_grids.apply(torch.cat(xs, 0).detach(), grid_id, self.tables, e0.offsets, float(np.log2(e0.per_level_scale)),
+                                       int(e0.base_resolution), n0.embedder.multires if n0.embedder is not None else 0, float(n0.divide_factor),
+                                       centers, scales)
+        outs, at = [], 0
+        for n, prep, c in zip(self.nets, preps, counts):
+            y, J = n.implicit_network.rows_to_value_and_jacobian(inp[at:at + c])
+            outs.append(n._finish(prep, y, J))
+            at += c
+        return outs

@@ -635,7 +635,7 @@ def run_hash_stock(name, *, seed, B=1000, L=16, base=16, end=2048, logmap=19, D=
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  touched rows {len(ge_rows)}")
 
 
-def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12):
+def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12, center=(0.1, -0.05, 0.08), scale=0.8, eye=(0.7, 0.0, 0.1), queries=True, width=256, feat=256):
     """the per-object network with its own hash grid -- ObjectSDFNetwork.forward (network.py:2157-2209) over
     SingleObjectImplicitNetworkGrid (:1835-2032) and SingleObjectRenderingNetwork (:2035-2109), plus direct calls of the implicit
     network's query methods.  The reference's ObjectSDFNetwork constructor hard-codes the stock 48.8 MB grid; the object is assembled
@@ -645,12 +645,13 @@ def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12):
     from model.ray_sampler import ErrorBoundSampler
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed + 1)
-    center, scale = torch.tensor([0.1, -0.05, 0.08]), 0.8
+    center = torch.tensor([float(c) for c in center])
     m = object.__new__(ObjectSDFNetwork)
     torch.nn.Module.__init__(m)
     m.scene_bounding_sphere = 1.0
-    m.implicit_network = SingleObjectImplicitNetworkGrid(object_center=center, object_scale=scale, fg_bg=fg_bg, logmap=logmap)
-    m.rendering_network = SingleObjectRenderingNetwork()
+    m.implicit_network = SingleObjectImplicitNetworkGrid(object_center=center, object_scale=scale, fg_bg=fg_bg, logmap=logmap, dims=[width, width],
+                                                         feature_vector_size=feat)
+    m.rendering_network = SingleObjectRenderingNetwork(feature_vector_size=feat, dims=[width, width])
     m.density = LaplaceDensity(params_init=dict(beta=beta), beta_min=0.0001)
     m.ray_sampler = ErrorBoundSampler(1.0, near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10, max_total_iters=5)
     m.train()
@@ -661,10 +662,11 @@ def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12):
         e.copy_((torch.rand(e.shape, generator=g) * 2 - 1) * 2e-2)
     uv, intr, _ = batch(R, 2, 64, seed + 2)
     from utils import rend_util
-    dirs, loc = rend_util.get_camera_params(uv.clone(), look_at_pose((0.7, 0.0, 0.1)), intr)
+    dirs, loc = rend_util.get_camera_params(uv.clone(), look_at_pose(eye), intr)
     d = dirs.reshape(-1, 3)
     o = loc[:, None].repeat(1, R, 1).reshape(-1, 3)
-    rec = {"meta.S": S, "meta.R": R, "meta.logmap": logmap, "meta.fg_bg": int(fg_bg), "meta.scale": np.float64(scale), "meta.center": center.numpy()}
+    rec = {"meta.S": S, "meta.R": R, "meta.logmap": logmap, "meta.fg_bg": int(fg_bg), "meta.scale": np.float64(scale), "meta.center": center.numpy(),
+           "meta.width": width, "meta.feat": feat}
     to_np("state.", m.state_dict(), rec)
     to_np("in.", dict(ray_origins=o, ray_dirs=d), rec)
     with DrawLog() as log:
@@ -679,6 +681,8 @@ def run_object_sdf(name, *, fg_bg, seed, R=20, S=16, beta=0.05, logmap=12):
     sum((out[k] * c).sum() for k, c in cots.items()).backward()
     to_np("cot.", cots, rec)
     to_np("grad.", {k: p.grad for k, p in m.named_parameters() if p.grad is not None}, rec)
+    if not queries:
+        return rec
     # direct queries of the implicit network on points inside and outside the object's cube
     x = torch.rand(40, 3, generator=g) * 2.2 - 1.1
     net = m.implicit_network
@@ -795,6 +799,19 @@ def main():
         run_object_sdf("object_sdf_fg", fg_bg=True, seed=210)
     if sel("object_sdf_bg"):
         run_object_sdf("object_sdf_bg", fg_bg=False, seed=220)
+    if sel("object_set8"):
+        # eight per-object networks (the reference's ObjectSDFNetwork.forward, each on its own rays and draws): what ObjectSDFNetworkSet
+        # evaluates with ONE batched-over-grids hash launch each way must equal them one by one
+        rec = {"meta.n": 8}
+        for i in range(8):
+            ang = 2 * np.pi * i / 8
+            sub = run_object_sdf(f"object_set8[{i}]", fg_bg=(i % 3 != 0), seed=400 + 10 * i, R=12, S=16, beta=0.03 + 0.01 * i, logmap=11,
+                                 center=(0.15 * np.cos(ang), 0.15 * np.sin(ang), 0.05 * (i % 2)), scale=0.6 + 0.05 * i,
+                                 eye=(0.7 * np.cos(ang + 0.3), 0.7 * np.sin(ang + 0.3), 0.1), queries=False, width=64, feat=32)
+            rec.update({f"o{i}.{k}": v for k, v in sub.items()})
+        path = os.path.join(HERE, "object_set8.npz")
+        np.savez_compressed(path, **rec)
+        print(f"object_set8: {os.path.getsize(path) / 1024:.0f} KiB")
     if sel("hash_small"):
         run_hash("hash_small", L=4, base=4, end=32, logmap=10, B=300, seed=0)
     if sel("hash_mid"):

@@ -155,6 +155,14 @@ def test_per_object_networks_match_reference(name):
     check_object_model(load(name), "cpu", strict=True)
 
 
+@pytest.mark.parametrize("i", [0, 3, 7])
+def test_eight_object_fixture_members_match_reference_one_by_one(i):
+    """tests/golden/object_set8.npz: eight of the reference's ObjectSDFNetwork.forward, each with its own centre, scale, initialisation, rays
+    and draws (what ObjectSDFNetworkSet evaluates together on the GPU, tests/test_model_gpu.py): a member through the single-object class."""
+    from object_helpers import check_object_model, sub_record
+    check_object_model(sub_record(load("object_set8"), i), "cpu", strict=True, queries=False)
+
+
 # ------------------------------------------------------------------------------------ host logic added in round 3
 def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
     """_pair_slices: the jobs of one hs_wgrad_pairs launch get workgroups in proportion to their (costed) bytes, the counts add up to the budget,

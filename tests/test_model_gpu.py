@@ -1416,6 +1416,53 @@ def test_per_object_networks_match_reference(name):
     check_object_model(load(name), DEV, strict=False)
 
 
+def test_eight_per_object_networks_through_one_batched_hash_launch_each_way(monkeypatch):
+    """SURVEY 8(f) rank 3, "many small hash grids": ObjectSDFNetworkSet evaluates EIGHT per-object networks (fixture object_set8: the imported
+    reference's ObjectSDFNetwork.forward, one by one) with ONE batched-over-grids hash gather for all their rendered + Eikonal points and ONE
+    fused value+Jacobian scatter for all their table gradients (csrc/hash_encode.hip: hsHashLayout::grid_id).  Every member's outputs and
+    parameter gradients must be the reference's, the members' tables must be views of the stacked parameter, and the launch counts must be 1 / 1."""
+    from object_helpers import build_object_model, compare_forward_backward, sub_record
+    from holoscene_amd.model.object_network import ObjectSDFNetworkSet
+    from holoscene_amd.hashencoder import backend as Bk
+    rec = load("object_set8")
+    n = int(rec["meta.n"])
+    subs = [sub_record(rec, i) for i in range(n)]
+    nets = [build_object_model(r, DEV).train() for r in subs]
+    group = ObjectSDFNetworkSet(nets).to(DEV)
+    for g_, m in enumerate(nets):
+        assert m.implicit_network.encoding.embeddings.data_ptr() == group.tables[g_].data_ptr()
+        assert torch.equal(m.implicit_network.encoding.embeddings.cpu(), torch.from_numpy(subs[g_]["state.implicit_network.encoding.embeddings"]))
+    be = Bk._backend
+    calls = {"fwd_grids": 0, "fwd_dydx_single": 0, "jac_grids": 0, "jac_single": 0}
+    raw_fwd, raw_jac = be.fwd, be.bwd_jac
+
+    def fwd(*a, **k):
+        if k.get("grids") is not None:
+            calls["fwd_grids"] += 1
+        elif a[10] is not None:         # a per-object lookup WITH derivatives would be a member's own value+Jacobian pass
+            calls["fwd_dydx_single"] += 1
+        return raw_fwd(*a, **k)
+
+    def jac(*a, **k):
+        calls["jac_grids" if k.get("grids") is not None else "jac_single"] += 1
+        return raw_jac(*a, **k)
+    monkeypatch.setattr(type(be), "fwd", classmethod(lambda cls, *a, **k: fwd(*a, **k)))
+    monkeypatch.setattr(type(be), "bwd_jac", classmethod(lambda cls, *a, **k: jac(*a, **k)))
+    dv = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    ins = [dv(section(r, "in.")) for r in subs]
+    outs = group([i_["ray_origins"] for i_ in ins], [i_["ray_dirs"] for i_ in ins], [dv(section(r, "rand.")) for r in subs])
+    loss = 0.0
+    for out, r in zip(outs, subs):
+        loss = loss + sum((out[k] * c.to(DEV)).sum() for k, c in section(r, "cot.").items())
+    loss.backward()
+    assert calls == {"fwd_grids": 1, "fwd_dydx_single": 0, "jac_grids": 1, "jac_single": 0}, calls
+    tg = group.table_grads()
+    for g_, (m, out, r) in enumerate(zip(nets, outs, subs)):
+        grads = {k: p.grad for k, p in m.named_parameters()}
+        grads["implicit_network.encoding.embeddings"] = tg[g_]           # the member's table gradient lives in the stacked parameter's
+        compare_forward_backward(out, grads, r, strict=False)
+
+
 def test_opt_in_finite_difference_eikonal_mode():
     """BASELINE configs[4] words a "4-tap Eikonal finite-difference"; the reference's gradients are analytic, so the FD
     form is an opt-in extra (model conf `eikonal_mode = fd`, fp32 only): on a smooth state it agrees with the analytic rows to O(h^2),
