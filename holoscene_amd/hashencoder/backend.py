@@ -152,7 +152,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -555,6 +555,36 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp2_pack(_dev(W0, "W0"), int(W0.stride(0)), _dev(b0, "b0"), _dev(W1, "W1"), _dev(b1, "b1"), _dev(W2, "W2"), _dev(b2, "b2"),
                                     d_out, *[_dev(b, "frag", torch.bfloat16) for b in bufs], _dev(bias, "bias"), int(log2_domain), _stream()), "hs_sdf_mlp2_pack")
         return (*bufs, bias)
+
+    @staticmethod
+    def sdf_mlp32_pack(W0, b0, W1, b1, W2, b2, d_out):
+        """fp32 effective matrices -> (W0i, W1i, bias): the fp32 operand images of csrc/sdf_mlp32.hip (reduction order permuted to the
+        accumulator layout, one block per 32-neuron tile)."""
+        lib = load_library()
+        lib.hs_sdf_mlp32_pack_bytes.restype = ctypes.c_int64
+        dev = W0.device
+        bufs = [torch.empty(int(lib.hs_sdf_mlp32_pack_bytes(i)) // 4, device=dev) for i in range(3)]
+        if W0.stride(1) != 1 or W0.stride(0) < 71:
+            raise RuntimeError("sdf_mlp32_pack: W0 must be row-major with at least 71 columns")
+        _check(lib.hs_sdf_mlp32_pack(_dev(W0, "W0"), int(W0.stride(0)), _dev(b0, "b0"), _dev(W1, "W1"), _dev(b1, "b1"), _dev(W2, "W2"), _dev(b2, "b2"),
+                                     int(d_out), *[_dev(b, "image") for b in bufs], _stream()), "hs_sdf_mlp32_pack")
+        return tuple(bufs)
+
+    @staticmethod
+    def sdf_mlp32_fwd(x, feat, packed, d_out, select, out_min, out_raw, gate=None, feat_level_major=False):
+        """hs_sdf_mlp32_fwd: the SDF trunk on fp32 operands (the reference's own arithmetic); arguments as sdf_mlp2_fwd, features fp32 only."""
+        lib = load_library()
+        mask = 0
+        if isinstance(select, (list, tuple)):
+            if not select or min(select) < 0 or max(select) >= d_out:
+                raise ValueError(f"object subset {select!r} outside [0, {d_out})")
+            for k in select:
+                mask |= 1 << int(k)
+            select = -1
+        W0i, W1i, bias = packed
+        _check(lib.hs_sdf_mlp32_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev(W0i, "W0i"), _dev(W1i, "W1i"), _dev(bias, "bias"), int(d_out),
+                                    int(select), ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"), ctypes.c_int64(x.shape[0]),
+                                    ctypes.byref(_gate(gate)), int(bool(feat_level_major)), _stream()), "hs_sdf_mlp32_fwd")
 
     @staticmethod
     def sdf_mlp2_fwd(x, feat, packed, d_out, select, out_min, out_raw, gate=None, feat_level_major=False):

@@ -143,6 +143,8 @@ TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 # inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
 # activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
 SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
+# the no-grad SDF queries of the fp32 configuration: "mfma" = csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32), "gemm" = library GEMMs
+FP32_SDF = os.environ.get("HOLOSCENE_FP32_SDF", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
 # weight gradients of the fused MLPs: "hip" = csrc/wgrad.hip (all products of a backward stage in one launch), "gemm" = library batched GEMMs
 WGRAD_IMPL = os.environ.get("HOLOSCENE_WGRAD_IMPL", "hip")
@@ -1623,7 +1625,16 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return getattr(enc, "num_levels", None) == 16 and getattr(enc, "level_dim", None) == 2 and getattr(enc, "input_dim", 3) == 3
 
     def _fused_sdf_supported(self, x):
-        return not torch.is_grad_enabled() and self._fused_trunk_supported(x)
+        return not torch.is_grad_enabled() and (self._fused_trunk_supported(x) or self._fused_sdf32_supported(x))
+
+    def _fused_sdf32_supported(self, x):
+        """The no-grad SDF queries of the fp32 configuration through csrc/sdf_mlp32.hip (fp32 operands on the fp32 matrix cores): the stock
+        trunk shape, d_out <= 32.  HOLOSCENE_FP32_SDF=gemm keeps the library GEMMs."""
+        lins = self._lins()
+        return (FP32_SDF == "mfma" and not self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None and self.embedder.multires == 6
+                and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].in_features == 71 and lins[0].out_features == 256
+                and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features == self.d_out <= 32
+                and not any(l in self.skip_in for l in range(3)))
 
     def _packed_weights(self):
         """bf16 images of the three weight-normalised matrices in the layout csrc/sdf_mlp.hip reads (rebuilt per call:
@@ -1659,11 +1670,24 @@ class ObjectImplicitNetworkGrid(nn.Module):
                                                          f2.detach().float().contiguous(), l2.bias.detach().float().contiguous(), l2.out_features)
         return self._packed_cache2
 
+    def _packed_weights32(self):
+        """fp32 operand images of csrc/sdf_mlp32.hip, one pack launch per parameter state."""
+        if getattr(self, "_packed_cache32", None) is not None:
+            return self._packed_cache32
+        l0, l1, l2 = self._lins()
+        with torch.no_grad():
+            f0, f1, f2 = effective_weights([l0, l1, l2])
+        c = lambda t: t.detach().float().contiguous()  # noqa: E731
+        self._packed_cache32 = _be._backend.sdf_mlp32_pack(c(f0), c(l0.bias), c(f1), c(l1.bias), c(f2), c(l2.bias), l2.out_features)
+        return self._packed_cache32
+
     def _sdf_mlp(self, x, feat, d_out, select, out, raw, gate, lm):
         # lm: False = fp32 [B, 32], True = fp32 [16, B, 2], 2 = int32 [16, B] bf16 words (wave-tile kernel only)
         """The fused SDF trunk on already gathered hash features: wave-tile kernel for d_out <= 32, workgroup-tile kernel otherwise."""
         be = _be._backend
-        if SDF_MLP_IMPL == "wave" and d_out <= 32:
+        if not self.mlp_bf16:      # fp32 operands on the fp32 matrix cores (csrc/sdf_mlp32.hip)
+            be.sdf_mlp32_fwd(x, feat, self._packed_weights32(), d_out, select, out, raw, gate=gate, feat_level_major=bool(lm))
+        elif SDF_MLP_IMPL == "wave" and d_out <= 32:
             be.sdf_mlp2_fwd(x, feat, self._packed_weights2(), d_out, select, out, raw, gate=gate, feat_level_major=lm)
         elif SDF_MLP_IMPL in ("wave", "tile"):
             w0, b0, w1, b1, w2, b2 = self._packed_weights()
@@ -1675,6 +1699,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         """The packed bf16 images are valid for one parameter state; the sampler drops them at the start of every call."""
         self._packed_cache = None
         self._packed_cache2 = None
+        self._packed_cache32 = None
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
         """min_k sdf_k (select -1), sdf_select (int) or the minimum over an object list [B,1] (and raw [B, d_out]) through csrc/sdf_mlp.hip."""
@@ -1718,7 +1743,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         d_out = self._lins()[2].out_features
         # ... and as bf16 words [L, R*S] when the wave-tile trunk kernel follows: it rounds the features to bf16 anyway (same rounding:
         # identical results), so the gather writes and the trunk reads half the bytes
-        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= 32 and enc.embeddings.shape[1] == 2
+        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= 32 and enc.embeddings.shape[1] == 2 and self.mlp_bf16
         if words:
             feat = torch.empty(L, R * S, device=dev, dtype=torch.int32)
             be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,

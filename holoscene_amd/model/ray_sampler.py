@@ -35,6 +35,8 @@ CONTROL = os.environ.get("HOLOSCENE_SAMPLER_CONTROL", "device")
 # device-controlled loop: the next round's draw fused into the update launch, rounds gated on the previous round's max beta ("1"),
 # or one draw + control-step launch per round between control slots ("0")
 FUSE_DRAW = os.environ.get("HOLOSCENE_SAMPLER_FUSE_DRAW", "1") != "0"
+# fp32 configuration: with the fused fp32 SDF sweep (csrc/sdf_mlp32.hip, gated launches) the loop control can live on the device there too
+FP32_DEVICE_CONTROL = os.environ.get("HOLOSCENE_FP32_DEVICE_CONTROL", "1") != "0"
 # ... and the tail -- final draw, extra-sample pick, merge / sort -- one launch instead of three (hs_sampler_tail); "0" restores the three
 FUSE_TAIL = os.environ.get("HOLOSCENE_SAMPLER_FUSE_TAIL", "1") != "0"
 
@@ -171,8 +173,9 @@ class ErrorBoundSampler(RaySampler):
     def device_control_ok(self, model, idx=None):
         net = model.implicit_network
         ok_idx = idx is None or isinstance(idx, int) or (isinstance(idx, (list, tuple)) and len(idx) > 0 and all(isinstance(k, int) for k in idx))
-        return (CONTROL == "device" and SAMPLER_IMPL == "hip" and ok_idx and getattr(net, "color_grid_feature", False)
-                and hasattr(net, "_fused_trunk_supported") and net._fused_trunk_supported(net.encoding.embeddings))
+        fused = hasattr(net, "_fused_trunk_supported") and (net._fused_trunk_supported(net.encoding.embeddings)
+                                                              or (FP32_DEVICE_CONTROL and net._fused_sdf32_supported(net.encoding.embeddings)))
+        return CONTROL == "device" and SAMPLER_IMPL == "hip" and ok_idx and getattr(net, "color_grid_feature", False) and fused
 
     def _query_sdf(self, model, points, idx):
         net = model.implicit_network

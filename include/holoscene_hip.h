@@ -385,6 +385,17 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);
 
+/* The same function on FP32 operands (csrc/sdf_mlp32.hip: v_mfma_f32_32x32x2_f32, fp32 activations in registers, torch.nn.Softplus(beta = 100)
+ * by expf / log1pf) -- the reference's own arithmetic (training/holoscene_train.py:45: no autocast) for the sampler sweeps of the fp32
+ * configuration.  Images: hs_sdf_mlp32_pack_bytes(0..2) bytes for W0i, W1i (W1's tiles, each followed by its slice of W2), bias; features fp32, point-major [B, 32]
+ * (feat_level_major = 0) or level-major [16, B, 2] (1); every other argument as hs_sdf_mlp2_fwd. */
+int64_t hs_sdf_mlp32_pack_bytes(int32_t which);
+int hs_sdf_mlp32_pack(const float *W0, int32_t ld0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
+                      float *W0i, float *W1i, float *bias, void *stream);
+int hs_sdf_mlp32_fwd(const float *x, const float *feat, const float *W0i, const float *W1i, const float *bias, int32_t d_out,
+                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
+                     void *stream);
+
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
  * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).
  *   X  [M, 96] bf16: hs_trunk_input_fwd output with pitch 96 (M = 4 * points, M % 4 == 0)

@@ -1542,3 +1542,46 @@ def test_colour_branch_wave_tile_kernels_are_run_to_run_identical_at_full_size()
         diff = [k for k in first if not torch.equal(first[k].view(torch.int16) if first[k].dtype == bf else first[k],
                                                     again[k].view(torch.int16) if again[k].dtype == bf else again[k])]
         assert not diff, f"run {run + 1} differs from run 0 in {diff}"
+
+
+@pytest.mark.parametrize("B,d_out", [(131072, 32), (1000, 21), (33, 5)])
+def test_fp32_fused_sdf_sweep_vs_library_gemms(B, d_out, monkeypatch):
+    """csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32, fp32 activations in registers, torch's Softplus formula) against the same
+    queries through library GEMMs (the reference's arithmetic, model/network.py:169-210, 305-326): the minimum over all objects, one object,
+    an object subset, the raw SDFs; points inside and outside the cube; ragged sizes; gated launches."""
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=2048).to(DEV)
+    net.set_mlp_precision("fp32")
+    with torch.no_grad():
+        net.encoding.embeddings.uniform_(-0.3, 0.3)
+        v = net.lin0.weight_v
+        v[:, 3:] = torch.randn_like(v[:, 3:]) * 0.05
+        net.lin2.weight_v.add_(0.05 * torch.randn_like(net.lin2.weight_v))
+        net.lin2.bias.add_(0.1 * torch.randn_like(net.lin2.bias))
+    x = torch.rand(B, 3, device=DEV) * 2.3 - 1.15
+    sub = [0, d_out - 1, d_out // 2]
+    with torch.no_grad():
+        assert net._fused_sdf32_supported(x)
+        got = {"min": net.get_sdf_vals(x), "raw": net.get_sdf_raw(x), "one": net.get_object_sdf_vals(x, d_out - 2), "sub": net.get_multi_object_sdf_vals(x, sub)}
+        net.invalidate_packed_weights()
+        monkeypatch.setattr(N, "FP32_SDF", "gemm")
+        assert not net._fused_sdf32_supported(x)
+        ref = {"min": net.get_sdf_vals(x), "raw": net.get_sdf_raw(x), "one": net.get_object_sdf_vals(x, d_out - 2), "sub": net.get_multi_object_sdf_vals(x, sub)}
+        monkeypatch.setattr(N, "FP32_SDF", "mfma")
+    for k in got:
+        assert got[k].shape == ref[k].shape, k
+        err = float((got[k] - ref[k]).abs().max())
+        print(f"PARITY fp32 fused SDF sweep B={B} K={d_out} {k}: max abs err {err:.3e} (max |sdf| {float(ref[k].abs().max()):.2f})")
+        assert err < 2e-5, (k, err)         # two fp32 implementations of the same 71 -> 256 -> 256 -> K sums (summation order differs)
+    # gated launch: a closed gate leaves the output untouched
+    with torch.no_grad():
+        R, S = 8, B // 8
+        if S > 0:
+            xx = x[:R * S].contiguous()
+            x01 = ((xx / net.divide_factor + 1.0) / 2.0).contiguous()
+            a, b = torch.tensor([1.0], device=DEV), torch.tensor([2.0], device=DEV)
+            closed = net.sdf_at_points(xx, x01, R, S, gate=(a, b))           # a > b is false: nothing runs (outputs are whatever empty() held)
+            opened = net.sdf_at_points(xx, x01, R, S, gate=(b, a))
+            assert closed.shape == opened.shape and torch.equal(opened.reshape(-1, 1), got["min"][:R * S])
