@@ -327,13 +327,18 @@ def test_full_size_rough_sdf_sampler_deviation_is_conditioning():
         own_off, own_out = _depth_stats(z_prod, z_orc, atol, br)
         _report(f"full_c1 product {prec} sampler vs the fixture: fraction off by more than {atol:g}", ref_off)
         _report(f"full_c1 product {prec} sampler vs the fixture: fraction outside bracket", ref_out)
-        # (2), measured: fp32 3.7 % off by more than 1e-5 (0.15 % outside the bracket) where the product is 11.5 % (0.64 %) from the reference;
+        # (2), measured: fp32 3.9 % off by more than 1e-5 (0.12 % outside the bracket) where the product is 6.6 % (0.24 %) from the reference;
         # bf16 3.9 % off by more than 1e-3 (0.6 %) against 35 % (5.9 %).  What remains with identical SDF values in is the same conditioning acting
         # on last-bit differences INSIDE the sampler (device expf / the association of its cumulative sums): step (1) moves 7 % of the depths
         # with one ulp of SDF.  Bounds = 1.5x measured.
         chk(f"{prec} sampler kernels vs the oracle on the SAME SDF values: fraction off by more than {atol:g}", own_off, 0.055 if prec == "fp32" else 0.06)
         chk(f"{prec} sampler kernels vs the oracle on the SAME SDF values: fraction outside bracket", own_out, 2.5e-3 if prec == "fp32" else 1e-2)
-        chk(f"{prec}: ... relative to the product's deviation from the reference", own_off / max(ref_off, 1e-6), 0.5)
+        if prec == "fp32":      # with the SDF sweeps on csrc/sdf_mlp32.hip the product's fp32 depths are AS close to the reference's as the oracle's own
+                                # are after one ulp of SDF perturbation (measured 6.6 % against 7.0 %; through library GEMMs it was 11.5 %)
+            chk("fp32 product vs the fixture, relative to the oracle's own sensitivity (+-1 ulp SDF / another host)", ref_off / max(ulp_off, base_off, 1e-4), 1.5)
+            chk("fp32 product vs the fixture, outside bracket, relative to the same (floor 1e-3)", ref_out / max(ulp_out, base_out, 1e-3), 2.0)
+        else:
+            chk(f"{prec}: ... relative to the product's deviation from the reference", own_off / max(ref_off, 1e-6), 0.5)
     chk.done()
 
 
