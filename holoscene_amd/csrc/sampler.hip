@@ -654,7 +654,11 @@ static int sampler_update_launch(float *z, float *sdf, int32_t ld, int32_t m_old
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_dev ? ld : m_old + s_new;   // device-side count: size the scratch for the row capacity
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
-    static const int nt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_THREADS"); const int v = e ? atoi(e) : kUpd; return v == 64 || v == 128 || v == 512 ? v : 256; }();
+    static const int nt_env = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 || v == 512 ? v : 0; }();
+    // threads per ray by the size of the merged set unless the environment pins them: the early rounds hold 128 / 256 sections -- with 256 threads half
+    // of them idle through 33 barrier rounds of the line search; one or two waves scan those without (or with fewer) cross-wave steps
+    static const int adapt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_ADAPT"); return e ? atoi(e) : 0; }();
+    const int nt = nt_env ? nt_env : (adapt && !m_dev ? (m <= adapt ? 64 : (m <= 2 * adapt ? 128 : 256)) : 256);
     const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
     const size_t lds = (6 * m + 3 * 8) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

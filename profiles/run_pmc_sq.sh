@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-fp32-point --no-graph --steps 3 --warmup 2 > $OUT/bench_$i.log 2>&1 || true
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-fp32-point --no-trajectory-point --no-graph --steps 3 --warmup 2 > $OUT/bench_$i.log 2>&1 || true
 done
 python - <<PY
 import csv, glob, collections
@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for fn in glob.glob('/tmp/pmc_${TAG}_*/*counter_collection.csv'):
     for r in csv.DictReader(open(fn)):
         k = r['Kernel_Name']
-        if not any(t in k for t in ('k_sdf_mlp', 'k_sdf_mlp2', 'k_trunk_fwd', 'k_trunk_bwd', 'k_appear', 'k_rr_', 'k_wgrad', 'k_hash_fwd', 'k_hash_bwd_jac', 'k_hash_bin_reduce', 'k_sampler_update', 'k_composite')):
+        if not any(t in k for t in ('k_sdf_mlp', 'k_sdf_mlp2', 'k_assemble', 'k_iter_', 'k_pack_iteration', 'k_draw_gather', 'k_sampler_draw', 'k_trunk_fwd', 'k_trunk_bwd', 'k_appear', 'k_rr_', 'k_wgrad', 'k_hash_fwd', 'k_hash_bwd_jac', 'k_hash_bin_reduce', 'k_sampler_update', 'k_composite')):
             continue
         k = k.replace('void ', '', 1).replace('(anonymous namespace)::', '').split('(')[0]
         a = agg[k][r['Counter_Name']]
