@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int hs_abi_version(void) { return 6; }
+int hs_abi_version(void) { return 7; }
 
 const char *hs_target_arch(void) { return "gfx950"; }
 

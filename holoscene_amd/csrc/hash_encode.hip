@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "holoscene_hip.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -423,6 +424,7 @@ __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const Level
 // contributes) their atomics were the tail of the launch (418 us of hs_hash_bwd_jac at beta = 0.1, 251 us since they are binned too:
 // bins = slabs of ceil(res^3 / kBins) cells).  Records that do not fit the bin's capacity fall back to atomics.
 constexpr uint32_t kBins = HS_SCATTER_BINS;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4 096 cells x 2 floats; five workgroups per CU hide each other's latency
 
 template <int C>
@@ -580,6 +582,140 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
             t[k].x += a.x; t[k].y += a.y; t[k].z += a.z; t[k].w += a.w;
             dst[j] = t[k];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------ reduce-and-step (hsTableStep)
+// The owner of a bin holds the FINAL gradient of its cells in LDS when this scatter is the table's only gradient producer of the
+// iteration: it takes the Adam step there.  Against k_hash_bin_reduce + the table's share of k_adam_flat + the zero-fill of the gradient
+// table this removes, per table and iteration, one 48.8 MB write (zero-fill), one read-modify-write of the touched quads (reduce) and
+// one 48.8 MB read (the optimiser's g stream): what is left is the optimiser's own minimum, 3 reads + 3 writes per parameter.
+// Every (level, bin) workgroup steps ALL its cells (dense Adam: an entry without a gradient decays its moments and still moves);
+// levels that are not binned, and overflowed bins, add what the scatter put into `gemb` with atomics and return those floats to zero.
+template <int D, int C>
+__global__ __launch_bounds__(512) void k_hash_bin_step(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
+                                                        hsHashLayout lay, hsTableStep ts) {
+    extern __shared__ float acc[];
+    const uint32_t level = blockIdx.y, bin = blockIdx.x;
+    const LevelInfo li = level_info<D>(offsets, level, sc);
+    const hsAdamState *st = ts.state;
+    const float step_size = st->step_size[ts.group], bc2_sqrt = st->bc2_sqrt;
+    const bool binned = binned_level<C>(li, lay.scatter_ws);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
+    const uint32_t per_bin = bin_width<C>(li), first = bin * per_bin;
+    const uint32_t total = binned ? counts[level * kBins + bin] : 0u;
+    const uint32_t n = binned ? min(total, lay.scatter_cap) : 0u;
+    const bool spilled = !binned || total > lay.scatter_cap;      // `gemb` may hold contributions to this bin's cells
+    if (first >= li.table) {                                     // (dense levels: bins past the end of the table hold nothing)
+        __syncthreads();
+        if (binned && threadIdx.x == 0) counts[level * kBins + bin] = 0u;
+        return;
+    }
+    const uint32_t nfl = min(per_bin, li.table - first) * C;     // floats of the table this bin covers
+    const size_t e0 = ((size_t)li.offset + (size_t)first) * C;
+    float *G = gemb + e0, *P = ts.p + e0, *M = ts.m + e0, *V = ts.v + e0;
+    if (!binned) {                                               // (a slab of a level that went through atomics alone: no LDS stage)
+        for (uint32_t j = threadIdx.x; j < nfl; j += blockDim.x) {
+            const float g = G[j];
+            if (g != 0.f) G[j] = 0.f;
+            float pp = P[j], mm = M[j], vv = V[j];
+            adam1(pp, g, mm, vv, step_size, bc2_sqrt, ts.beta1, ts.beta2, ts.eps, ts.grad_scale);
+            P[j] = pp; M[j] = mm; V[j] = vv;
+        }
+        return;
+    }
+    const BinRecord<C> *records = reinterpret_cast<const BinRecord<C> *>(reinterpret_cast<const char *>(lay.scatter_ws) +
+                                                                          HS_MAX_LEVELS * kBins * sizeof(uint32_t)) +
+                                  ((size_t)level * kBins + bin) * lay.scatter_cap;
+    const uint32_t nvec = per_bin * C / 4;                       // bin_width: a whole number of float4
+    float4 *acc4 = reinterpret_cast<float4 *>(acc);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(M) |
+                          reinterpret_cast<uintptr_t>(V)) & 15) == 0 && nfl == per_bin * C;
+    constexpr int kV = 4;                                        // kReduceLds / 16 B = 2 048 quads = kV x 512 threads: one pass
+    // parameter and moments of this thread's quads do not depend on the records: requested now, they arrive under the record phase
+    f32x4 tp[kV], tm[kV], tv[kV];
+    if (vec_ok) {
+#pragma unroll
+        for (int k = 0; k < kV; k++) {
+            const uint32_t j = threadIdx.x + k * blockDim.x;
+            if (j < nvec) {
+                tp[k] = reinterpret_cast<const f32x4 *>(P)[j];
+                tm[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(M) + j);
+                tv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(V) + j);
+            }
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[level * kBins + bin] = 0u;      // (everybody has read it) clean for the next scatter: hsHashLayout::ws_clean
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * blockDim.x < n; i += 4 * blockDim.x) {
+        BinRecord<C> r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = records[i + k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < C; c++) atomicAdd(&acc[r[k].cell * C + c], r[k].v[c]);
+    }
+    for (; i < n; i += blockDim.x) {
+        const BinRecord<C> r = records[i];
+#pragma unroll
+        for (int c = 0; c < C; c++) atomicAdd(&acc[r.cell * C + c], r.v[c]);
+    }
+    __syncthreads();
+    if (!vec_ok) {       // a dense level may start at an odd entry and end inside the bin: 4-byte accesses there
+        for (uint32_t j = threadIdx.x; j < nfl; j += blockDim.x) {
+            float g = acc[j];
+            if (spilled) {
+                const float g0 = G[j];
+                if (g0 != 0.f) { g += g0; G[j] = 0.f; }
+            }
+            float pp = P[j], mm = M[j], vv = V[j];
+            adam1(pp, g, mm, vv, step_size, bc2_sqrt, ts.beta1, ts.beta2, ts.eps, ts.grad_scale);
+            P[j] = pp; M[j] = mm; V[j] = vv;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < kV; k++) {
+        const uint32_t j = threadIdx.x + k * blockDim.x;
+        if (j >= nvec) continue;
+        float4 a = acc4[j];
+        if (spilled) {
+            const float4 g0 = reinterpret_cast<const float4 *>(G)[j];
+            if (g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f) {
+                a.x += g0.x; a.y += g0.y; a.z += g0.z; a.w += g0.w;
+                reinterpret_cast<float4 *>(G)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float ga[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float pp = tp[k][e], mm = tm[k][e], vv = tv[k][e];
+            adam1(pp, ga[e], mm, vv, step_size, bc2_sqrt, ts.beta1, ts.beta2, ts.eps, ts.grad_scale);
+            tp[k][e] = pp; tm[k][e] = mm; tv[k][e] = vv;
+        }
+        reinterpret_cast<f32x4 *>(P)[j] = tp[k];
+        __builtin_nontemporal_store(tm[k], reinterpret_cast<f32x4 *>(M) + j);
+        __builtin_nontemporal_store(tv[k], reinterpret_cast<f32x4 *>(V) + j);
+    }
+}
+
+bool step_ok(const hsHashLayout &lay, const float *grad_embeddings) {
+    const hsTableStep *ts = lay.step;
+    return !ts || (grad_embeddings && ts->p && ts->m && ts->v && ts->state && ts->group >= 0 && ts->group < HS_ADAM_MAX_GROUPS && !lay.grid_id);
+}
+
+// the reduction that follows a scatter: plain (add to the gradient table) or with the optimiser step
+template <int D, int C>
+void launch_bin_reduce(float *grad_embeddings, const int32_t *offsets, uint32_t L, const LevelScales &sc, const hsHashLayout &lay, hipStream_t st) {
+    if (lay.step) {
+        hsHashLayout dev = lay;
+        dev.step = nullptr;              // (a host pointer: the kernel receives the structure by value)
+        k_hash_bin_step<D, C><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, dev, *lay.step);
+    } else if (lay.scatter_ws) {
+        k_hash_bin_reduce<D, C><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
     }
 }
 
@@ -795,7 +931,7 @@ LevelScales make_scales(uint32_t L, float S, uint32_t H) {
 }
 
 hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
-    hsHashLayout lay;
+    hsHashLayout lay = {};
     lay.level_stride = (int64_t)B * C;  // [L,B,C]
     lay.point_stride = C;
     lay.dydx_level_stride = (int64_t)D * C;  // [B,L,D,C]
@@ -812,6 +948,7 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
     lay.r1_ux = lay.r1_g = nullptr;
     lay.r1_n = 0;
     lay.r1_scale = 0.f;
+    lay.step = nullptr;
     return lay;
 }
 
@@ -890,9 +1027,19 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
                 uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
                 void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    if (layout && layout->step && (B == 0 || !grad_embeddings)) {      // nothing to scatter: the table still takes its step
+        if (!offsets || !step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;
+        hsHashLayout none = *layout;
+        none.scatter_ws = nullptr;
+        dispatch_dc(D, C, [&](auto d, auto c) {
+            launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, make_scales(L, S, H), none, (hipStream_t)stream);
+        });
+        if (B == 0) return check_launch();
+    }
     if (B == 0) return HS_OK;
     if (!grad || !inputs || !offsets || !layout) return HS_ERR_NULL;
     if (grad_inputs && !dy_dx) return HS_ERR_NULL;
+    if (!step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
     if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
@@ -905,8 +1052,7 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
         dispatch_dc(D, C, [&](auto d, auto c) {
             k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
                 grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
-            if (lay.scatter_ws)
-                k_hash_bin_reduce<decltype(d)::value, decltype(c)::value><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
+            launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, sc, lay, st);
         });
     }
     if (grad_inputs)
@@ -939,8 +1085,18 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
     if (!layout) return HS_ERR_NULL;
-    if (B == 0 || (!g_feat && !g_dydx && !layout->r1_ux)) return HS_OK;
+    if (B == 0 || (!g_feat && !g_dydx && !layout->r1_ux)) {
+        if (!layout->step) return HS_OK;
+        if (!offsets || !step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;     // nothing to scatter: the table still takes its step
+        hsHashLayout none = *layout;
+        none.scatter_ws = nullptr;
+        dispatch_dc(D, C, [&](auto d, auto c) {
+            launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, make_scales(L, S, H), none, (hipStream_t)stream);
+        });
+        return check_launch();
+    }
     if (!inputs || !offsets || !grad_embeddings) return HS_ERR_NULL;
+    if (!step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;
     hsHashLayout lay = *layout;
     if (lay.r1_ux && (!lay.r1_g || lay.r1_n > B)) return HS_ERR_ARG;
     if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
@@ -953,8 +1109,7 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     dispatch_dc(D, C, [&](auto d, auto c) {
         k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
             g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
-        if (lay.scatter_ws)
-            k_hash_bin_reduce<decltype(d)::value, decltype(c)::value><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
+        launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, sc, lay, st);
     });
     return check_launch();
 }

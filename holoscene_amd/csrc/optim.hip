@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -32,15 +33,6 @@ __global__ void k_adam_tick(hsAdamState *st, float beta1, float beta2, double ga
         st->step_size[g] = (float)(lr / bc1);
     }
     st->bc2_sqrt = (float)sqrt(bc2);
-}
-
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float step_size, float bc2_sqrt, float beta1, float beta2, float eps,
-                                      float gscale) {
-    g *= gscale;
-    m = m + (1.f - beta1) * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * beta2 + (1.f - beta2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float denom = sqrtf(v) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
-    p = p - step_size * (m / denom);                 // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

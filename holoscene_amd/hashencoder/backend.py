@@ -29,7 +29,13 @@ class hsHashLayout(ctypes.Structure):
     _fields_ = [("level_stride", ctypes.c_int64), ("point_stride", ctypes.c_int64), ("dydx_level_stride", ctypes.c_int64),
                 ("dydx_point_stride", ctypes.c_int64), ("schedule", ctypes.c_int32), ("gate", hsGate), ("scatter_ws", ctypes.c_void_p),
                 ("scatter_cap", ctypes.c_uint32), ("grid_id", ctypes.c_void_p), ("grid_stride", ctypes.c_int64), ("ws_clean", ctypes.c_int32),
-                ("out_bf16", ctypes.c_int32), ("r1_ux", ctypes.c_void_p), ("r1_g", ctypes.c_void_p), ("r1_n", ctypes.c_uint32), ("r1_scale", ctypes.c_float)]
+                ("out_bf16", ctypes.c_int32), ("r1_ux", ctypes.c_void_p), ("r1_g", ctypes.c_void_p), ("r1_n", ctypes.c_uint32), ("r1_scale", ctypes.c_float),
+                ("step", ctypes.c_void_p)]
+
+
+class hsTableStep(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("state", ctypes.c_void_p), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("grad_scale", ctypes.c_float), ("group", ctypes.c_int32)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -80,7 +86,7 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
 # together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
@@ -229,6 +235,30 @@ def scatter_done(table):
             cb()
 
 
+# Reduce-and-step (hsTableStep, include/holoscene_hip.h): data_ptr of a flat-owned table's gradient view -> [hsTableStep, scatters served].
+# training/flat.py registers the tables for the span of ONE backward pass in which each has a single gradient producer; the scatter
+# wrappers below attach the step to that producer's launch.  A second scatter into a registered table would step it twice, and a
+# producer that cannot carry the step (double backward, the reference-compatible trio) would leave its contribution behind: both raise.
+TABLE_STEPS = {}
+SCATTER_COUNTS = None       # a dict while a trainer counts the gradient producers per table (training/trainer.py)
+
+
+def _table_step(grad_embeddings, can_step=True):
+    if grad_embeddings is None:
+        return None
+    ptr = grad_embeddings.data_ptr()
+    if SCATTER_COUNTS is not None:
+        SCATTER_COUNTS[ptr] = SCATTER_COUNTS.get(ptr, 0) + 1
+    ent = TABLE_STEPS.get(ptr)
+    if ent is None:
+        return None
+    if not can_step or ent[1]:
+        raise RuntimeError("a hash table registered for reduce-and-step received a second gradient producer in the same backward pass "
+                           "(or one that cannot carry the step): its optimiser step must go through FlatAdam.step instead")
+    ent[1] += 1
+    return ent[0]
+
+
 def point_major_layout(C, L, D):
     """features [B, L*C]; dy_dx [L, B, D*C] (level stride filled in per call)."""
     return dict(level_stride=C, point_stride=L * C, dydx_point_stride=D * C)
@@ -246,6 +276,7 @@ class _HipBackend:
     @staticmethod
     def hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs):
         lib = load_library()
+        _table_step(grad_embeddings, can_step=False)
         _check(lib.hs_hash_encode_backward(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(embeddings, "embeddings"),
                                            _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                            ctypes.c_float(S), H, int(bool(calc_grad_inputs)), _dev(dy_dx, "dy_dx"),
@@ -255,6 +286,7 @@ class _HipBackend:
     def hash_encode_second_backward(grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_grad_inputs,
                                     grad_grad, grad2_embeddings):
         lib = load_library()
+        _table_step(grad2_embeddings, can_step=False)
         _check(lib.hs_hash_encode_second_backward(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(embeddings, "embeddings"),
                                                   _dev(offsets, "offsets", torch.int32), B, D, C, L, ctypes.c_float(S), H,
                                                   int(bool(calc_grad_inputs)), _dev(dy_dx, "dy_dx"),
@@ -265,7 +297,7 @@ class _HipBackend:
     @staticmethod
     def _layout(B, D, C, L, gate=None, ws=None, level_major=False, grids=None):
         """grids: None, or (grid_id int32 [B], entries per grid): a batched-over-grids launch (hsHashLayout::grid_id)."""
-        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0, 0, None, None, 0, 0.0)
+        lay = hsHashLayout(C, L * C, B * D * C, D * C, SCHEDULE, _gate(gate), None, 0, None, 0, 0, 0, None, None, 0, 0.0, None)
         if grids is not None:
             if ws is not None:
                 raise ValueError("the binned scatter holds the records of ONE table: no scatter work space with grids=")
@@ -342,6 +374,9 @@ class _HipBackend:
     def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False, grids=None):
         lib = load_library()
         lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
+        step = _table_step(grad_embeddings)
+        if step is not None:
+            lay.step = ctypes.addressof(step)
         _check(lib.hs_hash_bwd(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
                                _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
                                _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay), _stream()), "hs_hash_bwd")
@@ -350,6 +385,7 @@ class _HipBackend:
     def bwd2(cls, grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, grids=None):
         lib = load_library()
         lay = cls._layout(B, D, C, L, grids=grids)
+        _table_step(grad2_embeddings, can_step=False)
         _check(lib.hs_hash_bwd2(_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32), B, D, C, L,
                                 ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), _dev(grad_grad_inputs, "grad_grad_inputs"),
                                 _dev(grad_grad, "grad_grad"), _dev(grad2_embeddings, "grad2_embeddings"), ctypes.byref(lay),
@@ -366,6 +402,9 @@ class _HipBackend:
             if ux.shape[0] != g1.shape[0] or ux.shape[0] > B or ux.shape[1] != L * C or g1.shape[1] != D:
                 raise RuntimeError("bwd_jac rank1: ux [n, L*C], g [n, D], n <= B")
             lay.r1_ux, lay.r1_g, lay.r1_n, lay.r1_scale = _dev(ux, "rank1 ux").value, _dev(g1, "rank1 g").value, int(ux.shape[0]), float(scale)
+        step = _table_step(grad_embeddings)
+        if step is not None:
+            lay.step = ctypes.addressof(step)
         _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
                                    _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
                                    ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")

@@ -18,6 +18,7 @@ ones on a side stream under the rest of the backward pass (trainer.py).  Each se
 rank; the pad elements are zero parameters with zero gradients.  Without ``early_params`` there is one segment and the layout is
 the plain concatenation.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -92,6 +93,8 @@ class FlatAdam:
                 sizes_end[0] = off + n
             if i < n_tables + len(groups[1]):
                 sizes_end[1] = off + n
+        self.n_tables, self.tables_end = n_tables, sizes_end[0]
+        self._stepped = []              # flat ranges whose Adam step rode on their scatter in the pass that just ended (table_steps)
         self.betas, self.eps = betas, eps
         self.gamma = float(decay_rate) ** (1.0 / float(decay_steps))
         self.world_size, self.rank = world_size, rank
@@ -104,11 +107,16 @@ class FlatAdam:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(dev)
 
     # ---- gradients
-    def zero_grad(self):
+    def zero_grad(self, tables=True):
         """One memset; the hash tables keep their gradient views attached (the scatter kernels accumulate into them in
         place), the ~30 small MLP tensors are detached so that autograd hands over each gradient tensor as is instead of
-        launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy."""
-        self._g_alloc.zero_()
+        launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy.
+        tables=False: the tables' gradient storage is known to be all zero (it was never written since the allocation, or the last
+        pass ended with `table_steps` / `clear_table_grads`): only the small tensors and the pool behind them are cleared."""
+        if tables:
+            self._g_alloc.zero_()
+        else:
+            self._g_alloc[self.tables_end:].zero_()
         _be.set_zero_pool(self._g_alloc[self.padded:])
         _be.FLAT_CLAIMS.clear()          # no view has been written yet: the first producer of each writes, later ones accumulate
         for p, _ in self.small:
@@ -228,13 +236,52 @@ class FlatAdam:
                                g_base=g_base, mv_base=self.mv_bases[s])
 
     def step(self, grad_scale=1.0):
-        """One Adam + ExponentialLR step over the whole buffer (single process, or after an all-reduce of the gradient)."""
+        """One Adam + ExponentialLR step over the whole buffer (single process, or after an all-reduce of the gradient) -- minus the
+        tables that took their step inside their scatter during the backward pass that just ended (`table_steps`)."""
         if self.shard_moments:
             raise RuntimeError("this rank stores only its shards of the Adam moments: tick() + step_segment(s)")
         self.tick()
-        _be._backend.adam_flat(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0, self.padded, self.state, self.betas[0], self.betas[1],
-                               self.eps, grad_scale, g_base=0, mv_base=0)
+        at = 0
+        for b, e in sorted(self._stepped) + [(self.padded, self.padded)]:
+            if b > at:
+                _be._backend.adam_flat(self.flat_p, self.flat_g, self.flat_m, self.flat_v, at, b, self.state, self.betas[0], self.betas[1],
+                                       self.eps, grad_scale, g_base=0, mv_base=0)
+            at = max(at, e)
+        self._stepped = []
         self.end_update()
+
+    # ---- reduce-and-step: the tables' Adam update inside their scatter's reduction (csrc/hash_encode.hip: k_hash_bin_step)
+    def table_steps_supported(self):
+        """Single process with full-length moments, every table a whole number of 16-byte quads at a quad boundary (the rest of the
+        buffer is then stepped by hs_adam_flat over quad-aligned ranges)."""
+        return (self.world_size == 1 and not self.shard_moments and self.flat_p.is_cuda and self.n_tables > 0
+                and all(self.offsets[i] % 4 == 0 and self.params[i].numel() % 4 == 0 for i in range(self.n_tables)))
+
+    @contextlib.contextmanager
+    def table_steps(self, grad_scale=1.0):
+        """For the backward pass inside the block, every hash table whose gradient has exactly ONE producer (a scatter through
+        backend.bwd / bwd_jac into its flat gradient view) takes its Adam step in that producer's reduction kernel.  Needs: `tick()`
+        done for this update (the iteration prologue), the tables' gradient storage all zero on entry (it is again on exit).  A table
+        that received no scatter keeps its turn in `step()`; the following `step()` covers exactly what is left."""
+        if not self._ticked:
+            raise RuntimeError("table_steps before tick(): the reduction kernels read the advanced optimiser state")
+        mine = {}
+        for i in range(self.n_tables):
+            p, off = self.params[i], self.offsets[i]
+            ts = _be.hsTableStep(p.data.data_ptr(), self.flat_m[off:].data_ptr(), self.flat_v[off:].data_ptr(), self.state.data_ptr(),
+                                 self.betas[0], self.betas[1], self.eps, grad_scale, 0)
+            key = self.flat_g[off:].data_ptr()
+            mine[key] = (off, off + p.numel())
+            _be.TABLE_STEPS[key] = [ts, 0]
+        try:
+            yield
+        finally:
+            self._stepped = [mine[k] for k in mine if _be.TABLE_STEPS.pop(k)[1]]
+
+    def clear_table_grads(self):
+        """Leave the tables' gradient storage all zero (the end of a pass that accumulated into it the plain way, in a trainer whose
+        other passes rely on `zero_grad(tables=False)`)."""
+        self.flat_g[:self.tables_end].zero_()
 
     def state_dict(self):
         """This rank's optimiser state (with sharded moments: its slice)."""

@@ -4,6 +4,7 @@ without its logging: zero_grad, forward, loss, backward, (gradient exchange), Ad
 No ``.item()`` inside the step (the reference pays ~25 device syncs per iteration for its grad-norm
 print, holoscene_train.py:366-372); scalars are returned as device tensors.
 """
+import contextlib
 import os
 import warnings
 
@@ -111,6 +112,14 @@ class Stage1Trainer:
         self.add_objectvio_iter = conf.get_int("train.add_objectvio_iter", default=100000)
         self.iter_step = 0
         self._graphs = {}
+        # Reduce-and-step (csrc/hash_encode.hip: k_hash_bin_step): in the variants of the whole-iteration graph in which every hash
+        # table has ONE gradient producer (all but the background-patch iterations), the tables take their Adam step inside that
+        # scatter's reduction; the gradient tables are then never zero-filled, written or read.  HOLOSCENE_TABLE_STEP=0: off (A/B).
+        # _table_step_ok: variant -> decided by counting the producers in the variant's first (plain) warm-up pass.
+        self._table_step = (graph and self.flat is not None and not self.dp and not freeze_parameters
+                            and os.environ.get("HOLOSCENE_TABLE_STEP", "1") != "0" and self.flat.table_steps_supported())
+        self._table_step_ok = {}
+        self._pass_fused = False
         # same seed on every rank -> identical initial parameters; from here on every rank draws from its own stream (frames, ray
         # jitter, inverse-CDF draws, Eikonal points): identical draws across data-parallel ranks would correlate the sampling noise
         if world_size > 1:
@@ -206,6 +215,7 @@ class Stage1Trainer:
                 self._finish_exchange()
             else:
                 self.flat.step()
+                self._leave_tables_clean()
         else:
             if self.dp:
                 dist_util.average_gradients(self.model.parameters(), self.world_size)
@@ -259,8 +269,16 @@ class Stage1Trainer:
             return
         if not self.dp:
             self.flat.step()
+            self._leave_tables_clean()
         elif self._overlap:
             self._finish_exchange()
+
+    def _leave_tables_clean(self):
+        """The passes that step the tables inside their scatters start from all-zero gradient tables without clearing them
+        (FlatAdam.zero_grad(tables=False)) and leave them so; every other pass of such a trainer clears them at its end."""
+        if self._table_step and not self._pass_fused:
+            self.flat.clear_table_grads()
+        self._pass_fused = False
 
     def _after_replay(self):
         if self.dp and not self._overlap and not self.freeze_parameters:
@@ -283,12 +301,19 @@ class Stage1Trainer:
 
     def _full_body(self, st, with_bg, call_reg):
         model = self.model
-        self.flat.zero_grad()
+        tick = self.flat if (self.flat is not None and not self.freeze_parameters and (not self.dp or self._overlap)) else None
+        # reduce-and-step: the first pass of a variant runs the plain way and counts the tables' gradient producers
+        variant, counting = (with_bg, call_reg), False
+        fused = self._table_step and tick is not None and self._table_step_ok.get(variant, False)
+        if self._table_step and tick is not None and variant not in self._table_step_ok and not torch.cuda.is_current_stream_capturing():
+            counting, _net._be.SCATTER_COUNTS = True, {}
+        self._pass_fused = fused
+        self.flat.zero_grad(tables=not fused)
         self._arm_early_exchange()
+        steps = self.flat.table_steps() if fused else contextlib.nullcontext()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
-        tick = self.flat if (self.flat is not None and not self.freeze_parameters and (not self.dp or self._overlap)) else None
         sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1])
         with _net.iteration_prologue(model, tick, sizes) as drawn:
             with torch.no_grad():
@@ -312,9 +337,19 @@ class Stage1Trainer:
             out["sampled"] = sampled
         out["iter_step"] = 0
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
-        loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
+        with steps:
+            loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
+        if counting:
+            seen, _net._be.SCATTER_COUNTS = _net._be.SCATTER_COUNTS, None
+            views = [self.flat.flat_g[self.flat.offsets[i]:].data_ptr() for i in range(self.flat.n_tables)]
+            self._table_step_ok[variant] = all(seen.get(v, 0) == 1 for v in views) and set(seen) <= set(views)
         self._update_in_body()
+        if fused and not torch.cuda.is_current_stream_capturing():
+            # (warm-up passes only: a host read) a gradient that reached a table past its scatter -- through autograd's accumulation --
+            # would have missed the step and broken the all-zero contract of the next pass
+            if bool(self.flat.flat_g[:self.flat.tables_end].any()):
+                raise RuntimeError("reduce-and-step: a hash table received gradient outside its scatter; set HOLOSCENE_TABLE_STEP=0")
         return out, loss_out
 
     @staticmethod

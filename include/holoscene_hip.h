@@ -96,6 +96,25 @@ typedef struct hsGate {
     const float *b;
 } hsGate;
 
+/* Reduce-and-step (new: the reference steps torch.optim.Adam over the tables after the backward pass, training/holoscene_train.py:374).
+ * When this scatter is the ONLY producer of the table's gradient in the iteration, the workgroup that owns a bin's cells holds their
+ * final gradient in LDS -- it applies the Adam update (hs_adam_flat's arithmetic, element for element) to p / m / v right there
+ * instead of adding the sums to `grad_embeddings`: the gradient table is neither zero-filled, nor written, nor read back by the
+ * optimiser (3 x 48.8 MB per table and iteration at the stock grid).  p, m, v: the table's parameter and moment storage, indexed like
+ * `grad_embeddings` (entry offsets[l] + cell, C floats each); state: the DEVICE-resident optimiser state hs_adam_tick has already
+ * advanced for this update; group: which of its step sizes applies.
+ * Contract on `grad_embeddings`: it must be all zero on entry; contributions that overflow a bin (or belong to a level that is not
+ * binned, or arrive without a work space) still go there as atomics, are added by the owner of the cell, and are returned to zero --
+ * so the buffer is all zero again afterwards and EVERY entry of the table has been stepped exactly once (entries without a gradient
+ * with g = 0: dense Adam semantics, as hs_adam_flat). */
+struct hsAdamState;
+typedef struct hsTableStep {
+    float *p, *m, *v;
+    const struct hsAdamState *state;
+    float beta1, beta2, eps, grad_scale;
+    int32_t group;
+} hsTableStep;
+
 typedef struct hsHashLayout {
     int64_t level_stride;      /* features / grads */
     int64_t point_stride;
@@ -122,6 +141,8 @@ typedef struct hsHashLayout {
     const float *r1_ux, *r1_g;
     uint32_t r1_n;
     float r1_scale;
+    /* hs_hash_bwd / hs_hash_bwd_jac only: NULL, or the table's optimiser step taken INSIDE the reduction (see hsTableStep) */
+    const struct hsTableStep *step;
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */

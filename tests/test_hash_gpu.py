@@ -213,6 +213,96 @@ def test_full_size_binned_scatter_properties():
     assert int(counts.abs().sum()) == 0
 
 
+def _adam_state(dev, n_group0, steps=3):
+    from holoscene_amd.hashencoder import backend as B
+    st = B.hsAdamState()
+    st.step = 0
+    st.group_end[0], st.group_end[1] = n_group0, n_group0
+    for i, v in enumerate((1e-2, 5e-4, 5e-4)):
+        st.lr0[i] = v
+        st.lr[i] = v
+    state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(dev)
+    for _ in range(steps):
+        _be().adam_tick(state, 0.9, 0.99, 0.9999)
+    return state
+
+
+@pytest.mark.parametrize("case", ["stock", "slab", "small", "jac", "empty", "no_ws"])
+def test_reduce_and_step_equals_scatter_then_adam(case):
+    """hsTableStep (k_hash_bin_step): the Adam step taken inside the scatter's reduction against the same scatter followed by hs_adam_flat over
+    the table -- every entry stepped exactly once (entries without a gradient included), the gradient table all zero afterwards, the bin
+    counters returned to zero.  stock: the stock grid, every level through the record bins.  slab: all points in a thin slab, so the dense
+    levels' bins overflow into atomics on the gradient table.  small: a grid whose coarse levels are not binned.  jac: through
+    hs_hash_bwd_jac.  empty: B = 0 (the table still steps).  no_ws: no work space, every contribution an atomic."""
+    from holoscene_amd.hashencoder import HashEncoder
+    from holoscene_amd.hashencoder import backend as B_
+    torch.manual_seed(5)
+    be = _be()
+    enc = (HashEncoder(num_levels=8, base_resolution=4, desired_resolution=128, log2_hashmap_size=12) if case == "small"
+           else HashEncoder(desired_resolution=2048)).cuda()
+    L, C = enc.num_levels, 2
+    S, H = float(np.log2(enc.per_level_scale)), int(enc.base_resolution)
+    n = (enc.embeddings.numel() + 3) // 4 * 4        # (hs_adam_flat walks whole quads; the table itself may end inside one)
+    B = 0 if case == "empty" else 60000
+    x = torch.rand(max(B, 1), 3, device="cuda")[:B].contiguous()
+    if case == "slab":
+        x[:, 2] = 0.5 + 0.002 * x[:, 2]
+    g = torch.randn(L, B, C, device="cuda")
+    g[:, ::7] = 0
+    gj = torch.randn(L, B, 3 * C, device="cuda") if case == "jac" else None
+    p0 = torch.randn(n, device="cuda") * 0.1
+    m0 = torch.randn(n, device="cuda") * 1e-3
+    v0 = (0.5 + torch.rand(n, device="cuda")) * 1e-5
+    state = _adam_state("cuda", n)
+
+    def scatter(target):
+        ws = None if case in ("no_ws", "empty") else be.scatter_workspace(max(B, 1), 3, C, L, "cuda")
+        if case == "jac":
+            be.bwd_jac(g, gj, x, enc.offsets, target, B, 3, C, L, S, H, ws=ws, level_major=True)
+        else:
+            be.bwd(g, x, enc.offsets, target, B, 3, C, L, S, H, None, None, ws=ws, level_major=True)
+        return ws
+
+    # the plain way
+    ge = torch.zeros(n, device="cuda")
+    scatter(ge[:enc.embeddings.numel()].view(-1, C))
+    p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+    be.adam_flat(p1, ge, m1, v1, 0, n, state, 0.9, 0.99, 1e-15, 1.0)
+    # reduce-and-step
+    g2 = torch.zeros(n, device="cuda")
+    p2, m2, v2 = p0.clone(), m0.clone(), v0.clone()
+    ts = B_.hsTableStep(p2.data_ptr(), m2.data_ptr(), v2.data_ptr(), state.data_ptr(), 0.9, 0.99, 1e-15, 1.0, 0)
+    B_.TABLE_STEPS[g2.data_ptr()] = [ts, 0]
+    try:
+        ws = scatter(g2[:enc.embeddings.numel()].view(-1, C))
+        assert B_.TABLE_STEPS[g2.data_ptr()][1] == 1
+        with pytest.raises(RuntimeError, match="second gradient producer"):
+            scatter(g2[:enc.embeddings.numel()].view(-1, C))
+    finally:
+        B_.TABLE_STEPS.pop(g2.data_ptr())
+    torch.cuda.synchronize()
+    assert not bool(g2.any()), "the gradient table is all zero again"
+    if ws is not None:
+        assert int(ws[0][:32 * 128 * 4].view(torch.int32).abs().sum()) == 0
+    if case == "slab":      # the case is only worth its name if bins did overflow
+        assert B * 8 > 4 * ws[1]
+    # the sums inside a cell are formed in a different order (LDS atomics in both paths: not even run-to-run stable), so the gradient
+    # agrees to rounding and the update to what that rounding does to m / sqrt(v)
+    # (a gradient element is a sum of up to thousands of O(1) contributions: its rounding is ~1e-6 of its size; m moves by 0.1 of that,
+    # v by 0.02 |g| of it, p by step_size / sqrt(v) of m's -- with sqrt(v0) ~ 3e-3 and step_size 0.037 that is ~17x)
+    k = enc.embeddings.numel()
+    ga = ge[:k].abs()
+    big = 1 + float(ga.max())        # (scale of the sums of |contributions|: cancellation makes a cell's rounding exceed 1e-6 of its own value)
+    for name, a, b, tol in (("m", m2[:k], m1[:k], 1e-6 * m1[:k].abs() + 3e-7 * big),
+                            ("v", v2[:k], v1[:k], 1e-6 * v1[:k].abs() + 1e-7 * ga * big + 1e-10),
+                            ("p", p2[:k], p1[:k], 5e-6 * big)):
+        err = (a - b).abs()
+        assert bool((err <= tol).all()), (case, name, float(err.max()), float((err / tol).max()))
+    assert float((p2[:k] - p1[:k]).abs().mean()) < 1e-7
+    moved = (p2[:k] != p0[:k]).float().mean()
+    assert float(moved) > 0.999, "every entry is stepped (dense Adam), with or without a gradient"
+
+
 def test_scatter_with_ray_ordered_points_vs_oracle():
     """Consecutive lanes in the same cell exercise the wave-merged scatter (runs of every length,
     runs crossing wave boundaries, OOB lanes splitting runs, a ragged last block)."""
