@@ -48,10 +48,13 @@ class FlatAdam:
         align = 4 * world_size                      # every rank's shard of every segment is a whole number of 16-byte quads
         up = lambda n: (n + align - 1) // align * align  # noqa: E731
         self.offsets, off, cuts = [], 0, [0]        # flat index of each parameter's first element; segment boundaries
+        n_tables = len(groups[0])
         for i, p in enumerate(self.params):
             if 0 < i <= len(early):                 # a boundary after every early table
                 off = up(off)
                 cuts.append(off)
+            if i <= n_tables:                       # every table, and what follows the last one, starts a 16-byte quad: the kernels that
+                off = (off + 3) // 4 * 4            # step a table on its own (k_hash_bin_step, hs_adam_flat over a sub-range) walk whole quads
             self.offsets.append(off)
             off += p.numel()
         self.numel = off                            # end of the last parameter (flat index space, inner pads included)
@@ -77,7 +80,6 @@ class FlatAdam:
         self._shard_p = {}              # per segment: send buffer of the all-gather
         self._ticked = False            # tick() already ran for the update in flight (segment-wise stepping)
         self.small = []          # (parameter, gradient view) of everything that is not a hash table
-        n_tables = len(groups[0])
         sizes_end = [0, 0]
         for i, p in enumerate(self.params):
             n, off = p.numel(), self.offsets[i]
@@ -252,10 +254,9 @@ class FlatAdam:
 
     # ---- reduce-and-step: the tables' Adam update inside their scatter's reduction (csrc/hash_encode.hip: k_hash_bin_step)
     def table_steps_supported(self):
-        """Single process with full-length moments, every table a whole number of 16-byte quads at a quad boundary (the rest of the
-        buffer is then stepped by hs_adam_flat over quad-aligned ranges)."""
-        return (self.world_size == 1 and not self.shard_moments and self.flat_p.is_cuda and self.n_tables > 0
-                and all(self.offsets[i] % 4 == 0 and self.params[i].numel() % 4 == 0 for i in range(self.n_tables)))
+        """Single process with full-length moments (every table starts a 16-byte quad and is followed by zero padding up to the next one:
+        the rest of the buffer is stepped by hs_adam_flat over quad-aligned ranges)."""
+        return self.world_size == 1 and not self.shard_moments and self.flat_p.is_cuda and self.n_tables > 0
 
     @contextlib.contextmanager
     def table_steps(self, grad_scale=1.0):
@@ -271,7 +272,7 @@ class FlatAdam:
             ts = _be.hsTableStep(p.data.data_ptr(), self.flat_m[off:].data_ptr(), self.flat_v[off:].data_ptr(), self.state.data_ptr(),
                                  self.betas[0], self.betas[1], self.eps, grad_scale, 0)
             key = self.flat_g[off:].data_ptr()
-            mine[key] = (off, off + p.numel())
+            mine[key] = (off, (off + p.numel() + 3) // 4 * 4)       # (the pad behind a table: zero parameters with zero gradients)
             _be.TABLE_STEPS[key] = [ts, 0]
         try:
             yield
