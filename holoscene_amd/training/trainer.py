@@ -117,7 +117,8 @@ class Stage1Trainer:
         # scatter's reduction; the gradient tables are then never zero-filled, written or read.  HOLOSCENE_TABLE_STEP=0: off (A/B).
         # _table_step_ok: variant -> decided by counting the producers in the variant's first (plain) warm-up pass.
         self._table_step = (graph and self.flat is not None and not self.dp and not freeze_parameters
-                            and os.environ.get("HOLOSCENE_TABLE_STEP", "1") != "0" and self.flat.table_steps_supported())
+                            and os.environ.get("HOLOSCENE_TABLE_STEP", "1") != "0" and self.flat.table_steps_supported()
+                            and self._full_graph_ok())       # (only the whole-iteration graph ticks the optimiser before the backward pass)
         self._table_step_ok = {}
         self._pass_fused = False
         # same seed on every rank -> identical initial parameters; from here on every rank draws from its own stream (frames, ray
