@@ -59,16 +59,18 @@ def _worker(rank, world, port, backend, q, zero1, steps, share_gpu):
     flat = FlatAdam(model, 5e-4, 20.0, 0.1, 1000, world_size=world, rank=rank, shard_moments=zero1)
     g = torch.Generator().manual_seed(50 + rank)
     hist = []
+    used = torch.zeros(flat.padded, dtype=torch.bool)        # (the layout pads every table to a 16-byte boundary: pads carry zero gradients)
+    for p_, off in zip(flat.params, flat.offsets):
+        used[off:off + p_.numel()] = True
     for _ in range(steps):
         flat.zero_grad()
-        local = torch.randn(flat.padded, generator=g)
-        local[flat.numel:] = 0
+        local = torch.randn(flat.padded, generator=g) * used
         flat.flat_g.copy_(local.to(dev))
         hist.append(local.clone())
         exchange_and_step_flat(flat, world, zero1=zero1)
     torch.cuda.synchronize()
     full_m, full_v = flat.gather_moments()
-    q.put((rank, [h.numpy() for h in hist], flat.flat_p.cpu().numpy().copy(), full_m.cpu().numpy().copy(), full_v.cpu().numpy().copy()))
+    q.put((rank, [h.numpy() for h in hist], flat.flat_p.cpu().numpy().copy(), full_m.cpu().numpy().copy(), full_v.cpu().numpy().copy(), list(flat.offsets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,22 +96,21 @@ def _run(world, backend, zero1, share_gpu, steps=3):
                             {"params": [ref.beta], "lr": 5e-4}], betas=(0.9, 0.99), eps=1e-15)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.1 ** (1 / 1000))
     plist = [ref.grid] + list(ref.net.parameters()) + [ref.beta]
-    n = sum(p.numel() for p in plist)
+    offsets = res[0][5]          # flat index of each parameter's first element (optimiser order = plist order)
     for s in range(steps):
         mean = sum(torch.from_numpy(r[1][s]) for r in res) / world
-        off = 0
-        for p in plist:
+        for p, off in zip(plist, offsets):
             p.grad = mean[off:off + p.numel()].view_as(p).clone()
-            off += p.numel()
         opt.step()
         sched.step()
+    pick = lambda flat_arr: torch.cat([torch.from_numpy(flat_arr[off:off + p.numel()]) for p, off in zip(plist, offsets)])  # noqa: E731
     want_p = torch.cat([p.detach().reshape(-1) for p in plist])
     want_m = torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in plist])
     want_v = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in plist])
-    assert torch.allclose(torch.from_numpy(flats[0][:n]), want_p, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(pick(flats[0]), want_p, rtol=1e-5, atol=1e-7)
     for r in res:       # the gathered moments (what a checkpoint exports) are complete on every rank
-        assert torch.allclose(torch.from_numpy(r[3][:n]), want_m, rtol=1e-4, atol=1e-7)
-        assert torch.allclose(torch.from_numpy(r[4][:n]), want_v, rtol=1e-4, atol=1e-9)
+        assert torch.allclose(pick(r[3]), want_m, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(pick(r[4]), want_v, rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize("zero1", [True, False])
