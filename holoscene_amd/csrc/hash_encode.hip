@@ -379,6 +379,9 @@ __device__ __forceinline__ bool wave_merge(const uint32_t g[D], float cache[(1 <
             // lane may absorb lane-off iff no run starts in (lane-off, lane]
             const unsigned long long span = (~0ull >> (63 - lane)) & (~0ull << ((lane - off + 1) & 63));
             const bool ok = lane >= off && (heads & span) == 0ull;
+            // no lane reaches back `off` lanes inside its run = no run is longer than `off`: the remaining (longer) steps have nothing to add.
+            // Runs are mostly 2-4 lanes long, so this ends after two or three of the six steps (each moves (1 << D) * C values across lanes)
+            if (__ballot(ok) == 0ull) break;
 #pragma unroll
             for (int i = 0; i < (1 << D) * C; i++) {
                 const float t = __shfl_up(cache[i], off);

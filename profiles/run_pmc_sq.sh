@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-fp32-point --no-trajectory-point --no-graph --steps 3 --warmup 2 > $OUT/bench_$i.log 2>&1 || true
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-second-point --no-fp32-point --no-trajectory-point --roofline-steps 0 --steps 12 --warmup 2 > $OUT/bench_$i.log 2>&1 || true
 done
 python - <<PY
 import csv, glob, collections

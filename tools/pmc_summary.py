@@ -60,7 +60,8 @@ detail = {k: {"dispatches": d["dispatches"], "bytes": int(d.get("FETCH_SIZE_KiB_
           for k, d in res.items() if k.startswith("k_hash") or k.startswith("k_rr") or k.startswith("k_wgrad")}
 json.dump({"commit": os.environ.get("HS_COMMIT", "see the commit that added this file"),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes with --kernel-trace only (profiles/run_pmc_r02.sh <tag>), over "
-                     "`python bench.py --no-graph --no-cpu-baseline --no-second-point --no-fp32-point --steps 3 --warmup 2` and over "
+                     "`python bench.py --no-cpu-baseline --no-second-point --no-fp32-point --no-trajectory-point --roofline-steps 0 --steps 12 --warmup 2` (the replayed "
+                     "whole-iteration graph: the counters see its kernels one by one) and over "
                      "tools/exp/pmc_calib.hip; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), averaged over the dispatches",
            "per_kernel_launch_bytes": launch_bytes, "per_kernel": per_kernel, "per_kernel_and_grid": detail}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("pmc_traffic.json:", {k: v for k, v in sorted(launch_bytes.items(), key=lambda kv: -kv[1])[:14]})
