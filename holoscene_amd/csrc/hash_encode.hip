@@ -462,9 +462,21 @@ __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restr
     uint32_t *counts = reinterpret_cast<uint32_t *>(lay.scatter_ws);
     BinRecord<C> *records = reinterpret_cast<BinRecord<C> *>(reinterpret_cast<char *>(lay.scatter_ws) + HS_MAX_LEVELS * kBins * sizeof(uint32_t));
     const uint32_t per_bin = bin_width<C>(li);
+    // cell -> bin without an integer division per corner (~25 instructions each, twice per corner): the hashed levels' bins are a power
+    // of two wide (a shift); a dense level's quotient comes from the float reciprocal, exact after one correction step (cells < 2^24)
+    const bool p2 = (per_bin & (per_bin - 1u)) == 0u;
+    const uint32_t sh = 31u - (uint32_t)__clz((int)per_bin);
+    const float inv_bin = 1.0f / (float)per_bin;
+    auto bin_of = [&](uint32_t c) -> uint32_t {
+        if (p2) return c >> sh;                  // (workgroup-uniform branch)
+        uint32_t q = (uint32_t)((float)c * inv_bin);
+        if (q * per_bin > c) q--;
+        else if ((q + 1u) * per_bin <= c) q++;
+        return q;
+    };
     if (threadIdx.x < kBins) hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t cell[1 << D], rank[1 << D];
+    uint32_t cell[1 << D], rank[1 << D], bins[1 << D];
     bool nz[1 << D];
 #pragma unroll
     for (int corner = 0; corner < (1 << D); corner++) {
@@ -476,7 +488,8 @@ __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restr
         for (int c = 0; c < C; c++) any |= cache[corner * C + c] != 0.f;
         nz[corner] = valid && any;
         cell[corner] = nz[corner] ? cell_index<D>(li, gl) : 0u;
-        rank[corner] = nz[corner] ? atomicAdd(&hist[cell[corner] / per_bin], 1u) : 0u;
+        bins[corner] = bin_of(cell[corner]);
+        rank[corner] = nz[corner] ? atomicAdd(&hist[bins[corner]], 1u) : 0u;
     }
     __syncthreads();
     if (threadIdx.x < kBins && hist[threadIdx.x] != 0u) base[threadIdx.x] = atomicAdd(&counts[level * kBins + threadIdx.x], hist[threadIdx.x]);
@@ -484,7 +497,7 @@ __device__ __forceinline__ void bin_cell(const hsHashLayout &lay, float *__restr
 #pragma unroll
     for (int corner = 0; corner < (1 << D); corner++) {
         if (!nz[corner]) continue;
-        const uint32_t bin = cell[corner] / per_bin, pos = base[bin] + rank[corner];
+        const uint32_t bin = bins[corner], pos = base[bin] + rank[corner];
         if (pos < lay.scatter_cap) {
             BinRecord<C> r;
             r.cell = cell[corner] - bin * per_bin;
