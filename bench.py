@@ -683,7 +683,10 @@ def main():
         "algorithmic_gflop": round(iter_flops / 1e9, 1), "algorithmic_gb": round(iter_bytes / 1e9, 3),
         "mfma_frac": round(iter_flops / (median_ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4),
         "hbm_frac": round(iter_bytes / (median_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "note": "SURVEY 8(d) formulas at the realised sampler rounds, divided by the median step time of the timed region"}
+        "note": "SURVEY 8(d) formulas at the realised sampler rounds, divided by the median step time of the timed region"
+                + ("; the timed graph steps the hash tables inside their scatters (reduce-and-step, DESIGN 13.9): it never zero-fills their gradient "
+                   "storage nor re-reads it in the optimiser, i.e. it moves 2 x 4 B per table parameter LESS than this model of the reference's "
+                   "algorithm counts -- the fraction is of the model's bytes, not of the build's" if getattr(tr, "_table_step", False) else "")}
     # (the same four numbers once more as flat scalars: a parser that keeps only scalar members of this object keeps them)
     for k_ in ("algorithmic_gflop", "algorithmic_gb", "mfma_frac", "hbm_frac"):
         roofline["whole_iteration_" + k_] = roofline["whole_iteration"][k_]
