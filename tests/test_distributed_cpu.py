@@ -228,3 +228,57 @@ def test_flat_exchange_equals_single_process_mean_gradient(zero1, segmented):
             assert step == 2.0
             assert torch.allclose(st["exp_avg"], torch.from_numpy(m).view_as(p), rtol=1e-4, atol=1e-7)
             assert torch.allclose(st["exp_avg_sq"], torch.from_numpy(v).view_as(p), rtol=1e-4, atol=1e-9)
+
+
+def test_flat_layout_quad_aligned_tables_and_the_step_around_stepped_tables(monkeypatch):
+    """FlatAdam's host logic for reduce-and-step (csrc/hash_encode.hip: k_hash_bin_step), on CPU with the torch stand-ins of the optimiser
+    kernels: every table starts a 16-byte quad (pads are zero parameters with zero gradients), `table_steps()` registers each table's
+    (p, m, v) for the scatter wrappers, and the `step()` that follows covers exactly the elements no scatter has stepped -- so one update
+    of the whole buffer = [tables stepped elsewhere] + [the rest here], element for element what a plain `step()` does."""
+    from holoscene_amd.hashencoder import backend
+    from holoscene_amd.training.flat import FlatAdam
+    for name in ("adam_tick", "adam_flat"):
+        monkeypatch.setattr(backend._HipBackend, name, staticmethod(getattr(_TorchAdamKernels, name)))
+    torch.manual_seed(0)
+    a, b = _TinyModel(), _TinyModel()
+    b.load_state_dict(a.state_dict())
+    fa, fb = FlatAdam(a, 5e-4, 20.0, 0.1, 1000), FlatAdam(b, 5e-4, 20.0, 0.1, 1000)
+    assert fa.n_tables == 2 and all(fa.offsets[i] % 4 == 0 for i in range(3)) and fa.offsets[1] == 2004 and fa.padded % 4 == 0
+    assert fa.tables_end == fa.offsets[1] + 2006
+    used = torch.zeros(fa.padded, dtype=torch.bool)
+    for p_, off in zip(fa.params, fa.offsets):
+        used[off:off + p_.numel()] = True
+    g = torch.randn(fa.padded) * used
+    # plain: one step over everything
+    fa.zero_grad()
+    fa.flat_g.copy_(g)
+    fa.step()
+    # reduce-and-step: the second table is "stepped by its scatter" (here: by hand, the kernel's arithmetic), the first receives no scatter
+    fb.zero_grad()
+    fb.flat_g.copy_(g)
+    fb.tick()
+    with fb.table_steps():
+        assert len(backend.TABLE_STEPS) == 2
+        key = fb.flat_g[fb.offsets[1]:].data_ptr()
+        ts, served = backend.TABLE_STEPS[key]
+        assert ts.p == fb.params[1].data.data_ptr() and ts.m == fb.flat_m[fb.offsets[1]:].data_ptr() and ts.group == 0 and served == 0
+        with pytest.raises(RuntimeError, match="cannot carry the step"):
+            backend._table_step(fb.flat_g[fb.offsets[1]:], can_step=False)
+        assert backend._table_step(fb.flat_g[fb.offsets[1]:]) is ts          # what bwd / bwd_jac do: take the step along
+        with pytest.raises(RuntimeError, match="second gradient producer"):
+            backend._table_step(fb.flat_g[fb.offsets[1]:])
+        lo, hi = fb.offsets[1], fb.offsets[1] + 2008                          # (the table and the pad behind it)
+        _TorchAdamKernels.adam_flat(fb.flat_p, fb.flat_g, fb.flat_m, fb.flat_v, lo, hi, fb.state, 0.9, 0.99, 1e-15, 1.0)
+    assert not backend.TABLE_STEPS and fb._stepped == [(lo, hi)]
+    calls = []
+    real = _TorchAdamKernels.adam_flat
+    monkeypatch.setattr(backend._HipBackend, "adam_flat", staticmethod(lambda *a_, **k_: (calls.append((a_[4], a_[5])), real(*a_, **k_))[1]))
+    fb.step()
+    assert calls == [(0, lo), (hi, fb.padded)] and fb._stepped == []
+    for x, y in ((fa.flat_p, fb.flat_p), (fa.flat_m, fb.flat_m), (fa.flat_v, fb.flat_v)):
+        assert torch.equal(x, y)
+    assert int(fa.read_state().step) == int(fb.read_state().step) == 1
+    fb.zero_grad(tables=False)
+    assert bool(fb.flat_g[:fb.tables_end].any()) and not bool(fb.flat_g[fb.tables_end:].any())     # only the small tensors' storage is cleared
+    fb.clear_table_grads()
+    assert not bool(fb.flat_g.any())
