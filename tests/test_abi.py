@@ -50,3 +50,36 @@ def test_cpu_tensor_is_rejected_loudly():
     enc = HashEncoder(num_levels=4, base_resolution=4, desired_resolution=32, log2_hashmap_size=10)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         enc(torch.zeros(4, 3))
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """Every structure the Python host mirrors with ctypes (hashencoder/backend.py) against the C header, compiled by gcc: same size, and
+    every field at the same offset under the same name -- a field added to one side only (hsHashLayout grew three times this round)
+    would otherwise show up as a silent argument shift on the GPU."""
+    import ctypes
+    import subprocess
+    from holoscene_amd.hashencoder import backend as B
+    names = [n for n in dir(B) if n.startswith("hs") and isinstance(getattr(B, n), type) and issubclass(getattr(B, n), ctypes.Structure)]
+    assert {"hsHashLayout", "hsTableStep", "hsAdamState", "hsGate", "hsAsmJob", "hsWgradPairJob"} <= set(names)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "holoscene_hip.h"', "int main(void) {"]
+    for n in names:
+        lines.append(f'    printf("{n} size %zu\\n", sizeof({n}));')
+        for f in getattr(B, n)._fields_:
+            lines.append(f'    printf("{n} {f[0]} %zu\\n", offsetof({n}, {f[0]}));')
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    want = {}
+    for line in out:
+        if line.strip():
+            n, f, v = line.split()
+            want[(n, f)] = int(v)
+    for n in names:
+        cls = getattr(B, n)
+        assert ctypes.sizeof(cls) == want[(n, "size")], (n, ctypes.sizeof(cls), want[(n, "size")])
+        for f in cls._fields_:
+            assert getattr(cls, f[0]).offset == want[(n, f[0])], (n, f[0], getattr(cls, f[0]).offset, want[(n, f[0])])
