@@ -576,9 +576,9 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             return float(tt) / n * 1e3
 
-        def variant(ws, exchange):
+        def variant(ws, exchange, table_step=None):
             t_ = Stage1Trainer(conf, device=dev, world_size=ws, rank=rank if ws > 1 else 0, seed=42, optimizer=args.optimizer,
-                               graph=(not args.no_graph) and args.optimizer == "flat", exchange=exchange)
+                               graph=(not args.no_graph) and args.optimizer == "flat", exchange=exchange, table_step=table_step)
             benchmark_model_state(t_.model, args.beta)
             if ws > 1:
                 dist_util.broadcast_parameters(t_.model)
@@ -590,10 +590,14 @@ def main():
             here_ms = timed_steps(tr, warm=0)
             other_ms, other_form = variant(world, "serial" if tr._overlap else "overlap")
             none_ms, _ = variant(1, None)
+            plain_ms, _ = variant(1, None, table_step=False)
             mine = "overlap" if tr._overlap else "serial"
             exchange_cmp = {"steps": 20, f"{mine}_ms_per_step": round(here_ms, 3), f"{other_form}_ms_per_step" if other_form != mine else "other_form_unavailable": round(other_ms, 3),
-                            "no_exchange_ms_per_step": round(none_ms, 3),
-                            "note": "same process, 20 steps each, max over ranks; no_exchange = a world-size-1 trainer on this rank's GPU"}
+                            "no_exchange_ms_per_step": round(none_ms, 3), "dp_equivalent_single_gpu_ms": round(plain_ms, 3),
+                            "note": "same process, 20 steps each, max over ranks; no_exchange = a world-size-1 trainer on this rank's GPU (hash tables stepped "
+                                    "inside their scatters, which no data-parallel rank can do: the exchange needs the gradient tables); dp_equivalent_single_gpu = "
+                                    "the same with table_step=False, i.e. the optimiser path the ranks actually run minus the collectives -- the honest "
+                                    "denominator of a weak-scaling efficiency"}
             exchange_ms = round(here_ms - none_ms, 3)
             exchange_cmp[f"exposed_{mine}_ms"] = exchange_ms
             if other_form != mine:
@@ -725,6 +729,21 @@ def main():
             e2 = float(t)
         second = {"beta": 0.1, "value": round(args.rays * world * n2 / e2, 1), "unit": "rays/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
                   "sampler_rounds_mean": round(sum(int(r_) for r_ in r2[8:]) / n2, 2)}
+    # ---- N = 1: the iteration as a data-parallel rank runs it, minus the collectives (no reduce-and-step: zero-fill, scatters into the
+    # gradient tables, Adam sweep over all 24.7 M parameters) -- the single-GPU time an N-rank curve should be quoted against
+    dp_equiv = None
+    if world == 1 and args.optimizer == "flat" and not args.no_graph and not args.no_second_point:
+        tr_p = Stage1Trainer(conf, device=dev, world_size=1, rank=0, seed=42, optimizer="flat", graph=True, table_step=False)
+        benchmark_model_state(tr_p.model, args.beta)
+        n_p = max(10, min(60, args.steps // 3))
+        for i in range(22 + n_p):
+            if i == 22:
+                barrier()
+                t0 = time.perf_counter()
+            tr_p.train_step_resident(scene)
+        barrier()
+        dp_equiv = round((time.perf_counter() - t0) / n_p * 1e3, 3)
+        del tr_p
     fp32_point = None
     if not args.no_fp32_point and args.precision == "bf16" and world == 1:
         # the reference's own precision, same workload, reported beside the headline
@@ -773,6 +792,10 @@ def main():
             line["config"]["trajectory_point"] = trajectory
             line["config"]["trajectory_rays_per_s"], line["config"]["trajectory_ms_per_step"] = trajectory["value"], trajectory["ms_per_step"]
             line["config"]["trajectory_sampler_rounds_mean"] = trajectory["sampler_rounds_mean"]
+        if dp_equiv is not None:
+            line["config"]["dp_equivalent_single_gpu_ms"] = dp_equiv
+            line["config"]["dp_equivalent_single_gpu_note"] = ("mean ms per step of the same trainer with table_step=False: the optimiser path every "
+                                                               "data-parallel rank runs (gradient tables zero-filled, scattered into, swept by Adam), no collectives")
         if world > 1:
             line["config"]["rccl_world_size"] = rccl_world
             line["config"]["exchange"] = exchange_form

@@ -63,11 +63,13 @@ class Stage1Trainer:
     """
 
     def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, rank=0, optimizer="flat", graph=False, zero1=True,
-                 freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None):
+                 freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None, table_step=None):
         """data_parallel: run the gradient exchange (default: world_size > 1; True with a one-rank process group exercises the
         collectives' code path on a single GPU).  exchange: "overlap" (default; env HOLOSCENE_EXCHANGE) = ZeRO-1 per segment with
         each hash table's segment exchanged on a side stream as soon as its gradient is final, collectives captured inside the
-        iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph."""
+        iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph.
+        table_step: reduce-and-step of the hash tables (below); None = on unless HOLOSCENE_TABLE_STEP=0.  False gives the optimiser
+        path every data-parallel rank runs (zero-fill, scatter into the gradient tables, Adam sweep) in a single process."""
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
@@ -117,7 +119,8 @@ class Stage1Trainer:
         # scatter's reduction; the gradient tables are then never zero-filled, written or read.  HOLOSCENE_TABLE_STEP=0: off (A/B).
         # _table_step_ok: variant -> decided by counting the producers in the variant's first (plain) warm-up pass.
         self._table_step = (graph and self.flat is not None and not self.dp and not freeze_parameters
-                            and os.environ.get("HOLOSCENE_TABLE_STEP", "1") != "0" and self.flat.table_steps_supported()
+                            and (os.environ.get("HOLOSCENE_TABLE_STEP", "1") != "0" if table_step is None else bool(table_step))
+                            and self.flat.table_steps_supported()
                             and self._full_graph_ok())       # (only the whole-iteration graph ticks the optimiser before the backward pass)
         self._table_step_ok = {}
         self._pass_fused = False
