@@ -15,6 +15,7 @@
 //
 //   forward   hc = relu(Wc0 f + bc0);  fv = Wc1 hc + bc1;  r0 = relu(Wr0 [enc | fv] + br0);  r1 = relu(Wr1 r0 + br1);  rgb = sigmoid(Wr2 r1 + br2)
 #include "launch_util.h"
+#include <stdlib.h>
 #include "wave_tile.h"
 #include "trunk_pack.h"
 
@@ -493,6 +494,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
 //   hc~ = (Wc1^T fv~) . [hc > 0];  featc~ = Wc0^T hc~;   d normals = (d enc / d normal)^T enc~(normal)
 // The four 256-wide cotangents leave tile-packed (they are the A operands of the weight gradients), y~ row-major [n, 32]; the ReLU signs
 // come from the forward pass's masks; nothing else of the forward pass is read.
+// STORE = false: ablation for DESIGN 14.1 only (the four tile-packed cotangents are not written: what the kernel would cost if its weight
+// gradients never left the chip); results are then incomplete on purpose (HOLOSCENE_A2_ABLATE=nostore, tools/exp/dw_fusion_bounds.py)
+template <bool STORE>
 __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__restrict__ g_rgb, const float *__restrict__ rgb, const float *__restrict__ normals,
                                                                const uint32_t *__restrict__ masks, const char *__restrict__ streamT,
                                                                uint16_t *__restrict__ gy_out, uint16_t *__restrict__ GR1t, uint16_t *__restrict__ GR0t,
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
         // (counted wait + bare barrier, as in the forward kernel: the tile-packed stores issued since chunk J's request may stay in flight)
         auto chunk_begin = [&](auto jc, auto livec) -> char * {
             constexpr int J = decltype(jc)::value;
-            if constexpr (!decltype(livec)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!decltype(livec)::value || !STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (J == 0) { if (r0 == wt0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
             else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if constexpr (J == 6 || J == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
                 hp[8 * nd + r] = anchor(p);
             } else {
                 constexpr int ks = 4 * qd + (sl - 16);
-                if (live) tp_store_n(T, tile, HS, ks, lane, hp + 4 * ks);
+                if (STORE && live) tp_store_n(T, tile, HS, ks, lane, hp + 4 * ks);
             }
         };
         using L2_ = std::integral_constant<int, 2>;
@@ -807,9 +811,18 @@ int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normal
     if (!g_rgb || !rgb || !normals || !masks || !streamT_image || !gy || !GR1t || !GR0t || !GFVt || !GHCt || !d_normals || !g_featc) return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kBufBytes;
     static hsLdsAttrOnce attr;
-    attr.set((const void *)k_appear2_bwd, (int)lds);
+    static const bool nostore = [] { const char *e = getenv("HOLOSCENE_A2_ABLATE"); return e && e[0] == 'n'; }();
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
-    k_appear2_bwd<<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
+    if (nostore) {
+        static hsLdsAttrOnce attr0;
+        attr0.set((const void *)k_appear2_bwd<false>, (int)lds);
+        k_appear2_bwd<false><<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
+            g_rgb, rgb, normals, masks, (const char *)streamT_image, (uint16_t *)gy, (uint16_t *)GR1t, (uint16_t *)GR0t, (uint16_t *)GFVt, (uint16_t *)GHCt,
+            d_normals, g_featc, gb2, n, normals_add);
+        return wt_check_launch();
+    }
+    attr.set((const void *)k_appear2_bwd<true>, (int)lds);
+    k_appear2_bwd<true><<<(int)(want < 256 ? want : 256), kThreadsW, lds, (hipStream_t)stream>>>(
         g_rgb, rgb, normals, masks, (const char *)streamT_image, (uint16_t *)gy, (uint16_t *)GR1t, (uint16_t *)GR0t, (uint16_t *)GFVt, (uint16_t *)GHCt, d_normals,
         g_featc, gb2, n, normals_add);
     return wt_check_launch();

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int hs_abi_version(void) { return 7; }
+int hs_abi_version(void) { return 8; }
 
 const char *hs_target_arch(void) { return "gfx950"; }
 

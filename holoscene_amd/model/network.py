@@ -544,7 +544,7 @@ class _trunk_render_rr(torch.autograd.Function):
         if RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
             be.trunk_rr_fwd(x[:n], feat[:n], dydx, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         else:
-            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
+            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
             be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
         eik = ()
@@ -1983,6 +1983,9 @@ class RenderingNetwork(nn.Module):
         return self.sigmoid(x[:, :3].float())
 
 
+DEFAULT_FP32_STAGES = ""
+
+
 class HoloSceneNetwork(nn.Module):
     def __init__(self, conf, plots_dir=None, graph_node_dict=None, ft_folder=None, num_images=1024):
         super().__init__()
@@ -2010,6 +2013,16 @@ class HoloSceneNetwork(nn.Module):
         self.implicit_network.set_mlp_precision(precision)
         self.rendering_network.set_mlp_precision(precision)
         self.mlp_precision = precision
+        # bf16 mode only: stages that nevertheless run in the reference's fp32 arithmetic (library GEMMs): any of "sampler" (the no-grad SDF
+        # sweeps), "trunk" (value + gradient of the rendered samples), "eikonal" (value + all K gradients of the 4R regulariser points),
+        # "colour" (feature MLP + rendering network).  Conf key `fp32_stages`, env HOLOSCENE_FP32_STAGES (comma separated).  The default is
+        # decided by what 300-iteration trainings showed (tools/exp/conv_hybrid.py).
+        st = conf.get_list("fp32_stages", default=None)
+        if st is None:
+            st = [t for t in os.environ.get("HOLOSCENE_FP32_STAGES", DEFAULT_FP32_STAGES).split(",") if t]
+        self.fp32_stages = frozenset(st)
+        if self.fp32_stages - {"sampler", "trunk", "eikonal", "colour"}:
+            raise ValueError(f"fp32_stages: unknown stage in {sorted(self.fp32_stages)}")
         self.plots_dir = plots_dir
         self.ft_folder = ft_folder
         self.all_mesh_bbox_dict = None  # only ever set by the Stage-2 trainer (holoscene_train_post.py:715-731)
@@ -2044,6 +2057,9 @@ class HoloSceneNetwork(nn.Module):
         """Colour of every sample [B,3]: colour hash grid -> feature MLP -> rendering network, through the fused matrix-core kernels
         (csrc/appearance_mlp.hip) when the shapes are the stock ones in bf16 mode, else library GEMMs."""
         net = self.implicit_network
+        with self._stage_fp32("colour") as forced:
+            if forced:
+                return self.rendering_network(points_flat, gradients, dirs_flat, net._color_features(points_flat), indices)
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
@@ -2402,7 +2418,27 @@ class HoloSceneNetwork(nn.Module):
                                beta_work=out["beta_work"])
         return out
 
+    @contextlib.contextmanager
+    def _stage_fp32(self, stage):
+        """Run the enclosed stage of a bf16 model in fp32 when `stage` is listed in fp32_stages (autograd Functions record the precision
+        they ran in, so the backward pass follows without the switch)."""
+        net, rn = self.implicit_network, self.rendering_network
+        if not (stage in self.fp32_stages and net.mlp_bf16):
+            yield False
+            return
+        net.set_mlp_precision("fp32")
+        rn.set_mlp_precision("fp32")
+        try:
+            yield True
+        finally:
+            net.set_mlp_precision("bf16")
+            rn.set_mlp_precision("bf16")
+
     def sample(self, rays, rng=None, idx=None):
+        with self._stage_fp32("sampler"):
+            return self._sample(rays, rng, idx)
+
+    def _sample(self, rays, rng=None, idx=None):
         return self.ray_sampler.get_z_vals(rays["ray_dirs"], rays["cam_loc"], self, idx=idx, rng=rng, z0=rays.get("z0"),
                                            beta_init=rays.get("beta_init"), x0=(rays["x0"], rays["x0_grid"]) if "x0" in rays else None,
                                            beta_work=rays.pop("beta_work", None))
@@ -2498,7 +2534,38 @@ class HoloSceneNetwork(nn.Module):
                 eik = torch.cat([e0, near_surface], 0)
                 x_all = torch.cat([points_flat, eik, eik + (jitter - 0.5) * 0.01], 0)
         trunk_W = None
-        if TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
+        hybrid = net.mlp_bf16 and bool(self.fp32_stages & {"trunk", "eikonal"})
+        if hybrid:
+            # per-stage precision (fp32_stages): the two point families of the trunk separately, each by its own precision's path
+            def generic(xs):
+                y_, J_ = net.sdf_and_jacobian(xs)
+                return y_[:, :net.d_out], J_[:, :net.d_out]
+            fused_ok = TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out
+
+            def fused(xs, n_m, x01s):
+                enc = net.encoding
+                l0, l1, l2 = net._lins()
+                W0, W1, W2 = effective_weights([l0, l1, l2])
+                return trunk_render(xs.detach(), n_m, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                                    net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01s)
+            x01m = None if x01_all is None else x01_all[:n_main]
+            x01e = None if x01_all is None else x01_all[n_main:]
+            with self._stage_fp32("trunk") as forced:
+                if forced or not fused_ok:
+                    sdf_raw, J_main = generic(x_all[:n_main])
+                    sdf, idx_min = sdf_raw.min(dim=-1, keepdim=True)
+                    gradients = torch.gather(J_main, 1, idx_min.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)
+                else:
+                    sdf_raw, sdf, idx_min, gradients = fused(x_all[:n_main], n_main, x01m)[:4]
+            min_eik = gtheta = None
+            y_eik, J_eik = sdf_raw[:0], sdf_raw.new_zeros(0, net.d_out, 3)
+            if x_all.shape[0] > n_main:
+                with self._stage_fp32("eikonal") as forced:
+                    if forced or not fused_ok:
+                        y_eik, J_eik = generic(x_all[n_main:])
+                    else:
+                        y_eik, min_eik, gtheta = fused(x_all[n_main:], 0, x01e)[4:]
+        elif TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
             trunk_W = W0, W1, W2 = effective_weights([l0, l1, l2])

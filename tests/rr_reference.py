@@ -44,7 +44,8 @@ def forward(x, feat, dydx, W, jac, bf16=True):
     h0 = r(sp100(a0))
     a1 = h0 @ r(W1).t() + b1
     h1 = r(sp100(a1))
-    y = h1 @ r(W2).t() + b2
+    W2v = r(W2) + r(W2 - r(W2)) if bf16 else W2       # the value product carries W2 as two bf16 planes (trunk_pack.h: the low plane)
+    y = h1 @ W2v.t() + b2
     sdf, idx = y.min(-1)
     s1, s0 = 1 - torch.exp(-100 * h1), 1 - torch.exp(-100 * h0)
     v1 = r(W2[idx] * s1)

@@ -6,7 +6,7 @@ accumulate.  A learnable synthetic scene -- every pixel of three 64 x 64 frames 
 weights) -- is fitted for 300 iterations from one initial state by (a) the benchmarked path, Stage1Trainer(graph=True, bf16), and (b) the fp32
 path on the same batches, on two scenes.  Adam with the reference's eps = 1e-15 takes sign-like steps, so any two runs decorrelate
 element by element within a dozen iterations; what a correct low-precision path must share with fp32 is the OUTCOME:
-(a) must end at the objective of (b) on the same scene -- see the test body for what is and what is not asserted.  Asserted, not printed:
+(a) must end at the objective of (b) on the same scene AND at its balance between the regularisers -- see the test body.  Asserted, not printed:
 no non-finite loss anywhere, all runs learn (the rgb term falls by more than half), the trailing objectives agree.
 """
 import pytest
@@ -89,15 +89,17 @@ def test_bf16_graph_training_tracks_fp32_training():
             print(f"PARITY convergence scene {scene} {k}: bf16 {a:.5f} fp32 {b:.5f} bf16 / fp32 {a / max(abs(b), 1e-12):.3f}, start {start:.5f}")
             # What is asserted (measured over twenty-odd runs, profiles/r04/convergence_run_to_run.txt): the OBJECTIVE ends within 10 % of the
             # fp32 run's on the same scene (observed <= 3.2 %, two runs of one path differ by up to 7 %); the rgb term, which falls to 6 % of
-            # its start (below bf16's resolution of the colours), within 4 % of that start; no single term off by a factor of two.
-            # What is NOT asserted: the split between the regularisers.  On scene 77 the bf16 runs -- graph or eager, any seed -- settle at an
-            # Eikonal term of 0.30 and a normal term of 0.9-1.1 where the fp32 runs settle at 0.51-0.54 and 0.78, at an equal objective
-            # (evaluated on fresh batches in either precision: 2.238 vs 2.272; tools/exp/conv_cross_eval.py); on scene 31 both
-            # paths end at the same split.
+            # its start (below bf16's resolution of the colours), within 4 % of that start; and the SPLIT between the regularisers: the
+            # Eikonal and normal-L1 terms within 15 % of the fp32 run's on both scenes.  Round 4 could not assert the last one: on scene 77 every
+            # bf16 run settled at an Eikonal term of 0.30 / normal 0.95-1.0 against fp32's 0.51-0.54 / 0.78.  The cause was ONE rounding: the
+            # last trunk layer's matrix as a single bf16 plane in the value product of the rendered samples (geometric initialisation leaves its rows at
+            # 0.11 +- 1e-4, bf16's grid there is 4.9e-4; tools/exp/conv_hybrid.py); k_rr_fwd now carries it as two planes.
             if k == "loss" and abs(a - b) > 0.10 * abs(b):
                 bad.append((scene, k, a, b))
             if k == "rgb_loss" and abs(a - b) > 0.04 * abs(start):
                 bad.append((scene, k, a, b))
+            if k in ("eikonal_loss", "normal_l1") and abs(a - b) > 0.15 * abs(b):
+                bad.append((scene, k, a, b, "regulariser split"))
             if not (0.5 * abs(b) <= abs(a) <= 2.0 * abs(b)) and abs(a - b) > 0.04 * abs(start):
                 bad.append((scene, k, a, b, "factor two"))
     assert not bad, bad
