@@ -210,6 +210,16 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                 y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (kW2LowPlane) {      // + W2lo h1 (wave_tile.h): the low plane's fragments from memory (16 KB, cache-resident; LDS is full)
+                uint32_t zlo = 0;
+                asm volatile("" : "+v"(zlo));
+                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f + kW2F) + lane + zlo;
+#pragma unroll
+                for (int s = 0; s < HS / 2; s++) {
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; i++) y[i] = y0[i] + y1[i];
         }
@@ -264,7 +274,7 @@ int64_t hs_sdf_mlp2_pack_bytes(int32_t which) {
     switch (which) {
         case 0: return (int64_t)kW0F * 2;
         case 1: return (int64_t)kW1F * 2;
-        case 2: return (int64_t)kW2F * 2;
+        case 2: return (int64_t)kW2F * 2 * 2;    /* two planes: W2's fragments, then those of W2 - bf16(W2) (wave_tile.h) */
         case 3: return (int64_t)kBias * 4;
         default: return -1;
     }
@@ -274,7 +284,7 @@ int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float 
                      void *W0f, void *W1f, void *W2f, float *bias, int32_t log2_domain, void *stream) {
     if (d_out < 1 || d_out > 32 || ld0 < 71) return HS_ERR_ARG;
     if (!W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !W0f || !W1f || !W2f || !bias) return HS_ERR_NULL;
-    const int slots = K0S * NT * 64 + HS * NT * 64 + HS * 64 + kBias;
+    const int slots = kSdfPackSlots;
     k_sdf_pack2<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(W0, ld0, b0, W1, b1, W2, b2, d_out, (uint16_t *)W0f, (uint16_t *)W1f,
                                                                       (uint16_t *)W2f, bias, log2_domain ? kAct : 1.f);
     return wt_check_launch();

@@ -328,6 +328,16 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (kW2LowPlane) {      // + W2lo h1 (wave_tile.h): value and tangent rows alike; fragments from memory (16 KB, cache-resident; LDS is full)
+                uint32_t zlo = 0;
+                asm volatile("" : "+v"(zlo));
+                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f + kW2F) + lane + zlo;
+                static_for<HS / 2>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                });
+            }
         }
         // ---- outputs: register i <-> output 8 (i >> 2) + 4 h + (i & 3); the bias belongs to the value row only
         if constexpr (!SPLIT) {

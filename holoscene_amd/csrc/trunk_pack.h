@@ -15,16 +15,12 @@ constexpr float kC = 144.269504f;           // 100 log2(e)
 __host__ __device__ inline int slot_column(int hh, int sigma) { return sigma < 40 ? input_column(hh, sigma) : -1; }
 
 // ---------------------------------------------------------------------------------------------------------------- packing
-// W1^T, W0^T (slot order), W2^T as fragment images, W2 as an fp32 gather table [32][256] and, behind the table, the LOW PLANE of W2's
-// forward fragments (kW2F bf16: fragment (s, lane) of W2 - bf16(W2)).  The last layer's rows are a large common value plus small learned
-// structure (geometric initialisation: 0.11 +- 1e-4, where bf16's grid is 4.9e-4): one bf16 plane of W2 in the VALUE product y = W2 h1 loses
-// that structure and training settles elsewhere; the forward kernels therefore add W2lo h1 to W2hi h1.
-constexpr int kW2LoOff = 32 * 256;          // floats from W2tab to the low-plane image
-constexpr int kRrPackSlots = HS * NT * 64 + HS * XS * 64 + 2 * NT * 64 + 32 * 256 / 4 + HS * 64;
+// W1^T, W0^T (slot order), W2^T as fragment images, W2 as an fp32 gather table [32][256]
+constexpr int kRrPackSlots = HS * NT * 64 + HS * XS * 64 + 2 * NT * 64 + 32 * 256 / 4;
 __device__ __forceinline__ void rr_pack_slot(int idx, const float *__restrict__ W0, int ld0, const float *__restrict__ W1, const float *__restrict__ W2, int d_out,
                                              uint16_t *__restrict__ W1Tf, uint16_t *__restrict__ W0Tf, uint16_t *__restrict__ W2Tf,
                                              float *__restrict__ W2tab) {
-    constexpr int n1 = HS * NT * 64, n0 = HS * XS * 64, n2 = 2 * NT * 64, nt = 32 * 256 / 4, nlo = HS * 64;
+    constexpr int n1 = HS * NT * 64, n0 = HS * XS * 64, n2 = 2 * NT * 64, nt = 32 * 256 / 4;
     float v[8];
     uint16_t *dst;
     if (idx < n1) {
@@ -52,14 +48,6 @@ __device__ __forceinline__ void rr_pack_slot(int idx, const float *__restrict__ 
         if (k < d_out) o = *reinterpret_cast<const float4 *>(W2 + (size_t)k * 256 + n);
         *reinterpret_cast<float4 *>(W2tab + 4 * i) = o;
         return;
-    } else if (idx < n1 + n0 + n2 + nt + nlo) {      // low plane of the forward fragments of W2 (wave_tile.h: sdf_pack2_slot's W2f order)
-        const int i = idx - n1 - n0 - n2 - nt, s = i / 64, lane = i & 63, n = lane & 31, kh = lane >> 5;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float w = n < d_out ? W2[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * kh + (e & 3)] : 0.f;
-            v[e] = w - __uint_as_float(pack2(w, 0.f) << 16);
-        }
-        dst = reinterpret_cast<uint16_t *>(W2tab + kW2LoOff) + (size_t)i * 8;
     } else {
         return;
     }

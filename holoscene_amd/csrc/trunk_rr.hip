@@ -162,10 +162,10 @@ __device__ __forceinline__ uint32_t tile_word(const TilePair &t, int p) { return
 // sdf_mlp2.hip's function with plain-domain Softplus; H0 / H1 leave tile-packed, the assembled inputs as Xp [n, 80] (trunk_mlp2.hip's column order)
 __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
                                                                 const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
-                                                                const float *__restrict__ biasg, const uint16_t *__restrict__ W2lo, int d_out,
-                                                                uint16_t *__restrict__ H0t, uint16_t *__restrict__ H1t, uint16_t *__restrict__ Xp,
-                                                                float *__restrict__ sdf_raw, float *__restrict__ sdf, int64_t *__restrict__ idx,
-                                                                uint16_t *__restrict__ onehot, int64_t n) {
+                                                                const float *__restrict__ biasg, int d_out, uint16_t *__restrict__ H0t,
+                                                                uint16_t *__restrict__ H1t, uint16_t *__restrict__ Xp, float *__restrict__ sdf_raw,
+                                                                float *__restrict__ sdf, int64_t *__restrict__ idx, uint16_t *__restrict__ onehot,
+                                                                int64_t n) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -272,12 +272,12 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__re
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            // the low plane of W2 (trunk_pack.h): same k-step order as k_rr_fwd, whose results this kernel reproduces bit for bit; its fragments
-            // come from global memory here (16 KB, cache-resident; this kernel's LDS is full and it is not on the default path)
+            // the low plane of W2 (wave_tile.h: behind the high plane in the packed image): same k-step order as k_rr_fwd, whose results this
+            // kernel reproduces bit for bit; its fragments come from global memory here (16 KB, cache-resident; this kernel's LDS is full)
             {
                 uint32_t zlo = 0;
                 asm volatile("" : "+v"(zlo));
-                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2lo) + lane + zlo;
+                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f + kW2F) + lane + zlo;
                 static_for<HS / 2>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
@@ -804,10 +804,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                                                           int64_t n, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) char ldsf[];
     float *bias = reinterpret_cast<float *>(ldsf + 2 * kFBuf);
-    char *W2lol = ldsf + 2 * kFBuf + kBias * sizeof(float);      // resident: the low plane of W2's fragments (16 KB, trunk_pack.h), behind the bias block
+    char *W2lol = ldsf + 2 * kFBuf + kBias * sizeof(float);      // resident: the low plane of W2's fragments (16 KB, wave_tile.h), behind the bias block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), row = lane & 31, h = lane >> 5;
     int par = 0;
-    dma_fill(W2tab + kW2LoOff, W2lol, kW2F * 2, wave, lane);       // (lands before the first chunk barrier: that one waits for vmcnt(0))
+    dma_fill(W2f + kW2F, W2lol, kW2F * 2, wave, lane);             // (lands before the first chunk barrier: that one waits for vmcnt(0))
     // chunk J of a super-tile: 0 W0 (8 tiles x 5 k-steps), 1-2 W1 (4 tiles each), 3 W2, 4-5 W1^T, 6 W0^T (3 slot tiles)
     auto request = [&](int J, int buf) {
         char *dst = ldsf + buf * kFBuf;
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            {   // + W2lo h1 (trunk_pack.h: the low plane)
+            {   // + W2lo h1 (wave_tile.h: the low plane)
                 const uint32_t lb = lds_base(W2lol, lane * 16);
                 static_for<HS / 2>([&](auto sc) {
                     constexpr int s_ = decltype(sc)::value;
@@ -1116,7 +1116,7 @@ int64_t hs_trunk_rr_pack_bytes(int32_t which) {
         case 0: return (int64_t)kW1F * 2;        /* W1^T image */
         case 1: return (int64_t)kW0TF * 2;       /* W0^T image */
         case 2: return (int64_t)kW2TF * 2;       /* W2^T image */
-        case 3: return (int64_t)32 * 256 * 4 + (int64_t)kW2F * 2;    /* W2 gather table | low plane of W2's forward fragments */
+        case 3: return (int64_t)32 * 256 * 4;    /* W2 gather table */
         default: return -1;
     }
 }
@@ -1156,18 +1156,17 @@ int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, i
     return wt_check_launch();
 }
 
-int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, const float *W2tab,
-                          int32_t d_out, void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream) {
+int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
+                          void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream) {
     if (d_out < 1 || d_out > 32) return HS_ERR_ARG;
     if (n == 0) return HS_OK;
-    if (!x || !feat || !W0f || !W1f || !W2f || !bias || !W2tab || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx || !onehot) return HS_ERR_NULL;
+    if (!x || !feat || !W0f || !W1f || !W2f || !bias || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx || !onehot) return HS_ERR_NULL;
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
     static hsLdsAttrOnce attr;
     attr.set((const void *)k_rr_fwd_value, (int)lds);
-    k_rr_fwd_value<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias,
-                                                                    reinterpret_cast<const uint16_t *>(W2tab + kW2LoOff), d_out, (uint16_t *)H0t,
-                                                                    (uint16_t *)H1t, (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, n);
+    k_rr_fwd_value<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                    (uint16_t *)H0t, (uint16_t *)H1t, (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, n);
     return wt_check_launch();
 }
 

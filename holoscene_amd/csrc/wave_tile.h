@@ -57,14 +57,23 @@ __host__ __device__ inline int input_column(int h, int j) {
 
 // ---------------------------------------------------------------------------------------------------------------- weight packing
 // fp32 effective (weight-normalised) matrices, row-major [out][in] -> bf16 fragment images + the bias block
-constexpr int kSdfPackSlots = K0S * NT * 64 + HS * NT * 64 + HS * 64 + kBias;      // one thread per 16-byte fragment slot / bias entry
+// W2f is TWO bf16 planes, [W2 high | W2 low] (kW2F elements each; low = W2 - bf16(W2) in the same fragment order): the last layer's rows are a
+// large common value plus small learned structure (geometric initialisation: 0.11 +- 1e-4 where bf16's grid is 4.9e-4), which a single plane
+// loses -- measured: bf16 training then settles at another balance of its regularisers.  Every forward kernel forms
+// y = W2hi h1 + W2lo h1; the resident LDS image stays [W1 | W2 high], the low plane is read from memory (16 KB, cache-resident) or kept in LDS
+// where there is room (k_rr_fwd).
+#ifndef HS_W2_LOW_PLANE
+#define HS_W2_LOW_PLANE 1
+#endif
+constexpr bool kW2LowPlane = HS_W2_LOW_PLANE;     // (0: ablation -- the single-plane products of rounds 1-4)
+constexpr int kSdfPackSlots = K0S * NT * 64 + HS * NT * 64 + 2 * HS * 64 + kBias;      // one thread per 16-byte fragment slot / bias entry
 __device__ __forceinline__ void sdf_pack2_slot(int idx, const float *__restrict__ W0, int ld0, const float *__restrict__ b0, const float *__restrict__ W1,
                                                const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2, int d_out,
                                                uint16_t *__restrict__ W0f, uint16_t *__restrict__ W1f, uint16_t *__restrict__ W2f,
                                                float *__restrict__ bias, float act) {
     // act: factor folded into W0 and the hidden biases (its inverse into W2): 100 log2(e) for the inference kernel's log2-domain
     // softplus, 1 for the training kernel (which stores plain-domain activations for the backward pass)
-    constexpr int n0 = K0S * NT * 64, n1 = HS * NT * 64, n2 = HS * 64;
+    constexpr int n0 = K0S * NT * 64, n1 = HS * NT * 64, n2 = 2 * HS * 64;
     float v[8];
     uint16_t *dst;
     if (idx < n0) {
@@ -81,9 +90,12 @@ __device__ __forceinline__ void sdf_pack2_slot(int idx, const float *__restrict_
         for (int e = 0; e < 8; e++) v[e] = W1[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)];
         dst = W1f + (size_t)i * 8;
     } else if (idx < n0 + n1 + n2) {
-        const int i = idx - n0 - n1, s = i / 64, lane = i & 63, n = lane & 31, h = lane >> 5;
+        const int i = idx - n0 - n1, plane = i / (HS * 64), s = (i / 64) % HS, lane = i & 63, n = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = n < d_out ? W2[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)] * (1.f / act) : 0.f;
+        for (int e = 0; e < 8; e++) {
+            const float w = n < d_out ? W2[(size_t)n * 256 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)] * (1.f / act) : 0.f;
+            v[e] = plane == 0 ? w : w - __uint_as_float(pack2(w, 0.f) << 16);      // low plane: what the high plane's rounding dropped
+        }
         dst = W2f + (size_t)i * 8;
     } else {
         const int i = idx - n0 - n1 - n2;

@@ -886,12 +886,12 @@ class _HipBackend:
         return out
 
     @staticmethod
-    def trunk_rr_fwd_value(x, feat, packed, rr, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot):
+    def trunk_rr_fwd_value(x, feat, packed, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot):
         lib = load_library()
         bf = torch.bfloat16
         W0f, W1f, W2f, bias = packed
         _check(lib.hs_trunk_rr_fwd_value(_dev(x, "x"), _dev(feat, "feat"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
-                                         _dev(rr[3], "W2tab"), int(d_out), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(Xp, "Xp", bf), _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"),
+                                         int(d_out), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(Xp, "Xp", bf), _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"),
                                          _dev(idx, "idx", torch.int64), _dev(onehot, "onehot", bf), ctypes.c_int64(x.shape[0]), _stream()), "hs_trunk_rr_fwd_value")
 
     @staticmethod

@@ -544,7 +544,7 @@ class _trunk_render_rr(torch.autograd.Function):
         if RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
             be.trunk_rr_fwd(x[:n], feat[:n], dydx, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         else:
-            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
+            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
             be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
         eik = ()
@@ -1604,12 +1604,29 @@ class ObjectImplicitNetworkGrid(nn.Module):
         return h
 
     # ---------------------------------------------------------------- fused matrix-core inference (bf16 mode)
-    def _fused_trunk_supported(self, x):
+    def fused_trunk_blockers(self):
+        """Why the hand-written matrix-core kernels cannot take this trunk (empty list: they can) -- the shape is whatever the conf says
+        (reference: model/network.py:19-167), the kernels are built for the stock one."""
         lins = self._lins()
-        return (self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None
-                and self.embedder.multires == 6 and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].out_features == 256
-                and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features <= 64
-                and not any(l in self.skip_in for l in range(3)))
+        why = []
+        if len(lins) != 3:
+            why.append(f"{len(lins)} linear layers (kernels: 3)")
+            return why
+        if self.embedder is None or self.embedder.multires != 6:
+            why.append(f"multires = {getattr(self.embedder, 'multires', 0)} (kernels: 6 frequencies)")
+        if self.grid_feature_dim != 32 or not self._stock_grid():
+            enc = self.encoding
+            why.append(f"hash grid {getattr(enc, 'num_levels', '?')} levels x {getattr(enc, 'level_dim', '?')} channels (kernels: 16 x 2)")
+        if not (lins[0].out_features == 256 and lins[1].in_features == 256 and lins[1].out_features == 256):
+            why.append(f"hidden widths {lins[0].out_features}, {lins[1].out_features} (kernels: 256, 256)")
+        if lins[2].out_features > 64:
+            why.append(f"d_out = {lins[2].out_features} (kernels: <= 64)")
+        if any(l in self.skip_in for l in range(3)):
+            why.append(f"skip connection into layer {sorted(l for l in self.skip_in if l < 3)}")
+        return why
+
+    def _fused_trunk_supported(self, x):
+        return self.mlp_bf16 and x.is_cuda and not self.fused_trunk_blockers()
 
     def _rr32_supported(self, x):
         """fp32 trunk of the stock shape (71 -> 256 -> 256 -> K, softplus 100, no skip, 16 x 2 hash features, 6 frequencies) on the device"""
@@ -2028,6 +2045,39 @@ class HoloSceneNetwork(nn.Module):
         self.all_mesh_bbox_dict = None  # only ever set by the Stage-2 trainer (holoscene_train_post.py:715-731)
 
     # ---------------------------------------------------------------- compositing (network.py:1803-1824)
+    def fused_path_report(self):
+        """Which parts of a bf16 training iteration leave the benchmarked kernels, and why: [] = none (the stock path: wave-tile kernels, ONE
+        weight-pack launch, whole-iteration graph).  Training warns once per model when the list is not empty (`_warn_off_fused_path`)."""
+        net, rn = self.implicit_network, self.rendering_network
+        if not net.mlp_bf16:
+            return []           # the fp32 configuration is a choice, not a fallback
+        out = []
+        blockers = net.fused_trunk_blockers()
+        if blockers:
+            out.append("SDF trunk on library GEMMs + elementwise launches, sampler rounds host-controlled, no whole-iteration graph: " + "; ".join(blockers))
+        else:
+            K = net._lins()[2].out_features
+            if K != net.d_out:
+                out.append(f"trunk output width {K} != d_out {net.d_out}: rendered samples on the library-GEMM value+Jacobian path")
+            elif K > 32:
+                out.append(f"d_out = {K} > 32: SDF sweeps, rendered samples and Eikonal points on the 128-point workgroup-tile kernels (four value+Jacobian rows per "
+                           "point) instead of the wave-tile / reverse-over-reverse kernels; per-call weight packing")
+        probe = self.density.beta
+        if probe.is_cuda and not self._fused_appearance_supported(probe):
+            out.append("colour branch on library GEMMs: it is not the stock one (idr mode, four layers of 256, 4 frequencies each, 16 x 2 colour grid, "
+                       "256-wide feature MLP)")
+        return out
+
+    def _warn_off_fused_path(self):
+        if getattr(self, "_off_fused_warned", False):
+            return
+        self._off_fused_warned = True
+        report = self.fused_path_report()
+        if report:
+            import warnings
+            warnings.warn("holoscene_amd: this conf does not run on the benchmarked bf16 kernels end to end -- " + " | ".join(report)
+                          + " (DESIGN.md section 5; expect a slower iteration, results unchanged)")
+
     def _fused_appearance_supported(self, x):
         net, rn = self.implicit_network, self.rendering_network
         if not (x.is_cuda and net.mlp_bf16 and rn.mlp_bf16 and net.color_grid_feature and rn.mode == "idr" and rn.num_layers == 4):
@@ -2494,6 +2544,8 @@ class HoloSceneNetwork(nn.Module):
         num_rays = ray_dirs.shape[0]
         N_samples = z_vals.shape[1]
         net = self.implicit_network
+        if self.training and ray_dirs.is_cuda:
+            self._warn_off_fused_path()
         if self.training and self.all_mesh_bbox_dict is not None:
             raise NotImplementedError("collision-driven Eikonal sampling belongs to Stage 2 (network.py:868-902)")
         n_main = num_rays * N_samples

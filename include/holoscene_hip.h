@@ -644,9 +644,9 @@ int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const 
  * closed form on rows that are SAMPLES: see the header of csrc/trunk_rr.hip for the equations.  bf16 operands, fp32 accumulation.
  * "TP" = tile-packed activation tensor: [ceil(n / 32)][16][64] x 8 bf16 (lane (sample, half)'s four packed words of every k-step);
  * rows past n are written as zeros.  Images: W0f / W1f / W2f / bias from hs_sdf_mlp2_pack(log2_domain = 0); W1Tf / W0Tf / W2Tf / W2tab
- * from hs_trunk_rr_pack (sizes: hs_trunk_rr_pack_bytes(0..3)).  W2tab = W2 as an fp32 gather table [32][256] FOLLOWED BY the low plane of
- * W2's forward fragments (16 KB of bf16: W2 - bf16(W2) in W2f's order): the forward kernels form y = (W2f + W2lo) h1 -- the last layer's rows are
- * a large common value plus small learned structure, which one bf16 plane loses (ABI 8).
+ * from hs_trunk_rr_pack (sizes: hs_trunk_rr_pack_bytes(0..3)).  W2f is TWO bf16 planes since ABI 8 (hs_sdf_mlp2_pack_bytes(2) = 32 KB): W2's
+ * fragments, then those of W2 - bf16(W2); every forward kernel forms y = (W2hi + W2lo) h1 -- the last layer's rows are a large common value plus
+ * small learned structure, which one bf16 plane loses.
  *   fwd_value: x [n,3], feat [n,32] (point-major)  ->  H0t, H1t (TP), Xp [n,80] bf16 (hs_trunk_mlp2_input_column order), sdf_raw [n,K],
  *              sdf [n], idx [n] (arg-min, lowest among equals), onehot [n,32] bf16 (1 at idx)
  *   fwd_grad:  dydx [L=16, n, 6] as hs_hash_fwd wrote it  ->  U0t, V1t, V0t (TP), grad [n,3] = d min / dx, uxh [n,32] (hash columns of ux)
@@ -666,8 +666,8 @@ int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float 
 int hs_trunk_pack_all(const float *W0, int32_t ld0, int32_t f_in, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
                       void *W0f, void *W1f, void *W2f, float *bias, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab, void *w1t, void *w2t, void *w0t,
                       void *stream);
-int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, const float *W2tab,
-                          int32_t d_out, void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
+int hs_trunk_rr_fwd_value(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
+                          void *H0t, void *H1t, void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, int64_t n, void *stream);
 int hs_trunk_rr_fwd_grad(const float *x, const float *dydx, const int64_t *idx, const float *W2tab, const void *W1Tf, const void *W0Tf, const void *H0t,
                          const void *H1t, void *U0t, void *V1t, void *V0t, float *grad, float *uxh, float jac_scale, int64_t n, int64_t ld, void *stream);
 /* (hs_trunk_rr_bwd_grad: g_dydx may be NULL -- its content is the rank-one product jac_scale * uxh[b, level * 2 + c] * g_grad[b, d], which

@@ -200,3 +200,27 @@ def test_render_outputs_defer_entries_until_read():
     assert o.get("zz", 7) == 7
     with pytest.raises(KeyError):
         o["zz"]
+
+
+def test_off_fused_path_is_reported_with_its_reason():
+    """A conf whose shapes the hand-written bf16 kernels do not cover must SAY so: fused_path_report names the
+    reason, render() warns once per model in training.  Stock shape: nothing to report."""
+    from holoscene_amd.model.network import HoloSceneNetwork
+    from holoscene_amd.training.trainer import stock_conf
+    stock = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=32, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
+    assert stock.implicit_network.fused_trunk_blockers() == [] and stock.fused_path_report() == []
+    k40 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=40, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
+    rep = k40.fused_path_report()
+    assert k40.implicit_network.fused_trunk_blockers() == [] and len(rep) == 1 and "d_out = 40 > 32" in rep[0]
+    l8 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=8, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
+    assert any("hash grid 8 levels" in w for w in l8.implicit_network.fused_trunk_blockers())
+    assert "library GEMMs" in l8.fused_path_report()[0]
+    with pytest.warns(UserWarning, match="does not run on the benchmarked bf16 kernels"):
+        l8._warn_off_fused_path()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        l8._warn_off_fused_path()           # once per model
+        stock._warn_off_fused_path()        # nothing to say
+    fp32 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=8, mlp_precision="fp32", logmap=8, end_size=64).get_config("model"))
+    assert fp32.fused_path_report() == []   # the reference's precision is a choice, not a fallback

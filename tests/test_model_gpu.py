@@ -809,11 +809,14 @@ def test_table_steps_inside_the_scatters_train_like_the_separate_adam_kernel(mon
                 assert not bool(tr.flat.flat_g[:tr.flat.tables_end].any()), it
         assert int(tr.flat.read_state().step) == 2
         snap = (tr.flat.flat_p.clone() - start, tr.flat.flat_m.clone(), tr.flat.flat_v.clone(), losses)
-        for _ in range(30):
+        for _ in range(58):
             idx, mi, gt = scene.next_batch()
             _, lo = tr.train_step(idx, mi, gt)
             losses.append(float(lo["loss"]))
-        assert all(l == l and abs(l) < 1e6 for l in losses) and sum(losses[-5:]) < sum(losses[:5])
+        # (random images at the stock learning rates: every precision -- fp32 included -- spikes to 12-16 between iterations 10 and 40 and
+        #  settles near 3.4 by iteration 50, tools/exp/loss_seq.py; medians, not sums of five)
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        assert all(l == l and abs(l) < 1e6 for l in losses) and med(losses[-10:]) < med(losses[:5]), losses
         if mode == "1":
             assert tr._table_step_ok == {(True, False): False, (False, False): True}
             assert not bool(tr.flat.flat_g[:tr.flat.tables_end].any())
@@ -889,6 +892,21 @@ def test_fused_background_pass_vs_torch_formulation(trunk_mode, monkeypatch):
         res[impl] = (out["bg_mask"], out["bg_depth_values"].detach(), out["bg_normal_map"].detach(), grads)
     a, b = res["hip"], res["torch"]
     assert float((a[0] != b[0]).float().mean()) <= (0.01 if tight else 0.03)          # argmax labels: ties aside, identical
+    if not tight:
+        # the labels against an fp32 evaluation of the same patch.  At this model state the K rows of the last layer's matrix differ by ~1e-4
+        # around 0.11 -- below the grid of ONE bf16 plane --, so the label arg-max is decided by what the second plane of W2 carries
+        # (wave_tile.h): with single-plane value products (rounds 1-4) 4.1 % of these labels differed from fp32, now 0.3 %.
+        net = model.implicit_network
+        net.set_mlp_precision("fp32")
+        model.rendering_network.set_mlp_precision("fp32")
+        monkeypatch.setattr(N, "BG_IMPL", "torch")
+        with torch.no_grad():
+            ref_mask = model.render(rays, z, z_eik, None, rng=rng, bg=dict(bg))["bg_mask"]
+        net.set_mlp_precision("bf16")
+        model.rendering_network.set_mlp_precision("bf16")
+        off_fused, off_plain = float((a[0] != ref_mask).float().mean()), float((b[0] != ref_mask).float().mean())
+        print(f"PARITY bg pass rr labels differing from the fp32 evaluation: fused {off_fused:.4f}, whole-tensor bf16 {off_plain:.4f}")
+        assert off_fused <= 0.01 and off_plain <= 0.01, (off_fused, off_plain)
     close(a[1], b[1], 1e-4 if tight else 5e-3, 1e-5 if tight else 5e-3, "bg depth")
     close(a[2], b[2], 1e-4 if tight else 1e-2, 1e-5 if tight else 3e-2, "bg normal map")       # rr: measured max 1.3e-2
     for ga, gb, p in zip(a[3], b[3], params):

@@ -44,7 +44,7 @@ def test_rr_kernels_vs_torch_restatement(n, K):
     H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
     Xp, onehot = torch.zeros(n, 80, device=DEV, dtype=bf), torch.zeros(n, 32, device=DEV, dtype=bf)
     sdf_raw, sdf, idx = torch.empty(n, K, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64)
-    be.trunk_rr_fwd_value(x, feat, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot)
+    be.trunk_rr_fwd_value(x, feat, packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot)
     f = R.forward(x, feat, dydx, W, jac)
     print("PARITY rr fwd_value y", rel(sdf_raw, f["y"]), "h0", rel(R.tp_decode(H0t, n), f["h0"]), "h1", rel(R.tp_decode(H1t, n), f["h1"]))
     assert rel(sdf_raw, f["y"]) < 1e-2 and rel(R.tp_decode(H0t, n), f["h0"]) < 1e-2 and rel(R.tp_decode(H1t, n), f["h1"]) < 1.5e-2
@@ -221,7 +221,7 @@ def test_fused_forward_equals_the_pair_at_the_benchmarked_size():
                     raw=torch.empty(n, K, device=DEV), sdf=torch.empty(n, device=DEV), idx=torch.empty(n, device=DEV, dtype=torch.int64),
                     grad=torch.empty(n, 3, device=DEV), uxh=torch.empty(n, 32, device=DEV))
     a = buffers()
-    be.trunk_rr_fwd_value(x, feat, packed, rr, K, a["H0t"], a["H1t"], a["Xp"], a["raw"], a["sdf"], a["idx"], a["onehot"])
+    be.trunk_rr_fwd_value(x, feat, packed, K, a["H0t"], a["H1t"], a["Xp"], a["raw"], a["sdf"], a["idx"], a["onehot"])
     be.trunk_rr_fwd_grad(x, dydx, a["idx"], rr, a["H0t"], a["H1t"], a["U0t"], a["V1t"], a["V0t"], a["grad"], a["uxh"], 0.5)
     for run in range(5):
         b = buffers()

@@ -21,7 +21,7 @@ grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
 
 
 def split():
-    be.trunk_rr_fwd_value(x, feat, packed, rr, K, H0t, H1t, Xp, raw, sdf, idx, onehot)
+    be.trunk_rr_fwd_value(x, feat, packed, K, H0t, H1t, Xp, raw, sdf, idx, onehot)
     be.trunk_rr_fwd_grad(x, dydx, idx, rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, 0.5)
 
 
