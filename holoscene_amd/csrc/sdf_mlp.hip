@@ -156,7 +156,9 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
         layer_mma(W1, HID, HID, H, Wc, acc, nq, ph, lane);
         epilogue_softplus(bias + HID, H, acc, nq, ph, lane);
         // ---- layer 2: stage W2 [32*NOUT_TILES][HID] with pitch HP into the chunk area
-        for (int idx = threadIdx.x; idx < 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
+        // (W2 = two bf16 planes [2][32 NOUT_TILES][HID]: the matrix, then what its rounding dropped -- the last layer's rows are a large common
+        //  value plus small learned structure that one plane loses; both planes fit the chunk area)
+        for (int idx = threadIdx.x; idx < 2 * 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
             const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
         }
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
 #pragma unroll
                 for (int t = 0; t < NOUT_TILES; t++) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(t * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)((NOUT_TILES + t) * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
                     y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[t], 0, 0, 0);
+                    y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, y[t], 0, 0, 0);
                 }
             }
             // lane holds, for point prow, neurons t*32 + (i&3) + 8*(i>>2) + 4*(lane>>5)
@@ -340,7 +344,9 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
         zero_acc(acc);
         layer_mma(W1, HID, HID, H, Wc, acc, nq, ph, lane);
         epilogue_tangent(bias + HID, H, acc, nq, ph, lane);
-        for (int idx = threadIdx.x; idx < 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
+        // (W2 = two bf16 planes [2][32 NOUT_TILES][HID]: the matrix, then what its rounding dropped -- the last layer's rows are a large common
+        //  value plus small learned structure that one plane loses; both planes fit the chunk area)
+        for (int idx = threadIdx.x; idx < 2 * 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
             const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
         }
@@ -359,7 +365,9 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
 #pragma unroll
                 for (int t = 0; t < NOUT_TILES; t++) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)(t * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Wc + (size_t)((NOUT_TILES + t) * 32 + (lane & 31)) * HP + ks * 16 + (lane >> 5) * 8);
                     y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[t], 0, 0, 0);
+                    y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, y[t], 0, 0, 0);
                 }
             }
             const int64_t gr = r0 + prow;

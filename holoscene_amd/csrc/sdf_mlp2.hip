@@ -22,6 +22,7 @@
 // Softplus(beta = 100) is evaluated in the scaled domain of sdf_mlp.hip (t = 100 log2(e) v: log2(1 + 2^t)), the biases initialise
 // the accumulators.  d_out <= 32 (one output tile); wider heads keep the workgroup-tile kernel.
 #include "launch_util.h"
+#include <stdlib.h>
 #include "wave_tile.h"
 
 #ifdef HS_SDF2_PROFILE     // tools/exp/sdf2_prof.hip: per-phase s_memtime stamps of a steady-state wave tile
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                                                             const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
                                                             const float *__restrict__ biasg, int d_out, int select, uint64_t select_mask,
                                                             float *__restrict__ out_min, float *__restrict__ out_raw, int64_t B, hsGate gate,
-                                                            int feat_level_major) {
+                                                            int feat_level_major, int lo_plane) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
 #ifdef HS_SDF2_PROFILE
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                 y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3][1], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (kW2LowPlane) {      // + W2lo h1 (wave_tile.h): the low plane's fragments from memory (16 KB, cache-resident; LDS is full)
+            if (kW2LowPlane && lo_plane) {    // + W2lo h1 (wave_tile.h): the low plane's fragments from memory (16 KB, cache-resident; LDS is full)
                 uint32_t zlo = 0;
                 asm volatile("" : "+v"(zlo));
                 const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f + kW2F) + lane + zlo;
@@ -304,9 +305,13 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     const int64_t ntiles = (B + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);      // one workgroup per CU (146 KB of LDS), wave tiles strided across the grid
+    // The no-grad sweeps leave W2's low plane out by default: they only place samples, a 300-iteration training with fp32 sweeps ends where
+    // one with these bf16 sweeps does (profiles/r05/bf16_stage_hunt.txt, stage "sampler"), and the plane's fragments -- from memory, this
+    // kernel's LDS is full -- cost 3 us per sweep (same-box A/B: 1.606 -> 1.621 ms per iteration).  HOLOSCENE_SDF_W2_PLANES=2 adds it.
+    static const int planes = [] { const char *e = getenv("HOLOSCENE_SDF_W2_PLANES"); return (e && e[0] == '2') ? 2 : 1; }();
     k_sdf_mlp2<<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
-                                                               feat_level_major);
+                                                               feat_level_major, planes == 2);
     return wt_check_launch();
 }
 

@@ -265,6 +265,19 @@ def _wgrad_rows_many(pairs, ready_parts=()):
     return [direct[i] for i in range(len(pairs))] + sums[len(parts):]
 
 
+def _w2_planes(f2, d_out, KP, scale=1.0):
+    """The last trunk layer for the workgroup-tile kernels (csrc/sdf_mlp.hip): bf16 [2 KP, 256] = [W2 | W2 - bf16(W2)] (rows >= d_out of each
+    plane zero), both scaled -- the second plane carries what one bf16 plane of these rows (a large common value plus small learned
+    structure) loses."""
+    w2 = torch.empty(2 * KP, 256, device=f2.device, dtype=torch.bfloat16)
+    f2s = f2 * scale if scale != 1.0 else f2
+    lo = (f2s - f2s.to(torch.bfloat16).float()).contiguous()
+    if os.environ.get("HOLOSCENE_W2_PLANES", "2") == "1":      # ablation: the single-plane products of rounds 1-4
+        lo = torch.zeros_like(lo)
+    _be._backend.pack_bf16([(f2s.contiguous(), w2[:KP], 0, 0, d_out, 256, False), (lo, w2[KP:], 0, 0, d_out, 256, False)])
+    return w2
+
+
 def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None, split=None):
     """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save.
     x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points).
@@ -308,9 +321,9 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L == 16 and C == 2 and D == 3   # k_trunk_fwd assembles its input rows itself
     if not build_in_kernel:
         _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
-    w0, w1, w2 = (torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf),
-                  torch.empty(KP, 256, device=dev, dtype=bf))
-    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False), (f2, w2, 0, 0, d_out, 256, False),
+    w0, w1 = torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)
+    w2 = _w2_planes(f2, d_out, KP)
+    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False),
                             (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
     if build_in_kernel:
         _be._backend.trunk_mlp_fwd(None, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y, x.float(), feat, dydx, X, L, C, jac_scale)
@@ -1661,14 +1674,15 @@ class ObjectImplicitNetworkGrid(nn.Module):
         l0, l1, l2 = self._lins()
         dev, bf = l0.weight_v.device, torch.bfloat16
         n2 = 32 * ((l2.out_features + 31) // 32)
-        w0, w1, w2 = torch.empty(256, 96, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf), torch.empty(n2, 256, device=dev, dtype=bf)
+        w0, w1 = torch.empty(256, 96, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)
         with torch.no_grad():
             f0, f1, f2 = effective_weights([l0, l1, l2])
         # k_sdf_mlp works in the scaled activation domain t = 100*log2(e)*v (csrc/sdf_mlp.hip, softplus_scaled): the factor goes into
-        # W0 (the kernel scales the biases), its inverse ln2/100 into W2; W1 needs none
+        # W0 (the kernel scales the biases), its inverse ln2/100 into W2 (two bf16 planes: _w2_planes); W1 needs none
         act = 100.0 * 1.4426950408889634
-        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False, act), (f1, w1, 0, 0, 256, 256, False),
-                                (f2, w2, 0, 0, l2.out_features, 256, False, 1.0 / act)])
+        with torch.no_grad():
+            w2 = _w2_planes(f2.detach().float(), l2.out_features, n2, 1.0 / act)
+        _be._backend.pack_bf16([(f0, w0, 0, 0, 256, l0.in_features, False, act), (f1, w1, 0, 0, 256, 256, False)])
         self._packed_cache = (w0, l0.bias.detach().float().contiguous(), w1, l1.bias.detach().float().contiguous(), w2,
                               l2.bias.detach().float().contiguous())
         return self._packed_cache

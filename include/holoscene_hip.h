@@ -356,7 +356,7 @@ int hs_composite_bwd(const float *z, const float *sdf, const float *raw, const f
  * SDF branch of ObjectImplicitNetworkGrid.forward (model/network.py:169-210) for no-grad queries (the sampler's
  * sweeps, get_sdf_vals / get_object_sdf_vals :305-318), bf16 operands / fp32 accumulation:
  *   x [B,3] f32, feat [B,32] f32 (hash features) -> posenc(6) ++ feat (71, zero-padded to 96) -> 256 -> 256 -> d_out.
- *   W0 [256,96] bf16 (columns >= 71 zero) PRE-MULTIPLIED by 100*log2(e), W1 [256,256] bf16 as is, W2 [32*ceil(d_out/32), 256]
+ *   W0 [256,96] bf16 (columns >= 71 zero) PRE-MULTIPLIED by 100*log2(e), W1 [256,256] bf16 as is, W2 [2][32*ceil(d_out/32), 256] (TWO planes since ABI 8: the matrix, then matrix - bf16(matrix))
  *   bf16 (rows >= d_out zero) PRE-MULTIPLIED by ln2/100 -- the kernel evaluates Softplus(beta=100) as log2(1 + 2^t) on
  *   t = 100*log2(e)*v (hs_pack_bf16's per-job `scale` does this); the biases are passed unscaled,
  *   b0,b1 [256] f32, b2 [d_out] f32; weights row-major [out][in] like nn.Linear.
@@ -420,7 +420,7 @@ int hs_sdf_mlp32_fwd(const float *x, const float *feat, const float *W0i, const 
 /* Training form of the same trunk over value+Jacobian rows (4 rows per point; replaces the three nn.Linear + Softplus
  * applications of model/network.py:203-206 AND the autograd.grad re-traversals of :213-236, see DESIGN V1).
  *   X  [M, 96] bf16: hs_trunk_input_fwd output with pitch 96 (M = 4 * points, M % 4 == 0)
- *   W0 [256, 96], W1 [256, 256], W2 [32*ceil(d_out/32), 256] bf16 (zero-padded), biases fp32
+ *   W0 [256, 96], W1 [256, 256], W2 [2][32*ceil(d_out/32), 256] bf16 (zero-padded; two planes since ABI 8: the matrix, then matrix - bf16(matrix)), biases fp32
  *   H0, H1 [M, 256] bf16: layer outputs kept for the backward pass (value rows softplus100(v), tangent rows
  *   sigmoid(100 v) * pre-activation);   Y [M, d_out] fp32 (b2 added on value rows only).
  *   X == NULL: the input rows are built inside the kernel from x [M/4,3], feat [M/4, L*C] and dydx [L, M/4, 3*C] (exactly

@@ -839,6 +839,14 @@ def main():
     if sel("stock_k21"):
         run_iteration(Net, Loss, "stock_k21", K=21, S=32, R=32, beta=0.05, eye=(0.7, 0.0, 0.1), iter_step=3, call_reg=False, seed=120,
                       shape="stock", distinct=True)
+    # K > 32 (the reference sizes d_out by the scene: holoscene_train.py:119-122; confs/custom/siebelgame ships d_out = 64): the fused path's
+    # two-output-tile kernels
+    if sel("stock_k40"):
+        run_iteration(Net, Loss, "stock_k40", K=40, S=32, R=32, beta=0.05, eye=(0.7, 0.0, 0.1), iter_step=3, call_reg=False, seed=160,
+                      shape="stock", distinct=True)
+    if sel("stock_k64_bg"):
+        run_iteration(Net, Loss, "stock_k64_bg", K=64, S=16, R=32, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=170,
+                      shape="stock", distinct=True)
     if sel("stock_steps3_k32"):
         run_three_steps(Net, Loss, "stock_steps3_k32", K=32, S=16, R=24, beta=0.05, eye=(0.0, 0.1, 0.6), seed=150, shape="stock",
                         distinct=True)
