@@ -473,7 +473,13 @@ __global__ __launch_bounds__(kDraw) void k_sampler_draw(const float *__restrict_
     if (tail.z_out == nullptr) return;
     // ---- tail: pick, merge, sort (the ray's merged depths are still in z; cdf / pdf / sdf are scratch from here on)
     __syncthreads();          // every inverse-CDF read is done; the drawn depths (global, written by this workgroup) are visible to it
-    const int n_extra = tail.n_extra, n = n_out + 2 + n_extra;      // n <= s_new <= m (launcher)
+    const int n_extra = tail.n_extra, n = n_out + 2 + n_extra;      // n <= s_new (launcher) <= m (the merged set: a device-side count)
+    if (n > m || n_extra > m) {       // a merged set smaller than the tail's n-float scratch rows (pdf, sdf: m floats each) or than the pick: the
+                                      // contract of hs_sampler_tail is broken -- write NaN depths (loud downstream), nothing out of bounds
+        for (int i = lane; i < n; i += kDraw) tail.z_out[(size_t)r * n + i] = NAN;
+        if (lane == 0 && tail.z_eik) tail.z_eik[r] = NAN;
+        return;
+    }
     int *idx = reinterpret_cast<int *>(cdf);                          // m ints
     float *v = pdf, *sorted = sdf;                                    // n floats each
     int *pk = reinterpret_cast<int *>(lds + 4 * m + 3 * 4);           // n_extra ints behind the draw's scratch (launcher sizes it)

@@ -111,8 +111,6 @@ def zero_pool_armed(device, n=1):
     return buf is not None and buf.device == _pool_device(device) and _ZERO_POOL["pos"] + n <= buf.numel()
 
 
-FLAT_CLAIMS = set()      # data pointers of the flat-gradient views a backward kernel has written since the optimiser's last zero_grad()
-                         # (model/network.py: flat_grad_target; cleared by training/flat.py: FlatAdam.zero_grad)
 
 
 def zeros_small(n, device):

@@ -1220,7 +1220,10 @@ class _composite(torch.autograd.Function):
         # inside iteration_prologue(): the per-ray partials d / d beta go to its relay (summed by hs_iter_epilogue), not through a sum launch
         # ... and the normal map's cotangent w.r.t. the normals goes to the colour branch's backward kernel, their other consumer, which adds its
         # own into the same buffer (no `grad += grad` launch): only when that Function registered exactly this tensor
-        ctx.nrelay = _NORMALS_RELAY if (_NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is g and ctx.needs_input_grad[4]) else None
+        # ... and only when the colour branch's backward is certain to run, i.e. when this Function's backward will hand its output (our `rgb`
+        # input) a cotangent: otherwise the normals' cotangent would wait in the relay for a consumer that never comes
+        ctx.nrelay = _NORMALS_RELAY if (_NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is g and ctx.needs_input_grad[4]
+                                        and ctx.needs_input_grad[3]) else None
         ctx.relay = None
         if _BETA_RELAY is not None and _BETA_RELAY["key"] is beta and _BETA_RELAY["users"] < 3 and beta.requires_grad:
             ctx.relay = _BETA_RELAY
@@ -1339,13 +1342,13 @@ def flat_grad_target(p):
     (adopted as p.grad without a copy); every later producer of the same backward pass (the background-patch iteration evaluates the trunk
     twice) ACCUMULATES into it and hands autograd nothing.  (None, False): no flat view, or p.grad already holds something else."""
     v = flat_grad_view(p)
-    if v is None:
-        return None, False
-    key = v.data_ptr()
-    if key in _be.FLAT_CLAIMS:
+    owner = getattr(p, "_hs_flat", None)          # the FlatAdam that owns the view: the claims live there, for ONE backward pass
+    if v is None or owner is None or not owner.pass_open:
+        return None, False      # (outside zero_grad() .. gather_grads(): autograd's own accumulation, no direct writes)
+    if id(p) in owner.claims:
         return v, False
     if p.grad is None:
-        _be.FLAT_CLAIMS.add(key)
+        owner.claims[id(p)] = p
         return v, True
     return None, False
 
@@ -1452,10 +1455,27 @@ def iteration_prologue(model, flat=None, rng_sizes=None):
     _SHARED_W, _BETA_RELAY, dens._shared = {id(l): W for l, W in zip(lins, Ws)}, relay, beta_eff
     _ITER_PACKS = model._pack_iteration()
     _NORMALS_RELAY = {"key": None, "cot": None}
+    global _LAST_RELAYS
+    _LAST_RELAYS = (relay, _NORMALS_RELAY)
     try:
         yield rng
     finally:
         _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY = prev_w, prev_relay, prev_beta, prev_packs, prev_nrm
+
+
+_LAST_RELAYS = None
+
+
+def assert_relays_consumed():
+    """After the backward pass of an iteration that ran inside iteration_prologue(): every cotangent a backward kernel left in a relay for
+    another kernel to take along (beta's per-ray partials -> hs_iter_epilogue, the normal map's cotangent -> the colour branch's backward) has
+    been taken.  A relay that still holds something means a gradient contribution was dropped (a consumer's backward did not run)."""
+    if _LAST_RELAYS is None:
+        return
+    beta_relay, nrm_relay = _LAST_RELAYS
+    if beta_relay["parts"] or (nrm_relay is not None and nrm_relay["cot"] is not None):
+        raise RuntimeError("a relayed cotangent was not consumed in this backward pass (beta partials: "
+                           f"{len(beta_relay['parts'])}, normals: {nrm_relay is not None and nrm_relay['cot'] is not None}): its consumer's backward did not run")
 
 
 def effective_weights(lins):

@@ -77,7 +77,11 @@ def save_checkpoints(trainer, checkpoints_path, epoch, write=True):
     opt_sd, sched_sd = optimizer_state_dicts(trainer)
     if not write:
         return
-    payloads = {MODEL_DIR: {"epoch": epoch, "model_state_dict": trainer.model.state_dict()},
+    model_payload = {"epoch": epoch, "model_state_dict": trainer.model.state_dict()}
+    rng = getattr(trainer.model, "_rng_state", None)       # the device-resident Philox stream of the iteration's draws (hs_iter_prologue): an extra
+    if rng is not None:                                     # key the reference's loader ignores; without it a resumed run restarts the draw stream
+        model_payload["hs_rng_state"] = rng.detach().cpu()
+    payloads = {MODEL_DIR: model_payload,
                 OPTIMIZER_DIR: {"epoch": epoch, "optimizer_state_dict": opt_sd},
                 SCHEDULER_DIR: {"epoch": epoch, "scheduler_state_dict": sched_sd}}
     for sub, payload in payloads.items():
@@ -91,6 +95,8 @@ def load_checkpoints(trainer, checkpoints_path, checkpoint="latest", map_locatio
     dev = map_location or trainer.device
     saved = torch.load(os.path.join(checkpoints_path, MODEL_DIR, str(checkpoint) + ".pth"), map_location=dev)
     trainer.model.load_state_dict({k.replace("module.", ""): v for k, v in saved["model_state_dict"].items()})
+    if "hs_rng_state" in saved and hasattr(trainer.model, "rng_state"):
+        trainer.model.rng_state(trainer.device).copy_(saved["hs_rng_state"].to(trainer.device))
     opt = torch.load(os.path.join(checkpoints_path, OPTIMIZER_DIR, str(checkpoint) + ".pth"), map_location=dev)
     sched = torch.load(os.path.join(checkpoints_path, SCHEDULER_DIR, str(checkpoint) + ".pth"), map_location=dev)
     trainer.iter_step = load_optimizer_state(trainer, opt["optimizer_state_dict"], sched["scheduler_state_dict"])

@@ -97,6 +97,13 @@ class FlatAdam:
                 sizes_end[1] = off + n
         self.n_tables, self.tables_end = n_tables, sizes_end[0]
         self._stepped = []              # flat ranges whose Adam step rode on their scatter in the pass that just ended (table_steps)
+        # direct gradient writes (model/network.py: flat_grad_target): which small parameters' views a backward kernel has written in the pass
+        # that is open -- between zero_grad() and gather_grads() --, by parameter identity.  Owned here, not process-wide: a second optimiser,
+        # model.zero_grad() or a backward pass that was not preceded by zero_grad() cannot meet a stale claim (the pass is then not open and
+        # every producer hands its gradient to autograd the ordinary way)
+        self.claims, self.pass_open = {}, False
+        for p, _ in self.small:
+            p._hs_flat = self
         self.betas, self.eps = betas, eps
         self.gamma = float(decay_rate) ** (1.0 / float(decay_steps))
         self.world_size, self.rank = world_size, rank
@@ -120,7 +127,8 @@ class FlatAdam:
         else:
             self._g_alloc[self.tables_end:].zero_()
         _be.set_zero_pool(self._g_alloc[self.padded:])
-        _be.FLAT_CLAIMS.clear()          # no view has been written yet: the first producer of each writes, later ones accumulate
+        self.claims.clear()              # no view has been written yet: the first producer of each writes, later ones accumulate
+        self.pass_open = True
         for p, _ in self.small:
             p.grad = None
 
@@ -130,6 +138,12 @@ class FlatAdam:
         `zero_grad(set_to_none=True)` -- the reference's loop -- skips it.  Stage 1 uses every parameter in every iteration, so the
         two agree there; a model with conditionally used parameters is told once."""
         _be.set_zero_pool(None)         # the backward pass this pool served is over
+        self.pass_open = False
+        for p in self.claims.values():  # a view a kernel wrote directly was handed to autograd as that parameter's gradient: it ends the pass as
+            if p.grad is None:          # .grad, or inside a sum autograd formed with another producer's tensor (copied back below) -- never as nothing
+                raise RuntimeError("FlatAdam: a backward kernel wrote a parameter's gradient straight into the flat buffer, but autograd did not adopt "
+                                   "it: the parameter ends the backward pass without a .grad (a gradient was dropped)")
+        self.claims.clear()
         have = [(p.grad, v) for p, v in self.small if p.grad is not None]
         if len(have) != len(self.small) and not getattr(self, "_warned_missing_grad", False):
             import warnings
@@ -284,11 +298,31 @@ class FlatAdam:
         other passes rely on `zero_grad(tables=False)`)."""
         self.flat_g[:self.tables_end].zero_()
 
+    LAYOUT_VERSION = 2      # 2: every table (and what follows the last one) starts a 16-byte quad (round 4); 1: plain concatenation
+
+    def layout(self):
+        return {"version": self.LAYOUT_VERSION, "offsets": list(self.offsets), "numel": int(self.numel), "padded": int(self.padded),
+                "segments": [list(s) for s in self.segments], "shards": [list(s) for s in self.shards], "shard_moments": bool(self.shard_moments)}
+
     def state_dict(self):
-        """This rank's optimiser state (with sharded moments: its slice)."""
-        return {"flat_m": self.flat_m, "flat_v": self.flat_v, "state": self.state}
+        """This rank's optimiser state (with sharded moments: its slice) and the layout it is laid out in: the raw buffers mean nothing
+        without the offsets (for an exchange format use training/checkpoint.py, which goes through per-parameter tensors)."""
+        return {"flat_m": self.flat_m, "flat_v": self.flat_v, "state": self.state, "layout": self.layout()}
 
     def load_state_dict(self, sd):
+        lay = sd.get("layout")
+        if lay is None:
+            if tuple(sd["flat_m"].shape) != tuple(self.flat_m.shape):
+                raise ValueError("FlatAdam.load_state_dict: the state carries no layout record and its length differs from this optimiser's; "
+                                 "it was written by another layout version -- reload through training/checkpoint.py (per-parameter format)")
+            import warnings
+            warnings.warn("FlatAdam.load_state_dict: state without a layout record (written before layout version 2): lengths match, offsets unchecked")
+        else:
+            mine = self.layout()
+            for k in ("version", "offsets", "padded", "shards", "shard_moments"):
+                if lay.get(k) != mine[k]:
+                    raise ValueError(f"FlatAdam.load_state_dict: layout mismatch in {k!r} (saved {lay.get(k)!r}, this optimiser {mine[k]!r}); the flat "
+                                     "buffers cannot be copied element for element -- reload through training/checkpoint.py")
         self.flat_m.copy_(sd["flat_m"])
         self.flat_v.copy_(sd["flat_v"])
         self.state.copy_(sd["state"])

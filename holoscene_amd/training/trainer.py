@@ -344,6 +344,8 @@ class Stage1Trainer:
         with steps:
             loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
         self.flat.gather_grads()
+        if not torch.cuda.is_current_stream_capturing():
+            _net.assert_relays_consumed()       # (warm-up passes: a host-side look at two Python containers)
         if counting:
             seen, _net._be.SCATTER_COUNTS = _net._be.SCATTER_COUNTS, None
             views = [self.flat.flat_g[self.flat.offsets[i]:].data_ptr() for i in range(self.flat.n_tables)]

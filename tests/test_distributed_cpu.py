@@ -290,3 +290,36 @@ def test_flat_layout_quad_aligned_tables_and_the_step_around_stepped_tables(monk
     assert bool(fb.flat_g[:fb.tables_end].any()) and not bool(fb.flat_g[fb.tables_end:].any())     # only the small tensors' storage is cleared
     fb.clear_table_grads()
     assert not bool(fb.flat_g.any())
+
+
+def test_flat_state_carries_its_layout_and_direct_gradient_claims_live_in_one_pass():
+    """(1) FlatAdam.state_dict records offsets / padding / sharding and load_state_dict refuses another layout instead of copying
+    misaligned moments; (2) the "first producer writes, later ones accumulate" claims on the flat gradient views belong to the optimiser and to
+    ONE backward pass (zero_grad .. gather_grads): outside it flat_grad_target hands nothing out, and a claimed view that autograd did not adopt
+    as .grad makes gather_grads raise."""
+    from holoscene_amd.model.network import flat_grad_target
+    from holoscene_amd.training.flat import FlatAdam
+    torch.manual_seed(0)
+    a = _TinyModel()
+    fa = FlatAdam(a, 5e-4, 20.0, 0.1, 1000)
+    sd = fa.state_dict()
+    assert sd["layout"]["version"] == FlatAdam.LAYOUT_VERSION and sd["layout"]["offsets"] == fa.offsets
+    fa.load_state_dict(sd)                                            # same layout: fine
+    fb = FlatAdam(_TinyModel(), 5e-4, 20.0, 0.1, 1000, world_size=2, rank=0, shard_moments=False)     # pads to multiples of 8: other offsets
+    if fb.layout()["offsets"] != sd["layout"]["offsets"] or fb.padded != fa.padded:
+        with pytest.raises(ValueError, match="layout mismatch"):
+            fb.load_state_dict(sd)
+    old = {k: v for k, v in sd.items() if k != "layout"}
+    old["flat_m"] = torch.zeros(fa.padded + 4)
+    with pytest.raises(ValueError, match="no layout record"):
+        fa.load_state_dict(old)
+    # claims: CPU views are never handed out (the kernels that write them are GPU kernels) -- exercise the bookkeeping on the instance
+    p = a.net.weight
+    assert flat_grad_target(p) == (None, False)
+    assert fa.pass_open is False and fa.claims == {}
+    fa.zero_grad()
+    assert fa.pass_open is True
+    fa.claims[id(p)] = p                                              # "a kernel wrote p's view" ...
+    p.grad = None                                                     # ... but autograd never adopted it
+    with pytest.raises(RuntimeError, match="did not adopt"):
+        fa.gather_grads()
