@@ -621,7 +621,7 @@ __global__ __launch_bounds__(512) void k_hash_bin_step(float *__restrict__ gemb,
     const uint32_t per_bin = bin_width<C>(li), first = bin * per_bin;
     const uint32_t total = binned ? counts[level * kBins + bin] : 0u;
     const uint32_t n = binned ? min(total, lay.scatter_cap) : 0u;
-    const bool spilled = !binned || total > lay.scatter_cap;      // `gemb` may hold contributions to this bin's cells
+    const bool spilled = !binned || total > lay.scatter_cap || ts.prior != 0;      // `gemb` may hold contributions to this bin's cells
     if (first >= li.table) {                                     // (dense levels: bins past the end of the table hold nothing)
         __syncthreads();
         if (binned && threadIdx.x == 0) counts[level * kBins + bin] = 0u;

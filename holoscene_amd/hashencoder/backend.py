@@ -35,7 +35,7 @@ class hsHashLayout(ctypes.Structure):
 
 class hsTableStep(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("state", ctypes.c_void_p), ("beta1", ctypes.c_float),
-                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("grad_scale", ctypes.c_float), ("group", ctypes.c_int32)]
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("grad_scale", ctypes.c_float), ("group", ctypes.c_int32), ("prior", ctypes.c_int32)]
 
 
 class hsPackJob(ctypes.Structure):
@@ -233,10 +233,12 @@ def scatter_done(table):
             cb()
 
 
-# Reduce-and-step (hsTableStep, include/holoscene_hip.h): data_ptr of a flat-owned table's gradient view -> [hsTableStep, scatters served].
-# training/flat.py registers the tables for the span of ONE backward pass in which each has a single gradient producer; the scatter
-# wrappers below attach the step to that producer's launch.  A second scatter into a registered table would step it twice, and a
-# producer that cannot carry the step (double backward, the reference-compatible trio) would leave its contribution behind: both raise.
+# Reduce-and-step (hsTableStep, include/holoscene_hip.h): data_ptr of a flat-owned table's gradient view -> [hsTableStep, scatters served,
+# scatters expected].  training/flat.py registers the tables for the span of ONE backward pass (FlatAdam.table_steps: the entries exist inside
+# that context only) with the number of gradient producers the trainer counted for the variant; the scatter wrappers below let the earlier
+# producers accumulate into the gradient table the plain way and attach the step (hsTableStep.prior = "add what is there") to the LAST one.
+# One more scatter than expected would miss the step, and a last producer that cannot carry it (double backward, the reference-compatible
+# trio) would leave the table unstepped: both raise.
 TABLE_STEPS = {}
 SCATTER_COUNTS = None       # a dict while a trainer counts the gradient producers per table (training/trainer.py)
 
@@ -250,10 +252,14 @@ def _table_step(grad_embeddings, can_step=True):
     ent = TABLE_STEPS.get(ptr)
     if ent is None:
         return None
-    if not can_step or ent[1]:
-        raise RuntimeError("a hash table registered for reduce-and-step received a second gradient producer in the same backward pass "
-                           "(or one that cannot carry the step): its optimiser step must go through FlatAdam.step instead")
-    ent[1] += 1
+    n = ent[1] + 1
+    if n < ent[2]:
+        ent[1] = n
+        return None             # an earlier producer: plain accumulation into the (all-zero on entry) gradient table
+    if n > ent[2] or not can_step:
+        raise RuntimeError("a hash table registered for reduce-and-step received more gradient producers in this backward pass than were counted "
+                           "for it, or its last producer cannot carry the step: its optimiser step must go through FlatAdam.step instead")
+    ent[1] = n
     return ent[0]
 
 

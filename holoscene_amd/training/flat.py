@@ -273,25 +273,32 @@ class FlatAdam:
         return self.world_size == 1 and not self.shard_moments and self.flat_p.is_cuda and self.n_tables > 0
 
     @contextlib.contextmanager
-    def table_steps(self, grad_scale=1.0):
+    def table_steps(self, grad_scale=1.0, producers=None):
         """For the backward pass inside the block, every hash table whose gradient has exactly ONE producer (a scatter through
         backend.bwd / bwd_jac into its flat gradient view) takes its Adam step in that producer's reduction kernel.  Needs: `tick()`
         done for this update (the iteration prologue), the tables' gradient storage all zero on entry (it is again on exit).  A table
-        that received no scatter keeps its turn in `step()`; the following `step()` covers exactly what is left."""
+        that received no scatter keeps its turn in `step()`; the following `step()` covers exactly what is left.
+        producers: per table (optimiser order) the number of scatters this pass will send it (default 1 each); with n > 1 the first n - 1
+        accumulate into the gradient table the plain way and the last one steps, adding what it finds there (hsTableStep.prior)."""
         if not self._ticked:
             raise RuntimeError("table_steps before tick(): the reduction kernels read the advanced optimiser state")
         mine = {}
         for i in range(self.n_tables):
             p, off = self.params[i], self.offsets[i]
+            n_prod = 1 if producers is None else int(producers[i])
             ts = _be.hsTableStep(p.data.data_ptr(), self.flat_m[off:].data_ptr(), self.flat_v[off:].data_ptr(), self.state.data_ptr(),
-                                 self.betas[0], self.betas[1], self.eps, grad_scale, 0)
+                                 self.betas[0], self.betas[1], self.eps, grad_scale, 0, 1 if n_prod > 1 else 0)
             key = self.flat_g[off:].data_ptr()
             mine[key] = (off, (off + p.numel() + 3) // 4 * 4)       # (the pad behind a table: zero parameters with zero gradients)
-            _be.TABLE_STEPS[key] = [ts, 0]
+            _be.TABLE_STEPS[key] = [ts, 0, n_prod]
         try:
             yield
         finally:
-            self._stepped = [mine[k] for k in mine if _be.TABLE_STEPS.pop(k)[1]]
+            done = {k: _be.TABLE_STEPS.pop(k) for k in mine}
+            short = [k for k, e in done.items() if 0 < e[1] < e[2]]
+            self._stepped = [mine[k] for k, e in done.items() if e[1] >= e[2]]
+            if short:       # fewer producers than counted: their contributions sit in the gradient table and no one has stepped the table
+                raise RuntimeError("reduce-and-step: a hash table received fewer gradient producers than were counted for this variant")
 
     def clear_table_grads(self):
         """Leave the tables' gradient storage all zero (the end of a pass that accumulated into it the plain way, in a trainer whose

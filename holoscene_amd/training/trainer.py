@@ -123,6 +123,7 @@ class Stage1Trainer:
                             and self.flat.table_steps_supported()
                             and self._full_graph_ok())       # (only the whole-iteration graph ticks the optimiser before the backward pass)
         self._table_step_ok = {}
+        self._table_producers = {}      # variant -> producers per table, counted in the variant's first (plain) pass
         self._pass_fused = False
         # same seed on every rank -> identical initial parameters; from here on every rank draws from its own stream (frames, ray
         # jitter, inverse-CDF draws, Eikonal points): identical draws across data-parallel ranks would correlate the sampling noise
@@ -314,7 +315,7 @@ class Stage1Trainer:
         self._pass_fused = fused
         self.flat.zero_grad(tables=not fused)
         self._arm_early_exchange()
-        steps = self.flat.table_steps() if fused else contextlib.nullcontext()
+        steps = self.flat.table_steps(producers=self._table_producers.get(variant)) if fused else contextlib.nullcontext()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
@@ -349,7 +350,10 @@ class Stage1Trainer:
         if counting:
             seen, _net._be.SCATTER_COUNTS = _net._be.SCATTER_COUNTS, None
             views = [self.flat.flat_g[self.flat.offsets[i]:].data_ptr() for i in range(self.flat.n_tables)]
-            self._table_step_ok[variant] = all(seen.get(v, 0) == 1 for v in views) and set(seen) <= set(views)
+            # every table with at least one in-place producer (with two -- the background-patch iteration's geometry table -- the first
+            # accumulates, the last steps: hsTableStep.prior) and no scatter into anything else
+            self._table_step_ok[variant] = all(seen.get(v, 0) >= 1 for v in views) and set(seen) <= set(views)
+            self._table_producers[variant] = [seen.get(v, 0) for v in views]
         self._update_in_body()
         if fused and not torch.cuda.is_current_stream_capturing():
             # (warm-up passes only: a host read) a gradient that reached a table past its scatter -- through autograd's accumulation --

@@ -113,6 +113,9 @@ typedef struct hsTableStep {
     const struct hsAdamState *state;
     float beta1, beta2, eps, grad_scale;
     int32_t group;
+    int32_t prior;             /* != 0: an EARLIER producer of this iteration has already added its gradient to `grad_embeddings` the plain way (the
+                                * background-patch iteration evaluates the trunk twice): the owner of every cell adds what it finds there and returns
+                                * it to zero, as it does for spilled contributions -- the LAST producer steps */
 } hsTableStep;
 
 typedef struct hsHashLayout {

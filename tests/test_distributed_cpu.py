@@ -268,12 +268,13 @@ def test_flat_layout_quad_aligned_tables_and_the_step_around_stepped_tables(monk
     with fb.table_steps():
         assert len(backend.TABLE_STEPS) == 2
         key = fb.flat_g[fb.offsets[1]:].data_ptr()
-        ts, served = backend.TABLE_STEPS[key]
+        ts, served, expected = backend.TABLE_STEPS[key]
+        assert expected == 1 and ts.prior == 0
         assert ts.p == fb.params[1].data.data_ptr() and ts.m == fb.flat_m[fb.offsets[1]:].data_ptr() and ts.group == 0 and served == 0
         with pytest.raises(RuntimeError, match="cannot carry the step"):
             backend._table_step(fb.flat_g[fb.offsets[1]:], can_step=False)
         assert backend._table_step(fb.flat_g[fb.offsets[1]:]) is ts          # what bwd / bwd_jac do: take the step along
-        with pytest.raises(RuntimeError, match="second gradient producer"):
+        with pytest.raises(RuntimeError, match="more gradient producers"):
             backend._table_step(fb.flat_g[fb.offsets[1]:])
         lo, hi = fb.offsets[1], fb.offsets[1] + 2008                          # (the table and the pad behind it)
         _TorchAdamKernels.adam_flat(fb.flat_p, fb.flat_g, fb.flat_m, fb.flat_v, lo, hi, fb.state, 0.9, 0.99, 1e-15, 1.0)

@@ -272,16 +272,41 @@ def test_reduce_and_step_equals_scatter_then_adam(case):
     g2 = torch.zeros(n, device="cuda")
     p2, m2, v2 = p0.clone(), m0.clone(), v0.clone()
     ts = B_.hsTableStep(p2.data_ptr(), m2.data_ptr(), v2.data_ptr(), state.data_ptr(), 0.9, 0.99, 1e-15, 1.0, 0)
-    B_.TABLE_STEPS[g2.data_ptr()] = [ts, 0]
+    B_.TABLE_STEPS[g2.data_ptr()] = [ts, 0, 1]
     try:
         ws = scatter(g2[:enc.embeddings.numel()].view(-1, C))
         assert B_.TABLE_STEPS[g2.data_ptr()][1] == 1
-        with pytest.raises(RuntimeError, match="second gradient producer"):
+        with pytest.raises(RuntimeError, match="more gradient producers"):
             scatter(g2[:enc.embeddings.numel()].view(-1, C))
     finally:
         B_.TABLE_STEPS.pop(g2.data_ptr())
     torch.cuda.synchronize()
     assert not bool(g2.any()), "the gradient table is all zero again"
+    # two producers of one iteration (the background-patch iteration's geometry table): the first accumulates into the gradient table the plain
+    # way, the LAST steps and adds what it finds there (hsTableStep.prior) = scatter twice, then Adam on the sum
+    ge2 = torch.zeros(n, device="cuda")
+    scatter(ge2[:enc.embeddings.numel()].view(-1, C))
+    scatter(ge2[:enc.embeddings.numel()].view(-1, C))
+    p3, m3, v3 = p0.clone(), m0.clone(), v0.clone()
+    be.adam_flat(p3, ge2, m3, v3, 0, n, state, 0.9, 0.99, 1e-15, 1.0)
+    g4 = torch.zeros(n, device="cuda")
+    p4, m4, v4 = p0.clone(), m0.clone(), v0.clone()
+    ts2 = B_.hsTableStep(p4.data_ptr(), m4.data_ptr(), v4.data_ptr(), state.data_ptr(), 0.9, 0.99, 1e-15, 1.0, 0, 1)
+    B_.TABLE_STEPS[g4.data_ptr()] = [ts2, 0, 2]
+    try:
+        scatter(g4[:enc.embeddings.numel()].view(-1, C))
+        assert B_.TABLE_STEPS[g4.data_ptr()][1] == 1 and (B == 0 or bool(g4.any())), "the first producer accumulated the plain way"
+        scatter(g4[:enc.embeddings.numel()].view(-1, C))
+        assert B_.TABLE_STEPS[g4.data_ptr()][1] == 2
+    finally:
+        B_.TABLE_STEPS.pop(g4.data_ptr())
+    torch.cuda.synchronize()
+    assert not bool(g4.any()), "two producers: the gradient table is all zero again"
+    kk = enc.embeddings.numel()
+    bigg = 1 + float(ge2[:kk].abs().max())
+    for name, a, b, tol in (("m", m4[:kk], m3[:kk], 1e-6 * m3[:kk].abs() + 2e-6 * bigg), ("p", p4[:kk], p3[:kk], 4e-5 * bigg)):
+        err = (a - b).abs()
+        assert bool((err <= tol).all()), (case, "two producers", name, float(err.max()), float((err / tol).max()))
     if ws is not None:
         assert int(ws[0][:32 * 128 * 4].view(torch.int32).abs().sum()) == 0
     if case == "slab":      # the case is only worth its name if bins did overflow

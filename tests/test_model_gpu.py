@@ -788,7 +788,7 @@ def _full_graph_trainer(beta, freeze, rays=256):
 def test_table_steps_inside_the_scatters_train_like_the_separate_adam_kernel(monkeypatch):
     """Reduce-and-step (hsTableStep: the hash tables' Adam update inside their scatter's reduction, FlatAdam.table_steps) against the plain
     whole-iteration graph (HOLOSCENE_TABLE_STEP=0): same batches, same draws.  Iteration 0 renders the background patch -- two producers
-    for the geometry table, so that variant stays plain in both trainers -- iterations 1.. are single-producer and take the new path.
+    for the geometry table: the first accumulates the plain way, the last one steps (hsTableStep.prior) --, iterations 1.. are single-producer.
     After two iterations the moments (linear in the gradients) and the parameter updates agree to what float-atomic ordering does to
     two runs of ONE path; the gradient tables are all zero after every iteration; the optimiser state advances once per iteration."""
     res = {}
@@ -818,7 +818,10 @@ def test_table_steps_inside_the_scatters_train_like_the_separate_adam_kernel(mon
         med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
         assert all(l == l and abs(l) < 1e6 for l in losses) and med(losses[-10:]) < med(losses[:5]), losses
         if mode == "1":
-            assert tr._table_step_ok == {(True, False): False, (False, False): True}
+            # both variants step inside their scatters: the background-patch one sends the geometry table two scatters (the patch's trunk, then
+            # the main pass's): the first accumulates, the last steps and adds what it finds (hsTableStep.prior)
+            assert tr._table_step_ok == {(True, False): True, (False, False): True}
+            assert sorted(tr._table_producers[(True, False)]) == [1, 2] and tr._table_producers[(False, False)] == [1, 1]
             assert not bool(tr.flat.flat_g[:tr.flat.tables_end].any())
         res[mode] = (snap, tr.flat.tables_end)
     (du0, m0, v0, l0), te = res["0"]
