@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
                                                               const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f,
                                                               const uint16_t *__restrict__ W2f, const float *__restrict__ biasg, int d_out,
                                                               uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y,
-                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp, int64_t ld) {
+                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp, int64_t ld, int lo_plane) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (kW2LowPlane) {      // + W2lo h1 (wave_tile.h): value and tangent rows alike; fragments from memory (16 KB, cache-resident; LDS is full)
+            if (kW2LowPlane && lo_plane) {    // + W2lo h1 (wave_tile.h): value and tangent rows alike; fragments from memory (16 KB, cache-resident; LDS is full)
                 uint32_t zlo = 0;
                 asm volatile("" : "+v"(zlo));
                 const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f + kW2F) + lane + zlo;
@@ -475,12 +475,17 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     const int64_t ntiles = (M + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
+    // W2's low plane (wave_tile.h) for every call whose VALUES feed the renderer or a caller -- i.e. all but the one that evaluates nothing but the
+    // Eikonal regulariser's points (split outputs, no rendered sample among the rows): there only the gradients are used, a training
+    // with those points in fp32 ends where one with single-plane bf16 does (profiles/r05/bf16_stage_hunt.txt, stage "eikonal"), and the
+    // plane's fragments -- from memory, one tile per wave, nothing to hide them under -- cost that 4 096-point launch 6 of its 30 us
+    const int lo_plane = !(split && sp.n_main == 0);
     if (split)
         k_trunk_fwd2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane);
     else
         k_trunk_fwd2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane);
     return wt_check_launch();
 }
 
