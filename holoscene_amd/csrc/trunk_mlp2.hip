@@ -454,8 +454,9 @@ int32_t hs_trunk_mlp2_input_column(int32_t c) {
 }
 
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, void *stream) {
-    if (d_out < 1 || d_out > 32 || (M & 3) || (ld != 0 && ld < (M >> 2))) return HS_ERR_ARG;
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, int32_t w2_planes,
+                      void *stream) {
+    if (d_out < 1 || d_out > 32 || (M & 3) || (ld != 0 && ld < (M >> 2)) || w2_planes < 1 || w2_planes > 2) return HS_ERR_ARG;
     if (ld == 0) ld = M >> 2;
     if (M == 0) return HS_OK;
     if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !H0 || !H1 || (!Y && !split) || !Xp) return HS_ERR_NULL;
@@ -475,11 +476,10 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     const int64_t ntiles = (M + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
-    // W2's low plane (wave_tile.h) for every call whose VALUES feed the renderer or a caller -- i.e. all but the one that evaluates nothing but the
-    // Eikonal regulariser's points (split outputs, no rendered sample among the rows): there only the gradients are used, a training
-    // with those points in fp32 ends where one with single-plane bf16 does (profiles/r05/bf16_stage_hunt.txt, stage "eikonal"), and the
-    // plane's fragments -- from memory, one tile per wave, nothing to hide them under -- cost that 4 096-point launch 6 of its 30 us
-    const int lo_plane = !(split && sp.n_main == 0);
+    // w2_planes = 1: the caller evaluates nothing but the Eikonal regulariser's points -- only their gradients are used, a training with those
+    // points in fp32 ends where one with single-plane bf16 does (profiles/r05/bf16_stage_hunt.txt, stage "eikonal"), and the low plane's
+    // fragments (from memory, one tile per wave, nothing to hide them under) cost that 4 096-point launch 6 of its 30 us
+    const int lo_plane = w2_planes == 2;
     if (split)
         k_trunk_fwd2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                  (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane);

@@ -647,7 +647,7 @@ class _HipBackend:
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
 
     @staticmethod
-    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None, ld=0, off=0):
+    def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None, ld=0, off=0, w2_planes=2):
         """split = (n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, grad_theta): the kernel writes hs_trunk_split_fwd's outputs itself and
         Y (then None) is never stored.  ld / off: dydx is a [L, ld, 6] buffer whose points [off, off + M / 4) are this call's."""
         lib = load_library()
@@ -662,7 +662,7 @@ class _HipBackend:
         _check(lib.hs_trunk_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat"), _dev_at(dydx, "dydx", off * 6), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
                                      _dev(bias, "bias"), d_out, _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Y, "Y") if Y is not None else None,
                                      _dev(Xp, "Xp", bf), ctypes.c_int64(H0.shape[0]), ctypes.c_float(jac_scale),
-                                     ctypes.byref(sp) if sp is not None else None, ctypes.c_int64(ld), _stream()), "hs_trunk_mlp2_fwd")
+                                     ctypes.byref(sp) if sp is not None else None, ctypes.c_int64(ld), int(w2_planes), _stream()), "hs_trunk_mlp2_fwd")
 
     @staticmethod
     def trunk_mlp2_columns():

@@ -566,7 +566,7 @@ class _trunk_render_rr(torch.autograd.Function):
             H0e, H1e, Xpe = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 80, device=dev, dtype=bf)
             w1t, w2t, w0t = trans
             be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
-                              split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n)
+                              split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
             eik = (H0e, H1e, Xpe, w0t, w1t, w2t)
         if ctx.needs_input_grad[2]:
             _be.expect_scatter(ctx.table)

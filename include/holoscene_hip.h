@@ -400,9 +400,11 @@ typedef struct hsTrunkSplit {
     float *grad_theta;     /* [(K+1) Be, 3] */
 } hsTrunkSplit;
 int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
-/* (hs_trunk_mlp2_fwd: ld = points per level of dydx; 0 = M / 4) */
+/* (hs_trunk_mlp2_fwd: ld = points per level of dydx; 0 = M / 4.  w2_planes: 2 = y = (W2hi + W2lo) h1, the default of every caller whose values
+ * are used; 1 = the high plane only -- for a call that evaluates nothing but the Eikonal regulariser's points (ABI 8)) */
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
-                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld, void *stream);
+                      int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld,
+                      int32_t w2_planes, void *stream);
 /* (hs_sdf_mlp2_fwd: feat_level_major 0 = fp32 [B, 32]; 1 = fp32 [16, B, 2]; 2 = `feat` points at uint32 [16, B], each word a level's two
  * channels as bf16 -- what hs_hash_fwd writes with hsHashLayout::out_bf16; results identical to the fp32 forms, which round the same way) */
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,

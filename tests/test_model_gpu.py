@@ -1135,13 +1135,16 @@ def test_whole_iteration_graph_matches_eager_execution(beta):
 def test_whole_iteration_graph_training_reduces_loss():
     tr, scene = _full_graph_trainer(0.05, False)
     losses = []
-    for _ in range(40):
+    for _ in range(60):
         idx, mi, gt = scene.next_batch()
         _, lo = tr.train_step(idx, mi, gt)
         losses.append(float(lo["loss"]))
     assert all(l == l and abs(l) < 1e6 for l in losses)
-    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5
-    assert tr.flat.read_state().step >= 40
+    # (random images at the stock learning rates: every precision, fp32 included, spikes to 12-16 between iterations 10 and 40 and settles near
+    #  3.4 by iteration 50 -- tools/exp/loss_seq.py --, so medians over the settled tail, not means of five)
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    assert med(losses[-10:]) < med(losses[:5]), losses
+    assert tr.flat.read_state().step >= 60
 
 
 @pytest.mark.parametrize("d_out,B,n_main", [(32, 4096, 3072), (5, 1000, 1000), (21, 130, 0)])
