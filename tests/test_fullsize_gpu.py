@@ -174,7 +174,11 @@ def test_full_size_bf16_whole_iteration_graph_vs_reference(rec_c1, depths):
             chk(f"out.{k} relL2", rel_l2(out[k], ref[k]), 5 * BF16_ITER_TOL[k])
         for k, v in section(rec, "loss.").items():
             chk(f"loss.{k} rel", abs(float(lo[k]) - float(v)) / max(abs(float(v)), 1e-12), 10 * BF16_LOSS_RTOL[k])
-        # the graph's Adam node: direction of the first update (eps = 1e-15 makes it ~lr sign(g) element by element)
+        # the graph's Adam node: direction of the first update (eps = 1e-15 makes it ~lr sign(g) element by element).  These cosines are a SMOKE
+        # bound, not a precision statement: the first Adam step is the sign of every gradient element, so the many near-zero elements of a
+        # table flip with any perturbation (fp32 on another summation order already gives 0.98 after three steps) and 0.47-0.50 is what a
+        # correct bf16 gradient on its OWN depths produces; a dropped term or a wrong sign convention shows as <= 0.2.  The precision
+        # statement is test_full_size_bf16_gradients_with_aligned_discontinuities below (<= 1 % per tensor on aligned inputs).
         worst, worst_k = 1.0, None
         for k, v in plain(section(rec, "adam1.")).items():
             du, dr = (params[k].detach().cpu() - start[k]).double().flatten(), (v - start[k]).double().flatten()
