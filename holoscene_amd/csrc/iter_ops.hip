@@ -73,9 +73,12 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.96
 
 constexpr int kRngPerThread = 16, kRngPerBlock = 256 * kRngPerThread;
 
+constexpr int kZeroPerBlock = 256 * 16;      // floats a zeroing workgroup clears (four 16-byte stores per thread)
 struct PrologueArgs {
     WnJobsI wn;
-    int32_t wn_blocks, rng_blocks;
+    int32_t wn_blocks, rng_blocks, zero_blocks;
+    float *zero;                                // [n_zero] floats to clear (the small parameters' gradient storage + the accumulator pool), 16-byte aligned
+    int64_t n_zero;
     float *pool;              // rng
     int64_t n_pool;
     uint64_t *rng_state;      // [0] seed, [1] counter, [2] workgroups done (0 between launches)
@@ -130,6 +133,17 @@ __global__ __launch_bounds__(256) void k_iter_prologue(PrologueArgs a) {
                 a.rng_state[1] = ctr + 1;
                 a.rng_state[2] = 0;
             }
+        }
+        return;
+    }
+    if (b < a.wn_blocks + a.rng_blocks + a.zero_blocks) {      // the iteration's memset rides along (it was a launch of its own: 5 us + a launch gap)
+        const int64_t base = (int64_t)(b - a.wn_blocks - a.rng_blocks) * kZeroPerBlock;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t i = base + (int64_t)q * 1024 + threadIdx.x * 4;
+            if (i + 3 < a.n_zero) *reinterpret_cast<float4 *>(a.zero + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else
+                for (int e = 0; e < 4 && i + e < a.n_zero; e++) a.zero[i + e] = 0.f;
         }
         return;
     }
@@ -195,12 +209,16 @@ int fill_wn(WnJobsI &wj, const hsWnJob *jobs, int32_t n_jobs, bool backward, int
 extern "C" {
 
 int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
-                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, void *stream) {
+                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
+                     int64_t n_zero, void *stream) {
     PrologueArgs a;
     int rows = 0;
     const int rc = fill_wn(a.wn, jobs, n_jobs, false, rows);
     if (rc != HS_OK) return rc;
-    if (n_rng < 0 || n_beta < 0) return HS_ERR_ARG;
+    if (n_rng < 0 || n_beta < 0 || n_zero < 0 || (n_zero > 0 && ((uintptr_t)zero & 15))) return HS_ERR_ARG;
+    if (n_zero > 0 && !zero) return HS_ERR_NULL;
+    a.zero = zero; a.n_zero = n_zero;
+    a.zero_blocks = (int32_t)((n_zero + kZeroPerBlock - 1) / kZeroPerBlock);
     if ((n_rng > 0 && (!rng_pool || !rng_state)) || (n_beta > 0 && (!beta || !beta_min || !beta_out))) return HS_ERR_NULL;
     a.wn_blocks = (rows + 3) / 4;
     a.rng_blocks = (int32_t)((n_rng + kRngPerBlock - 1) / kRngPerBlock);
@@ -208,7 +226,7 @@ int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64
     a.beta = beta; a.beta_min = beta_min; a.beta_out = beta_out; a.n_beta = n_beta;
     a.adam = adam; a.beta1 = beta1; a.beta2 = beta2; a.gamma = gamma;
     const bool tail = n_beta > 0 || adam != nullptr;
-    const int grid = a.wn_blocks + a.rng_blocks + (tail ? 1 : 0);
+    const int grid = a.wn_blocks + a.rng_blocks + a.zero_blocks + (tail ? 1 : 0);
     if (grid == 0) return HS_OK;
     k_iter_prologue<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;

@@ -711,7 +711,7 @@ class _HipBackend:
         return outs
 
     @staticmethod
-    def iter_prologue(vs, gs, rng_pool=None, rng_state=None, beta=None, beta_min=None, adam=None):
+    def iter_prologue(vs, gs, rng_pool=None, rng_state=None, beta=None, beta_min=None, adam=None, zero=None):
         """hs_iter_prologue: the weight-normalised matrices of (vs, gs), the pool of U[0, 1) draws, |beta| + beta_min and the optimiser tick in
         one launch.  adam: None or (state uint8 tensor, beta1, beta2, gamma).  -> (Ws, beta_eff or None)"""
         lib = load_library()
@@ -726,7 +726,8 @@ class _HipBackend:
         _check(lib.hs_iter_prologue(arr, len(vs), _dev(rng_pool, "rng_pool"), ctypes.c_int64(0 if rng_pool is None else rng_pool.numel()),
                                     _dev(rng_state, "rng_state", torch.int64), _dev(beta, "beta"), _dev(beta_min, "beta_min"), _dev(beta_out, "beta_out"),
                                     0 if beta is None else beta.numel(), _dev(st, "adam state", torch.uint8), ctypes.c_float(b1), ctypes.c_float(b2),
-                                    ctypes.c_double(gamma), _stream()), "hs_iter_prologue")
+                                    ctypes.c_double(gamma), _dev(zero, "zero"), ctypes.c_int64(0 if zero is None else zero.numel()), _stream()),
+               "hs_iter_prologue")
         return outs, beta_out
 
     @staticmethod

@@ -1381,12 +1381,12 @@ class _iter_prologue(torch.autograd.Function):
     have them (flat_grad_view): no multi-tensor copy afterwards."""
 
     @staticmethod
-    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, *vg):
+    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, zero, *vg):
         ctx.set_materialize_grads(False)
         vs = [t.detach().float().contiguous() for t in vg[0::2]]
         gs = [t.detach().float().contiguous() for t in vg[1::2]]
         b = beta.detach().float().reshape(-1).contiguous()
-        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam)
+        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam, zero)
         ctx.save_for_backward(b, *vs, *gs)
         ctx.n, ctx.relay, ctx.beta_shape = len(vs), relay, beta.shape
         ctx.params = (beta,) + tuple(vg)
@@ -1413,11 +1413,11 @@ class _iter_prologue(torch.autograd.Function):
             gb = gb.view(ctx.beta_shape)
         else:
             _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs)
-        return (gb, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
+        return (gb, None, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
 
 
 @contextlib.contextmanager
-def iteration_prologue(model, flat=None, rng_sizes=None):
+def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
     """One launch for everything a Stage-1 iteration needs before its first ray: within the block model.density.get_beta() and
     effective_weights() return the tensors evaluated here (as under density.shared_beta() + shared_effective_weights()), `flat`'s Adam
     state is ticked (training/flat.py: FlatAdam -- its step() then skips the tick launch), and the block yields the `rng` dictionary of
@@ -1438,7 +1438,7 @@ def iteration_prologue(model, flat=None, rng_sizes=None):
     if flat is not None and not flat._ticked:
         adam = (flat.state, flat.betas[0], flat.betas[1], flat.gamma)
     relay = {"key": None, "parts": [], "users": 0}
-    outs = _iter_prologue.apply(dens.beta, dens.beta_min, pool, model.rng_state(dev) if pool is not None else None, adam, relay,
+    outs = _iter_prologue.apply(dens.beta, dens.beta_min, pool, model.rng_state(dev) if pool is not None else None, adam, relay, zero,
                                 *[t for l in lins for t in (l.weight_v, l.weight_g)])
     if adam is not None:
         flat._ticked = True

@@ -116,14 +116,18 @@ class FlatAdam:
         self.state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(dev)
 
     # ---- gradients
-    def zero_grad(self, tables=True):
+    def zero_grad(self, tables=True, defer=False):
         """One memset; the hash tables keep their gradient views attached (the scatter kernels accumulate into them in
         place), the ~30 small MLP tensors are detached so that autograd hands over each gradient tensor as is instead of
         launching one `grad += new` kernel per parameter -- `gather_grads` then moves them with one multi-tensor copy.
         tables=False: the tables' gradient storage is known to be all zero (it was never written since the allocation, or the last
-        pass ended with `table_steps` / `clear_table_grads`): only the small tensors and the pool behind them are cleared."""
+        pass ended with `table_steps` / `clear_table_grads`): only the small tensors and the pool behind them are cleared.
+        defer (with tables=False): do not launch that memset but RETURN the range; the caller has it cleared by the iteration's first kernel."""
+        deferred = None
         if tables:
             self._g_alloc.zero_()
+        elif defer:     # the caller clears this range itself before any gradient is produced (hs_iter_prologue's zero range: no launch of its own)
+            deferred = self._g_alloc[self.offsets[self.n_tables]:]        # (the first small parameter starts a 16-byte quad; the pads before it are never written)
         else:
             self._g_alloc[self.tables_end:].zero_()
         _be.set_zero_pool(self._g_alloc[self.padded:])
@@ -131,6 +135,7 @@ class FlatAdam:
         self.pass_open = True
         for p, _ in self.small:
             p.grad = None
+        return deferred
 
     def gather_grads(self):
         """Dense-update semantics: the fused Adam walks the WHOLE flat buffer, so a parameter that received no gradient this

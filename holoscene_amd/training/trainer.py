@@ -313,14 +313,14 @@ class Stage1Trainer:
         if self._table_step and tick is not None and variant not in self._table_step_ok and not torch.cuda.is_current_stream_capturing():
             counting, _net._be.SCATTER_COUNTS = True, {}
         self._pass_fused = fused
-        self.flat.zero_grad(tables=not fused)
+        zero = self.flat.zero_grad(tables=not fused, defer=fused)       # fused: the 1.3 MB memset rides in the prologue launch below
         self._arm_early_exchange()
         steps = self.flat.table_steps(producers=self._table_producers.get(variant)) if fused else contextlib.nullcontext()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
         sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1])
-        with _net.iteration_prologue(model, tick, sizes) as drawn:
+        with _net.iteration_prologue(model, tick, sizes, zero=zero) as drawn:
             with torch.no_grad():
                 if "rng" in st:     # injected draws (static tensors the caller overwrites before each replay)
                     rng = st["rng"]

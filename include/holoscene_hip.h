@@ -612,11 +612,12 @@ int hs_pack_iteration(const float *W0, int32_t ld0, int32_t f_in, const float *b
  * rng_state[0] (seed) at counter rng_state[1]; the launch advances the counter (rng_state: three device uint64, [2] = scratch, zero between
  * launches), so every replay of a captured graph draws a new pool -- replaces torch.rand's generator kernel + its two Philox-state fills
  * (the reference draws where it needs them: network.py:785, 847-853, ray_sampler.py:79, 238, 269, 279); (c) beta_out = |beta| + beta_min[0]
- * (model/density.py:28-30); (d) adam != NULL: hs_adam_tick's update of the optimiser state.  Any part may be empty.
+ * (model/density.py:28-30); (d) adam != NULL: hs_adam_tick's update of the optimiser state; (e) zero[0..n_zero) <- 0 (16-byte aligned: the iteration's
+ * gradient memset, optimizer.zero_grad of holoscene_train.py:354 for everything the scatters do not own).  Any part may be empty.
  * hs_iter_epilogue: the weight-norm BACKWARD of `jobs` + g_beta_out[i] = sgn(beta[i]) * (sum over up to 4 arrays [part_len[q], n_beta] of partial
  * cotangents -- the per-ray partials the compositing backward leaves --), written where the caller points (the flat gradient buffer's views). */
 int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
-                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, void *stream);
+                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, float *zero, int64_t n_zero, void *stream);
 int hs_iter_epilogue(const hsWnJob *jobs, int32_t n_jobs, const float *beta, const float *const *g_beta_parts, const int32_t *part_len,
                      int32_t n_parts, float *g_beta_out, int32_t n_beta, void *stream);
 
