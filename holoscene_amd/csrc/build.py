@@ -30,26 +30,34 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant: build a SECOND library `libholoscene_hip_<variant>.so` with extra compile flags (kernel A/B runs on one box:
+    HOLOSCENE_LIB=<that path> selects it in hashencoder/backend.py); its objects live in their own directory."""
+    if variant is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    lib = LIB if variant is None else os.path.join(HERE, f"libholoscene_hip_{variant}.so")
+    objdir = HERE if variant is None else os.path.join(HERE, f"obj_{variant}")
+    os.makedirs(objdir, exist_ok=True)
     for src in sources():
-        obj = src[:-4] + ".o"
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", HERE, "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", HERE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m holoscene_amd.csrc.build [--force] [--variant NAME -DFLAG ...]
+    args = sys.argv[1:]
+    var = args[args.index("--variant") + 1] if "--variant" in args else None
+    print(build(force="--force" in args, verbose=True, variant=var, extra_flags=[a for a in args if a.startswith("-D")]))

@@ -20,6 +20,9 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
 
 #include "holoscene_hip.h"
 #include "wave_ops.h"
@@ -157,6 +160,96 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
         f += fe[i];
     }
     return block_max<NT>(best, sc + 2 * (NT / kWave), tid);
+}
+
+// error_bound with the thread's sections held in REGISTERS across the eleven evaluations of a line search (HOLOSCENE_SAMPLER_SEARCH=lds restores
+// the form above).  A thread owns the same <= CH sections in both sweeps of every evaluation, so what the LDS form re-reads per evaluation (s, d, d*)
+// and parks between its sweeps (fe, ee) never has to leave the lane; what does not depend on beta is formed once (-|s|, sign(s), d^2, -d*); the
+// loops are unrolled over CH with the tail slots padded by d = 0 (their terms are exact zeros: the sums are untouched) and masked out of the
+// maximum; the scans and the maximum take their DPP operand inside the add / max (wave_ops.h: incl_scan2, max_dpp).  Same operations on the same
+// values in the same order as the form above -- sign(s) * em1 for its select (an exact product; the zero it yields for s = 0 may carry a sign,
+// which the following addition of half_inv_b absorbs) -- hence bit-identical bounds; ~315 -> ~200 instructions per evaluation at three sections.
+template <int CH>
+struct SecRegs {
+    float nas[CH], sg[CH], d[CH], dd[CH], nds[CH];
+    int cnt;
+};
+
+template <int NT, int CH>
+__device__ __forceinline__ SecRegs<CH> load_sections(const float *__restrict__ sdf, const float *__restrict__ dists, const float *__restrict__ dstar,
+                                                     int n, int tid) {
+    SecRegs<CH> r;
+    int lo, hi;
+    chunk_of(n, tid, NT, lo, hi);
+    r.cnt = hi - lo;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const bool in = k < r.cnt;
+        const float s = in ? sdf[lo + k] : 0.f, d = in ? dists[lo + k] : 0.f, ds = in ? dstar[lo + k] : 0.f;
+        r.nas[k] = -fabsf(s);
+        r.sg[k] = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+        r.d[k] = d;
+        r.dd[k] = d * d;
+        r.nds[k] = -ds;
+    }
+    return r;
+}
+
+template <int NT, int CH>
+__device__ __forceinline__ float error_bound_regs(const SecRegs<CH> &r, float beta, int tid, float *sc) {
+    constexpr int kW = NT / kWave;
+    const float inv_b = 1.f / beta, q = 0.25f * inv_b * inv_b, half_inv_b = 0.5f * inv_b;
+    float fi[CH], ei[CH], fsum = 0.f, esum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const float x = r.nas[k] * inv_b;
+        const float ser = x + 0.5f * x * x, ex = __expf(x) - 1.f;
+        const float em1 = x > -1e-3f ? ser : ex;
+        const float sig = half_inv_b + half_inv_b * (r.sg[k] * em1);
+        fi[k] = r.d[k] * sig;
+        ei[k] = fast_exp(r.nds[k] * inv_b) * r.dd[k] * q;
+        fsum += fi[k]; esum += ei[k];
+    }
+    // exclusive prefixes over the workgroup's threads (block_excl_scan2, with the folded-DPP wave scan)
+    float f = fsum, e = esum;
+    {
+        const int lane = tid & 63, w = tid >> 6;
+        float ai = f, bi = e;
+        hs_wave::incl_scan2(ai, bi);
+        float pa = 0.f, pb = 0.f;
+        if constexpr (kW > 1) {
+            if (lane == 63) { sc[w] = ai; sc[kW + w] = bi; }
+            __syncthreads();
+            float va[kW], vb[kW];
+#pragma unroll
+            for (int j = 0; j < kW; j++) { va[j] = sc[j]; vb[j] = sc[kW + j]; }
+#pragma unroll
+            for (int j = 0; j < kW - 1; j++) {
+                pa = j < w ? pa + va[j] : pa;
+                pb = j < w ? pb + vb[j] : pb;
+            }
+        }
+        f = pa + (ai - f);
+        e = pb + (bi - e);
+    }
+    float best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        e += ei[k];
+        const float b = (fminf(fast_exp(e), 1.0e6f) - 1.0f) * fast_exp(-f);
+        best = k < r.cnt ? fmaxf(best, b) : best;
+        f += fi[k];
+    }
+    // block_max; a NaN bound (NaN inputs) is dropped by fmaxf above as in the LDS form, so no lane passes a NaN on
+    float *scm = sc + 2 * kW;
+    best = hs_wave::max_dpp(best);
+    if constexpr (kW == 1) return best;
+    if ((tid & 63) == 0) scm[tid >> 6] = best;
+    __syncthreads();
+    float m = scm[0];
+#pragma unroll
+    for (int j = 1; j < kW; j++) m = fmaxf(m, scm[j]);
+    return m;
 }
 
 __device__ __forceinline__ int lower_bound(const float *a, int n, float v) {  // # elements < v
@@ -324,7 +417,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
                                                            const float *__restrict__ samples, const float *__restrict__ new_sdf, int s_new,
                                                            float *__restrict__ beta_io, const float *__restrict__ beta0_p, float eps,
                                                            int beta_iters, float *__restrict__ beta_max, int R, hsGate gate, const int32_t *__restrict__ m_dev,
-                                                           UpdDraw dr) {
+                                                           UpdDraw dr, bool search_in_regs) {
     extern __shared__ float lds[];
     if (gate_closed(gate)) return;
     const int r = blockIdx.x, lane = threadIdx.x;   // lane = thread index inside the ray's workgroup (4 waves)
@@ -371,18 +464,33 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     HS_SSTAMP(3);
     const float beta0 = *beta0_p;
     float hi = beta_io[r];
-    if (error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta0, lane, sc) <= eps) hi = beta0;
-    HS_SSTAMP(4);
-    float lo = beta0;
-    // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
-    // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
-    if (hi != lo)
-    for (int it = 0; it < beta_iters; it++) {
-        const float mid = (lo + hi) / 2.f;
-        const float err = error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, mid, lane, sc);
-        if (err <= eps) hi = mid;
-        else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
-    }
+    // the line search over an evaluator of the bound: eb(beta)
+    auto search = [&](auto &&eb) {
+        if (eb(beta0) <= eps) hi = beta0;
+        HS_SSTAMP(4);
+        float lo = beta0;
+        // a ray whose bound already holds at beta0 has hi == lo == beta0: every midpoint is beta0 and neither end can move, so the
+        // line search is skipped (exactly the reference's result; these workgroups retire ~11x sooner)
+        if (hi != lo)
+        for (int it = 0; it < beta_iters; it++) {
+            const float mid = (lo + hi) / 2.f;
+            const float err = eb(mid);
+            if (err <= eps) hi = mid;
+            else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
+        }
+    };
+    auto search_regs = [&](auto chc) {
+        constexpr int CH = decltype(chc)::value;
+        const SecRegs<CH> regs = load_sections<kUpd, CH>(sdf, dists, dstar, n, lane);
+        search([&](float beta) { return error_bound_regs<kUpd, CH>(regs, beta, lane, sc); });
+    };
+    const int ch = (n + kUpd - 1) / kUpd;       // sections per thread (workgroup-uniform)
+    if (search_in_regs && ch == 1) search_regs(std::integral_constant<int, 1>{});
+    else if (search_in_regs && ch == 2) search_regs(std::integral_constant<int, 2>{});
+    else if (search_in_regs && ch == 3) search_regs(std::integral_constant<int, 3>{});
+    else if (search_in_regs && ch == 4) search_regs(std::integral_constant<int, 4>{});
+    else if (search_in_regs && ch <= 6) search_regs(std::integral_constant<int, 6>{});
+    else search([&](float beta) { return error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta, lane, sc); });
     HS_SSTAMP(5);
     if (lane == 0) {
         beta_io[r] = hi;
@@ -668,10 +776,11 @@ static int sampler_update_launch(float *z, float *sdf, int32_t ld, int32_t m_old
     const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
     const size_t lds = (6 * m + 3 * 8) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
-    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
-    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
-    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr);
+    static const bool sr = [] { const char *e = getenv("HOLOSCENE_SAMPLER_SEARCH"); return !(e && strcmp(e, "lds") == 0); }();     // A/B: lds = round 4's form
+    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
+    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
+    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
+    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
     return check_launch();
 }
 

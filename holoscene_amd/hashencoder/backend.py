@@ -14,7 +14,7 @@ import os
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libholoscene_hip.so")
+LIB_PATH = os.environ.get("HOLOSCENE_LIB") or os.path.join(_CSRC, "libholoscene_hip.so")      # (HOLOSCENE_LIB: a variant build, csrc/build.py --variant; kernel A/B runs)
 
 _ERRORS = {-1: "unsupported D/C/size combination (GridEncoding: D must be 2 or 3, C must be 1, 2, 4, or 8)",
            -2: "HIP kernel launch failed", -3: "required pointer was NULL"}
