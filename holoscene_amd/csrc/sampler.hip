@@ -77,7 +77,8 @@ template <int NT>
 __device__ __forceinline__ void block_excl_scan2(float &a, float &b, float *sc, int tid) {
     constexpr int kUpdWaves = NT / kWave;
     const int lane = tid & 63, w = tid >> 6;
-    const float ai = wave_incl_scan(a, lane), bi = wave_incl_scan(b, lane);
+    float ai = a, bi = b;
+    hs_wave::incl_scan2(ai, bi);          // (same association as two hs_wave::incl_scan: bit-identical; ~half the instructions)
     float pa = 0.f, pb = 0.f;
     if constexpr (kUpdWaves > 1) {
         if (lane == 63) { sc[w] = ai; sc[kUpdWaves + w] = bi; }
@@ -433,7 +434,9 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     for (int i = lane; i < s_new; i += kUpd) { tz[m_old + i] = nz[i]; ts[m_old + i] = ns[i]; }
     __syncthreads();
     HS_SSTAMP(1);
-    // stable merge by rank (old before new on ties)
+    // stable merge by rank (old before new on ties).  (Measured and rejected, round 5: the thread's searches as fixed-step descents advancing
+    // together -- one LDS latency per step for all of them -- took 8.1 k ticks against these loops' 4.3 k: four waves share a SIMD, the phase is
+    // bound by its instruction count like the rest of the kernel, not by the latency of its dependent reads.)
     for (int i = lane; i < m_old; i += kUpd) {
         const int p = i + lower_bound(tz + m_old, s_new, tz[i]);
         z[p] = tz[i]; sdf[p] = ts[i];
@@ -479,6 +482,9 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
             else if (err > eps) lo = mid;  // (a NaN bound moves neither end, as in the reference's masked assignments)
         }
     };
+    // (Measured and rejected, round 5: the fused draw on the same section registers -- no second Heron bound, density and error term of a section
+    // evaluated once instead of twice.  The draw's share of a ray fell from 8.3 k to 6.2 k ticks in tools/exp/sampler_prof.hip, the launch inside
+    // the replayed iteration did not move: 21.6 -> 21.9 us, rocprofv3 on one box.  Removed again.)
     auto search_regs = [&](auto chc) {
         constexpr int CH = decltype(chc)::value;
         const SecRegs<CH> regs = load_sections<kUpd, CH>(sdf, dists, dstar, n, lane);
@@ -489,7 +495,6 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     else if (search_in_regs && ch == 2) search_regs(std::integral_constant<int, 2>{});
     else if (search_in_regs && ch == 3) search_regs(std::integral_constant<int, 3>{});
     else if (search_in_regs && ch == 4) search_regs(std::integral_constant<int, 4>{});
-    else if (search_in_regs && ch <= 6) search_regs(std::integral_constant<int, 6>{});
     else search([&](float beta) { return error_bound<kUpd>(sdf, dists, dstar, tz, ts, n, beta, lane, sc); });
     HS_SSTAMP(5);
     if (lane == 0) {
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(kUpd) void k_sampler_update(float *__restrict__ z_i
     if (dr.out) {           // workgroup-uniform
         __syncthreads();    // the line search's scratch (tz, ts, sc) is free from here on
         draw_phase<kUpd>(z, sdf, tz, ts, sc, m, hi, 0, dr.add_tiny, nullptr, dr.n_out, dr.out, r, lane, dr.ext);
+        HS_SSTAMP(6);
     }
 }
 

@@ -4,9 +4,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 int main() {
-    const int R = 1024, m_old = 320, s_new = 64, ld = m_old + s_new;
+    const int m_old = getenv("M_OLD") ? atoi(getenv("M_OLD")) : 320, s_new = getenv("S_NEW") ? atoi(getenv("S_NEW")) : 64;
+    const int R = 1024, ld = m_old + s_new;
     std::vector<float> z(R * ld), sd(R * ld), nz(R * s_new), ns(R * s_new), beta(R);
     unsigned s = 1;
     auto rnd = [&] { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
@@ -28,7 +30,12 @@ int main() {
     hipMemcpy(dnz, nz.data(), nz.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dns, ns.data(), ns.size() * 4, hipMemcpyHostToDevice);
     auto reset = [&] { hipMemcpy(dz, z.data(), z.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ds, sd.data(), z.size() * 4, hipMemcpyHostToDevice);
                        hipMemcpy(db, beta.data(), R * 4, hipMemcpyHostToDevice); };
-    auto run = [&] { return hs_sampler_update(dz, ds, ld, m_old, dnz, dns, s_new, db, db0, 0.1f, 10, dmax, R, nullptr, nullptr, nullptr); };
+    float *dout, *dcam, *ddir, *dx, *dx01;
+    hipMalloc(&dout, R * 128 * 4); hipMalloc(&dcam, R * 3 * 4); hipMalloc(&ddir, R * 3 * 4); hipMalloc(&dx, R * 128 * 3 * 4); hipMalloc(&dx01, R * 128 * 3 * 4);
+    hipMemset(dcam, 0, R * 3 * 4); hipMemset(ddir, 0, R * 3 * 4);
+    const bool fused = getenv("FUSED_DRAW") != nullptr;      // FUSED_DRAW=1: hs_sampler_update_draw (the launch of the device-controlled loop)
+    auto run = [&] { return fused ? hs_sampler_update_draw(dz, ds, ld, m_old, dnz, dns, s_new, db, db0, 0.1f, 10, dmax, R, nullptr, 1e-7f, 128, dout, dcam, ddir, 1.f, dx, dx01, nullptr)
+                                  : hs_sampler_update(dz, ds, ld, m_old, dnz, dns, s_new, db, db0, 0.1f, 10, dmax, R, nullptr, nullptr, nullptr); };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; i++) { reset(); run(); }
     hipDeviceSynchronize();
@@ -38,18 +45,19 @@ int main() {
     std::vector<unsigned long long> p(1024 * 8);
     hipMemcpyFromSymbol(p.data(), HIP_SYMBOL(g_sampler_prof), p.size() * 8);
     std::vector<float> bo(R); hipMemcpy(bo.data(), db, R * 4, hipMemcpyDeviceToHost);
-    const char *names[5] = {"stage old + new into LDS", "merge by rank", "write back + d*", "bound at beta0", "line search"};
+    const char *names[6] = {"stage old + new into LDS", "merge by rank", "write back + d*", "bound at beta0", "line search", "fused draw"};
+    const int np = fused ? 6 : 5;
     for (int pass = 0; pass < 2; pass++) {
-        double acc[5] = {0}; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+        double acc[6] = {0}; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
         for (int r = 0; r < R; r++) {
             const bool searched = bo[r] != b0;
             if (searched != (pass == 0)) continue;
             const unsigned long long *q = &p[r * 8];
-            for (int i = 0; i < 5; i++) acc[i] += (double)(q[i + 1] - q[i]);
-            t0 = std::min(t0, q[0]); t1 = std::max(t1, q[5]); n++;
+            for (int i = 0; i < np; i++) acc[i] += (double)(q[i + 1] - q[i]);
+            t0 = std::min(t0, q[0]); t1 = std::max(t1, q[np]); n++;
         }
         printf("%s rays: %d; first start .. last end %llu ticks\n", pass == 0 ? "searching" : "settled at beta0", n, n ? t1 - t0 : 0ull);
-        for (int i = 0; i < 5; i++) printf("  %-28s %8.0f ticks\n", names[i], n ? acc[i] / n : 0.0);
+        for (int i = 0; i < np; i++) printf("  %-28s %8.0f ticks\n", names[i], n ? acc[i] / n : 0.0);
     }
     return 0;
 }
