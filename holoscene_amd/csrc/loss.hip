@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -43,6 +44,28 @@ __device__ float block_sum(float v, float *scratch) {
     float t = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += scratch[w];
     return t;
+}
+
+// N sums over the whole block at once; every thread gets all of them.  One rendezvous for the lot: k_loss_rays forms eleven block sums, and as
+// eleven calls of block_sum they were 22 barriers over 16 waves and 66 LDS-crossbar shuffles -- most of that 13 us single-workgroup launch.
+// scratch: >= N * kBlock / 64 floats.  (wave sums on DPP operands, wave partials added in wave order: deterministic)
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N], float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = hs_wave::sum(v[i]);
+    __syncthreads();          // (the previous call's readers are done with scratch)
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) scratch[wave * N + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = 0.f;
+    for (int w = 0; w < nw; w++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += scratch[w * N + i];
+    }
 }
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
@@ -95,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
                                                       float w_l1, float w_cos, float *__restrict__ out, float *__restrict__ g_rgb,
                                                       float *__restrict__ g_depth, float *__restrict__ g_nmap, const float *__restrict__ acc2, int nparts, float invH,
                                                       float w_opac, float w_eik, float w_smooth) {
-    __shared__ float scratch[kBlock / 64];
+    __shared__ float scratch[8 * kBlock / 64];
     const float invR = 1.f / (float)R;
     // ---- pass 1: rgb, normals, opacity (ray-local), and the five sums of the depth least-squares system
     float s_rgb = 0.f, s_l1 = 0.f, s_cos = 0.f, s_op = 0.f, sA = 0.f, sB = 0.f, sD = 0.f, sE = 0.f;
@@ -141,11 +164,13 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
         const float p = depth[r], tt = depth_gt[r];
         sA += p * p; sB += p; sD += p * tt; sE += tt;
     }
-    const float Lrgb = block_sum(s_rgb, scratch) * invR * (1.f / 3.f);
-    const float Ll1 = block_sum(s_l1, scratch) * invR;
-    const float Lcos = block_sum(s_cos, scratch) * invR;
-    const float Lop = block_sum(s_op, scratch) * invR / (float)K;
-    const float A = block_sum(sA, scratch), Bs = block_sum(sB, scratch), D = block_sum(sD, scratch), E = block_sum(sE, scratch);
+    float s8[8] = {s_rgb, s_l1, s_cos, s_op, sA, sB, sD, sE};
+    block_sum_n<8>(s8, scratch);
+    const float Lrgb = s8[0] * invR * (1.f / 3.f);
+    const float Ll1 = s8[1] * invR;
+    const float Lcos = s8[2] * invR;
+    const float Lop = s8[3] * invR / (float)K;
+    const float A = s8[4], Bs = s8[5], D = s8[6], E = s8[7];
     const float Cn = (float)R;
     const float det = A * Cn - Bs * Bs;
     const float w = (Cn * D - Bs * E) / det, q = (A * E - Bs * D) / det;
@@ -157,8 +182,10 @@ __global__ __launch_bounds__(kBlock) void k_loss_rays(const float *__restrict__ 
         s_d += fminf(sq, 1.f);
         if (sq <= 1.f) { s0 += res; s1 += res * p; }
     }
-    const float Ld = block_sum(s_d, scratch) * invR;
-    const float S0 = block_sum(s0, scratch), S1 = block_sum(s1, scratch);
+    float s3[3] = {s_d, s0, s1};
+    block_sum_n<3>(s3, scratch);
+    const float Ld = s3[0] * invR;
+    const float S0 = s3[1], S1 = s3[2];
     for (int r = threadIdx.x; r < R; r += kBlock) {
         const float p = depth[r], tt = depth_gt[r], res = w * p + q - tt;
         const float c = (res * res <= 1.f) ? 1.f : 0.f;

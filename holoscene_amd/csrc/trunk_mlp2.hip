@@ -26,7 +26,7 @@ __device__ unsigned long long g_trunk2_prof[256 * 8 * 8];
 #ifndef HS_TSTAMP_TILE
 #define HS_TSTAMP_TILE 2      // which of the wave's tiles is stamped (the last ones run on a half-empty chip)
 #endif
-#define HS_TSTAMP(i) do { if (lane == 0 && tile == (int64_t)blockIdx.x * kWaves + wave + (int64_t)HS_TSTAMP_TILE * gridDim.x * kWaves) \
+#define HS_TSTAMP(i) do { if (lane == 0 && tile == (int64_t)wave * gridDim.x + blockIdx.x + (int64_t)HS_TSTAMP_TILE * gridDim.x * kWaves) \
         g_trunk2_prof[(blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HS_TSTAMP(i) do { } while (0)
@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
         for (int i = 0; i < 8; i++) r.f[i] = *reinterpret_cast<const float2 *>(fp + i * fstride);
         return r;
     };
-    const int64_t tile0 = (int64_t)blockIdx.x * kWaves + wave, tstride = (int64_t)gridDim.x * kWaves;
+    // tile -> (workgroup, wave): wave-major, i.e. tile = wave * gridDim.x + blockIdx.x (+ rounds of gridDim.x * kWaves).  A launch with fewer tiles
+    // than 256 x 8 then spreads them over ALL compute units, one or two waves each, instead of filling eight waves of a few (the Eikonal set's
+    // 512 tiles: 256 workgroups with two live waves on two SIMDs instead of 64 full ones sharing theirs)
+    const int64_t tile0 = (int64_t)wave * gridDim.x + blockIdx.x, tstride = (int64_t)gridDim.x * kWaves;
     Raw raw = load_raw(tile0 < ntiles ? tile0 : 0);
     for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
         HS_TSTAMP(0);
@@ -474,7 +477,8 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     attr_a.set((const void *)k_trunk_fwd2<false>, (int)lds);
     attr_b.set((const void *)k_trunk_fwd2<true>, (int)lds);
     const int64_t ntiles = (M + kRows - 1) / kRows;
-    const int64_t want = (ntiles + kWaves - 1) / kWaves;
+    static const bool spread = [] { const char *e = getenv("HOLOSCENE_TRUNK2_SPREAD"); return !(e && e[0] == '0'); }();      // A/B: 0 = packed workgroups
+    const int64_t want = spread ? ntiles : (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
     // w2_planes = 1: the caller evaluates nothing but the Eikonal regulariser's points -- only their gradients are used, a training with those
     // points in fp32 ends where one with single-plane bf16 does (profiles/r05/bf16_stage_hunt.txt, stage "eikonal"), and the low plane's
