@@ -237,7 +237,14 @@ __device__ __forceinline__ void pair_slice(const hsWgradPairJob &job, int slice,
 //   * a row-major operand ([M, 80] / [M, 32]) lands linearly (pitch 160 / 64 B); rows beyond job.rows are read as copies of the last
 //     valid row: their partner in the pair is tile-packed, whose rows there are zero (hs_wgrad_pairs' contract for these kinds).
 // The vector-memory counter retires in order and the loop issues nothing else, so a wave waits for "all but the younger stages' requests".
-constexpr int kLdsD = 4 * 2 * 16 * (1024 + 128), kBlkD = 1024 + 128;      // 144 KB of stages; their number follows from the kind's stage size
+// (round 5: THREE stages' worth of LDS for the widest kind instead of the four that fit -- and 4 / 6 instead of 5 / 8 stages for the narrower kinds:
+// 113 -> 106 us per launch under rocprofv3 on three boxes, the bench's median -7 us in five alternating pairs.  Fewer requests in flight per
+// compute unit (2 x 36 KB instead of 3 x 36 KB) serve the same bytes sooner: the queue in front of the memory is what a stage waits in.
+// -DHS_WGP_STAGES=4 restores round 4's depth; all three stages of the narrow kinds alone, or five, measured slower than either.)
+#ifndef HS_WGP_STAGES
+#define HS_WGP_STAGES 3
+#endif
+constexpr int kLdsD = HS_WGP_STAGES * 2 * 16 * (1024 + 128), kBlkD = 1024 + 128;      // 144 KB of stages; their number follows from the kind's stage size
 template <int W, bool TP> struct OperandD {
     static constexpr int pieces = TP ? W / 16 : (64 * W + 1023) / 1024;       // DMA instructions (1 KB each) per stage
     static constexpr int bytes = TP ? pieces * kBlkD : pieces * 1024;         // LDS bytes per stage
