@@ -33,6 +33,10 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef HS_HASH_FWD_THREADS
+#define HS_HASH_FWD_THREADS 256
+#endif
+constexpr int kFwdThreads = HS_HASH_FWD_THREADS;      // the gather kernels' workgroup
 
 struct LevelScales {
     float v[HS_MAX_LEVELS];
@@ -157,14 +161,14 @@ __device__ __forceinline__ size_t grid_entry0(const hsHashLayout &lay, uint32_t 
 
 // ------------------------------------------------------------------------------------ forward
 template <int D, int C, bool DYDX>
-__global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__ x, const float *__restrict__ emb,
+__global__ __launch_bounds__(kFwdThreads) void k_hash_fwd(const float *__restrict__ x, const float *__restrict__ emb,
                                                         const int32_t *__restrict__ offsets, float *__restrict__ out,
                                                         float *__restrict__ dydx, uint32_t B, uint32_t L, LevelScales sc,
                                                         hsHashLayout lay, uint32_t n_chunks) {
     uint32_t level, chunk;
     if (lay.gate.a != nullptr && !(*lay.gate.a > *lay.gate.b)) return;   // hsGate: this sampler round was not needed
     decode_block(L, n_chunks, lay.schedule, level, chunk);
-    const uint32_t b = chunk * kThreads + threadIdx.x;
+    const uint32_t b = chunk * kFwdThreads + threadIdx.x;
     if (b >= B) return;
     const LevelInfo li = level_info<D>(offsets, level, sc);
     const float *__restrict__ grid = emb + grid_entry0(lay, grid_of(lay, b), li) * C;
@@ -244,14 +248,14 @@ __global__ __launch_bounds__(kThreads) void k_hash_fwd(const float *__restrict__
 // DYDX: also d out / d x01 (the one-lane kernel's expressions and summation order: for the x derivative the even lane takes its
 // neighbour's four entries through DPP, for y / z the two lanes' terms alternate in the sum as in the value).
 template <int C, bool DYDX>
-__global__ __launch_bounds__(kThreads) void k_hash_fwd_pair(const float *__restrict__ x, const float *__restrict__ emb,
+__global__ __launch_bounds__(kFwdThreads) void k_hash_fwd_pair(const float *__restrict__ x, const float *__restrict__ emb,
                                                              const int32_t *__restrict__ offsets, float *__restrict__ out, float *__restrict__ dydx,
                                                              uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
     constexpr int D = 3;
     uint32_t level, chunk;
     if (lay.gate.a != nullptr && !(*lay.gate.a > *lay.gate.b)) return;
     decode_block(L, n_chunks, lay.schedule, level, chunk);
-    const uint32_t t = chunk * kThreads + threadIdx.x, b = t >> 1, xb = t & 1u;
+    const uint32_t t = chunk * kFwdThreads + threadIdx.x, b = t >> 1, xb = t & 1u;
     if (b >= B) return;                      // both lanes of a pair leave together
     const LevelInfo li = level_info<D>(offsets, level, sc);
     const float *__restrict__ grid = emb + grid_entry0(lay, grid_of(lay, b), li) * C;
@@ -428,7 +432,13 @@ __device__ __forceinline__ void scatter_cell(float *__restrict__ gg, const Level
 // bins = slabs of ceil(res^3 / kBins) cells).  Records that do not fit the bin's capacity fall back to atomics.
 constexpr uint32_t kBins = HS_SCATTER_BINS;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t kReduceLds = 32768;   // bytes of LDS per reduce workgroup: 4 096 cells x 2 floats; five workgroups per CU hide each other's latency
+constexpr uint32_t kReduceLds = 32768u * 128u / kBins;   // bytes of LDS per reduce workgroup: 4 096 cells x 2 floats at 128 bins; five workgroups per CU hide each other's latency
+#ifndef HS_BIN_THREADS
+#define HS_BIN_THREADS 512
+#endif
+constexpr int kBinThreads = HS_BIN_THREADS;                // threads of a reduce / step workgroup; kBinV quads per thread cover the bin in one pass
+constexpr int kBinV = (int)(kReduceLds / 16u) / kBinThreads;
+static_assert(kBinV >= 1 && kBinV * kBinThreads * 16 == (int)kReduceLds, "a reduce workgroup covers its bin in one pass of whole quads");
 
 template <int C>
 struct BinRecord { uint32_t cell; float v[C]; };
@@ -521,7 +531,7 @@ __global__ void k_zero_u32(uint32_t *p, int n) {
 }
 
 template <int D, int C>
-__global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
+__global__ __launch_bounds__(kBinThreads) void k_hash_bin_reduce(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
                                                           hsHashLayout lay) {
     extern __shared__ float acc[];
     const uint32_t level = blockIdx.y, bin = blockIdx.x;
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
     // workgroup whose whole life is a chain of such round trips (2 048 workgroups on 1 280 slots: the launch lasts ~2 workgroup lives)
     float *dstf = gemb + ((size_t)li.offset + (size_t)first) * C;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(dstf) & 15) == 0 && nfl == per_bin * C;
-    constexpr int kV = 4;                                        // kReduceLds / 16 B = 2 048 quads = kV x 512 threads: one pass
+    constexpr int kV = kBinV;                                    // kReduceLds / 16 B quads = kV x kBinThreads: one pass
     float4 t[kV];
     if (vec_ok) {
 #pragma unroll
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(512) void k_hash_bin_reduce(float *__restrict__ gem
 // Every (level, bin) workgroup steps ALL its cells (dense Adam: an entry without a gradient decays its moments and still moves);
 // levels that are not binned, and overflowed bins, add what the scatter put into `gemb` with atomics and return those floats to zero.
 template <int D, int C>
-__global__ __launch_bounds__(512) void k_hash_bin_step(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
+__global__ __launch_bounds__(kBinThreads) void k_hash_bin_step(float *__restrict__ gemb, const int32_t *__restrict__ offsets, uint32_t L, LevelScales sc,
                                                         hsHashLayout lay, hsTableStep ts) {
     extern __shared__ float acc[];
     const uint32_t level = blockIdx.y, bin = blockIdx.x;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(512) void k_hash_bin_step(float *__restrict__ gemb,
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(M) |
                           reinterpret_cast<uintptr_t>(V)) & 15) == 0 && nfl == per_bin * C;
-    constexpr int kV = 4;                                        // kReduceLds / 16 B = 2 048 quads = kV x 512 threads: one pass
+    constexpr int kV = kBinV;                                    // kReduceLds / 16 B quads = kV x kBinThreads: one pass
     // parameter and moments of this thread's quads do not depend on the records: requested now, they arrive under the record phase
     f32x4 tp[kV], tm[kV], tv[kV];
     if (vec_ok) {
@@ -729,9 +739,9 @@ void launch_bin_reduce(float *grad_embeddings, const int32_t *offsets, uint32_t 
     if (lay.step) {
         hsHashLayout dev = lay;
         dev.step = nullptr;              // (a host pointer: the kernel receives the structure by value)
-        k_hash_bin_step<D, C><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, dev, *lay.step);
+        k_hash_bin_step<D, C><<<dim3(kBins, L), dim3(kBinThreads), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, dev, *lay.step);
     } else if (lay.scatter_ws) {
-        k_hash_bin_reduce<D, C><<<dim3(kBins, L), dim3(512), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
+        k_hash_bin_reduce<D, C><<<dim3(kBins, L), dim3(kBinThreads), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
     }
 }
 
@@ -1019,14 +1029,14 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
     if (lay.grid_id && (lay.scatter_ws || lay.grid_stride <= 0)) return HS_ERR_ARG;   // the record bins are per (level, bin) of ONE table
     if (lay.schedule == 1 && (L % 8u) != 0u) lay.schedule = 0;
     if (lay.out_bf16 && (C != 2 || D != 3 || dy_dx || !pair_forward())) return HS_ERR_ARG;     // the packed-word output: the pair kernel's value form only
-    const uint32_t n_chunks = (B + kThreads - 1) / kThreads;
+    const uint32_t n_chunks = (B + kFwdThreads - 1) / kFwdThreads;
     const LevelScales sc = make_scales(L, S, H);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(n_chunks * L), block(kThreads);
+    const dim3 grid(n_chunks * L), block(kFwdThreads);
     dispatch_dc(D, C, [&](auto d, auto c) {
         constexpr int D_ = decltype(d)::value, C_ = decltype(c)::value;
         if (D_ == 3 && pair_forward()) {
-            const uint32_t n_chunks2 = (2 * B + kThreads - 1) / kThreads;      // two lanes per point
+            const uint32_t n_chunks2 = (2 * B + kFwdThreads - 1) / kFwdThreads;      // two lanes per point
             if (dy_dx)
                 k_hash_fwd_pair<C_, true><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks2);
             else

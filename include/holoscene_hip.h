@@ -149,7 +149,9 @@ typedef struct hsHashLayout {
 } hsHashLayout;
 
 /* Work space for the binned scatter (bytes; negative = error code) and the per-bin record capacity to put in the layout. */
+#ifndef HS_SCATTER_BINS
 #define HS_SCATTER_BINS 128
+#endif
 int64_t hs_hash_scatter_ws_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t *cap_out);
 
 int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *offsets, float *outputs,

@@ -1,1 +1,1 @@
-for v in b100 b110 b125 wide3; do bash tools/exp/kstat_lib.sh $v "wgrad" | tail -2; done
+for v in bins256 bins256t256 t256; do bash tools/exp/kstat_lib.sh $v "hash_b" | tail -4; done

@@ -35,8 +35,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // ---- A
 template <bool WORDS>
 __global__ __launch_bounds__(256) void kA(const float *__restrict__ x, const void *__restrict__ embv, unsigned *__restrict__ out, unsigned B, Lvs ls,
-                                          unsigned n_chunks) {
+                                          unsigned n_chunks, unsigned xcd_mask = 0xffu) {
     const unsigned bid = blockIdx.x, xcd = bid & 7u, j = bid >> 3, slot = j / n_chunks, chunk = j - slot * n_chunks;
+    if (!((xcd_mask >> xcd) & 1u)) return;
     const unsigned level = (slot & 1u) ? (slot * 8u + 7u - xcd) : (slot * 8u + xcd);
     const unsigned t = chunk * 256 + threadIdx.x, b = t >> 1, xb = t & 1u;
     if (b >= B) return;
@@ -64,6 +65,44 @@ __global__ __launch_bounds__(256) void kA(const float *__restrict__ x, const voi
         a1 += p1; a1 += dpp_swap(p1);
     }
     if (xb == 0) out[(size_t)level * B + b] = pack_bf16(a0, a1);
+}
+
+
+// ---- E: form A with the coordinate loads and the store on HALF the lanes: lane l < 32 loads the coordinates of the wave's point l (three dword
+// loads over 8 quads instead of 16) and hands them to lanes 2l, 2l + 1 through the LDS crossbar (ds_bpermute: no addresser work); the 32 results
+// are moved to lanes 0..31 the same way and stored from there
+__global__ __launch_bounds__(256) void kE(const float *__restrict__ x, const float2 *__restrict__ emb, unsigned *__restrict__ out, unsigned B, Lvs ls,
+                                          unsigned n_chunks) {
+    const unsigned bid = blockIdx.x, xcd = bid & 7u, j = bid >> 3, slot = j / n_chunks, chunk = j - slot * n_chunks;
+    const unsigned level = (slot & 1u) ? (slot * 8u + 7u - xcd) : (slot * 8u + xcd);
+    const unsigned t = chunk * 256 + threadIdx.x, b = t >> 1, xb = t & 1u, lane = threadIdx.x & 63u;
+    const unsigned wave_b0 = (chunk * 256 + (threadIdx.x & ~63u)) >> 1;        // first point of this wave
+    if (wave_b0 >= B) return;
+    const Lv l = ls.v[level];
+    const float2 *g = emb + l.offset;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (lane < 32 && wave_b0 + lane < B) { const float *xp = x + (size_t)(wave_b0 + lane) * 3; px = xp[0]; py = xp[1]; pz = xp[2]; }
+    const int src = (int)(lane >> 1) << 2;
+    const float ps[3] = {__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(px))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(py))),
+                         __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pz)))};
+    float w[3]; unsigned c[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { float p = ps[d] * l.scale; float f = floorf(p); c[d] = (unsigned)f; w[d] = sstep(p - f); }
+    float2 e[4];
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) e[yz] = g[cell(l, c[0] + xb, c[1] + (yz & 1), c[2] + (yz >> 1))];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) {
+        const float wt = (xb ? w[0] : 1 - w[0]) * ((yz & 1) ? w[1] : 1 - w[1]) * ((yz >> 1) ? w[2] : 1 - w[2]);
+        const float p0 = wt * e[yz].x, p1 = wt * e[yz].y;
+        a0 += p0; a0 += dpp_swap(p0);
+        a1 += p1; a1 += dpp_swap(p1);
+    }
+    const unsigned word = pack_bf16(a0, a1);
+    const unsigned mine = (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane & 31u) << 3), (int)word);     // lane l < 32 <- lane 2 l
+    if (lane < 32 && wave_b0 + lane < B) out[(size_t)level * B + wave_b0 + lane] = mine;
+    (void)b;
 }
 
 // ---- B / C: two levels per wave.  WORDS: the table is uint32 (bf16 pair) per entry
@@ -178,6 +217,11 @@ int main() {
     }
     run("C two levels, bf16 words", [&] { kB<true><<<n_chunks * 8, 256>>>(dx, dw, dout, B, ls, n_chunks); });
     run("D one level, bf16 words", [&] { kA<true><<<n_chunks * 16, 256>>>(dx, dw, dout, B, ls, n_chunks); });
+    for (unsigned m : {0x1fu, 0xe0u, 0x01u, 0x10u, 0x20u, 0x80u}) {
+        char nm[64]; snprintf(nm, sizeof nm, "A, XCD mask %02x only", m);
+        run(nm, [&] { kA<false><<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks, m); });
+    }
+    run("E half-wave loads / store", [&] { kE<<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks); });
     run("A again", [&] { kA<false><<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks); });
     return 0;
 }
