@@ -177,7 +177,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_hash_fwd(const float *__restric
 
     uint32_t g[D];
     float w[D], dw[D];
-    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
+    // an EMPTY level (offsets[l + 1] == offsets[l]) encodes to zeros: how a grid of fewer than 16 levels is presented to the fused 16-level kernels
+    if (li.table == 0u || !locate<D>(x + (size_t)b * D, li, g, w, dw)) {
 #pragma unroll
         for (int c = 0; c < C; c++) o[c] = 0.f;
         if (DYDX) {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_hash_fwd_pair(const float *__re
     float *jo = DYDX ? dydx + (int64_t)level * lay.dydx_level_stride + (int64_t)b * lay.dydx_point_stride : nullptr;
     uint32_t g[D];
     float w[D], dw[D];
-    if (!locate<D>(x + (size_t)b * D, li, g, w, dw)) {
+    if (li.table == 0u || !locate<D>(x + (size_t)b * D, li, g, w, dw)) {      // (an empty level: zeros, as in k_hash_fwd)
         if (xb == 0) {
             if (!DYDX && lay.out_bf16) {
                 o[0] = 0.f;             // (one zero word)
@@ -754,6 +755,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
     const LevelInfo li = level_info<D>(offsets, level, sc);
+    if (li.table == 0u) return;       // an empty level has no table to scatter into (block-uniform)
     uint32_t g[D];
     float w[D], dw[D];
     const bool valid = b < B && locate<D>(x + (size_t)b * D, li, g, w, dw);
@@ -833,6 +835,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict_
     }
     if (!g2emb) return;  // uniform
     const LevelInfo li = level_info<D>(offsets, level, sc);
+    if (li.table == 0u) return;       // (block-uniform)
     uint32_t g[D];
     float w[D], dw[D];
     const bool valid = inb && locate<D>(x + (size_t)b * D, li, g, w, dw);
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
     decode_block(L, n_chunks, lay.schedule, level, chunk);
     const uint32_t b = chunk * kThreads + threadIdx.x;
     const LevelInfo li = level_info<D>(offsets, level, sc);
+    if (li.table == 0u) return;       // an empty level has no table to scatter into (block-uniform)
     uint32_t g[D];
     float w[D], dw[D];
     const bool valid = b < B && locate<D>(x + (size_t)b * D, li, g, w, dw);

@@ -126,6 +126,31 @@ class HashEncoder(nn.Module):
         std = 1e-4
         self.embeddings.data.uniform_(-std, std)
 
+    # ---- a grid of fewer than 16 levels as the fused kernels see it.  The matrix-core kernels of model/network.py address hash features as 16 levels
+    # x 2 channels (no L argument: a lane half owns levels 8 h .. 8 h + 7).  A grid with L < 16 levels of 2 channels is handed to them with EMPTY
+    # levels behind its own (offsets[l + 1] == offsets[l]): the hash kernels encode an empty level to zeros and scatter nothing into it
+    # (csrc/hash_encode.hip), so every consumer sees the stock layout with zero features in the slots the conf does not have -- their weight
+    # columns are zero-padded to match (network.py: fused_cols) and receive exactly-zero gradients.
+    FUSED_LEVELS = 16
+
+    @property
+    def fused_pads(self):
+        return self.level_dim == 2 and self.input_dim == 3 and self.num_levels < self.FUSED_LEVELS
+
+    @property
+    def fused_num_levels(self):
+        return self.FUSED_LEVELS if self.fused_pads else self.num_levels
+
+    @property
+    def fused_offsets(self):
+        if not self.fused_pads:
+            return self.offsets
+        pad = getattr(self, "_fused_offsets", None)
+        if pad is None or pad.device != self.offsets.device:
+            pad = torch.cat([self.offsets, self.offsets[-1:].expand(self.FUSED_LEVELS - self.num_levels)]).contiguous()
+            self._fused_offsets = pad        # (not a registered buffer: state dicts keep the reference's keys)
+        return pad
+
     def __repr__(self):
         return (f"HashEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
                 f"base_resolution={self.base_resolution} per_level_scale={self.per_level_scale} params={tuple(self.embeddings.shape)}")

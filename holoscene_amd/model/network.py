@@ -1314,7 +1314,7 @@ def shared_effective_weights(lins):
     lins = [l for l in lins if isinstance(l, WNLinear) and l.weight_v.is_cuda]
     if lins:
         Ws = _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
-        _SHARED_W = {id(l): W for l, W in zip(lins, Ws)}
+        _SHARED_W = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}
     try:
         yield
     finally:
@@ -1452,7 +1452,7 @@ def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
             off += n
     global _ITER_PACKS, _NORMALS_RELAY
     prev_w, prev_relay, prev_beta, prev_packs, prev_nrm = _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY
-    _SHARED_W, _BETA_RELAY, dens._shared = {id(l): W for l, W in zip(lins, Ws)}, relay, beta_eff
+    _SHARED_W, _BETA_RELAY, dens._shared = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}, relay, beta_eff
     _ITER_PACKS = model._pack_iteration()
     _NORMALS_RELAY = {"key": None, "cot": None}
     global _LAST_RELAYS
@@ -1478,12 +1478,22 @@ def assert_relays_consumed():
                            f"{len(beta_relay['parts'])}, normals: {nrm_relay is not None and nrm_relay['cot'] is not None}): its consumer's backward did not run")
 
 
+def fused_cols(W, l):
+    """W [out, n] of layer l with zero columns appended up to l.fused_cols -- the layers that read hash features of a grid with fewer than 16
+    levels (hashencoder/hashgrid.py: fused_offsets) as the fused 16-level kernels want them.  A plain pad: autograd slices the gradient back."""
+    n = getattr(l, "fused_cols", None)
+    if n is None or W.shape[1] >= n or not W.is_cuda:
+        return W
+    return torch.nn.functional.pad(W, (0, n - W.shape[1]))
+
+
 def effective_weights(lins):
-    """Weight-normalised matrices of a list of WNLinear layers (one fused launch on the GPU)."""
+    """Weight-normalised matrices of a list of WNLinear layers (one fused launch on the GPU); columns zero-padded where a layer asks (fused_cols)."""
     if _SHARED_W is not None and all(id(l) in _SHARED_W for l in lins):
         return tuple(_SHARED_W[id(l)] for l in lins)
     if lins[0].weight_v.is_cuda:
-        return _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
+        Ws = _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
+        return tuple(fused_cols(W, l) for W, l in zip(Ws, lins))
     return tuple(l.weight for l in lins)
 
 
@@ -1601,6 +1611,13 @@ class ObjectImplicitNetworkGrid(nn.Module):
             setattr(self, "lin" + str(l), lin)
         self.softplus = nn.Softplus(beta=100)
         self.cache_sdf = None
+        # a grid of fewer than 16 levels (x 2 channels) on the fused 16-level kernels: empty levels behind its own (HashEncoder.fused_offsets), zero
+        # columns behind the feature columns of the layers that read them (effective_weights / fused_cols).  Only when the features are the last
+        # columns of the first layer's input, as the stock layout has them: [x | positional encoding | hash features]
+        if self.encoding.fused_pads and multires == 6 and self.lin0.in_features == 39 + self.grid_feature_dim and 0 not in self.skip_in:
+            self.lin0.fused_cols = 39 + 2 * HashEncoder.FUSED_LEVELS
+            if color_grid_feature:
+                self.color_grid_feature_map_mlp[0].fused_cols = 2 * HashEncoder.FUSED_LEVELS
         self.set_mlp_precision(default_mlp_precision())
 
     def set_mlp_precision(self, precision):
@@ -1647,9 +1664,9 @@ class ObjectImplicitNetworkGrid(nn.Module):
             return why
         if self.embedder is None or self.embedder.multires != 6:
             why.append(f"multires = {getattr(self.embedder, 'multires', 0)} (kernels: 6 frequencies)")
-        if self.grid_feature_dim != 32 or not self._stock_grid():
+        if not self._stock_grid(padded=True) or not self._stock_inputs(padded=True):
             enc = self.encoding
-            why.append(f"hash grid {getattr(enc, 'num_levels', '?')} levels x {getattr(enc, 'level_dim', '?')} channels (kernels: 16 x 2)")
+            why.append(f"hash grid {getattr(enc, 'num_levels', '?')} levels x {getattr(enc, 'level_dim', '?')} channels (kernels: <= 16 levels x 2, features last in the first layer's input)")
         if not (lins[0].out_features == 256 and lins[1].in_features == 256 and lins[1].out_features == 256):
             why.append(f"hidden widths {lins[0].out_features}, {lins[1].out_features} (kernels: 256, 256)")
         if lins[2].out_features > 64:
@@ -1668,11 +1685,21 @@ class ObjectImplicitNetworkGrid(nn.Module):
                 and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].in_features == 71 and lins[2].out_features == self.d_out
                 and not any(l in self.skip_in for l in range(3)))
 
-    def _stock_grid(self):
+    def _stock_grid(self, padded=False):
         """The fused MLP kernels address hash features as 16 levels x 2 channels (csrc/sdf_mlp2.hip, trunk_mlp2.hip: no L / C arguments);
-        any other split of the 32 features (8 x 4, 32 x 1) takes the library-GEMM path."""
+        any other split of the 32 features (8 x 4, 32 x 1) takes the library-GEMM path.  padded: also a grid of FEWER levels x 2 channels whose
+        first layer pads its columns (lin0.fused_cols) -- the bf16 kernels then see empty levels behind the conf's own."""
         enc = self.encoding
+        if padded and getattr(enc, "fused_pads", False) and getattr(self.lin0, "fused_cols", None) is not None:
+            return True
         return getattr(enc, "num_levels", None) == 16 and getattr(enc, "level_dim", None) == 2 and getattr(enc, "input_dim", 3) == 3
+
+    def _stock_inputs(self, padded=False):
+        """first layer = [x | 6 octaves | 16 x 2 hash features] = 71 columns (padded: or fewer feature columns, zero-padded to that)"""
+        l0 = self._lins()[0]
+        if padded and getattr(l0, "fused_cols", None) == 71:
+            return self.grid_feature_dim == 2 * self.encoding.num_levels and l0.in_features == 39 + self.grid_feature_dim
+        return self.grid_feature_dim == 32 and l0.in_features == 71
 
     def _fused_sdf_supported(self, x):
         return not torch.is_grad_enabled() and (self._fused_trunk_supported(x) or self._fused_sdf32_supported(x))
@@ -1757,12 +1784,12 @@ class ObjectImplicitNetworkGrid(nn.Module):
         x = x.contiguous().float()
         B = x.shape[0]
         enc = self.encoding
-        L, C = enc.num_levels, enc.level_dim
+        L, C = enc.fused_num_levels, enc.level_dim        # (a grid of fewer levels: empty ones behind its own, HashEncoder.fused_offsets)
         lm = L == 16 and C == 2        # level-major features: coalesced stores in the gather kernel (see sdf_along_rays)
         x01 = ((x / self.divide_factor + 1.0) / 2.0).contiguous()
         feat = torch.empty((L, B, C) if lm else (B, L * C), device=x.device)
         be = _be._backend
-        be.fwd(x01, enc.embeddings, enc.offsets, feat, B, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+        be.fwd(x01, enc.embeddings, enc.fused_offsets, feat, B, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
                level_major=lm)
         d_out = self._lins()[2].out_features
         out = torch.empty(B, 1, device=x.device)
@@ -1787,7 +1814,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         dev = x.device
         be = _be._backend
         enc = self.encoding
-        L, C = enc.num_levels, enc.level_dim
+        L, C = enc.fused_num_levels, enc.level_dim
         # level-major features [L, R*S, C]: the gather kernel's stores become fully coalesced (point-major 8-byte pieces at a
         # 128-byte stride were written 4x, PMC WRITE_SIZE 66 MB for 17 MB), and the MFMA kernel reads 8-byte runs per level
         lm = L == 16 and C == 2
@@ -1797,11 +1824,11 @@ class ObjectImplicitNetworkGrid(nn.Module):
         words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= 32 and enc.embeddings.shape[1] == 2 and self.mlp_bf16
         if words:
             feat = torch.empty(L, R * S, device=dev, dtype=torch.int32)
-            be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+            be.fwd(x01, enc.embeddings, enc.fused_offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
                    gate=gate, level_major=True, out_bf16=True)
         else:
             feat = torch.empty((L, R * S, C) if lm else (R * S, L * C), device=dev)
-            be.fwd(x01, enc.embeddings, enc.offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
+            be.fwd(x01, enc.embeddings, enc.fused_offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
                    gate=gate, level_major=lm)
         out = torch.empty(R, S, device=dev)
         self._sdf_mlp(x, feat, d_out, select, out, None, gate, 2 if words else lm)
@@ -1817,8 +1844,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         enc = self.encoding
         if TRUNK_IMPL == "mfma" and self._fused_trunk_supported(x):
             l0, l1, l2 = self._lins()
-            return _fused_trunk.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
-                                      self.embedder.multires, float(self.divide_factor), l0.weight, l0.bias, l1.weight, l1.bias,
+            return _fused_trunk.apply(x, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                                      self.embedder.multires, float(self.divide_factor), fused_cols(l0.weight, l0), l0.bias, l1.weight, l1.bias,
                                       l2.weight, l2.bias)
         inp = _trunk_input.apply(x, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                                  self.embedder.multires if self.embedder is not None else 0, float(self.divide_factor),
@@ -2118,8 +2145,10 @@ class HoloSceneNetwork(nn.Module):
             return False
         mlp = net.color_grid_feature_map_mlp
         enc = net.color_encoding
-        return (rn.multires_view == 4 and rn.multires_point == 4 and rn.multires_normal == 4 and enc.num_levels == 16 and enc.level_dim == 2
-                and tuple(mlp[0].weight.shape) == (256, 32) and tuple(mlp[2].weight.shape) == (256, 256)
+        padded = getattr(mlp[0], "fused_cols", None) == 32 and enc.fused_pads       # fewer levels: empty ones behind them, zero columns in mlp[0]
+        return (rn.multires_view == 4 and rn.multires_point == 4 and rn.multires_normal == 4 and enc.level_dim == 2
+                and ((enc.num_levels == 16 and tuple(mlp[0].weight.shape) == (256, 32)) or (padded and tuple(mlp[0].weight.shape) == (256, 2 * enc.num_levels)))
+                and tuple(mlp[2].weight.shape) == (256, 256)
                 and tuple(rn.lin0.weight_v.shape) == (256, 337) and tuple(rn.lin1.weight_v.shape) == (256, 256)
                 and tuple(rn.lin2.weight_v.shape) == (3, 256))
 
@@ -2147,8 +2176,8 @@ class HoloSceneNetwork(nn.Module):
         if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
-            return fused_appearance(points_flat, dirs_flat, gradients, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)),
-                                           int(enc.base_resolution), float(net.divide_factor), mlp[0].weight, mlp[0].bias, mlp[2].weight,
+            return fused_appearance(points_flat, dirs_flat, gradients, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)),
+                                           int(enc.base_resolution), float(net.divide_factor), self._color_w0(), mlp[0].bias, mlp[2].weight,
                                            mlp[2].bias, R0, rn.lin0.bias, R1, rn.lin1.bias, R2, rn.lin2.bias, x01)
         return self.rendering_network(points_flat, gradients, dirs_flat, net._color_features(points_flat), indices)
 
@@ -2392,6 +2421,17 @@ class HoloSceneNetwork(nn.Module):
         return list(self.implicit_network._lins()) + [l for l in (getattr(rn, "lin0", None), getattr(rn, "lin1", None), getattr(rn, "lin2", None))
                                                        if l is not None]
 
+    def _color_w0(self):
+        """The colour feature MLP's first matrix as the fused colour kernels read it: 32 feature columns (zero ones behind those of a grid with
+        fewer than 16 levels).  ONE tensor per iteration_prologue() block -- the packed images are keyed by its identity."""
+        lin = self.implicit_network.color_grid_feature_map_mlp[0]
+        if getattr(lin, "fused_cols", None) is None or not lin.weight.is_cuda:
+            return lin.weight
+        packs = _ITER_PACKS
+        if packs is not None and packs.get("net") == id(self.implicit_network) and packs.get("color_w0") is not None:
+            return packs["color_w0"]
+        return fused_cols(lin.weight, lin)
+
     def _pack_iteration(self):
         """Inside iteration_prologue(): the fragment images of this iteration's weights for the sampler sweeps, the training trunk and the
         colour branch from one launch -- None when the model does not run on the fused bf16 kernels (the pack sites then pack for themselves)."""
@@ -2404,17 +2444,19 @@ class HoloSceneNetwork(nn.Module):
         if l2.out_features != net.d_out or net.d_out > 32:
             return None
         grad = torch.is_grad_enabled()          # (the colour branch's backward image only when a backward pass can follow)
+        mlp = net.color_grid_feature_map_mlp
+        c0 = fused_cols(mlp[0].weight, mlp[0])  # (differentiable: made outside the no_grad block; == mlp[0].weight on the stock grid)
         with torch.no_grad():
             W0, W1, W2 = effective_weights([l0, l1, l2])
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
-            mlp = net.color_grid_feature_map_mlp
             f = lambda t: t.detach().float().contiguous()  # noqa: E731
             out = _be._backend.pack_iteration(
                 (f(W0), f(l0.bias), f(W1), f(l1.bias), f(W2), f(l2.bias), net.d_out, True, True, self.training),
-                ((mlp[0].weight, mlp[2].weight, R0, R1, R2), (mlp[0].bias, mlp[2].bias, rn.lin0.bias, rn.lin1.bias, rn.lin2.bias), grad))
+                ((c0, mlp[2].weight, R0, R1, R2), (mlp[0].bias, mlp[2].bias, rn.lin0.bias, rn.lin1.bias, rn.lin2.bias), grad))
         out["net"] = id(net)
         out["trunk_key"] = (id(W0), id(W1), id(W2))
-        out["appear_key"] = (id(mlp[0].weight), id(mlp[2].weight), id(R0), id(R1), id(R2))
+        out["appear_key"] = (id(c0), id(mlp[2].weight), id(R0), id(R1), id(R2))
+        out["color_w0"] = c0 if c0 is not mlp[0].weight else None
         return out
 
     def uniform_sizes(self, num_rays):
@@ -2632,7 +2674,7 @@ class HoloSceneNetwork(nn.Module):
                 enc = net.encoding
                 l0, l1, l2 = net._lins()
                 W0, W1, W2 = effective_weights([l0, l1, l2])
-                return trunk_render(xs.detach(), n_m, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                return trunk_render(xs.detach(), n_m, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                                     net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01s)
             x01m = None if x01_all is None else x01_all[:n_main]
             x01e = None if x01_all is None else x01_all[n_main:]
@@ -2656,7 +2698,7 @@ class HoloSceneNetwork(nn.Module):
             l0, l1, l2 = net._lins()
             trunk_W = W0, W1, W2 = effective_weights([l0, l1, l2])
             sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = trunk_render(
-                x_all.detach(), n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                x_all.detach(), n_main, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
         elif FP32_TRUNK == "rr" and net._rr32_supported(x_all) and n_main > 0:
             # fp32: the rendered samples by the reverse-over-reverse closed form (rows = samples), the Eikonal points by value+Jacobian rows
@@ -2752,7 +2794,7 @@ class HoloSceneNetwork(nn.Module):
                 l0, l1, l2 = net._lins()
                 W0, W1, W2 = trunk_W if trunk_W is not None else effective_weights([l0, l1, l2])   # the main pass's normalised weights
                 raw_b, sdf_b, _, grad_b, _, _, _ = trunk_render(
-                    xb, B0, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
+                    xb, B0, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                     net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, xb01)
                 beta, unused_rgb = self.density.get_beta(), grad_b.detach()     # (the colour slot of the kernel is not needed here)
                 with torch.no_grad():

@@ -212,8 +212,13 @@ def test_off_fused_path_is_reported_with_its_reason():
     k40 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=40, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
     rep = k40.fused_path_report()
     assert k40.implicit_network.fused_trunk_blockers() == [] and len(rep) == 1 and "d_out = 40 > 32" in rep[0]
-    l8 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=8, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
-    assert any("hash grid 8 levels" in w for w in l8.implicit_network.fused_trunk_blockers())
+    # (a grid of FEWER than 16 levels x 2 channels is on the fused path since round 5: empty levels behind its own, HashEncoder.fused_offsets)
+    l8ok = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=8, mlp_precision="bf16", logmap=8, end_size=64).get_config("model"))
+    assert l8ok.implicit_network.fused_trunk_blockers() == [] and l8ok.implicit_network.lin0.fused_cols == 71
+    assert l8ok.implicit_network.encoding.fused_offsets.shape[0] == 17 and l8ok.implicit_network.encoding.offsets.shape[0] == 9
+    c20 = stock_conf(num_rays=8, S=8, d_out=2, num_levels=20, mlp_precision="bf16", logmap=8, end_size=64)
+    l8 = HoloSceneNetwork(c20.get_config("model"))
+    assert any("hash grid 20 levels" in w for w in l8.implicit_network.fused_trunk_blockers())
     assert "library GEMMs" in l8.fused_path_report()[0]
     with pytest.warns(UserWarning, match="does not run on the benchmarked bf16 kernels"):
         l8._warn_off_fused_path()
@@ -222,5 +227,5 @@ def test_off_fused_path_is_reported_with_its_reason():
         warnings.simplefilter("error")
         l8._warn_off_fused_path()           # once per model
         stock._warn_off_fused_path()        # nothing to say
-    fp32 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=8, mlp_precision="fp32", logmap=8, end_size=64).get_config("model"))
+    fp32 = HoloSceneNetwork(stock_conf(num_rays=8, S=8, d_out=2, num_levels=20, mlp_precision="fp32", logmap=8, end_size=64).get_config("model"))
     assert fp32.fused_path_report() == []   # the reference's precision is a choice, not a fallback
