@@ -49,6 +49,8 @@ const char *hs_target_arch(void);
 /* ------------------------------------------------------------------ 1. reference-compatible hash encoder
  *
  * All tensors float32, contiguous.  offsets is a DEVICE int32[L+1] array (as in
+ * (An EMPTY level -- offsets[l + 1] == offsets[l] -- encodes to zeros and takes no gradient, in every hash entry point below: how a grid of fewer
+ * than 16 levels is presented to the fused 16-level kernels, hashencoder/hashgrid.py: HashEncoder.fused_offsets.)
  * the reference, hashencoder.cu:107,120,151).  S = log2(per_level_scale),
  * H = base resolution.  D in {2,3}; C in {1,2,4,8} (second backward: C >= 2,
  * hashencoder.cu:678-684).
