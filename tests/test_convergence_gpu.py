@@ -68,29 +68,44 @@ def _fit(precision, graph, scene, seed0=5000):
     return {k: torch.stack(v).float().cpu() for k, v in hist.items()}, tr
 
 
+RUNS = 5        # runs per scene and precision: the statistics below are MEDIANS over them
+
+
 def test_bf16_graph_training_tracks_fp32_training():
+    """A run of either precision ends away from its pack now and then (tools/exp/conv_tail_spread.py, twelve runs each: scene 77 bf16 objectives
+    2.30 .. 2.48 against fp32's 2.319 .. 2.326, scene 31 fp32 one run of twelve at 2.66 / normal-L1 1.19 against 2.53 .. 2.59 / 1.02 .. 1.05; one bf16
+    run in eight at 2.89): float atomics and Adam's sign-like steps make every run its own trajectory.  One bf16 run against one fp32 run, as this
+    test compared until round 5, therefore failed about one time in eight.  What a precision path must share with the reference's is the
+    DISTRIBUTION of outcomes, so the comparison is between the medians of RUNS runs each -- a systematic shift (round 4's single-plane W2: every bf16
+    run at an Eikonal term of 0.30 against 0.52) moves the median by as much as it moved every run."""
     make = _teacher_scene()
     runs = {}
     for scene, seed0 in ((31, 5000), (77, 9000)):
-        bf, tr_bf = _fit("bf16", True, make(scene), seed0=seed0)
-        assert ("full", False, False) in tr_bf._graphs, "the bf16 run must have gone through the whole-iteration graph"
-        runs[scene] = (bf, _fit("fp32", False, make(scene), seed0=seed0)[0])
+        bfs, fps = [], []
+        for r in range(RUNS):
+            bf, tr_bf = _fit("bf16", True, make(scene), seed0=seed0)
+            assert ("full", False, False) in tr_bf._graphs, "the bf16 run must have gone through the whole-iteration graph"
+            bfs.append(bf)
+            fps.append(_fit("fp32", False, make(scene), seed0=seed0)[0])
+        runs[scene] = (bfs, fps)
     tail = lambda h, k: float(h[k][-TAIL:].mean())  # noqa: E731
+    med = lambda hs, k: float(torch.tensor([tail(h, k) for h in hs]).median())  # noqa: E731
     bad = []
-    for scene, (bf, fp) in runs.items():
-        for name, h in (("bf16", bf), ("fp32", fp)):
-            for k, v in h.items():
-                assert bool(torch.isfinite(v).all()), (scene, name, k)
-            first, last = float(h["rgb_loss"][:10].mean()), tail(h, "rgb_loss")
-            print(f"PARITY convergence scene {scene} {name}: rgb_loss {first:.4f} -> {last:.4f}, eikonal {tail(h, 'eikonal_loss'):.4f}, loss {tail(h, 'loss'):.4f}")
-            assert last < 0.5 * first, (scene, name, "the run does not learn", first, last)
+    for scene, (bfs, fps) in runs.items():
+        for name, hs in (("bf16", bfs), ("fp32", fps)):
+            for h in hs:
+                for k, v in h.items():
+                    assert bool(torch.isfinite(v).all()), (scene, name, k)
+                first, last = float(h["rgb_loss"][:10].mean()), tail(h, "rgb_loss")
+                assert last < 0.5 * first, (scene, name, "the run does not learn", first, last)
+            print(f"PARITY convergence scene {scene} {name}: trailing objective of the {RUNS} runs " + " ".join(f"{tail(h, 'loss'):.3f}" for h in hs)
+                  + "; Eikonal " + " ".join(f"{tail(h, 'eikonal_loss'):.3f}" for h in hs))
         for k in ("loss", "rgb_loss", "eikonal_loss", "depth_loss", "normal_l1"):
-            a, b, start = tail(bf, k), tail(fp, k), float(fp[k][:10].mean())
-            print(f"PARITY convergence scene {scene} {k}: bf16 {a:.5f} fp32 {b:.5f} bf16 / fp32 {a / max(abs(b), 1e-12):.3f}, start {start:.5f}")
-            # What is asserted (measured over twenty-odd runs, profiles/r04/convergence_run_to_run.txt): the OBJECTIVE ends within 10 % of the
-            # fp32 run's on the same scene (observed <= 3.2 %, two runs of one path differ by up to 7 %); the rgb term, which falls to 6 % of
-            # its start (below bf16's resolution of the colours), within 4 % of that start; and the SPLIT between the regularisers: the
-            # Eikonal and normal-L1 terms within 15 % of the fp32 run's on both scenes.  Round 4 could not assert the last one: on scene 77 every
+            a, b, start = med(bfs, k), med(fps, k), float(torch.tensor([float(h[k][:10].mean()) for h in fps]).median())
+            print(f"PARITY convergence scene {scene} {k}: median bf16 {a:.5f} fp32 {b:.5f} bf16 / fp32 {a / max(abs(b), 1e-12):.3f}, start {start:.5f}")
+            # What is asserted, on the medians: the OBJECTIVE within 10 % of the fp32 runs' on the same scene (observed <= 3.2 %); the rgb term, which
+            # falls to 6 % of its start (below bf16's resolution of the colours), within 4 % of that start; and the SPLIT between the regularisers: the
+            # Eikonal and normal-L1 terms within 15 % of the fp32 runs' on both scenes.  Round 4 could not assert the last one: on scene 77 every
             # bf16 run settled at an Eikonal term of 0.30 / normal 0.95-1.0 against fp32's 0.51-0.54 / 0.78.  The cause was ONE rounding: the
             # last trunk layer's matrix as a single bf16 plane in the value product of the rendered samples (geometric initialisation leaves its rows at
             # 0.11 +- 1e-4, bf16's grid there is 4.9e-4; tools/exp/conv_hybrid.py, DESIGN 14.2); k_rr_fwd now carries it as two planes.

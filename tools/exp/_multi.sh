@@ -1,1 +1,1 @@
-for v in bins256 bins256t256 t256; do bash tools/exp/kstat_lib.sh $v "hash_b" | tail -4; done
+for i in 1 2 3 4 5 6 7 8 9 10; do timeout 600 python -m pytest tests/test_convergence_gpu.py -x -q 2>&1 | grep -a "passed\|failed\|^E  " | tail -3; done
