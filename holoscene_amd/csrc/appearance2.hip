@@ -205,10 +205,23 @@ typedef short short2_t __attribute__((ext_vector_type(2)));
 
 // (the lane part of the address passes through an opaque register produced HERE: the scheduler otherwise computes the ~90 store addresses
 // of a tile at its top and spills them -- 80 of the first version's 120 spilled registers)
+#ifndef HS_NT_A2_FWD
+#define HS_NT_A2_FWD 1
+#endif
+#ifndef HS_NT_A2_BWD
+#define HS_NT_A2_BWD 0
+#endif
+template <bool NT = false>      // NT: a non-temporal store (trunk_rr.hip: tp_store)
 __device__ __forceinline__ void tp_store_n(uint16_t *__restrict__ T, int64_t tile, int ksteps, int s, int lane, const uint32_t *w4) {
     uint32_t lo = (uint32_t)lane * 8u;
     asm volatile("" : "+v"(lo));
-    *reinterpret_cast<uint4 *>(T + ((size_t)tile * ksteps + s) * 512 + lo) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    if constexpr (NT) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t vv = {w4[0], w4[1], w4[2], w4[3]};
+        __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t *>(T + ((size_t)tile * ksteps + s) * 512 + lo));
+    } else {
+        *reinterpret_cast<uint4 *>(T + ((size_t)tile * ksteps + s) * 512 + lo) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
 }
 
 // resident image by LDS-DMA (sdf_mlp2.hip), `bytes` a multiple of 1 KB
@@ -359,8 +372,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
                 pew[18 + (j >> 1)] = ok ? pack2(a0, a1) : 0u;
             }
             if (live) {
-                static_for<2>([&](auto sc) { constexpr int s = decltype(sc)::value; tp_store_n(XAt, tile, XAS, s, lane, fcw + 4 * s); });
-                static_for<6>([&](auto sc) { constexpr int s = decltype(sc)::value; tp_store_n(XAt, tile, XAS, 2 + s, lane, pew + 4 * s); });
+                static_for<2>([&](auto sc) { constexpr int s = decltype(sc)::value; tp_store_n<HS_NT_A2_FWD>(XAt, tile, XAS, s, lane, fcw + 4 * s); });
+                static_for<6>([&](auto sc) { constexpr int s = decltype(sc)::value; tp_store_n<HS_NT_A2_FWD>(XAt, tile, XAS, 2 + s, lane, pew + 4 * s); });
             }
         }
         const uint32_t bias_b = lds_base(bias, 16 * h);
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
                 else hp[8 * nd + r] = anchor(pack2(src[j][2 * r], src[j][2 * r + 1])) & okm;
             } else {
                 constexpr int ks = 4 * qd + (sl - 16);
-                if (live) tp_store_n(T, tile, HS, ks, lane, hp + 4 * ks);
+                if (live) tp_store_n<HS_NT_A2_FWD>(T, tile, HS, ks, lane, hp + 4 * ks);
             }
         };
         auto store_mask = [&](int layer) {
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__res
                 hp[8 * nd + r] = anchor(p);
             } else {
                 constexpr int ks = 4 * qd + (sl - 16);
-                if (STORE && live) tp_store_n(T, tile, HS, ks, lane, hp + 4 * ks);
+                if (STORE && live) tp_store_n<HS_NT_A2_BWD>(T, tile, HS, ks, lane, hp + 4 * ks);
             }
         };
         using L2_ = std::integral_constant<int, 2>;

@@ -56,12 +56,43 @@ __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 
 // s = sigmoid(100 a) from the stored h = softplus100(a): exp(-100 h) = 1 - s
 __device__ __forceinline__ float sig_of_h(float h) { return 1.f - __builtin_amdgcn_exp2f(-kC * h); }
 
+#ifndef HS_NT_LOAD_LAST
+#define HS_NT_LOAD_LAST 1
+#endif
+template <bool NT = false>      // NT: a non-temporal load -- a saved tensor at its LAST read
 __device__ __forceinline__ uint4 tp_load(const uint16_t *__restrict__ T, int64_t tile, int s, int lane) {
-    return *reinterpret_cast<const uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8);
+    if constexpr (NT) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8);
+    }
 }
+// NT: a non-temporal store -- for the saved activations whose reader is far away (the backward pass, the weight-gradient pass): 0.26 GB per
+// k_rr_fwd launch that would otherwise push the hash tables, the weight images and the neighbours' tiles out of the caches on their way to memory
+#ifndef HS_NT_FWD
+#define HS_NT_FWD 1
+#endif
+#ifndef HS_NT_BG_U
+#define HS_NT_BG_U 1
+#endif
+#ifndef HS_NT_BG_A
+#define HS_NT_BG_A 1
+#endif
+#ifndef HS_NT_BV
+#define HS_NT_BV 1
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void tp_store(uint16_t *__restrict__ T, int64_t tile, int s, int lane, const uint32_t *w4, bool ok) {
     uint4 v = ok ? make_uint4(w4[0], w4[1], w4[2], w4[3]) : make_uint4(0u, 0u, 0u, 0u);      // rows past the end hold zeros: the weight gradients sum whole tiles
-    *reinterpret_cast<uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8) = v;
+    if constexpr (NT) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t vv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8));
+    } else {
+        *reinterpret_cast<uint4 *>(T + (((size_t)tile * HS + s) * 64 + lane) * 8) = v;
+    }
 }
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
@@ -141,10 +172,11 @@ __device__ __forceinline__ void phase1r(f32x16 &cur, const uint32_t *bin, FragFn
 
 // the two TP pieces (k-steps 2 nt, 2 nt + 1) that hold tile nt's 8 words of this lane
 struct TilePair { uint4 a, b; };
+template <bool NT = false>
 __device__ __forceinline__ TilePair tp_load_tile(const uint16_t *__restrict__ T, int64_t tile, int nt, int lane) {
     TilePair r;
-    r.a = tp_load(T, tile, 2 * nt, lane);
-    r.b = tp_load(T, tile, 2 * nt + 1, lane);
+    r.a = tp_load<NT>(T, tile, 2 * nt, lane);
+    r.b = tp_load<NT>(T, tile, 2 * nt + 1, lane);
     return r;
 }
 // The loads of a phase's saved activations are `const __restrict__` and would otherwise be scheduled to the top of the tile (all 8 tiles of
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_value(const float *__re
         auto epi = [&](auto slc, const f32x16 &src, uint32_t *hp, int nd, uint16_t *T) {
             constexpr int sl = decltype(slc)::value;
             if constexpr (sl < 8) hp[8 * nd + sl] = anchor(pack2(softplus100(src[2 * sl]), softplus100(src[2 * sl + 1])));
-            else tp_store(T, tile, 2 * nd + (sl - 8), lane, hp + 8 * nd + 4 * (sl - 8), ok);
+            else tp_store<HS_NT_FWD>(T, tile, 2 * nd + (sl - 8), lane, hp + 8 * nd + 4 * (sl - 8), ok);
         };
         {
             bf16x8 w0[3][K0S];
@@ -404,9 +436,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                 u0p[8 * nd + sl] = anchor(pack2(va * sa, vb * sb));
                 wa[sl] = anchor(pack2(va * lo_bf(uwd) * (100.f * sa * (1.f - sa)), vb * hi_bf(uwd) * (100.f * sb * (1.f - sb))));
             } else if constexpr (sl < 10) {
-                tp_store(U0bt, tile, 2 * nd + (sl - 8), lane, u0p + 8 * nd + 4 * (sl - 8), ok);
+                tp_store<HS_NT_BG_U>(U0bt, tile, 2 * nd + (sl - 8), lane, u0p + 8 * nd + 4 * (sl - 8), ok);
             } else {
-                tp_store(A0pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
+                tp_store<HS_NT_BG_A>(A0pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
             }
         };
         {
@@ -420,7 +452,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                 if constexpr (nt + 2 < NT)
                     static_for<K0S>([&](auto sc) { constexpr int s = decltype(sc)::value; w0[(nt + 2) % 3][s] = W0q[(size_t)(s * NT + nt + 2) * 64]; });
                 // tile nt's saved activations are consumed by its epilogue in phase nt + 1 (buffer nt & 1; phase nt's epilogue reads the other one)
-                { const int64_t tl = here(tile); hw[nt & 1] = tp_load_tile(H0t, tl, nt, lane); uw[nt & 1] = tp_load_tile(U0t, tl, nt, lane); }
+                { const int64_t tl = here(tile); hw[nt & 1] = tp_load_tile(H0t, tl, nt, lane); uw[nt & 1] = tp_load_tile<HS_NT_LOAD_LAST>(U0t, tl, nt, lane); }
                 auto f0 = [&](int s) { return w0[nt % 3][s]; };
                 if constexpr (nt == 0) phase1r<K0S, 0, K0S, 12, false, true>(acc[0], hin, f0, [](auto) {});
                 else phase1r<K0S, 0, K0S, 12, true, true>(acc[nt & 1], hin, f0, [&](auto slc) { epi0(slc, acc[(nt & 1) ^ 1], nt - 1); });
@@ -449,9 +481,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
                 wb[sl] = anchor(pack2(va * sa, vb * sb));
                 wa[sl] = anchor(pack2(va * u1.x * (100.f * sa * (1.f - sa)), vb * u1.y * (100.f * sb * (1.f - sb))));
             } else if constexpr (sl < 10) {
-                tp_store(U1bt, tile, 2 * nd + (sl - 8), lane, wb + 4 * (sl - 8), ok);
+                tp_store<HS_NT_BG_U>(U1bt, tile, 2 * nd + (sl - 8), lane, wb + 4 * (sl - 8), ok);
             } else {
-                tp_store(A1pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
+                tp_store<HS_NT_BG_A>(A1pt, tile, 2 * nd + (sl - 10), lane, wa + 4 * (sl - 10), ok);
             }
         };
         static_for<NT>([&](auto nc) {
@@ -544,7 +576,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
                     vin[4 * s + 1] = pack2(ua.z * sig_of_h(lo_bf(hw.y)), ua.w * sig_of_h(hi_bf(hw.y)));
                     vin[4 * s + 2] = pack2(ub.x * sig_of_h(lo_bf(hw.z)), ub.y * sig_of_h(hi_bf(hw.z)));
                     vin[4 * s + 3] = pack2(ub.z * sig_of_h(lo_bf(hw.w)), ub.w * sig_of_h(hi_bf(hw.w)));
-                    tp_store(V1t, tile, s, lane, vin + 4 * s, ok);
+                    tp_store<HS_NT_FWD>(V1t, tile, s, lane, vin + 4 * s, ok);
                 }
             });
         }
@@ -565,9 +597,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
                 uw8[sl] = anchor(pack2(ua, ub));
                 v0p[8 * nd + sl] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
             } else if constexpr (sl < 10) {
-                tp_store(U0t, tile, 2 * nd + (sl - 8), lane, uw8 + 4 * (sl - 8), ok);
+                tp_store<HS_NT_FWD>(U0t, tile, 2 * nd + (sl - 8), lane, uw8 + 4 * (sl - 8), ok);
             } else {
-                tp_store(V0t, tile, 2 * nd + (sl - 10), lane, v0p + 8 * nd + 4 * (sl - 10), ok);
+                tp_store<HS_NT_FWD>(V0t, tile, 2 * nd + (sl - 10), lane, v0p + 8 * nd + 4 * (sl - 10), ok);
             }
         };
         static_for<NT>([&](auto nc) {
@@ -651,7 +683,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
         auto load = [&](const uint16_t *H, const uint16_t *P, int nd) {
             const int64_t tl = here(tile);
             hw[nd & 1] = tp_load_tile(H, tl, nd, lane);
-            if constexpr (PRIME) pw[nd & 1] = tp_load_tile(P, tl, nd, lane);
+            if constexpr (PRIME) pw[nd & 1] = tp_load_tile<HS_NT_LOAD_LAST>(P, tl, nd, lane);
         };
         // a~ = a' + h~ s for the finished tile nd: next product's input and TP (weight gradient)
         auto epi = [&](auto slc, const f32x16 &src, uint32_t *ap, uint16_t *T, int nd) {
@@ -666,7 +698,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
                 }
                 ap[8 * nd + sl] = anchor(pack2(va, vb));
             } else {
-                tp_store(T, tile, 2 * nd + (sl - 8), lane, ap + 8 * nd + 4 * (sl - 8), ok);
+                tp_store<HS_NT_BV>(T, tile, 2 * nd + (sl - 8), lane, ap + 8 * nd + 4 * (sl - 8), ok);
             }
         };
         load(H1t, A1pt, 0);
@@ -903,7 +935,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                 hp[8 * nd + r] = anchor(pack2(softplus100(src[j][2 * r]), softplus100(src[j][2 * r + 1])));
             } else {
                 constexpr int ks = 4 * qd + (sl - 16);
-                tp_store(T, here(tile), ks, lane, hp + 4 * ks, ok);
+                tp_store<HS_NT_FWD>(T, here(tile), ks, lane, hp + 4 * ks, ok);
             }
         };
         // ---- layer 0 (chunk 0)
@@ -1021,7 +1053,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                 h1p[4 * s_ + 1] = pack2(ua[2] * sig_of_h(lo_bf(w1)), ua[3] * sig_of_h(hi_bf(w1)));
                 h1p[4 * s_ + 2] = pack2(ub[0] * sig_of_h(lo_bf(w2)), ub[1] * sig_of_h(hi_bf(w2)));
                 h1p[4 * s_ + 3] = pack2(ub[2] * sig_of_h(lo_bf(w3)), ub[3] * sig_of_h(hi_bf(w3)));
-                tp_store(V1t, here(tile), s_, lane, h1p + 4 * s_, ok);
+                tp_store<HS_NT_FWD>(V1t, here(tile), s_, lane, h1p + 4 * s_, ok);
             });
         }
         // ---- u0 = W1^T v1 (chunks 4, 5) in quarter phases; a finished quarter leaves as u0 (TP) and, times s0 of h0, as v0 IN PLACE of h0 (TP)
@@ -1036,9 +1068,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                 uw[w] = anchor(pack2(ua, ub));
                 h0p[8 * nd + r] = anchor(pack2(ua * sig_of_h(lo_bf(hwd)), ub * sig_of_h(hi_bf(hwd))));
             } else if constexpr (w == 4) {
-                tp_store(U0t, here(tile), 4 * qd + t, lane, uw, ok);
+                tp_store<HS_NT_FWD>(U0t, here(tile), 4 * qd + t, lane, uw, ok);
             } else {
-                tp_store(V0t, here(tile), 4 * qd + t, lane, h0p + 4 * (4 * qd + t), ok);
+                tp_store<HS_NT_FWD>(V0t, here(tile), 4 * qd + t, lane, h0p + 4 * (4 * qd + t), ok);
             }
         };
         {

@@ -270,7 +270,16 @@ __device__ __forceinline__ void request_piece(const char *__restrict__ src, int 
     // first fragment read of a stage): the stages would land one after the other with nothing overlapped.  This way the landing is tracked
     // by wait_vm() alone; the compiler's own vector-memory waits only become more conservative (the counter retires in issue order).
     const uint32_t to_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)to);
+    // `nt`: the operands are at their LAST read (1 GB per iteration that would otherwise sweep the hash tables and the weight images out of the
+    // caches: bench median -15 us in four alternating pairs; -DHS_WGP_NT_LOADS=0 for A/B)
+#ifndef HS_WGP_NT_LOADS
+#define HS_WGP_NT_LOADS 1
+#endif
+#if HS_WGP_NT_LOADS
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(to_lds), "v"(from) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(to_lds), "v"(from) : "memory");
+#endif
 }
 
 #define HS_WAIT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
