@@ -32,6 +32,13 @@
 
 namespace {
 
+// experiments (tools/ab_lib.sh): the gathers' outputs as non-temporal stores
+#ifndef HS_NT_GATHER_OUT
+#define HS_NT_GATHER_OUT 0
+#endif
+#ifndef HS_NT_GATHER_DYDX
+#define HS_NT_GATHER_DYDX 0
+#endif
 constexpr int kThreads = 256;
 #ifndef HS_HASH_FWD_THREADS
 #define HS_HASH_FWD_THREADS 256
@@ -307,7 +314,13 @@ __global__ __launch_bounds__(kFwdThreads) void k_hash_fwd_pair(const float *__re
                 typedef float f2_t __attribute__((ext_vector_type(2)));
                 typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
                 const f2_t v = {acc[0], acc[1]};
-                *reinterpret_cast<uint32_t *>(o) = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+                // (NT: the words go to ANOTHER XCD's sweep workgroup through memory in any case; kept out of this XCD's L2 they leave its two levels' lines there)
+                if (HS_NT_GATHER_OUT) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t)), reinterpret_cast<uint32_t *>(o));
+                else *reinterpret_cast<uint32_t *>(o) = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+            } else if (HS_NT_GATHER_DYDX && DYDX) {
+                typedef float f2nt_t __attribute__((ext_vector_type(2)));
+                const f2nt_t vv = {acc[0], acc[1]};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f2nt_t *>(o));
             } else {
                 *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
             }
@@ -353,7 +366,10 @@ __global__ __launch_bounds__(kFwdThreads) void k_hash_fwd_pair(const float *__re
 #pragma unroll
             for (int gd = 0; gd < D; gd++)
 #pragma unroll
-                for (int c = 0; c < C; c++) jo[gd * C + c] = ga[gd][c];
+                for (int c = 0; c < C; c++) {
+                    if (HS_NT_GATHER_DYDX) __builtin_nontemporal_store(ga[gd][c], jo + gd * C + c);
+                    else jo[gd * C + c] = ga[gd][c];
+                }
         }
     }
 }

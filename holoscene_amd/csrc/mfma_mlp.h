@@ -217,6 +217,9 @@ __device__ __forceinline__ void store_tile_regs(uint16_t *H, const TileRegs &t) 
 }
 
 
+#ifndef HS_NT_TILE_STORE
+#define HS_NT_TILE_STORE 0
+#endif
 // activation tile -> global, 16 B per lane, rows contiguous (coalesced 512 B per row)
 __device__ __forceinline__ void store_tile(const uint16_t *H, uint16_t *__restrict__ dst, int64_t r0, int64_t M) {
 #ifdef HS_EXP_NO_STORE
@@ -224,7 +227,14 @@ __device__ __forceinline__ void store_tile(const uint16_t *H, uint16_t *__restri
 #endif
     for (int idx = threadIdx.x; idx < BM * (HID / 8); idx += kThreads) {
         const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
-        if (r0 + row < M) *reinterpret_cast<uint4 *>(dst + (size_t)(r0 + row) * HID + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+        if (r0 + row < M) {
+#if HS_NT_TILE_STORE       // non-temporal: the tile's reader is another kernel, far away
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t *>(H + (size_t)row * HP + seg * 8), reinterpret_cast<u32x4_t *>(dst + (size_t)(r0 + row) * HID + seg * 8));
+#else
+            *reinterpret_cast<uint4 *>(dst + (size_t)(r0 + row) * HID + seg * 8) = *reinterpret_cast<const uint4 *>(H + (size_t)row * HP + seg * 8);
+#endif
+        }
     }
 }
 

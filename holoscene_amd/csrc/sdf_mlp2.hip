@@ -118,7 +118,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                                              // the words ARE this lane's feature inputs (levels 8 h .. 8 h + 7), no conversion
                 const uint32_t *fl = reinterpret_cast<const uint32_t *>(feat) + (size_t)(8 * h) * B + (ok ? gp : 0);
 #pragma unroll
-                for (int i = 0; i < 8; i++) fw[i] = ok ? fl[(size_t)i * B] : 0u;
+#ifndef HS_NT_SDF_IN
+#define HS_NT_SDF_IN 0
+#endif
+                for (int i = 0; i < 8; i++) fw[i] = ok ? (HS_NT_SDF_IN ? __builtin_nontemporal_load(fl + (size_t)i * B) : fl[(size_t)i * B]) : 0u;      // (NT: the words' only read)
 #pragma unroll
                 for (int j = 18; j < 34; j++) v[j] = 0.f;
             } else if (feat_level_major) {      // feat [16, B, 2]

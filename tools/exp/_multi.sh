@@ -1,2 +1,2 @@
-for v in wnt lnt wnt lnt; do bash tools/ab_lib.sh $v 2; done
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
+bash tools/ab_lib.sh tnt 2 --objects 64
+bash tools/ab_lib.sh tnt 2
