@@ -156,7 +156,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -394,6 +394,33 @@ class _HipBackend:
                                 ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"), _dev(grad_grad_inputs, "grad_grad_inputs"),
                                 _dev(grad_grad, "grad_grad"), _dev(grad2_embeddings, "grad2_embeddings"), ctypes.byref(lay),
                                 _stream()), "hs_hash_bwd2")
+
+    # ---- the reference's three entry points in its other scalar types (include/holoscene_hip.h: *_dt; csrc/hash_encode_dt.hip).  Reference layouts:
+    # outputs / grad [L, B, C], dy_dx [B, L * D * C]; every tensor of the inputs' dtype (torch.float64 / float16; float32 forwards to the functions above)
+    DTYPES = {torch.float32: 0, torch.float64: 1, torch.float16: 2}
+
+    @classmethod
+    def encode_forward_dt(cls, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx=None):
+        lib, dt = load_library(), inputs.dtype
+        _check(lib.hs_hash_encode_forward_dt(cls.DTYPES[dt], _dev(inputs, "inputs", dt), _dev(embeddings, "embeddings", dt), _dev(offsets, "offsets", torch.int32),
+                                             _dev(outputs, "outputs", dt), B, D, C, L, ctypes.c_float(S), H, int(dy_dx is not None), _dev(dy_dx, "dy_dx", dt),
+                                             _stream()), "hs_hash_encode_forward_dt")
+
+    @classmethod
+    def encode_backward_dt(cls, grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx=None, grad_inputs=None):
+        lib, dt = load_library(), inputs.dtype
+        _check(lib.hs_hash_encode_backward_dt(cls.DTYPES[dt], _dev(grad, "grad", dt), _dev(inputs, "inputs", dt), _dev(embeddings, "embeddings", dt),
+                                              _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings", dt), B, D, C, L, ctypes.c_float(S), H,
+                                              int(grad_inputs is not None), _dev(dy_dx, "dy_dx", dt), _dev(grad_inputs, "grad_inputs", dt), _stream()),
+               "hs_hash_encode_backward_dt")
+
+    @classmethod
+    def encode_second_backward_dt(cls, grad, inputs, embeddings, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings):
+        lib, dt = load_library(), inputs.dtype
+        _check(lib.hs_hash_encode_second_backward_dt(cls.DTYPES[dt], _dev(grad, "grad", dt), _dev(inputs, "inputs", dt), _dev(embeddings, "embeddings", dt),
+                                                     _dev(offsets, "offsets", torch.int32), B, D, C, L, ctypes.c_float(S), H, 1, _dev(dy_dx, "dy_dx", dt),
+                                                     _dev(grad_grad_inputs, "grad_grad_inputs", dt), _dev(grad_grad, "grad_grad", dt),
+                                                     _dev(grad2_embeddings, "grad2_embeddings", dt), _stream()), "hs_hash_encode_second_backward_dt")
 
     @classmethod
     def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None, rank1=None):

@@ -89,7 +89,62 @@ class _hash_encode_backward(Function):
         return grad_grad, None, grad2_embeddings, None, None, None, None, None
 
 
-hash_encode = _hash_encode.apply
+class _hash_encode_dt(Function):
+    """The reference's Function (hashgrid.py:14-101) for its OTHER scalar types -- double (a gradcheck) and half (a caller under autocast: the
+    reference casts its inputs with custom_fwd(cast_inputs=torch.half)) -- on the *_dt entry points (csrc/hash_encode_dt.hip): the reference's
+    layouts and its order of operations, nothing of the float path's machinery.  inputs and embeddings share the dtype."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+        inputs, embeddings, offsets = inputs.contiguous(), embeddings.contiguous(), offsets.contiguous()
+        B, D = inputs.shape
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        S, H = float(np.log2(per_level_scale)), int(base_resolution)
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=inputs.dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=inputs.dtype) if calc_grad_inputs else None
+        _be._backend.encode_forward_dt(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H)
+        return outputs.permute(1, 0, 2).reshape(B, L * C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        gx, ge = _hash_encode_dt_backward.apply(grad, inputs, embeddings, offsets, dy_dx, ctx.dims)
+        return (gx if dy_dx is not None else None), ge, None, None, None, None
+
+
+class _hash_encode_dt_backward(Function):
+    @staticmethod
+    def forward(ctx, grad, inputs, embeddings, offsets, dy_dx, dims):
+        B, D, C, L, S, H = dims
+        grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
+        grad_embeddings = torch.zeros_like(embeddings)
+        _be._backend.encode_backward_dt(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs)
+        ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
+        ctx.dims = dims
+        return grad_inputs, grad_embeddings
+
+    @staticmethod
+    def backward(ctx, grad_grad_inputs, _grad_grad_embeddings):
+        grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        if grad_grad_inputs is None or dy_dx is None:
+            return None, None, None, None, None, None
+        grad_grad, grad2_embeddings = torch.empty_like(grad), torch.zeros_like(embeddings)
+        _be._backend.encode_second_backward_dt(grad, inputs, embeddings, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs.contiguous().to(grad.dtype),
+                                               grad_grad, grad2_embeddings)
+        return grad_grad, None, grad2_embeddings, None, None, None       # (no gradient for the inputs: hashgrid.py:101)
+
+
+def hash_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+    """float32: the path everything in this package is built around; float64 / float16 (inputs and table alike): the plain kernels of the
+    reference's other instantiations."""
+    if inputs.dtype in (torch.float64, torch.float16) and inputs.is_cuda:
+        return _hash_encode_dt.apply(inputs, embeddings.to(inputs.dtype), offsets, per_level_scale, base_resolution, calc_grad_inputs)
+    return _hash_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs)
 
 
 def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size):

@@ -77,6 +77,22 @@ int hs_hash_encode_second_backward(const float *grad, const float *inputs, const
                                    const float *dy_dx, const float *grad_grad_inputs, float *grad_grad, float *grad2_embeddings,
                                    void *stream);
 
+/* The same three entry points for the reference's other scalar types (AT_DISPATCH_FLOATING_TYPES_AND_HALF: hashencoder.cu:747, 778, 817 -- the
+ * tensors' dtype selects the instantiation there; here `dtype` does).  HS_DTYPE_F32 forwards to the functions above; F64 / F16 run plain
+ * kernels in the reference's order of operations under C++'s promotions and at::Half's operators (csrc/hash_encode_dt.hip): bit-identical to
+ * oracle/hash_oracle_dt.c except for the order of the scatters' atomics.  Layouts as above (outputs [L,B,C], dy_dx [B, L*D*C]), every tensor of `dtype`. */
+#define HS_DTYPE_F32 0
+#define HS_DTYPE_F64 1
+#define HS_DTYPE_F16 2
+int hs_hash_encode_forward_dt(int32_t dtype, const void *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void *dy_dx, void *stream);
+int hs_hash_encode_backward_dt(int32_t dtype, const void *grad, const void *inputs, const void *embeddings, const int32_t *offsets,
+                               void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                               const void *dy_dx, void *grad_inputs, void *stream);
+int hs_hash_encode_second_backward_dt(int32_t dtype, const void *grad, const void *inputs, const void *embeddings, const int32_t *offsets,
+                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void *dy_dx,
+                                      const void *grad_grad_inputs, void *grad_grad, void *grad2_embeddings, void *stream);
+
 /* ------------------------------------------------------------------ 2. strided / selective variants
  *
  * Same arithmetic, but (a) feature-like tensors are addressed as

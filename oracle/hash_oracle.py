@@ -29,8 +29,8 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libhash_oracle.so")
-        src = os.path.join(_HERE, "hash_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [os.path.join(_HERE, n) for n in ("hash_oracle.c", "hash_oracle_dt.c", "hash_oracle_dt_impl.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
             build()
         _LIB = ctypes.CDLL(so)
         for name in ("hs_oracle_hash_fwd", "hs_oracle_hash_bwd", "hs_oracle_hash_bwd2", "hs_oracle_level_table"):
@@ -41,6 +41,42 @@ def lib():
 def _p(t):
     assert t.is_contiguous() and t.device.type == "cpu"
     return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- the reference's other scalar types (oracle/hash_oracle_dt.c): torch.float64 / torch.float16 tensors, reference layouts
+# (outputs [L, B, C], dy_dx [B, L * D * C], grad [L, B, C])
+def _sfx(t):
+    return {torch.float64: "_f64", torch.float16: "_f16"}[t.dtype]
+
+
+def fwd_dt(x, emb, offsets, S, H, calc_dydx):
+    B, D = x.shape
+    C, L = emb.shape[1], offsets.shape[0] - 1
+    out = torch.empty(L, B, C, dtype=x.dtype)
+    dydx = torch.empty(B, L * D * C, dtype=x.dtype) if calc_dydx else None
+    rc = getattr(lib(), "hs_oracle_dt_fwd" + _sfx(x))(_p(x), _p(emb), _p(offsets), _p(out), B, D, C, L, ctypes.c_float(S), int(H), _p(dydx) if calc_dydx else None)
+    assert rc == 0
+    return out, dydx
+
+
+def bwd_dt(grad, x, emb, offsets, S, H, dydx=None, want_gx=False):
+    B, D = x.shape
+    C, L = emb.shape[1], offsets.shape[0] - 1
+    gemb = torch.zeros_like(emb)
+    gx = torch.empty_like(x) if want_gx else None
+    rc = getattr(lib(), "hs_oracle_dt_bwd" + _sfx(x))(_p(grad), _p(x), _p(offsets), _p(gemb), B, D, C, L, ctypes.c_float(S), int(H),
+                                                      _p(dydx) if want_gx else None, _p(gx) if want_gx else None)
+    assert rc == 0
+    return gemb, gx
+
+
+def bwd2_dt(grad, x, emb, offsets, S, H, dydx, ggx):
+    B, D = x.shape
+    C, L = emb.shape[1], offsets.shape[0] - 1
+    gg, g2 = torch.empty_like(grad), torch.zeros_like(emb)
+    rc = getattr(lib(), "hs_oracle_dt_bwd2" + _sfx(x))(_p(grad), _p(x), _p(offsets), B, D, C, L, ctypes.c_float(S), int(H), _p(dydx), _p(ggx), _p(gg), _p(g2))
+    assert rc == 0
+    return gg, g2
 
 
 def level_offsets(num_levels, base_resolution, per_level_scale, log2_hashmap_size, input_dim=3):
