@@ -32,6 +32,13 @@
 
 namespace {
 
+// experiments (tools/ab_lib.sh): dynamic LDS nobody uses = fewer resident workgroups (occupancy / bytes in flight per compute unit)
+#ifndef HS_BIN_LDS_EXTRA
+#define HS_BIN_LDS_EXTRA 0
+#endif
+#ifndef HS_FWD_LDS_PAD
+#define HS_FWD_LDS_PAD 0
+#endif
 // experiments (tools/ab_lib.sh): the gathers' outputs as non-temporal stores
 #ifndef HS_NT_GATHER_OUT
 #define HS_NT_GATHER_OUT 0
@@ -756,7 +763,7 @@ void launch_bin_reduce(float *grad_embeddings, const int32_t *offsets, uint32_t 
     if (lay.step) {
         hsHashLayout dev = lay;
         dev.step = nullptr;              // (a host pointer: the kernel receives the structure by value)
-        k_hash_bin_step<D, C><<<dim3(kBins, L), dim3(kBinThreads), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, dev, *lay.step);
+        k_hash_bin_step<D, C><<<dim3(kBins, L), dim3(kBinThreads), kReduceLds + HS_BIN_LDS_EXTRA, st>>>(grad_embeddings, offsets, L, sc, dev, *lay.step);
     } else if (lay.scatter_ws) {
         k_hash_bin_reduce<D, C><<<dim3(kBins, L), dim3(kBinThreads), kReduceLds, st>>>(grad_embeddings, offsets, L, sc, lay);
     }
@@ -1058,9 +1065,9 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
         if (D_ == 3 && pair_forward()) {
             const uint32_t n_chunks2 = (2 * B + kFwdThreads - 1) / kFwdThreads;      // two lanes per point
             if (dy_dx)
-                k_hash_fwd_pair<C_, true><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks2);
+                k_hash_fwd_pair<C_, true><<<dim3(n_chunks2 * L), block, HS_FWD_LDS_PAD, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks2);
             else
-                k_hash_fwd_pair<C_, false><<<dim3(n_chunks2 * L), block, 0, st>>>(inputs, embeddings, offsets, outputs, nullptr, B, L, sc, lay, n_chunks2);
+                k_hash_fwd_pair<C_, false><<<dim3(n_chunks2 * L), block, HS_FWD_LDS_PAD, st>>>(inputs, embeddings, offsets, outputs, nullptr, B, L, sc, lay, n_chunks2);
         } else if (dy_dx)
             k_hash_fwd<D_, C_, true><<<grid, block, 0, st>>>(inputs, embeddings, offsets, outputs, dy_dx, B, L, sc, lay, n_chunks);
         else
