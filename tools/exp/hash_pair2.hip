@@ -105,6 +105,39 @@ __global__ __launch_bounds__(256) void kE(const float *__restrict__ x, const flo
     (void)b;
 }
 
+
+// ---- V: ONE pass over the points for TWO tables of the same geometry (the geometry table's and the colour table's gathers of the rendered
+// samples share positions, cells and weights): locate and index once, eight gathers per lane
+__global__ __launch_bounds__(256) void kV(const float *__restrict__ x, const float2 *__restrict__ embA, const float2 *__restrict__ embB, unsigned *__restrict__ outA,
+                                          unsigned *__restrict__ outB, unsigned B, Lvs ls, unsigned n_chunks) {
+    const unsigned bid = blockIdx.x, xcd = bid & 7u, j = bid >> 3, slot = j / n_chunks, chunk = j - slot * n_chunks;
+    const unsigned level = (slot & 1u) ? (slot * 8u + 7u - xcd) : (slot * 8u + xcd);
+    const unsigned t = chunk * 256 + threadIdx.x, b = t >> 1, xb = t & 1u;
+    if (b >= B) return;
+    const Lv l = ls.v[level];
+    float w[3]; unsigned c[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { float p = x[b * 3 + d] * l.scale; float f = floorf(p); c[d] = (unsigned)f; w[d] = sstep(p - f); }
+    float2 ea[4], eb[4];
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) {
+        const unsigned ci = l.offset + cell(l, c[0] + xb, c[1] + (yz & 1), c[2] + (yz >> 1));
+        ea[yz] = embA[ci];
+        eb[yz] = embB[ci];
+    }
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int yz = 0; yz < 4; yz++) {
+        const float wt = (xb ? w[0] : 1 - w[0]) * ((yz & 1) ? w[1] : 1 - w[1]) * ((yz >> 1) ? w[2] : 1 - w[2]);
+        float p;
+        p = wt * ea[yz].x; a0 += p; a0 += dpp_swap(p);
+        p = wt * ea[yz].y; a1 += p; a1 += dpp_swap(p);
+        p = wt * eb[yz].x; b0 += p; b0 += dpp_swap(p);
+        p = wt * eb[yz].y; b1 += p; b1 += dpp_swap(p);
+    }
+    if (xb == 0) { outA[(size_t)level * B + b] = pack_bf16(a0, a1); outB[(size_t)level * B + b] = pack_bf16(b0, b1); }
+}
+
 // ---- B / C: two levels per wave.  WORDS: the table is uint32 (bf16 pair) per entry
 template <bool WORDS>
 __global__ __launch_bounds__(256) void kB(const float *__restrict__ x, const void *__restrict__ embv, unsigned *__restrict__ out, unsigned B, Lvs ls,
@@ -222,6 +255,10 @@ int main() {
         run(nm, [&] { kA<false><<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks, m); });
     }
     run("E half-wave loads / store", [&] { kE<<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks); });
+    float2 *de2; unsigned *dout2; hipMalloc(&de2, he.size() * 4); hipMalloc(&dout2, (size_t)16 * B * 4);
+    hipMemcpy(de2, he.data(), he.size() * 4, hipMemcpyHostToDevice);
+    run("A twice (two tables, two launches)", [&] { kA<false><<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks); kA<false><<<n_chunks * 16, 256>>>(dx, de2, dout2, B, ls, n_chunks); });
+    run("V two tables, one pass", [&] { kV<<<n_chunks * 16, 256>>>(dx, de, de2, dout, dout2, B, ls, n_chunks); });
     run("A again", [&] { kA<false><<<n_chunks * 16, 256>>>(dx, de, dout, B, ls, n_chunks); });
     return 0;
 }
