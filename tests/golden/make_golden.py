@@ -137,6 +137,9 @@ class DrawLog:
 # fixture stays small: those are the shapes the fused matrix-core kernels of the product are built for.
 SHAPES = {"tiny": dict(L=4, base=4, end=32, logmap=10, width=64, feat=32),
           "stock": dict(L=16, base=16, end=2048, logmap=12, width=256, feat=256),
+          # the stock layer shapes over a grid of EIGHT levels (BASELINE configs[0]'s grid): on the product's side this runs the fused 16-level
+          # kernels through empty levels and zero weight columns (hashgrid.py: fused_offsets, network.py: fused_cols)
+          "stock_l8": dict(L=8, base=16, end=256, logmap=12, width=256, feat=256),
           # BASELINE configs[1] as it is benchmarked: the full 2^19-entry tables (48.8 MB each).  A fixture of this shape stores its tables
           # as seeds (+ digest) and every table-sized result as a digest: strided row sample + per-level sums (helpers.table_digest)
           "full": dict(L=16, base=16, end=2048, logmap=19, width=256, feat=256)}
@@ -841,6 +844,11 @@ def main():
                       shape="stock", distinct=True)
     # K > 32 (the reference sizes d_out by the scene: holoscene_train.py:119-122; confs/custom/siebelgame ships d_out = 64): the fused path's
     # two-output-tile kernels
+    # (K = 3: with many objects on so coarse a grid the bf16 arg-min flips at object boundaries dominate the per-tensor gradient comparison -- a
+    #  K = 21 fixture of this shape agreed in every per-sample quantity and every loss term to 0.3 % and missed the 3 % gradient bound by the flips)
+    if sel("stock_l8_k3_bg"):
+        run_iteration(Net, Loss, "stock_l8_k3_bg", K=3, S=16, R=32, beta=0.02, eye=(0.7, 0.0, 0.1), iter_step=0, call_reg=True, seed=190,
+                      shape="stock_l8", distinct=True)
     if sel("stock_k40"):
         run_iteration(Net, Loss, "stock_k40", K=40, S=32, R=32, beta=0.05, eye=(0.7, 0.0, 0.1), iter_step=3, call_reg=False, seed=160,
                       shape="stock", distinct=True)

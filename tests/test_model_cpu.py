@@ -32,7 +32,7 @@ def test_sampler(name):
     assert z_eik.shape == rec["out.z_samples_eik"].shape
 
 
-@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21", "stock_k40", "stock_k64_bg"])
+@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21", "stock_k40", "stock_k64_bg", "stock_l8_k3_bg"])
 def test_iteration(name):
     rec = load(name)
     model = build_model(rec)

@@ -138,7 +138,7 @@ def test_network_methods_match_reference(name):
     close(o.occlusion_opacity(T, dists, vin["raw"]), rec["vr.out.occlusion"], 1e-5, 1e-7, "occlusion")
 
 
-@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21", "stock_k40", "stock_k64_bg"])
+@pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21", "stock_k40", "stock_k64_bg", "stock_l8_k3_bg"])
 def test_iteration_matches_reference(name):
     rec = load(name)
     sd = section(rec, "state.")
