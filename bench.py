@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--rays", type=int, default=1024)
     p.add_argument("--samples", type=int, default=128)
     p.add_argument("--objects", type=int, default=32)
+    p.add_argument("--levels", type=int, default=16, help="hash-grid levels (BASELINE configs[0]: 8; fewer than 16 run the fused kernels through empty levels)")
+    p.add_argument("--end-size", type=int, default=2048, help="finest grid resolution (configs[0]: 256)")
+    p.add_argument("--logmap", type=int, default=19, help="log2 of the per-level table size (configs[0]: 15)")
     p.add_argument("--beta", type=float, default=0.001)
     p.add_argument("--lr-scale", type=float, default=1e-6,
                    help="learning-rate multiplier.  The synthetic targets are noise, and at the reference's rates (grid lr 1e-2 per step on "
@@ -426,7 +429,7 @@ def trajectory_point(args, dev, steps=300):
     fraction of exactly-zero cotangents (which the scatter kernels skip) move as the surfaces form."""
     from holoscene_amd.training.synthetic import SyntheticScene
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
-    mk = lambda prec: stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=0.1, mlp_precision=prec, learning_rate=5.0e-4)  # noqa: E731
+    mk = lambda prec: stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=0.1, mlp_precision=prec, learning_rate=5.0e-4)  # noqa: E731
     teacher = Stage1Trainer(mk("bf16"), device=dev, optimizer="torch", seed=7)
     benchmark_model_state(teacher.model, 0.02, seed=7)
     g = torch.Generator().manual_seed(99)
@@ -495,7 +498,7 @@ def main():
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
     from holoscene_amd.training import distributed as dist_util
 
-    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision=args.precision,
+    conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=args.beta, mlp_precision=args.precision,
                       learning_rate=5.0e-4 * args.lr_scale, eikonal_mode=args.eikonal)
     tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
                        graph=(not args.no_graph) and args.optimizer == "flat")
@@ -716,7 +719,7 @@ def main():
     second = None
     if not args.no_second_point:
         del tr
-        conf2 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=0.1, mlp_precision=args.precision,
+        conf2 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=0.1, mlp_precision=args.precision,
                            learning_rate=5.0e-4 * args.lr_scale)
         tr2 = Stage1Trainer(conf2, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
                             graph=(not args.no_graph) and args.optimizer == "flat")
@@ -758,7 +761,7 @@ def main():
     fp32_point = None
     if not args.no_fp32_point and args.precision == "bf16" and world == 1:
         # the reference's own precision, same workload, reported beside the headline
-        conf3 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, beta=args.beta, mlp_precision="fp32",
+        conf3 = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=args.beta, mlp_precision="fp32",
                            learning_rate=5.0e-4 * args.lr_scale)
         tr3 = Stage1Trainer(conf3, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
                             graph=(not args.no_graph) and args.optimizer == "flat")
@@ -779,12 +782,14 @@ def main():
         trajectory = trajectory_point(args, dev)
     if rank == 0:
         line = {
-            "metric": "training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1", "value": round(value, 1), "unit": "rays/s",
+            "metric": ("training rays/s at 1 024 rays x 128 samples, Replica room_0 Stage-1" if (args.rays, args.samples) == (1024, 128)
+                       else f"training rays/s at {args.rays} rays x {args.samples} samples, Stage-1 iteration"), "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "ms_per_step_median": round(median_ms, 3), "iteration_kinds": iteration_kinds, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: Replica room_0 Stage-1 shape, {args.rays} rays x {args.samples} samples "
-                                   f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L=16 hash grid T=2^19 16->2048, "
+            "config": {"workload": ("BASELINE configs[1]: Replica room_0 Stage-1 shape" if (args.levels, args.end_size, args.logmap) == (16, 2048, 19)
+                                    else "Stage-1 iteration, non-stock grid") + f", {args.rays} rays x {args.samples} samples "
+                                   f"({args.samples // 2 + args.samples // 4 + 2} rendered pts/ray), K={args.objects}, L={args.levels} hash grid T=2^{args.logmap} 16->{args.end_size}, "
                                    f"full iteration (pixel-batch gather from HBM-resident frames+sampler+render+eikonal+loss+backward+Adam; every 10th "
                                    f"iteration also the 32x32 background-patch pass, render_bg_iter=10), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)"
