@@ -22,6 +22,7 @@ import torch
 
 from ..hashencoder import backend as _be
 from .density import laplace_density
+from ..utils import rend_util as _rend_util
 
 # "hip": fused per-ray kernels (csrc/sampler.hip) -- the product path; raises without CUDA tensors / the library.
 # "torch": the pre-fusion whole-tensor formulation below, kept for A/B timing and for exercising the host
@@ -156,8 +157,8 @@ class ErrorBoundSampler(RaySampler):
         self.add_tiny = add_tiny
         self.cpu_rng = cpu_rng
         self.inverse_sphere_bg = inverse_sphere_bg
-        if inverse_sphere_bg:
-            raise NotImplementedError("inverse_sphere_bg is not used by any Stage-1 config (confs/*: absent) and is not built")
+        if inverse_sphere_bg:     # ray_sampler.py:127-128 (no conf of the reference sets it; kept for the constructor's full argument list)
+            self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, N_samples_inverse_sphere, False, far=1.0, cpu_rng=cpu_rng)
         self._rounds = 0       # realised Algorithm-1 rounds of the latest call: an int, or a 1-element device tensor
         self._ctl_init = None
 
@@ -190,13 +191,27 @@ class ErrorBoundSampler(RaySampler):
         """z0 / beta_init (/ x0 = positions (x, x01) of z0): optionally the first uniform depths and Lemma-2 beta already produced
         by the fused ray-setup kernel (HoloSceneNetwork._setup_rays_fused); otherwise they are computed here as in the reference.
         beta_work: a copy of beta_init this call may overwrite (its per-ray beta state), saving the clone."""
+        rng = rng or {}
+        bounds = None
+        if self.inverse_sphere_bg:
+            # ray_sampler.py:262-265: the far sample appended at the end is each ray's exit from the bounding sphere (the near one stays
+            # self.near) -- the per-ray bounds the near/far entry point already hands to the final kernels
+            far = _rend_util.get_sphere_intersections(cam_loc, ray_dirs, r=self.scene_bounding_sphere)[:, 1]
+            bounds = (torch.full_like(far, float(self.near)), far.contiguous().float())
         if SAMPLER_IMPL == "hip":
             if ray_dirs.is_cuda and self.device_control_ok(model, idx):
-                return self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init, x0, beta_work=beta_work)
-            return self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng or {}, z0, beta_init)
-        if SAMPLER_IMPL != "torch":
+                out = self._get_z_vals_device(ray_dirs, cam_loc, model, idx, rng, z0, beta_init, x0, bounds=bounds, beta_work=beta_work)
+            else:
+                out = self._get_z_vals_hip(ray_dirs, cam_loc, model, idx, rng, z0, beta_init, bounds=bounds)
+        elif SAMPLER_IMPL == "torch":
+            out = self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng, bounds=bounds)
+        else:
             raise RuntimeError(f"unknown HOLOSCENE_SAMPLER_IMPL={SAMPLER_IMPL!r}")
-        return self._get_z_vals_torch(ray_dirs, cam_loc, model, idx, rng or {})
+        if self.inverse_sphere_bg:
+            # ray_sampler.py:282-285: uniform depths in (0, 1) of the inverted-sphere parametrisation, returned beside the foreground's
+            z_inv, _, _ = self.inverse_sphere_sampler.get_z_vals(ray_dirs, cam_loc, model, t_rand=rng.get("t_rand_inverse"))
+            return (out[0], z_inv * (1.0 / self.scene_bounding_sphere)), out[1]
+        return out
 
     @torch.no_grad()
     def get_z_vals_near_far(self, ray_dirs, cam_loc, model, near, far, idx=None, rng=None):

@@ -58,3 +58,15 @@ def get_camera_params(uv, pose, intrinsics, ray_offset=None):
     world = torch.bmm(p, pts).permute(0, 2, 1)
     world = world[..., :3] / world[..., 3:4]
     return F.normalize(world - cam_loc[:, None, :], dim=2), cam_loc
+
+
+def get_sphere_intersections(cam_loc, ray_directions, r=1.0):
+    """Depths [n, 2] (entry, exit; clamped at 0) at which rays from cam_loc [n, 3] along unit ray_directions [n, 3] cross the sphere of
+    radius r about the origin (utils/rend_util.py:169-185 of the reference).  The reference prints 'BOUNDING SPHERE PROBLEM!' and
+    exits the process when a ray misses the sphere; here that is a RuntimeError with the same words."""
+    ray_cam_dot = (ray_directions.reshape(-1, 3) * cam_loc.reshape(-1, 3)).sum(-1, keepdim=True)
+    under_sqrt = ray_cam_dot ** 2 - (cam_loc.reshape(-1, 3).norm(2, 1, keepdim=True) ** 2 - r ** 2)
+    if bool((under_sqrt <= 0).any()):
+        raise RuntimeError("BOUNDING SPHERE PROBLEM!")
+    signs = torch.tensor([-1.0, 1.0], device=cam_loc.device)
+    return (torch.sqrt(under_sqrt) * signs - ray_cam_dot).clamp_min(0.0)

@@ -323,7 +323,7 @@ def run_iteration(Net, Loss, name, *, K, S, R, beta, eye, iter_step, call_reg, s
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  loss={float(lo['loss']):.6f}  N={out['z_vals'].shape[1]}  rounds={rec['meta.rounds']}")
 
 
-def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shape="tiny", pert_scale=1e-3, emb_scale=1e-3, distinct=False):
+def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shape="tiny", pert_scale=1e-3, emb_scale=1e-3, distinct=False, inverse=0):
     torch.manual_seed(seed)
     conf = small_conf(K, S, beta, **SHAPES[shape])
     model = Net(conf=conf, graph_node_dict=None, num_images=4)
@@ -350,6 +350,10 @@ def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shap
     # the merged sample set and its SDF values, d* (Theorem 1), the error bound at beta0, beta after the line search.  Taken by
     # observing the arguments of get_error_bound (:182-188, 1 + beta_iters calls per round) and of the density call that follows the
     # search (:193); the reference's source is not touched.
+    if inverse:     # the constructor's inverse_sphere_bg branch (ray_sampler.py:127-128, 264-265, 282-285); no conf of the reference sets it
+        from model.ray_sampler import ErrorBoundSampler
+        model.ray_sampler = ErrorBoundSampler(1.0, near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10,
+                                              max_total_iters=5, inverse_sphere_bg=True, N_samples_inverse_sphere=inverse)
     sm = model.ray_sampler
     rounds_log = []
     orig_eb, orig_dens = sm.get_error_bound, model.density.forward
@@ -382,6 +386,11 @@ def run_sampler(Net, name, *, K, S, R, beta, eye, seed, train=True, res=64, shap
         to_np("state.", model.state_dict(), rec)
     to_np("in.", dict(ray_dirs=d, cam_loc=o), rec)
     names = ["t_rand", "u_final", "perm", "eik_idx"] if train else ["eik_idx"]
+    if inverse:
+        names += ["t_rand_inverse"] if train else []
+        z, z_inv = z
+        rec["meta.inverse"] = inverse
+        rec["out.z_vals_inverse_sphere"] = z_inv.numpy().copy()
     assert len(log.draws) == len(names), [k for k, _ in log.draws]
     for n, (_, v) in zip(names, log.draws):
         rec[f"rand.{n}"] = v.numpy()
@@ -828,6 +837,9 @@ def main():
     for i, (S, beta, eye) in enumerate(cases):
         if sel(f"sampler_{i}"):
             run_sampler(Net, f"sampler_{i}", K=2, S=S, R=24, beta=beta, eye=eye, seed=1)
+    if sel("sampler_inv"):     # sampler_2's scene (3 rounds) through the inverse_sphere_bg branch
+        S, beta, eye = cases[2]
+        run_sampler(Net, "sampler_inv", K=2, S=S, R=24, beta=beta, eye=eye, seed=1, inverse=16)
     if sel("sampler_eval"):
         run_sampler(Net, "sampler_eval", K=2, S=32, R=24, beta=0.1, eye=(0, 0, 0.6), seed=1, train=False)
     if sel("steps3_k3"):

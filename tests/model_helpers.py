@@ -17,6 +17,8 @@ def conf_from_meta(rec, **over):
                                multires_normal=4),
         density=dict(params_init=dict(beta=beta), beta_min=0.0001),
         ray_sampler=dict(near=0.0, N_samples=S // 2, N_samples_eval=S, N_samples_extra=S // 4, eps=0.1, beta_iters=10, max_total_iters=5))
+    if m.get("inverse"):     # sampler_inv: the constructor's inverse_sphere_bg branch
+        c["ray_sampler"].update(inverse_sphere_bg=True, N_samples_inverse_sphere=m["inverse"])
     c.update(over)
     return c
 

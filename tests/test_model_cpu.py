@@ -32,6 +32,27 @@ def test_sampler(name):
     assert z_eik.shape == rec["out.z_samples_eik"].shape
 
 
+def test_sampler_inverse_sphere_branch():
+    """inverse_sphere_bg=True (ray_sampler.py:127-128, 262-265, 282-285; set by no conf of the reference): the far sample appended to the
+    final set is each ray's exit from the bounding sphere, and the call returns (z_vals, z_vals_inverse_sphere) -- against the reference's own
+    call on its draws.  A ray that misses the sphere ends the reference's process; here it raises with the same words."""
+    rec = load("sampler_inv")
+    model = build_model(rec).train()
+    assert model.ray_sampler.inverse_sphere_bg
+    ins = section(rec, "in.")
+    (z, z_inv), z_eik = model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model, rng=rand_dict(rec))
+    assert model.ray_sampler.last_rounds == int(rec["meta.rounds"])
+    z_close(z, torch.from_numpy(rec["out.z_vals"]))
+    close(z_inv, rec["out.z_vals_inverse_sphere"], 1e-6, 1e-7, "z_vals_inverse_sphere")
+    assert torch.equal(z_eik, torch.gather(z, 1, torch.from_numpy(rec["rand.eik_idx"])[:, None]))
+    # the sphere exit is one of the final depths of every ray, the constant far bound (3.5) is not
+    from holoscene_amd.utils.rend_util import get_sphere_intersections
+    far = get_sphere_intersections(ins["cam_loc"], ins["ray_dirs"], r=1.0)[:, 1:]
+    assert bool(((z - far).abs().min(dim=1)[0] == 0).all()) and float(z.max()) < 2.0
+    with pytest.raises(RuntimeError, match="BOUNDING SPHERE PROBLEM"):
+        model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"] + torch.tensor([5.0, 0.0, 0.0]), model, rng=rand_dict(rec))
+
+
 @pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5", "stock_k32_bg", "stock_k21", "stock_k40", "stock_k64_bg", "stock_l8_k3_bg"])
 def test_iteration(name):
     rec = load(name)

@@ -33,6 +33,26 @@ def test_sampler(name, impl, monkeypatch):
     assert torch.equal(z_eik, torch.gather(z, 1, eik_idx[:, None]))
 
 
+@pytest.mark.parametrize("impl,control", [("hip", "device"), ("hip", "host"), ("torch", "host")])
+def test_sampler_inverse_sphere_branch(impl, control, monkeypatch):
+    """inverse_sphere_bg=True (ray_sampler.py:127-128, 262-265, 282-285) through the fused kernels -- the per-ray far bound reaches the
+    tail / final kernels as `far_rays` -- against the reference's own call on its draws (tests/golden/sampler_inv.npz)."""
+    from holoscene_amd.model import ray_sampler
+    monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", impl)
+    monkeypatch.setattr(ray_sampler, "CONTROL", control)
+    rec = load("sampler_inv")
+    model = build_model(rec, DEV).train()
+    ins = _dev(section(rec, "in."))
+    (z, z_inv), z_eik = model.ray_sampler.get_z_vals(ins["ray_dirs"], ins["cam_loc"], model, rng=_dev(rand_dict(rec)))
+    assert model.ray_sampler.last_rounds == int(rec["meta.rounds"])
+    z_close(z, torch.from_numpy(rec["out.z_vals"]), frac_loose=0.05)
+    close(z_inv, rec["out.z_vals_inverse_sphere"], 1e-6, 1e-7, "z_vals_inverse_sphere")
+    assert torch.equal(z_eik, torch.gather(z, 1, torch.from_numpy(rec["rand.eik_idx"]).to(DEV)[:, None]))
+    from holoscene_amd.utils.rend_util import get_sphere_intersections
+    far = get_sphere_intersections(ins["cam_loc"], ins["ray_dirs"], r=1.0)[:, 1:]
+    assert bool(((z - far).abs().min(dim=1)[0] == 0).all()) and float(z.max()) < 2.0
+
+
 @pytest.mark.parametrize("name", ["iter_k3_bg", "iter_k5"])
 def test_iteration(name):
     rec = load(name)
