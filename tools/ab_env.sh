@@ -5,6 +5,6 @@ ARGS="--no-cpu-baseline --no-second-point --no-fp32-point --no-trajectory-point 
 cd ${GRAFT_REPO_ROOT:-.}
 for i in $(seq $RUNS); do
   for v in $A $B; do
-    env $VAR=$v python bench.py $ARGS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$VAR=$v', d['ms_per_step'], d.get('ms_per_step_median'), round(d['value']))"
+    env $VAR=$v python bench.py $ARGS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$VAR=$v', d['ms_per_step'], d.get('ms_per_step_median'), round(d['value']), 'bg', d['iteration_kinds']['background_patch']['ms_mean'])"
   done
 done
