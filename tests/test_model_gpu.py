@@ -1761,9 +1761,10 @@ def test_whole_iteration_at_baseline_config0_shape_vs_oracle():
     assert rel < 3e-2, rel
 
 
-def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatch):
+@pytest.mark.parametrize("L", [8, 13, 5])
+def test_grid_of_fewer_levels_runs_on_the_fused_sixteen_level_kernels(L, monkeypatch):
     """A hash grid of FEWER than 16 levels (BASELINE configs[0]: L = 8) on the hand-written bf16 kernels: the hash kernels are handed empty levels
-    behind the grid's own (HashEncoder.fused_offsets -> zeros, nothing scattered), the layers that read hash features zero columns (fused_cols).
+    behind the grid's own -- also an ODD count, and one that ends inside a lane half's eight levels (L = 13, 5) -- (HashEncoder.fused_offsets -> zeros, nothing scattered), the layers that read hash features zero columns (fused_cols).
     (1) hash kernels: the padded call = the plain call on the real levels, zeros elsewhere, the same table gradient; (2) the model takes the
     fused kernels (counted) and the whole-iteration graph; (3) its losses and gradients agree with the fp32 library path of the same state as
     the stock grid's bf16 path does with its own."""
@@ -1774,32 +1775,32 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
     be = be_mod._backend
     torch.manual_seed(3)
     # ---- (1)
-    enc = HashEncoder(3, 8, 2, 2, 16, 15, 256).to(DEV)
+    enc = HashEncoder(3, L, 2, 2, 16, 15, 256).to(DEV)
     with torch.no_grad():
         enc.embeddings.uniform_(-0.5, 0.5)
     B = 5000
     x = torch.rand(B, 3, device=DEV)
     S, H = float(np.log2(enc.per_level_scale)), int(enc.base_resolution)
-    f8, d8 = torch.empty(8, B, 2, device=DEV), torch.empty(8, B, 6, device=DEV)
+    f8, d8 = torch.empty(L, B, 2, device=DEV), torch.empty(L, B, 6, device=DEV)
     f16, d16 = torch.full((16, B, 2), 7.0, device=DEV), torch.full((16, B, 6), 7.0, device=DEV)
-    be.fwd(x, enc.embeddings, enc.offsets, f8, B, 3, 2, 8, S, H, d8, level_major=True)
+    be.fwd(x, enc.embeddings, enc.offsets, f8, B, 3, 2, L, S, H, d8, level_major=True)
     be.fwd(x, enc.embeddings, enc.fused_offsets, f16, B, 3, 2, 16, S, H, d16, level_major=True)
-    assert torch.equal(f16[:8], f8) and torch.equal(d16[:8], d8) and not f16[8:].any() and not d16[8:].any()
+    assert torch.equal(f16[:L], f8) and torch.equal(d16[:L], d8) and not f16[L:].any() and not d16[L:].any()
     w16 = torch.empty(16, B, device=DEV, dtype=torch.int32)
     be.fwd(x, enc.embeddings, enc.fused_offsets, w16, B, 3, 2, 16, S, H, None, level_major=True, out_bf16=True)
-    assert not w16[8:].any() and w16[:8].any()
-    g8, gj8 = torch.randn(8, B, 2, device=DEV), torch.randn(8, B, 6, device=DEV)
+    assert not w16[L:].any() and w16[:L].any()
+    g8, gj8 = torch.randn(L, B, 2, device=DEV), torch.randn(L, B, 6, device=DEV)
     g16, gj16 = torch.randn(16, B, 2, device=DEV), torch.randn(16, B, 6, device=DEV)
-    g16[:8], gj16[:8] = g8, gj8
+    g16[:L], gj16[:L] = g8, gj8
     t8, t16 = torch.zeros_like(enc.embeddings), torch.zeros_like(enc.embeddings)
-    be.bwd_jac(g8, gj8, x, enc.offsets, t8, B, 3, 2, 8, S, H, level_major=True)
+    be.bwd_jac(g8, gj8, x, enc.offsets, t8, B, 3, 2, L, S, H, level_major=True)
     be.bwd_jac(g16, gj16, x, enc.fused_offsets, t16, B, 3, 2, 16, S, H, level_major=True)
     assert float((t16 - t8).abs().max()) <= 1e-5 * float(t8.abs().max())       # (float atomics: order)
     # ---- (2), (3)
     from holoscene_amd.training.synthetic import look_at_pose
     from holoscene_amd.training.trainer import benchmark_model_state
     R, res = 256, 512
-    conf = lambda prec: stock_conf(num_rays=R, S=64, d_out=2, num_levels=8, end_size=256, logmap=15, beta=0.05, mlp_precision=prec, use_bg_reg=False)  # noqa: E731
+    conf = lambda prec: stock_conf(num_rays=R, S=64, d_out=2, num_levels=L, end_size=256, logmap=15, beta=0.05, mlp_precision=prec, use_bg_reg=False)  # noqa: E731
     tr = Stage1Trainer(conf("bf16"), device=DEV, optimizer="flat", graph=True, freeze_parameters=True, inject_draws=True)
     net = tr.model.implicit_network
     assert net.fused_trunk_blockers() == [] and tr.model.fused_path_report() == [] and tr._full_graph_ok()
@@ -1842,7 +1843,7 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
     _, lf = ref.train_step(torch.tensor([0]), mi, dv(gt), rng=dv(rand))
     for k in ("loss", "rgb_loss", "eikonal_loss", "depth_loss"):
         rel = abs(float(lb[k]) - float(lf[k])) / max(abs(float(lf[k])), 1e-12)
-        print(f"PARITY L = 8 grid on the fused kernels (whole-iteration graph), bf16 vs fp32 library path: {k} rel {rel:.3e}")
+        print(f"PARITY L = {L} grid on the fused kernels (whole-iteration graph), bf16 vs fp32 library path: {k} rel {rel:.3e}")
         assert rel < 3e-2, (k, rel)
     # ---- (4) the padding machinery on its own: the same network written as a SIXTEEN-level grid whose levels 8..15 hold zero tables (same
     # level scales: end = base x pls^15) and whose feature-reading layers have zero columns for them runs the stock path with no padding at all
@@ -1853,7 +1854,7 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
     bn = big.model.implicit_network
     assert abs(float(bn.encoding.per_level_scale) - pls) < 1e-6 * pls and getattr(bn.lin0, "fused_cols", None) is None
     n8 = int(net.encoding.offsets[-1])
-    assert torch.equal(bn.encoding.offsets[:9].cpu(), net.encoding.offsets.cpu())
+    assert torch.equal(bn.encoding.offsets[:L + 1].cpu(), net.encoding.offsets.cpu())
     sd8 = tr.model.state_dict()
     with torch.no_grad():
         sdb = big.model.state_dict()
@@ -1863,7 +1864,7 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
         for e8, e16 in ((net.encoding, bn.encoding), (net.color_encoding, bn.color_encoding)):
             e16.embeddings.zero_()
             e16.embeddings[:n8].copy_(e8.embeddings)
-        for name, cols in (("lin0.weight_v", 55), ("color_grid_feature_map_mlp.0.weight", 16)):
+        for name, cols in (("lin0.weight_v", 39 + 2 * L), ("color_grid_feature_map_mlp.0.weight", 2 * L)):
             w8, w16 = dict(net.named_parameters())[name], dict(bn.named_parameters())[name]
             w16.zero_()
             w16[:, :cols].copy_(w8)
@@ -1872,7 +1873,7 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
     _, l16 = big.train_step(torch.tensor([0]), mi, dv(gt), rng=dv(rand))
     for k in ("loss", "rgb_loss", "eikonal_loss", "depth_loss", "normal_l1"):
         rel = abs(float(lb[k]) - float(l16[k])) / max(abs(float(l16[k])), 1e-12)
-        print(f"PARITY L = 8 grid padded to the fused kernels vs the same network as an explicit 16-level grid: {k} rel {rel:.3e}")
+        print(f"PARITY L = {L} grid padded to the fused kernels vs the same network as an explicit 16-level grid: {k} rel {rel:.3e}")
         assert rel < 1e-5, (k, rel)
     gb = dict(tr.model.named_parameters())
     g16 = dict(big.model.named_parameters())
@@ -1883,14 +1884,14 @@ def test_grid_of_eight_levels_runs_on_the_fused_sixteen_level_kernels(monkeypatc
         if k.endswith("encoding.embeddings"):
             b = b[:n8]
         elif k.endswith("lin0.weight_v") and "implicit" in k:
-            assert not b[:, 55:].any(), "zero features give zero weight gradients"
-            b = b[:, :55]
+            assert not b[:, 39 + 2 * L:].any(), "zero features give zero weight gradients"
+            b = b[:, :39 + 2 * L]
         elif k.endswith("color_grid_feature_map_mlp.0.weight"):
-            assert not b[:, 16:].any()
-            b = b[:, :16]
+            assert not b[:, 2 * L:].any()
+            b = b[:, :2 * L]
         rel = float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30))
         if rel > worst[1]:
             worst = (k, rel)
-    print(f"PARITY L = 8 grid padded vs explicit 16-level grid: worst gradient relL2 {worst[1]:.3e} ({worst[0]})")
+    print(f"PARITY L = {L} grid padded vs explicit 16-level grid: worst gradient relL2 {worst[1]:.3e} ({worst[0]})")
     assert worst[1] < 1e-4, worst       # (table scatters: float-atomic order)
-    assert gb["implicit_network.lin0.weight_v"].grad.shape == (256, 55)
+    assert gb["implicit_network.lin0.weight_v"].grad.shape == (256, 39 + 2 * L)
