@@ -1706,10 +1706,10 @@ class ObjectImplicitNetworkGrid(nn.Module):
 
     def _fused_sdf32_supported(self, x):
         """The no-grad SDF queries of the fp32 configuration through csrc/sdf_mlp32.hip (fp32 operands on the fp32 matrix cores): the stock
-        trunk shape, d_out <= 32.  HOLOSCENE_FP32_SDF=gemm keeps the library GEMMs."""
+        trunk shape (or a grid of fewer levels padded to it: _stock_grid), d_out <= 32.  HOLOSCENE_FP32_SDF=gemm keeps the library GEMMs."""
         lins = self._lins()
         return (FP32_SDF == "mfma" and not self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None and self.embedder.multires == 6
-                and self.grid_feature_dim == 32 and self._stock_grid() and lins[0].in_features == 71 and lins[0].out_features == 256
+                and self._stock_grid(padded=True) and self._stock_inputs(padded=True) and lins[0].out_features == 256
                 and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features == self.d_out <= 32
                 and not any(l in self.skip_in for l in range(3)))
 

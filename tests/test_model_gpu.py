@@ -1636,15 +1636,15 @@ def test_colour_branch_wave_tile_kernels_are_run_to_run_identical_at_full_size()
         assert not diff, f"run {run + 1} differs from run 0 in {diff}"
 
 
-@pytest.mark.parametrize("B,d_out", [(131072, 32), (1000, 21), (33, 5)])
-def test_fp32_fused_sdf_sweep_vs_library_gemms(B, d_out, monkeypatch):
+@pytest.mark.parametrize("B,d_out,L", [(131072, 32, 16), (1000, 21, 16), (33, 5, 16), (4000, 2, 8), (1000, 7, 13)])
+def test_fp32_fused_sdf_sweep_vs_library_gemms(B, d_out, L, monkeypatch):
     """csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32, fp32 activations in registers, torch's Softplus formula) against the same
     queries through library GEMMs (the reference's arithmetic, model/network.py:169-210, 305-326): the minimum over all objects, one object,
     an object subset, the raw SDFs; points inside and outside the cube; ragged sizes; gated launches."""
     from holoscene_amd.model import network as N
     torch.manual_seed(d_out)
     net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
-                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=2048).to(DEV)
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=L, logmap=15, end_size=2048 if L == 16 else 256).to(DEV)       # (L < 16: empty levels behind the grid's own, zero columns in lin0 -- DESIGN 14.11)
     net.set_mlp_precision("fp32")
     with torch.no_grad():
         net.encoding.embeddings.uniform_(-0.3, 0.3)
