@@ -221,11 +221,14 @@ def test_fused_flat_adam_matches_torch_adam():
     assert sorted(model.state_dict().keys()) == sorted(ref_model.state_dict().keys())
 
 
-def test_graph_replay_matches_eager_execution():
+def test_graph_replay_matches_eager_execution(monkeypatch):
     """The captured HIP graph (render + loss + backward) must reproduce the eager execution of the same body on the
     same static inputs and the same generator state: outputs equal, gradients equal up to float-atomic ordering."""
+    from holoscene_amd.model import ray_sampler
     from holoscene_amd.training.synthetic import SyntheticScene
     from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    monkeypatch.setattr(ray_sampler, "CONTROL", "host")     # the render-only graph behind a host-controlled sampler (with device control this
+                                                            # conf takes the whole-iteration graph: the fp32 sweeps accept its 8-level grid)
     tr = Stage1Trainer(stock_conf(num_rays=256, S=32, d_out=4, num_levels=8, end_size=256, logmap=14, beta=0.05), device=DEV,
                        optimizer="flat", graph=True, freeze_parameters=True)
     benchmark_model_state(tr.model, 0.05)
