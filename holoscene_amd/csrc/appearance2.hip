@@ -22,9 +22,10 @@
 namespace {
 
 #ifndef HS_A2_LA
-#define HS_A2_LA 2
+#define HS_A2_LA 1
 #endif
-constexpr int kLA = HS_A2_LA;          // k-steps an A fragment is read from LDS ahead of its MFMA
+constexpr int kLA = HS_A2_LA;          // k-steps an A fragment is read from LDS ahead of its MFMA (1: backward 66.4 -> 64.4 us, forward 69.9 -> 69.2;
+                                       // bench median -3 .. -9 us in six alternating pairs on two boxes; 0 the same as 1, 3 slower than 2)
 constexpr int XAS = 8;                 // k-steps of the assembled-input image: 2 (colour features) + 6 (encodings, 81 -> 96)
 constexpr int kA2Bias = 4 * 256 + 32;  // bc0 | bc1 | br0 | br1 | br2
 // the streamed fragment image: per layer, per 32-neuron tile, [k-steps][64 lanes] x 16 B
