@@ -118,6 +118,13 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                                              // the words ARE this lane's feature inputs (levels 8 h .. 8 h + 7), no conversion
                 const uint32_t *fl = reinterpret_cast<const uint32_t *>(feat) + (size_t)(8 * h) * B + (ok ? gp : 0);
 #pragma unroll
+// k-steps a weight fragment is requested ahead of its MFMAs: layer 0 (W0 from L2) / layer 1 (W1 from LDS)
+#ifndef HS_SDF2_AH0
+#define HS_SDF2_AH0 1
+#endif
+#ifndef HS_SDF2_AH1
+#define HS_SDF2_AH1 2
+#endif
 #ifndef HS_NT_SDF_IN
 #define HS_NT_SDF_IN 0
 #endif
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                 init_acc(acc[q & 1][1], bias + 32 * (2 * q + 1), h);
                 if (q < 3) HS_W0_FETCH(q + 1);
                 auto f0 = [&](int s, int j) { return w0[q & 1][2 * s + j]; };
-                if (q == 0) phase2<K0S, 1, K0S, 16, false>(acc[0], hin, f0, [](auto) {});
-                else phase2<K0S, 1, K0S, 16, true>(acc[q & 1], hin, f0, [&](auto slc) { constexpr int sl = decltype(slc)::value;
+                if (q == 0) phase2<K0S, HS_SDF2_AH0, K0S, 16, false>(acc[0], hin, f0, [](auto) {});
+                else phase2<K0S, HS_SDF2_AH0, K0S, 16, true>(acc[q & 1], hin, f0, [&](auto slc) { constexpr int sl = decltype(slc)::value;
                     h0p[16 * (q - 1) + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[(q & 1) ^ 1][sl >> 3], 2 * (sl & 7)); });
             }
 #undef HS_W0_FETCH
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
             init_acc(acc[q & 1][1], bias + 256 + 32 * (2 * q + 1), h);
             auto f1 = [&](int s, int j) { return W1v[(size_t)(s * NT + 2 * q + j) * 64]; };
             // q = 0 finishes layer 0's last quarter (needed from k-step 12 on) within its first 8 k-steps
-            if (q == 0) phase2<HS, 2, 8, 16, true>(acc[0], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value; h0p[48 + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[1][sl >> 3], 2 * (sl & 7)); });
-            else phase2<HS, 2, HS, 16, true>(acc[q & 1], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value;
+            if (q == 0) phase2<HS, HS_SDF2_AH1, 8, 16, true>(acc[0], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value; h0p[48 + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[1][sl >> 3], 2 * (sl & 7)); });
+            else phase2<HS, HS_SDF2_AH1, HS, 16, true>(acc[q & 1], h0p, f1, [&](auto slc) { constexpr int sl = decltype(slc)::value;
                 h1p[16 * (q - 1) + 8 * (sl >> 3) + (sl & 7)] = epilogue_pair(acc[(q & 1) ^ 1][sl >> 3], 2 * (sl & 7)); });
         }
         HS_STAMP(3);

@@ -56,6 +56,10 @@ __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 
 // s = sigmoid(100 a) from the stored h = softplus100(a): exp(-100 h) = 1 - s
 __device__ __forceinline__ float sig_of_h(float h) { return 1.f - __builtin_amdgcn_exp2f(-kC * h); }
 
+// k-steps an LDS-resident weight fragment is read ahead of its MFMA in the backward kernels (and the separate forward-gradient kernel)
+#ifndef HS_RR_AH
+#define HS_RR_AH 2
+#endif
 #ifndef HS_NT_LOAD_LAST
 #define HS_NT_LOAD_LAST 1
 #endif
@@ -495,8 +499,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_grad(const float *__res
 #pragma unroll
                 for (int q = 0; q < 4; q++) u1w[nt & 1][q] = *reinterpret_cast<const float4 *>(ur + 8 * q);
             }
-            if constexpr (nt == 0) phase1r<HS, 2, 10, 12, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 7); });
-            else phase1r<HS, 2, HS, 12, true, true>(acc[nt & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(nt & 1) ^ 1], nt - 1); });
+            if constexpr (nt == 0) phase1r<HS, HS_RR_AH, 10, 12, true, true>(acc[0], u0p, f1, [&](auto slc) { epi0(slc, acc[1], 7); });
+            else phase1r<HS, HS_RR_AH, HS, 12, true, true>(acc[nt & 1], u0p, f1, [&](auto slc) { epi1(slc, acc[(nt & 1) ^ 1], nt - 1); });
         });
         static_for<12>([&](auto slc) { epi1(slc, acc[1], 7); });
     }
@@ -534,7 +538,10 @@ __device__ __forceinline__ void up_input_product(const bf16x8 *__restrict__ W0Tv
         __builtin_amdgcn_sched_barrier(0);
     });
 }
-constexpr int kUpAhead = 3;
+#ifndef HS_RR_UP_AH
+#define HS_RR_UP_AH 3
+#endif
+constexpr int kUpAhead = HS_RR_UP_AH;
 
 // slot sigma (0..47) of this lane half sits in accumulator (sigma >> 4), register (sigma & 15)
 #define HS_SLOT(o0, o1, o2, sigma) ((sigma) < 16 ? o0[(sigma) & 15] : (sigma) < 32 ? o1[(sigma) & 15] : o2[(sigma) & 15])
@@ -606,8 +613,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
             constexpr int nt = decltype(nc)::value;
             auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
             hw[nt & 1] = tp_load_tile(H0t, here(tile), nt, lane);        // consumed by tile nt's epilogue, in phase nt + 1
-            if constexpr (nt == 0) phase1r<HS, 2, HS, 12, false, true>(acc[0], vin, f1, [](auto) {});
-            else phase1r<HS, 2, HS, 12, true, true>(acc[nt & 1], vin, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], nt - 1); });
+            if constexpr (nt == 0) phase1r<HS, HS_RR_AH, HS, 12, false, true>(acc[0], vin, f1, [](auto) {});
+            else phase1r<HS, HS_RR_AH, HS, 12, true, true>(acc[nt & 1], vin, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], nt - 1); });
         });
         // ---- ux = W0^T v0 (tile 7's epilogue -- k-steps 14, 15 of this product -- in the shadow of k-steps 0..11)
         f32x16 &o0 = acc[0];
@@ -723,8 +730,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
             constexpr int nt = decltype(nc)::value;
             auto f1 = [&](int s) { return W1v[(size_t)(s * NT + nt) * 64]; };
             load(H0t, A0pt, nt);        // consumed by tile nt's epilogue, in phase nt + 1
-            if constexpr (nt == 0) phase1r<HS, 2, HS, 10, false, true>(acc[0], a1p, f1, [](auto) {});
-            else phase1r<HS, 2, HS, 10, true, true>(acc[nt & 1], a1p, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], a0p, A0t, nt - 1); });
+            if constexpr (nt == 0) phase1r<HS, HS_RR_AH, HS, 10, false, true>(acc[0], a1p, f1, [](auto) {});
+            else phase1r<HS, HS_RR_AH, HS, 10, true, true>(acc[nt & 1], a1p, f1, [&](auto slc) { epi(slc, acc[(nt & 1) ^ 1], a0p, A0t, nt - 1); });
         });
         // ---- xt~ = W0^T a0~; only the hash-feature slots are wanted (x is a constant): g_feat [L, ld, 2], level-major
         f32x16 &o0 = acc[0];
