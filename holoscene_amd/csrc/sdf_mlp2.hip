@@ -47,11 +47,17 @@ __device__ __forceinline__ uint32_t epilogue_pair(const f32x16 &acc, int r) {
     return anchor(w);      // keeps the softplus in the MFMA shadow it was placed in (wave_tile.h)
 }
 
+// WIDE: 33..64 outputs -- a second 32-neuron tile of the last layer after the first, its fragments (W2b: the [high | low] planes of rows 32..63,
+// packed like W2f) and biases (bias2: a pack's bias block whose b2 slots hold rows 32..63) read from memory (16 KB, cache-resident; LDS is full).
+// The 32-output instantiation is the kernel the benchmark runs, untouched by the other.
+template <bool WIDE> struct WideArgs {};
+template <> struct WideArgs<true> { const uint16_t *W2b; const float *bias2; };
+template <bool WIDE>
 __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
                                                             const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
                                                             const float *__restrict__ biasg, int d_out, int select, uint64_t select_mask,
                                                             float *__restrict__ out_min, float *__restrict__ out_raw, int64_t B, hsGate gate,
-                                                            int feat_level_major, int lo_plane) {
+                                                            int feat_level_major, int lo_plane, WideArgs<WIDE> wide) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
 #ifdef HS_SDF2_PROFILE
@@ -245,21 +251,73 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                 if (take) best = fminf(best, val);
             }
         }
-        best = fminf(best, __shfl_xor(best, 32));
-        if (h == 0 && ok) out_min[gp] = best;
-        if (out_raw && ok) {
-            float *dst = out_raw + gp * d_out;
-            if ((d_out & 3) == 0) {      // 16-byte runs: neurons 8 q + 4 h .. + 3
+        if constexpr (!WIDE) {
+            best = fminf(best, __shfl_xor(best, 32));
+            if (h == 0 && ok) out_min[gp] = best;
+            if (out_raw && ok) {
+                float *dst = out_raw + gp * d_out;
+                if ((d_out & 3) == 0) {      // 16-byte runs: neurons 8 q + 4 h .. + 3
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (8 * q + 4 * h < d_out) *reinterpret_cast<float4 *>(dst + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-            } else {
+                    for (int q = 0; q < 4; q++)
+                        if (8 * q + 4 * h < d_out) *reinterpret_cast<float4 *>(dst + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int n = 8 * (i >> 2) + 4 * h + (i & 3);
-                    if (n < d_out) dst[n] = y[i];
+                    for (int i = 0; i < 16; i++) {
+                        const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                        if (n < d_out) dst[n] = y[i];
+                    }
                 }
             }
+        } else {
+            auto store_raw = [&](int base) {      // this lane's 16 outputs of the tile that starts at neuron `base`
+                float *dst = out_raw + gp * d_out + base;
+                if ((d_out & 3) == 0) {      // 16-byte runs: neurons 8 q + 4 h .. + 3
+    #pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (base + 8 * q + 4 * h < d_out) *reinterpret_cast<float4 *>(dst + 8 * q + 4 * h) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                        if (base + n < d_out) dst[n] = y[i];
+                    }
+                }
+            };
+            if (out_raw && ok) store_raw(0);
+            const uint16_t *__restrict__ W2b = wide.W2b;
+            const float *__restrict__ bias2 = wide.bias2;
+            f32x16 &y0 = acc[0][0], &y1 = acc[0][1];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { y0[i] = 0.f; y1[i] = 0.f; }
+            uint32_t zb = 0;
+            asm volatile("" : "+v"(zb));
+            const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2b) + lane + zb;
+#pragma unroll
+            for (int s = 0; s < HS / 2; s++) {
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+            }
+            if (kW2LowPlane && lo_plane) {
+                const bf16x8 *W2r = W2q + (size_t)HS * 64;
+#pragma unroll
+                for (int s = 0; s < HS / 2; s++) {
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                const float val = y0[i] + y1[i] + bias2[512 + n];
+                y[i] = val;
+                if (32 + n < d_out) {
+                    const bool take = select_mask ? ((select_mask >> (32 + n)) & 1ull) != 0ull : (select < 0 || 32 + n == select);
+                    if (take) best = fminf(best, val);
+                }
+            }
+            if (out_raw && ok) store_raw(32);
+            best = fminf(best, __shfl_xor(best, 32));
+            if (h == 0 && ok) out_min[gp] = best;
         }
         HS_STAMP(4);
     }
@@ -311,7 +369,7 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;   // the resident image is copied in one sweep: W2f directly behind W1f
     const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
     static hsLdsAttrOnce attr;
-    attr.set((const void *)k_sdf_mlp2, (int)lds);
+    attr.set((const void *)k_sdf_mlp2<false>, (int)lds);
     const int64_t ntiles = (B + kRows - 1) / kRows;
     const int64_t want = (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);      // one workgroup per CU (146 KB of LDS), wave tiles strided across the grid
@@ -319,9 +377,30 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     // one with these bf16 sweeps does (profiles/r05/bf16_stage_hunt.txt, stage "sampler"), and the plane's fragments -- from memory, this
     // kernel's LDS is full -- cost 3 us per sweep (same-box A/B: 1.606 -> 1.621 ms per iteration).  HOLOSCENE_SDF_W2_PLANES=2 adds it.
     static const int planes = [] { const char *e = getenv("HOLOSCENE_SDF_W2_PLANES"); return (e && e[0] == '2') ? 2 : 1; }();
-    k_sdf_mlp2<<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                               select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
-                                                               feat_level_major, planes == 2);
+    k_sdf_mlp2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                      select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
+                                                                      feat_level_major, planes == 2, WideArgs<false>{});
+    return wt_check_launch();
+}
+
+int hs_sdf_mlp2_fwd_wide(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, const void *W2f_b,
+                         const float *bias_b, int32_t d_out, int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B,
+                         const hsGate *gate, int32_t feat_level_major, void *stream) {
+    if (d_out < 33 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
+    if (select_mask && d_out < 64 && (select_mask >> d_out)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!x || !feat || !W0f || !W1f || !W2f || !bias || !W2f_b || !bias_b || !out_min) return HS_ERR_NULL;
+    if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
+    const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_sdf_mlp2<true>, (int)lds);
+    const int64_t ntiles = (B + kRows - 1) / kRows;
+    const int64_t want = (ntiles + kWaves - 1) / kWaves;
+    const int grid = (int)(want < 256 ? want : 256);
+    static const int planes = [] { const char *e = getenv("HOLOSCENE_SDF_W2_PLANES"); return (e && e[0] == '2') ? 2 : 1; }();
+    k_sdf_mlp2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
+                                                                     select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
+                                                                     feat_level_major, planes == 2, WideArgs<true>{(const uint16_t *)W2f_b, bias_b});
     return wt_check_launch();
 }
 

@@ -143,6 +143,7 @@ TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 # inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
 # activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
 SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
+SDF_WIDE = os.environ.get("HOLOSCENE_SDF_WIDE", "1") != "0"     # 33..64 objects: sampler sweeps on the wave-tile kernel (0: workgroup-tile kernel, A/B)
 # the no-grad SDF queries of the fp32 configuration: "mfma" = csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32), "gemm" = library GEMMs
 FP32_SDF = os.environ.get("HOLOSCENE_FP32_SDF", "mfma")
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
@@ -1748,6 +1749,20 @@ class ObjectImplicitNetworkGrid(nn.Module):
                                                          f2.detach().float().contiguous(), l2.bias.detach().float().contiguous(), l2.out_features)
         return self._packed_cache2
 
+    def _packed_weights2_wide(self):
+        """33 <= d_out <= 64: two packs of the wave-tile kernel's images, the last layer's rows 0..31 and 32.. (hs_sdf_mlp2_fwd_wide)."""
+        if getattr(self, "_packed_cache2w", None) is not None:
+            return self._packed_cache2w
+        l0, l1, l2 = self._lins()
+        with torch.no_grad():
+            f0, f1, f2 = effective_weights([l0, l1, l2])
+        c = lambda t: t.detach().float().contiguous()  # noqa: E731
+        K = l2.out_features
+        pk = _be._backend.sdf_mlp2_pack
+        self._packed_cache2w = (pk(c(f0), c(l0.bias), c(f1), c(l1.bias), c(f2[:32]), c(l2.bias[:32]), 32),
+                                pk(c(f0), c(l0.bias), c(f1), c(l1.bias), c(f2[32:]), c(l2.bias[32:]), K - 32))
+        return self._packed_cache2w
+
     def _packed_weights32(self):
         """fp32 operand images of csrc/sdf_mlp32.hip, one pack launch per parameter state."""
         if getattr(self, "_packed_cache32", None) is not None:
@@ -1767,6 +1782,11 @@ class ObjectImplicitNetworkGrid(nn.Module):
             be.sdf_mlp32_fwd(x, feat, self._packed_weights32(), d_out, select, out, raw, gate=gate, feat_level_major=bool(lm))
         elif SDF_MLP_IMPL == "wave" and d_out <= 32:
             be.sdf_mlp2_fwd(x, feat, self._packed_weights2(), d_out, select, out, raw, gate=gate, feat_level_major=lm)
+        elif SDF_MLP_IMPL == "wave" and d_out <= 64 and SDF_WIDE:
+            # 33..64 objects: the wave-tile kernel with the last layer's second 32-row tile after the first (32 us per sweep where the
+            # workgroup-tile kernel below takes 65)
+            pa, pb = self._packed_weights2_wide()
+            be.sdf_mlp2_fwd_wide(x, feat, pa, pb, d_out, select, out, raw, gate=gate, feat_level_major=lm)
         elif SDF_MLP_IMPL in ("wave", "tile"):
             w0, b0, w1, b1, w2, b2 = self._packed_weights()
             be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, raw, gate=gate, feat_level_major=lm)
@@ -1777,6 +1797,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         """The packed bf16 images are valid for one parameter state; the sampler drops them at the start of every call."""
         self._packed_cache = None
         self._packed_cache2 = None
+        self._packed_cache2w = None
         self._packed_cache32 = None
 
     def _sdf_fused(self, x, select=-1, want_raw=False):
@@ -1821,7 +1842,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         d_out = self._lins()[2].out_features
         # ... and as bf16 words [L, R*S] when the wave-tile trunk kernel follows: it rounds the features to bf16 anyway (same rounding:
         # identical results), so the gather writes and the trunk reads half the bytes
-        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= 32 and enc.embeddings.shape[1] == 2 and self.mlp_bf16
+        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= (64 if SDF_WIDE else 32) and enc.embeddings.shape[1] == 2 and self.mlp_bf16
         if words:
             feat = torch.empty(L, R * S, device=dev, dtype=torch.int32)
             be.fwd(x01, enc.embeddings, enc.fused_offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,

@@ -430,6 +430,12 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,
                     int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, int32_t feat_level_major,
                     void *stream);
+/* 33 <= d_out <= 64 objects (the reference sizes the last layer by the scene's label count, training/holoscene_train.py:119-122): the last layer's
+ * second 32-row tile after the first.  W0f / W1f / W2f / bias: a pack of (W0, W1, W2[0:32], b2[0:32]) with d_out = 32; W2f_b / bias_b: the W2f and
+ * bias buffers of a second pack whose W2 / b2 arguments are rows 32.. (d_out - 32 of them).  select / select_mask index all d_out outputs. */
+int hs_sdf_mlp2_fwd_wide(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, const void *W2f_b,
+                         const float *bias_b, int32_t d_out, int32_t select, uint64_t select_mask, float *out_min, float *out_raw, int64_t B,
+                         const hsGate *gate, int32_t feat_level_major, void *stream);
 
 /* The same function on FP32 operands (csrc/sdf_mlp32.hip: v_mfma_f32_32x32x2_f32, fp32 activations in registers, torch.nn.Softplus(beta = 100)
  * by expf / log1pf) -- the reference's own arithmetic (training/holoscene_train.py:45: no autocast) for the sampler sweeps of the fp32

@@ -319,7 +319,7 @@ def test_fused_composite_matches_torch_formulation(R, N, K):
         close(a, b, 2e-3, 2e-5 * max(scale, 1e-6), n_)
 
 
-@pytest.mark.parametrize("d_out,B", [(32, 131072), (21, 1000), (2, 129), (40, 4096)])
+@pytest.mark.parametrize("d_out,B", [(32, 131072), (21, 1000), (2, 129), (40, 4096), (64, 70001), (33, 333)])
 def test_fused_mfma_sdf_kernel_vs_torch(d_out, B):
     """csrc/sdf_mlp.hip (bf16 MFMA, fp32 accumulate) vs the plain fp32 PyTorch SDF trunk on the same weights.
     Tolerance: bf16 operand rounding (2^-8 relative per product, 256-term sums) -> 1e-2 of the value scale."""
@@ -346,6 +346,57 @@ def test_fused_mfma_sdf_kernel_vs_torch(d_out, B):
     assert (got_min - ref_min).abs().max() < 1e-2 * scale
     assert torch.equal(got_min, got_raw.min(-1, keepdim=True)[0]), "min output must be the min of the raw outputs of the same launch"
     assert torch.equal(got_sel, got_raw[:, d_out - 1])
+
+
+@pytest.mark.parametrize("d_out,B", [(64, 131072), (40, 1000), (33, 65)])
+def test_wide_sdf_sweep_vs_workgroup_tile_kernel(d_out, B, monkeypatch):
+    """33..64 objects: the wave-tile kernel with the last layer's second tile (hs_sdf_mlp2_fwd_wide) against the workgroup-tile kernel it replaces
+    for the sampler sweeps (csrc/sdf_mlp.hip) on the same weights -- minimum over all objects, one object on either side of the tile boundary, a
+    subset spanning it, the raw outputs; through the ray entry point (bf16-word features, gated) too.  Both round operands to bf16 and
+    accumulate in fp32: agreement to the order of summation."""
+    from holoscene_amd.hashencoder import backend as be_mod
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+        net.lin2.weight_v.add_(0.05 * torch.randn_like(net.lin2.weight_v))
+        net.lin2.bias.add_(0.1 * torch.randn_like(net.lin2.bias))
+    net.set_mlp_precision("bf16")
+    x = (torch.rand(B, 3, device=DEV) * 2.4 - 1.2)
+    sub = [3, 31, 32, d_out - 1]
+    calls = []
+    orig = be_mod._backend.sdf_mlp2_fwd_wide
+    monkeypatch.setattr(be_mod._backend, "sdf_mlp2_fwd_wide", staticmethod(lambda *a, **k: calls.append(1) or orig(*a, **k)))
+
+    def queries():
+        net.invalidate_packed_weights()
+        with torch.no_grad():
+            out = {"min": net.get_sdf_vals(x), "raw": net.get_sdf_raw(x), "lo": net.get_object_sdf_vals(x, 31), "hi": net.get_object_sdf_vals(x, 32),
+                   "last": net.get_object_sdf_vals(x, d_out - 1), "sub": net.get_multi_object_sdf_vals(x, sub)}
+            R, S = (8, B // 8) if B >= 64 else (1, B)
+            xx = x[:R * S].contiguous()
+            x01 = ((xx / net.divide_factor + 1.0) / 2.0).contiguous()
+            a, b = torch.tensor([1.0], device=DEV), torch.tensor([2.0], device=DEV)
+            out["rays"] = net.sdf_at_points(xx, x01, R, S, gate=(b, a)).reshape(-1, 1)
+        return out
+    wide = queries()
+    assert len(calls) >= 7, calls
+    assert torch.equal(wide["min"], wide["raw"].min(-1, keepdim=True)[0]) and torch.equal(wide["lo"], wide["raw"][:, 31])
+    assert torch.equal(wide["hi"], wide["raw"][:, 32]) and torch.equal(wide["last"], wide["raw"][:, d_out - 1])
+    assert torch.equal(wide["sub"], wide["raw"][:, sub].min(-1, keepdim=True)[0])
+    assert torch.equal(wide["rays"], wide["min"][:wide["rays"].shape[0]])
+    monkeypatch.setattr(N, "SDF_WIDE", False)
+    n = len(calls)
+    tile = queries()
+    assert len(calls) == n
+    scale = float(tile["raw"].abs().max())
+    for k in wide:
+        err = float((wide[k] - tile[k]).abs().max())
+        print(f"PARITY wide SDF sweep K={d_out} B={B} {k}: max abs diff from the workgroup-tile kernel {err:.3e} (scale {scale:.2f})")
+        assert wide[k].shape == tile[k].shape and err < 3e-3 * scale, (k, err)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
