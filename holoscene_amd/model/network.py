@@ -1783,7 +1783,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         elif SDF_MLP_IMPL == "wave" and d_out <= 32:
             be.sdf_mlp2_fwd(x, feat, self._packed_weights2(), d_out, select, out, raw, gate=gate, feat_level_major=lm)
         elif SDF_MLP_IMPL == "wave" and d_out <= 64 and SDF_WIDE:
-            # 33..64 objects: the wave-tile kernel with the last layer's second 32-row tile after the first (32 us per sweep where the
+            # 33..64 objects: the wave-tile kernel with the last layer's second 32-row tile after the first (36 us per sweep where the
             # workgroup-tile kernel below takes 65)
             pa, pb = self._packed_weights2_wide()
             be.sdf_mlp2_fwd_wide(x, feat, pa, pb, d_out, select, out, raw, gate=gate, feat_level_major=lm)
