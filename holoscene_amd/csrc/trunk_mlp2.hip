@@ -129,12 +129,18 @@ __device__ __forceinline__ void store_line(const uint32_t *hw16, int nt, uint16_
     for (int i = 0; i < 2 * TILES; i++) store_pair(hw16 + 8 * (i >> 1), i & 1, nt + (i >> 1), Hrow, ok, h);
 }
 
-template <bool SPLIT>
+// WIDE (with SPLIT): 33..64 outputs -- the last layer's second 32-row tile after the first, as in sdf_mlp2.hip's k_sdf_mlp2<true>: fragments (both
+// planes) and biases of rows 32.. from a second pack in memory; the split outputs are formed tile by tile and the value row picks between the tiles.
+template <bool WIDE> struct TrunkWideArgs {};
+template <> struct TrunkWideArgs<true> { const uint16_t *W2b; const float *bias2; };
+template <bool SPLIT, bool WIDE = false>
 __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__restrict__ x, const float *__restrict__ feat, const float *__restrict__ dydx,
                                                               const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f,
                                                               const uint16_t *__restrict__ W2f, const float *__restrict__ biasg, int d_out,
                                                               uint16_t *__restrict__ H0, uint16_t *__restrict__ H1, float *__restrict__ Y,
-                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp, int64_t ld, int lo_plane) {
+                                                              uint16_t *__restrict__ Xp, int64_t M, float jac_scale, hsTrunkSplit sp, int64_t ld, int lo_plane,
+                                                              TrunkWideArgs<WIDE> wide) {
+    static_assert(SPLIT || !WIDE, "the wide form exists for the split outputs only");
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -343,7 +349,120 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_trunk_fwd2(const float *__rest
             }
         }
         // ---- outputs: register i <-> output 8 (i >> 2) + 4 h + (i & 3); the bias belongs to the value row only
-        if constexpr (!SPLIT) {
+        if constexpr (WIDE) {
+            const int K = d_out;
+            const int64_t b = gr >> 2, Bp4 = M >> 2, Be = Bp4 - sp.n_main;
+            const bool main_pt = b < sp.n_main;
+            const int64_t e = b - sp.n_main;
+            const int d = t - 1;
+            // one 32-column tile of the outputs: its raw columns / its objects' gradient rows leave at once; what the choice between the tiles needs
+            // (row minimum and index, this lane's output at the value row's index) is returned
+            auto tile_out = [&](int base, const float (&o)[16], float &best, int &bi, float &at_hit, bool &mine) {
+                best = INFINITY;
+                bi = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                    if (base + n < K && o[i] < best) { best = o[i]; bi = n; }
+                }
+                {
+                    const float ob = __shfl_xor(best, 32);
+                    const int oi = __shfl_xor(bi, 32);
+                    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                const int hit = __builtin_amdgcn_update_dpp(0, bi, 0x00, 0xf, 0xf, true);
+                at_hit = 0.f;
+                mine = ((hit >> 2) & 1) == h;
+                const int ih = 4 * (hit >> 3) + (hit & 3);
+#pragma unroll
+                for (int i = 0; i < 16; i++) at_hit = i == ih ? o[i] : at_hit;
+                if (ok) {
+                    if (is_value) {
+                        float *dst = (main_pt ? sp.sdf_raw + b * K : sp.y_eik + e * K) + base;
+                        if ((K & 3) == 0) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                if (base + 8 * q + 4 * h < K) *reinterpret_cast<float4 *>(dst + 8 * q + 4 * h) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                                if (base + n < K) dst[n] = o[i];
+                            }
+                        }
+                    } else if (!main_pt) {
+                        int64_t step = Be * 3;
+                        asm volatile("" : "+s"(step));
+                        float *gp = sp.grad_theta + ((int64_t)(base + 4 * h) * Be + e) * 3 + d;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                            if (base + n < K) gp[(int64_t)(8 * (i >> 2) + (i & 3)) * step] = o[i];
+                        }
+                    }
+                }
+            };
+            float o[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bv = lds_at<f32x4>(bo, (uint32_t)(8 * q) * 4u);
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[4 * q + k] = y0[4 * q + k] + y1[4 * q + k] + (is_value ? bv[k] : 0.f);
+            }
+            float best0, at0, best1, at1;
+            int bi0, bi1;
+            bool mine0, mine1;
+            tile_out(0, o, best0, bi0, at0, mine0);
+            {
+                uint32_t zb = 0;
+                asm volatile("" : "+v"(zb));
+                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(wide.W2b) + lane + zb;
+                static_for<HS / 2>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[0], frag_of(h1p), zero, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[64], frag_of(h1p + 4), zero, 0, 0, 0);
+                    } else {
+                        y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                    }
+                });
+                if (kW2LowPlane && lo_plane) {
+                    const bf16x8 *W2r = W2q + (size_t)HS * 64;
+                    static_for<HS / 2>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s) * 64], frag_of(h1p + 4 * (2 * s)), y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s + 1) * 64], frag_of(h1p + 4 * (2 * s + 1)), y1, 0, 0, 0);
+                    });
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+                o[i] = y0[i] + y1[i] + (is_value ? wide.bias2[512 + n] : 0.f);
+            }
+            tile_out(32, o, best1, bi1, at1, mine1);
+            // the value row chooses (strict <: equal minima keep the lower index); the quad's tangent rows follow it
+            const int w1 = best1 < best0 ? 1 : 0;
+            const int wq = __builtin_amdgcn_update_dpp(0, w1, 0x00, 0xf, 0xf, true);
+            if (ok) {
+                if (is_value) {
+                    if (h == 0) {
+                        sp.idx[b] = w1 ? 32 + bi1 : bi0;
+                        const float best = w1 ? best1 : best0;
+                        if (main_pt) sp.sdf[b] = best; else sp.min_eik[e] = best;
+                    }
+                } else {
+                    const float at = wq ? at1 : at0;
+                    const bool mine = wq ? mine1 : mine0;
+                    if (mine) {
+                        if (main_pt) sp.grad[b * 3 + d] = at;
+                        else sp.grad_theta[((int64_t)K * Be + e) * 3 + d] = at;
+                    }
+                }
+            }
+        } else if constexpr (!SPLIT) {
           if (ok) {
             float *dst = Y + gr * d_out;
             if ((d_out & 3) == 0) {
@@ -486,10 +605,35 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     const int lo_plane = w2_planes == 2;
     if (split)
         k_trunk_fwd2<true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane, TrunkWideArgs<false>{});
     else
         k_trunk_fwd2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
-                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane);
+                                                                 (uint16_t *)H0, (uint16_t *)H1, Y, (uint16_t *)Xp, M, jac_scale, sp, ld, lo_plane, TrunkWideArgs<false>{});
+    return wt_check_launch();
+}
+
+int hs_trunk_mlp2_fwd_wide(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                           const void *W2f_b, const float *bias_b, int32_t d_out, void *H0, void *H1, void *Xp, int64_t M, float jac_scale,
+                           const hsTrunkSplit *split, int64_t ld, int32_t w2_planes, void *stream) {
+    if (d_out < 33 || d_out > 64 || (M & 3) || (ld != 0 && ld < (M >> 2)) || w2_planes < 1 || w2_planes > 2) return HS_ERR_ARG;
+    if (ld == 0) ld = M >> 2;
+    if (M == 0) return HS_OK;
+    if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !W2f_b || !bias_b || !H0 || !H1 || !split || !Xp) return HS_ERR_NULL;
+    const hsTrunkSplit sp = *split;
+    const int64_t Bp = M >> 2;
+    if (sp.n_main < 0 || sp.n_main > Bp) return HS_ERR_ARG;
+    if (!sp.idx || (sp.n_main > 0 && (!sp.sdf_raw || !sp.sdf || !sp.grad)) || (sp.n_main < Bp && (!sp.y_eik || !sp.min_eik || !sp.grad_theta))) return HS_ERR_NULL;
+    if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
+    const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float);
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_trunk_fwd2<true, true>, (int)lds);
+    const int64_t ntiles = (M + kRows - 1) / kRows;
+    static const bool spread = [] { const char *e = getenv("HOLOSCENE_TRUNK2_SPREAD"); return !(e && e[0] == '0'); }();
+    const int64_t want = spread ? ntiles : (ntiles + kWaves - 1) / kWaves;
+    const int grid = (int)(want < 256 ? want : 256);
+    k_trunk_fwd2<true, true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias,
+                                                                            d_out, (uint16_t *)H0, (uint16_t *)H1, nullptr, (uint16_t *)Xp, M, jac_scale, sp, ld,
+                                                                            w2_planes == 2, TrunkWideArgs<true>{(const uint16_t *)W2f_b, bias_b});
     return wt_check_launch();
 }
 

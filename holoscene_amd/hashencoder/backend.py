@@ -156,7 +156,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -690,6 +690,22 @@ class _HipBackend:
                                         _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"), _dev(packed_b[2], "W2f_b", bf), _dev(packed_b[3], "bias_b"),
                                         d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                         ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd_wide")
+
+    @staticmethod
+    def trunk_mlp2_fwd_wide(x, feat, dydx, packed, packed_b, d_out, H0, H1, Xp, jac_scale, split, ld=0, off=0, w2_planes=2):
+        """33 <= d_out <= 64 (hs_trunk_mlp2_fwd_wide): packed = sdf_mlp2_pack(log2_domain=False) of the last layer's rows 0..31, packed_b = of rows
+        32.. ; the split outputs only."""
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, W2f, bias = packed
+        n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta = split
+        opt = lambda t, name, dt=torch.float32: _dev(t, name, dt).value if t is not None and t.numel() else None   # noqa: E731
+        sp = hsTrunkSplit(int(n_main), opt(sdf_raw, "sdf_raw"), opt(sdf, "sdf"), _dev(idx, "idx", torch.int64).value, opt(grad, "grad"),
+                          opt(y_eik, "y_eik"), opt(min_eik, "min_eik"), opt(gtheta, "grad_theta"))
+        _check(lib.hs_trunk_mlp2_fwd_wide(_dev(x, "x"), _dev(feat, "feat"), _dev_at(dydx, "dydx", off * 6), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf),
+                                          _dev(W2f, "W2f", bf), _dev(bias, "bias"), _dev(packed_b[2], "W2f_b", bf), _dev(packed_b[3], "bias_b"), d_out,
+                                          _dev(H0, "H0", bf), _dev(H1, "H1", bf), _dev(Xp, "Xp", bf), ctypes.c_int64(H0.shape[0]), ctypes.c_float(jac_scale),
+                                          ctypes.byref(sp), ctypes.c_int64(ld), int(w2_planes), _stream()), "hs_trunk_mlp2_fwd_wide")
 
     @staticmethod
     def trunk_mlp2_fwd(x, feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split=None, ld=0, off=0, w2_planes=2):

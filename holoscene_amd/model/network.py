@@ -158,6 +158,7 @@ TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") !
 # forward pass of the training trunk: "wave" = csrc/trunk_mlp2.hip (wave-tile form: builds its own input rows from x / features / dy_dx,
 # register-resident activations; d_out <= 32), "tile" = k_trunk_fwd of csrc/sdf_mlp.hip fed by k_trunk_input_fwd
 TRUNK_FWD_IMPL = os.environ.get("HOLOSCENE_TRUNK_FWD_IMPL", "wave")
+TRUNK_WIDE = os.environ.get("HOLOSCENE_TRUNK_WIDE", "1") != "0"   # 33..64 objects: the training trunk's forward on the wave-tile kernel (k_trunk_fwd2<true, true>)
 # the wave-tile trunk kernel writes the per-object SDFs / minimum / its gradient itself ("1") or stores Y for hs_trunk_split_fwd ("0")
 TRUNK_SPLIT_FUSED = os.environ.get("HOLOSCENE_TRUNK_SPLIT_FUSED", "1") != "0"
 # the trunk's weight-gradient GEMMs before ("1") or after ("0") the table scatter of the same backward stage (_trunk_bwd_core)
@@ -301,13 +302,25 @@ def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     M = 4 * B
     H0 = torch.empty(M, 256, device=dev, dtype=bf)
     H1 = torch.empty(M, 256, device=dev, dtype=bf)
-    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and nfreq == 6 and L == 16 and C == 2 and D == 3 and F_in == 71   # the kernel hard-codes the stock 16 x 2 grid
-    fuse_split = wave and split is not None and TRUNK_SPLIT_FUSED      # the kernel writes the split outputs itself: no Y at all
+    stock = nfreq == 6 and L == 16 and C == 2 and D == 3 and F_in == 71      # the kernel hard-codes the stock 16 x 2 grid
+    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and stock
+    # 33..64 outputs: the same kernel with the last layer's second tile in its tail (split outputs only)
+    wide = TRUNK_FWD_IMPL == "wave" and TRUNK_WIDE and 32 < d_out <= 64 and stock and split is not None and TRUNK_SPLIT_FUSED
+    fuse_split = (wave and split is not None and TRUNK_SPLIT_FUSED) or wide      # the kernel writes the split outputs itself: no Y at all
     Y = None if fuse_split else torch.empty(M, d_out, device=dev, dtype=torch.float32)
     bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
     w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
     w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
     f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
+    if wide:
+        _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
+        pk = _be._backend.sdf_mlp2_pack
+        pa = pk(f0, bb[0], f1, bb[1], f2[:32].contiguous(), bb[2][:32].contiguous(), 32, log2_domain=False)
+        pb = pk(f0, bb[0], f1, bb[1], f2[32:].contiguous(), bb[2][32:].contiguous(), d_out - 32, log2_domain=False)
+        Xp = torch.empty(M, 80, device=dev, dtype=bf)
+        _be._backend.trunk_mlp2_fwd_wide(x.float(), feat, dydx, pa, pb, d_out, H0, H1, Xp, jac_scale, split)
+        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
+        return None, (x01, embeddings, offsets, Xp, H0, H1, w0t, w1t, w2t)
     if wave:
         # wave-tile forward (csrc/trunk_mlp2.hip): fragment-order operands, input rows assembled in the kernel and kept as Xp [M,80]
         _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])

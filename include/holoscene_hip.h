@@ -425,6 +425,11 @@ int32_t hs_trunk_mlp2_input_column(int32_t reference_column);
 int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
                       int32_t d_out, void *H0, void *H1, float *Y, void *Xp, int64_t M, float jac_scale, const hsTrunkSplit *split, int64_t ld,
                       int32_t w2_planes, void *stream);
+/* 33 <= d_out <= 64 with the split outputs (Y is never stored): the last layer's second 32-row tile after the first, as hs_sdf_mlp2_fwd_wide --
+ * W2f_b / bias_b are the W2f and bias buffers of a second hs_sdf_mlp2_pack(log2_domain = 0) whose W2 / b2 arguments are rows 32.. */
+int hs_trunk_mlp2_fwd_wide(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                           const void *W2f_b, const float *bias_b, int32_t d_out, void *H0, void *H1, void *Xp, int64_t M, float jac_scale,
+                           const hsTrunkSplit *split, int64_t ld, int32_t w2_planes, void *stream);
 /* (hs_sdf_mlp2_fwd: feat_level_major 0 = fp32 [B, 32]; 1 = fp32 [16, B, 2]; 2 = `feat` points at uint32 [16, B], each word a level's two
  * channels as bf16 -- what hs_hash_fwd writes with hsHashLayout::out_bf16; results identical to the fp32 forms, which round the same way) */
 int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const void *W1f, const void *W2f, const float *bias, int32_t d_out,

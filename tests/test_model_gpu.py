@@ -1273,6 +1273,77 @@ def test_fused_trunk_render_split_equals_torch_ops_on_the_same_trunk(d_out, B, n
         assert rel < 2e-3, (n, rel)    # the two routes round the same cotangent to bf16 at the same place; only summation orders differ
 
 
+@pytest.mark.parametrize("d_out,B,n_main", [(64, 4096, 3072), (40, 1000, 1000), (33, 130, 0)])
+def test_wide_trunk_forward_vs_workgroup_tile_kernels(d_out, B, n_main, monkeypatch):
+    """33..64 objects: the training trunk's forward on the wave-tile kernel with the last layer's second tile (k_trunk_fwd2<true, true>,
+    hs_trunk_mlp2_fwd_wide) against the workgroup-tile kernels + split kernel it replaces -- the seven outputs (raw SDFs, minimum, its index, its
+    gradient; the Eikonal points' outputs and stacked gradient rows) and, through the SAME backward kernels, every parameter gradient.  Both
+    forwards round operands to bf16 and accumulate in fp32; the index may differ only where two objects tie within that rounding."""
+    from holoscene_amd.hashencoder import backend as be_mod
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=16, logmap=15, end_size=512).to(DEV)
+    net.set_mlp_precision("bf16")
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+        net.lin2.weight_v.add_(0.05 * torch.randn_like(net.lin2.weight_v))
+        net.lin2.bias.add_(0.1 * torch.randn_like(net.lin2.bias))
+    x = torch.rand(B, 3, device=DEV) * 2.4 - 1.2
+    Be = B - n_main
+    cot = [torch.randn(n_main, d_out, device=DEV), torch.randn(n_main, 1, device=DEV), torch.randn(n_main, 3, device=DEV),
+           torch.randn(Be, d_out, device=DEV), torch.randn(Be, 1, device=DEV), torch.randn((d_out + 1) * Be, 3, device=DEV)]
+    params = [net.encoding.embeddings] + [p for l in net._lins() for p in (l.weight_v, l.weight_g, l.bias)]
+    enc = net.encoding
+    l0, l1, l2 = net._lins()
+    calls = []
+    orig = be_mod._backend.trunk_mlp2_fwd_wide
+    monkeypatch.setattr(be_mod._backend, "trunk_mlp2_fwd_wide", staticmethod(lambda *a, **k: calls.append(1) or orig(*a, **k)))
+
+    def run(wide):
+        monkeypatch.setattr(N, "TRUNK_WIDE", wide)
+        sdf_raw, sdf, idx, grad, y_e, min_e, gtheta = N._fused_trunk_render.apply(
+            x, n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), 6, 1.0, l0.weight, l0.bias, l1.weight,
+            l1.bias, l2.weight, l2.bias)
+        outs = [sdf_raw, sdf, grad, y_e, min_e, gtheta]
+        loss = sum((o * c).sum() for o, c in zip(outs, cot))
+        return [o.detach() for o in outs], idx, [g.float() for g in torch.autograd.grad(loss, params)]
+    wo, wi, wg = run(True)
+    assert len(calls) == 1
+    to, ti, tg = run(False)
+    assert len(calls) == 1
+    # self-consistency of the wide outputs, bit for bit: the minimum is the minimum of the raw outputs at the reported index
+    raw_all = torch.cat([wo[0], wo[3]], 0)
+    min_all = torch.cat([wo[1], wo[4]], 0)
+    assert torch.equal(min_all, raw_all.min(-1, keepdim=True)[0]) and torch.equal(torch.gather(raw_all, 1, wi), min_all)
+    assert torch.equal(wi, raw_all.argmin(-1, keepdim=True)), "lowest index among equal minima"
+    if Be:      # the last Be rows of grad_theta are the minimum's gradient = the reported object's rows
+        gt = wo[5]
+        per_obj = gt[:d_out * Be].view(d_out, Be, 3)
+        assert torch.equal(gt[d_out * Be:], per_obj[wi[n_main:, 0], torch.arange(Be, device=DEV)])
+    scale = float(to[0].abs().max()) if n_main else float(to[3].abs().max())
+    same = (wi == ti).float().mean()
+    print(f"PARITY wide trunk forward K={d_out}: argmin agrees on {float(same):.4f} of the points")
+    assert float(same) > 0.995
+    for a, b, n in zip(wo, to, ("sdf_raw", "sdf", "grad", "y_eik", "min_eik", "grad_theta")):
+        if a.numel() == 0:
+            continue
+        keep = slice(None)
+        if n == "grad":      # the gradient of the minimum follows the index
+            keep = (wi[:n_main, 0] == ti[:n_main, 0])
+        elif n == "grad_theta":
+            keep = torch.cat([torch.ones(d_out * Be, dtype=torch.bool, device=DEV), wi[n_main:, 0] == ti[n_main:, 0]])
+        err = float((a[keep] - b[keep]).abs().max())
+        ref = float(b.abs().max())
+        print(f"PARITY wide trunk forward K={d_out} {n}: max abs diff from the workgroup-tile path {err:.3e} (scale {ref:.2f})")
+        assert err < 4e-3 * max(ref, 1.0), (n, err)
+    for a, b, n in zip(wg, tg, ["table"] + [f"lin{i}.{k}" for i in range(3) for k in ("v", "g", "bias")]):
+        rel = float((a - b).norm() / (b.norm() + 1e-20))
+        print(f"PARITY wide trunk forward K={d_out} gradient {n}: relL2 {rel:.3e}")
+        assert rel < 3e-2, (n, rel)
+
+
 @pytest.mark.parametrize("Bn", [256, 300])
 def test_appearance_relu_masks_equal_saved_signs(Bn):
     """The ballots hs_appearance_fwd leaves for the backward (3 layers x 8 waves x 64 words per 128-point tile) decode to exactly the signs
