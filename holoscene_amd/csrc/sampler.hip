@@ -169,7 +169,8 @@ __device__ float error_bound(const float *__restrict__ sdf, const float *__restr
 // loops are unrolled over CH with the tail slots padded by d = 0 (their terms are exact zeros: the sums are untouched) and masked out of the
 // maximum; the scans and the maximum take their DPP operand inside the add / max (wave_ops.h: incl_scan2, max_dpp).  Same operations on the same
 // values in the same order as the form above -- sign(s) * em1 for its select (an exact product; the zero it yields for s = 0 may carry a sign,
-// which the following addition of half_inv_b absorbs) -- hence bit-identical bounds; ~315 -> ~200 instructions per evaluation at three sections.
+// which the following addition of half_inv_b absorbs) -- hence bit-identical bounds for finite SDF values (a NaN value gives 0 * NaN = NaN
+// here where the select gives 0: both forms then drop that section's bound in fmaxf, the sums differ); ~315 -> ~200 instructions per evaluation at three sections.
 template <int CH>
 struct SecRegs {
     float nas[CH], sg[CH], d[CH], dd[CH], nds[CH];

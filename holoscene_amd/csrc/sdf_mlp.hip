@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_sdf_mlp(const float *__restrict__ 
         // ---- layer 2: stage W2 [32*NOUT_TILES][HID] with pitch HP into the chunk area
         // (W2 = two bf16 planes [2][32 NOUT_TILES][HID]: the matrix, then what its rounding dropped -- the last layer's rows are a large common
         //  value plus small learned structure that one plane loses; both planes fit the chunk area)
+        static_assert(2 * 32 * NOUT_TILES * HP <= 2 * HID * WP, "both W2 planes must fit the weight-chunk area (holds for HS_MLP_KC = 64; not for the header's default 32)");
         for (int idx = threadIdx.x; idx < 2 * 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
             const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_trunk_fwd(const uint16_t *__restri
         epilogue_tangent(bias + HID, H, acc, nq, ph, lane);
         // (W2 = two bf16 planes [2][32 NOUT_TILES][HID]: the matrix, then what its rounding dropped -- the last layer's rows are a large common
         //  value plus small learned structure that one plane loses; both planes fit the chunk area)
+        static_assert(2 * 32 * NOUT_TILES * HP <= 2 * HID * WP, "both W2 planes must fit the weight-chunk area (holds for HS_MLP_KC = 64; not for the header's default 32)");
         for (int idx = threadIdx.x; idx < 2 * 32 * NOUT_TILES * (HID / 8); idx += kThreads) {
             const int row = idx / (HID / 8), seg = idx - row * (HID / 8);
             *reinterpret_cast<uint4 *>(Wc + (size_t)row * HP + seg * 8) = *reinterpret_cast<const uint4 *>(W2 + (size_t)row * HID + seg * 8);

@@ -29,6 +29,13 @@
 __device__ unsigned long long g_sdf2_prof[256 * 8 * 16];   // [block][wave][stamp]
 #endif
 
+#ifdef HS_SWEEP_PROFILE    // tools/exp/sweep_prof.hip: s_memtime stamps inside the gather of k_sdf_mlp2<., true> (with HS_SDF2_PROFILE)
+__device__ unsigned long long g_sweep_prof[256 * 8 * 8];    // [block][wave][first / second tile][reads issued, posenc done, blended, -]
+#define HS_GSTAMP(i) do { if ((threadIdx.x & 63) == 0) g_sweep_prof[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + prof_slot + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HS_GSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 // log2(1 + 2^t); above t = 30 that IS t in fp32 (sdf_mlp.hip: softplus_scaled).  No clamp of the exponential's argument: beyond
@@ -47,17 +54,216 @@ __device__ __forceinline__ uint32_t epilogue_pair(const f32x16 &acc, int r) {
     return anchor(w);      // keeps the softplus in the MFMA shadow it was placed in (wave_tile.h)
 }
 
+// ---- the in-kernel gather of the GATHER instantiations (see GatherLevel below): eight levels of one point on one lane
+struct GatherLevel;
+__device__ __forceinline__ float gw_smoothstep(float t) { return t * t * (3.0f - 2.0f * t); }     // hash_encode.hip: smoothstep
+// `between()` -- the trunk's own input arithmetic (eighteen sines and cosines) -- runs while the 64 reads are in flight; it is written into both arms of
+// the inside / outside branch so that the reads' destination registers never cross a join (as two functions around the call they went to scratch).
+template <class GL, class F>
+__device__ __forceinline__ void gather_words(uint32_t (&fw)[8], const float *__restrict__ x01, const char *__restrict__ table, const GL *lv, int64_t gp, bool ok,
+                                             F &&between, [[maybe_unused]] int prof_slot = 0) {
+    const float p0 = ok ? x01[gp * 3] : 2.f, p1 = ok ? x01[gp * 3 + 1] : 2.f, p2 = ok ? x01[gp * 3 + 2] : 2.f;
+    const bool inside = !(p0 < 0.f || p0 > 1.f) && !(p1 < 0.f || p1 > 1.f) && !(p2 < 0.f || p2 > 1.f);     // hash_encode.hip: locate
+#pragma unroll
+    for (int i = 0; i < 8; i++) fw[i] = 0u;
+    if (!inside) {                               // (points outside the unit cube: zero features, hashencoder.cu:124-149 -- and no reads)
+        between();
+        return;
+    }
+    float2 e[8][8];
+    float w[8][3];
+    // phase A: locate, index, request -- all eight levels' reads are in flight before the first is used
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint4 la = *reinterpret_cast<const uint4 *>(&lv[i]), lb = *(reinterpret_cast<const uint4 *>(&lv[i]) + 1);
+        const float scale = __uint_as_float(la.x);
+        const uint32_t A = la.y, Bm = la.z, mask = la.w, limit = lb.x, byte_off = lb.y, flags = lb.z;
+        uint32_t g[3];
+        const float ps[3] = {p0, p1, p2};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float pos = ps[d] * scale;
+            const float fl = floorf(pos);
+            g[d] = (uint32_t)fl;
+            pos -= (float)g[d];
+            w[i][d] = gw_smoothstep(pos);
+        }
+        const uint32_t a0 = g[1] * A, a1 = a0 + A, b0 = g[2] * Bm, b1 = b0 + Bm, x0 = g[0], x1 = g[0] + 1u;
+        uint32_t idx[8];
+        if (flags & 1u) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) idx[c] = ((c & 1) ? x1 : x0) ^ ((c & 2) ? a1 : a0) ^ ((c & 4) ? b1 : b0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) idx[c] = ((c & 1) ? x1 : x0) + ((c & 2) ? a1 : a0) + ((c & 4) ? b1 : b0);
+        }
+        uint32_t top = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; c++) { idx[c] &= mask; top = max(top, idx[c]); }
+        if (top >= limit) {       // rare: a table that is not a power of two, and a corner past its end (x = 1 on an integer scale): the reference's modulo
+            const uint32_t t = lb.w;
+#pragma unroll
+            for (int c = 0; c < 8; c++) idx[c] = idx[c] >= t ? idx[c] % t : idx[c];
+        }
+        const char *base = table + byte_off;
+#pragma unroll
+        for (int c = 0; c < 8; c++) e[i][c] = *reinterpret_cast<const float2 *>(base + ((size_t)idx[c] << 3));
+    }
+    HS_GSTAMP(0);
+    between();
+    HS_GSTAMP(1);
+    // phase B: blend in the reference's order (k_hash_fwd / k_hash_fwd_pair: corners 0..7, x bit fastest; weight = ((1 * wx) * wy) * wz)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float wt = 1.f;
+            wt *= (c & 1) ? w[i][0] : 1 - w[i][0];
+            wt *= (c & 2) ? w[i][1] : 1 - w[i][1];
+            wt *= (c & 4) ? w[i][2] : 1 - w[i][2];
+            const float q0 = wt * e[i][c].x, q1 = wt * e[i][c].y;
+            acc0 += q0;
+            acc1 += q1;
+        }
+        const uint32_t flags = reinterpret_cast<const uint32_t *>(&lv[i])[6];
+        fw[i] = (flags & 2u) ? 0u : pack2(acc0, acc1);
+    }
+    HS_GSTAMP(2);
+}
+
+// The same gather with TWO LANES PER POINT, as k_hash_fwd_pair has them: lanes (2 p, 2 p + 1) hold the two x-corners of point p's cell, every lane
+// walks all sixteen levels with four reads each.  The single-lane form above asks the L1 for 64 different lines per instruction (two points' worth of
+// nothing in common) and is bound by its tag rate: tools/exp/sweep_prof.hip measured 62 clocks per gather instruction, 31 us per 131 072 points, all of
+// it in front of the trunk.  Here an instruction covers 32 points x 2 corners that share a line 15 times in 16 -- half the lookups.  The sum keeps the
+// reference's order: the lane holding x = 0 adds its own product, then its neighbour's (DPP); for levels 0..7 that is the even lane, for levels 8..15
+// the ODD one, so that lane 2 p + h ends up with the eight words lane (p, h) of the trunk's tile feeds to the first layer -- one ds_bpermute per word.
+template <class GL, class F>
+__device__ __forceinline__ void gather_words_pair(uint32_t (&fw)[8], const float *__restrict__ x01, const char *__restrict__ table, const GL *lv, int64_t tile0,
+                                                  int64_t B, int lane, F &&between, [[maybe_unused]] int prof_slot = 0) {
+    const int xb0 = lane & 1;
+    const int64_t gq = tile0 + (lane >> 1);
+    const bool okq = gq < B;
+    const float p0 = okq ? x01[gq * 3] : 2.f, p1 = okq ? x01[gq * 3 + 1] : 2.f, p2 = okq ? x01[gq * 3 + 2] : 2.f;
+    const bool inside = !(p0 < 0.f || p0 > 1.f) && !(p1 < 0.f || p1 > 1.f) && !(p2 < 0.f || p2 > 1.f);     // both lanes of a pair alike
+    uint32_t fwp[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) fwp[i] = 0u;
+    if (inside) {
+        auto half = [&](auto hc) {
+            constexpr int HB = decltype(hc)::value;          // levels 8 HB .. 8 HB + 7
+            float2 e[8][4];
+            float w[8][3];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const GL *L = lv + 8 * HB + i;
+                const uint4 la = *reinterpret_cast<const uint4 *>(L), lb = *(reinterpret_cast<const uint4 *>(L) + 1);
+                const float scale = __uint_as_float(la.x);
+                const uint32_t A = la.y, Bm = la.z, mask = la.w, limit = lb.x, byte_off = lb.y, flags = lb.z;
+                uint32_t g[3];
+                const float ps[3] = {p0, p1, p2};
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float pos = ps[d] * scale;
+                    const float fl = floorf(pos);
+                    g[d] = (uint32_t)fl;
+                    pos -= (float)g[d];
+                    w[i][d] = gw_smoothstep(pos);
+                }
+                const uint32_t xb = (uint32_t)(xb0 ^ HB);
+                const uint32_t a0 = g[1] * A, a1 = a0 + A, b0 = g[2] * Bm, b1 = b0 + Bm, xs = g[0] + xb;
+                uint32_t idx[4];
+                if (flags & 1u) {          // (wave-uniform: one level at a time)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) idx[c] = xs ^ ((c & 1) ? a1 : a0) ^ ((c & 2) ? b1 : b0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) idx[c] = xs + ((c & 1) ? a1 : a0) + ((c & 2) ? b1 : b0);
+                }
+                uint32_t top = 0u;
+#pragma unroll
+                for (int c = 0; c < 4; c++) { idx[c] &= mask; top = max(top, idx[c]); }
+                if (top >= limit) {
+                    const uint32_t t = lb.w;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) idx[c] = idx[c] >= t ? idx[c] % t : idx[c];
+                }
+                const char *base = table + byte_off;
+#pragma unroll
+                for (int c = 0; c < 4; c++) e[i][c] = *reinterpret_cast<const float2 *>(base + ((size_t)idx[c] << 3));
+            }
+            if constexpr (HB == 0) { HS_GSTAMP(0); between(); HS_GSTAMP(1); }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t xb = (uint32_t)(xb0 ^ HB);
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float wt = 1.f;
+                    wt *= xb ? w[i][0] : 1 - w[i][0];
+                    wt *= (c & 1) ? w[i][1] : 1 - w[i][1];
+                    wt *= (c & 2) ? w[i][2] : 1 - w[i][2];
+                    const float q0 = wt * e[i][c].x, q1 = wt * e[i][c].y;
+                    acc0 += q0;                                                                                              // corner (0, yz) on the lane that holds x = 0
+                    acc0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q0), 0xB1, 0xf, 0xf, true));        // corner (1, yz): quad_perm [1,0,3,2]
+                    acc1 += q1;
+                    acc1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q1), 0xB1, 0xf, 0xf, true));
+                }
+                const uint32_t flags = reinterpret_cast<const uint32_t *>(lv + 8 * HB + i)[6];
+                const uint32_t word = (flags & 2u) ? 0u : pack2(acc0, acc1);
+                fwp[i] = xb == 0u ? word : fwp[i];       // the x = 0 lane of this half's levels: even lanes keep levels 0..7, odd lanes 8..15
+            }
+        };
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
+    } else {
+        between();
+    }
+    HS_GSTAMP(2);
+    // lane (row, h) of the trunk's tile takes its eight words from lane 2 row + h
+    const int src = (2 * (lane & 31) + (lane >> 5)) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) fw[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)fwp[i]);
+}
+
+#ifndef HS_SWEEP_PAIR
+#define HS_SWEEP_PAIR 1      // 0: the one-lane-per-point gather (A/B, python -m holoscene_amd.csrc.build --variant lane -DHS_SWEEP_PAIR=0)
+#endif
+
 // WIDE: 33..64 outputs -- a second 32-neuron tile of the last layer after the first, its fragments (W2b: the [high | low] planes of rows 32..63,
 // packed like W2f) and biases (bias2: a pack's bias block whose b2 slots hold rows 32..63) read from memory (16 KB, cache-resident; LDS is full).
 // The 32-output instantiation is the kernel the benchmark runs, untouched by the other.
 template <bool WIDE> struct WideArgs {};
 template <> struct WideArgs<true> { const uint16_t *W2b; const float *bias2; };
-template <bool WIDE>
+
+// GATHER: the sweep gathers its own hash features (hs_sdf_sweep_fwd) -- `feat` is the TABLE (16 levels x 2 channels, hsHashLayout-free: one grid),
+// x01 the points' grid coordinates.  Lane (point, h) needs the features of levels 8 h .. 8 h + 7 of ITS point and nobody else does: it locates the
+// point in each of its eight levels, issues the 64 corner reads (global_load_dwordx2, the eight levels' reads in flight together) and blends them in
+// the reference's order -- corner 0, 1, ..., 7 with the x bit alternating, a product then a sum per corner and channel, no contraction (this file is
+// built with -ffp-contract=off like hash_encode.hip) -- so the word it packs is bit for bit the word k_hash_fwd_pair<2, false> writes with
+// hsHashLayout::out_bf16, and every result of the sweep is bit-identical to gather launch + k_sdf_mlp2.  What the fusion buys: the gather is bound by the
+// texture addresser and the L1 tag rate, the trunk by the matrix pipe and the VALU; as two launches they run one after the other (31 + 31 us per
+// 131 072 points), as one kernel a compute unit's eight waves drift into different phases and the units overlap; the 8 MB feature round trip and one
+// launch boundary per round go away.  What it costs: every compute unit now reads all sixteen levels, so an XCD's 4 MB L2 sees the whole 48.8 MB
+// table instead of the two levels the XCD-affine gather schedule deals it (measured on the gather alone: 31.1 -> 37.1 us without the affinity).
+struct GatherLevel {        // 32 bytes per level, in LDS behind the bias block (two ds_read_b128 per level and tile)
+    float scale;            // hashencoder.cu:152
+    uint32_t A, B;          // index = g0 (op) g1 A (op) g2 B: the hash primes with xor, or (res, res^2) with +
+    uint32_t mask;          // table - 1 for power-of-two tables, else ~0 (then `limit` catches what the reference's modulo wraps)
+    uint32_t limit;         // an index >= limit takes the modulo: the table size when it is not a power of two, else ~0 (never)
+    uint32_t byte_off;      // of the level's first entry from the table's base (8-byte entries)
+    uint32_t flags;         // 1: hashed (xor), 2: empty level (HashEncoder.fused_offsets pads a grid of fewer levels: zero features)
+    uint32_t table;
+};
+template <bool GATHER> struct GatherArgs {};
+template <> struct GatherArgs<true> { const float *x01; const int32_t *offsets; float scale[16]; int stagger; };
+
+template <bool WIDE, bool GATHER = false>
 __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restrict__ x, const float *__restrict__ feat, const uint16_t *__restrict__ W0f,
                                                             const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
                                                             const float *__restrict__ biasg, int d_out, int select, uint64_t select_mask,
                                                             float *__restrict__ out_min, float *__restrict__ out_raw, int64_t B, hsGate gate,
-                                                            int feat_level_major, int lo_plane, WideArgs<WIDE> wide) {
+                                                            int feat_level_major, int lo_plane, WideArgs<WIDE> wide, GatherArgs<GATHER> ga = {}) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     if (gate.a != nullptr && !(*gate.a > *gate.b)) return;
 #ifdef HS_SDF2_PROFILE
@@ -86,6 +292,27 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
                                              (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
         }
         for (int i = threadIdx.x; i < kBias; i += kThreadsW) bias[i] = biasg[i];
+        if constexpr (GATHER) {     // the sixteen levels' geometry (hash_encode.hip: level_info / cell_index), once per workgroup
+            if (threadIdx.x < 16) {
+                GatherLevel gl;
+                const uint32_t off = (uint32_t)ga.offsets[threadIdx.x], table = (uint32_t)ga.offsets[threadIdx.x + 1] - off;
+                gl.scale = ga.scale[threadIdx.x];
+                const uint32_t res = (uint32_t)ceilf(gl.scale) + 1u;
+                uint32_t stride = 1;
+#pragma unroll
+                for (int d = 0; d < 3; d++)
+                    if (stride <= table) stride *= res;
+                const bool hashed = stride > table, pow2 = (table & (table - 1u)) == 0u, empty = table == 0u;
+                gl.A = hashed ? 2654435761u : res;
+                gl.B = hashed ? 805459861u : res * res;
+                gl.mask = empty ? 0u : (pow2 ? table - 1u : 0xffffffffu);
+                gl.limit = (pow2 || empty) ? 0xffffffffu : table;
+                gl.byte_off = empty ? 0u : off * 8u;
+                gl.flags = (hashed ? 1u : 0u) | (empty ? 2u : 0u);
+                gl.table = table;
+                reinterpret_cast<GatherLevel *>(bias + kBias)[threadIdx.x] = gl;
+            }
+        }
     }
     __syncthreads();            // the bias block (layer 0 initialises its accumulators from it); the weight image is still landing
     bool resident = false;      // this wave has passed the rendezvous that makes the LDS weights visible
@@ -107,20 +334,38 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
         {
             float v[40];
             const float x0 = ok ? x[gp * 3] : 0.f, x1 = ok ? x[gp * 3 + 1] : 0.f, x2 = ok ? x[gp * 3 + 2] : 0.f;
-            const float xs[3] = {x0, x1, x2};
+            auto posenc = [&]() {
+                const float xs[3] = {x0, x1, x2};
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float f = h ? (float)(8 << k) : (float)(1 << k);    // octave 3h + k
+                for (int k = 0; k < 3; k++) {
+                    const float f = h ? (float)(8 << k) : (float)(1 << k);    // octave 3h + k
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    float sn, cs;
-                    __sincosf(xs[d] * f, &sn, &cs);
-                    v[6 * k + d] = sn;
-                    v[6 * k + 3 + d] = cs;
+                    for (int d = 0; d < 3; d++) {
+                        float sn, cs;
+                        __sincosf(xs[d] * f, &sn, &cs);
+                        v[6 * k + d] = sn;
+                        v[6 * k + 3 + d] = cs;
+                    }
                 }
-            }
+            };
+            if constexpr (!GATHER) posenc();
             uint32_t fw[8];
-            if (feat_level_major == 2) {     // feat: uint32 [16, B], the two channels of a level as bf16 (hs_hash_fwd, hsHashLayout::out_bf16):
+            if constexpr (GATHER) {
+                // Left alone, a compute unit's eight waves issue their first tiles' reads together, the addresser serves them interleaved, they all
+                // return together and the waves walk gather | trunk | gather | trunk in lockstep: the units take turns (measured: 69 us = the
+                // gather's 37 + the trunk's 32).  Wave w starts its first gather w x stagger later, so the reads reach the (in-order) addresser
+                // wave after wave and wave 0 is in its matrix products while wave 1's reads are served.
+                if (!resident && ga.stagger > 0)
+                    for (int i = 0; i < wave * ga.stagger; i++) __builtin_amdgcn_s_sleep(8);       // 512 clocks per unit
+                if constexpr (HS_SWEEP_PAIR)
+                    gather_words_pair(fw, ga.x01, reinterpret_cast<const char *>(feat), reinterpret_cast<const GatherLevel *>(bias + kBias), tile * kRows, B, lane,
+                                      posenc, tile >= (int64_t)gridDim.x * kWaves ? 4 : 0);
+                else
+                    gather_words(fw, ga.x01, reinterpret_cast<const char *>(feat), reinterpret_cast<const GatherLevel *>(bias + kBias) + 8 * h, gp, ok, posenc,
+                                 tile >= (int64_t)gridDim.x * kWaves ? 4 : 0);
+#pragma unroll
+                for (int j = 18; j < 34; j++) v[j] = 0.f;
+            } else if (feat_level_major == 2) {     // feat: uint32 [16, B], the two channels of a level as bf16 (hs_hash_fwd, hsHashLayout::out_bf16):
                                              // the words ARE this lane's feature inputs (levels 8 h .. 8 h + 7), no conversion
                 const uint32_t *fl = reinterpret_cast<const uint32_t *>(feat) + (size_t)(8 * h) * B + (ok ? gp : 0);
 #pragma unroll
@@ -157,7 +402,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_sdf_mlp2(const float *__restri
             v[37] = v[38] = v[39] = 0.f;
 #pragma unroll
             for (int j = 0; j < 40; j += 2) hin[j >> 1] = pack2(v[j], v[j + 1]);
-            if (feat_level_major == 2) {
+            if (GATHER || feat_level_major == 2) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) hin[9 + i] = fw[i];
             }
@@ -380,6 +625,45 @@ int hs_sdf_mlp2_fwd(const float *x, const float *feat, const void *W0f, const vo
     k_sdf_mlp2<false><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, d_out,
                                                                       select, select_mask, out_min, out_raw, B, gate ? *gate : hsGate{nullptr, nullptr},
                                                                       feat_level_major, planes == 2, WideArgs<false>{});
+    return wt_check_launch();
+}
+
+// The sampler's sweep as ONE launch: hash gather inside the wave tile (k_sdf_mlp2<WIDE, true>).  One table of 16 levels x 2 channels (a grid of
+// fewer levels: HashEncoder.fused_offsets' empty levels), 3-D points; W2f_b / bias_b: the second output tile's pack for 33..64 outputs, else NULL.
+int hs_sdf_sweep_fwd(const float *x, const float *x01, const float *embeddings, const int32_t *offsets, float S, uint32_t H, const void *W0f,
+                     const void *W1f, const void *W2f, const float *bias, const void *W2f_b, const float *bias_b, int32_t d_out, int32_t select,
+                     uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate, void *stream) {
+    const bool wide = d_out > 32;
+    if (d_out < 1 || d_out > 64 || select >= d_out) return HS_ERR_ARG;
+    if (select_mask && d_out < 64 && (select_mask >> d_out)) return HS_ERR_ARG;
+    if (B == 0) return HS_OK;
+    if (!x || !x01 || !embeddings || !offsets || !W0f || !W1f || !W2f || !bias || !out_min || (wide && (!W2f_b || !bias_b))) return HS_ERR_NULL;
+    if ((const char *)W2f != (const char *)W1f + (size_t)kW1F * 2) return HS_ERR_ARG;
+    const size_t lds = (size_t)(kW1F + kW2F) * sizeof(uint16_t) + kBias * sizeof(float) + 16 * sizeof(GatherLevel);
+    const int64_t ntiles = (B + kRows - 1) / kRows;
+    const int64_t want = (ntiles + kWaves - 1) / kWaves;
+    const int grid = (int)(want < 256 ? want : 256);
+    static const int planes = [] { const char *e = getenv("HOLOSCENE_SDF_W2_PLANES"); return (e && e[0] == '2') ? 2 : 1; }();
+    GatherArgs<true> ga;
+    ga.x01 = x01;
+    ga.offsets = offsets;
+    static const int stagger = [] { const char *e = getenv("HOLOSCENE_SWEEP_STAGGER"); return e ? atoi(e) : 4; }();      // units of 512 clocks per wave index
+    ga.stagger = stagger;
+    for (int l = 0; l < 16; l++) ga.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;      // hash_encode.hip: make_scales (hashencoder.cu:152)
+    const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
+    if (wide) {
+        static hsLdsAttrOnce attr;
+        attr.set((const void *)k_sdf_mlp2<true, true>, (int)lds);
+        k_sdf_mlp2<true, true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, embeddings, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias,
+                                                                              d_out, select, select_mask, out_min, out_raw, B, g, 2, planes == 2,
+                                                                              WideArgs<true>{(const uint16_t *)W2f_b, bias_b}, ga);
+    } else {
+        static hsLdsAttrOnce attr;
+        attr.set((const void *)k_sdf_mlp2<false, true>, (int)lds);
+        k_sdf_mlp2<false, true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, embeddings, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias,
+                                                                               d_out, select, select_mask, out_min, out_raw, B, g, 2, planes == 2,
+                                                                               WideArgs<false>{}, ga);
+    }
     return wt_check_launch();
 }
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ float max(float v) {     // the same value on every l
 // is bound by its instruction count (11 evaluations per ray and round, two scans and a maximum each).
 __device__ __forceinline__ void incl_scan2(float &a, float &b) {
     asm volatile(
-        "s_nop 1\n\t"
+        "s_nop 4\n\t"      /* 5 wait states: covers VALU-writes-EXEC -> DPP as well as VALU-write -> DPP read (the hazard recogniser does not see inside the block) */
         "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 0\n\t"
@@ -72,7 +72,7 @@ __device__ __forceinline__ void incl_scan2(float &a, float &b) {
 
 __device__ __forceinline__ float max_dpp(float v) {     // hs_wave::max for values that are not NaN on any lane (v_max_f32 then IS fmaxf)
     asm volatile(
-        "s_nop 1\n\t"
+        "s_nop 4\n\t"      /* 5 wait states: covers VALU-writes-EXEC -> DPP as well as VALU-write -> DPP read (the hazard recogniser does not see inside the block) */
         "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"

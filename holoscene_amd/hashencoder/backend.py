@@ -156,7 +156,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -672,6 +672,28 @@ class _HipBackend:
         _check(lib.hs_sdf_mlp2_fwd(_dev(x, "x"), _dev(feat, "feat", torch.int32 if int(feat_level_major) == 2 else torch.float32), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
                                    d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), int(feat_level_major), _stream()), "hs_sdf_mlp2_fwd")
+
+    @staticmethod
+    def sdf_sweep_fwd(x, x01, embeddings, offsets, S, H, packed, packed_b, d_out, select, out_min, out_raw, gate=None):
+        """hs_sdf_sweep_fwd: hash gather + SDF trunk of one sampler sweep in one launch (16 levels x 2 channels; packed_b: the second output tile's pack
+        for 33..64 outputs).  Bit-identical to fwd(out_bf16=True) + sdf_mlp2_fwd / _wide."""
+        lib = load_library()
+        bf = torch.bfloat16
+        mask = 0
+        if isinstance(select, (list, tuple)):
+            if not select or min(select) < 0 or max(select) >= d_out:
+                raise ValueError(f"object subset {select!r} outside [0, {d_out})")
+            for k in select:
+                mask |= 1 << int(k)
+            select = -1
+        if offsets.numel() != 17 or embeddings.dim() != 2 or embeddings.shape[1] != 2:
+            raise RuntimeError("sdf_sweep_fwd: one table of 16 levels (offsets [17]) x 2 channels")
+        W0f, W1f, W2f, bias = packed
+        _check(lib.hs_sdf_sweep_fwd(_dev(x, "x"), _dev(x01, "x01"), _dev(embeddings, "embeddings"), _dev(offsets, "offsets", torch.int32), ctypes.c_float(S), int(H),
+                                    _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf), _dev(bias, "bias"),
+                                    _dev(packed_b[2], "W2f_b", bf) if packed_b is not None else None, _dev(packed_b[3], "bias_b") if packed_b is not None else None,
+                                    d_out, select, ctypes.c_uint64(mask), _dev(out_min, "out_min"), _dev(out_raw, "out_raw"),
+                                    ctypes.c_int64(x.shape[0]), ctypes.byref(_gate(gate)), _stream()), "hs_sdf_sweep_fwd")
 
     @staticmethod
     def sdf_mlp2_fwd_wide(x, feat, packed, packed_b, d_out, select, out_min, out_raw, gate=None, feat_level_major=False):

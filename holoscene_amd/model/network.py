@@ -143,6 +143,10 @@ TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
 # inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
 # activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
 SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
+# the sampler's sweeps gather their hash features inside the trunk kernel (hs_sdf_sweep_fwd: one launch per sweep, bit-identical).  Built in round 6 and
+# MEASURED SLOWER than the two launches (gather 31 + trunk 32 us -> 70 us one lane per point, 80 us two lanes per point; profiles/r06/fused_sweep.txt,
+# DESIGN 15.2): at the trunk's two waves per SIMD the gather's index arithmetic and reads run serially in front of the matrix products.  Default off.
+SDF_SWEEP_FUSED = os.environ.get("HOLOSCENE_SDF_SWEEP_FUSED", "0") != "0"
 SDF_WIDE = os.environ.get("HOLOSCENE_SDF_WIDE", "1") != "0"     # 33..64 objects: sampler sweeps on the wave-tile kernel (0: workgroup-tile kernel, A/B)
 # the no-grad SDF queries of the fp32 configuration: "mfma" = csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32), "gemm" = library GEMMs
 FP32_SDF = os.environ.get("HOLOSCENE_FP32_SDF", "mfma")
@@ -1441,6 +1445,8 @@ def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
     dens = model.density
     dev = dens.beta.device
     if not lins or dev.type != "cuda" or dens.beta.dtype != torch.float32:
+        if zero is not None:        # FlatAdam.zero_grad(defer=True) left this range to the prologue launch: the fallback must clear it itself
+            zero.zero_()
         with dens.shared_beta(), shared_effective_weights(model.weight_norm_layers()):
             yield None
         return
@@ -1856,6 +1862,17 @@ class ObjectImplicitNetworkGrid(nn.Module):
         # ... and as bf16 words [L, R*S] when the wave-tile trunk kernel follows: it rounds the features to bf16 anyway (same rounding:
         # identical results), so the gather writes and the trunk reads half the bytes
         words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= (64 if SDF_WIDE else 32) and enc.embeddings.shape[1] == 2 and self.mlp_bf16
+        if words and SDF_SWEEP_FUSED and enc.level_dim == 2 and enc.fused_offsets.numel() == 17 and (d_out <= 32 or SDF_WIDE):
+            # ONE launch per sweep: every lane of the trunk's wave tile gathers the eight levels of its own point (csrc/sdf_mlp2.hip: k_sdf_mlp2<., true>);
+            # bit-identical to the gather + trunk pair below
+            out = torch.empty(R, S, device=dev)
+            if d_out <= 32:
+                pa, pb = self._packed_weights2(), None
+            else:
+                pa, pb = self._packed_weights2_wide()
+            be.sdf_sweep_fwd(x, x01, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), pa, pb, d_out, select,
+                             out, None, gate=gate)
+            return out
         if words:
             feat = torch.empty(L, R * S, device=dev, dtype=torch.int32)
             be.fwd(x01, enc.embeddings, enc.fused_offsets, feat, R * S, 3, C, L, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), None,
@@ -2155,8 +2172,9 @@ class HoloSceneNetwork(nn.Module):
             if K != net.d_out:
                 out.append(f"trunk output width {K} != d_out {net.d_out}: rendered samples on the library-GEMM value+Jacobian path")
             elif K > 32:
-                out.append(f"d_out = {K} > 32: SDF sweeps, rendered samples and Eikonal points on the 128-point workgroup-tile kernels (four value+Jacobian rows per "
-                           "point) instead of the wave-tile / reverse-over-reverse kernels; per-call weight packing")
+                out.append(f"d_out = {K} > 32: sampler sweeps and the trunk forward on the two-output-tile wave kernels (k_sdf_mlp2<true>, k_trunk_fwd2<true, true>: "
+                           "four value+Jacobian rows per rendered sample instead of reverse-over-reverse), the trunk backward on the 128-point workgroup-tile "
+                           "kernel (k_trunk_bwd<64>) with library weight-gradient GEMMs; per-call weight packing")
         probe = self.density.beta
         if probe.is_cuda and not self._fused_appearance_supported(probe):
             out.append("colour branch on library GEMMs: it is not the stock one (idr mode, four layers of 256, 4 frequencies each, 16 x 2 colour grid, "

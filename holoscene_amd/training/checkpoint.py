@@ -72,15 +72,43 @@ def load_optimizer_state(trainer, optimizer_state_dict, scheduler_state_dict):
     return n
 
 
+def _gather_rng_states(trainer):
+    """[world, 3] int64 on the CPU: every rank's (seed, counter, scratch) of the model's device-resident Philox stream, or None when the model has
+    not drawn yet.  Ranks reseed after the common initialisation (trainer.py: seed + 7919 (rank + 1)) so that their ray jitter, inverse-CDF and
+    Eikonal draws differ; a checkpoint that kept only the writing rank's stream would hand that ONE stream to every rank of the resumed run."""
+    rng = getattr(trainer.model, "_rng_state", None)
+    world = int(getattr(trainer, "world_size", 1) or 1)
+    if world > 1 and getattr(trainer, "dp", False):
+        import torch.distributed as dist
+        mine = (torch.full((3,), -1, dtype=torch.int64) if rng is None else rng.detach().cpu().to(torch.int64)).to(trainer.device if dist.get_backend() == "nccl" else "cpu")
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        allr = torch.stack([r.cpu() for r in rows])
+        return None if bool((allr[:, 0] < 0).any()) else allr
+    return None if rng is None else rng.detach().cpu().to(torch.int64).view(1, 3)
+
+
+def _restore_rng_state(trainer, saved):
+    """Row `rank` of a [world, 3] state saved at the same world size; anything else (another world size, the one-row form of an older checkpoint
+    loaded by several ranks) leaves the streams the ranks seeded for themselves: correlated draws across ranks would be worse than a restart."""
+    saved = saved.view(-1, 3)
+    world, rank = int(getattr(trainer, "world_size", 1) or 1), int(getattr(trainer, "rank", 0) or 0)
+    if saved.shape[0] != world:
+        import warnings
+        warnings.warn(f"checkpoint holds {saved.shape[0]} draw stream(s), this run has {world} rank(s): keeping the freshly seeded per-rank streams")
+        return
+    trainer.model.rng_state(trainer.device).copy_(saved[rank].to(trainer.device))
+
+
 def save_checkpoints(trainer, checkpoints_path, epoch, write=True):
     """Under data parallelism EVERY rank calls this (the ZeRO-1 moment gather is a collective); pass write=(rank == 0)."""
     opt_sd, sched_sd = optimizer_state_dicts(trainer)
+    rng = _gather_rng_states(trainer)                      # a collective under data parallelism: before the non-writing ranks leave
     if not write:
         return
     model_payload = {"epoch": epoch, "model_state_dict": trainer.model.state_dict()}
-    rng = getattr(trainer.model, "_rng_state", None)       # the device-resident Philox stream of the iteration's draws (hs_iter_prologue): an extra
-    if rng is not None:                                     # key the reference's loader ignores; without it a resumed run restarts the draw stream
-        model_payload["hs_rng_state"] = rng.detach().cpu()
+    if rng is not None:         # the device-resident Philox streams of the iteration's draws (hs_iter_prologue), one row per rank: an extra key
+        model_payload["hs_rng_state"] = rng                # the reference's loader ignores; without it a resumed run restarts the draw stream
     payloads = {MODEL_DIR: model_payload,
                 OPTIMIZER_DIR: {"epoch": epoch, "optimizer_state_dict": opt_sd},
                 SCHEDULER_DIR: {"epoch": epoch, "scheduler_state_dict": sched_sd}}
@@ -96,7 +124,7 @@ def load_checkpoints(trainer, checkpoints_path, checkpoint="latest", map_locatio
     saved = torch.load(os.path.join(checkpoints_path, MODEL_DIR, str(checkpoint) + ".pth"), map_location=dev)
     trainer.model.load_state_dict({k.replace("module.", ""): v for k, v in saved["model_state_dict"].items()})
     if "hs_rng_state" in saved and hasattr(trainer.model, "rng_state"):
-        trainer.model.rng_state(trainer.device).copy_(saved["hs_rng_state"].to(trainer.device))
+        _restore_rng_state(trainer, saved["hs_rng_state"])
     opt = torch.load(os.path.join(checkpoints_path, OPTIMIZER_DIR, str(checkpoint) + ".pth"), map_location=dev)
     sched = torch.load(os.path.join(checkpoints_path, SCHEDULER_DIR, str(checkpoint) + ".pth"), map_location=dev)
     trainer.iter_step = load_optimizer_state(trainer, opt["optimizer_state_dict"], sched["scheduler_state_dict"])

@@ -127,7 +127,8 @@ class FlatAdam:
         if tables:
             self._g_alloc.zero_()
         elif defer:     # the caller clears this range itself before any gradient is produced (hs_iter_prologue's zero range: no launch of its own)
-            deferred = self._g_alloc[self.offsets[self.n_tables]:]        # (the first small parameter starts a 16-byte quad; the pads before it are never written)
+            first_small = self.offsets[self.n_tables] if self.n_tables < len(self.offsets) else self.tables_end     # (no small parameter at all: the pool only)
+            deferred = self._g_alloc[first_small:]        # (the first small parameter starts a 16-byte quad; the pads before it are never written)
         else:
             self._g_alloc[self.tables_end:].zero_()
         _be.set_zero_pool(self._g_alloc[self.padded:])

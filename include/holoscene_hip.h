@@ -400,6 +400,15 @@ int64_t hs_sdf_mlp2_pack_bytes(int32_t which);
 int hs_sdf_mlp2_pack(const float *W0, int32_t ld0, const float *b0, const float *W1, const float *b1, const float *W2, const float *b2, int32_t d_out,
                      void *W0f, void *W1f, void *W2f, float *bias, int32_t log2_domain /* 1: hs_sdf_mlp2_fwd; 0: hs_trunk_mlp2_fwd */, void *stream);
 
+/* The sampler's per-round SDF query as ONE launch (ErrorBoundSampler.get_z_vals' `model.implicit_network.get_sdf_vals(points)`, ray_sampler.py:151-157
+ * = HashEncoder.forward hashgrid.py:154 + the SDF branch of ObjectImplicitNetworkGrid.forward network.py:169-210): hs_hash_fwd(out_bf16) and
+ * hs_sdf_mlp2_fwd / _wide in one kernel -- every lane gathers the eight levels of its own point that it feeds to the first layer.  Bit-identical to the
+ * two launches.  x [B,3] world positions, x01 [B,3] grid coordinates, embeddings [offsets[16], 2] fp32, offsets int32 [17] (empty levels allowed behind
+ * the grid's own), S / H as hs_hash_fwd; the packs as hs_sdf_mlp2_fwd; W2f_b / bias_b: second output tile's pack when 32 < d_out <= 64, else NULL. */
+int hs_sdf_sweep_fwd(const float *x, const float *x01, const float *embeddings, const int32_t *offsets, float S, uint32_t H, const void *W0f,
+                     const void *W1f, const void *W2f, const float *bias, const void *W2f_b, const float *bias_b, int32_t d_out, int32_t select,
+                     uint64_t select_mask, float *out_min, float *out_raw, int64_t B, const hsGate *gate /* NULL = none */, void *stream);
+
 /* Training form of the wave-tile kernel (csrc/trunk_mlp2.hip; d_out <= 32, L*C = 32, 6 encoding octaves): the value+Jacobian trunk pass of
  * hs_trunk_mlp_fwd below, same rows (4 per point: value, d/dx, d/dy, d/dz) and the same saved tensors for hs_trunk_mlp_bwd -- H0, H1
  * [M,256] bf16 row-major layer OUTPUTS, Y [M,d_out] f32 -- built straight from x [M/4,3], feat [M/4,32] (point-major) and dydx [L,M/4,3C]

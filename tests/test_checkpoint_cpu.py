@@ -68,3 +68,77 @@ def test_fresh_flat_optimizer_saves_an_empty_adam_state(tmp_path):
     other = _trainer("flat")
     ck.load_checkpoints(other, str(tmp_path), 0)
     assert other.flat.read_state().step == 0 and float(other.flat.flat_m.abs().max()) == 0.0
+
+
+# ---- the device-resident draw stream in a checkpoint: one row per data-parallel rank
+class _StreamModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(2))
+
+    def rng_state(self, device):
+        if getattr(self, "_rng_state", None) is None:
+            self._rng_state = torch.tensor([int(torch.randint(0, 2 ** 62, (1,)).item()), 0, 0], dtype=torch.int64)
+        return self._rng_state
+
+
+class _StreamTrainer:
+    def __init__(self, world_size=1, rank=0):
+        self.model, self.world_size, self.rank, self.dp, self.device = _StreamModel(), world_size, rank, world_size > 1, "cpu"
+
+
+def test_single_process_stream_round_trips_and_other_world_sizes_keep_their_own_streams():
+    a = _StreamTrainer()
+    a.model.rng_state("cpu")[1] = 41
+    saved = ck._gather_rng_states(a)
+    assert saved.shape == (1, 3) and int(saved[0, 1]) == 41
+    b = _StreamTrainer()
+    ck._restore_rng_state(b, saved)
+    assert torch.equal(b.model.rng_state("cpu"), a.model.rng_state("cpu"))
+    # the one-row state of a single-process (or pre-fix) checkpoint must NOT be handed to every rank of a two-rank run
+    c = _StreamTrainer(world_size=2, rank=1)
+    mine = c.model.rng_state("cpu").clone()
+    import pytest
+    with pytest.warns(UserWarning, match="draw stream"):
+        ck._restore_rng_state(c, saved.view(3))          # (the old 1-D form)
+    assert torch.equal(c.model.rng_state("cpu"), mine)
+
+
+def _stream_worker(rank, world, port, path, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5 + 7919 * (rank + 1))       # trainer.py: every rank reseeds after the common initialisation
+    tr = _StreamTrainer(world, rank)
+    tr.model.rng_state("cpu")[1] = 100 + rank      # ranks have advanced their counters differently
+    allr = ck._gather_rng_states(tr)               # what save_checkpoints stores (every rank calls it; rank 0 writes)
+    if rank == 0:
+        torch.save({"hs_rng_state": allr}, path)
+    dist.barrier()
+    fresh = _StreamTrainer(world, rank)
+    fresh.model.rng_state("cpu")
+    ck._restore_rng_state(fresh, torch.load(path)["hs_rng_state"])
+    q.put((rank, tr.model.rng_state("cpu").tolist(), fresh.model.rng_state("cpu").tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_resume_their_own_draw_streams(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, str(tmp_path / "rng.pth"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, before0, after0), (_, before1, after1) = got
+    assert after0 == before0 and after1 == before1        # every rank resumes ITS stream ...
+    assert before0[0] != before1[0] and after0 != after1   # ... and they differ (seed and counter)

@@ -2020,3 +2020,51 @@ def test_grid_of_fewer_levels_runs_on_the_fused_sixteen_level_kernels(L, monkeyp
     print(f"PARITY L = {L} grid padded vs explicit 16-level grid: worst gradient relL2 {worst[1]:.3e} ({worst[0]})")
     assert worst[1] < 1e-4, worst       # (table scatters: float-atomic order)
     assert gb["implicit_network.lin0.weight_v"].grad.shape == (256, 39 + 2 * L)
+
+
+@pytest.mark.parametrize("d_out,levels,logmap,end_size,B", [(32, 16, 19, 2048, 131072), (21, 16, 15, 512, 1000), (64, 16, 19, 2048, 65536 + 33), (40, 16, 15, 512, 65),
+                                                            (3, 8, 15, 256, 4099)])
+def test_sweep_with_the_gather_inside_is_bit_identical_to_gather_plus_trunk(d_out, levels, logmap, end_size, B, monkeypatch):
+    """hs_sdf_sweep_fwd (k_sdf_mlp2<., true>: every lane gathers the eight hash levels of its own point) against the two launches it replaces --
+    hs_hash_fwd(out_bf16) + hs_sdf_mlp2_fwd / _wide -- through the sampler's entry point: bit for bit, for the minimum over all objects, one
+    object, a subset; stock grid (dense levels 0-4 with tables that are not powers of two, hashed levels above), a grid of fewer levels (empty
+    levels behind its own), points outside the cube, on its faces (x = 1: the reference's modulo wrap on integer-scale levels) and a ragged tail."""
+    from holoscene_amd.hashencoder import backend as be_mod
+    from holoscene_amd.model import network as N
+    torch.manual_seed(d_out + levels)
+    net = N.ObjectImplicitNetworkGrid(256, 1.0, d_in=3, d_out=d_out, dims=[256, 256], geometric_init=True, bias=0.9, skip_in=[4], multires=6,
+                                      divide_factor=1.0, sigmoid=10, color_grid_feature=True, num_levels=levels, logmap=logmap, end_size=end_size).to(DEV)
+    with torch.no_grad():
+        net.lin0.weight_v[:, 3:].normal_(0, 1e-2)
+        net.encoding.embeddings.uniform_(-0.5, 0.5)
+        net.lin2.weight_v.add_(0.05 * torch.randn_like(net.lin2.weight_v))
+        net.lin2.bias.add_(0.1 * torch.randn_like(net.lin2.bias))
+    net.set_mlp_precision("bf16")
+    x = (torch.rand(B, 3, device=DEV) * 2.4 - 1.2)
+    x[:64] = (torch.randint(0, 2, (64, 3), device=DEV).float() * 2 - 1)         # cube corners: x01 in {0, 1} exactly
+    x[64:128, 0] = 1.0                                                           # a face
+    x01 = ((x / net.divide_factor + 1.0) / 2.0).contiguous()
+    calls = []
+    orig = be_mod._backend.sdf_sweep_fwd
+    monkeypatch.setattr(be_mod._backend, "sdf_sweep_fwd", staticmethod(lambda *a, **k: calls.append(1) or orig(*a, **k)))
+    a, b = torch.tensor([1.0], device=DEV), torch.tensor([2.0], device=DEV)
+    sels = [-1, d_out - 1, 0, [0, d_out - 1] + ([31, 32] if d_out > 33 else [])]
+
+    def queries():
+        net.invalidate_packed_weights()
+        with torch.no_grad():
+            return [net.sdf_at_points(x, x01, 1, B, sel, gate=(b, a)).clone() for sel in sels]
+    monkeypatch.setattr(N, "SDF_SWEEP_FUSED", True)
+    fused = queries()
+    assert len(calls) == len(sels)
+    monkeypatch.setattr(N, "SDF_SWEEP_FUSED", False)
+    pair = queries()
+    assert len(calls) == len(sels)
+    inside = ((x01 >= 0) & (x01 <= 1)).all(-1).float().mean().item()
+    for sel, f, p in zip(sels, fused, pair):
+        same = torch.equal(f, p)
+        print(f"PARITY fused sweep K={d_out} L={levels} B={B} select={sel}: bit-identical to gather + trunk: {same} ({inside:.2f} of the points inside the cube)")
+        assert same, (sel, float((f - p).abs().max()))
+    # a closed gate leaves the output untouched
+    out = net.sdf_at_points(x, x01, 1, B, -1, gate=(a, b))
+    assert out.shape == (1, B)
