@@ -40,6 +40,11 @@ def parse():
     p.add_argument("--levels", type=int, default=16, help="hash-grid levels (BASELINE configs[0]: 8; fewer than 16 run the fused kernels through empty levels)")
     p.add_argument("--end-size", type=int, default=2048, help="finest grid resolution (configs[0]: 256)")
     p.add_argument("--logmap", type=int, default=19, help="log2 of the per-level table size (configs[0]: 15)")
+    p.add_argument("--img-res", type=int, nargs=2, default=[512, 512], metavar=("H", "W"),
+                   help="frame size of the synthetic scene (BASELINE configs[3] / SURVEY 8(d) C4: 584 876, confs/scannetpp/*.conf:41)")
+    p.add_argument("--roofline-counters", action="store_true",
+                   help="measure roofline.other_roof IN THIS RUN: two child runs of this workload under rocprofv3 --pmc (TA_TA_BUSY_sum | SQ_BUSY_CYCLES, "
+                        "--kernel-trace only), ~1 min; skipped when rocprofv3 is absent.  Without it the line carries the committed value as other_roof_committed")
     p.add_argument("--beta", type=float, default=0.001)
     p.add_argument("--lr-scale", type=float, default=1e-6,
                    help="learning-rate multiplier.  The synthetic targets are noise, and at the reference's rates (grid lr 1e-2 per step on "
@@ -365,6 +370,48 @@ class KernelTimers:
         return out
 
 
+def measure_other_roof(args, kernel):
+    """The texture addresser's busy fraction over the dominant gather kernel's own cycles, measured now: this workload twice more as a child process
+    under `rocprofv3 --pmc <one set> --kernel-trace` (the microarchitecture guide's recipe: counters in their own passes, no other trace domain).
+    TA_TA_BUSY_sum is summed over the 256 addressers, SQ_BUSY_CYCLES over the 32 shader engines; both averaged over the kernel's dispatches."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--rays", str(args.rays), "--samples", str(args.samples), "--objects", str(args.objects),
+             "--levels", str(args.levels), "--end-size", str(args.end_size), "--logmap", str(args.logmap), "--beta", str(args.beta), "--precision", args.precision,
+             "--img-res", str(args.img_res[0]), str(args.img_res[1]), "--no-cpu-baseline", "--no-second-point", "--no-fp32-point", "--no-trajectory-point",
+             "--roofline-steps", "0", "--steps", "12", "--warmup", "2"]
+    avg = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for i, cs in enumerate((["TA_TA_BUSY_sum", "TA_TOTAL_WAVEFRONTS_sum"], ["SQ_BUSY_CYCLES", "SQ_INSTS_VALU"])):
+            out = os.path.join(tmp, f"p{i}")
+            r = subprocess.run(["rocprofv3", "--pmc", *cs, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", *child], cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if kernel.split("<")[0] in row["Kernel_Name"] and "false" in row["Kernel_Name"]:      # the value-only sweeps (no dy_dx)
+                        a = acc.setdefault(row["Counter_Name"], [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(row["Counter_Value"])
+            avg.update({k: v[1] / v[0] for k, v in acc.items() if v[0]})
+    if "TA_TA_BUSY_sum" not in avg or "SQ_BUSY_CYCLES" not in avg:
+        return None
+    cyc = avg["SQ_BUSY_CYCLES"] / 32.0
+    return {"name": "texture addresser busy: TA_TA_BUSY / 256 addressers / kernel cycles (SQ_BUSY_CYCLES / 32)", "frac": round(avg["TA_TA_BUSY_sum"] / 256.0 / cyc, 4),
+            "also": {"valu_issue": round(4.0 * avg.get("SQ_INSTS_VALU", float("nan")) / (1024.0 * cyc), 4),
+                     "ta_cycles_per_wave_instruction": round(avg["TA_TA_BUSY_sum"] / avg["TA_TOTAL_WAVEFRONTS_sum"], 1) if avg.get("TA_TOTAL_WAVEFRONTS_sum") else None,
+                     "kernel_cycles": round(cyc)},
+            "kernel": kernel + " (value-only launches, averaged)", "source": "rocprofv3 --pmc, two child runs of this command (12 steps each)", "measured_in_this_run": True}
+
+
 def cpu_baseline(seconds):
     """The CPU oracle timed twice -- the reference's own setting, torch.set_num_threads(1) (training/holoscene_train.py:46), and all host
     threads -- and the FASTER of the two reported as the baseline (`cores` = the threads it used; at configs[0]'s size the per-op thread
@@ -505,7 +552,7 @@ def main():
     benchmark_model_state(tr.model, args.beta)
     if world > 1:
         dist_util.broadcast_parameters(tr.model)
-    scene = SyntheticScene(args.rays, args.objects, seed=1234 + rank, device=dev)
+    scene = SyntheticScene(args.rays, args.objects, img_res=tuple(args.img_res), seed=1234 + rank, device=dev)
     rounds_seen = []
 
     def step():
@@ -691,10 +738,15 @@ def main():
         gb = json.load(open(gb_file))
         key = next((k for k in gb if "false" in k and "4194304" in k), None) or next(iter(gb), None)
         if key:
-            roofline["other_roof"] = {"name": "texture addresser busy: TA_TA_BUSY / 256 addressers / kernel cycles (SQ_BUSY_CYCLES / 32)", "frac": gb[key]["ta_busy"],
-                                      "also": {k_: gb[key][k_] for k_ in ("tcp_busy", "l1_tag_rate", "valu_issue", "wait_over_wave_cycles")},
-                                      "kernel": key, "source": "profiles/r05/gather_bound.json", "measured_in_this_run": False}
-            roofline["other_roof_frac"] = gb[key]["ta_busy"]
+            # (a value read from a committed counter pass is named as such; --roofline-counters measures `other_roof` in the run, below)
+            roofline["other_roof_committed"] = {"name": "texture addresser busy: TA_TA_BUSY / 256 addressers / kernel cycles (SQ_BUSY_CYCLES / 32)", "frac": gb[key]["ta_busy"],
+                                                "also": {k_: gb[key][k_] for k_ in ("tcp_busy", "l1_tag_rate", "valu_issue", "wait_over_wave_cycles")},
+                                                "kernel": key, "source": "profiles/r05/gather_bound.json", "measured_in_this_run": False}
+    if dom is not None and args.roofline_counters and dom["kernel"].startswith("k_hash_fwd"):
+        measured = measure_other_roof(args, dom["kernel"].split(" ")[0])
+        if measured is not None:
+            roofline["other_roof"] = measured
+            roofline["other_roof_frac"] = measured["frac"]
     roofline["traffic_source"] = traffic_src or "no PMC pass committed for this kernel yet"
     roofline["kernels"] = kernels
     roofline["whole_iteration"] = {
@@ -745,7 +797,7 @@ def main():
                   "sampler_rounds_mean": round(sum(int(r_) for r_ in r2[8:]) / n2, 2)}
     # ---- N = 1: the iteration as a data-parallel rank runs it, minus the collectives (no reduce-and-step: zero-fill, scatters into the
     # gradient tables, Adam sweep over all 24.7 M parameters) -- the single-GPU time an N-rank curve should be quoted against
-    dp_equiv = None
+    dp_equiv = dp_rank_shape = None
     if world == 1 and args.optimizer == "flat" and not args.no_graph and not args.no_second_point:
         tr_p = Stage1Trainer(conf, device=dev, world_size=1, rank=0, seed=42, optimizer="flat", graph=True, table_step=False)
         benchmark_model_state(tr_p.model, args.beta)
@@ -758,6 +810,24 @@ def main():
         barrier()
         dp_equiv = round((time.perf_counter() - t0) / n_p * 1e3, 3)
         del tr_p
+        # ... and at BASELINE configs[2]'s PER-RANK shape (4 096 rays over 8 ranks = 512 rays each): what one rank of the 8-GPU job computes per step before
+        # any exchange cost -- the per-rank denominator of the first real scaling curve (8 x this is the ceiling of configs[2])
+        if args.rays == 1024 and args.samples == 128:
+            conf_r = stock_conf(num_rays=512, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=args.beta,
+                                mlp_precision=args.precision, learning_rate=5.0e-4 * args.lr_scale, eikonal_mode=args.eikonal)
+            tr_r = Stage1Trainer(conf_r, device=dev, world_size=1, rank=0, seed=42, optimizer="flat", graph=True, table_step=False)
+            benchmark_model_state(tr_r.model, args.beta)
+            scene_r = SyntheticScene(512, args.objects, img_res=tuple(args.img_res), seed=1234, device=dev)
+            for i in range(22 + n_p):
+                if i == 22:
+                    barrier()
+                    t0 = time.perf_counter()
+                tr_r.train_step_resident(scene_r)
+            barrier()
+            ms_r = (time.perf_counter() - t0) / n_p * 1e3
+            dp_rank_shape = {"rays_per_rank": 512, "ms_per_step": round(ms_r, 3), "rays_per_s_per_rank": round(512 / ms_r * 1e3, 1),
+                             "note": "configs[2]'s per-rank shape (4 096 rays / 8 ranks) on ONE GPU, optimiser path of a data-parallel rank (table_step=False), no collectives"}
+            del tr_r, scene_r
     fp32_point = None
     if not args.no_fp32_point and args.precision == "bf16" and world == 1:
         # the reference's own precision, same workload, reported beside the headline
@@ -794,7 +864,7 @@ def main():
                                    f"iteration also the 32x32 background-patch pass, render_bg_iter=10), beta={args.beta}, lr x{args.lr_scale:g}, "
                                    f"MLP GEMMs {args.precision} (fp32 accumulate, fp32 master weights/hash tables/optimizer)"
                                    + ("" if args.eikonal == "analytic" else ", Eikonal set by 4-tap finite differences (opt-in extra, not the reference's analytic gradients)"),
-                       "rays_per_gpu": args.rays, "sampler_rounds_mean": round(rounds_mean, 2),
+                       "rays_per_gpu": args.rays, "frame": f"{args.img_res[0]} x {args.img_res[1]}", "sampler_rounds_mean": round(rounds_mean, 2),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
@@ -812,6 +882,8 @@ def main():
             line["config"]["dp_equivalent_single_gpu_ms"] = dp_equiv
             line["config"]["dp_equivalent_single_gpu_note"] = ("mean ms per step of the same trainer with table_step=False: the optimiser path every "
                                                                "data-parallel rank runs (gradient tables zero-filled, scattered into, swept by Adam), no collectives")
+        if dp_rank_shape is not None:
+            line["config"]["dp_rank_shape"] = dp_rank_shape
         if world > 1:
             line["config"]["rccl_world_size"] = rccl_world
             line["config"]["exchange"] = exchange_form

@@ -222,3 +222,129 @@ def test_trainer_overlapped_exchange_in_graph_equals_single_process():
             # (tools/exp/dp_overlap_check.py).  Two iterations cover both graph variants; a segment that missed its update, or
             # stepped from a stale gradient, is an O(1) error at any horizon.
             assert float(np.mean(err)) <= 5e-2 * float(np.mean(np.abs(want))) + 1e-9, (label, name, float(np.mean(err)), scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL trainer at world size 8 without an 8-GPU node: eight ranks share the one GPU over `gloo` (RCCL refuses duplicate devices, so the
+# collectives cannot be captured: the exchange runs serially after the whole-iteration graph -- the form an RCCL run falls back to when its probe
+# fails -- over the same three-segment ZeRO-1 layout).  Stock-size tables: 12 196 216 floats per grid (6 098 108 entries x 2; not a multiple of 8 ranks x 4
+# floats), so shard bounds, staging slices, the sharded moments and the checkpoint export are exercised at the sizes an 8-GPU run has.
+# Parity: after every step each rank's parameters equal Adam applied to the MEAN of the eight ranks' gradients -- the mean formed
+# independently here by one all_reduce of the gradients each rank recorded before the exchange touched them.
+def _trainer8_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from holoscene_amd.training import checkpoint as ck
+    from holoscene_amd.training import distributed as dist_util
+    from holoscene_amd.training import trainer as trainer_mod
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    conf = stock_conf(num_rays=128, S=32, d_out=4, num_levels=16, end_size=2048, logmap=19, beta=0.05, mlp_precision="bf16")
+    tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, optimizer="flat", graph=True, exchange="overlap")
+    benchmark_model_state(tr.model, 0.05)
+    dist_util.broadcast_parameters(tr.model)
+    flat = tr.flat
+    info = {"overlap": bool(tr._overlap), "segments": list(flat.segments), "shards": list(flat.shards), "padded": int(flat.padded),
+            "moments": int(flat.flat_m.numel()), "table_step": bool(tr._table_step), "seg_mod": [(e - b) % world for b, e in flat.segments],
+            "table_numel": [int(p.numel()) for p in flat.params[:flat.n_tables]], "n_params": sum(int(p.numel()) for p in flat.params)}
+    # reference optimiser state, kept in full on every rank: torch ops, Adam's textbook form (training/holoscene_train.py:156-169: betas (0.9, 0.99), eps 1e-15)
+    m_ref, v_ref = torch.zeros(flat.padded, device=dev), torch.zeros(flat.padded, device=dev)
+    lr_of = torch.empty(flat.padded, device=dev)
+    st0 = flat.read_state()
+    ends = [int(st0.group_end[0]), int(st0.group_end[1]), flat.padded]
+    lo = 0
+    for g_, hi in enumerate(ends):
+        lr_of[lo:hi] = float(st0.lr0[g_])
+        lo = hi
+    errs, rec = [], {}
+    orig = dist_util.exchange_and_step_flat
+
+    def recording(fl, ws, zero1=True, group=None, done=()):
+        rec["p"], rec["g"] = fl.flat_p.clone(), fl.flat_g.clone()
+        orig(fl, ws, zero1=zero1, group=group, done=done)
+    trainer_mod.dist_util.exchange_and_step_flat = recording
+    scene = SyntheticScene(128, 4, img_res=(64, 64), num_frames=3, ring=4, seed=1234 + rank, device=dev)
+    steps = 3
+    for t in range(1, steps + 1):
+        tr.train_step_resident(scene)
+        torch.cuda.synchronize()
+        g_mean = rec["g"].clone()
+        dist.all_reduce(g_mean)
+        g_mean /= world
+        m_ref.mul_(0.9).add_(g_mean, alpha=0.1)
+        v_ref.mul_(0.99).addcmul_(g_mean, g_mean, value=0.01)
+        gamma = 0.1 ** (1.0 / flat_decay_steps(tr))
+        lr = lr_of * gamma ** (t - 1)
+        want = rec["p"] - lr * (m_ref / (1 - 0.9 ** t)) / ((v_ref / (1 - 0.99 ** t)).sqrt() + 1e-15)
+        upd = (want - rec["p"]).abs()
+        err = (flat.flat_p - want).abs()
+        mask = torch.zeros(flat.padded, dtype=torch.bool, device=dev)
+        for p_, off in zip(flat.params, flat.offsets):
+            mask[off:off + p_.numel()] = True
+        errs.append((float(err[mask].max()), float(upd[mask].max()), float((err[mask] > 1e-3 * upd[mask] + 1e-9).float().mean()),
+                     float((rec["g"][mask] != 0).float().mean())))
+    full_m, full_v = flat.gather_moments()        # a collective: every rank
+    mom = (float((full_m - m_ref).abs().max()), float(m_ref.abs().max()), float((full_v - v_ref).abs().max()), float(v_ref.abs().max()))
+    ck.save_checkpoints(tr, tmp, 0, write=(rank == 0))     # ZeRO-1 export: every rank calls (moment gather + per-rank draw streams), rank 0 writes
+    dist.barrier()
+    saved_rng = torch.load(os.path.join(tmp, "ModelParameters", "latest.pth"))["hs_rng_state"]
+    opt_sd = torch.load(os.path.join(tmp, "OptimizerParameters", "latest.pth"))["optimizer_state_dict"]
+    n_state = sum(int(s_["exp_avg"].numel()) for s_ in opt_sd["state"].values())
+    psum = float(flat.flat_p.double().sum())
+    q.put((rank, info, errs, mom, tuple(saved_rng.shape), int(saved_rng[rank, 0]) == int(tr.model.rng_state(dev)[0]), n_state, psum, int(flat.read_state().step)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def flat_decay_steps(tr):
+    return float(tr.decay_steps)
+
+
+def test_real_trainer_eight_ranks_sharing_the_gpu_stock_size_tables(tmp_path):
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer8_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res = []
+    for _ in range(1500):
+        try:
+            res.append(q.get(timeout=1.0))
+            if len(res) == world:
+                break
+        except _queue.Empty:
+            if any(not p.is_alive() and p.exitcode not in (0, None) for p in procs):
+                break
+    assert len(res) == world, f"workers exited early: {[p.exitcode for p in procs]}"
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    info = res[0][1]
+    # the layout of an 8-rank run at the stock grid: three segments (colour table | SDF table | MLPs + beta), no reduce-and-step, sharded moments
+    assert not info["overlap"] and not info["table_step"] and len(info["segments"]) == 3
+    assert info["table_numel"] == [12196216, 12196216] and all(m_ == 0 for m_ in info["seg_mod"])      # segments padded to multiples of the world size
+    covered = 0
+    for s_, (b, e) in enumerate(info["segments"]):
+        n = (e - b) // world
+        for r_ in range(world):
+            assert tuple(res[r_][1]["shards"][s_]) == (b + r_ * n, b + (r_ + 1) * n)
+        covered += e - b
+    assert covered == info["padded"] and info["moments"] == info["padded"] // world
+    for rank, _, errs, mom, rng_shape, rng_mine, n_state, psum, step in res:
+        assert step == 3 and rng_shape == (world, 3) and rng_mine
+        assert n_state == info["n_params"]         # the export holds FULL moments of every parameter although each rank stores an eighth
+        for t, (emax, umax, frac_bad, nz) in enumerate(errs):
+            print(f"PARITY world-8 trainer rank {rank} step {t + 1}: max |p - Adam(mean gradient)| {emax:.3e} (largest update {umax:.3e}), "
+                  f"{frac_bad:.2e} of the elements beyond 1e-3 of their update; {nz:.3f} of the local gradient non-zero")
+            # (a gradient whose eight contributions cancel to the last bits may change sign with the order of summation -- gloo's reduce against the
+            #  all_reduce that formed the reference mean -- and Adam's first steps are sign-like: such an element is off by up to twice its update)
+            assert emax <= 2.1 * umax and frac_bad < 1e-5, (rank, t, emax, umax, frac_bad)
+        assert mom[0] <= 1e-5 * mom[1] + 1e-12 and mom[2] <= 1e-5 * mom[3] + 1e-15, mom
+    assert len({r[7] for r in res}) == 1, "replicas diverged"

@@ -500,3 +500,59 @@ def test_full_size_bf16_gradients_with_aligned_discontinuities(monkeypatch):
         else:
             chk(f"trunk {n} relL2", rl2(a, b), 1.5e-2)       # measured 0.01-1.02 % (lin1.v, lin1.bias at 1.02 %; the other seven <= 0.92 %)
     chk.done()
+
+
+def test_full_size_configs3_frame_584_by_876():
+    """BASELINE configs[3]'s frame (confs/scannetpp/*.conf:41: img_res = [584, 876]; SURVEY 8(d) C4: R = 1 024, S = 128, K = 21 on the shared net) at
+    size, by properties: (1) the on-device pixel draw + row gather over the 511 584-pixel non-square frame equals fancy indexing on an identically
+    seeded scene, every uv inside the frame and the draw reaching both beyond the short side; (2) the fused ray set-up equals rend_util's lift at
+    this frame's intrinsics; (3) the whole-iteration bf16 graph of a K = 21 model runs regular and background-patch iterations on it (the patch
+    origin is drawn from the frame's own extent) with finite loss terms, its first objective within 2 % of the eager iteration on the same batch."""
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    from holoscene_amd.utils import rend_util
+    H, W, R, K = 584, 876, 1024, 21
+    a = SyntheticScene(R, K, img_res=(H, W), num_frames=2, seed=7, device=DEV)
+    b = SyntheticScene(R, K, img_res=(H, W), num_frames=2, seed=7, device=DEV)
+    _, mi, gt = a.next_batch()
+    dst_i = {k: torch.full_like(v, -3) for k, v in mi.items()}
+    dst_g = {k: torch.full_like(v, -3) for k, v in gt.items()}
+    b.write_batch(dst_i, dst_g)
+    seen_u = seen_v = 0.0
+    for _ in range(3):
+        for k in mi:
+            assert torch.equal(mi[k], dst_i[k]), k
+        for k in gt:
+            assert torch.equal(gt[k], dst_g[k]), k
+        uv = dst_i["uv"][0]
+        assert float(uv[:, 0].min()) >= 0 and float(uv[:, 0].max()) <= W - 1 and float(uv[:, 1].min()) >= 0 and float(uv[:, 1].max()) <= H - 1
+        assert len(torch.unique(gt["segs"])) == K                       # the instance-balanced draw (ns_dataset.py:409-430) sees every stripe
+        seen_u, seen_v = max(seen_u, float(uv[:, 0].max())), max(seen_v, float(uv[:, 1].max()))
+        _, mi, gt = a.next_batch()
+        b.write_batch(dst_i, dst_g)
+    assert seen_u > H and seen_v > 0.9 * (H - 1), (seen_u, seen_v)      # columns beyond the short side, rows down to the bottom
+    conf = stock_conf(num_rays=R, S=128, d_out=K, beta=0.001, mlp_precision="bf16")
+    tr = Stage1Trainer(conf, device=DEV, optimizer="flat", graph=True, freeze_parameters=True)
+    benchmark_model_state(tr.model, 0.001)
+    model = tr.model.train()
+    # (2) rays of this frame: k_ray_setup against rend_util.get_camera_params (no pixel jitter: offsets None)
+    rays = model._setup_rays_fused(mi["uv"], None, mi["pose"], mi["intrinsics"], None)
+    dirs_ref, loc_ref = rend_util.get_camera_params(mi["uv"].clone(), mi["pose"], mi["intrinsics"])
+    assert torch.allclose(rays["ray_dirs"], dirs_ref.reshape(-1, 3), atol=2e-6) and torch.allclose(rays["cam_loc"][0], loc_ref.reshape(-1)[:3], atol=1e-7)
+    # (3) iterations 0 (background patch) .. 11 (the next one with a patch is 10) through the whole-iteration graph
+    eager = Stage1Trainer(conf, device=DEV, optimizer="flat", graph=False, freeze_parameters=True)
+    eager.model.load_state_dict(tr.model.state_dict())
+    c = SyntheticScene(R, K, img_res=(H, W), num_frames=2, seed=11, device=DEV)
+    d = SyntheticScene(R, K, img_res=(H, W), num_frames=2, seed=11, device=DEV)
+    torch.manual_seed(5)
+    _, l_e = eager.train_step(*c.next_batch())
+    torch.manual_seed(5)
+    _, l_g = tr.train_step_resident(d)
+    le, lg = float(l_e["loss"]), float(l_g["loss"])
+    print(f"PARITY configs[3] frame 584 x 876, K = 21, iteration 0 (background patch): objective eager {le:.6f} / whole-iteration graph {lg:.6f}")
+    assert np.isfinite(le) and abs(le - lg) <= 2e-2 * abs(le), (le, lg)
+    for i in range(1, 12):
+        _, lo = tr.train_step_resident(d)
+        vals = {k: float(v) for k, v in lo.items() if torch.is_tensor(v) and v.numel() == 1}
+        assert all(np.isfinite(v) for v in vals.values()), (i, vals)
+    assert len(tr._graphs) == 2 and int(torch.as_tensor(tr.model.ray_sampler._rounds).reshape(-1)[0]) >= 1
