@@ -656,13 +656,15 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd_grad(const float *__res
 
 // ---------------------------------------------------------------------------------------------------------------- backward, value part
 // PRIME: the gradient part ran (a0', a1' exist); without it (no cotangent on d min / dx) they are zero
-template <bool PRIME>
+// WIDE (33..64 objects): y~ arrives as two planes [2][n][32]; the second plane's product h1~ += W2b^T y~[32..] takes the fragments of W2Tf_b (the W2^T image of
+// rows 32..63, packed like W2Tf) from memory -- 16 KB, cache-resident; the LDS holds W1^T and the first image
+template <bool PRIME, bool WIDE = false>
 __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *__restrict__ gy, const uint16_t *__restrict__ W2Tf,
                                                                 const uint16_t *__restrict__ W1Tf, const uint16_t *__restrict__ W0Tf,
                                                                 const uint16_t *__restrict__ H0t, const uint16_t *__restrict__ H1t,
                                                                 const uint16_t *__restrict__ A0pt, const uint16_t *__restrict__ A1pt,
                                                                 uint16_t *__restrict__ A0t, uint16_t *__restrict__ A1t, float *__restrict__ g_feat,
-                                                                int64_t n, int64_t ld) {
+                                                                int64_t n, int64_t ld, const uint16_t *__restrict__ W2Tf_b = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t *W1l = lds;
     uint16_t *W2l = lds + kW1F;
@@ -678,11 +680,17 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
         const int64_t gp = tile * kRows + row;
         const bool ok = gp < n;
         // B fragments of the output cotangent: k-step s = objects 16 s + 8 h + 0..7 of this sample
-        uint32_t gin[8];
+        uint32_t gin[WIDE ? 16 : 8];
         {
             const uint4 a = ok ? *reinterpret_cast<const uint4 *>(gy + gp * 32 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
             const uint4 b = ok ? *reinterpret_cast<const uint4 *>(gy + gp * 32 + 16 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
             gin[0] = a.x; gin[1] = a.y; gin[2] = a.z; gin[3] = a.w; gin[4] = b.x; gin[5] = b.y; gin[6] = b.z; gin[7] = b.w;
+            if constexpr (WIDE) {
+                const uint16_t *gy2 = gy + (size_t)n * 32;          // plane 1: objects 32..63
+                const uint4 c = ok ? *reinterpret_cast<const uint4 *>(gy2 + gp * 32 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+                const uint4 d = ok ? *reinterpret_cast<const uint4 *>(gy2 + gp * 32 + 16 + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+                gin[8] = c.x; gin[9] = c.y; gin[10] = c.z; gin[11] = c.w; gin[12] = d.x; gin[13] = d.y; gin[14] = d.z; gin[15] = d.w;
+            }
         }
         uint32_t a1p[64], a0p[64];
         f32x16 acc[2];
@@ -722,6 +730,13 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
             f32x16 &cur = acc[nt & 1];
             cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(0 * NT + nt) * 64], frag_of(gin), zero, 0, 0, 0);
             cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2v[(size_t)(1 * NT + nt) * 64], frag_of(gin + 4), cur, 0, 0, 0);
+            if constexpr (WIDE) {
+                uint32_t zb = 0;
+                asm volatile("" : "+v"(zb));      // opaque zero: the (tile-invariant) fragment loads stay at this point of the tile loop
+                const bf16x8 *W2bv = reinterpret_cast<const bf16x8 *>(W2Tf_b) + lane + zb;
+                cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2bv[(size_t)(0 * NT + nt) * 64], frag_of(gin + 8), cur, 0, 0, 0);
+                cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2bv[(size_t)(1 * NT + nt) * 64], frag_of(gin + 12), cur, 0, 0, 0);
+            }
             static_for<10>([&](auto slc) { epi(slc, cur, a1p, A1t, nt); });
             if constexpr (nt + 2 < NT) load(H1t, A1pt, nt + 2);
         });
@@ -760,16 +775,19 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
 // sums in fp32 (the last layer's bias gradient = their sum: no same-address atomics).  Thread = (row, group of eight columns): two 16-byte
 // loads and ONE 16-byte store per row piece (the first version wrote two bytes per thread: 21 us for 19 MB), column sums in registers,
 // folded over the wave's sixteen rows by shuffles at the end.
+template <int CG>       // column groups of eight per row: 4 (K <= 32) or 8 (K <= 64: gy is then TWO planes [2][n][32], objects 0..31 | 32..63)
 __global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
                                                uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n) {
-    __shared__ float part[4][32];
-    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    constexpr int RP = 256 / CG, RW = 64 / CG;       // rows per pass of the workgroup / of a wave
+    __shared__ float part[4][8 * CG];
+    const int cg = threadIdx.x & (CG - 1), rl = threadIdx.x / CG, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + RP - 1) / RP * RP;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
     const bool vec = (K & 3) == 0;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint16_t *gyp = gy + (size_t)(cg >> 2) * (size_t)n * 32;        // this column group's plane
 #pragma unroll 2
-    for (int64_t r = r0 + rl; r < r1; r += 64) {
+    for (int64_t r = r0 + rl; r < r1; r += RP) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (g_raw) {
             const float *src = g_raw + r * K + 8 * cg;
@@ -790,18 +808,20 @@ __global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, 
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] += v[j];
-        *reinterpret_cast<uint4 *>(gy + r * 32 + 8 * cg) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        *reinterpret_cast<uint4 *>(gyp + r * 32 + 8 * (cg & 3)) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
     if (gb2_part) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
 #pragma unroll
-            for (int off = 4; off < 64; off <<= 1) acc[j] += __shfl_xor(acc[j], off);
-            if (lane < 4) part[wave][8 * lane + j] = acc[j];
+            for (int off = CG; off < 64; off <<= 1) acc[j] += __shfl_xor(acc[j], off);
+            if (lane < CG) part[wave][8 * lane + j] = acc[j];
         }
         __syncthreads();
-        if (threadIdx.x < 32) gb2_part[(size_t)blockIdx.x * 32 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (threadIdx.x < 8 * CG)
+            gb2_part[(size_t)blockIdx.x * (8 * CG) + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
     }
+    (void)RW;
 }
 
 // ================================================================================================================ fused forward
@@ -832,6 +852,11 @@ __device__ __forceinline__ void dma_tiles(const uint16_t *__restrict__ img, char
     }
 }
 
+// WIDE (33..64 objects): the last layer's second 32-row tile after the first, as in k_sdf_mlp2<true> -- its fragments (W2f_b: [high | low] planes of rows
+// 32..63) and biases (bias_b: a pack's bias block whose b2 slots hold rows 32..63) from memory (the LDS is full); the arg-min runs over both tiles (strict <:
+// equal minima keep the lower index); sdf_raw is [n, d_out], the one-hot image two planes [2][n][32]; the arg-min row of W2 (W2tab: 64 rows) is read from
+// memory in two halves of eight k-steps, requested BEFORE the tile's output stores (the vector-memory counter retires in order).
+template <bool WIDE>
 __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict__ x, const float *__restrict__ feat, const float *__restrict__ dydx,
                                                           const uint16_t *__restrict__ W0f, const uint16_t *__restrict__ W1f, const uint16_t *__restrict__ W2f,
                                                           const float *__restrict__ biasg, const float *__restrict__ W2tab,
@@ -840,7 +865,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                                                           float *__restrict__ sdf_raw, float *__restrict__ sdf, int64_t *__restrict__ idx,
                                                           uint16_t *__restrict__ onehot, uint16_t *__restrict__ U0t, uint16_t *__restrict__ V1t,
                                                           uint16_t *__restrict__ V0t, float *__restrict__ grad, float *__restrict__ uxh, float jac_scale,
-                                                          int64_t n, int64_t ld) {
+                                                          int64_t n, int64_t ld, const uint16_t *__restrict__ W2f_b = nullptr, const float *__restrict__ bias2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char ldsf[];
     float *bias = reinterpret_cast<float *>(ldsf + 2 * kFBuf);
     char *W2lol = ldsf + 2 * kFBuf + kBias * sizeof(float);      // resident: the low plane of W2's fragments (16 KB, wave_tile.h), behind the bias block
@@ -975,6 +1000,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
         // ---- layer 2 (chunk 3): two partial accumulators, layer 1's quarter 3 in the shadow of k-steps 0..9; then the K SDFs, minimum, arg-min
         int bi = 0x7fffffff;
         char *cb3;
+        [[maybe_unused]] f32x4 u1g[WIDE ? 8 : 1][2];       // WIDE: eight k-steps of the arg-min row of W2, from memory
         {
             char *cb = cb3 = chunk_begin(std::integral_constant<int, 3>{}, std::true_type{});
             const uint32_t ab = lds_base(cb, lane * 16);
@@ -1017,31 +1043,83 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
                     if (nn < d_out && y[i] < best) { best = y[i]; bi = nn; }
                 }
             }
+            // this lane's sixteen raw outputs of the tile that starts at object `base`
+            auto store_raw = [&](int base) {
+                const int64_t gq = here(gp);
+                int hq = h;         // (opaque, as in k_rr_fwd_value)
+                asm volatile("" : "+v"(hq));
+                float *dst = sdf_raw + gq * d_out + base;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n0 = 8 * q + 4 * hq;
+                    if ((d_out & 3) == 0) {
+                        if (base + n0 < d_out) *reinterpret_cast<float4 *>(dst + n0) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (base + n0 + j < d_out) dst[n0 + j] = y[4 * q + j];
+                    }
+                }
+            };
+            if constexpr (WIDE) {
+                if (ok) store_raw(0);
+                // ---- second output tile: objects 32..63 (fragments and biases from memory)
+                uint32_t zb = 0;
+                asm volatile("" : "+v"(zb));
+                const bf16x8 *W2q = reinterpret_cast<const bf16x8 *>(W2f_b) + lane + zb, *W2r = W2q + (size_t)HS * 64;
+                static_for<HS / 2>([&](auto sc) {
+                    constexpr int s_ = decltype(sc)::value;
+                    if constexpr (s_ == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[0], frag_of(h1p), zero, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[64], frag_of(h1p + 4), zero, 0, 0, 0);
+                    } else {
+                        y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s_) * 64], frag_of(h1p + 4 * (2 * s_)), y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2q[(size_t)(2 * s_ + 1) * 64], frag_of(h1p + 4 * (2 * s_ + 1)), y1, 0, 0, 0);
+                    }
+                });
+                static_for<HS / 2>([&](auto sc) {
+                    constexpr int s_ = decltype(sc)::value;
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s_) * 64], frag_of(h1p + 4 * (2 * s_)), y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2r[(size_t)(2 * s_ + 1) * 64], frag_of(h1p + 4 * (2 * s_ + 1)), y1, 0, 0, 0);
+                });
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int nn = 8 * (i >> 2) + 4 * hq2 + (i & 3);
+                    y[i] = y0[i] + y1[i] + bias2[512 + nn];
+                    if (32 + nn < d_out && y[i] < best) { best = y[i]; bi = 32 + nn; }
+                }
+            }
             {
                 const float ob = __shfl_xor(best, 32);
                 const int oi = __shfl_xor(bi, 32);
                 if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
+            if constexpr (WIDE) {       // the arg-min row's first half (k-steps 0..7), requested in front of the stores below
+                const float *grow = W2tab + (size_t)(ok ? bi : 0) * 256 + 4 * h;
+#pragma unroll
+                for (int s_ = 0; s_ < 8; s_++) {
+                    u1g[s_][0] = *reinterpret_cast<const f32x4 *>(grow + 16 * s_);
+                    u1g[s_][1] = *reinterpret_cast<const f32x4 *>(grow + 16 * s_ + 8);
+                }
+            }
             if (ok) {
+                store_raw(WIDE ? 32 : 0);
                 const int64_t gq = here(gp);
-                int hq = h;         // (opaque, as in k_rr_fwd_value)
+                int hq = h;
                 asm volatile("" : "+v"(hq));
-                float *dst = sdf_raw + gq * d_out;
-                uint16_t *oh = onehot + gq * 32;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int n0 = 8 * q + 4 * hq;
-                    if ((d_out & 3) == 0) {
-                        if (n0 < d_out) *reinterpret_cast<float4 *>(dst + n0) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-                    } else {
+                for (int pl = 0; pl < (WIDE ? 2 : 1); pl++) {
+                    uint16_t *oh = onehot + (size_t)pl * (size_t)n * 32 + gq * 32;
+                    const int bl = bi - 32 * pl;
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (n0 + j < d_out) dst[n0 + j] = y[4 * q + j];
+                    for (int q = 0; q < 4; q++) {
+                        const int n0 = 8 * q + 4 * hq;
+                        uint2 o;      // bf16 1.0 = 0x3f80
+                        o.x = (bl == n0 ? 0x3f80u : 0u) | (bl == n0 + 1 ? 0x3f800000u : 0u);
+                        o.y = (bl == n0 + 2 ? 0x3f80u : 0u) | (bl == n0 + 3 ? 0x3f800000u : 0u);
+                        *reinterpret_cast<uint2 *>(oh + n0) = o;
                     }
-                    uint2 o;      // bf16 1.0 = 0x3f80
-                    o.x = (bi == n0 ? 0x3f80u : 0u) | (bi == n0 + 1 ? 0x3f800000u : 0u);
-                    o.y = (bi == n0 + 2 ? 0x3f80u : 0u) | (bi == n0 + 3 ? 0x3f800000u : 0u);
-                    *reinterpret_cast<uint2 *>(oh + n0) = o;
                 }
                 if (h == 0) { sdf[gq] = best; idx[gq] = bi; }
             }
@@ -1051,10 +1129,25 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_fwd(const float *__restrict
         //      the activation stores of the k-step before is not "there" until those stores have been acknowledged -- sixteen store round
         //      trips per tile in the two-kernel form's k_rr_fwd_grad
         {
-            const uint32_t wl = lds_base(cb3 + kW2Rows + (size_t)(ok ? bi : 0) * kW2Pitch, 16 * h);
+            const uint32_t wl = lds_base(cb3 + kW2Rows + (size_t)((ok && !WIDE) ? bi : 0) * kW2Pitch, 16 * h);
             static_for<HS>([&](auto sc) {
                 constexpr int s_ = decltype(sc)::value;
-                const f32x4 ua = lds_at<f32x4>(wl, 64 * s_), ub = lds_at<f32x4>(wl, 64 * s_ + 32);
+                f32x4 ua, ub;
+                if constexpr (WIDE) {
+                    if constexpr (s_ == 8) {       // second half of the row (one wait behind the first eight k-steps' stores)
+                        const float *grow = W2tab + (size_t)(ok ? bi : 0) * 256 + 4 * h + 128;
+#pragma unroll
+                        for (int t_ = 0; t_ < 8; t_++) {
+                            u1g[t_][0] = *reinterpret_cast<const f32x4 *>(grow + 16 * t_);
+                            u1g[t_][1] = *reinterpret_cast<const f32x4 *>(grow + 16 * t_ + 8);
+                        }
+                    }
+                    ua = u1g[s_ & 7][0];
+                    ub = u1g[s_ & 7][1];
+                } else {
+                    ua = lds_at<f32x4>(wl, 64 * s_);
+                    ub = lds_at<f32x4>(wl, 64 * s_ + 32);
+                }
                 const uint32_t w0 = h1p[4 * s_], w1 = h1p[4 * s_ + 1], w2 = h1p[4 * s_ + 2], w3 = h1p[4 * s_ + 3];
                 h1p[4 * s_] = pack2(ua[0] * sig_of_h(lo_bf(w0)), ua[1] * sig_of_h(hi_bf(w0)));
                 h1p[4 * s_ + 1] = pack2(ua[2] * sig_of_h(lo_bf(w1)), ua[3] * sig_of_h(hi_bf(w1)));
@@ -1188,10 +1281,11 @@ static int rr_grid(int64_t n) {
 }
 
 int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, void *stream) {
-    if (K < 1 || K > 32) return HS_ERR_ARG;
+    if (K < 1 || K > 64) return HS_ERR_ARG;
     if (n == 0) return HS_OK;
     if (!gy || (g_sdf && !idx)) return HS_ERR_NULL;
-    k_rr_gy<<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);
+    if (K <= 32) k_rr_gy<4><<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);
+    else k_rr_gy<8><<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);       /* gy [2][n][32], gb2_part [blocks, 64] */
     return wt_check_launch();
 }
 
@@ -1222,11 +1316,34 @@ int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const 
         return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kFBuf + kBias * sizeof(float) + (size_t)kW2F * sizeof(uint16_t);
     static hsLdsAttrOnce attr;
-    attr.set((const void *)k_rr_fwd, (int)lds);
-    k_rr_fwd<<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, W2tab,
-                                                               (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, d_out, (uint16_t *)H0t, (uint16_t *)H1t,
-                                                               (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, (uint16_t *)U0t, (uint16_t *)V1t,
-                                                               (uint16_t *)V0t, grad, uxh, jac_scale, n, ld);
+    attr.set((const void *)k_rr_fwd<false>, (int)lds);
+    k_rr_fwd<false><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, W2tab,
+                                                                      (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, d_out, (uint16_t *)H0t, (uint16_t *)H1t,
+                                                                      (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, (uint16_t *)U0t, (uint16_t *)V1t,
+                                                                      (uint16_t *)V0t, grad, uxh, jac_scale, n, ld);
+    return wt_check_launch();
+}
+
+/* 33..64 objects: W0f .. bias = the pack of the last layer's rows 0..31 (hs_trunk_pack_all / hs_sdf_mlp2_pack(log2_domain = 0)), W2f_b / bias_b = W2f / bias of the
+ * pack of rows 32..63; W2tab fp32 [64, 256] (rows >= d_out unused); sdf_raw [n, d_out]; onehot two planes [2][n][32] */
+int hs_trunk_rr_fwd_wide(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                         const void *W2f_b, const float *bias_b, const float *W2tab, const void *W1Tf, const void *W0Tf, int32_t d_out, void *H0t, void *H1t,
+                         void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, void *U0t, void *V1t, void *V0t, float *grad, float *uxh,
+                         float jac_scale, int64_t n, int64_t ld, void *stream) {
+    if (d_out < 33 || d_out > 64) return HS_ERR_ARG;
+    if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
+    if (!x || !feat || !dydx || !W0f || !W1f || !W2f || !bias || !W2f_b || !bias_b || !W2tab || !W1Tf || !W0Tf || !H0t || !H1t || !Xp || !sdf_raw || !sdf || !idx ||
+        !onehot || !U0t || !V1t || !V0t || !grad || !uxh)
+        return HS_ERR_NULL;
+    const size_t lds = 2 * (size_t)kFBuf + kBias * sizeof(float) + (size_t)kW2F * sizeof(uint16_t);
+    static hsLdsAttrOnce attr;
+    attr.set((const void *)k_rr_fwd<true>, (int)lds);
+    k_rr_fwd<true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias, W2tab,
+                                                                     (const uint16_t *)W1Tf, (const uint16_t *)W0Tf, d_out, (uint16_t *)H0t, (uint16_t *)H1t,
+                                                                     (uint16_t *)Xp, sdf_raw, sdf, idx, (uint16_t *)onehot, (uint16_t *)U0t, (uint16_t *)V1t,
+                                                                     (uint16_t *)V0t, grad, uxh, jac_scale, n, ld, (const uint16_t *)W2f_b, bias_b);
     return wt_check_launch();
 }
 
@@ -1279,6 +1396,28 @@ int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, co
         k_rr_bwd_value<false><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
                                                                                (const uint16_t *)H0t, (const uint16_t *)H1t, nullptr, nullptr, (uint16_t *)A0t, (uint16_t *)A1t,
                                                                                g_feat, n, ld);
+    return wt_check_launch();
+}
+
+/* 33..64 objects: gy = two planes [2][n][32] (hs_trunk_rr_gy with K > 32), W2Tf / W2Tf_b = the W2^T images of rows 0..31 / 32..63 (hs_trunk_rr_pack of each half) */
+int hs_trunk_rr_bwd_value_wide(const void *gy, const void *W2Tf, const void *W2Tf_b, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t,
+                               const void *A0pt, const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, int64_t ld, void *stream) {
+    if (n == 0) return HS_OK;
+    if (ld == 0) ld = n;
+    if (ld < n) return HS_ERR_ARG;
+    if (!gy || !W2Tf || !W2Tf_b || !W1Tf || !W0Tf || !H0t || !H1t || !A0t || !A1t || !g_feat || (!A0pt) != (!A1pt)) return HS_ERR_NULL;
+    const size_t lds = (size_t)(kW1F + kW2TF) * sizeof(uint16_t);
+    static hsLdsAttrOnce attr_a, attr_b;
+    attr_a.set((const void *)k_rr_bwd_value<true, true>, (int)lds);
+    attr_b.set((const void *)k_rr_bwd_value<false, true>, (int)lds);
+    if (A0pt)
+        k_rr_bwd_value<true, true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
+                                                                                    (const uint16_t *)H0t, (const uint16_t *)H1t, (const uint16_t *)A0pt, (const uint16_t *)A1pt,
+                                                                                    (uint16_t *)A0t, (uint16_t *)A1t, g_feat, n, ld, (const uint16_t *)W2Tf_b);
+    else
+        k_rr_bwd_value<false, true><<<rr_grid(n), kThreadsW, lds, (hipStream_t)stream>>>((const uint16_t *)gy, (const uint16_t *)W2Tf, (const uint16_t *)W1Tf, (const uint16_t *)W0Tf,
+                                                                                     (const uint16_t *)H0t, (const uint16_t *)H1t, nullptr, nullptr, (uint16_t *)A0t, (uint16_t *)A1t,
+                                                                                     g_feat, n, ld, (const uint16_t *)W2Tf_b);
     return wt_check_launch();
 }
 

@@ -156,7 +156,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -875,12 +875,59 @@ class _HipBackend:
 
     @staticmethod
     def trunk_rr_gy(g_raw, g_sdf, idx, K, gy, gb2_part):
-        """gb2_part: None or fp32 [RR_GY_BLOCKS, 32] (per-block column sums of gy)."""
+        """gy: bf16 [n, 32] (K <= 32) or two planes [2, n, 32] (33..64 objects: 0..31 | 32..63).  gb2_part: None or fp32 [RR_GY_BLOCKS, 32 or 64]
+        (per-block column sums of gy)."""
         lib = load_library()
-        if gb2_part is not None and tuple(gb2_part.shape) != (_HipBackend.RR_GY_BLOCKS, 32):
-            raise RuntimeError("trunk_rr_gy: gb2_part must be [RR_GY_BLOCKS, 32]")
+        KP = 32 if K <= 32 else 64
+        if tuple(gy.shape[:-2]) != ((2,) if KP == 64 else ()) or gy.shape[-1] != 32:
+            raise RuntimeError("trunk_rr_gy: gy must be [n, 32] for K <= 32, [2, n, 32] for 33..64 objects")
+        if gb2_part is not None and tuple(gb2_part.shape) != (_HipBackend.RR_GY_BLOCKS, KP):
+            raise RuntimeError(f"trunk_rr_gy: gb2_part must be [RR_GY_BLOCKS, {KP}]")
         _check(lib.hs_trunk_rr_gy(_dev(g_raw, "g_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), int(K), _dev(gy, "gy", torch.bfloat16),
-                                  _dev(gb2_part, "gb2_part"), ctypes.c_int64(gy.shape[0]), _stream()), "hs_trunk_rr_gy")
+                                  _dev(gb2_part, "gb2_part"), ctypes.c_int64(gy.shape[-2]), _stream()), "hs_trunk_rr_gy")
+
+    @staticmethod
+    def trunk_pack_wide(W0, b0, W1, b1, W2, b2, d_out):
+        """33 <= d_out <= 64: the weight images of a reverse-over-reverse training pass with two output tiles -- (packed, packed_b, rr, W2Tf_b): `packed` /
+        `rr` as trunk_pack_all of the last layer's rows 0..31 with rr's gather table W2tab grown to fp32 [64, 256] (rows 32.. from the second half),
+        packed_b = sdf_mlp2_pack(log2_domain=False) of rows 32.. (its W2f / bias are what the kernels read), W2Tf_b = the W2^T image of rows 32.. .
+        Three launches per parameter state (the one-launch pack of the iteration covers d_out <= 32 only)."""
+        cls = _HipBackend
+        c = lambda t: t.contiguous()  # noqa: E731
+        packed, rr, _ = cls.trunk_pack_all(W0, b0, W1, b1, c(W2[:32]), c(b2[:32]), 32, transposes=False)
+        packed_b = cls.sdf_mlp2_pack(W0, b0, W1, b1, c(W2[32:]), c(b2[32:]), int(d_out) - 32, log2_domain=False)
+        _, _, W2Tf_b, tab_b = cls.trunk_rr_pack(W0, W1, c(W2[32:]), int(d_out) - 32)
+        W2tab = torch.cat([rr[3].view(32, 256), tab_b.view(32, 256)]).contiguous().view(-1)
+        return packed, packed_b, (rr[0], rr[1], rr[2], W2tab), W2Tf_b
+
+    @staticmethod
+    def trunk_rr_fwd_wide(x, feat, dydx, packed, packed_b, rr, d_out, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot, U0t, V1t, V0t, grad, uxh, jac_scale, ld=0):
+        """trunk_rr_fwd for 33..64 objects (k_rr_fwd<true>): rr's W2tab is the 64-row table of trunk_pack_wide, onehot two planes [2, n, 32]."""
+        lib = load_library()
+        bf = torch.bfloat16
+        W0f, W1f, W2f, bias = packed
+        W1Tf, W0Tf, _, W2tab = rr
+        if W2tab.numel() != 64 * 256 or tuple(onehot.shape) != (2, x.shape[0], 32) or tuple(sdf_raw.shape) != (x.shape[0], d_out):
+            raise RuntimeError("trunk_rr_fwd_wide: W2tab [64 * 256], onehot [2, n, 32], sdf_raw [n, d_out]")
+        _check(lib.hs_trunk_rr_fwd_wide(_dev(x, "x"), _dev(feat, "feat"), _dev(dydx, "dydx"), _dev(W0f, "W0f", bf), _dev(W1f, "W1f", bf), _dev(W2f, "W2f", bf),
+                                        _dev(bias, "bias"), _dev(packed_b[2], "W2f_b", bf), _dev(packed_b[3], "bias_b"), _dev(W2tab, "W2tab"),
+                                        _dev(W1Tf, "W1Tf", bf), _dev(W0Tf, "W0Tf", bf), int(d_out), _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(Xp, "Xp", bf),
+                                        _dev(sdf_raw, "sdf_raw"), _dev(sdf, "sdf"), _dev(idx, "idx", torch.int64), _dev(onehot, "onehot", bf), _dev(U0t, "U0t", bf),
+                                        _dev(V1t, "V1t", bf), _dev(V0t, "V0t", bf), _dev(grad, "grad"), _dev(uxh, "uxh"), ctypes.c_float(jac_scale),
+                                        ctypes.c_int64(x.shape[0]), ctypes.c_int64(ld), _stream()), "hs_trunk_rr_fwd_wide")
+
+    @staticmethod
+    def trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=0):
+        """trunk_rr_bwd_value for 33..64 objects: gy two planes [2, n, 32]."""
+        lib = load_library()
+        bf = torch.bfloat16
+        W1Tf, W0Tf, W2Tf, _ = rr
+        if tuple(gy.shape) != (2, n, 32):
+            raise RuntimeError("trunk_rr_bwd_value_wide: gy must be [2, n, 32]")
+        _check(lib.hs_trunk_rr_bwd_value_wide(_dev(gy, "gy", bf), _dev(W2Tf, "W2Tf", bf), _dev(W2Tf_b, "W2Tf_b", bf), _dev(W1Tf, "W1Tf", bf), _dev(W0Tf, "W0Tf", bf),
+                                              _dev(H0t, "H0t", bf), _dev(H1t, "H1t", bf), _dev(A0pt, "A0pt", bf), _dev(A1pt, "A1pt", bf), _dev(A0t, "A0t", bf),
+                                              _dev(A1t, "A1t", bf), _dev(g_feat, "g_feat"), ctypes.c_int64(n), ctypes.c_int64(ld), _stream()),
+               "hs_trunk_rr_bwd_value_wide")
 
     @staticmethod
     def trunk_rr_pack(W0, W1, W2, d_out):

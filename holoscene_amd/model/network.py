@@ -486,6 +486,7 @@ class _fused_trunk_render(torch.autograd.Function):
 # reverse pass for d min / dx, closed-form double backward), "jac" = the value+Jacobian rows of _fused_trunk_render for every point
 # (4 rows per sample; what the Eikonal points, which need all K gradients, always use)
 TRUNK_MODE = os.environ.get("HOLOSCENE_TRUNK_MODE", "rr")
+RR_WIDE = os.environ.get("HOLOSCENE_RR_WIDE", "1") != "0"      # 33..64 objects on the reverse-over-reverse kernels too (0: the four-row value+Jacobian kernels, A/B)
 
 
 def _rr_slices(n, budget=256):
@@ -561,7 +562,16 @@ class _trunk_render_rr(torch.autograd.Function):
         f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
         # every weight image of this pass -- fragment images, their transposes, the Eikonal points' row-major transposes -- in one launch
         ip = _ITER_PACKS
-        if ip is not None and ip["trunk"] is not None and ip["trunk_key"] == (id(W0), id(W1), id(W2)) and (Be == 0 or ip["trunk"][2] is not None):
+        wide = K > 32        # 33..64 objects: the last layer as two 32-row tiles (k_rr_fwd<true>, k_rr_bwd_value<., true>; per-call packing)
+        packed_b = W2Tf_b = None
+        if wide:
+            bc = [t.detach().float().contiguous() for t in (b0, b1, b2)]
+            packed, packed_b, rr, W2Tf_b = be.trunk_pack_wide(f0, bc[0], f1, bc[1], f2, bc[2], K)
+            trans = None
+            if Be > 0:      # the Eikonal points' backward kernel (k_trunk_bwd<64>) reads row-major transposes
+                trans = (torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 64, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf))
+                be.pack_bf16([(f1, trans[0], 0, 0, 256, 256, True), (f2, trans[1], 0, 0, 256, K, True), (f0, trans[2], 0, 0, W0.shape[1], 256, True)])
+        elif ip is not None and ip["trunk"] is not None and ip["trunk_key"] == (id(W0), id(W1), id(W2)) and (Be == 0 or ip["trunk"][2] is not None):
             packed, rr, trans = ip["trunk"]       # packed at the top of the iteration, together with every other image (hs_pack_iteration)
         else:
             packed, rr, trans = be.trunk_pack_all(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2,
@@ -569,10 +579,12 @@ class _trunk_render_rr(torch.autograd.Function):
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
         H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
-        Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty(n, 32, device=dev, dtype=bf)
+        Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty((2, n, 32) if wide else (n, 32), device=dev, dtype=bf)
         sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(B, 1, device=dev, dtype=torch.int64)
         grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
-        if RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
+        if wide:
+            be.trunk_rr_fwd_wide(x[:n], feat[:n], dydx, packed, packed_b, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
+        elif RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
             be.trunk_rr_fwd(x[:n], feat[:n], dydx, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
         else:
             be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
@@ -583,12 +595,17 @@ class _trunk_render_rr(torch.autograd.Function):
             Me = 4 * Be
             H0e, H1e, Xpe = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 80, device=dev, dtype=bf)
             w1t, w2t, w0t = trans
-            be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
-                              split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
+            if wide:
+                be.trunk_mlp2_fwd_wide(x[n:], feat[n:], dydx, packed, packed_b, K, H0e, H1e, Xpe, jac,
+                                       (0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
+            else:
+                be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
+                                  split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
             eik = (H0e, H1e, Xpe, w0t, w1t, w2t)
         if ctx.needs_input_grad[2]:
             _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik)
+        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik, *((W2Tf_b,) if wide else ()))
+        ctx.wide = wide
         ctx.cfg = (B, n, L, C, K, S, Hres, jac, W0.shape[1])
         ctx.bias_params = (b0, b1, b2)       # their gradients go straight into the flat gradient buffer when there is one (flat_grad_target)
         ctx.mark_non_differentiable(idx)
@@ -610,9 +627,14 @@ class _trunk_render_rr(torch.autograd.Function):
         # ---- rendered samples: cotangent of the K outputs with the minimum's folded in at its index, then the two rr kernels
         M = be.tp_rows(n)
         tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
-        gy = torch.empty(n, 32, device=dev, dtype=bf)
-        gbz = _be.zeros_small(2 * 256 + 32, dev)            # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
-        gb2_part = torch.empty(be.RR_GY_BLOCKS, 32, device=dev) if need_w else None
+        wide = ctx.wide
+        KP = 64 if wide else 32
+        W2Tf_b = sv[-1] if wide else None
+        if wide:
+            sv = sv[:-1]
+        gy = torch.empty((2, n, 32) if wide else (n, 32), device=dev, dtype=bf)
+        gbz = _be.zeros_small(2 * 256 + KP, dev)            # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
+        gb2_part = torch.empty(be.RR_GY_BLOCKS, KP, device=dev) if need_w else None
         be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
         A0t, A1t = tp(), tp()
         second = g_grad is not None
@@ -624,11 +646,17 @@ class _trunk_render_rr(torch.autograd.Function):
             gg = c(g_grad)
             rank1 = (uxh, gg, jac) if need_table else None
             be.trunk_rr_bwd_grad(x[:n], dydx, gg, uxh, idx[:n], rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, None, jac, ld=B)
-            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
+            if wide:
+                be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
+            else:
+                be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
         else:
             rank1 = None
             g_dydx[:, :n].zero_()
-            be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
+            if wide:
+                be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
+            else:
+                be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
         # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
         eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
         w2_part = None
@@ -636,10 +664,10 @@ class _trunk_render_rr(torch.autograd.Function):
         if eik_live:
             H0e, H1e, Xpe, w0t, w1t, w2t = sv[22:]
             Me = 4 * Be
-            g_img = torch.empty(Me, 32, device=dev, dtype=bf)
+            g_img = torch.empty(Me, KP, device=dev, dtype=bf)
             be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
             gA1, gA0 = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf)
-            w2_part = torch.empty(be.trunk_bwd_parts(Me), 32, 256, device=dev) if need_w else None
+            w2_part = torch.empty(be.trunk_bwd_parts(Me), KP, 256, device=dev) if need_w else None
             be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,
                              gb2=gbz[512:] if need_w else None, dW2_part=w2_part, ld=B, off=n)
             if need_w and Me % 32 == 0:
@@ -651,22 +679,49 @@ class _trunk_render_rr(torch.autograd.Function):
         if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
             T, npair = be.tp_rows(n) // 32, 2 if second else 1
             cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True)]
-                               + [(j[0], Me // 32, 1, True) for j in eik_jobs])
+                               + ([((32, 256), T, npair, True)] if wide else []) + [(j[0], Me // 32, 1, True) for j in eik_jobs])
             s1, s0, s2 = cut[:3]
-            se1, se0 = cut[3:] if eik_jobs else (0, 0)
+            s2b = cut[3] if wide else 0
+            se1, se0 = cut[3 + int(wide):] if eik_jobs else (0, 0)
             eik_jobs = [(j[0], sl) + tuple(j[2:]) for j, sl in zip(eik_jobs, (se1, se0))]
             # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
             # samples ride along: db0, db1 as the column sums of a0~, a1~ from one more MFMA per fragment of the jobs that stream them
             # (hsWgradPairJob::colsum)
             st1, st0 = torch.empty(s1 + se1, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se0, 256, 128, device=dev, dtype=bf)
             st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
+            st2b = torch.empty(s2b, 32, 256, device=dev, dtype=bf) if wide else None
             cs = []
+            gy_a, oh_a = (gy[0], onehot[0]) if wide else (gy, onehot)
             be.wgrad_pairs([((256, 256, "colsum"), s1, (A1t, H0t), (V1t, U0bt) if second else None),
                             ((256, 80, "colsum"), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                            ((32, 256), s2, (gy, H1t), (onehot, U1bt) if second else None)] + eik_jobs, n,
-                           outs_into=[st1[:s1], st0[:s0], st2] + ([st1[s1:], st0[s0:]] if eik_jobs else []), colsum_out=cs)
+                            ((32, 256), s2, (gy_a, H1t), (oh_a, U1bt) if second else None)]
+                           + ([((32, 256), s2b, (gy[1], H1t), (onehot[1], U1bt) if second else None)] if wide else []) + eik_jobs, n,
+                           outs_into=[st1[:s1], st0[:s0], st2] + ([st2b] if wide else []) + ([st1[s1:], st0[s0:]] if eik_jobs else []), colsum_out=cs)
             csb1, csb0 = cs[0], cs[1]        # [s1, 256], [s0, 256] fp32
-            if eik_live and not eik_jobs:
+            if wide:
+                # two output tiles: the (K, 256) matrix is assembled half by half into one tensor (rows 0..31 | 32..K-1), the Eikonal rows' partials
+                # [parts, 64, 256] likewise; everything else as below
+                p0, p1, p2 = ctx.bias_params
+                D1, D0, D2 = _DirectGrad(p1, (1, 256)), _DirectGrad(p0, (1, 256)), _DirectGrad(p2, (1, K))
+                gW2 = torch.empty(K, 256, device=dev)
+                parts = w2_part.shape[0] if (eik_live and w2_part is not None) else 0
+                eik_a = [(w2_part, 256, 0, parts, 64 * 256)] if parts else []
+                eik_b = [(w2_part.view(-1)[32 * 256:], 256, 0, parts, 64 * 256)] if parts else []
+                eW = None
+                if eik_live and not eik_jobs:       # (Eikonal row counts that are not whole tiles: their 256-wide gradients through the row-major kernel)
+                    eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)])
+                gW1, gW0, _, _, gb1, gb0, gb2 = be.assemble([
+                    ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
+                    ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
+                    ((32, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + eik_a, (gW2[:32], None)),
+                    ((K - 32, 256), [(st2b, 256, 0, st2b.shape[0], 32 * 256)] + eik_b, (gW2[32:], None)),
+                    D1.job([(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]),
+                    D0.job([(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]),
+                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 64)])])
+                if eW is not None:
+                    gW1, gW0 = gW1 + eW[0], gW0 + eW[1].index_select(1, _xp_columns(dev))
+                gb1, gb0, gb2 = D1.grad(gb1, (256,)), D0.grad(gb0, (256,)), D2.grad(gb2, (K,))
+            elif eik_live and not eik_jobs:
                 eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
                 sums = be.sum_slices([st1, st0, st2, csb1, csb0])
                 gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
@@ -823,7 +878,8 @@ def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, 
     """_fused_trunk_render's seven outputs; TRUNK_MODE == "rr" (and the stock shapes): the rendered samples through the
     reverse-over-reverse kernels (_trunk_render_rr)."""
     K = W2.shape[0]
-    if TRUNK_MODE == "rr" and n_main > 0 and K <= 32 and nfreq == 6 and offsets.shape[0] - 1 == 16 and embeddings.shape[1] == 2 and W0.shape[1] == 71:
+    if (TRUNK_MODE == "rr" and n_main > 0 and (K <= 32 or (K <= 64 and RR_WIDE and RR_FORWARD == "fused")) and nfreq == 6 and offsets.shape[0] - 1 == 16
+            and embeddings.shape[1] == 2 and W0.shape[1] == 71):
         return _trunk_render_rr.apply(x, n_main, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01)
     if TRUNK_MODE not in ("rr", "jac"):
         raise RuntimeError(f"unknown HOLOSCENE_TRUNK_MODE={TRUNK_MODE!r}")
@@ -2172,9 +2228,13 @@ class HoloSceneNetwork(nn.Module):
             if K != net.d_out:
                 out.append(f"trunk output width {K} != d_out {net.d_out}: rendered samples on the library-GEMM value+Jacobian path")
             elif K > 32:
-                out.append(f"d_out = {K} > 32: sampler sweeps and the trunk forward on the two-output-tile wave kernels (k_sdf_mlp2<true>, k_trunk_fwd2<true, true>: "
-                           "four value+Jacobian rows per rendered sample instead of reverse-over-reverse), the trunk backward on the 128-point workgroup-tile "
-                           "kernel (k_trunk_bwd<64>) with library weight-gradient GEMMs; per-call weight packing")
+                if RR_WIDE and TRUNK_MODE == "rr" and RR_FORWARD == "fused":
+                    out.append(f"d_out = {K} > 32: the benchmarked kernels with the last layer as two 32-row tiles (k_sdf_mlp2<true>, k_rr_fwd<true>, "
+                               "k_rr_bwd_value<., true>, two 32-row weight-gradient jobs); three weight-pack launches per parameter state instead of the "
+                               "iteration's one, the Eikonal points' backward on the 128-point workgroup-tile kernel (k_trunk_bwd<64>)")
+                else:
+                    out.append(f"d_out = {K} > 32 with HOLOSCENE_RR_WIDE=0 / TRUNK_MODE != rr: rendered samples on the four-row value+Jacobian kernels "
+                               "(k_trunk_fwd2<true, true>, k_trunk_bwd<64>, library weight-gradient GEMMs); per-call weight packing")
         probe = self.density.beta
         if probe.is_cuda and not self._fused_appearance_supported(probe):
             out.append("colour branch on library GEMMs: it is not the stock one (idr mode, four layers of 256, 4 frequencies each, 16 x 2 colour grid, "

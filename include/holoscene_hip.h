@@ -724,6 +724,18 @@ int hs_trunk_rr_bwd_grad(const float *x, const float *dydx, const float *g_grad,
 int hs_trunk_rr_bwd_value(const void *gy, const void *W2Tf, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t, const void *A0pt,
                           const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, int64_t ld, void *stream);
 
+/* The same two kernels for 33..64 objects (confs/custom/siebelgame: d_out = 64; training/holoscene_train.py:119-122: d_out = len(label_mapping)): the last
+ * layer as TWO 32-row tiles.  W0f .. bias / W2Tf: the images of rows 0..31 (hs_trunk_pack_all), W2f_b / bias_b / W2Tf_b: W2f / bias / W2Tf of the packs of rows
+ * 32..63 (hs_sdf_mlp2_pack(log2_domain = 0), hs_trunk_rr_pack), W2tab fp32 [64, 256] (both halves' tables, rows >= d_out unused).  sdf_raw [n, d_out];
+ * onehot and gy (hs_trunk_rr_gy with K > 32; gb2_part then [blocks, 64]) are two planes [2][n][32]: objects 0..31 | 32..63 -- each plane is what the
+ * 32-column weight-gradient jobs of hs_wgrad_pairs take.  hs_trunk_rr_bwd_grad needs no second form: it reads W2tab by the arg-min index. */
+int hs_trunk_rr_fwd_wide(const float *x, const float *feat, const float *dydx, const void *W0f, const void *W1f, const void *W2f, const float *bias,
+                         const void *W2f_b, const float *bias_b, const float *W2tab, const void *W1Tf, const void *W0Tf, int32_t d_out, void *H0t, void *H1t,
+                         void *Xp, float *sdf_raw, float *sdf, int64_t *idx, void *onehot, void *U0t, void *V1t, void *V0t, float *grad, float *uxh,
+                         float jac_scale, int64_t n, int64_t ld, void *stream);
+int hs_trunk_rr_bwd_value_wide(const void *gy, const void *W2Tf, const void *W2Tf_b, const void *W1Tf, const void *W0Tf, const void *H0t, const void *H1t,
+                               const void *A0pt, const void *A1pt, void *A0t, void *A1t, float *g_feat, int64_t n, int64_t ld, void *stream);
+
 /* Weight gradients of that formulation: part[slice] = sum over the job's one or two operand pairs of A^T B over the slice's rows
  * (csrc/wgrad_pairs.hip).  kind: HS_WGP_256x256 (A, B tile-packed), HS_WGP_256x80 (A tile-packed, B row-major [rows, 80]; result
  * [256, 128], columns >= 80 zero), HS_WGP_32x256 (A row-major [rows, 32], B tile-packed).  M = 32 * number of tiles; a slice is

@@ -229,3 +229,111 @@ def test_fused_forward_equals_the_pair_at_the_benchmarked_size():
                         b["grad"], b["uxh"], 0.5)
         diff = [k for k in a if not torch.equal(a[k].view(torch.int16) if a[k].dtype == bf else a[k], b[k].view(torch.int16) if b[k].dtype == bf else b[k])]
         assert not diff, f"run {run}: fused forward differs from the pair in {diff}"
+
+
+@pytest.mark.parametrize("n,K", [(1000, 64), (4099, 40), (37, 33)])
+def test_rr_wide_kernels_vs_torch_restatement(n, K):
+    """33..64 objects (confs/custom/siebelgame: d_out = 64) on the reverse-over-reverse kernels: k_rr_fwd<true> (second output tile, arg-min over both,
+    one-hot image in two planes, the arg-min row of W2 from the 64-row table), hs_trunk_rr_gy's two-plane image, k_rr_bwd_value<., true> and the two
+    32-column weight-gradient jobs -- each against the torch restatement (tests/rr_reference.py), as the K <= 32 test above does kernel by kernel."""
+    from holoscene_amd.hashencoder.backend import _backend as be
+    x, feat, dydx, W = _problem(n, K, n + K)
+    W0, b0, W1, b1, W2, b2 = W
+    jac, bf = 0.5, torch.bfloat16
+    packed, packed_b, rr, W2Tf_b = be.trunk_pack_wide(W0, b0, W1, b1, W2, b2, K)
+    assert torch.equal(rr[3].view(64, 256)[:K], W2), "the gather table holds W2's rows in fp32"
+    M = be.tp_rows(n)
+    tp = lambda: torch.full((M * 256,), 7.0, device=DEV, dtype=bf)  # noqa: E731
+    H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
+    Xp, onehot = torch.zeros(n, 80, device=DEV, dtype=bf), torch.full((2, n, 32), 7.0, device=DEV, dtype=bf)
+    sdf_raw, sdf, idx = torch.empty(n, K, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64)
+    grad, uxh = torch.empty(n, 3, device=DEV), torch.empty(n, 32, device=DEV)
+    be.trunk_rr_fwd_wide(x, feat, dydx, packed, packed_b, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx, onehot, U0t, V1t, V0t, grad, uxh, jac)
+    f = R.forward(x, feat, dydx, W, jac)
+    e = {"y": rel(sdf_raw, f["y"]), "h0": rel(R.tp_decode(H0t, n), f["h0"]), "h1": rel(R.tp_decode(H1t, n), f["h1"])}
+    print(f"PARITY rr wide K={K} n={n} forward values", e)
+    assert e["y"] < 1e-2 and e["h0"] < 1e-2 and e["h1"] < 1.5e-2, e
+    assert torch.equal(sdf, sdf_raw.min(-1)[0]) and torch.equal(idx, sdf_raw.min(-1)[1]), "minimum / arg-min over BOTH tiles of the kernel's own outputs"
+    if K >= 40:
+        assert float((idx >= 32).float().mean()) > 0.05 and float((idx < 32).float().mean()) > 0.05, "the problem exercises both tiles"
+    oh = torch.nn.functional.one_hot(idx, 64).float()
+    assert torch.equal(onehot[0].float(), oh[:, :32]) and torch.equal(onehot[1].float(), oh[:, 32:])
+    f2 = dict(f)
+    f2["idx"] = idx
+    f2["h0"], f2["h1"] = R.tp_decode(H0t, n), R.tp_decode(H1t, n)
+    f2["s0"], f2["s1"] = 1 - torch.exp(-100 * f2["h0"]), 1 - torch.exp(-100 * f2["h1"])
+    v1 = R.bfr(W2[idx] * f2["s1"], True)
+    u0f = v1 @ R.bfr(W1, True)
+    f2.update(v1=v1, u0f=u0f, u0=R.bfr(u0f, True), v0=R.bfr(u0f * f2["s0"], True))
+    f2["ux"] = f2["v0"] @ R.bfr(W0, True)
+    f2["uxh"] = f2["ux"][:, R.NPE:]
+    f2["grad"] = torch.einsum("bj,bjd->bd", f2["ux"], f["E"])
+    e = {"v1": rel(R.tp_decode(V1t, n), f2["v1"]), "u0": rel(R.tp_decode(U0t, n), f2["u0"]), "v0": rel(R.tp_decode(V0t, n), f2["v0"]),
+         "uxh": rel(uxh, f2["uxh"]), "grad": rel(grad, f2["grad"])}
+    print(f"PARITY rr wide K={K} forward gradient chain", e)
+    assert max(e.values()) < 1.5e-2, e
+    # ---- the first tile's arithmetic is the 32-object kernel's: with objects 32.. pushed out of reach every tile-packed output is bit-identical to it
+    W2far, b2far = W2.clone(), b2.clone()
+    b2far[32:] += 1e3
+    pk, pkb, rrf, _ = be.trunk_pack_wide(W0, b0, W1, b1, W2far, b2far, K)
+    Fw = {k: tp() for k in ("H0t", "H1t", "U0t", "V1t", "V0t")}
+    rawf, sdff, idxf, ohf = torch.empty(n, K, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64), torch.zeros(2, n, 32, device=DEV, dtype=bf)
+    gradf, uxhf = torch.empty(n, 3, device=DEV), torch.empty(n, 32, device=DEV)
+    be.trunk_rr_fwd_wide(x, feat, dydx, pk, pkb, rrf, K, Fw["H0t"], Fw["H1t"], torch.zeros(n, 80, device=DEV, dtype=bf), rawf, sdff, idxf, ohf, Fw["U0t"], Fw["V1t"],
+                         Fw["V0t"], gradf, uxhf, jac)
+    p32 = be.sdf_mlp2_pack(W0, b0, W1, b1, W2[:32].contiguous(), b2[:32].contiguous(), 32, log2_domain=False)
+    r32 = be.trunk_rr_pack(W0, W1, W2[:32].contiguous(), 32)
+    Fn = {k: tp() for k in ("H0t", "H1t", "U0t", "V1t", "V0t")}
+    rawn, sdfn, idxn, ohn = torch.empty(n, 32, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV, dtype=torch.int64), torch.zeros(n, 32, device=DEV, dtype=bf)
+    gradn, uxhn = torch.empty(n, 3, device=DEV), torch.empty(n, 32, device=DEV)
+    be.trunk_rr_fwd(x, feat, dydx, p32, r32, 32, Fn["H0t"], Fn["H1t"], torch.zeros(n, 80, device=DEV, dtype=bf), rawn, sdfn, idxn, ohn, Fn["U0t"], Fn["V1t"], Fn["V0t"],
+                    gradn, uxhn, jac)
+    same = {k: torch.equal(Fw[k].view(torch.int16), Fn[k].view(torch.int16)) for k in Fw}
+    same.update(raw=torch.equal(rawf[:, :32], rawn), sdf=torch.equal(sdff, sdfn), idx=torch.equal(idxf, idxn), grad=torch.equal(gradf, gradn), uxh=torch.equal(uxhf, uxhn),
+                onehot=torch.equal(ohf[0].view(torch.int16), ohn.view(torch.int16)) and float(ohf[1].float().abs().max()) == 0.0)
+    assert all(same.values()), f"two-tile kernel differs from the 32-object kernel where the second tile cannot win: {same}"
+    # ---- backward: gradient part (the 32-object kernel on the 64-row table), cotangent image, value part
+    g = torch.Generator().manual_seed(5)
+    g_grad = torch.randn(n, 3, generator=g).to(DEV)
+    g_y = (torch.randn(n, K, generator=g) * 0.5).to(DEV)
+    f3 = dict(f2)
+    f3["u0"], f3["v0"], f3["v1"], f3["uxh"] = R.tp_decode(U0t, n), R.tp_decode(V0t, n), R.tp_decode(V1t, n), uxh
+    ref = R.backward(f3, W, g_y, g_grad, jac)
+    U0bt, A0pt, A1pt, U1bt, A0t, A1t = tp(), tp(), tp(), tp(), tp(), tp()
+    UXb = torch.zeros(n, 80, device=DEV, dtype=bf)
+    be.trunk_rr_bwd_grad(x, dydx, g_grad, uxh, idx, rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, None, jac)
+    e = {"u0b": rel(R.tp_decode(U0bt, n), ref["u0b"]), "a0p": rel(R.tp_decode(A0pt, n), ref["a0p"]), "u1b": rel(R.tp_decode(U1bt, n), ref["u1b"]),
+         "a1p": rel(R.tp_decode(A1pt, n), ref["a1p"])}
+    print(f"PARITY rr wide K={K} bwd_grad", e)
+    assert max(e.values()) < 2e-2, e
+    gy = torch.full((2, n, 32), 7.0, device=DEV, dtype=bf)
+    part = torch.full((be.RR_GY_BLOCKS, 64), 7.0, device=DEV)
+    g_sdf = torch.randn(n, generator=g).to(DEV)
+    be.trunk_rr_gy(g_y, g_sdf, idx, K, gy, part)
+    want_gy = torch.zeros(n, 64, device=DEV)
+    want_gy[:, :K] = g_y
+    want_gy[torch.arange(n, device=DEV), idx] += g_sdf
+    assert torch.equal(gy[0], want_gy[:, :32].to(bf)) and torch.equal(gy[1], want_gy[:, 32:].to(bf)), "gy planes = bf16(g_raw + g_sdf at the arg-min column)"
+    assert torch.allclose(part.sum(0), want_gy.sum(0), rtol=1e-4, atol=1e-3)
+    g_yt = want_gy[:, :K].to(bf).float()          # the cotangent the value part sees (minimum's folded in, rounded to bf16)
+    g_feat = torch.empty(16, n, 2, device=DEV)
+    be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n)
+    r2 = R.backward(f3, W, g_yt, g_grad, jac)
+    e = {"a1": rel(R.tp_decode(A1t, n), r2["a1"]), "a0": rel(R.tp_decode(A0t, n), r2["a0"]), "g_feat": rel(g_feat, r2["g_feat"])}
+    print(f"PARITY rr wide K={K} bwd_value", e)
+    assert max(e.values()) < 2e-2, e
+    A0n, A1n, g_featn = tp(), tp(), torch.empty(16, n, 2, device=DEV)
+    be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, None, None, A0n, A1n, g_featn, n)
+    r0 = R.backward(f3, W, g_yt, None, jac)
+    e = {"a1": rel(R.tp_decode(A1n, n), r0["a1"]), "a0": rel(R.tp_decode(A0n, n), r0["a0"]), "g_feat": rel(g_featn, r0["g_feat"])}
+    assert max(e.values()) < 2e-2, e
+    # ---- the last layer's weight gradient as two 32-row jobs of one launch
+    tiles = M // 32
+    S = max(d for d in range(1, 65) if tiles % d == 0)
+    parts = be.wgrad_pairs([((32, 256), S, (gy[0], H1t), (onehot[0], U1bt)), ((32, 256), S, (gy[1], H1t), (onehot[1], U1bt))], n)
+    dW2 = torch.cat([p.float().sum(0) for p in parts])
+    gyf = torch.cat([gy[0], gy[1]], 1).float()
+    want2 = gyf.t() @ f3["h1"] + oh.t() @ R.tp_decode(U1bt, n)
+    e2 = rel_l2(dW2, want2)
+    print(f"PARITY rr wide K={K} dW2 (two 32-row jobs) relL2 {e2:.2e}")
+    assert e2 < 1e-2 and (K == 64 or float(dW2[K:].abs().max()) == 0.0)
