@@ -19,6 +19,10 @@
 #include "wave_tile.h"
 #include "trunk_pack.h"
 
+#ifndef HS_A2_NOSTORE
+#define HS_A2_NOSTORE 0      // 1 (a variant build): k_appear2_bwd without its cotangent stores -- the ablation of DESIGN 14.3
+#endif
+
 namespace {
 
 #ifndef HS_A2_LA
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_fwd(const float *__res
 // The four 256-wide cotangents leave tile-packed (they are the A operands of the weight gradients), y~ row-major [n, 32]; the ReLU signs
 // come from the forward pass's masks; nothing else of the forward pass is read.
 // STORE = false: ablation for DESIGN 14.1 only (the four tile-packed cotangents are not written: what the kernel would cost if its weight
-// gradients never left the chip); results are then incomplete on purpose (HOLOSCENE_A2_ABLATE=nostore, tools/exp/dw_fusion_bounds.py)
+// gradients never left the chip); results are then incomplete on purpose (-DHS_A2_NOSTORE=1 in a variant build, tools/exp/dw_fusion_bounds.py)
 template <bool STORE>
 __global__ __launch_bounds__(kThreadsW, 2) void k_appear2_bwd(const float *__restrict__ g_rgb, const float *__restrict__ rgb, const float *__restrict__ normals,
                                                                const uint32_t *__restrict__ masks, const char *__restrict__ streamT,
@@ -825,7 +829,7 @@ int hs_appearance2_bwd(const float *g_rgb, const float *rgb, const float *normal
     if (!g_rgb || !rgb || !normals || !masks || !streamT_image || !gy || !GR1t || !GR0t || !GFVt || !GHCt || !d_normals || !g_featc) return HS_ERR_NULL;
     const size_t lds = 2 * (size_t)kBufBytes;
     static hsLdsAttrOnce attr;
-    static const bool nostore = [] { const char *e = getenv("HOLOSCENE_A2_ABLATE"); return e && e[0] == 'n'; }();
+    constexpr bool nostore = HS_A2_NOSTORE;      /* ablation (-DHS_A2_NOSTORE=1 in a variant build): the backward without its cotangent stores */
     const int64_t ntiles = (n + kRows - 1) / kRows, want = (ntiles + kWaves - 1) / kWaves;
     if (nostore) {
         static hsLdsAttrOnce attr0;

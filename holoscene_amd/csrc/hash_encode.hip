@@ -1007,15 +1007,8 @@ hsHashLayout reference_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
 
 int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH; }
 
-// the dense-level switch is read from the environment once, on the first scatter launch (an eager one: warm-up passes precede captures)
-void apply_bin_dense_switch() {
-    static const bool done = [] {
-        const char *e = getenv("HOLOSCENE_BIN_DENSE");
-        if (e && e[0] == '0') { const int v = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_dense), &v, sizeof(v)); }
-        return true;
-    }();
-    (void)done;
-}
+// (the dense levels go through the bins too: g_bin_dense stays 1 -- the wave-merged atomic path for them measured slower in round 4)
+void apply_bin_dense_switch() {}
 
 bool dims_ok(uint32_t D, uint32_t C, uint32_t L) { return (D == 2 || D == 3) && (C == 1 || C == 2 || C == 4 || C == 8) && L >= 1 && L <= HS_MAX_LEVELS; }
 
@@ -1037,11 +1030,8 @@ void dispatch_dc(uint32_t D, uint32_t C, F &&f) {
     else with_c(Int<2>{});
 }
 
-// HOLOSCENE_HASH_FWD=point selects the one-lane-per-point value kernel (the A/B switch of k_hash_fwd_pair)
-bool pair_forward() {
-    static const bool v = [] { const char *e = getenv("HOLOSCENE_HASH_FWD"); return !(e && strcmp(e, "point") == 0); }();
-    return v;
-}
+// D = 3 gathers run two lanes per point (k_hash_fwd_pair); k_hash_fwd -- one lane per point -- serves D = 2
+constexpr bool pair_forward() { return true; }
 
 }  // namespace
 

@@ -141,7 +141,7 @@ int hs_adam_flat_shard(float *p, const float *g, float *m, float *v, int64_t beg
     // HOLOSCENE_ADAM_STREAM=0: plain accesses (A/B).  Eight alternating runs in one session: 2.210-2.219 ms per iteration with the
     // streaming accesses, 2.217-2.226 without (the kernel itself is unchanged at ~125 us; the next iteration's first gathers find
     // more of the parameter tables still cached).
-    static const bool stream_mv = [] { const char *e = getenv("HOLOSCENE_ADAM_STREAM"); return !(e && e[0] == '0'); }();
+    constexpr bool stream_mv = true;
     if (stream_mv) k_adam_flat<true><<<grid, kThreads, 0, (hipStream_t)stream>>>(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale, g_base, mv_base);
     else k_adam_flat<false><<<grid, kThreads, 0, (hipStream_t)stream>>>(p, g, m, v, begin, end, state, beta1, beta2, eps, grad_scale, g_base, mv_base);
     return check_launch();

@@ -757,11 +757,10 @@ int check_launch() { return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAU
 
 template <typename... Args>
 void launch_draw(int R, int m_cap, int n_extra, hipStream_t st, Args... args) {
-    static const int nt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_DRAW_THREADS"); const int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
+    // 128 threads per ray (one wave per ray leaves a SIMD with ONE wave walking 6-7 sections through libm exp / expm1: 15.9-17.6 us per launch at 64
+    // threads, 11.9-12.4 at 128, 11.6-15.3 at 256 in the iteration, measured in round 3)
     const size_t lds = (4 * (size_t)m_cap + 3 * 4 + (size_t)n_extra) * sizeof(float);
-    if (nt == 64) k_sampler_draw<64><<<dim3(R), dim3(64), lds, st>>>(args...);
-    else if (nt == 128) k_sampler_draw<128><<<dim3(R), dim3(128), lds, st>>>(args...);
-    else k_sampler_draw<256><<<dim3(R), dim3(256), lds, st>>>(args...);
+    k_sampler_draw<128><<<dim3(R), dim3(128), lds, st>>>(args...);
 }
 
 }  // namespace
@@ -775,19 +774,12 @@ static int sampler_update_launch(float *z, float *sdf, int32_t ld, int32_t m_old
     if (!z || !sdf || !samples || !new_sdf || !beta || !beta0 || !beta_max) return HS_ERR_NULL;
     const int m = m_dev ? ld : m_old + s_new;   // device-side count: size the scratch for the row capacity
     if (m < 2 || m > ld || m > HS_SAMPLER_MAX_M) return HS_ERR_ARG;
-    static const int nt_env = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 || v == 512 ? v : 0; }();
-    // threads per ray by the size of the merged set unless the environment pins them: the early rounds hold 128 / 256 sections -- with 256 threads half
-    // of them idle through 33 barrier rounds of the line search; one or two waves scan those without (or with fewer) cross-wave steps
-    static const int adapt = [] { const char *e = getenv("HOLOSCENE_SAMPLER_UPDATE_ADAPT"); return e ? atoi(e) : 0; }();
-    const int nt = nt_env ? nt_env : (adapt && !m_dev ? (m <= adapt ? 64 : (m <= 2 * adapt ? 128 : 256)) : 256);
+    // 256 threads (four waves) per ray whatever the size of the merged set: 64 / 128 threads for the early rounds' 128 / 256 sections measured equal
+    // (round 5: the kernel waits on its dependent chain, not on issue slots), 512 slower.  The line search holds a thread's <= 4 sections in registers
+    // (error_bound_regs); larger merged sets fall back to the LDS form inside the kernel.
     const hsGate g = gate ? *gate : hsGate{nullptr, nullptr};
     const size_t lds = (6 * m + 3 * 8) * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
-    static const bool sr = [] { const char *e = getenv("HOLOSCENE_SAMPLER_SEARCH"); return !(e && strcmp(e, "lds") == 0); }();     // A/B: lds = round 4's form
-    if (nt == 64) k_sampler_update<64><<<dim3(R), dim3(64), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
-    else if (nt == 128) k_sampler_update<128><<<dim3(R), dim3(128), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
-    else if (nt == 512) k_sampler_update<512><<<dim3(R), dim3(512), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
-    else k_sampler_update<256><<<dim3(R), dim3(256), lds, st>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, sr);
+    k_sampler_update<256><<<dim3(R), dim3(256), lds, (hipStream_t)stream>>>(z, sdf, ld, m_old, samples, new_sdf, s_new, beta, beta0, eps, beta_iters, beta_max, R, g, m_dev, dr, true);
     return check_launch();
 }
 

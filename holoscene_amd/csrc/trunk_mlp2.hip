@@ -596,7 +596,7 @@ int hs_trunk_mlp2_fwd(const float *x, const float *feat, const float *dydx, cons
     attr_a.set((const void *)k_trunk_fwd2<false>, (int)lds);
     attr_b.set((const void *)k_trunk_fwd2<true>, (int)lds);
     const int64_t ntiles = (M + kRows - 1) / kRows;
-    static const bool spread = [] { const char *e = getenv("HOLOSCENE_TRUNK2_SPREAD"); return !(e && e[0] == '0'); }();      // A/B: 0 = packed workgroups
+    constexpr bool spread = true;      // (false: packed workgroups, 24.8 against 20.6 us -- DESIGN 14.10)
     const int64_t want = spread ? ntiles : (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
     // w2_planes = 1: the caller evaluates nothing but the Eikonal regulariser's points -- only their gradients are used, a training with those
@@ -628,7 +628,7 @@ int hs_trunk_mlp2_fwd_wide(const float *x, const float *feat, const float *dydx,
     static hsLdsAttrOnce attr;
     attr.set((const void *)k_trunk_fwd2<true, true>, (int)lds);
     const int64_t ntiles = (M + kRows - 1) / kRows;
-    static const bool spread = [] { const char *e = getenv("HOLOSCENE_TRUNK2_SPREAD"); return !(e && e[0] == '0'); }();
+    constexpr bool spread = true;
     const int64_t want = spread ? ntiles : (ntiles + kWaves - 1) / kWaves;
     const int grid = (int)(want < 256 ? want : 256);
     k_trunk_fwd2<true, true><<<grid, kThreadsW, lds, (hipStream_t)stream>>>(x, feat, dydx, (const uint16_t *)W0f, (const uint16_t *)W1f, (const uint16_t *)W2f, bias,

@@ -9,6 +9,8 @@
 // and keeps the whole result of its slice in registers (256 x 256 fp32 = 128 VGPRs per wave, 8 waves).  The operands run along the ROWS
 // of row-major tiles, which is what gfx950's transposing LDS read delivers (`ds_read_b64_tr_b16`, sdf_mlp.hip: tr_frag).
 // Partial results leave as bf16 slices [S, NA, MB] (the same rounding the library's bf16 bmm output had); hs_sum_slices adds them in fp32.
+// Status (round 6): the benchmarked path forms its weight gradients in wgrad_pairs.hip; hs_wgrad_rows serves the workgroup-tile kernel family
+// (appearance_mlp.hip, the d_out > 64 / non-stock fallbacks' row-major operands) and the tests that cross-check the two.
 #include "launch_util.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -423,7 +423,7 @@ int hs_wgrad_pairs(const hsWgradPairJob *jobs, int32_t n_jobs, void *stream) {
     if (!jobs) return HS_ERR_NULL;
     PairJobs pj;
     pj.n = n_jobs;
-    static const bool dma = [] { const char *e = getenv("HOLOSCENE_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+    constexpr bool dma = true;
     pj.dma = dma ? 1 : 0;
     pj.first[0] = 0;
     for (int i = 0; i < n_jobs; i++) {

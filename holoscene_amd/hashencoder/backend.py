@@ -190,7 +190,7 @@ def _stream():
 
 SCHEDULE = int(os.environ.get("HOLOSCENE_HASH_SCHEDULE", "1"))
 # Scatter the hashed levels through per-bin record lists + an LDS reduction instead of global atomics (csrc/hash_encode.hip)
-SCATTER_BINS = os.environ.get("HOLOSCENE_SCATTER_BINS", "1") != "0"
+SCATTER_BINS = True
 
 def accumulates_into_grad(table):
     """True for a hash table whose gradient lives in flat gradient storage (training/flat.py marks the parameter with

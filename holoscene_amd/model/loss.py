@@ -17,7 +17,7 @@ from ..utils.conf import get_class
 
 # "hip": value + analytic gradient of the per-ray and Eikonal/smoothness terms in two fused kernels (csrc/loss.hip);
 # "torch": the whole-tensor formulation below (A/B reference, and what CPU host-logic tests select explicitly).
-LOSS_IMPL = os.environ.get("HOLOSCENE_LOSS_IMPL", "hip")
+LOSS_IMPL = "hip"
 
 
 _ZERO = {}

@@ -137,36 +137,40 @@ class _trunk_input(torch.autograd.Function):
         return None, g_emb, None, None, None, None, None, None, None, None
 
 
+# ---- implementation selectors.  MODULE CONSTANTS since round 6, not environment switches: the other side of each is either a measured loser (DESIGN.md,
+# appendix) or the older kernel family the tests keep as a cross-check, which they select by patching the attribute.  The environment switches that
+# remain are listed in README.md ("Switches").
+W2_SINGLE_PLANE = False     # ablation of DESIGN 14.2: the last trunk layer as ONE bf16 plane in the workgroup-tile kernels' forward
 # "mfma": the bf16 trunk forward runs in ONE matrix-core kernel (csrc/sdf_mlp.hip, k_trunk_fwd) when the layer shapes are the
 # stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
-TRUNK_IMPL = os.environ.get("HOLOSCENE_TRUNK_IMPL", "mfma")
+TRUNK_IMPL = "mfma"
 # inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
 # activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
-SDF_MLP_IMPL = os.environ.get("HOLOSCENE_SDF_MLP_IMPL", "wave")
+SDF_MLP_IMPL = "wave"
 # the sampler's sweeps gather their hash features inside the trunk kernel (hs_sdf_sweep_fwd: one launch per sweep, bit-identical).  Built in round 6 and
 # MEASURED SLOWER than the two launches (gather 31 + trunk 32 us -> 70 us one lane per point, 80 us two lanes per point; profiles/r06/fused_sweep.txt,
 # DESIGN 15.2): at the trunk's two waves per SIMD the gather's index arithmetic and reads run serially in front of the matrix products.  Default off.
 SDF_SWEEP_FUSED = os.environ.get("HOLOSCENE_SDF_SWEEP_FUSED", "0") != "0"
-SDF_WIDE = os.environ.get("HOLOSCENE_SDF_WIDE", "1") != "0"     # 33..64 objects: sampler sweeps on the wave-tile kernel (0: workgroup-tile kernel, A/B)
+SDF_WIDE = True     # 33..64 objects: sampler sweeps on the wave-tile kernel (0: workgroup-tile kernel, A/B)
 # the no-grad SDF queries of the fp32 configuration: "mfma" = csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32), "gemm" = library GEMMs
-FP32_SDF = os.environ.get("HOLOSCENE_FP32_SDF", "mfma")
+FP32_SDF = "mfma"
 _TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
 # weight gradients of the fused MLPs: "hip" = csrc/wgrad.hip (all products of a backward stage in one launch), "gemm" = library batched GEMMs
-WGRAD_IMPL = os.environ.get("HOLOSCENE_WGRAD_IMPL", "hip")
-TRUNK_W2_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_W2_IN_KERNEL", "1") == "1"   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
+WGRAD_IMPL = "hip"
+TRUNK_W2_IN_KERNEL = True   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
 _FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
 _BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
 # 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
 # 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
-TRUNK_INPUT_IN_KERNEL = os.environ.get("HOLOSCENE_TRUNK_INPUT_IN_KERNEL", "0") != "0"
+TRUNK_INPUT_IN_KERNEL = False
 # forward pass of the training trunk: "wave" = csrc/trunk_mlp2.hip (wave-tile form: builds its own input rows from x / features / dy_dx,
 # register-resident activations; d_out <= 32), "tile" = k_trunk_fwd of csrc/sdf_mlp.hip fed by k_trunk_input_fwd
-TRUNK_FWD_IMPL = os.environ.get("HOLOSCENE_TRUNK_FWD_IMPL", "wave")
-TRUNK_WIDE = os.environ.get("HOLOSCENE_TRUNK_WIDE", "1") != "0"   # 33..64 objects: the training trunk's forward on the wave-tile kernel (k_trunk_fwd2<true, true>)
+TRUNK_FWD_IMPL = "wave"
+TRUNK_WIDE = True   # 33..64 objects: the training trunk's forward on the wave-tile kernel (k_trunk_fwd2<true, true>)
 # the wave-tile trunk kernel writes the per-object SDFs / minimum / its gradient itself ("1") or stores Y for hs_trunk_split_fwd ("0")
-TRUNK_SPLIT_FUSED = os.environ.get("HOLOSCENE_TRUNK_SPLIT_FUSED", "1") != "0"
+TRUNK_SPLIT_FUSED = True
 # the trunk's weight-gradient GEMMs before ("1") or after ("0") the table scatter of the same backward stage (_trunk_bwd_core)
-TRUNK_WGRAD_FIRST = os.environ.get("HOLOSCENE_TRUNK_WGRAD_FIRST", "1") != "0"
+TRUNK_WGRAD_FIRST = True
 _XP_COLUMNS = {}
 
 
@@ -278,7 +282,7 @@ def _w2_planes(f2, d_out, KP, scale=1.0):
     w2 = torch.empty(2 * KP, 256, device=f2.device, dtype=torch.bfloat16)
     f2s = f2 * scale if scale != 1.0 else f2
     lo = (f2s - f2s.to(torch.bfloat16).float()).contiguous()
-    if os.environ.get("HOLOSCENE_W2_PLANES", "2") == "1":      # ablation: the single-plane products of rounds 1-4
+    if W2_SINGLE_PLANE:      # ablation: the single-plane products of rounds 1-4
         lo = torch.zeros_like(lo)
     _be._backend.pack_bf16([(f2s.contiguous(), w2[:KP], 0, 0, d_out, 256, False), (lo, w2[KP:], 0, 0, d_out, 256, False)])
     return w2
@@ -500,7 +504,7 @@ def _rr_slices(n, budget=256):
     return fine, coarse, coarse
 
 
-_PAIR_REG_COST = float(os.environ.get("HOLOSCENE_PAIR_REG_COST", "1.5"))
+_PAIR_REG_COST = 1.5
 _PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432, (256, 128): 24576}      # bytes of one operand pair per 32-row tile
 
 
@@ -888,20 +892,20 @@ def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, 
 
 # "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
 # bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
-APPEARANCE_IMPL = os.environ.get("HOLOSCENE_APPEARANCE_IMPL", "mfma")
+APPEARANCE_IMPL = "mfma"
 # k_appear_bwd takes the ReLU signs from ballots the forward kernel wrote ("1") or from the saved layer outputs hc, r0, r1 ("0")
-APPEARANCE_RELU_MASKS = os.environ.get("HOLOSCENE_APPEARANCE_RELU_MASKS", "1") != "0"
+APPEARANCE_RELU_MASKS = True
 # background-surface pass of render(): "hip" = the main pass's fused kernels (trunk + split, compositing) when their shapes are
 # supported; "torch" = the whole-tensor formulation (always used otherwise)
-BG_IMPL = os.environ.get("HOLOSCENE_BG_IMPL", "hip")
+BG_IMPL = "hip"
 
 
 # weight gradients of the appearance branch: "pairs" = six row-major jobs of one hs_wgrad_pairs launch (byte-proportional slices),
 # "rows" = hs_wgrad_rows (csrc/wgrad.hip: 128 equal slices per product)
-APPEARANCE_WGRAD = os.environ.get("HOLOSCENE_APPEARANCE_WGRAD", "pairs")
+APPEARANCE_WGRAD = "pairs"
 # "fused": k_rr_fwd, the value and the gradient chain of a sample tile in one kernel (bit-identical outputs; 107-112 us against 52 + 70 for
 # the pair, same box, alternating runs); "split": k_rr_fwd_value then k_rr_fwd_grad
-RR_FORWARD = os.environ.get("HOLOSCENE_RR_FORWARD", "fused")
+RR_FORWARD = "fused"
 
 
 class _fused_appearance(torch.autograd.Function):
@@ -996,7 +1000,7 @@ class _fused_appearance(torch.autograd.Function):
 # form of the fused colour branch: "wave" = csrc/appearance2.hip (a wave owns 32 samples through all five layers, weight chunks shared
 # through LDS, tile-packed saved activations, the weight gradients on hs_wgrad_pairs' tile-packed kinds), "tile" = csrc/appearance_mlp.hip
 # (128-point workgroup tiles; row-major saved activations)
-APPEARANCE_FORM = os.environ.get("HOLOSCENE_APPEARANCE_FORM", "wave")
+APPEARANCE_FORM = "wave"
 _XA_COLS = {}
 
 
@@ -1184,7 +1188,7 @@ def _split_rows(M):
 # planes per operand (three: the accuracy of an fp32 GEMM, measured 1.1-1.2x the library on the 256-wide layers; two: 16 mantissa
 # bits per operand, 1.4-1.6x)
 # the sampler's hash features between the gather and the SDF trunk kernel as bf16 words (identical results, half the bytes) / as fp32
-SDF_FEAT_BF16 = os.environ.get("HOLOSCENE_SDF_FEAT_BF16", "1") != "0"
+SDF_FEAT_BF16 = True
 FP32_GEMM_PLANES = {"lib": 0, "split3": 3, "split2": 2}[os.environ.get("HOLOSCENE_FP32_GEMM", "lib")]
 _SPLIT_MIN_ROWS = 4096
 
@@ -1261,7 +1265,7 @@ def linear_rows(x, weight, bias=None, bf16=False):
 
 # "hip": fused per-ray compositing kernels (csrc/composite.hip); "torch": the whole-tensor formulation
 # (HoloSceneNetwork.volume_rendering / occlusion_opacity), kept for A/B and for CPU host-logic tests.
-COMPOSITE_IMPL = os.environ.get("HOLOSCENE_COMPOSITE_IMPL", "hip")
+COMPOSITE_IMPL = "hip"
 
 
 class _composite(torch.autograd.Function):

@@ -35,11 +35,11 @@ SAMPLER_IMPL = os.environ.get("HOLOSCENE_SAMPLER_IMPL", "hip")
 CONTROL = os.environ.get("HOLOSCENE_SAMPLER_CONTROL", "device")
 # device-controlled loop: the next round's draw fused into the update launch, rounds gated on the previous round's max beta ("1"),
 # or one draw + control-step launch per round between control slots ("0")
-FUSE_DRAW = os.environ.get("HOLOSCENE_SAMPLER_FUSE_DRAW", "1") != "0"
+FUSE_DRAW = True
 # fp32 configuration: with the fused fp32 SDF sweep (csrc/sdf_mlp32.hip, gated launches) the loop control can live on the device there too
-FP32_DEVICE_CONTROL = os.environ.get("HOLOSCENE_FP32_DEVICE_CONTROL", "1") != "0"
+FP32_DEVICE_CONTROL = True
 # ... and the tail -- final draw, extra-sample pick, merge / sort -- one launch instead of three (hs_sampler_tail); "0" restores the three
-FUSE_TAIL = os.environ.get("HOLOSCENE_SAMPLER_FUSE_TAIL", "1") != "0"
+FUSE_TAIL = True
 
 
 def _rand(shape, device, cpu_rng):

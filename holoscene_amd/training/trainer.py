@@ -313,8 +313,8 @@ class Stage1Trainer:
         if self._table_step and tick is not None and variant not in self._table_step_ok and not torch.cuda.is_current_stream_capturing():
             counting, _net._be.SCATTER_COUNTS = True, {}
         self._pass_fused = fused
-        # fused: the 1.3 MB memset rides in the prologue launch below (HOLOSCENE_PROLOGUE_ZERO=0: its own fill launch, A/B)
-        zero = self.flat.zero_grad(tables=not fused, defer=fused and os.environ.get("HOLOSCENE_PROLOGUE_ZERO", "1") != "0")
+        # fused: the 1.3 MB memset rides in the prologue launch below
+        zero = self.flat.zero_grad(tables=not fused, defer=fused)
         self._arm_early_exchange()
         steps = self.flat.table_steps(producers=self._table_producers.get(variant)) if fused else contextlib.nullcontext()
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
