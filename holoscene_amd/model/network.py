@@ -35,1596 +35,10 @@ from .ray_sampler import ErrorBoundSampler
 
 
 # ------------------------------------------------------------------------------------------------
-class _hash_encode_jac(torch.autograd.Function):
-    """(x01, embeddings) -> (features [B, L*C], dy_dx [L, B, D*C]); once differentiable.
-
-    backward: grad_embeddings = d<features,g_f>/dE + d<dy_dx,g_j>/dE in one scatter pass; the
-    gradient w.r.t. x01 is <g_f, dy_dx> (the reference likewise drops d(dy_dx)/dx, hashgrid.py:101).
-    """
-
-    @staticmethod
-    def forward(ctx, x01, embeddings, offsets, S, H):
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        if ctx.needs_input_grad[1]:
-            _be.expect_scatter(ctx.table)
-        x01 = x01.contiguous()
-        B, D = x01.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        feat = torch.empty(B, L * C, device=x01.device, dtype=x01.dtype)
-        dydx = torch.empty(L, B, D * C, device=x01.device, dtype=x01.dtype)
-        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, H, dydx)
-        ctx.save_for_backward(x01, embeddings, offsets, dydx)
-        ctx.dims = (B, D, C, L, S, H)
-        return feat, dydx
-
-    @staticmethod
-    def backward(ctx, g_feat, g_dydx):
-        x01, embeddings, offsets, dydx = ctx.saved_tensors
-        B, D, C, L, S, H = ctx.dims
-        g_emb = g_x = None
-        if ctx.needs_input_grad[1]:
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            _be._backend.bwd_jac(None if g_feat is None else g_feat.contiguous(), None if g_dydx is None else g_dydx.contiguous(),
-                                 x01, offsets, target, B, D, C, L, S, H)
-            g_emb = None if inplace else target
-            if inplace:
-                _be.scatter_done(table)
-        if ctx.needs_input_grad[0] and g_feat is not None:
-            g_x = torch.empty_like(x01)
-            _be._backend.bwd(g_feat.contiguous(), x01, offsets, None, B, D, C, L, S, H, dydx, g_x)
-        return g_x, g_emb, None, None, None
-
-
-def hash_encode_jac(encoder, x, size=1.0):
-    """HashEncoder.forward plus the Jacobian w.r.t. the *unnormalised* input x:
-    returns feat [B, L*C] and jac [B, D, L*C] with jac[b,d,:] = d feat / d x_d."""
-    x01 = (x + size) / (2 * size)
-    feat, dydx = _hash_encode_jac.apply(x01.view(-1, encoder.input_dim), encoder.embeddings, encoder.offsets,
-                                        float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution))
-    L, B, _ = dydx.shape
-    D, C = encoder.input_dim, encoder.level_dim
-    jac = dydx.view(L, B, D, C).permute(1, 2, 0, 3).reshape(B, D, L * C) * (1.0 / (2 * size))
-    return feat, jac
-
-
-class _trunk_input(torch.autograd.Function):
-    """x [B,3] (constant) + hash table -> the 4-row trunk input [B,4,F] (value row + d/dx rows) in two kernels:
-    hash encode (features + dy_dx) and the fused posenc/Jacobian/concat builder (csrc/encode_ops.hip).
-    backward: one slicing kernel + the fused value+Jacobian scatter into the table gradient."""
-
-    @staticmethod
-    def forward(ctx, x, embeddings, offsets, S, H, nfreq, divide_factor, out_dtype, center=None, obj_scale=1.0):
-        """center / obj_scale: the per-object frame of SingleObjectImplicitNetworkGrid (network.py:1947): the grid is looked up at
-        (x - center) / obj_scale / divide_factor while the positional encoding sees x itself."""
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        if ctx.needs_input_grad[1]:
-            _be.expect_scatter(ctx.table)
-        x = x.contiguous()
-        xg = x if center is None else (x - center) / obj_scale
-        x01 = ((xg / divide_factor + 1.0) / 2.0).contiguous()   # HashEncoder.forward's mapping to [0,1] (hashgrid.py:158)
-        B, D = x01.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        feat = torch.empty(B, L * C, device=x.device, dtype=x.dtype)
-        dydx = torch.empty(L, B, D * C, device=x.device, dtype=x.dtype)
-        _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, H, dydx)
-        jac_scale = 0.5 / (divide_factor * obj_scale)
-        out = torch.empty(B, 4, 3 + 6 * nfreq + L * C, device=x.device, dtype=out_dtype)
-        _be._backend.trunk_input_fwd(x, feat, dydx, out, nfreq, L, C, jac_scale)
-        ctx.save_for_backward(x01, embeddings, offsets)
-        ctx.cfg = (B, D, C, L, S, H, nfreq, jac_scale)
-        return out
-
-    @staticmethod
-    def backward(ctx, G):
-        x01, embeddings, offsets = ctx.saved_tensors
-        B, D, C, L, S, H, nfreq, jac_scale = ctx.cfg
-        g_emb = None
-        if ctx.needs_input_grad[1]:
-            g_feat = torch.empty(B, L * C, device=G.device, dtype=torch.float32)
-            g_dydx = torch.empty(L, B, D * C, device=G.device, dtype=torch.float32)
-            _be._backend.trunk_input_bwd(G.contiguous(), g_feat, g_dydx, nfreq, L, C, jac_scale)
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, H)
-            g_emb = None if inplace else target
-            if inplace:
-                _be.scatter_done(table)
-        return None, g_emb, None, None, None, None, None, None, None, None
-
-
-# ---- implementation selectors.  MODULE CONSTANTS since round 6, not environment switches: the other side of each is either a measured loser (DESIGN.md,
-# appendix) or the older kernel family the tests keep as a cross-check, which they select by patching the attribute.  The environment switches that
-# remain are listed in README.md ("Switches").
-W2_SINGLE_PLANE = False     # ablation of DESIGN 14.2: the last trunk layer as ONE bf16 plane in the workgroup-tile kernels' forward
-# "mfma": the bf16 trunk forward runs in ONE matrix-core kernel (csrc/sdf_mlp.hip, k_trunk_fwd) when the layer shapes are the
-# stock 71->256->256->K; "gemm": library GEMMs + softplus_tangent stages (always used for fp32 and non-stock shapes).
-TRUNK_IMPL = "mfma"
-# inference SDF trunk (the sampler's sweeps): "wave" = csrc/sdf_mlp2.hip (a wave owns 32 points end to end, register-resident
-# activations, LDS-resident weights; d_out <= 32), "tile" = csrc/sdf_mlp.hip (one 128-point tile per workgroup; any d_out <= 64)
-SDF_MLP_IMPL = "wave"
-# the sampler's sweeps gather their hash features inside the trunk kernel (hs_sdf_sweep_fwd: one launch per sweep, bit-identical).  Built in round 6 and
-# MEASURED SLOWER than the two launches (gather 31 + trunk 32 us -> 70 us one lane per point, 80 us two lanes per point; profiles/r06/fused_sweep.txt,
-# DESIGN 15.2): at the trunk's two waves per SIMD the gather's index arithmetic and reads run serially in front of the matrix products.  Default off.
-SDF_SWEEP_FUSED = os.environ.get("HOLOSCENE_SDF_SWEEP_FUSED", "0") != "0"
-SDF_WIDE = True     # 33..64 objects: sampler sweeps on the wave-tile kernel (0: workgroup-tile kernel, A/B)
-# the no-grad SDF queries of the fp32 configuration: "mfma" = csrc/sdf_mlp32.hip (fp32 operands on v_mfma_f32_32x32x2_f32), "gemm" = library GEMMs
-FP32_SDF = "mfma"
-_TRUNK_PITCH = 96   # k_trunk_fwd's padded input width
-# weight gradients of the fused MLPs: "hip" = csrc/wgrad.hip (all products of a backward stage in one launch), "gemm" = library batched GEMMs
-WGRAD_IMPL = "hip"
-TRUNK_W2_IN_KERNEL = True   # dW2 accumulated inside k_trunk_bwd (else a library GEMM)
-_FROM_KERNEL = object()   # _trunk_bwd_core: take the last layer's bias gradient from k_trunk_bwd's column sums
-_BIN_MIN_POINTS = 16384   # below this the binned scatter's fixed costs (704 reduce workgroups, 46 MB of table RMW) do not pay
-# 1: k_trunk_fwd assembles its input rows itself instead of reading hs_trunk_input_fwd's output (measured neutral: 3.962 vs
-# 3.954 ms per iteration, same box; the serial staging inside the matrix-core kernel costs what the separate launch did)
-TRUNK_INPUT_IN_KERNEL = False
-# forward pass of the training trunk: "wave" = csrc/trunk_mlp2.hip (wave-tile form: builds its own input rows from x / features / dy_dx,
-# register-resident activations; d_out <= 32), "tile" = k_trunk_fwd of csrc/sdf_mlp.hip fed by k_trunk_input_fwd
-TRUNK_FWD_IMPL = "wave"
-TRUNK_WIDE = True   # 33..64 objects: the training trunk's forward on the wave-tile kernel (k_trunk_fwd2<true, true>)
-# the wave-tile trunk kernel writes the per-object SDFs / minimum / its gradient itself ("1") or stores Y for hs_trunk_split_fwd ("0")
-TRUNK_SPLIT_FUSED = True
-# the trunk's weight-gradient GEMMs before ("1") or after ("0") the table scatter of the same backward stage (_trunk_bwd_core)
-TRUNK_WGRAD_FIRST = True
-_XP_COLUMNS = {}
-
-
-def _xp_columns(dev):
-    """Position in the wave-tile kernel's 80-column input image of each of the 71 reference input columns (device int64)."""
-    key = str(dev)
-    if key not in _XP_COLUMNS:
-        _XP_COLUMNS[key] = _be._backend.trunk_mlp2_columns().to(dev)
-    return _XP_COLUMNS[key]
-
-
-class _Outputs(dict):
-    """render()'s output dictionary.  An entry registered with defer() is evaluated on first access (or when the dictionary is
-    enumerated): per-sample products nobody reads during training then cost no launch in the replayed iteration."""
-
-    def defer(self, key, fn):
-        self.__dict__.setdefault("_deferred", {})[key] = fn
-
-    def _pending(self):
-        return self.__dict__.get("_deferred", {})
-
-    def __missing__(self, key):
-        fn = self._pending().pop(key, None)
-        if fn is None:
-            raise KeyError(key)
-        self[key] = v = fn()
-        return v
-
-    def _materialise(self):
-        for k in list(self._pending()):
-            self[k]
-        return self
-
-    def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._pending()
-
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
-    def keys(self):
-        return dict.keys(self._materialise())
-
-    def items(self):
-        return dict.items(self._materialise())
-
-    def values(self):
-        return dict.values(self._materialise())
-
-    def __iter__(self):
-        return dict.__iter__(self._materialise())
-
-    def __len__(self):
-        return dict.__len__(self._materialise())
-
-    def pop(self, key, *default):
-        fn = self._pending().pop(key, None)        # a deferred entry is evaluated by pop like by any other read (dict semantics)
-        if fn is not None:
-            return fn()
-        return dict.pop(self, key, *default)
-
-
-def _xp_columns32(dev):
-    key = "i32:" + str(dev)
-    if key not in _XP_COLUMNS:
-        _XP_COLUMNS[key] = _xp_columns(dev).to(torch.int32)
-    return _XP_COLUMNS[key]
-
-
-def _wgrad_rows(g, x):
-    """g^T @ x over M rows as a split-M batched GEMM (see _linear_rows) -> fp32 [g.shape[1], x.shape[1]]."""
-    M = x.shape[0]
-    S = _split_rows(M)
-    if S > 1:
-        return torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
-    return (g.t() @ x).float()
-
-
-def _wgrad_rows_many(pairs, ready_parts=()):
-    """[_wgrad_rows(g, x) for g, x in pairs] with the slice sums of all of them in ONE launch (hs_sum_slices); `ready_parts` are
-    slice stacks some kernel already produced (k_trunk_bwd's dW2 slices): their sums are appended to the result."""
-    parts, direct, mine = [], {}, []
-    for i, (g, x) in enumerate(pairs):
-        M = x.shape[0]
-        S = _split_rows(M)
-        if (WGRAD_IMPL == "hip" and S == 128 and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_cuda and g.is_contiguous()
-                and x.is_contiguous() and (g.shape[1], x.shape[1]) in _be._backend.WGRAD_SHAPES):
-            mine.append((i, g, x))          # hs_wgrad_rows: all such products of this call in one launch (csrc/wgrad.hip)
-        elif S > 1 and g.dtype == torch.bfloat16 and g.is_cuda and (g.shape[1] * x.shape[1]) % 4 == 0:
-            parts.append((i, torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1))))
-        else:
-            direct[i] = _wgrad_rows(g, x)
-    if len(mine) >= 2:     # two or more products fill the chip together (tools/microbench_wgrad.py: six appearance products 123 vs 171 us)
-        parts += [(i, p) for (i, _, _), p in zip(mine, _be._backend.wgrad_rows([(g, x) for _, g, x in mine], 128))]
-    else:                  # a single product is 128 workgroups here; the library's kernel for it is faster (89 vs 168 us at M = 417 792)
-        for i, g, x in mine:
-            M = x.shape[0]
-            parts.append((i, torch.bmm(g.view(128, M // 128, -1).transpose(1, 2), x.view(128, M // 128, -1))))
-    stacks = [p for _, p in parts] + list(ready_parts)
-    sums = _be._backend.sum_slices(stacks) if stacks else []
-    for (i, _), s_ in zip(parts, sums):
-        direct[i] = s_
-    return [direct[i] for i in range(len(pairs))] + sums[len(parts):]
-
-
-def _w2_planes(f2, d_out, KP, scale=1.0):
-    """The last trunk layer for the workgroup-tile kernels (csrc/sdf_mlp.hip): bf16 [2 KP, 256] = [W2 | W2 - bf16(W2)] (rows >= d_out of each
-    plane zero), both scaled -- the second plane carries what one bf16 plane of these rows (a large common value plus small learned
-    structure) loses."""
-    w2 = torch.empty(2 * KP, 256, device=f2.device, dtype=torch.bfloat16)
-    f2s = f2 * scale if scale != 1.0 else f2
-    lo = (f2s - f2s.to(torch.bfloat16).float()).contiguous()
-    if W2_SINGLE_PLANE:      # ablation: the single-plane products of rounds 1-4
-        lo = torch.zeros_like(lo)
-    _be._backend.pack_bf16([(f2s.contiguous(), w2[:KP], 0, 0, d_out, 256, False), (lo, w2[KP:], 0, 0, d_out, 256, False)])
-    return w2
-
-
-def _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None, split=None):
-    """hash encode -> 4-row bf16 input (pitch 96) -> k_trunk_fwd.  Returns Y [4B, d_out] fp32 and the tensors to save.
-    x01: optionally the grid coordinates (x/divide_factor + 1)/2 already computed (hs_render_points).
-    split: hs_trunk_split_fwd's (n_main, outputs...) -- where the wave-tile kernel runs it writes them itself and the returned Y is
-    None (nothing stored); otherwise Y is returned and the caller runs the split kernel."""
-    ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-    x = x.contiguous()
-    if x01 is None:
-        x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
-    B, D = x01.shape
-    L = offsets.shape[0] - 1
-    C = embeddings.shape[1]
-    dev, bf = x.device, torch.bfloat16
-    feat = torch.empty(B, L * C, device=dev, dtype=x.dtype)
-    dydx = torch.empty(L, B, D * C, device=dev, dtype=x.dtype)
-    _be._backend.fwd(x01, embeddings, offsets, feat, B, D, C, L, S, Hres, dydx)
-    jac_scale = 0.5 / divide_factor
-    F_in, d_out = W0.shape[1], W2.shape[0]
-    KP = 32 * ((d_out + 31) // 32)
-    M = 4 * B
-    H0 = torch.empty(M, 256, device=dev, dtype=bf)
-    H1 = torch.empty(M, 256, device=dev, dtype=bf)
-    stock = nfreq == 6 and L == 16 and C == 2 and D == 3 and F_in == 71      # the kernel hard-codes the stock 16 x 2 grid
-    wave = TRUNK_FWD_IMPL == "wave" and d_out <= 32 and stock
-    # 33..64 outputs: the same kernel with the last layer's second tile in its tail (split outputs only)
-    wide = TRUNK_FWD_IMPL == "wave" and TRUNK_WIDE and 32 < d_out <= 64 and stock and split is not None and TRUNK_SPLIT_FUSED
-    fuse_split = (wave and split is not None and TRUNK_SPLIT_FUSED) or wide      # the kernel writes the split outputs itself: no Y at all
-    Y = None if fuse_split else torch.empty(M, d_out, device=dev, dtype=torch.float32)
-    bb = [t.detach().float().contiguous() for t in (b0, b1, b2)]
-    w1t, w2t = torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, KP, device=dev, dtype=bf)   # the backward kernel's operands
-    w0t = torch.empty(256, 256, device=dev, dtype=bf)                                                    # W0^T, rows >= F_in zero
-    f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-    if wide:
-        _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
-        pk = _be._backend.sdf_mlp2_pack
-        pa = pk(f0, bb[0], f1, bb[1], f2[:32].contiguous(), bb[2][:32].contiguous(), 32, log2_domain=False)
-        pb = pk(f0, bb[0], f1, bb[1], f2[32:].contiguous(), bb[2][32:].contiguous(), d_out - 32, log2_domain=False)
-        Xp = torch.empty(M, 80, device=dev, dtype=bf)
-        _be._backend.trunk_mlp2_fwd_wide(x.float(), feat, dydx, pa, pb, d_out, H0, H1, Xp, jac_scale, split)
-        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
-        return None, (x01, embeddings, offsets, Xp, H0, H1, w0t, w1t, w2t)
-    if wave:
-        # wave-tile forward (csrc/trunk_mlp2.hip): fragment-order operands, input rows assembled in the kernel and kept as Xp [M,80]
-        _be._backend.pack_bf16([(f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
-        packed = _be._backend.sdf_mlp2_pack(f0, bb[0], f1, bb[1], f2, bb[2], d_out, log2_domain=False)
-        Xp = torch.empty(M, 80, device=dev, dtype=bf)
-        _be._backend.trunk_mlp2_fwd(x.float(), feat, dydx, packed, d_out, H0, H1, Y, Xp, jac_scale, split if fuse_split else None)
-        ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
-        return Y, (x01, embeddings, offsets, Xp, H0, H1, w0t, w1t, w2t)
-    if TRUNK_FWD_IMPL not in ("wave", "tile"):
-        raise RuntimeError(f"unknown HOLOSCENE_TRUNK_FWD_IMPL={TRUNK_FWD_IMPL!r}")
-    X = torch.empty(B, 4, _TRUNK_PITCH, device=dev, dtype=bf)
-    build_in_kernel = TRUNK_INPUT_IN_KERNEL and nfreq == 6 and L == 16 and C == 2 and D == 3   # k_trunk_fwd assembles its input rows itself
-    if not build_in_kernel:
-        _be._backend.trunk_input_fwd(x, feat, dydx, X, nfreq, L, C, jac_scale)
-    w0, w1 = torch.empty(256, _TRUNK_PITCH, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf)
-    w2 = _w2_planes(f2, d_out, KP)
-    _be._backend.pack_bf16([(f0, w0, 0, 0, 256, F_in, False), (f1, w1, 0, 0, 256, 256, False),
-                            (f1, w1t, 0, 0, 256, 256, True), (f2, w2t, 0, 0, 256, d_out, True), (f0, w0t, 0, 0, F_in, 256, True)])
-    if build_in_kernel:
-        _be._backend.trunk_mlp_fwd(None, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y, x.float(), feat, dydx, X, L, C, jac_scale)
-    else:
-        _be._backend.trunk_mlp_fwd(X, w0, bb[0], w1, bb[1], w2, bb[2], d_out, H0, H1, Y)
-    ctx.cfg = (B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out)
-    return Y, (x01, embeddings, offsets, X, H0, H1, w0t, w1t, w2t)
-
-
-def _trunk_bwd_core(ctx, saved, g, gb2, need_table, need_w):
-    """g: cotangent of Y as a bf16 [4B, KP] image.  Returns the gradients of (embeddings, W0, b0, W1, b1, W2, b2):
-    k_trunk_bwd for the data path, library split-M GEMMs for the weight gradients, the 256->96 input-gradient GEMM, and the
-    fused value+Jacobian scatter into the table gradient."""
-    x01, embeddings, offsets, X, H0, H1, w0t, w1t, w2t = saved
-    B, D, C, L, S, Hres, nfreq, jac_scale, F_in, d_out = ctx.cfg
-    dev, bf = X.device, torch.bfloat16
-    M = 4 * B
-    gA1 = torch.empty(M, 256, device=dev, dtype=bf)
-    gA0 = torch.empty(M, 256, device=dev, dtype=bf)
-    KP = g.shape[1]
-    gbz = _be.zeros_small(2 * 256 + KP, dev)         # one zero-fill for the three bias-gradient accumulators
-    gb1, gb0, gb2k = gbz[:256], gbz[256:512], gbz[512:]
-    g_feat = g_dydx = None
-    if need_table:   # produced by the same kernel: the hash-feature part of the input cotangent, laid out for the scatter
-        g_feat = torch.empty(L, B, C, device=dev, dtype=torch.float32)     # level-major: coalesced for both writer and scatter
-        g_dydx = torch.empty(L, B, D * C, device=dev, dtype=torch.float32)
-    # the last layer's weight gradient g^T . H1 is accumulated by the same kernel (per-workgroup slices, summed with the GEMM partials below)
-    w2_part = torch.empty(_be._backend.trunk_bwd_parts(M), KP, 256, device=dev) if (need_w and TRUNK_W2_IN_KERNEL) else None
-    _be._backend.trunk_mlp_bwd(g, H1, H0, w2t, w1t, gA1, gA0, gb1, gb0, w0t if need_table else None, g_feat, g_dydx, L, C, jac_scale,
-                               gb2=gb2k if gb2 is _FROM_KERNEL else None, dW2_part=w2_part)
-    if gb2 is _FROM_KERNEL:
-        gb2 = gb2k[:d_out]
-
-    def scatter():
-        table = ctx.table
-        inplace = _be.accumulates_into_grad(table)
-        target = table.grad if inplace else torch.zeros_like(embeddings)
-        _be._backend.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, D, C, L, S, Hres,
-                             ws=_be._backend.scatter_workspace(B, D, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
-        if inplace:
-            _be.scatter_done(table)     # data parallelism: the SDF table's segment can go while the weight-gradient GEMMs run
-        return None if inplace else target
-
-    def weight_gradients():
-        Xm = X.view(M, X.shape[-1])       # [M, 96] reference column order, or the wave-tile kernel's [M, 80] image in its own order
-        if w2_part is not None:
-            gW1, gW0, gW2 = _wgrad_rows_many([(gA1, H0), (gA0, Xm)], ready_parts=[w2_part])
-        else:
-            gW2, gW1, gW0 = _wgrad_rows_many([(g, H1), (gA1, H0), (gA0, Xm)])
-        gW0 = gW0[:, :F_in] if Xm.shape[1] == _TRUNK_PITCH else gW0.index_select(1, _xp_columns(dev))
-        return gW2[:d_out], gW1, gW0
-
-    # Order of the two consumers of k_trunk_bwd's outputs.  The weight-gradient GEMMs are HBM-bound readers of gA1 / gA0 (0.59 GB
-    # the kernel has just written): run FIRST they find the tail of it in the 256 MB memory-side cache, run after the scatter
-    # (0.25 GB of its own traffic) they do not.  Under data parallelism the scatter goes first instead: the SDF table's exchange
-    # then runs under the GEMMs (training/trainer.py), which is worth more than the cache hits.
-    g_emb = None
-    gW2 = gW1 = gW0 = None
-    wgrad_first = TRUNK_WGRAD_FIRST and getattr(ctx.table, "_hs_scatter_watch", None) is None
-    if need_w and wgrad_first:
-        gW2, gW1, gW0 = weight_gradients()
-    if need_table:
-        g_emb = scatter()
-    if need_w and not wgrad_first:
-        gW2, gW1, gW0 = weight_gradients()
-    return g_emb, gW0, gb0, gW1, gb1, gW2, gb2
-
-
-class _fused_trunk(torch.autograd.Function):
-    """x [B,3] (constant), hash table, the three effective weight matrices and biases -> y [B,K] f32, J [B,K,3] f32
-    (k_trunk_fwd / k_trunk_bwd, see _trunk_fwd_core / _trunk_bwd_core)."""
-
-    @staticmethod
-    def forward(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2):
-        ctx.set_materialize_grads(False)
-        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2)
-        if ctx.needs_input_grad[1]:
-            _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(*saved)
-        Y = Y.view(x.shape[0], 4, -1)
-        return Y[:, 0].contiguous(), Y[:, 1:].transpose(1, 2).contiguous()
-
-    @staticmethod
-    def backward(ctx, gy, gJ):
-        saved = ctx.saved_tensors
-        B, d_out = ctx.cfg[0], ctx.cfg[-1]
-        KP = saved[-1].shape[1]
-        g = torch.zeros(B, 4, KP, device=saved[3].device, dtype=torch.bfloat16)
-        if gy is not None:
-            g[:, 0, :d_out] = gy
-        if gJ is not None:
-            g[:, 1:, :d_out] = gJ.transpose(1, 2)
-        gb2 = gy.sum(0) if ctx.needs_input_grad[12] and gy is not None else None
-        g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g.view(4 * B, KP), gb2, ctx.needs_input_grad[1], ctx.needs_input_grad[7])
-        return None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
-
-
-class _fused_trunk_render(torch.autograd.Function):
-    """The trunk pass of one training iteration: rows [0, n_main) are rendered samples, the rest the Eikonal set.
-    Returns sdf_raw [n_main,K], sdf [n_main,1] (min over objects), idx [B,1] (argmin, not differentiable),
-    gradients [n_main,3] (d min-sdf / dx), and for the Eikonal points y_eik [Be,K], min_eik [Be,1] and grad_theta
-    [(K+1)*Be, 3] -- the stacked rows of ObjectImplicitNetworkGrid.gradient (network.py:212-254).
-    Versus _fused_trunk + torch ops: no [B,K,3] Jacobian for the rendered points, no min/gather/transpose/cat chain for the
-    Eikonal set, and the cotangent image of the trunk output is assembled by one kernel instead of autograd's zero-fill /
-    scatter / pad chain (csrc/encode_ops.hip)."""
-
-    @staticmethod
-    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
-        ctx.set_materialize_grads(False)    # unused outputs reach backward as None (the kernels take NULL), not as zero-filled tensors
-        B, K = x.shape[0], W2.shape[0]
-        dev = x.device
-        Be = B - n_main
-        sdf_raw, sdf = torch.empty(n_main, K, device=dev), torch.empty(n_main, 1, device=dev)
-        idx = torch.empty(B, 1, device=dev, dtype=torch.int64)
-        grad = torch.empty(n_main, 3, device=dev)
-        y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
-        Y, saved = _trunk_fwd_core(ctx, x, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01,
-                                   split=(n_main, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta))
-        if Y is not None:       # the kernel that ran does not produce the split outputs itself
-            _be._backend.trunk_split_fwd(Y, n_main, K, sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta)
-        if ctx.needs_input_grad[2]:
-            _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(*saved, idx)
-        ctx.n_main = n_main
-        ctx.mark_non_differentiable(idx)
-        return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
-
-    @staticmethod
-    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_mineik, g_theta):
-        *saved, idx = ctx.saved_tensors
-        B, d_out = ctx.cfg[0], ctx.cfg[-1]
-        KP = saved[-1].shape[1]
-        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
-        g = torch.empty(4 * B, KP, device=idx.device, dtype=torch.bfloat16)
-        _be._backend.trunk_split_bwd(c(g_raw), c(g_sdf), idx, c(g_grad), c(g_yeik), c(g_mineik), c(g_theta), B, ctx.n_main, d_out, g)
-        gb2 = _FROM_KERNEL if ctx.needs_input_grad[13] else None
-        g_emb, gW0, gb0, gW1, gb1, gW2, gb2 = _trunk_bwd_core(ctx, saved, g, gb2, ctx.needs_input_grad[2], ctx.needs_input_grad[8])
-        return None, None, g_emb, None, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
-
-
-# How the rendered samples go through the trunk: "rr" = reverse-over-reverse (csrc/trunk_rr.hip: rows are samples; value pass + one
-# reverse pass for d min / dx, closed-form double backward), "jac" = the value+Jacobian rows of _fused_trunk_render for every point
-# (4 rows per sample; what the Eikonal points, which need all K gradients, always use)
-TRUNK_MODE = os.environ.get("HOLOSCENE_TRUNK_MODE", "rr")
-RR_WIDE = os.environ.get("HOLOSCENE_RR_WIDE", "1") != "0"      # 33..64 objects on the reverse-over-reverse kernels too (0: the four-row value+Jacobian kernels, A/B)
-
-
-def _rr_slices(n, budget=256):
-    """Row slices of the three weight-gradient jobs of an rr backward pass (csrc/wgrad_pairs.hip): a slice is a whole number of 32-row
-    tiles, the jobs together should fill the chip once (`budget` workgroups), the 256 x 256 job -- two tile-packed pairs, the most
-    bytes -- gets the finest cut."""
-    tiles = (n + 31) // 32
-    divs = [d for d in range(1, min(tiles, budget // 2) + 1) if tiles % d == 0]
-    fine = max(divs)
-    coarse = max(d for d in divs if d <= max(1, (budget - fine) // 2))
-    return fine, coarse, coarse
-
-
-_PAIR_REG_COST = 1.5
-_PAIR_TILE_BYTES = {(256, 256): 32768, (256, 80): 21504, (32, 256): 18432, (256, 128): 24576}      # bytes of one operand pair per 32-row tile
-
-
-def _pair_slices(jobs, budget=256):
-    """Slice counts for the jobs of ONE hs_wgrad_pairs launch: a workgroup streams its slice at a fixed rate (one workgroup per CU, the
-    launch lasts as long as its largest slice), so every job is cut in proportion to its BYTES and the counts add up to the chip.
-    jobs: [(shape, tiles, pairs, has_B)] -> [slices]."""
-    cost = []
-    for shape, tiles, pairs, has_b in jobs:
-        per = _PAIR_TILE_BYTES[tuple(shape[:2])] if has_b else 64 * shape[0]
-        # row-major-only jobs stay on the kernel's register-staged form, which streams ~1.4x slower per byte than the LDS-DMA form
-        # (3.3 against 4.6 TB/s measured, tools/exp/wgrad_cold_time.py): lighter slices, or they are the launch's tail
-        cost.append(float(per * pairs * tiles) * (_PAIR_REG_COST if "rm" in shape else 1.0))
-    total = sum(cost)
-    want = [max(1, min(t, int(c / total * budget))) for c, (_, t, _, _) in zip(cost, jobs)]
-    spare = budget - sum(want)
-    while spare > 0:          # hand the remaining workgroups to whoever has the most bytes per slice
-        i = max(range(len(jobs)), key=lambda k: cost[k] / want[k] if want[k] < jobs[k][1] else 0.0)
-        if want[i] >= jobs[i][1]:
-            break
-        want[i] += 1
-        spare -= 1
-    return want
-
-
-def _rows_slices(rows, cap):
-    """Largest slice count <= cap that cuts `rows` row-major rows into whole 32-row tiles."""
-    tiles = rows // 32
-    return max(d for d in range(1, max(1, min(tiles, cap)) + 1) if tiles % d == 0)
-
-
-def _tp_colsum(T):
-    """Column sums of a tile-packed activation tensor -> [256] fp32 in neuron order (bias gradients)."""
-    t = T.view(-1, 16, 2, 32, 2, 4).sum((0, 3), dtype=torch.float32)       # [s, h, e >> 2, e & 3]; fp32 accumulation, no fp32 copy
-    return t.permute(0, 2, 1, 3).reshape(256)                               # neuron = 16 s + 8 (e >> 2) + 4 h + (e & 3)
-
-
-class _trunk_render_rr(torch.autograd.Function):
-    """_fused_trunk_render with the n_main rendered samples on the reverse-over-reverse kernels (csrc/trunk_rr.hip: rows are samples) and
-    the Eikonal points, which need all K gradients, on the value+Jacobian ones (4 rows per point) -- ONE hash gather for all points in the
-    forward, ONE table scatter in the backward (both kernel families read / write their own point range of the level-major buffers
-    through a level stride).  Same seven outputs, same values."""
-
-    @staticmethod
-    def forward(ctx, x, n_main, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
-        ctx.set_materialize_grads(False)
-        be = _be._backend
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        x = x.contiguous().float()
-        if x01 is None:
-            x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
-        B, n, dev, bf = x.shape[0], int(n_main), x.device, torch.bfloat16
-        Be = B - n
-        L, C, K = offsets.shape[0] - 1, embeddings.shape[1], W2.shape[0]
-        feat = torch.empty(B, L * C, device=dev)
-        dydx = torch.empty(L, B, 3 * C, device=dev)
-        be.fwd(x01, embeddings, offsets, feat, B, 3, C, L, S, Hres, dydx)
-        jac = 0.5 / divide_factor
-        f0, f1, f2 = W0.detach().float().contiguous(), W1.detach().float().contiguous(), W2.detach().float().contiguous()
-        # every weight image of this pass -- fragment images, their transposes, the Eikonal points' row-major transposes -- in one launch
-        ip = _ITER_PACKS
-        wide = K > 32        # 33..64 objects: the last layer as two 32-row tiles (k_rr_fwd<true>, k_rr_bwd_value<., true>; per-call packing)
-        packed_b = W2Tf_b = None
-        if wide:
-            bc = [t.detach().float().contiguous() for t in (b0, b1, b2)]
-            packed, packed_b, rr, W2Tf_b = be.trunk_pack_wide(f0, bc[0], f1, bc[1], f2, bc[2], K)
-            trans = None
-            if Be > 0:      # the Eikonal points' backward kernel (k_trunk_bwd<64>) reads row-major transposes
-                trans = (torch.empty(256, 256, device=dev, dtype=bf), torch.empty(256, 64, device=dev, dtype=bf), torch.empty(256, 256, device=dev, dtype=bf))
-                be.pack_bf16([(f1, trans[0], 0, 0, 256, 256, True), (f2, trans[1], 0, 0, 256, K, True), (f0, trans[2], 0, 0, W0.shape[1], 256, True)])
-        elif ip is not None and ip["trunk"] is not None and ip["trunk_key"] == (id(W0), id(W1), id(W2)) and (Be == 0 or ip["trunk"][2] is not None):
-            packed, rr, trans = ip["trunk"]       # packed at the top of the iteration, together with every other image (hs_pack_iteration)
-        else:
-            packed, rr, trans = be.trunk_pack_all(f0, b0.detach().float().contiguous(), f1, b1.detach().float().contiguous(), f2,
-                                                  b2.detach().float().contiguous(), K, transposes=Be > 0)
-        M = be.tp_rows(n)
-        tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
-        H0t, H1t, U0t, V1t, V0t = tp(), tp(), tp(), tp(), tp()
-        Xp, onehot = torch.empty(n, 80, device=dev, dtype=bf), torch.empty((2, n, 32) if wide else (n, 32), device=dev, dtype=bf)
-        sdf_raw, sdf, idx = torch.empty(n, K, device=dev), torch.empty(n, 1, device=dev), torch.empty(B, 1, device=dev, dtype=torch.int64)
-        grad, uxh = torch.empty(n, 3, device=dev), torch.empty(n, 32, device=dev)
-        if wide:
-            be.trunk_rr_fwd_wide(x[:n], feat[:n], dydx, packed, packed_b, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
-        elif RR_FORWARD == "fused":       # value and gradient chains of a sample tile in one kernel, the activations never re-read
-            be.trunk_rr_fwd(x[:n], feat[:n], dydx, packed, rr, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot, U0t, V1t, V0t, grad, uxh, jac, ld=B)
-        else:
-            be.trunk_rr_fwd_value(x[:n], feat[:n], packed, K, H0t, H1t, Xp, sdf_raw, sdf, idx[:n], onehot)
-            be.trunk_rr_fwd_grad(x[:n], dydx, idx[:n], rr, H0t, H1t, U0t, V1t, V0t, grad, uxh, jac, ld=B)
-        y_eik, min_eik, gtheta = torch.empty(Be, K, device=dev), torch.empty(Be, 1, device=dev), torch.empty((K + 1) * Be, 3, device=dev)
-        eik = ()
-        if Be > 0:      # value + three tangent rows per Eikonal point (csrc/trunk_mlp2.hip), same weight images
-            Me = 4 * Be
-            H0e, H1e, Xpe = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 80, device=dev, dtype=bf)
-            w1t, w2t, w0t = trans
-            if wide:
-                be.trunk_mlp2_fwd_wide(x[n:], feat[n:], dydx, packed, packed_b, K, H0e, H1e, Xpe, jac,
-                                       (0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
-            else:
-                be.trunk_mlp2_fwd(x[n:], feat[n:], dydx, packed, K, H0e, H1e, None, Xpe, jac,
-                                  split=(0, None, None, idx[n:], None, y_eik, min_eik, gtheta), ld=B, off=n, w2_planes=1)
-            eik = (H0e, H1e, Xpe, w0t, w1t, w2t)
-        if ctx.needs_input_grad[2]:
-            _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, *packed, *rr, *eik, *((W2Tf_b,) if wide else ()))
-        ctx.wide = wide
-        ctx.cfg = (B, n, L, C, K, S, Hres, jac, W0.shape[1])
-        ctx.bias_params = (b0, b1, b2)       # their gradients go straight into the flat gradient buffer when there is one (flat_grad_target)
-        ctx.mark_non_differentiable(idx)
-        return sdf_raw, sdf, idx, grad, y_eik, min_eik, gtheta
-
-    @staticmethod
-    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad, g_yeik, g_mineik, g_theta):
-        be = _be._backend
-        sv = ctx.saved_tensors
-        x, x01, embeddings, offsets, dydx, idx, H0t, H1t, U0t, V1t, V0t, Xp, onehot, uxh, W0f, W1f, W2f, bias, W1Tf, W0Tf, W2Tf, W2tab = sv[:22]
-        packed, rr = (W0f, W1f, W2f, bias), (W1Tf, W0Tf, W2Tf, W2tab)
-        B, n, L, C, K, S, Hres, jac, F_in = ctx.cfg
-        Be = B - n
-        dev, bf = x.device, torch.bfloat16
-        need_table, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[7]
-        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
-        g_feat = torch.empty(L, B, C, device=dev)
-        g_dydx = torch.empty(L, B, 3 * C, device=dev)
-        # ---- rendered samples: cotangent of the K outputs with the minimum's folded in at its index, then the two rr kernels
-        M = be.tp_rows(n)
-        tp = lambda: torch.empty(M * 256, device=dev, dtype=bf)  # noqa: E731
-        wide = ctx.wide
-        KP = 64 if wide else 32
-        W2Tf_b = sv[-1] if wide else None
-        if wide:
-            sv = sv[:-1]
-        gy = torch.empty((2, n, 32) if wide else (n, 32), device=dev, dtype=bf)
-        gbz = _be.zeros_small(2 * 256 + KP, dev)            # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
-        gb2_part = torch.empty(be.RR_GY_BLOCKS, KP, device=dev) if need_w else None
-        be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
-        A0t, A1t = tp(), tp()
-        second = g_grad is not None
-        if second:
-            U0bt, A0pt, A1pt, U1bt = tp(), tp(), tp(), tp()
-            UXb = torch.empty(n, 80, device=dev, dtype=bf)
-            # (the samples' dy_dx cotangent is rank one -- jac * ux[level, c] * g~[d] --: the table scatter forms it itself from uxh and g~
-            #  (hsHashLayout::r1_ux) instead of this kernel writing and that one reading 24 B x 16 levels per sample)
-            gg = c(g_grad)
-            rank1 = (uxh, gg, jac) if need_table else None
-            be.trunk_rr_bwd_grad(x[:n], dydx, gg, uxh, idx[:n], rr, packed, H0t, H1t, U0t, U0bt, A0pt, A1pt, U1bt, UXb, None, jac, ld=B)
-            if wide:
-                be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
-            else:
-                be.trunk_rr_bwd_value(gy, rr, H0t, H1t, A0pt, A1pt, A0t, A1t, g_feat, n, ld=B)
-        else:
-            rank1 = None
-            g_dydx[:, :n].zero_()
-            if wide:
-                be.trunk_rr_bwd_value_wide(gy, rr, W2Tf_b, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
-            else:
-                be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
-        # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
-        eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
-        w2_part = None
-        eik_jobs = []
-        if eik_live:
-            H0e, H1e, Xpe, w0t, w1t, w2t = sv[22:]
-            Me = 4 * Be
-            g_img = torch.empty(Me, KP, device=dev, dtype=bf)
-            be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
-            gA1, gA0 = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf)
-            w2_part = torch.empty(be.trunk_bwd_parts(Me), KP, 256, device=dev) if need_w else None
-            be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,
-                             gb2=gbz[512:] if need_w else None, dW2_part=w2_part, ld=B, off=n)
-            if need_w and Me % 32 == 0:
-                eik_jobs = [((256, 256, "rm"), 0, (gA1, H0e), None, Me), ((256, 80, "rm"), 0, (gA0, Xpe), None, Me)]
-        elif Be > 0:
-            g_feat[:, n:].zero_()
-            g_dydx[:, n:].zero_()
-        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
-        if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
-            T, npair = be.tp_rows(n) // 32, 2 if second else 1
-            cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True)]
-                               + ([((32, 256), T, npair, True)] if wide else []) + [(j[0], Me // 32, 1, True) for j in eik_jobs])
-            s1, s0, s2 = cut[:3]
-            s2b = cut[3] if wide else 0
-            se1, se0 = cut[3 + int(wide):] if eik_jobs else (0, 0)
-            eik_jobs = [(j[0], sl) + tuple(j[2:]) for j, sl in zip(eik_jobs, (se1, se0))]
-            # the Eikonal rows' partials go behind the samples' in the same stacks: one slice sum per weight matrix.  Bias gradients of the
-            # samples ride along: db0, db1 as the column sums of a0~, a1~ from one more MFMA per fragment of the jobs that stream them
-            # (hsWgradPairJob::colsum)
-            st1, st0 = torch.empty(s1 + se1, 256, 256, device=dev, dtype=bf), torch.empty(s0 + se0, 256, 128, device=dev, dtype=bf)
-            st2 = torch.empty(s2, 32, 256, device=dev, dtype=bf)
-            st2b = torch.empty(s2b, 32, 256, device=dev, dtype=bf) if wide else None
-            cs = []
-            gy_a, oh_a = (gy[0], onehot[0]) if wide else (gy, onehot)
-            be.wgrad_pairs([((256, 256, "colsum"), s1, (A1t, H0t), (V1t, U0bt) if second else None),
-                            ((256, 80, "colsum"), s0, (A0t, Xp), (V0t, UXb) if second else None),
-                            ((32, 256), s2, (gy_a, H1t), (oh_a, U1bt) if second else None)]
-                           + ([((32, 256), s2b, (gy[1], H1t), (onehot[1], U1bt) if second else None)] if wide else []) + eik_jobs, n,
-                           outs_into=[st1[:s1], st0[:s0], st2] + ([st2b] if wide else []) + ([st1[s1:], st0[s0:]] if eik_jobs else []), colsum_out=cs)
-            csb1, csb0 = cs[0], cs[1]        # [s1, 256], [s0, 256] fp32
-            if wide:
-                # two output tiles: the (K, 256) matrix is assembled half by half into one tensor (rows 0..31 | 32..K-1), the Eikonal rows' partials
-                # [parts, 64, 256] likewise; everything else as below
-                p0, p1, p2 = ctx.bias_params
-                D1, D0, D2 = _DirectGrad(p1, (1, 256)), _DirectGrad(p0, (1, 256)), _DirectGrad(p2, (1, K))
-                gW2 = torch.empty(K, 256, device=dev)
-                parts = w2_part.shape[0] if (eik_live and w2_part is not None) else 0
-                eik_a = [(w2_part, 256, 0, parts, 64 * 256)] if parts else []
-                eik_b = [(w2_part.view(-1)[32 * 256:], 256, 0, parts, 64 * 256)] if parts else []
-                eW = None
-                if eik_live and not eik_jobs:       # (Eikonal row counts that are not whole tiles: their 256-wide gradients through the row-major kernel)
-                    eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)])
-                gW1, gW0, _, _, gb1, gb0, gb2 = be.assemble([
-                    ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
-                    ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
-                    ((32, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + eik_a, (gW2[:32], None)),
-                    ((K - 32, 256), [(st2b, 256, 0, st2b.shape[0], 32 * 256)] + eik_b, (gW2[32:], None)),
-                    D1.job([(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]),
-                    D0.job([(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]),
-                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 64)])])
-                if eW is not None:
-                    gW1, gW0 = gW1 + eW[0], gW0 + eW[1].index_select(1, _xp_columns(dev))
-                gb1, gb0, gb2 = D1.grad(gb1, (256,)), D0.grad(gb0, (256,)), D2.grad(gb2, (K,))
-            elif eik_live and not eik_jobs:
-                eW = _wgrad_rows_many([(gA1, H0e), (gA0, Xpe)], ready_parts=[w2_part])
-                sums = be.sum_slices([st1, st0, st2, csb1, csb0])
-                gW1, gW0p, gW2p = sums[0] + eW[0], sums[1][:, :80] + eW[1], sums[2] + eW[2]
-                gb1, gb0, gb2 = gbz[:256] + sums[3], gbz[256:512] + sums[4], gbz[512:512 + K] + gb2_part.sum(0)[:K]
-                gW0 = gW0p.index_select(1, _xp_columns(dev))
-                gW2 = gW2p[:K]
-            else:
-                # the slice sums of every partial stack, the column selection of dW0 / dW2 of both point families and the three bias gradients
-                # (into the flat gradient buffer's views when the biases have them): ONE launch (csrc/small_ops.hip: hs_assemble on bf16 stacks)
-                p0, p1, p2 = ctx.bias_params
-                D1, D0, D2 = _DirectGrad(p1, (1, 256)), _DirectGrad(p0, (1, 256)), _DirectGrad(p2, (1, K))
-                gW1, gW0, gW2, gb1, gb0, gb2 = be.assemble([
-                    ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
-                    ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
-                    ((K, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + ([(w2_part, 256, 0, w2_part.shape[0], 32 * 256)] if eik_live else [])),
-                    D1.job([(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]),
-                    D0.job([(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]),
-                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
-                gb1, gb0, gb2 = D1.grad(gb1, (256,)), D0.grad(gb0, (256,)), D2.grad(gb2, (K,))
-        g_emb = None
-        if need_table:      # one value+Jacobian scatter for all B points
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, 3, C, L, S, Hres,
-                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rank1=rank1)
-            if inplace:
-                _be.scatter_done(table)
-            g_emb = None if inplace else target
-        return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
-
-
-# The fp32 configuration's trunk of the RENDERED samples.  "rr": the reverse-over-reverse formulation of _trunk_render_rr in fp32 torch
-# arithmetic (rows are samples: value pass, one reverse pass for d min / dx, closed-form backward of both: 16 sample-row GEMMs instead of
-# the 36 of four value+Jacobian rows per point); "jac": every point through sdf_and_jacobian (the Eikonal points always do: all K gradients)
-# (measured equal: 10.5 against 10.4 ms per fp32 iteration -- the 20 fewer GEMMs are paid back in eager elementwise launches -- so the
-# established form stays the default)
-FP32_TRUNK = os.environ.get("HOLOSCENE_FP32_TRUNK", "jac")
-
-
-def _posenc6(x):
-    out = [x]
-    for k in range(6):
-        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
-    return torch.cat(out, -1)
-
-
-class _trunk_rr32(torch.autograd.Function):
-    """x [n, 3] (constant), hash table, effective weights (W0 [256, 71], W1 [256, 256], W2 [K, 256]) -> sdf_raw [n, K], sdf [n, 1], idx [n, 1],
-    gradients [n, 3] = d min_k sdf_k / dx.  Same function as ObjectImplicitNetworkGrid.forward + gradient on the minimum
-    (model/network.py:169-210, 293-299 of the reference), all arithmetic fp32:
-        value:     xt = [posenc(x) | hash(x)], a0 = W0 xt + b0, h0 = softplus100(a0), a1 = W1 h0 + b1, h1 = softplus100(a1), y = W2 h1 + b2
-        gradient:  v1 = W2[k*] . s1, u0 = W1^T v1, v0 = u0 . s0, ux = W0^T v0, grad = E^T ux     (s = sigmoid(100 a), E = d xt / dx)
-    and the backward of both in closed form (tests/rr_reference.py states the same formulas for the bf16 kernels; checked against
-    autograd's double backward in tools/exp/rr_trunk_math.py)."""
-
-    @staticmethod
-    def forward(ctx, x, x01, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2):
-        ctx.set_materialize_grads(False)
-        be = _be._backend
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        x = x.contiguous().float()
-        if x01 is None:
-            x01 = ((x / divide_factor + 1.0) / 2.0).contiguous()
-        n, dev = x.shape[0], x.device
-        L, C = offsets.shape[0] - 1, embeddings.shape[1]
-        feat, dydx = torch.empty(n, L * C, device=dev), torch.empty(L, n, 3 * C, device=dev)
-        be.fwd(x01, embeddings, offsets, feat, n, 3, C, L, S, Hres, dydx)
-        jac = 0.5 / divide_factor
-        W0, W1, W2 = W0.detach().float(), W1.detach().float(), W2.detach().float()
-        fr = torch.exp2(torch.arange(6, device=dev, dtype=torch.float32)).view(1, 6, 1)      # (device-side: this runs under graph capture)
-        ang = x.view(n, 1, 3) * fr                                       # [n, 6, 3]
-        sn, cs = torch.sin(ang), torch.cos(ang)
-        xt = torch.cat([x, torch.cat([sn, cs], -1).reshape(n, 36), feat, x.new_zeros(n, 9)], -1)      # [x | sin f0 x, cos f0 x | ... | hash | 0]: 80 columns
-        dpe = torch.cat([fr * cs, -fr * sn], -1).reshape(n, 36)          # d posenc / d x, in xt's column order (column 3 + 6 k + 3 t + d <-> x_d)
-        W0p = F.pad(W0, (0, 9))                             # [256, 80]: the library's kernels for 71 columns run at a tenth of the rate
-        a0 = torch.addmm(b0.detach().float(), xt, W0p.t())
-        h0 = F.softplus(a0, beta=100)
-        s0 = torch.sigmoid_(a0.mul_(100.0))                 # in place: a0 is not needed again
-        a1 = torch.addmm(b1.detach().float(), h0, W1.t())
-        h1 = F.softplus(a1, beta=100)
-        s1 = torch.sigmoid_(a1.mul_(100.0))
-        y = torch.addmm(b2.detach().float(), h1, W2.t())
-        sdf, idx = y.min(-1, keepdim=True)
-        v1 = W2[idx.view(-1)] * s1
-        u0 = v1 @ W1
-        v0 = u0 * s0
-        ux = v0 @ W0p                                       # [n, 80]
-        dy = dydx.view(L, n, 3, C)
-        uxh = ux[:, 39:71].contiguous()
-        # (sums written as products + reductions: einsum turns them into n batched 3 x 32 GEMMs, 1.35 ms each)
-        grad = ux[:, 0:3] + (dpe * ux[:, 3:39]).view(n, 12, 3).sum(1) + jac * (dy * uxh.view(n, L, 1, C).transpose(0, 1)).sum((0, 3))
-        if ctx.needs_input_grad[2]:
-            _be.expect_scatter(ctx.table)
-        ctx.save_for_backward(x01, embeddings, offsets, dydx, idx, xt, h0, h1, s0, s1, u0, v1, v0, uxh, W0p, W1, W2, dpe)
-        ctx.cfg = (n, L, C, S, Hres, jac)
-        ctx.mark_non_differentiable(idx)
-        return y, sdf, idx, grad
-
-    @staticmethod
-    def backward(ctx, g_raw, g_sdf, _g_idx, g_grad):
-        x01, embeddings, offsets, dydx, idx, xt, h0, h1, s0, s1, u0, v1, v0, uxh, W0p, W1, W2, dpe = ctx.saved_tensors
-        n, L, C, S, Hres, jac = ctx.cfg
-        be = _be._backend
-        dev = x01.device
-        K = W2.shape[0]
-        gy = torch.zeros(n, K, device=dev) if g_raw is None else g_raw.float().clone()
-        if g_sdf is not None:
-            gy.scatter_add_(1, idx, g_sdf.float().reshape(n, 1))
-        need_w, need_table = ctx.needs_input_grad[7], ctx.needs_input_grad[2]
-        a0p = a1p = g_dydx = None
-        if g_grad is not None:
-            g = g_grad.float()
-            dy = dydx.view(L, n, 3, C)
-            uxb = torch.cat([g, (dpe.view(n, 12, 3) * g.view(n, 1, 3)).reshape(n, 36),
-                             jac * (dy * g.view(1, n, 3, 1)).sum(2).transpose(0, 1).reshape(n, L * C), g.new_zeros(n, 9)], -1)          # E g~  [n, 80]
-            v0b = uxb @ W0p.t()
-            u0b = v0b * s0
-            a0p = v0b * u0 * (100.0 * s0 * (1.0 - s0))
-            v1b = u0b @ W1.t()
-            u1b = v1b * s1
-            a1p = v1b * W2[idx.view(-1)] * (100.0 * s1 * (1.0 - s1))
-            # cotangent of dy_dx: rank one, jac * ux[level, c] * g~[d]  ([L, n, 3 C] = [level][sample][d * C + c])
-            g_dydx = (jac * uxh.reshape(n, L, 1, C) * g.reshape(n, 1, 3, 1)).permute(1, 0, 2, 3).reshape(L, n, 3 * C).contiguous()
-        h1b = gy @ W2
-        a1 = h1b * s1 if a1p is None else a1p + h1b * s1
-        h0b = a1 @ W1
-        a0 = h0b * s0 if a0p is None else a0p + h0b * s0
-        gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
-        if need_w:
-            gW1, gW0, gW2 = _wgrad_rows(a1, h0), _wgrad_rows(a0, xt), _wgrad_rows(gy, h1)
-            if g_grad is not None:
-                onehot = F.one_hot(idx.view(-1), K).float()
-                gW1, gW0, gW2 = gW1 + _wgrad_rows(v1, u0b), gW0 + _wgrad_rows(v0, uxb), gW2 + _wgrad_rows(onehot, u1b)
-            gW0 = gW0[:, :71]
-            gb0, gb1, gb2 = a0.sum(0), a1.sum(0), gy.sum(0)
-        g_emb = None
-        if need_table:
-            g_feat = (a0 @ W0p[:, 39:71].contiguous()).reshape(n, L, C).permute(1, 0, 2).contiguous()         # level-major [L, n, C]
-            if g_dydx is None:
-                g_dydx = torch.zeros(L, n, 3 * C, device=dev)
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd_jac(g_feat, g_dydx, x01, offsets, target, n, 3, C, L, S, Hres,
-                       ws=be.scatter_workspace(n, 3, C, L, dev) if n >= _BIN_MIN_POINTS else None, level_major=True)
-            if inplace:
-                _be.scatter_done(table)
-            g_emb = None if inplace else target
-        return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2
-
-
-def trunk_render(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01=None):
-    """_fused_trunk_render's seven outputs; TRUNK_MODE == "rr" (and the stock shapes): the rendered samples through the
-    reverse-over-reverse kernels (_trunk_render_rr)."""
-    K = W2.shape[0]
-    if (TRUNK_MODE == "rr" and n_main > 0 and (K <= 32 or (K <= 64 and RR_WIDE and RR_FORWARD == "fused")) and nfreq == 6 and offsets.shape[0] - 1 == 16
-            and embeddings.shape[1] == 2 and W0.shape[1] == 71):
-        return _trunk_render_rr.apply(x, n_main, embeddings, offsets, S, Hres, divide_factor, W0, b0, W1, b1, W2, b2, x01)
-    if TRUNK_MODE not in ("rr", "jac"):
-        raise RuntimeError(f"unknown HOLOSCENE_TRUNK_MODE={TRUNK_MODE!r}")
-    return _fused_trunk_render.apply(x, n_main, embeddings, offsets, S, Hres, nfreq, divide_factor, W0, b0, W1, b1, W2, b2, x01)
-
-
-# "mfma": colour MLP + rendering MLP of the rendered points as one matrix-core kernel per direction (csrc/appearance_mlp.hip) in
-# bf16 mode with the stock layer shapes; "gemm": library GEMMs + elementwise kernels (always used for fp32 / other shapes).
-APPEARANCE_IMPL = "mfma"
-# k_appear_bwd takes the ReLU signs from ballots the forward kernel wrote ("1") or from the saved layer outputs hc, r0, r1 ("0")
-APPEARANCE_RELU_MASKS = True
-# background-surface pass of render(): "hip" = the main pass's fused kernels (trunk + split, compositing) when their shapes are
-# supported; "torch" = the whole-tensor formulation (always used otherwise)
-BG_IMPL = "hip"
-
-
-# weight gradients of the appearance branch: "pairs" = six row-major jobs of one hs_wgrad_pairs launch (byte-proportional slices),
-# "rows" = hs_wgrad_rows (csrc/wgrad.hip: 128 equal slices per product)
-APPEARANCE_WGRAD = "pairs"
-# "fused": k_rr_fwd, the value and the gradient chain of a sample tile in one kernel (bit-identical outputs; 107-112 us against 52 + 70 for
-# the pair, same box, alternating runs); "split": k_rr_fwd_value then k_rr_fwd_grad
-RR_FORWARD = "fused"
-
-
-class _fused_appearance(torch.autograd.Function):
-    """(points, view dirs, normals, colour hash table, colour-MLP and rendering-MLP weights) -> rgb [B,3].
-
-    forward: colour hash encode -> k_appear_fwd (5 layers, activations stay on the CU; layer outputs written once).
-    backward: k_appear_bwd (whole data-gradient chain incl. d/d normals and d/d colour features + bias sums), library
-    split-M GEMMs for the five weight gradients, scatter into the colour table gradient."""
-
-    @staticmethod
-    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        if ctx.needs_input_grad[3]:
-            _be.expect_scatter(ctx.table)      # data parallelism: a table's segment is exchanged once its last scatter has run
-        be = _be._backend
-        points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
-        if x01 is None:
-            x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
-        B = points.shape[0]
-        L, C = offsets.shape[0] - 1, embeddings.shape[1]
-        dev, bf = points.device, torch.bfloat16
-        featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for k_appear_fwd
-        be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
-        new = lambda r, c: torch.empty(r, c, device=dev, dtype=bf)  # noqa: E731
-        W = {"Wc0": new(256, 32), "Wc1": new(256, 256), "Wr0f": new(256, 256), "Wr0p": new(256, 96), "Wr1": new(256, 256), "Wr2": new(32, 256),
-             "Wr2t": new(256, 32), "Wr1t": new(256, 256), "Wr0ft": new(256, 256), "Wr0nt": new(32, 256), "Wc1t": new(256, 256), "Wc0t": new(32, 256)}
-        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-        wc0, wc1, wr0, wr1, wr2 = f32(Wc0), f32(Wc1), f32(Wr0), f32(Wr1), f32(Wr2)
-        be.pack_bf16([(wc0, W["Wc0"], 0, 0, 256, 32, False), (wc1, W["Wc1"], 0, 0, 256, 256, False), (wr0, W["Wr0f"], 0, 81, 256, 256, False),
-                      (wr0, W["Wr0p"], 0, 0, 256, 81, False), (wr1, W["Wr1"], 0, 0, 256, 256, False), (wr2, W["Wr2"], 0, 0, 3, 256, False),
-                      (wr2, W["Wr2t"], 0, 0, 256, 3, True), (wr1, W["Wr1t"], 0, 0, 256, 256, True), (wr0, W["Wr0ft"], 0, 81, 256, 256, True),
-                      (wr0, W["Wr0nt"], 0, 54, 27, 256, True), (wc1, W["Wc1t"], 0, 0, 256, 256, True), (wc0, W["Wc0t"], 0, 0, 32, 256, True)])
-        xin, hc, fv, r0, r1 = new(B, 128), new(B, 256), new(B, 256), new(B, 256), new(B, 256)
-        rgb = torch.empty(B, 3, device=dev)
-        # signs of the three ReLU layers as wave ballots: the backward kernel reads these 2.4 MB instead of hc, r0 and r1 (154 MB)
-        masks = torch.empty(be.appearance_mask_words(B), device=dev, dtype=torch.int64) if APPEARANCE_RELU_MASKS else None
-        be.appearance_fwd(featc, points, dirs, normals, W, (f32(bc0), f32(bc1), f32(br0), f32(br1), f32(br2)), xin, hc, fv, r0, r1, rgb, masks)
-        ctx.masks = masks
-        ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, xin, hc, fv, r0, r1, *[W[k] for k in ("Wr2t", "Wr1t", "Wr0ft", "Wr0nt", "Wc1t", "Wc0t")])
-        ctx.cfg = (B, C, L, S, Hres)
-        return rgb
-
-    @staticmethod
-    def backward(ctx, g_rgb):
-        x01, embeddings, offsets, normals, rgb, xin, hc, fv, r0, r1, Wr2t, Wr1t, Wr0ft, Wr0nt, Wc1t, Wc0t = ctx.saved_tensors
-        B, C, L, S, Hres = ctx.cfg
-        be = _be._backend
-        dev, bf = rgb.device, torch.bfloat16
-        new = lambda c: torch.empty(B, c, device=dev, dtype=bf)  # noqa: E731
-        gy, gA_r1, gA_r0, g_fv, gA_hc = new(32), new(256), new(256), new(256), new(256)
-        d_normals = torch.empty(B, 3, device=dev)
-        g_featc = torch.empty(L, B, C, device=dev)
-        gb = _be.zeros_small(5 * 256, dev).view(5, 256)
-        W = {"Wr2t": Wr2t, "Wr1t": Wr1t, "Wr0ft": Wr0ft, "Wr0nt": Wr0nt, "Wc1t": Wc1t, "Wc0t": Wc0t}
-        be.appearance_bwd(g_rgb.contiguous().float(), rgb, normals, r1, r0, hc, W, gy, gA_r1, gA_r0, g_fv, gA_hc, d_normals, g_featc, gb, ctx.masks)
-        need_w = ctx.needs_input_grad[8]
-        gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbr2 = None
-        if need_w:
-            prods = [(gy, r1), (gA_r1, r0), (gA_r0, xin), (gA_r0, fv), (g_fv, hc), (gA_hc, xin)]
-            if APPEARANCE_WGRAD == "pairs" and B % 32 == 0 and xin.shape[1] == 128 and all(t.is_contiguous() for pr in prods for t in pr):
-                # the six products as single-pair row-major jobs of ONE hs_wgrad_pairs launch: 256 workgroups, slices cut by bytes (12.2)
-                shapes = [(a.shape[1], b.shape[1], "rm") for a, b in prods]
-                cut = _pair_slices([(sh, B // 32, 1, True) for sh in shapes])
-                stacks = be.wgrad_pairs([(sh, c, pr, None, B) for sh, c, pr in zip(shapes, cut, prods)], B)
-                w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = be.sum_slices(stacks)
-            else:
-                w_r2, gWr1, w_r0x, w_r0f, gWc1, w_c0 = _wgrad_rows_many(prods)
-            gWr2 = w_r2[:3]
-            gbr2 = gb[4, :3]
-            if w_r0x.is_cuda and w_r0x.dtype == torch.float32 and w_r0x.is_contiguous() and w_r0f.is_contiguous() and w_c0.is_contiguous():
-                # the two halves of dWr0 side by side and dWc0's 32 real columns: one launch instead of a concatenation and a strided copy
-                gWr0 = torch.empty(w_r0x.shape[0], 81 + w_r0f.shape[1], device=dev)
-                _, _, gWc0 = be.assemble([((w_r0x.shape[0], 81), [(w_r0x, w_r0x.shape[1], 32)], (gWr0, 0)),
-                                          ((w_r0f.shape[0], w_r0f.shape[1]), [(w_r0f, w_r0f.shape[1], 0)], (gWr0, 81)),
-                                          ((w_c0.shape[0], 32), [(w_c0, w_c0.shape[1], 0)])])
-            else:
-                gWr0 = torch.cat([w_r0x[:, 32:113], w_r0f], 1)
-                gWc0 = w_c0[:, :32]
-        g_emb = None
-        if ctx.needs_input_grad[3]:
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
-            g_emb = None if inplace else target
-            if inplace:
-                _be.scatter_done(table)
-        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gb[3], gWc1, gb[2], gWr0, gb[1], gWr1, gb[0], gWr2, gbr2, None)
-
-
-# form of the fused colour branch: "wave" = csrc/appearance2.hip (a wave owns 32 samples through all five layers, weight chunks shared
-# through LDS, tile-packed saved activations, the weight gradients on hs_wgrad_pairs' tile-packed kinds), "tile" = csrc/appearance_mlp.hip
-# (128-point workgroup tiles; row-major saved activations)
-APPEARANCE_FORM = "wave"
-_XA_COLS = {}
-
-
-def _xa_columns(dev):
-    """Position, in the 128-wide weight-gradient result against hs_appearance2_fwd's assembled-input image, of (a) the 81 encoded inputs of
-    the rendering network and (b) the 32 colour features (int32 device tensors).  Logical column of (k-step s, lane half h, element e) of a
-    tile-packed operand = 16 s + 8 (e >> 2) + 4 h + (e & 3) (csrc/wgrad_pairs.hip: store_chunk_p); k-steps 0, 1 hold the colour features
-    (feature 16 h + 8 s + e), k-steps 2..7 the encoding slots 8 (s - 2) + e of half h."""
-    key = str(dev)
-    if key not in _XA_COLS:
-        lib = _be.load_library()
-        L = lambda s_, h, e: 16 * s_ + 8 * (e >> 2) + 4 * h + (e & 3)  # noqa: E731
-        enc = [-1] * 81
-        for h in range(2):
-            for j in range(48):
-                c = int(lib.hs_appearance2_enc_column(h, j))
-                if c >= 0:
-                    enc[c] = L(2 + j // 8, h, j % 8)
-        assert min(enc) >= 0
-        fc = [L((f % 16) // 8, f // 16, f % 8) for f in range(32)]
-        _XA_COLS[key] = (torch.tensor(enc, dtype=torch.int32, device=dev), torch.tensor(fc, dtype=torch.int32, device=dev))
-    return _XA_COLS[key]
-
-
-class _fused_appearance_wave(torch.autograd.Function):
-    """_fused_appearance on the wave-tile kernels (csrc/appearance2.hip): same inputs, same result, same gradients.
-
-    forward: colour hash gather -> hs_appearance2_fwd; kept: the four layer outputs and the assembled inputs TILE-PACKED, the ReLU signs
-    as bit masks, rgb.  backward: hs_appearance2_bwd (reads the masks only) -> the four cotangents tile-packed -> ONE hs_wgrad_pairs launch
-    for the six weight gradients and the four bias gradients (column sums) -> one slice sum, one assembly -> colour-table scatter."""
-
-    @staticmethod
-    def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
-        ctx.set_materialize_grads(False)
-        ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
-        if ctx.needs_input_grad[3]:
-            _be.expect_scatter(ctx.table)
-        be = _be._backend
-        points, dirs, normals = points.contiguous().float(), dirs.contiguous().float(), normals.contiguous().float()
-        if x01 is None:
-            x01 = ((points / divide_factor + 1.0) / 2.0).contiguous()
-        B = points.shape[0]
-        L, C = offsets.shape[0] - 1, embeddings.shape[1]
-        dev, bf = points.device, torch.bfloat16
-        if SDF_FEAT_BF16 and C == 2:      # bf16 words [L, B]: the kernel rounds the features to bf16 anyway (same rounding), half the bytes both ways
-            featc = torch.empty(L, B, device=dev, dtype=torch.int32)
-            be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True, out_bf16=True)
-        else:
-            featc = torch.empty(L, B, C, device=dev)      # level-major: coalesced stores in the gather kernel, 8-byte runs for the consumer
-            be.fwd(x01, embeddings, offsets, featc, B, 3, C, L, S, Hres, None, level_major=True)
-        mats = (Wc0, Wc1, Wr0, Wr1, Wr2)
-        need_bwd = any(ctx.needs_input_grad)
-        ip = _ITER_PACKS
-        if ip is not None and ip["appear"] is not None and ip["appear_key"] == tuple(id(t) for t in mats) and (not need_bwd or ip["appear"]["streamT"] is not None):
-            P = ip["appear"]
-        else:
-            P = be.appearance2_pack(*mats, (bc0, bc1, br0, br1, br2), transposed=need_bwd)
-        sT = P["streamT"]
-        tiles = (B + 31) // 32
-        tp = lambda ks: torch.empty(tiles * ks * 512, device=dev, dtype=bf)  # noqa: E731
-        XAt, HCt, FVt, R0t, R1t = tp(8), tp(16), tp(16), tp(16), tp(16)
-        masks = torch.empty(tiles * 3 * 256, device=dev, dtype=torch.int32)
-        rgb = torch.empty(B, 3, device=dev)
-        be.appearance2_fwd(featc, points, dirs, normals, P, XAt, HCt, FVt, R0t, R1t, masks, rgb)
-        if need_bwd:
-            ctx.save_for_backward(x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT)
-        ctx.cfg = (B, C, L, S, Hres, Wr0.shape[1])
-        ctx.direct_params = (Wc0, bc0, Wc1, bc1, br0, br1, br2)      # plain parameters of this Function: gradients in place (flat_grad_target)
-        ctx.nrelay = None
-        if _NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is None and ctx.needs_input_grad[2]:
-            _NORMALS_RELAY["key"] = ctx.nrelay_key = normals      # (the contiguous fp32 tensor itself when the caller's was one)
-            ctx.nrelay = _NORMALS_RELAY
-        return rgb
-
-    @staticmethod
-    def backward(ctx, g_rgb):
-        if g_rgb is None:
-            return (None,) * 19
-        x01, embeddings, offsets, normals, rgb, XAt, HCt, FVt, R0t, R1t, masks, sT = ctx.saved_tensors
-        B, C, L, S, Hres, ldr0 = ctx.cfg
-        be = _be._backend
-        dev, bf = rgb.device, torch.bfloat16
-        tiles = (B + 31) // 32
-        tp = lambda: torch.empty(tiles * 16 * 512, device=dev, dtype=bf)  # noqa: E731
-        gy = torch.empty(B, 32, device=dev, dtype=bf)
-        GR1, GR0, GFV, GHC = tp(), tp(), tp(), tp()
-        g_featc = torch.empty(L, B, C, device=dev)
-        need_w = ctx.needs_input_grad[8]
-        gb2 = torch.empty(tiles, 4, device=dev) if need_w else None
-        other = None
-        if ctx.nrelay is not None:        # the compositing backward's cotangent of the same normals: this kernel adds into it
-            other, ctx.nrelay["cot"] = ctx.nrelay["cot"], None
-        d_normals = other if other is not None else torch.empty(B, 3, device=dev)
-        be.appearance2_bwd(g_rgb.contiguous().float(), rgb, normals, masks, sT, gy, GR1, GR0, GFV, GHC, d_normals, g_featc, gb2, normals_add=other is not None)
-        gWc0 = gWc1 = gWr0 = gWr1 = gWr2 = gbc0 = gbc1 = gbr0 = gbr1 = gbr2 = None
-        if need_w:
-            # six products, four of them with the column sums of their cotangent (= the bias gradients) riding along; slices cut by bytes
-            shapes = [(32, 256), (256, 256, "colsum"), (256, 128, "tp", "colsum"), (256, 256), (256, 256, "colsum"), (256, 128, "tp", "colsum")]
-            prods = [(gy, R1t), (GR1, R0t), (GR0, XAt), (GR0, FVt), (GFV, HCt), (GHC, XAt)]
-            cut = _pair_slices([(sh, tiles, 1, True) for sh in shapes])
-            cs = []
-            stacks = be.wgrad_pairs([(sh, c_, pr, None, B) for sh, c_, pr in zip(shapes, cut, prods)], B, colsum_out=cs)
-            # slice sums of the six partial stacks and the four column-sum stacks, the column selections (encodings | features of Wr0, the 32
-            # colour features of Wc0) and the output layer's bias: ONE launch; plain parameters' gradients land in the flat buffer's views
-            k_r2, k_r1, k_r0x, k_r0f, k_c1, k_c0 = stacks
-            c_r1, c_r0, c_c1, c_c0 = cs[1], cs[2], cs[4], cs[5]
-            enc_cols, fc_cols = _xa_columns(dev)
-            gWr0 = torch.empty(256, ldr0, device=dev)
-            pWc0, pbc0, pWc1, pbc1, pbr0, pbr1, pbr2 = ctx.direct_params
-            DWc1, DWc0 = _DirectGrad(pWc1, (256, 256)), _DirectGrad(pWc0, (256, 32))
-            Dbr1, Dbr0, Dbc1, Dbc0 = (_DirectGrad(p_, (1, 256)) for p_ in (pbr1, pbr0, pbc1, pbc0))
-            Dbr2 = _DirectGrad(pbr2, (1, 3))
-            stk = lambda t, ld, col: (t, ld, col, t.shape[0], t[0].numel())  # noqa: E731
-            out = be.assemble([((3, 256), [stk(k_r2, 256, 0)]),
-                               ((256, 256), [stk(k_r1, 256, 0)]),
-                               ((256, 81), [stk(k_r0x, 128, enc_cols)], (gWr0, 0)),
-                               ((256, ldr0 - 81), [stk(k_r0f, 256, 0)], (gWr0, 81)),
-                               DWc1.job([stk(k_c1, 256, 0)]),
-                               DWc0.job([stk(k_c0, 128, fc_cols)]),
-                               Dbr1.job([stk(c_r1, 0, 0)]),
-                               Dbr0.job([stk(c_r0, 0, 0)]),
-                               Dbc1.job([stk(c_c1, 0, 0)]),
-                               Dbc0.job([stk(c_c0, 0, 0)]),
-                               Dbr2.job([(gb2, 0, 0, tiles, 4)])])
-            gWr2, gWr1, _, _, gWc1, gWc0, gbr1, gbr0, gbc1, gbc0, gbr2 = out
-            gWc1, gWc0 = DWc1.grad(gWc1, (256, 256)), DWc0.grad(gWc0, (256, 32))
-            gbr1, gbr0, gbc1, gbc0, gbr2 = Dbr1.grad(gbr1, (256,)), Dbr0.grad(gbr0, (256,)), Dbc1.grad(gbc1, (256,)), Dbc0.grad(gbc0, (256,)), Dbr2.grad(gbr2, (3,))
-        g_emb = None
-        if ctx.needs_input_grad[3]:
-            table = ctx.table
-            inplace = _be.accumulates_into_grad(table)
-            target = table.grad if inplace else torch.zeros_like(embeddings)
-            be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
-            g_emb = None if inplace else target
-            if inplace:
-                _be.scatter_done(table)
-        return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gbc0, gWc1, gbc1, gWr0, gbr0, gWr1, gbr1, gWr2, gbr2, None)
-
-
-def fused_appearance(*args):
-    """The fused colour branch in the selected form (APPEARANCE_FORM)."""
-    Wr0 = args[12]
-    if APPEARANCE_FORM == "wave" and args[0].is_cuda and args[0].shape[0] > 0 and Wr0.shape[1] == 337:
-        return _fused_appearance_wave.apply(*args)
-    if APPEARANCE_FORM not in ("wave", "tile"):
-        raise RuntimeError(f"unknown HOLOSCENE_APPEARANCE_FORM={APPEARANCE_FORM!r}")
-    return _fused_appearance.apply(*args)
-
-
-class _render_input(torch.autograd.Function):
-    """[posenc(points), posenc(view_dirs), posenc(normals), feature_vectors] in one kernel; the backward returns
-    the gradients of the two differentiable inputs (normals, feature_vectors)."""
-
-    @staticmethod
-    def forward(ctx, points, view_dirs, normals, feature_vectors, nfreq):
-        points, view_dirs, normals = points.contiguous().float(), view_dirs.contiguous().float(), normals.contiguous().float()
-        fv = feature_vectors.contiguous()
-        B, Fv = fv.shape
-        out = torch.empty(B, 3 * (3 + 6 * nfreq) + Fv, device=fv.device, dtype=fv.dtype)
-        _be._backend.render_input_fwd(points, view_dirs, normals, fv, out, nfreq)
-        ctx.save_for_backward(normals)
-        ctx.cfg = (nfreq, Fv)
-        return out
-
-    @staticmethod
-    def backward(ctx, G):
-        (normals,) = ctx.saved_tensors
-        nfreq, Fv = ctx.cfg
-        G = G.contiguous()
-        d_n = torch.empty_like(normals)
-        _be._backend.render_input_bwd(G, normals, d_n, None, nfreq, Fv)
-        return None, None, d_n, G[:, 3 * (3 + 6 * nfreq):], None   # feature gradient = a strided view of G, no copy
-
-
-def _split_rows(M):
-    """Number of row slices for the weight-gradient reduction over M rows (M = 4 x points reaches 4e5)."""
-    for s in (128, 64, 32, 16, 8, 4, 2):
-        if M % s == 0 and M // s >= 512:
-            return s
-    return 1
-
-
-# fp32 GEMMs of the fp32 configuration: "lib" = the library's (fp32 MFMA), "split3" / "split2" = csrc/gemm_split.hip with three / two bf16
-# planes per operand (three: the accuracy of an fp32 GEMM, measured 1.1-1.2x the library on the 256-wide layers; two: 16 mantissa
-# bits per operand, 1.4-1.6x)
-# the sampler's hash features between the gather and the SDF trunk kernel as bf16 words (identical results, half the bytes) / as fp32
-SDF_FEAT_BF16 = True
-FP32_GEMM_PLANES = {"lib": 0, "split3": 3, "split2": 2}[os.environ.get("HOLOSCENE_FP32_GEMM", "lib")]
-_SPLIT_MIN_ROWS = 4096
-
-
-class _linear_rows(torch.autograd.Function):
-    """y = x @ W^T (+ bias) for x [M, in] with very large M.
-
-    The forward is one library GEMM.  The backward replaces autograd's default weight gradient -- a single
-    [out, M] x [M, in] GEMM whose 256x256 output gives the library only 64 workgroups to walk M = 4e5 (1 ms
-    each on MI355X, measured) and a tall-skinny column sum for the bias (1 ms) -- by a split-M batched GEMM
-    (S slices in parallel, then a tiny sum over S) and a two-stage bias reduction.
-
-    bf16=True: operands are rounded to bf16 and multiplied on the bf16 matrix cores with fp32 accumulation
-    (4x less HBM traffic and 16x the MFMA rate of fp32); the result and the saved activations stay bf16 so the
-    next stage reads half the bytes.  Master weights, biases and weight gradients remain fp32."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, bf16):
-        if bf16:
-            x = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
-            w = weight.to(torch.bfloat16)
-        else:
-            w = weight
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        ctx.bf16 = bf16
-        ctx.split = 0
-        if not bf16 and FP32_GEMM_PLANES and x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= _SPLIT_MIN_ROWS:
-            # fp32 operands as sums of bf16 planes on the bf16 matrix cores (csrc/gemm_split.hip): three planes = an fp32 GEMM's accuracy
-            ctx.split = FP32_GEMM_PLANES
-            return _be._backend.gemm_split_nt(x, w.detach().float(), None if bias is None else bias.detach().float().contiguous(), planes=ctx.split)
-        if bias is not None:
-            return torch.addmm(bias.to(w.dtype), x, w.t())   # bias rides the GEMM epilogue (no separate pass over [M, out])
-        return x @ w.t()
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g = g.contiguous()
-        if ctx.bf16 and g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
-        M = x.shape[0]
-        S = _split_rows(M)
-        if ctx.split:
-            be = _be._backend
-            g = g.float()
-            gx = be.gemm_split_nt(g, w.detach().float().t().contiguous(), planes=ctx.split) if ctx.needs_input_grad[0] else None
-            gw = gb = None
-            if ctx.needs_input_grad[1]:
-                tiles = ((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128)
-                Sg = max(1, min(M // 256, 1024 // tiles))
-                gw = be.sum_slices([be.gemm_split_tn(g, x, Sg, planes=ctx.split)])[0]
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = g.view(S, M // S, -1).sum(1, dtype=torch.float32).sum(0) if S > 1 else g.sum(0, dtype=torch.float32)
-            return gx, gw, gb, None
-        gx = g @ w if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        if ctx.needs_input_grad[1]:
-            if S > 1:
-                gw = torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
-            else:
-                gw = (g.t() @ x).float()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.view(S, M // S, -1).sum(1, dtype=torch.float32).sum(0) if S > 1 else g.sum(0, dtype=torch.float32)
-        return gx, gw, gb, None
-
-
-def linear_rows(x, weight, bias=None, bf16=False):
-    """F.linear for [..., in] inputs, flattened to rows."""
-    lead = x.shape[:-1]
-    y = _linear_rows.apply(x.reshape(-1, x.shape[-1]), weight, bias, bf16)
-    return y.view(*lead, weight.shape[0])
-
-
-# "hip": fused per-ray compositing kernels (csrc/composite.hip); "torch": the whole-tensor formulation
-# (HoloSceneNetwork.volume_rendering / occlusion_opacity), kept for A/B and for CPU host-logic tests.
-COMPOSITE_IMPL = "hip"
-
-
-class _composite(torch.autograd.Function):
-    """(z, sdf, raw, rgb, g, beta, depth_scale) -> weights, transmittance, rgb_values, depth_values, normal_map
-    (un-rotated), semantic_values, object_opacity -- one kernel forward, one backward."""
-
-    @staticmethod
-    def forward(ctx, z, sdf, raw, rgb, g, beta, depth_scale, sem_scale, rot=None):
-        """rot: optional [3,3] world-to-camera rotation; the normal output is then the camera-frame normal map (network.py:917-918)."""
-        ctx.set_materialize_grads(False)
-        ctx.rot = None if rot is None else rot.detach().contiguous().float()
-        z, sdf, raw, rgb, g = z.contiguous(), sdf.contiguous(), raw.contiguous(), rgb.contiguous(), g.contiguous()
-        depth_scale = depth_scale.contiguous()
-        beta1 = beta.detach().reshape(1).contiguous()
-        R, N = z.shape
-        K = raw.shape[-1]
-        dev = z.device
-        weights = torch.empty(R, N, device=dev)
-        trans = torch.empty(R, N, device=dev)
-        rgb_out = torch.empty(R, 3, device=dev)
-        depth_out = torch.empty(R, 1, device=dev)
-        normal_out = torch.empty(R, 3, device=dev)
-        sem_out = torch.empty(R, K, device=dev)
-        opac_out = torch.empty(R, K, device=dev)
-        _be._backend.composite_fwd(z, sdf, raw, rgb, g, beta1, depth_scale, float(sem_scale), weights, trans, rgb_out, depth_out, normal_out,
-                                   sem_out, opac_out, rot=ctx.rot)
-        ctx.save_for_backward(z, sdf, raw, rgb, g, beta1, depth_scale)
-        ctx.sem_scale = float(sem_scale)
-        ctx.beta_shape = beta.shape
-        # inside iteration_prologue(): the per-ray partials d / d beta go to its relay (summed by hs_iter_epilogue), not through a sum launch
-        # ... and the normal map's cotangent w.r.t. the normals goes to the colour branch's backward kernel, their other consumer, which adds its
-        # own into the same buffer (no `grad += grad` launch): only when that Function registered exactly this tensor
-        # ... and only when the colour branch's backward is certain to run, i.e. when this Function's backward will hand its output (our `rgb`
-        # input) a cotangent: otherwise the normals' cotangent would wait in the relay for a consumer that never comes
-        ctx.nrelay = _NORMALS_RELAY if (_NORMALS_RELAY is not None and _NORMALS_RELAY["key"] is g and ctx.needs_input_grad[4]
-                                        and ctx.needs_input_grad[3]) else None
-        ctx.relay = None
-        if _BETA_RELAY is not None and _BETA_RELAY["key"] is beta and _BETA_RELAY["users"] < 3 and beta.requires_grad:
-            ctx.relay = _BETA_RELAY
-            _BETA_RELAY["users"] += 1
-        ctx.mark_non_differentiable(trans)
-        return weights, trans, rgb_out, depth_out, normal_out, sem_out, opac_out
-
-    @staticmethod
-    def backward(ctx, g_w, _g_t, g_rgb, g_depth, g_normal, g_sem, g_opac):
-        z, sdf, raw, rgb, g, beta1, depth_scale = ctx.saved_tensors
-        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
-        d_sdf = torch.empty_like(sdf)
-        d_raw = torch.empty_like(raw)
-        d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[3] else None
-        d_g = torch.empty_like(g) if ctx.needs_input_grad[4] else None
-        d_beta = torch.empty(z.shape[0], device=z.device) if ctx.needs_input_grad[5] else None   # per-ray partials
-        _be._backend.composite_bwd(z, sdf, raw, rgb, g, beta1, depth_scale, ctx.sem_scale, c(g_w), c(g_rgb), c(g_depth), c(g_normal), c(g_sem),
-                                   c(g_opac), d_sdf, d_raw, d_rgb, d_g, d_beta, rot=ctx.rot)
-        if d_beta is not None and ctx.relay is not None:
-            ctx.relay["parts"].append(d_beta)
-            d_beta = None
-        if d_g is not None and ctx.nrelay is not None:
-            ctx.nrelay["cot"] = d_g
-            d_g = None
-        return None, d_sdf, d_raw, d_rgb, d_g, (None if d_beta is None else d_beta.sum().reshape(ctx.beta_shape)), None, None, None
-
-
-def default_mlp_precision():
-    return os.environ.get("HOLOSCENE_MLP_PRECISION", "fp32")
-
-
-class WNLinear(nn.Module):
-    """Linear layer with weight normalisation, parameter names as ``nn.utils.weight_norm`` produces
-    them (bias, weight_g [out,1], weight_v [out,in]; W = g * v / ||v||_row) so reference checkpoints load."""
-
-    def __init__(self, in_features, out_features):
-        super().__init__()
-        lin = nn.Linear(in_features, out_features)
-        self.in_features, self.out_features = in_features, out_features
-        self.bf16 = False
-        self.bias = nn.Parameter(lin.bias.detach().clone())
-        self.weight_g = nn.Parameter(lin.weight.detach().norm(2, dim=1, keepdim=True))
-        self.weight_v = nn.Parameter(lin.weight.detach().clone())
-
-    def reset_g(self):
-        with torch.no_grad():
-            self.weight_g.copy_(self.weight_v.norm(2, dim=1, keepdim=True))
-
-    @property
-    def weight(self):
-        return torch._weight_norm(self.weight_v, self.weight_g, 0)
-
-    def forward(self, x):
-        return linear_rows(x, self.weight, self.bias, self.bf16)
-
-
-class _weight_norm_many(torch.autograd.Function):
-    """(v0, g0, v1, g1, ...) -> (W0, W1, ...), W = g * v / ||v||_row: all layers of a network in one launch each way
-    (csrc/appearance_mlp.hip: k_weight_norm) instead of one torch._weight_norm kernel per layer and direction."""
-
-    @staticmethod
-    def forward(ctx, *vg):
-        ctx.set_materialize_grads(False)
-        vs = [t.detach().float().contiguous() for t in vg[0::2]]
-        gs = [t.detach().float().contiguous() for t in vg[1::2]]
-        ctx.save_for_backward(*vs, *gs)
-        ctx.n = len(vs)
-        return tuple(_be._backend.weight_norm_fwd(vs, gs))
-
-    @staticmethod
-    def backward(ctx, *gWs):
-        vs, gs = ctx.saved_tensors[:ctx.n], ctx.saved_tensors[ctx.n:]
-        gWs = [torch.zeros_like(v) if gW is None else gW.contiguous().float() for v, gW in zip(vs, gWs)]
-        out = _be._backend.weight_norm_bwd(list(vs), list(gs), gWs)
-        return tuple(o.view_as(p) for o, p in zip(out, [t for pair in zip(vs, gs) for t in pair]))
-
-
-_SHARED_W = None
-
-
-@contextlib.contextmanager
-def shared_effective_weights(lins):
-    """Within the block effective_weights() of any subset of `lins` returns tensors normalised ONCE on entry (one launch for all
-    layers, and one for all their gradients on the way back): a training iteration asks for the trunk's matrices in the
-    sampler, the renderer and the background pass, and for the rendering network's in the renderer; the parameters cannot
-    change in between.  Enter with grad enabled when the block differentiates through the weights."""
-    global _SHARED_W
-    lins = [l for l in lins if isinstance(l, WNLinear) and l.weight_v.is_cuda]
-    if lins:
-        Ws = _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
-        _SHARED_W = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}
-    try:
-        yield
-    finally:
-        _SHARED_W = None
-
-
-# ---- the head and the tail of a training iteration as one launch each (csrc/iter_ops.hip)
-_ITER_PACKS = None      # armed by iteration_prologue(): every packed weight image of the iteration from ONE launch (hs_pack_iteration), keyed by the
-                        # identity of the effective matrices they were packed from -- the pack sites below take theirs from here when the keys match
-_NORMALS_RELAY = None   # armed by iteration_prologue(): {"key": the normals tensor both the colour branch and the compositing kernel consume, "cot": ...} --
-                        # _composite.backward leaves the normal map's cotangent there and the colour branch's backward kernel adds its own into it
-_BETA_RELAY = None      # armed by iteration_prologue(): {"key": beta_eff, "parts": [...]} -- _composite.backward leaves its per-ray partial
-                        # derivatives w.r.t. beta there instead of launching a sum; _iter_prologue.backward adds them up inside its one launch
-
-
-def flat_grad_view(p):
-    """The view of the flat gradient buffer that belongs to parameter p (training/flat.py), or None."""
-    v = getattr(p, "_hs_flat_view", None)
-    return v if v is not None and v.is_cuda else None
-
-
-def flat_grad_target(p):
-    """Where a backward kernel may put the gradient of parameter p without a copy afterwards: (view of the flat gradient buffer, first) --
-    first = this is the first producer since the optimiser's zero_grad(): it WRITES the view and hands it to autograd as the gradient
-    (adopted as p.grad without a copy); every later producer of the same backward pass (the background-patch iteration evaluates the trunk
-    twice) ACCUMULATES into it and hands autograd nothing.  (None, False): no flat view, or p.grad already holds something else."""
-    v = flat_grad_view(p)
-    owner = getattr(p, "_hs_flat", None)          # the FlatAdam that owns the view: the claims live there, for ONE backward pass
-    if v is None or owner is None or not owner.pass_open:
-        return None, False      # (outside zero_grad() .. gather_grads(): autograd's own accumulation, no direct writes)
-    if id(p) in owner.claims:
-        return v, False
-    if p.grad is None:
-        owner.claims[id(p)] = p
-        return v, True
-    return None, False
-
-
-class _DirectGrad:
-    """One hs_assemble job whose result is a parameter's gradient: into the flat view when there is one (flat_grad_target)."""
-
-    def __init__(self, p, shape):
-        self.shape = shape
-        self.d, self.first = flat_grad_target(p) if p is not None else (None, False)
-        if self.d is not None and self.d.numel() != shape[0] * shape[1]:
-            self.d, self.first = None, False
-
-    def job(self, terms):
-        if self.d is None:
-            return (self.shape, list(terms))
-        extra = [] if self.first else [(self.d, self.shape[1], 0)]        # later producers add to what is there
-        return (self.shape, list(terms) + extra, (self.d, None))
-
-    def grad(self, out, like_shape):
-        if self.d is None:
-            return out.view(like_shape)
-        return self.d.view(like_shape)[...] if self.first else None      # (a NEW tensor object on the view: autograd may adopt it as .grad)
-
-
-class _iter_prologue(torch.autograd.Function):
-    """(beta, v0, g0, v1, g1, ...) -> (|beta| + beta_min, W0, W1, ...) and, on the side, the iteration's pool of U[0, 1) draws and the
-    optimiser tick: hs_iter_prologue.  Backward: hs_iter_epilogue -- every weight-norm backward, beta's backward and the sum of the
-    compositing kernels' per-ray partials in one launch, written straight into the flat gradient buffer's views when the parameters
-    have them (flat_grad_view): no multi-tensor copy afterwards."""
-
-    @staticmethod
-    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, zero, *vg):
-        ctx.set_materialize_grads(False)
-        vs = [t.detach().float().contiguous() for t in vg[0::2]]
-        gs = [t.detach().float().contiguous() for t in vg[1::2]]
-        b = beta.detach().float().reshape(-1).contiguous()
-        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam, zero)
-        ctx.save_for_backward(b, *vs, *gs)
-        ctx.n, ctx.relay, ctx.beta_shape = len(vs), relay, beta.shape
-        ctx.params = (beta,) + tuple(vg)
-        return (beta_eff.view(beta.shape),) + tuple(Ws)
-
-    @staticmethod
-    def backward(ctx, g_beta, *gWs):
-        b = ctx.saved_tensors[0]
-        vs, gs = ctx.saved_tensors[1:1 + ctx.n], ctx.saved_tensors[1 + ctx.n:]
-        gWs = [torch.zeros_like(v) if gW is None else gW.contiguous().float() for v, gW in zip(vs, gWs)]
-        tg = [flat_grad_target(p) for p in ctx.params]
-        dst = [d if first else None for d, first in tg]         # this Function is the only producer of these gradients: write, or keep out of the view
-        fresh = lambda d, like: torch.empty_like(like) if d is None else d.view_as(like)[...]  # noqa: E731   (a NEW tensor object on the flat view: autograd may adopt it as .grad)
-        outs = [(fresh(dst[1 + 2 * i], v), fresh(dst[2 + 2 * i], g)) for i, (v, g) in enumerate(zip(vs, gs))]
-        parts = list(ctx.relay["parts"]) if ctx.relay is not None else []
-        if ctx.relay is not None:
-            ctx.relay["parts"].clear()
-        if g_beta is not None:
-            parts.append(g_beta.detach().float().reshape(-1).contiguous())
-        gb = None
-        if ctx.needs_input_grad[0] and parts:
-            gb = fresh(dst[0], b)
-            _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs, b, parts, gb)
-            gb = gb.view(ctx.beta_shape)
-        else:
-            _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs)
-        return (gb, None, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
-
-
-@contextlib.contextmanager
-def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
-    """One launch for everything a Stage-1 iteration needs before its first ray: within the block model.density.get_beta() and
-    effective_weights() return the tensors evaluated here (as under density.shared_beta() + shared_effective_weights()), `flat`'s Adam
-    state is ticked (training/flat.py: FlatAdam -- its step() then skips the tick launch), and the block yields the `rng` dictionary of
-    model.draw_uniforms (views of one pool of U[0, 1) draws from the model's own device-resident Philox stream).  Enter with grad enabled."""
-    global _SHARED_W, _BETA_RELAY
-    lins = [l for l in model.weight_norm_layers() if isinstance(l, WNLinear) and l.weight_v.is_cuda]
-    dens = model.density
-    dev = dens.beta.device
-    if not lins or dev.type != "cuda" or dens.beta.dtype != torch.float32:
-        if zero is not None:        # FlatAdam.zero_grad(defer=True) left this range to the prologue launch: the fallback must clear it itself
-            zero.zero_()
-        with dens.shared_beta(), shared_effective_weights(model.weight_norm_layers()):
-            yield None
-        return
-    pool = rng = None
-    if rng_sizes is not None:
-        total = sum(int(np.prod(v)) for v in rng_sizes.values())
-        pool = torch.empty(total, device=dev)
-    adam = None
-    if flat is not None and not flat._ticked:
-        adam = (flat.state, flat.betas[0], flat.betas[1], flat.gamma)
-    relay = {"key": None, "parts": [], "users": 0}
-    outs = _iter_prologue.apply(dens.beta, dens.beta_min, pool, model.rng_state(dev) if pool is not None else None, adam, relay, zero,
-                                *[t for l in lins for t in (l.weight_v, l.weight_g)])
-    if adam is not None:
-        flat._ticked = True
-    beta_eff, Ws = outs[0], outs[1:]
-    relay["key"] = beta_eff
-    if pool is not None:
-        rng, off = {}, 0
-        for k, shp in rng_sizes.items():
-            n = int(np.prod(shp))
-            rng[k] = pool[off:off + n].view(shp)
-            off += n
-    global _ITER_PACKS, _NORMALS_RELAY
-    prev_w, prev_relay, prev_beta, prev_packs, prev_nrm = _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY
-    _SHARED_W, _BETA_RELAY, dens._shared = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}, relay, beta_eff
-    _ITER_PACKS = model._pack_iteration()
-    _NORMALS_RELAY = {"key": None, "cot": None}
-    global _LAST_RELAYS
-    _LAST_RELAYS = (relay, _NORMALS_RELAY)
-    try:
-        yield rng
-    finally:
-        _SHARED_W, _BETA_RELAY, dens._shared, _ITER_PACKS, _NORMALS_RELAY = prev_w, prev_relay, prev_beta, prev_packs, prev_nrm
-
-
-_LAST_RELAYS = None
-
-
-def assert_relays_consumed():
-    """After the backward pass of an iteration that ran inside iteration_prologue(): every cotangent a backward kernel left in a relay for
-    another kernel to take along (beta's per-ray partials -> hs_iter_epilogue, the normal map's cotangent -> the colour branch's backward) has
-    been taken.  A relay that still holds something means a gradient contribution was dropped (a consumer's backward did not run)."""
-    if _LAST_RELAYS is None:
-        return
-    beta_relay, nrm_relay = _LAST_RELAYS
-    if beta_relay["parts"] or (nrm_relay is not None and nrm_relay["cot"] is not None):
-        raise RuntimeError("a relayed cotangent was not consumed in this backward pass (beta partials: "
-                           f"{len(beta_relay['parts'])}, normals: {nrm_relay is not None and nrm_relay['cot'] is not None}): its consumer's backward did not run")
-
-
-def fused_cols(W, l):
-    """W [out, n] of layer l with zero columns appended up to l.fused_cols -- the layers that read hash features of a grid with fewer than 16
-    levels (hashencoder/hashgrid.py: fused_offsets) as the fused 16-level kernels want them.  A plain pad: autograd slices the gradient back."""
-    n = getattr(l, "fused_cols", None)
-    if n is None or W.shape[1] >= n or not W.is_cuda:
-        return W
-    return torch.nn.functional.pad(W, (0, n - W.shape[1]))
-
-
-def effective_weights(lins):
-    """Weight-normalised matrices of a list of WNLinear layers (one fused launch on the GPU); columns zero-padded where a layer asks (fused_cols)."""
-    if _SHARED_W is not None and all(id(l) in _SHARED_W for l in lins):
-        return tuple(_SHARED_W[id(l)] for l in lins)
-    if lins[0].weight_v.is_cuda:
-        Ws = _weight_norm_many.apply(*[t for l in lins for t in (l.weight_v, l.weight_g)])
-        return tuple(fused_cols(W, l) for W, l in zip(Ws, lins))
-    return tuple(l.weight for l in lins)
-
-
-class _softplus_tangent(torch.autograd.Function):
-    """[B,rows,W] pre-activations (row 0 = value, rest = tangents) + bias -> activations, one fused pass
-    each way (csrc/mlp_ops.hip)."""
-
-    @staticmethod
-    def forward(ctx, A, bias):
-        A = A.contiguous()
-        out = torch.empty_like(A)
-        _be._backend.softplus_tangent_fwd(A, bias, out)
-        ctx.save_for_backward(A, bias)
-        return out
-
-    @staticmethod
-    def backward(ctx, G):
-        A, bias = ctx.saved_tensors
-        gA = torch.empty_like(A)
-        gbias = torch.zeros_like(bias) if ctx.needs_input_grad[1] else None
-        _be._backend.softplus_tangent_bwd(A, bias, G.contiguous(), gA, gbias)
-        return gA, gbias
-
-
-softplus_tangent = _softplus_tangent.apply
-
-
-class _split_value_jacobian(torch.autograd.Function):
-    """Last trunk layer output [B,4,K] (any float dtype) + bias -> y [B,K] f32, J [B,K,3] f32.
-    Written as a Function so the backward assembles the [B,4,K] cotangent with ONE concatenation instead of
-    autograd's zero-fill + two slice-adds over a 12.8 M-element tensor (0.2 ms per call at B = 100 352)."""
-
-    @staticmethod
-    def forward(ctx, out, bias):
-        ctx.dtype = out.dtype
-        o = out.float()
-        return o[:, 0] + bias, o[:, 1:].transpose(1, 2).contiguous()
-
-    @staticmethod
-    def backward(ctx, gy, gJ):
-        g = torch.cat([gy.unsqueeze(1), gJ.transpose(1, 2)], 1).to(ctx.dtype)
-        return g, (gy.sum(0) if ctx.needs_input_grad[1] else None)
-
-
-def softplus100(a):
-    return F.softplus(a, beta=100)
-
-
-def softplus100_grad(a):
-    """d softplus(a; beta=100)/da = sigmoid(100 a) (exactly 1 in fp32 above PyTorch's linear threshold)."""
-    return torch.sigmoid(100.0 * a)
+from . import fused_ops as ops
+from .fused_ops import softplus_tangent      # noqa: F401  (re-exported)
+from .fused_ops import (WNLinear, _Outputs, _composite, _fused_trunk, _render_input, _split_value_jacobian, _trunk_input, _trunk_rr32, _w2_planes, default_mlp_precision, effective_weights, fused_appearance, fused_cols, iteration_prologue, linear_rows, shared_effective_weights, trunk_render)      # noqa: F401
+from .fused_ops import (_hash_encode_jac, hash_encode_jac, _xp_columns, _xp_columns32, _wgrad_rows, _wgrad_rows_many, _trunk_fwd_core, _trunk_bwd_core, _fused_trunk_render, _rr_slices, _pair_slices, _rows_slices, _tp_colsum, _trunk_render_rr, _posenc6, _fused_appearance, _xa_columns, _fused_appearance_wave, _split_rows, _linear_rows, _weight_norm_many, flat_grad_view, flat_grad_target, _DirectGrad, _iter_prologue, assert_relays_consumed, _softplus_tangent, softplus100, softplus100_grad)      # noqa: F401  (re-exported: callers reach them as network.<name>)
 
 
 class ObjectImplicitNetworkGrid(nn.Module):
@@ -1728,7 +142,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
             if l in self.skip_in:
                 h = torch.cat([h, inp.to(h.dtype)], 1) / np.sqrt(2)
             if l < len(lins) - 1:
-                h = softplus_tangent(linear_rows(h, lin.weight, None, self.mlp_bf16).unsqueeze(1), lin.bias).squeeze(1)
+                h = ops.softplus_tangent(linear_rows(h, lin.weight, None, self.mlp_bf16).unsqueeze(1), lin.bias).squeeze(1)
             else:
                 h = linear_rows(h, lin.weight, None, self.mlp_bf16).float() + lin.bias
         return h
@@ -1788,7 +202,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
         """The no-grad SDF queries of the fp32 configuration through csrc/sdf_mlp32.hip (fp32 operands on the fp32 matrix cores): the stock
         trunk shape (or a grid of fewer levels padded to it: _stock_grid), d_out <= 32.  HOLOSCENE_FP32_SDF=gemm keeps the library GEMMs."""
         lins = self._lins()
-        return (FP32_SDF == "mfma" and not self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None and self.embedder.multires == 6
+        return (ops.FP32_SDF == "mfma" and not self.mlp_bf16 and x.is_cuda and len(lins) == 3 and self.embedder is not None and self.embedder.multires == 6
                 and self._stock_grid(padded=True) and self._stock_inputs(padded=True) and lins[0].out_features == 256
                 and lins[1].in_features == 256 and lins[1].out_features == 256 and lins[2].out_features == self.d_out <= 32
                 and not any(l in self.skip_in for l in range(3)))
@@ -1818,8 +232,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         """Fragment-order images for the wave-tile kernel (csrc/sdf_mlp2.hip), one pack launch per parameter state."""
         if getattr(self, "_packed_cache2", None) is not None:
             return self._packed_cache2
-        if _ITER_PACKS is not None and _ITER_PACKS.get("net") == id(self) and _ITER_PACKS["sdf"] is not None:
-            return _ITER_PACKS["sdf"]            # (not cached on the module: valid inside this iteration_prologue() only)
+        if ops._SCOPE.packs is not None and ops._SCOPE.packs.get("net") == id(self) and ops._SCOPE.packs["sdf"] is not None:
+            return ops._SCOPE.packs["sdf"]            # (not cached on the module: valid inside this iteration_prologue() only)
         l0, l1, l2 = self._lins()
         with torch.no_grad():
             f0, f1, f2 = effective_weights([l0, l1, l2])
@@ -1859,18 +273,18 @@ class ObjectImplicitNetworkGrid(nn.Module):
         be = _be._backend
         if not self.mlp_bf16:      # fp32 operands on the fp32 matrix cores (csrc/sdf_mlp32.hip)
             be.sdf_mlp32_fwd(x, feat, self._packed_weights32(), d_out, select, out, raw, gate=gate, feat_level_major=bool(lm))
-        elif SDF_MLP_IMPL == "wave" and d_out <= 32:
+        elif ops.SDF_MLP_IMPL == "wave" and d_out <= 32:
             be.sdf_mlp2_fwd(x, feat, self._packed_weights2(), d_out, select, out, raw, gate=gate, feat_level_major=lm)
-        elif SDF_MLP_IMPL == "wave" and d_out <= 64 and SDF_WIDE:
+        elif ops.SDF_MLP_IMPL == "wave" and d_out <= 64 and ops.SDF_WIDE:
             # 33..64 objects: the wave-tile kernel with the last layer's second 32-row tile after the first (36 us per sweep where the
             # workgroup-tile kernel below takes 65)
             pa, pb = self._packed_weights2_wide()
             be.sdf_mlp2_fwd_wide(x, feat, pa, pb, d_out, select, out, raw, gate=gate, feat_level_major=lm)
-        elif SDF_MLP_IMPL in ("wave", "tile"):
+        elif ops.SDF_MLP_IMPL in ("wave", "tile"):
             w0, b0, w1, b1, w2, b2 = self._packed_weights()
             be.sdf_mlp_fwd(x, feat, w0, b0, w1, b1, w2, b2, d_out, select, out, raw, gate=gate, feat_level_major=lm)
         else:
-            raise RuntimeError(f"unknown HOLOSCENE_SDF_MLP_IMPL={SDF_MLP_IMPL!r}")
+            raise RuntimeError(f"unknown HOLOSCENE_SDF_MLP_IMPL={ops.SDF_MLP_IMPL!r}")
 
     def invalidate_packed_weights(self):
         """The packed bf16 images are valid for one parameter state; the sampler drops them at the start of every call."""
@@ -1921,8 +335,8 @@ class ObjectImplicitNetworkGrid(nn.Module):
         d_out = self._lins()[2].out_features
         # ... and as bf16 words [L, R*S] when the wave-tile trunk kernel follows: it rounds the features to bf16 anyway (same rounding:
         # identical results), so the gather writes and the trunk reads half the bytes
-        words = lm and SDF_FEAT_BF16 and SDF_MLP_IMPL == "wave" and d_out <= (64 if SDF_WIDE else 32) and enc.embeddings.shape[1] == 2 and self.mlp_bf16
-        if words and SDF_SWEEP_FUSED and enc.level_dim == 2 and enc.fused_offsets.numel() == 17 and (d_out <= 32 or SDF_WIDE):
+        words = lm and ops.SDF_FEAT_BF16 and ops.SDF_MLP_IMPL == "wave" and d_out <= (64 if ops.SDF_WIDE else 32) and enc.embeddings.shape[1] == 2 and self.mlp_bf16
+        if words and ops.SDF_SWEEP_FUSED and enc.level_dim == 2 and enc.fused_offsets.numel() == 17 and (d_out <= 32 or ops.SDF_WIDE):
             # ONE launch per sweep: every lane of the trunk's wave tile gathers the eight levels of its own point (csrc/sdf_mlp2.hip: k_sdf_mlp2<., true>);
             # bit-identical to the gather + trunk pair below
             out = torch.empty(R, S, device=dev)
@@ -1950,10 +364,10 @@ class ObjectImplicitNetworkGrid(nn.Module):
         Differentiable w.r.t. every parameter by plain first-order autograd.
 
         Each point carries 4 rows through the trunk: the value and its three input tangents.  A Linear acts
-        on all rows alike (one GEMM with M = 4B); Softplus becomes the fused `softplus_tangent` stage."""
+        on all rows alike (one GEMM with M = 4B); Softplus becomes the fused `ops.softplus_tangent` stage."""
         x = x.detach()
         enc = self.encoding
-        if TRUNK_IMPL == "mfma" and self._fused_trunk_supported(x):
+        if ops.TRUNK_IMPL == "mfma" and self._fused_trunk_supported(x):
             l0, l1, l2 = self._lins()
             return _fused_trunk.apply(x, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                                       self.embedder.multires, float(self.divide_factor), fused_cols(l0.weight, l0), l0.bias, l1.weight, l1.bias,
@@ -1968,7 +382,7 @@ class ObjectImplicitNetworkGrid(nn.Module):
                 h = torch.cat([h, inp.to(h.dtype)], 2) / np.sqrt(2)
             out = linear_rows(h, lin.weight, None, self.mlp_bf16)        # one GEMM, M = 4B
             if l < len(lins) - 1:
-                h = softplus_tangent(out, lin.bias)
+                h = ops.softplus_tangent(out, lin.bias)
             else:
                 return _split_value_jacobian.apply(out, lin.bias)
 
@@ -2232,12 +646,12 @@ class HoloSceneNetwork(nn.Module):
             if K != net.d_out:
                 out.append(f"trunk output width {K} != d_out {net.d_out}: rendered samples on the library-GEMM value+Jacobian path")
             elif K > 32:
-                if RR_WIDE and TRUNK_MODE == "rr" and RR_FORWARD == "fused":
+                if ops.RR_WIDE and ops.TRUNK_MODE == "rr" and ops.RR_FORWARD == "fused":
                     out.append(f"d_out = {K} > 32: the benchmarked kernels with the last layer as two 32-row tiles (k_sdf_mlp2<true>, k_rr_fwd<true>, "
                                "k_rr_bwd_value<., true>, two 32-row weight-gradient jobs); three weight-pack launches per parameter state instead of the "
                                "iteration's one, the Eikonal points' backward on the 128-point workgroup-tile kernel (k_trunk_bwd<64>)")
                 else:
-                    out.append(f"d_out = {K} > 32 with HOLOSCENE_RR_WIDE=0 / TRUNK_MODE != rr: rendered samples on the four-row value+Jacobian kernels "
+                    out.append(f"d_out = {K} > 32 with HOLOSCENE_RR_WIDE=0 / ops.TRUNK_MODE != rr: rendered samples on the four-row value+Jacobian kernels "
                                "(k_trunk_fwd2<true, true>, k_trunk_bwd<64>, library weight-gradient GEMMs); per-call weight packing")
         probe = self.density.beta
         if probe.is_cuda and not self._fused_appearance_supported(probe):
@@ -2289,7 +703,7 @@ class HoloSceneNetwork(nn.Module):
         with self._stage_fp32("colour") as forced:
             if forced:
                 return self.rendering_network(points_flat, gradients, dirs_flat, net._color_features(points_flat), indices)
-        if APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
+        if ops.APPEARANCE_IMPL == "mfma" and self._fused_appearance_supported(points_flat):
             enc, mlp, rn = net.color_encoding, net.color_grid_feature_map_mlp, self.rendering_network
             R0, R1, R2 = effective_weights([rn.lin0, rn.lin1, rn.lin2])
             return fused_appearance(points_flat, dirs_flat, gradients, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)),
@@ -2329,7 +743,7 @@ class HoloSceneNetwork(nn.Module):
         else:
             rgb = self.rendering_network(points_flat, g_rgb, dirs_flat, fv, indices).reshape(-1, N, 3)
         base = {"rgb": rgb, "z_vals": z_vals, "depth_vals": z_vals * depth_scale, "sdf": sdf.reshape(z_vals.shape)}
-        if COMPOSITE_IMPL == "hip" and z_vals.is_cuda and not nf_outputs and not detach_rgb:
+        if ops.COMPOSITE_IMPL == "hip" and z_vals.is_cuda and not nf_outputs and not detach_rgb:
             # the fused compositing kernel (csrc/composite.hip) once per weight set.  Pass A runs on the SDF the semantics belong to,
             # with one extra "object" column appended to the per-object SDFs so that its occlusion-aware opacity comes out of the
             # same launch; pass B runs on the object-subset minimum and delivers colour, depth and the (rotated) normal map.
@@ -2450,7 +864,7 @@ class HoloSceneNetwork(nn.Module):
             rgb = self._rgb_at(points_flat, dirs_flat, gradients, 0).reshape(-1, N, 3)
         else:
             rgb = self.rendering_network(points_flat, gradients, dirs_flat, fv, 0).reshape(-1, N, 3)
-        if COMPOSITE_IMPL == "hip" and z_vals.is_cuda:      # one launch: weights, colour, world-frame normal map, composited semantics
+        if ops.COMPOSITE_IMPL == "hip" and z_vals.is_cuda:      # one launch: weights, colour, world-frame normal map, composited semantics
             ones = torch.ones(z_vals.shape[0], 1, device=z_vals.device)
             raw_cols = sdf_raw if (obj is None or nm) else sdf_raw[:, [obj]]
             a = _composite.apply(z_vals, sdf.reshape(-1, 1), raw_cols, rgb.reshape(-1, 3), gradients, self.density.get_beta(), ones, net.sigmoid)
@@ -2543,7 +957,7 @@ class HoloSceneNetwork(nn.Module):
         lin = self.implicit_network.color_grid_feature_map_mlp[0]
         if getattr(lin, "fused_cols", None) is None or not lin.weight.is_cuda:
             return lin.weight
-        packs = _ITER_PACKS
+        packs = ops._SCOPE.packs
         if packs is not None and packs.get("net") == id(self.implicit_network) and packs.get("color_w0") is not None:
             return packs["color_w0"]
         return fused_cols(lin.weight, lin)
@@ -2553,8 +967,8 @@ class HoloSceneNetwork(nn.Module):
         colour branch from one launch -- None when the model does not run on the fused bf16 kernels (the pack sites then pack for themselves)."""
         net, rn = self.implicit_network, self.rendering_network
         probe = self.density.beta
-        if not (probe.is_cuda and TRUNK_IMPL == "mfma" and TRUNK_MODE == "rr" and RR_FORWARD == "fused" and SDF_MLP_IMPL == "wave" and APPEARANCE_IMPL == "mfma"
-                and APPEARANCE_FORM == "wave" and net._fused_trunk_supported(probe) and self._fused_appearance_supported(probe)):
+        if not (probe.is_cuda and ops.TRUNK_IMPL == "mfma" and ops.TRUNK_MODE == "rr" and ops.RR_FORWARD == "fused" and ops.SDF_MLP_IMPL == "wave" and ops.APPEARANCE_IMPL == "mfma"
+                and ops.APPEARANCE_FORM == "wave" and net._fused_trunk_supported(probe) and self._fused_appearance_supported(probe)):
             return None
         l0, l1, l2 = net._lins()
         if l2.out_features != net.d_out or net.d_out > 32:
@@ -2745,7 +1159,7 @@ class HoloSceneNetwork(nn.Module):
         # and the Eikonal points together (half the trunk launches; the GEMMs simply get 4 % more rows)
         e0 = jitter = None
         eik_scale, eik_shift = 1.0, 0.0
-        fused_points = ray_dirs.is_cuda and COMPOSITE_IMPL == "hip"
+        fused_points = ray_dirs.is_cuda and ops.COMPOSITE_IMPL == "hip"
         if self.training:
             b = float(self.scene_bounding_sphere)
             if "eik_uniform" in rng:
@@ -2784,7 +1198,7 @@ class HoloSceneNetwork(nn.Module):
             def generic(xs):
                 y_, J_ = net.sdf_and_jacobian(xs)
                 return y_[:, :net.d_out], J_[:, :net.d_out]
-            fused_ok = TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out
+            fused_ok = ops.TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out
 
             def fused(xs, n_m, x01s):
                 enc = net.encoding
@@ -2809,14 +1223,14 @@ class HoloSceneNetwork(nn.Module):
                         y_eik, J_eik = generic(x_all[n_main:])
                     else:
                         y_eik, min_eik, gtheta = fused(x_all[n_main:], 0, x01e)[4:]
-        elif TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
+        elif ops.TRUNK_IMPL == "mfma" and net._fused_trunk_supported(x_all) and net._lins()[2].out_features == net.d_out:
             enc = net.encoding
             l0, l1, l2 = net._lins()
             trunk_W = W0, W1, W2 = effective_weights([l0, l1, l2])
             sdf_raw, sdf, idx_min, gradients, y_eik, min_eik, gtheta = trunk_render(
                 x_all.detach(), n_main, enc.embeddings, enc.fused_offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution),
                 net.embedder.multires, float(net.divide_factor), W0, l0.bias, W1, l1.bias, W2, l2.bias, x01_all)
-        elif FP32_TRUNK == "rr" and net._rr32_supported(x_all) and n_main > 0:
+        elif ops.FP32_TRUNK == "rr" and net._rr32_supported(x_all) and n_main > 0:
             # fp32: the rendered samples by the reverse-over-reverse closed form (rows = samples), the Eikonal points by value+Jacobian rows
             enc = net.encoding
             l0, l1, l2 = net._lins()
@@ -2841,14 +1255,14 @@ class HoloSceneNetwork(nn.Module):
         if not net.color_grid_feature:
             raise NotImplementedError("Stage-1 configs use color_grid_feature=True (confs/*/*.conf)")
         rgb = self._rgb_at(points_flat, dirs_flat, gradients, indices, None if x01_all is None else x01_all[:n_main]).reshape(-1, N_samples, 3)
-        if COMPOSITE_IMPL == "hip":
+        if ops.COMPOSITE_IMPL == "hip":
             if not z_vals.is_cuda:
                 raise RuntimeError("fused compositing needs CUDA tensors (set HOLOSCENE_COMPOSITE_IMPL=torch explicitly for the "
                                    "whole-tensor formulation)")
             weights, _, rgb_values, depth_values, normal_cam, semantic_values, object_opacity = _composite.apply(
                 z_vals, sdf, sdf_raw, rgb.reshape(-1, 3), gradients, self.density.get_beta(), depth_scale, self.implicit_network.sigmoid, rot)
             normal_world = None     # the kernel rotated the normal map into the camera frame
-        elif COMPOSITE_IMPL == "torch":
+        elif ops.COMPOSITE_IMPL == "torch":
             semantic = (net.sigmoid * torch.sigmoid(-net.sigmoid * sdf_raw)).reshape(-1, N_samples, self.num_semantic)
             weights, transmittance, dists = self.volume_rendering(z_vals, sdf)
             object_opacity = self.occlusion_opacity(z_vals, transmittance, dists, sdf_raw).sum(-1).transpose(0, 1)
@@ -2858,7 +1272,7 @@ class HoloSceneNetwork(nn.Module):
             normals = (gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)).reshape(-1, N_samples, 3)
             normal_world = torch.sum(weights.unsqueeze(-1) * normals, 1)
         else:
-            raise RuntimeError(f"unknown HOLOSCENE_COMPOSITE_IMPL={COMPOSITE_IMPL!r}")
+            raise RuntimeError(f"unknown HOLOSCENE_COMPOSITE_IMPL={ops.COMPOSITE_IMPL!r}")
         if self.white_bkgd:
             rgb_values = rgb_values + (1.0 - torch.sum(weights, -1)[..., None]) * self.bg_color.unsqueeze(0)
 
@@ -2898,7 +1312,7 @@ class HoloSceneNetwork(nn.Module):
         if bg is not None:  # background-surface pass (network.py:943-968)
             bg_z, ray_dirs0, cam_loc0 = bg["z_vals"], bg["ray_dirs"], bg["cam_loc"]
             n_bg = bg_z.shape[1]
-            fused_bg = (BG_IMPL == "hip" and fused_points and COMPOSITE_IMPL == "hip" and TRUNK_IMPL == "mfma"
+            fused_bg = (ops.BG_IMPL == "hip" and fused_points and ops.COMPOSITE_IMPL == "hip" and ops.TRUNK_IMPL == "mfma"
                         and net._fused_trunk_supported(bg_z) and net._lins()[2].out_features == net.d_out)
             if fused_bg:
                 # the same kernels as the main pass: positions, value+Jacobian trunk + split (no Eikonal rows), compositing -- once
@@ -2918,8 +1332,8 @@ class HoloSceneNetwork(nn.Module):
                 output["bg_mask"] = torch.argmax(bg_semantic, dim=-1, keepdim=True)
                 comp = _composite.apply(bg_z, raw_b[:, 0:1], raw_b, unused_rgb, grad_b, beta, bg["depth_scale"], net.sigmoid, rot)
                 output["bg_depth_values"], output["bg_normal_map"] = comp[3], comp[4]      # (camera frame: rotated by the kernel)
-            elif BG_IMPL not in ("hip", "torch"):
-                raise RuntimeError(f"unknown HOLOSCENE_BG_IMPL={BG_IMPL!r}")
+            elif ops.BG_IMPL not in ("hip", "torch"):
+                raise RuntimeError(f"unknown HOLOSCENE_BG_IMPL={ops.BG_IMPL!r}")
             else:
                 bg_points = (cam_loc0.unsqueeze(1) + bg_z.unsqueeze(2) * ray_dirs0.unsqueeze(1)).reshape(-1, 3)
                 scene_sdf, _, bg_gradients, scene_semantic, bg_sdf = self.implicit_network.get_specific_outputs(bg_points, 0)

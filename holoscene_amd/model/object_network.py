@@ -18,7 +18,8 @@ from .density import LaplaceDensity
 from .embedder import Embedder
 from .ray_sampler import ErrorBoundSampler
 from . import network as _net
-from .network import RenderingNetwork, WNLinear, _composite, _trunk_input, linear_rows, softplus_tangent
+from .network import RenderingNetwork
+from .fused_ops import WNLinear, _composite, _trunk_input, linear_rows, softplus_tangent
 
 
 class SingleObjectImplicitNetworkGrid(nn.Module):
@@ -198,7 +199,7 @@ class ObjectSDFNetwork(nn.Module):
         net, dev, N = self.implicit_network, z_vals.device, z_vals.shape[1]
         sdf, feature_vectors, gradients = y[:n_main, :net.d_out], y[:n_main, net.d_out:], J[:n_main].sum(dim=1)
         rgb_flat = self.rendering_network(points_flat, gradients, dirs_flat, feature_vectors)
-        if z_vals.is_cuda and _net.COMPOSITE_IMPL == "hip":
+        if z_vals.is_cuda and _net.ops.COMPOSITE_IMPL == "hip":
             ones = torch.ones(z_vals.shape[0], 1, device=dev)
             weights, _, rgb_values, depth_values, normal_map, _, object_opacity = _composite.apply(
                 z_vals, sdf, sdf, rgb_flat, gradients, self.density.get_beta(), ones, float(net.sigmoid))

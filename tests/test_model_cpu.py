@@ -15,7 +15,7 @@ def _oracle_hash(monkeypatch):
     from holoscene_amd.model import ray_sampler
     monkeypatch.setattr(ray_sampler, "SAMPLER_IMPL", "torch")  # explicit opt-in: host-logic check of the whole-tensor formulation
     from holoscene_amd.model import network
-    monkeypatch.setattr(network, "COMPOSITE_IMPL", "torch")
+    monkeypatch.setattr(network.ops, "COMPOSITE_IMPL", "torch")
     from holoscene_amd.model import loss
     monkeypatch.setattr(loss, "LOSS_IMPL", "torch")
 
@@ -189,7 +189,7 @@ def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
     """_pair_slices: the jobs of one hs_wgrad_pairs launch get workgroups in proportion to their (costed) bytes, the counts add up to the budget,
     no job gets more slices than it has tiles, and no slice is more than ~15 % above the mean load."""
     import math
-    from holoscene_amd.model.network import _PAIR_TILE_BYTES, _pair_slices
+    from holoscene_amd.model.fused_ops import _PAIR_TILE_BYTES, _pair_slices
     for T, Te, npair in [(3136, 512, 2), (3136, 512, 1), (12288, 1024, 2), (40, 8, 2), (3, 1, 2)]:
         jobs = [((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True), ((256, 80), T, 1, False),
                 ((256, 256, "rm"), Te, 1, True), ((256, 80, "rm"), Te, 1, True)]
@@ -198,7 +198,7 @@ def test_pair_slices_fill_the_chip_in_proportion_to_bytes():
         total_tiles = sum(j[1] for j in jobs)
         assert sum(cut) == min(256, total_tiles)
         if T >= 3136:
-            from holoscene_amd.model.network import _PAIR_REG_COST        # row-major-only jobs: the slower register-staged form, costed per byte
+            from holoscene_amd.model.fused_ops import _PAIR_REG_COST        # row-major-only jobs: the slower register-staged form, costed per byte
             per = [(_PAIR_TILE_BYTES[tuple(j[0][:2])] if j[3] else 64 * j[0][0]) * j[2] * (_PAIR_REG_COST if "rm" in j[0] else 1.0) for j in jobs]
             load = [math.ceil(j[1] / c) * p for j, c, p in zip(jobs, cut, per)]
             mean = sum(j[1] * p for j, p in zip(jobs, per)) / 256

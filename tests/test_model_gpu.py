@@ -388,7 +388,7 @@ def test_wide_sdf_sweep_vs_workgroup_tile_kernel(d_out, B, monkeypatch):
     assert torch.equal(wide["hi"], wide["raw"][:, 32]) and torch.equal(wide["last"], wide["raw"][:, d_out - 1])
     assert torch.equal(wide["sub"], wide["raw"][:, sub].min(-1, keepdim=True)[0])
     assert torch.equal(wide["rays"], wide["min"][:wide["rays"].shape[0]])
-    monkeypatch.setattr(N, "SDF_WIDE", False)
+    monkeypatch.setattr(N.ops, "SDF_WIDE", False)
     n = len(calls)
     tile = queries()
     assert len(calls) == n
@@ -568,7 +568,7 @@ def test_fused_mfma_training_trunk_vs_gemm_path(d_out, B, monkeypatch):
 
     def run(prec, impl):
         net.set_mlp_precision(prec)
-        monkeypatch.setattr(N, "TRUNK_IMPL", impl)
+        monkeypatch.setattr(N.ops, "TRUNK_IMPL", impl)
         y, J = net.sdf_and_jacobian(x)
         gr = torch.autograd.grad((y * cy).sum() + (J * cJ).sum(), params)
         return y.detach(), J.detach(), [g.float() for g in gr]
@@ -577,9 +577,9 @@ def test_fused_mfma_training_trunk_vs_gemm_path(d_out, B, monkeypatch):
     gem = run("bf16", "gemm")
     assert net._fused_trunk_supported(x)
     got = run("bf16", "mfma")
-    monkeypatch.setattr(N, "TRUNK_INPUT_IN_KERNEL", True)     # the kernel assembling its own input rows: same numbers up to the
+    monkeypatch.setattr(N.ops, "TRUNK_INPUT_IN_KERNEL", True)     # the kernel assembling its own input rows: same numbers up to the
     got_in = run("bf16", "mfma")                               # hardware vs libm sin/cos before the bf16 rounding
-    monkeypatch.setattr(N, "TRUNK_INPUT_IN_KERNEL", False)
+    monkeypatch.setattr(N.ops, "TRUNK_INPUT_IN_KERNEL", False)
 
     def errs(a, b):
         return float((a - b).abs().max()), float(b.abs().max()), float((a - b).norm() / (b.norm() + 1e-20))
@@ -947,7 +947,7 @@ def test_fused_background_pass_vs_torch_formulation(trunk_mode, monkeypatch):
     arithmetic: tight bounds); "rr" (the default): the fused side takes d min / dx by the reverse-over-reverse kernels -- another
     order of bf16 roundings, so bf16-level bounds."""
     from holoscene_amd.model import network as N
-    monkeypatch.setattr(N, "TRUNK_MODE", trunk_mode)
+    monkeypatch.setattr(N.ops, "TRUNK_MODE", trunk_mode)
     tight = trunk_mode == "jac"
     tr, scene = _full_graph_trainer(0.01, True)
     model = tr.model.train()
@@ -962,7 +962,7 @@ def test_fused_background_pass_vs_torch_formulation(trunk_mode, monkeypatch):
     cot_d, cot_n = torch.randn(1024, 1, device=DEV), torch.randn(1024, 3, device=DEV)
     res = {}
     for impl in ("torch", "hip"):
-        monkeypatch.setattr(N, "BG_IMPL", impl)
+        monkeypatch.setattr(N.ops, "BG_IMPL", impl)
         out = model.render(rays, z, z_eik, None, rng=rng, bg=dict(bg))
         val = (out["bg_depth_values"] * cot_d).sum() + (out["bg_normal_map"] * cot_n).sum()
         grads = torch.autograd.grad(val, params, allow_unused=True)
@@ -976,7 +976,7 @@ def test_fused_background_pass_vs_torch_formulation(trunk_mode, monkeypatch):
         net = model.implicit_network
         net.set_mlp_precision("fp32")
         model.rendering_network.set_mlp_precision("fp32")
-        monkeypatch.setattr(N, "BG_IMPL", "torch")
+        monkeypatch.setattr(N.ops, "BG_IMPL", "torch")
         with torch.no_grad():
             ref_mask = model.render(rays, z, z_eik, None, rng=rng, bg=dict(bg))["bg_mask"]
         net.set_mlp_precision("bf16")
@@ -1051,7 +1051,7 @@ def test_stage23_entry_points_fused_colour_path(monkeypatch):
     table = model.implicit_network.color_encoding.embeddings
     res = {}
     for impl in ("gemm", "mfma"):
-        monkeypatch.setattr(N, "APPEARANCE_IMPL", impl)
+        monkeypatch.setattr(N.ops, "APPEARANCE_IMPL", impl)
         outs = [model.forward_multi_obj_rays_subset_all_sdf(o, d, pose, [1, 2], [0, 1, 2]),
                 model.forward_multi_obj_rays_subset_all_sdf_detach_rgb_for_geometry(o, d, pose, [1, 2], [0, 1, 2]),
                 {"rgb_values": model.get_colors_normals_from_point_rays_obj(o, d, pose, 2)[0]}]
@@ -1302,7 +1302,7 @@ def test_wide_trunk_forward_vs_workgroup_tile_kernels(d_out, B, n_main, monkeypa
     monkeypatch.setattr(be_mod._backend, "trunk_mlp2_fwd_wide", staticmethod(lambda *a, **k: calls.append(1) or orig(*a, **k)))
 
     def run(wide):
-        monkeypatch.setattr(N, "TRUNK_WIDE", wide)
+        monkeypatch.setattr(N.ops, "TRUNK_WIDE", wide)
         sdf_raw, sdf, idx, grad, y_e, min_e, gtheta = N._fused_trunk_render.apply(
             x, n_main, enc.embeddings, enc.offsets, float(np.log2(enc.per_level_scale)), int(enc.base_resolution), 6, 1.0, l0.weight, l0.bias, l1.weight,
             l1.bias, l2.weight, l2.bias)
@@ -1783,10 +1783,10 @@ def test_fp32_fused_sdf_sweep_vs_library_gemms(B, d_out, L, monkeypatch):
         assert net._fused_sdf32_supported(x)
         got = {"min": net.get_sdf_vals(x), "raw": net.get_sdf_raw(x), "one": net.get_object_sdf_vals(x, d_out - 2), "sub": net.get_multi_object_sdf_vals(x, sub)}
         net.invalidate_packed_weights()
-        monkeypatch.setattr(N, "FP32_SDF", "gemm")
+        monkeypatch.setattr(N.ops, "FP32_SDF", "gemm")
         assert not net._fused_sdf32_supported(x)
         ref = {"min": net.get_sdf_vals(x), "raw": net.get_sdf_raw(x), "one": net.get_object_sdf_vals(x, d_out - 2), "sub": net.get_multi_object_sdf_vals(x, sub)}
-        monkeypatch.setattr(N, "FP32_SDF", "mfma")
+        monkeypatch.setattr(N.ops, "FP32_SDF", "mfma")
     for k in got:
         assert got[k].shape == ref[k].shape, k
         err = float((got[k] - ref[k]).abs().max())
@@ -2054,10 +2054,10 @@ def test_sweep_with_the_gather_inside_is_bit_identical_to_gather_plus_trunk(d_ou
         net.invalidate_packed_weights()
         with torch.no_grad():
             return [net.sdf_at_points(x, x01, 1, B, sel, gate=(b, a)).clone() for sel in sels]
-    monkeypatch.setattr(N, "SDF_SWEEP_FUSED", True)
+    monkeypatch.setattr(N.ops, "SDF_SWEEP_FUSED", True)
     fused = queries()
     assert len(calls) == len(sels)
-    monkeypatch.setattr(N, "SDF_SWEEP_FUSED", False)
+    monkeypatch.setattr(N.ops, "SDF_SWEEP_FUSED", False)
     pair = queries()
     assert len(calls) == len(sels)
     inside = ((x01 >= 0) & (x01 <= 1)).all(-1).float().mean().item()

@@ -40,7 +40,7 @@ def capture(name):
     for mod in (network, ray_sampler):
         if hasattr(mod, "_be"):
             mod._be._backend = oracle_backend.OracleBackend
-    ray_sampler.SAMPLER_IMPL, network.COMPOSITE_IMPL, loss_mod.LOSS_IMPL = "torch", "torch", "torch"
+    ray_sampler.SAMPLER_IMPL, network.ops.COMPOSITE_IMPL, loss_mod.LOSS_IMPL = "torch", "torch", "torch"
     rec = load(name)
     model = build_model(rec).train()
     got = {}

@@ -21,8 +21,8 @@ def t(fn, n=20):
         a.record(); g.replay(); b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / n * 1e3
 print("fused fp32 sweep (gather + k_sdf_mlp32): %.1f us" % t(lambda: net.sdf_at_points(x, x01, 1024, 128)))
-N.FP32_SDF = "gemm"
+N.ops.FP32_SDF = "gemm"
 print("library GEMM form (get_sdf_vals):       %.1f us" % t(lambda: net.get_sdf_vals(x)))
-N.FP32_SDF = "mfma"
+N.ops.FP32_SDF = "mfma"
 net.set_mlp_precision("bf16")
 print("bf16 sweep (gather + k_sdf_mlp2):        %.1f us" % t(lambda: net.sdf_at_points(x, x01, 1024, 128)))
