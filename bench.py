@@ -710,7 +710,7 @@ def main():
         + 7 * 4 * n_params + 4 * n_params
     dom = kernels[0] if kernels else None
     traffic, traffic_src = None, None
-    for cand in ("r05", "r04", "r03", "r02", "r01"):
+    for cand in ("r06", "r05", "r04", "r03", "r02", "r01"):
         pmc_file = os.path.join(ROOT, "profiles", cand, "pmc_traffic.json")
         if os.path.exists(pmc_file):
             pm = json.load(open(pmc_file))
@@ -733,7 +733,7 @@ def main():
                          "other_roof_frac": dom.get("hbm_frac") if mf else dom.get("mfma_frac")})
     # the roof the dominant kernel IS under when it is not the contract's (HBM / MFMA): for the hash gather the texture addresser's busy fraction
     # from the committed counter passes (profiles/run_pmc_tcp.sh + run_pmc_issue.sh -> tools/pmc_gather_bound.py)
-    gb_file = os.path.join(ROOT, "profiles", "r05", "gather_bound.json")
+    gb_file = next((f for f in (os.path.join(ROOT, "profiles", r_, "gather_bound.json") for r_ in ("r06", "r05")) if os.path.exists(f)), "")
     if dom is not None and dom["kernel"].startswith("k_hash_fwd") and os.path.exists(gb_file):
         gb = json.load(open(gb_file))
         key = next((k for k in gb if "false" in k and "4194304" in k), None) or next(iter(gb), None)
@@ -741,7 +741,7 @@ def main():
             # (a value read from a committed counter pass is named as such; --roofline-counters measures `other_roof` in the run, below)
             roofline["other_roof_committed"] = {"name": "texture addresser busy: TA_TA_BUSY / 256 addressers / kernel cycles (SQ_BUSY_CYCLES / 32)", "frac": gb[key]["ta_busy"],
                                                 "also": {k_: gb[key][k_] for k_ in ("tcp_busy", "l1_tag_rate", "valu_issue", "wait_over_wave_cycles")},
-                                                "kernel": key, "source": "profiles/r05/gather_bound.json", "measured_in_this_run": False}
+                                                "kernel": key, "source": os.path.relpath(gb_file, ROOT), "measured_in_this_run": False}
     if dom is not None and args.roofline_counters and dom["kernel"].startswith("k_hash_fwd"):
         measured = measure_other_roof(args, dom["kernel"].split(" ")[0])
         if measured is not None:
