@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int hs_abi_version(void) { return 8; }
+int hs_abi_version(void) { return 9; }
 
 const char *hs_target_arch(void) { return "gfx950"; }
 

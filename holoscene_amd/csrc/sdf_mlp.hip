@@ -534,11 +534,14 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
     // wave owning 32 of the 256 columns accumulates its [KP x 32] block over all tiles of the workgroup in registers (16 VGPRs per 32
     // outputs) instead of a library GEMM re-reading H1 (214 MB) and g.  The fragments run along the rows of row-major tiles, hence 2-byte
     // LDS reads (8 per operand and k-step): ~3 % more work in this kernel for one GEMM launch (66 us) less.
-    f32x16 accW[KP / 32];
+    constexpr int kWaves = kThreads / 64, kColPasses = HID / (32 * kWaves);     // 32-column blocks of dW2 per wave: 1 (8 waves) or 2 (4 waves, BM = 64)
+    f32x16 accW[kColPasses][KP / 32];
 #pragma unroll
-    for (int mt = 0; mt < KP / 32; mt++)
+    for (int cp = 0; cp < kColPasses; cp++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) accW[mt][i] = 0.f;
+        for (int mt = 0; mt < KP / 32; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) accW[cp][mt][i] = 0.f;
     const int64_t ntiles = (M + BM - 1) / BM;
     // The H0 tile (64 KB) is requested early, right after the K = 32 product -- requested where it is consumed, each layer-output tile
     // costs ~8 k cycles of exposed wait (tools/exp/tbwd_prof.hip).  Requesting the NEXT tile's H1 under the input-cotangent phase as well
@@ -582,11 +585,14 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
             const uint32_t gb_ = lds_addr_of(Gs + (size_t)((lane >> 5) * 8 + (L16 >> 2)) * GP + 16 * cg + 4 * (L16 & 3));
 #pragma unroll 2
             for (int ks = 0; ks < BM / 16; ks++) {
-                const bf16x8 bfrag = tr_frag(hb + (uint32_t)(ks * 16 * HP * 2), 4 * HP * 2);
 #pragma unroll
-                for (int mt = 0; mt < KP / 32; mt++) {
-                    const bf16x8 afrag = tr_frag(gb_ + (uint32_t)((ks * 16 * GP + mt * 32) * 2), 4 * GP * 2);
-                    accW[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, accW[mt], 0, 0, 0);
+                for (int cp = 0; cp < kColPasses; cp++) {
+                    const bf16x8 bfrag = tr_frag(hb + (uint32_t)((ks * 16 * HP + cp * 32 * kWaves) * 2), 4 * HP * 2);
+#pragma unroll
+                    for (int mt = 0; mt < KP / 32; mt++) {
+                        const bf16x8 afrag = tr_frag(gb_ + (uint32_t)((ks * 16 * GP + mt * 32) * 2), 4 * GP * 2);
+                        accW[cp][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, accW[cp][mt], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();   // the epilogue below rewrites H in place
@@ -678,9 +684,11 @@ __global__ __launch_bounds__(kThreads) void k_trunk_bwd(const uint16_t *__restri
     if (dW2_part) {   // this workgroup's slice [KP][256]; lane: column wave*32 + (lane & 31), outputs (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
         float *dst = dW2_part + (size_t)blockIdx.x * KP * HID + wave * 32 + (lane & 31);
 #pragma unroll
-        for (int mt = 0; mt < KP / 32; mt++)
+        for (int cp = 0; cp < kColPasses; cp++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) dst[(size_t)(mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * HID] = accW[mt][i];
+            for (int mt = 0; mt < KP / 32; mt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) dst[(size_t)(mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * HID + cp * 32 * kWaves] = accW[cp][mt][i];
     }
     if (threadIdx.x < HID) {
         if (gb1) unsafeAtomicAdd(gb1 + threadIdx.x, sum1);

@@ -25,6 +25,7 @@
 #include "launch_util.h"
 #include "wave_tile.h"
 #include "trunk_pack.h"
+#include "split_bwd.h"
 
 namespace {
 
@@ -776,13 +777,13 @@ __global__ __launch_bounds__(kThreadsW, 2) void k_rr_bwd_value(const uint16_t *_
 // loads and ONE 16-byte store per row piece (the first version wrote two bytes per thread: 21 us for 19 MB), column sums in registers,
 // folded over the wave's sixteen rows by shuffles at the end.
 template <int CG>       // column groups of eight per row: 4 (K <= 32) or 8 (K <= 64: gy is then TWO planes [2][n][32], objects 0..31 | 32..63)
-__global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
-                                               uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n) {
+__device__ __forceinline__ void rr_gy_body(int block, int nblocks, const float *__restrict__ g_raw, const float *__restrict__ g_sdf,
+                                           const int64_t *__restrict__ idx, int K, uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n) {
     constexpr int RP = 256 / CG, RW = 64 / CG;       // rows per pass of the workgroup / of a wave
     __shared__ float part[4][8 * CG];
     const int cg = threadIdx.x & (CG - 1), rl = threadIdx.x / CG, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = ((n + gridDim.x - 1) / gridDim.x + RP - 1) / RP * RP;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    const int64_t per = ((n + nblocks - 1) / nblocks + RP - 1) / RP * RP;
+    const int64_t r0 = (int64_t)block * per, r1 = r0 + per < n ? r0 + per : n;
     const bool vec = (K & 3) == 0;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint16_t *gyp = gy + (size_t)(cg >> 2) * (size_t)n * 32;        // this column group's plane
@@ -819,9 +820,28 @@ __global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, 
         }
         __syncthreads();
         if (threadIdx.x < 8 * CG)
-            gb2_part[(size_t)blockIdx.x * (8 * CG) + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            gb2_part[(size_t)block * (8 * CG) + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
     }
     (void)RW;
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) void k_rr_gy(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
+                                               uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n) {
+    rr_gy_body<CG>((int)blockIdx.x, (int)gridDim.x, g_raw, g_sdf, idx, K, gy, gb2_part, n);
+}
+
+// The two output-cotangent images of a trunk backward pass in ONE launch: workgroups [0, HS_RR_GY_BLOCKS) form gy of the rendered samples (above),
+// the rest the [4 Be, KPe] image of the Eikonal points' value+Jacobian rows (split_bwd.h).  Both read only what the loss and the compositing
+// backward left; as two launches the second cost its ~7 us whatever it did.
+template <int CG>
+__global__ __launch_bounds__(256) void k_rr_gy_split(const float *__restrict__ g_raw, const float *__restrict__ g_sdf, const int64_t *__restrict__ idx, int K,
+                                                     uint16_t *__restrict__ gy, float *__restrict__ gb2_part, int64_t n,
+                                                     const int64_t *__restrict__ idx_e, const float *__restrict__ g_yeik, const float *__restrict__ g_mineik,
+                                                     const float *__restrict__ g_theta, int64_t Be, int KPe, __hip_bfloat16 *__restrict__ g_img) {
+    if ((int)blockIdx.x < HS_RR_GY_BLOCKS) rr_gy_body<CG>((int)blockIdx.x, HS_RR_GY_BLOCKS, g_raw, g_sdf, idx, K, gy, gb2_part, n);
+    else trunk_split_bwd_body((int)blockIdx.x - HS_RR_GY_BLOCKS, (int)gridDim.x - HS_RR_GY_BLOCKS, nullptr, nullptr, idx_e, nullptr, g_yeik, g_mineik, g_theta, Be, 0, K,
+                              KPe, g_img);
 }
 
 // ================================================================================================================ fused forward
@@ -1286,6 +1306,21 @@ int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, i
     if (!gy || (g_sdf && !idx)) return HS_ERR_NULL;
     if (K <= 32) k_rr_gy<4><<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);
     else k_rr_gy<8><<<HS_RR_GY_BLOCKS, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n);       /* gy [2][n][32], gb2_part [blocks, 64] */
+    return wt_check_launch();
+}
+
+int hs_trunk_rr_gy_split(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, const int64_t *idx_e,
+                         const float *g_y_eik, const float *g_min_eik, const float *g_grad_theta, int64_t Be, int32_t KPe, void *g_img, void *stream) {
+    if (K < 1 || K > 64 || K > KPe || (KPe & 31) || n < 1 || Be < 1) return HS_ERR_ARG;
+    if (!gy || (g_sdf && !idx) || !idx_e || !g_img) return HS_ERR_NULL;
+    const int64_t want = (Be * 4 * (KPe / 8) + 255) / 256;
+    const int split_blocks = (int)(want < 2048 ? want : 2048);
+    if (K <= 32)
+        k_rr_gy_split<4><<<HS_RR_GY_BLOCKS + split_blocks, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n, idx_e, g_y_eik, g_min_eik,
+                                                                                         g_grad_theta, Be, KPe, (__hip_bfloat16 *)g_img);
+    else
+        k_rr_gy_split<8><<<HS_RR_GY_BLOCKS + split_blocks, 256, 0, (hipStream_t)stream>>>(g_raw, g_sdf, idx, K, (uint16_t *)gy, gb2_part, n, idx_e, g_y_eik, g_min_eik,
+                                                                                         g_grad_theta, Be, KPe, (__hip_bfloat16 *)g_img);
     return wt_check_launch();
 }
 

@@ -86,7 +86,7 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
 # together with the flat gradient buffer -- one memset per iteration instead of one ~5 us fill launch per accumulator.  The sequence of
@@ -156,7 +156,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_gy_split", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -885,6 +885,24 @@ class _HipBackend:
             raise RuntimeError(f"trunk_rr_gy: gb2_part must be [RR_GY_BLOCKS, {KP}]")
         _check(lib.hs_trunk_rr_gy(_dev(g_raw, "g_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), int(K), _dev(gy, "gy", torch.bfloat16),
                                   _dev(gb2_part, "gb2_part"), ctypes.c_int64(gy.shape[-2]), _stream()), "hs_trunk_rr_gy")
+
+    @staticmethod
+    def trunk_rr_gy_split(g_raw, g_sdf, idx, K, gy, gb2_part, idx_e, g_yeik, g_mineik, g_theta, g_img):
+        """trunk_rr_gy(...) and trunk_split_bwd(None, None, idx_e, None, g_yeik, g_mineik, g_theta, Be, 0, K, g_img) in one launch (g_img: bf16
+        [4 Be, 32 or 64], the output-cotangent image of the Be Eikonal points' value+Jacobian rows)."""
+        lib = load_library()
+        KP = 32 if K <= 32 else 64
+        if tuple(gy.shape[:-2]) != ((2,) if KP == 64 else ()) or gy.shape[-1] != 32:
+            raise RuntimeError("trunk_rr_gy_split: gy must be [n, 32] for K <= 32, [2, n, 32] for 33..64 objects")
+        if gb2_part is not None and tuple(gb2_part.shape) != (_HipBackend.RR_GY_BLOCKS, KP):
+            raise RuntimeError(f"trunk_rr_gy_split: gb2_part must be [RR_GY_BLOCKS, {KP}]")
+        Be = idx_e.shape[0]
+        if g_img.dim() != 2 or g_img.shape[0] != 4 * Be or g_img.shape[1] not in (32, 64):
+            raise RuntimeError("trunk_rr_gy_split: g_img must be [4 Be, 32 or 64]")
+        _check(lib.hs_trunk_rr_gy_split(_dev(g_raw, "g_raw"), _dev(g_sdf, "g_sdf"), _dev(idx, "idx", torch.int64), int(K), _dev(gy, "gy", torch.bfloat16),
+                                        _dev(gb2_part, "gb2_part"), ctypes.c_int64(gy.shape[-2]), _dev(idx_e, "idx_e", torch.int64), _dev(g_yeik, "g_y_eik"),
+                                        _dev(g_mineik, "g_min_eik"), _dev(g_theta, "g_grad_theta"), ctypes.c_int64(Be), int(g_img.shape[1]),
+                                        _dev(g_img, "g_img", torch.bfloat16), _stream()), "hs_trunk_rr_gy_split")
 
     @staticmethod
     def trunk_pack_wide(W0, b0, W1, b1, W2, b2, d_out):

@@ -625,7 +625,16 @@ class _trunk_render_rr(torch.autograd.Function):
         gy = torch.empty((2, n, 32) if wide else (n, 32), device=dev, dtype=bf)
         gbz = _be.zeros_small(2 * 256 + KP, dev)            # bias-gradient accumulators: [b1 | b0 | b2] (Eikonal rows add theirs by atomics)
         gb2_part = torch.empty(be.RR_GY_BLOCKS, KP, device=dev) if need_w else None
-        be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
+        # the Eikonal points' output-cotangent image is formed by the same launch (both read only what the loss left)
+        eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
+        g_img = torch.empty(4 * Be, KP, device=dev, dtype=bf) if eik_live else None
+        if eik_live and n > 0:
+            be.trunk_rr_gy_split(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part, idx[n:].reshape(-1), c(g_yeik),
+                                 c(g_mineik), c(g_theta), g_img)
+        else:
+            be.trunk_rr_gy(c(g_raw), None if g_sdf is None else c(g_sdf).reshape(-1), idx[:n], K, gy, gb2_part)
+            if eik_live:
+                be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
         A0t, A1t = tp(), tp()
         second = g_grad is not None
         if second:
@@ -648,14 +657,11 @@ class _trunk_render_rr(torch.autograd.Function):
             else:
                 be.trunk_rr_bwd_value(gy, rr, H0t, H1t, None, None, A0t, A1t, g_feat, n, ld=B)
         # ---- Eikonal points: the value+Jacobian backward kernel writes their share of the scatter cotangents
-        eik_live = Be > 0 and (g_yeik is not None or g_mineik is not None or g_theta is not None)
         w2_part = None
         eik_jobs = []
         if eik_live:
             H0e, H1e, Xpe, w0t, w1t, w2t = sv[22:]
             Me = 4 * Be
-            g_img = torch.empty(Me, KP, device=dev, dtype=bf)
-            be.trunk_split_bwd(None, None, idx[n:], None, c(g_yeik), c(g_mineik), c(g_theta), Be, 0, K, g_img)
             gA1, gA0 = torch.empty(Me, 256, device=dev, dtype=bf), torch.empty(Me, 256, device=dev, dtype=bf)
             w2_part = torch.empty(be.trunk_bwd_parts(Me), KP, 256, device=dev) if need_w else None
             be.trunk_mlp_bwd(g_img, H1e, H0e, w2t, w1t, gA1, gA0, gbz[:256], gbz[256:512], w0t, g_feat, g_dydx, L, C, jac,

@@ -703,6 +703,10 @@ int hs_trunk_rr_fwd(const float *x, const float *feat, const float *dydx, const 
  * skip): per-block column sums of gy (their sum = the last layer's bias gradient) */
 #define HS_RR_GY_BLOCKS 512
 int hs_trunk_rr_gy(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, void *stream);
+/* hs_trunk_rr_gy and hs_trunk_split_bwd(NULL, NULL, idx_e, NULL, g_y_eik, g_min_eik, g_grad_theta, Be, 0, K, KPe, g_img) -- the cotangent image of the
+ * Be Eikonal points' value+Jacobian rows -- in one launch (the two read nothing of each other). */
+int hs_trunk_rr_gy_split(const float *g_raw, const float *g_sdf, const int64_t *idx, int32_t K, void *gy, float *gb2_part, int64_t n, const int64_t *idx_e,
+                         const float *g_y_eik, const float *g_min_eik, const float *g_grad_theta, int64_t Be, int32_t KPe, void *g_img, void *stream);
 int64_t hs_trunk_rr_pack_bytes(int32_t which);
 int hs_trunk_rr_pack(const float *W0, int32_t ld0, const float *W1, const float *W2, int32_t d_out, void *W1Tf, void *W0Tf, void *W2Tf, float *W2tab,
                      void *stream);
@@ -829,7 +833,7 @@ int hs_loss_rays(const float *rgb, const float *rgb_gt, const float *depth, cons
                  float w_depth, float w_l1, float w_cos, float w_opac, float *out5, float *g_rgb, float *g_depth, float *g_normal_map,
                  float *g_opacity, float *scratch /* [2R] work space */, void *stream);
 int hs_loss_eikonal(const float *g1, const float *g2, int64_t H, float w_eik, float w_smooth, float *acc2, float *d_g1, float *d_g2, void *stream);
-/* Both of the above plus the weighted total (loss.py:325-334, 655-657) as three launches with no host-side glue:
+/* Both of the above plus the weighted total (loss.py:325-334, 655-657) as two launches with no host-side glue:
  * weights7 (HOST array) = weights of {rgb, depth, normal_l1, normal_cos, opacity, eikonal, smooth};
  * out8 = the seven unweighted terms in that order, then sum_i weights7[i] * term_i.  scratch [2R + 2 * HS_LOSS_EIK_BLOCKS] (needs no initialisation). */
 #define HS_LOSS_EIK_BLOCKS 256
