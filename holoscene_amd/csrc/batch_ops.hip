@@ -20,72 +20,9 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "batch_draw.h"
 
 namespace {
-
-constexpr int kDrawThreads = 256;
-constexpr int kDrawLdsCls = 510;
-
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {      // splitmix64 finaliser
-    x += 0x9e3779b97f4a7c15ull;
-    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-    return x ^ (x >> 31);
-}
-
-// P(i) for a keyed pseudo-random permutation P of [0, n), n >= 2, i < n
-__device__ __forceinline__ uint32_t perm_index(uint32_t i, uint32_t n, uint64_t key) {
-    int h = 1;
-    while ((1u << (2 * h)) < n) h++;             // 4^h >= n: two h-bit halves
-    const uint32_t mask = (1u << h) - 1u;
-    uint32_t x = i;
-    do {
-        uint32_t l = x >> h, r = x & mask;
-#pragma unroll
-        for (int round = 0; round < 4; round++) {
-            const uint32_t f = (uint32_t)(mix64(key + ((uint64_t)round << 56) + r) >> 32) & mask;
-            const uint32_t t = l ^ f;
-            l = r;
-            r = t;
-        }
-        x = (l << h) | r;
-    } while (x >= n);
-    return x;
-}
-
-struct DrawArgs {
-    const int32_t *class_ptr, *class_pix, *out_off;
-    int32_t n_cls, per_class, n_bg, n_uniform, total_pixels;
-    uint64_t seed, counter;
-    int64_t *out;
-};
-
-// the pixel that output position t of the batch holds (t < out_off[n_cls + 1]).  Segment by bisection over out_off (a linear walk is
-// n_cls dependent global loads: 17 us at 33 segments)
-__device__ __forceinline__ int64_t drawn_pixel(const DrawArgs &a, int32_t t) {
-    // the segment table through LDS when it fits (one load latency for the workgroup instead of log2(n_cls) dependent ones per thread)
-    __shared__ int32_t s_off[kDrawLdsCls + 2];
-    const bool staged = a.n_cls <= kDrawLdsCls;
-    if (staged) {
-        for (int i = threadIdx.x; i < a.n_cls + 2; i += kDrawThreads) s_off[i] = a.out_off[i];
-        __syncthreads();
-    }
-    const int32_t *off = staged ? s_off : a.out_off;
-    int lo = 0, hi = a.n_cls;           // the largest c in [0, n_cls] with out_off[c] <= t (empty segments in front of it are skipped)
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (off[mid] <= t) lo = mid; else hi = mid - 1;
-    }
-    const int c = lo;
-    const bool uniform = c == a.n_cls;
-    const int32_t first = uniform ? 0 : a.class_ptr[c];
-    const int32_t n = uniform ? a.total_pixels : a.class_ptr[c + 1] - first;
-    const int32_t quota = uniform ? a.n_uniform : (c == 0 ? a.n_bg : a.per_class);
-    const int32_t i = t - off[c];
-    int32_t pos = i;            // n <= quota: the whole class (ns_dataset.py:422-427); never taken by the uniform half of a real image
-    if (n > quota) pos = (int32_t)perm_index((uint32_t)i, (uint32_t)n, mix64(a.seed ^ mix64(a.counter * 0x100000001b3ull + (uint64_t)c)));
-    return uniform ? (int64_t)pos : (int64_t)a.class_pix[first + pos];
-}
 
 __global__ __launch_bounds__(kDrawThreads) void k_draw_pixels(DrawArgs a, int32_t total) {
     const int32_t t = blockIdx.x * kDrawThreads + threadIdx.x;
@@ -95,7 +32,6 @@ __global__ __launch_bounds__(kDrawThreads) void k_draw_pixels(DrawArgs a, int32_
 
 // the draw and the batch's row gather in one launch: dst_j[t, :] = src_j[pixel(t), :] for the jobs indexed by the drawn pixels (idx == out),
 // dst_j[i, :] = src_j[idx_j[i], :] for the others (the frame's pose row: one row by a one-entry index).  Rows in 4-byte words.
-struct DrawGatherJobs { hsGatherJob j[HS_GATHER_MAX_JOBS]; int32_t n; };
 
 __global__ __launch_bounds__(kDrawThreads) void k_draw_gather(DrawArgs a, int32_t total, DrawGatherJobs jobs) {
     const int32_t t = blockIdx.x * kDrawThreads + threadIdx.x;
@@ -132,6 +68,12 @@ __global__ __launch_bounds__(kDrawThreads) void k_draw_gather(DrawArgs a, int32_
             for (int w = 0; w < words; w++) dst[w] = src[w];
         }
     }
+}
+
+// the scheduled form as a launch of its own (batch_draw.h: draw_gather_sched_body; k_iter_prologue takes the same body along)
+__global__ __launch_bounds__(kDrawThreads) void k_draw_gather_sched(hsDrawSched s, int32_t n_uniform, int32_t total_pixels, int32_t total, int64_t *out,
+                                                                   DrawGatherJobs jobs) {
+    draw_gather_sched_body((int)blockIdx.x, (int)gridDim.x, s, n_uniform, total_pixels, total, out, jobs);
 }
 
 int draw_args(DrawArgs &a, const int32_t *class_ptr, const int32_t *class_pix, const int32_t *out_off, int32_t n_cls, int32_t per_class, int32_t n_bg,
@@ -178,6 +120,28 @@ int hs_draw_gather(const int32_t *class_ptr, const int32_t *class_pix, const int
     }
     if (most == 0) return HS_OK;
     k_draw_gather<<<(unsigned)((most + kDrawThreads - 1) / kDrawThreads), kDrawThreads, 0, (hipStream_t)stream>>>(a, n_out, gj);
+    return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
+}
+
+int hs_draw_gather_sched(const hsDrawSched *sched, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *out, const hsGatherJob *jobs,
+                         int32_t n_jobs, void *stream) {
+    if (!sched || !out) return HS_ERR_NULL;
+    if (!sched->frames || !sched->sched || !sched->cursor) return HS_ERR_NULL;
+    if (sched->n_sched < 1 || sched->n_frames < 1 || n_uniform < 0 || total_pixels < 1 || n_out < 0 || n_jobs < 0 || n_jobs > HS_GATHER_MAX_JOBS) return HS_ERR_ARG;
+    if (n_jobs > 0 && !jobs) return HS_ERR_NULL;
+    DrawGatherJobs gj;
+    gj.n = n_jobs;
+    int64_t most = n_out;
+    for (int i = 0; i < n_jobs; i++) {
+        const hsGatherJob &j = jobs[i];
+        if (j.n < 0 || j.row_bytes < 0 || (j.row_bytes & 3)) return HS_ERR_ARG;
+        if (j.n > 0 && !j.dst) return HS_ERR_NULL;           /* src NULL: per frame; idx NULL: the frame's own row */
+        if (j.idx == out && j.n != n_out) return HS_ERR_ARG;
+        gj.j[i] = j;
+        most = j.n > most ? j.n : most;
+    }
+    if (most == 0) return HS_OK;
+    k_draw_gather_sched<<<(unsigned)((most + kDrawThreads - 1) / kDrawThreads), kDrawThreads, 0, (hipStream_t)stream>>>(*sched, n_uniform, total_pixels, n_out, out, gj);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
 }
 

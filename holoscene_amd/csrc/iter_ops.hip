@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "holoscene_hip.h"
+#include "batch_draw.h"
 
 namespace {
 
@@ -88,6 +89,12 @@ struct PrologueArgs {
     hsAdamState *adam;        // tick (NULL: none)
     float beta1, beta2;
     double gamma;
+    // the iteration's batch (batch_draw.h): draw_blocks workgroups in FRONT of the others -- its chain of dependent round trips is the longest
+    // thing in this launch (22 us as a launch of its own); nothing else here reads what it writes
+    int32_t draw_blocks, draw_uniform, draw_pixels, draw_total;
+    int64_t *draw_out;
+    hsDrawSched draw;
+    DrawGatherJobs draw_jobs;
 };
 
 __device__ __forceinline__ void adam_tick_device(hsAdamState *st, float beta1, float beta2, double gamma) {       // optim.hip: k_adam_tick
@@ -105,7 +112,11 @@ __device__ __forceinline__ void adam_tick_device(hsAdamState *st, float beta1, f
 }
 
 __global__ __launch_bounds__(256) void k_iter_prologue(PrologueArgs a) {
-    const int b = blockIdx.x;
+    if ((int)blockIdx.x < a.draw_blocks) {
+        draw_gather_sched_body((int)blockIdx.x, a.draw_blocks, a.draw, a.draw_uniform, a.draw_pixels, a.draw_total, a.draw_out, a.draw_jobs);
+        return;
+    }
+    const int b = (int)blockIdx.x - a.draw_blocks;
     if (b < a.wn_blocks) {
         wn_row<false>(a.wn, b * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
@@ -208,9 +219,11 @@ int fill_wn(WnJobsI &wj, const hsWnJob *jobs, int32_t n_jobs, bool backward, int
 
 extern "C" {
 
-int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
-                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
-                     int64_t n_zero, void *stream) {
+int hs_iter_prologue_draw(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
+                          const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
+                          int64_t n_zero, const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out,
+                          const hsGatherJob *gather, int32_t n_gather, void *stream) {
+    static_assert(kDrawThreads == 256, "the draw's workgroups ride in a 256-thread launch");
     PrologueArgs a;
     int rows = 0;
     const int rc = fill_wn(a.wn, jobs, n_jobs, false, rows);
@@ -225,11 +238,36 @@ int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64
     a.pool = rng_pool; a.n_pool = n_rng; a.rng_state = rng_state;
     a.beta = beta; a.beta_min = beta_min; a.beta_out = beta_out; a.n_beta = n_beta;
     a.adam = adam; a.beta1 = beta1; a.beta2 = beta2; a.gamma = gamma;
+    a.draw_blocks = 0;
+    if (draw) {     /* hs_draw_gather_sched's arguments and checks */
+        if (!draw->frames || !draw->sched || !draw->cursor || !draw_out) return HS_ERR_NULL;
+        if (draw->n_sched < 1 || draw->n_frames < 1 || n_uniform < 0 || total_pixels < 1 || n_out < 0 || n_gather < 0 || n_gather > HS_GATHER_MAX_JOBS) return HS_ERR_ARG;
+        if (n_gather > 0 && !gather) return HS_ERR_NULL;
+        a.draw = *draw; a.draw_uniform = n_uniform; a.draw_pixels = total_pixels; a.draw_total = n_out; a.draw_out = draw_out;
+        a.draw_jobs.n = n_gather;
+        int64_t most = n_out;
+        for (int i = 0; i < n_gather; i++) {
+            const hsGatherJob &j = gather[i];
+            if (j.n < 0 || j.row_bytes < 0 || (j.row_bytes & 3)) return HS_ERR_ARG;
+            if (j.n > 0 && !j.dst) return HS_ERR_NULL;
+            if (j.idx == draw_out && j.n != n_out) return HS_ERR_ARG;
+            a.draw_jobs.j[i] = j;
+            most = j.n > most ? j.n : most;
+        }
+        a.draw_blocks = (int32_t)((most + kDrawThreads - 1) / kDrawThreads);
+    }
     const bool tail = n_beta > 0 || adam != nullptr;
-    const int grid = a.wn_blocks + a.rng_blocks + a.zero_blocks + (tail ? 1 : 0);
+    const int grid = a.draw_blocks + a.wn_blocks + a.rng_blocks + a.zero_blocks + (tail ? 1 : 0);
     if (grid == 0) return HS_OK;
     k_iter_prologue<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_LAUNCH;
+}
+
+int hs_iter_prologue(const hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
+                     const float *beta_min, float *beta_out, int32_t n_beta, hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
+                     int64_t n_zero, void *stream) {
+    return hs_iter_prologue_draw(jobs, n_jobs, rng_pool, n_rng, rng_state, beta, beta_min, beta_out, n_beta, adam, beta1, beta2, gamma, zero, n_zero, nullptr, 0, 0,
+                                 0, nullptr, nullptr, 0, stream);
 }
 
 int hs_iter_epilogue(const hsWnJob *jobs, int32_t n_jobs, const float *beta, const float *const *g_beta_parts, const int32_t *part_len,

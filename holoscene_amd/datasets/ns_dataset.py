@@ -20,7 +20,7 @@ import random
 import numpy as np
 import torch
 
-from .pixel_sampler import PixelSampler
+from .pixel_sampler import DeviceSchedule, FrameQueue, PixelSampler, ScheduledDraw
 
 
 def rank_seed(seed, rank=None):
@@ -63,6 +63,8 @@ class ResidentNSDataset:
         self._sampler = PixelSampler(self._class_pixels, self.total_pixels, num_pixels, dev, seed=seed)
         self._fidx = torch.arange(self.n_images, dtype=torch.int64, device=dev)      # per-frame index rows for write_batch's gather plans (no host->device copy in the loop)
         self._plans = {}
+        self._frames = FrameQueue(lambda: self.pick_frame())     # the frames of the next batches, in the order every path takes them
+        self._schedule = None
 
     @classmethod
     def from_reference(cls, ds, num_pixels, device="cuda", **kw):
@@ -102,15 +104,37 @@ class ResidentNSDataset:
         return torch.tensor([frame]), sample, gt
 
     def next_batch(self):
-        frame = self.pick_frame()
+        frame = self._frames.take()
         idx, n = self._sampler.draw(frame)
         return self.get(frame, idx[:n])
+
+    def peek_batch(self):
+        """next_batch() without consuming it: the next draw -- by any path -- yields the same batch again."""
+        c = self._sampler._counter
+        out = self.next_batch()
+        self._frames.untake(int(out[0][0]))
+        self._sampler._counter = c
+        return out
+
+    def scheduled_draw(self, dst_input, dst_gt):
+        """The draw + gather of write_batch() as a launch whose arguments live on the device (pixel_sampler.py: DeviceSchedule / ScheduledDraw) --
+        a node of the training graph -- or None when a frame's rule yields fewer rays than the block holds (ns_dataset.py:422-427)."""
+        if self.device.type != "cuda" or any(self._sampler.count(f) != dst_input["uv"].shape[1] for f in range(self.n_images)):
+            return None
+        idx = self._sampler.idx
+        per = lambda t: [t[f] for f in range(self.n_images)]  # noqa: E731
+        jobs = [(self.uv_all, dst_input["uv"], idx), (self.pose_all, dst_input["pose"], None), (self.intrinsics_all, dst_input["intrinsics"], None),
+                (per(self.rgb), dst_gt["rgb"], idx), (per(self.depth), dst_gt["depth"], idx), (per(self.normal), dst_gt["normal"], idx),
+                (per(self.mask), dst_gt["mask"], idx), (per(self.segs), dst_gt["segs"], idx)]
+        if self._schedule is None:
+            self._schedule = DeviceSchedule(self._sampler, self._frames)
+        return ScheduledDraw(self, self._schedule, jobs)
 
     def write_batch(self, dst_input, dst_gt):
         """The next batch gathered straight into existing buffers (the training graph's static input block): one launch for the draw
         and the gather together."""
         from ..hashencoder import backend as _be
-        frame = self.pick_frame()
+        frame = self._frames.take()
         n = self._sampler.count(frame)
         if n != dst_input["uv"].shape[1]:
             self._sampler.skip()

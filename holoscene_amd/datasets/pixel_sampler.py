@@ -10,6 +10,8 @@ draw per iteration, as the reference has it -- nothing is ever served twice.
 On a CPU device (tests) the same rule runs on the host with a torch.Generator.  The reference's own permutations stay injectable
 (`host_indices(frame, draws=...)`) for the parity fixtures.
 """
+import collections
+
 import torch
 
 
@@ -93,3 +95,86 @@ class PixelSampler:
         _be._backend.draw_pixels(ptr, pix, off, n_cls, per_class, n_bg, self.R - self.half, self.total, self._seed, self._counter, self.idx,
                                  n_out=n, gather=gather)
         return self.idx, n
+
+
+class DeviceSchedule:
+    """What the batch draw needs when it runs as a NODE OF THE TRAINING GRAPH (csrc/batch_ops.hip: hs_draw_gather_sched).  A launch between two graph
+    replays leaves the chip idle around it (~14 us per iteration at configs[1], profiles/r06); inside the graph its arguments cannot come from the
+    host, so they live on the device: a ring `sched` of the frames of the next batches and the batch number `cursor`, which the launch itself advances.
+    ONE schedule per dataset, shared by the launch plans of all its destination blocks (the graph variants of a trainer).
+    Batch number b = the sampler's counter before the draw, the draw's own counter b + 1: a batch is the same batch whichever path draws it, and the
+    frames come from ONE queue (`frames`) that the eager paths consume too -- interleaving them walks one sequence.
+
+    Host protocol around a replay of a graph that contains a ScheduledDraw.launch(): before_replay() (ring covers the batch, cursor holds its number: a
+    host->device copy only every `n_sched` batches, or after an eager draw moved the counter), after_replay() (bookkeeping).  resync(): the device cursor
+    moved without the host's bookkeeping (the warm-up passes of a capture)."""
+
+    def __init__(self, sampler, frames, n_sched=512):
+        self.sampler, self.frames, self.n = sampler, frames, int(n_sched)
+        dev = sampler.device
+        self.sched = torch.zeros(self.n, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.lo = self.hi = 0           # the ring holds the frames of batches [lo, hi)
+        self.cursor_at = None           # the batch number the device cursor is known to hold
+
+    def before_replay(self):
+        b = self.sampler._counter
+        if not (self.lo <= b < self.hi):
+            q = self.frames.queue
+            while len(q) < self.n:
+                q.append(self.frames.pick())
+            ring = [0] * self.n
+            for i in range(self.n):
+                ring[(b + i) % self.n] = q[i]
+            self.sched.copy_(torch.tensor(ring, dtype=torch.int32))     # (stream-ordered behind every replay that read the old content)
+            self.lo, self.hi = b, b + self.n
+        if self.cursor_at != b:
+            self.cursor.copy_(torch.tensor([b, 0], dtype=torch.int64))
+            self.cursor_at = b
+
+    def after_replay(self):
+        self.frames.take()
+        self.sampler._counter += 1
+        self.cursor_at += 1
+
+    def resync(self):
+        self.cursor_at = None
+
+
+class ScheduledDraw:
+    """The draw + gather of one destination block as a launch driven by a DeviceSchedule.  jobs: (src | per-frame list of src, dst, idx | None)."""
+
+    def __init__(self, dataset, schedule, jobs):
+        from ..hashencoder import backend as _be
+        self.dataset, self.schedule = dataset, schedule
+        sampler = schedule.sampler
+        descs = []
+        for f, (ptr, pix, off, n) in enumerate(sampler._device_frames()):
+            n_cls, per_class, n_bg = sampler.quotas(f)
+            descs.append((ptr, pix, off, n_cls, per_class, n_bg))
+        self.plan = _be._backend.draw_sched_plan(descs, jobs, sampler.idx, schedule.sched, schedule.cursor, sampler._seed, 1)
+        self.before_replay, self.after_replay, self.resync = schedule.before_replay, schedule.after_replay, schedule.resync
+
+    def launch(self):
+        from ..hashencoder import backend as _be
+        _be._backend.draw_gather_sched(*self.args())
+
+    def args(self):
+        """(plan, n_uniform, total_pixels, n_out): what hs_draw_gather_sched takes -- or hs_iter_prologue_draw, which takes this draw along
+        (backend.iter_prologue(draw=...))."""
+        s = self.schedule.sampler
+        return self.plan, s.R - s.half, s.total, s.R
+
+
+class FrameQueue:
+    """The frames of the next batches in the order every path takes them: `take()` = the frame of the next batch (picked now unless a
+    ScheduledDraw already picked ahead to fill its device ring)."""
+
+    def __init__(self, pick):
+        self.pick, self.queue = pick, collections.deque()
+
+    def take(self):
+        return self.queue.popleft() if self.queue else self.pick()
+
+    def untake(self, frame):
+        self.queue.appendleft(frame)

@@ -86,6 +86,19 @@ class hsGatherJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("n", ctypes.c_int64), ("row_bytes", ctypes.c_int32)]
 
 
+GATHER_MAX_JOBS = 12        # HS_GATHER_MAX_JOBS
+
+
+class hsFrameDesc(ctypes.Structure):
+    _fields_ = [("class_ptr", ctypes.c_void_p), ("class_pix", ctypes.c_void_p), ("out_off", ctypes.c_void_p), ("n_cls", ctypes.c_int32),
+                ("per_class", ctypes.c_int32), ("n_bg", ctypes.c_int32), ("reserved", ctypes.c_int32), ("src", ctypes.c_void_p * GATHER_MAX_JOBS)]
+
+
+class hsDrawSched(ctypes.Structure):
+    _fields_ = [("frames", ctypes.c_void_p), ("sched", ctypes.c_void_p), ("cursor", ctypes.c_void_p), ("seed", ctypes.c_uint64),
+                ("counter_base", ctypes.c_uint64), ("n_sched", ctypes.c_int32), ("n_frames", ctypes.c_int32)]
+
+
 ABI_VERSION = 9
 
 # Small zero-initialised accumulators (bias-gradient sums the backward kernels add to by atomics): slices of a pool the optimiser zeroes
@@ -156,7 +169,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_iter_prologue", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_gy_split", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_draw_gather_sched", "hs_iter_prologue", "hs_iter_prologue_draw", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_gy_split", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -794,9 +807,10 @@ class _HipBackend:
         return outs
 
     @staticmethod
-    def iter_prologue(vs, gs, rng_pool=None, rng_state=None, beta=None, beta_min=None, adam=None, zero=None):
+    def iter_prologue(vs, gs, rng_pool=None, rng_state=None, beta=None, beta_min=None, adam=None, zero=None, draw=None):
         """hs_iter_prologue: the weight-normalised matrices of (vs, gs), the pool of U[0, 1) draws, |beta| + beta_min and the optimiser tick in
-        one launch.  adam: None or (state uint8 tensor, beta1, beta2, gamma).  -> (Ws, beta_eff or None)"""
+        one launch.  adam: None or (state uint8 tensor, beta1, beta2, gamma).  draw: None or (draw_sched_plan(), n_uniform, total_pixels, n_out) --
+        the iteration's batch drawn and gathered by the same launch (hs_iter_prologue_draw).  -> (Ws, beta_eff or None)"""
         lib = load_library()
         arr = (hsWnJob * max(len(vs), 1))()
         outs = []
@@ -806,11 +820,16 @@ class _HipBackend:
             outs.append(W)
         beta_out = torch.empty_like(beta) if beta is not None else None
         st, b1, b2, gamma = adam if adam is not None else (None, 0.0, 0.0, 1.0)
-        _check(lib.hs_iter_prologue(arr, len(vs), _dev(rng_pool, "rng_pool"), ctypes.c_int64(0 if rng_pool is None else rng_pool.numel()),
-                                    _dev(rng_state, "rng_state", torch.int64), _dev(beta, "beta"), _dev(beta_min, "beta_min"), _dev(beta_out, "beta_out"),
-                                    0 if beta is None else beta.numel(), _dev(st, "adam state", torch.uint8), ctypes.c_float(b1), ctypes.c_float(b2),
-                                    ctypes.c_double(gamma), _dev(zero, "zero"), ctypes.c_int64(0 if zero is None else zero.numel()), _stream()),
-               "hs_iter_prologue")
+        head = (arr, len(vs), _dev(rng_pool, "rng_pool"), ctypes.c_int64(0 if rng_pool is None else rng_pool.numel()),
+                _dev(rng_state, "rng_state", torch.int64), _dev(beta, "beta"), _dev(beta_min, "beta_min"), _dev(beta_out, "beta_out"),
+                0 if beta is None else beta.numel(), _dev(st, "adam state", torch.uint8), ctypes.c_float(b1), ctypes.c_float(b2),
+                ctypes.c_double(gamma), _dev(zero, "zero"), ctypes.c_int64(0 if zero is None else zero.numel()))
+        if draw is None:
+            _check(lib.hs_iter_prologue(*head, _stream()), "hs_iter_prologue")
+        else:
+            (dst, darr, n_jobs, keep), n_uniform, total_pixels, n_out = draw
+            _check(lib.hs_iter_prologue_draw(*head, ctypes.byref(dst), int(n_uniform), int(total_pixels), int(n_out), _dev(keep[3], "out", torch.int64), darr,
+                                             n_jobs, _stream()), "hs_iter_prologue_draw")
         return outs, beta_out
 
     @staticmethod
@@ -864,6 +883,54 @@ class _HipBackend:
             _check(lib.hs_draw_pixels(*args, _stream()), "hs_draw_pixels")
         else:
             _check(lib.hs_draw_gather(*args, gather[0], gather[1], _stream()), "hs_draw_gather")
+
+    @staticmethod
+    def draw_sched_plan(frames, jobs, out, sched, cursor, seed, counter_base):
+        """A reusable description of hs_draw_gather_sched (the batch draw as a node of the iteration's graph; include/holoscene_hip.h: hsDrawSched).
+        frames: per frame (class_ptr, class_pix, out_off, n_cls, per_class, n_bg) as draw_pixels takes them; jobs: (src, dst, idx) with src a
+        tensor or a LIST of per-frame tensors, idx the drawn-index tensor `out`, another int64 index tensor, or None (= the frame's own row);
+        sched int32 [n_sched], cursor int64 [2] device tensors.  The plan keeps every tensor alive."""
+        if len(jobs) > GATHER_MAX_JOBS:
+            raise RuntimeError("draw_sched_plan: too many gather jobs")
+        dev = out.device
+        arr = (hsGatherJob * len(jobs))()
+        descs = (hsFrameDesc * len(frames))()
+        for f, (ptr, pix, off, n_cls, per_class, n_bg) in enumerate(frames):
+            d = descs[f]
+            d.class_ptr, d.class_pix, d.out_off = _dev(ptr, "class_ptr", torch.int32).value, _dev(pix, "class_pix", torch.int32).value, _dev(off, "out_off", torch.int32).value
+            d.n_cls, d.per_class, d.n_bg = int(n_cls), int(per_class), int(n_bg)
+        for q, (a, (src, dst, idx)) in enumerate(zip(arr, jobs)):
+            per_frame = isinstance(src, (list, tuple))
+            srcs = list(src) if per_frame else [src]
+            if per_frame and len(srcs) != len(frames):
+                raise RuntimeError("draw_sched_plan: one source per frame expected")
+            for t in srcs + [dst] + ([] if idx is None else [idx]):
+                if not (t.is_cuda and t.is_contiguous()):
+                    raise RuntimeError("draw_sched_plan: contiguous CUDA tensors expected")
+            s0 = srcs[0]
+            row = (s0.numel() // s0.shape[0]) * s0.element_size()
+            n = dst.numel() * dst.element_size() // row
+            if row % 4 or dst.numel() * dst.element_size() != n * row or any(t.dtype != dst.dtype or (t.numel() // t.shape[0]) * t.element_size() != row for t in srcs):
+                raise RuntimeError("draw_sched_plan: dst must hold whole rows of src's row size (a multiple of 4 bytes), one dtype")
+            if idx is not None and (idx.dtype != torch.int64 or idx.numel() != n):
+                raise RuntimeError("draw_sched_plan: idx must be int64 with one entry per destination row")
+            a.src = None if per_frame else s0.data_ptr()
+            a.dst, a.idx, a.n, a.row_bytes = dst.data_ptr(), (None if idx is None else idx.data_ptr()), n, row
+            if per_frame:
+                for f, t in enumerate(srcs):
+                    descs[f].src[q] = t.data_ptr()
+        frames_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        st = hsDrawSched()
+        st.frames, st.sched, st.cursor = frames_dev.data_ptr(), _dev(sched, "sched", torch.int32).value, _dev(cursor, "cursor", torch.int64).value
+        st.seed, st.counter_base, st.n_sched, st.n_frames = int(seed) & (2 ** 64 - 1), int(counter_base) & (2 ** 64 - 1), sched.numel(), len(frames)
+        return (st, arr, len(jobs), (frames_dev, frames, jobs, out, sched, cursor))
+
+    @staticmethod
+    def draw_gather_sched(plan, n_uniform, total_pixels, n_out):
+        lib = load_library()
+        st, arr, n_jobs, keep = plan
+        _check(lib.hs_draw_gather_sched(ctypes.byref(st), int(n_uniform), int(total_pixels), int(n_out), _dev(keep[3], "out", torch.int64), arr, n_jobs, _stream()),
+               "hs_draw_gather_sched")
 
     # ---- reverse-over-reverse trunk of the rendered samples (csrc/trunk_rr.hip, csrc/wgrad_pairs.hip)
     @staticmethod

@@ -1460,12 +1460,12 @@ class _iter_prologue(torch.autograd.Function):
     have them (flat_grad_view): no multi-tensor copy afterwards."""
 
     @staticmethod
-    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, zero, *vg):
+    def forward(ctx, beta, beta_min, rng_pool, rng_state, adam, relay, zero, draw, *vg):
         ctx.set_materialize_grads(False)
         vs = [t.detach().float().contiguous() for t in vg[0::2]]
         gs = [t.detach().float().contiguous() for t in vg[1::2]]
         b = beta.detach().float().reshape(-1).contiguous()
-        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam, zero)
+        Ws, beta_eff = _be._backend.iter_prologue(vs, gs, rng_pool, rng_state, b, beta_min.detach().float().reshape(-1).contiguous(), adam, zero, draw)
         ctx.save_for_backward(b, *vs, *gs)
         ctx.n, ctx.relay, ctx.beta_shape = len(vs), relay, beta.shape
         ctx.params = (beta,) + tuple(vg)
@@ -1492,21 +1492,25 @@ class _iter_prologue(torch.autograd.Function):
             gb = gb.view(ctx.beta_shape)
         else:
             _be._backend.iter_epilogue(list(vs), list(gs), gWs, outs)
-        return (gb, None, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
+        return (gb, None, None, None, None, None, None, None) + tuple(t for pair in outs for t in pair)
 
 
 @contextlib.contextmanager
-def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
+def iteration_prologue(model, flat=None, rng_sizes=None, zero=None, draw=None):
     """One launch for everything a Stage-1 iteration needs before its first ray: within the block model.density.get_beta() and
     effective_weights() return the tensors evaluated here (as under density.shared_beta() + shared_effective_weights()), `flat`'s Adam
     state is ticked (training/flat.py: FlatAdam -- its step() then skips the tick launch), and the block yields the `rng` dictionary of
-    model.draw_uniforms (views of one pool of U[0, 1) draws from the model's own device-resident Philox stream).  Enter with grad enabled."""
+    model.draw_uniforms (views of one pool of U[0, 1) draws from the model's own device-resident Philox stream).  Enter with grad enabled.
+    draw: a datasets.pixel_sampler.ScheduledDraw -- the iteration's batch, drawn and gathered by the same launch (as a launch of its own where this
+    model takes the fallback below)."""
     lins = [l for l in model.weight_norm_layers() if isinstance(l, WNLinear) and l.weight_v.is_cuda]
     dens = model.density
     dev = dens.beta.device
     if not lins or dev.type != "cuda" or dens.beta.dtype != torch.float32:
         if zero is not None:        # FlatAdam.zero_grad(defer=True) left this range to the prologue launch: the fallback must clear it itself
             zero.zero_()
+        if draw is not None:
+            draw.launch()
         with dens.shared_beta(), shared_effective_weights(model.weight_norm_layers()):
             yield None
         return
@@ -1519,7 +1523,7 @@ def iteration_prologue(model, flat=None, rng_sizes=None, zero=None):
         adam = (flat.state, flat.betas[0], flat.betas[1], flat.gamma)
     relay = {"key": None, "parts": [], "users": 0}
     outs = _iter_prologue.apply(dens.beta, dens.beta_min, pool, model.rng_state(dev) if pool is not None else None, adam, relay, zero,
-                                *[t for l in lins for t in (l.weight_v, l.weight_g)])
+                                None if draw is None else draw.args(), *[t for l in lins for t in (l.weight_v, l.weight_g)])
     if adam is not None:
         flat._ticked = True
     beta_eff, Ws = outs[0], outs[1:]

@@ -15,7 +15,7 @@ import random
 import numpy as np
 import torch
 
-from ..datasets.pixel_sampler import PixelSampler
+from ..datasets.pixel_sampler import DeviceSchedule, FrameQueue, PixelSampler, ScheduledDraw
 
 
 def look_at_pose(eye, target=(0.0, 0.0, 0.0)):
@@ -57,7 +57,8 @@ class SyntheticScene:
         self._class_pixels = [torch.nonzero(self.segs.cpu().reshape(-1) == c).reshape(-1) for c in range(num_classes)]
         self._sampler = PixelSampler([self._class_pixels] * num_frames, npix, num_rays, self.device, seed=seed)
         self._py = random.Random(seed)
-        self._plans, self._const_done = {}, set()
+        self._frames = FrameQueue(lambda: self._py.randint(0, self.F - 1))      # ns_dataset.py:383
+        self._plans, self._const_done, self._schedule = {}, set(), None
         self._fidx = torch.arange(num_frames, dtype=torch.int64, device=self.device)
         self._fixed, self._cursor = None, 0
         if not redraw:      # a fixed set of batches, drawn once on the host
@@ -74,7 +75,7 @@ class SyntheticScene:
             self._cursor += 1
             self._sampler.idx.copy_(idx)
             return f, self._sampler.idx
-        f = self._py.randint(0, self.F - 1)     # ns_dataset.py:383
+        f = self._frames.take()
         idx, _ = self._sampler.draw(f)
         return f, idx
 
@@ -93,7 +94,7 @@ class SyntheticScene:
         from ..hashencoder import backend as _be
         fused = self._fixed is None
         if fused:
-            frame, idx = self._py.randint(0, self.F - 1), self._sampler.idx     # ns_dataset.py:383; the draw itself rides in the gather launch below
+            frame, idx = self._frames.take(), self._sampler.idx     # the draw itself rides in the gather launch below
         else:
             frame, idx = self._next()
         tag = dst_input["uv"].data_ptr()
@@ -104,11 +105,44 @@ class SyntheticScene:
             plan = self._plans[key] = _be._backend.gather_plan([
                 (self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], fidx), (self.rgb[frame], dst_gt["rgb"], idx),
                 (self.depth[frame], dst_gt["depth"], idx), (self.normal[frame], dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)])
-        if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
-            dst_input["intrinsics"].copy_(self.intrinsics)
-            dst_gt["mask"].fill_(1.0)
-            self._const_done.add(tag)
+        self._write_constants(dst_input, dst_gt)
         if fused:
             self._sampler.draw(frame, gather=plan)      # pixel draw + row gather: one launch (csrc/batch_ops.hip: hs_draw_gather)
         else:
             _be._backend.gather_rows(plan)
+
+    def _write_constants(self, dst_input, dst_gt):
+        tag = dst_input["uv"].data_ptr()
+        if tag not in self._const_done:     # per-batch constants of this scene: written once per destination block
+            dst_input["intrinsics"].copy_(self.intrinsics)
+            dst_gt["mask"].fill_(1.0)
+            self._const_done.add(tag)
+
+    def peek_batch(self):
+        """next_batch() without consuming it: the next draw -- by any path -- yields the same batch again."""
+        if self._fixed is not None:
+            cur = self._cursor
+            out = self.next_batch()
+            self._cursor = cur
+            return out
+        c = self._sampler._counter
+        out = self.next_batch()
+        self._frames.untake(int(out[0][0]))
+        self._sampler._counter = c
+        return out
+
+    def scheduled_draw(self, dst_input, dst_gt):
+        """The draw + gather of write_batch() as a launch whose arguments live on the device (datasets/pixel_sampler.py: ScheduledDraw), or None
+        when this scene cannot (fixed batches; a frame whose rule yields fewer rays than the block holds)."""
+        if self._fixed is not None or self.device.type != "cuda":
+            return None
+        if any(self._sampler.count(f) != dst_input["uv"].shape[1] for f in range(self.F)):
+            return None
+        self._write_constants(dst_input, dst_gt)
+        idx = self._sampler.idx
+        per = lambda t: [t[f] for f in range(self.F)]  # noqa: E731
+        jobs = [(self.uv_all, dst_input["uv"], idx), (self.poses, dst_input["pose"], None), (per(self.rgb), dst_gt["rgb"], idx),
+                (per(self.depth), dst_gt["depth"], idx), (per(self.normal), dst_gt["normal"], idx), (self.segs, dst_gt["segs"], idx)]
+        if self._schedule is None:
+            self._schedule = DeviceSchedule(self._sampler, self._frames)
+        return ScheduledDraw(self, self._schedule, jobs)

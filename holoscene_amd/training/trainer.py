@@ -63,13 +63,15 @@ class Stage1Trainer:
     """
 
     def __init__(self, conf, device="cuda", num_images=8, seed=42, world_size=1, rank=0, optimizer="flat", graph=False, zero1=True,
-                 freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None, table_step=None):
+                 freeze_parameters=False, inject_draws=False, data_parallel=None, exchange=None, table_step=None, draw_in_graph=True):
         """data_parallel: run the gradient exchange (default: world_size > 1; True with a one-rank process group exercises the
         collectives' code path on a single GPU).  exchange: "overlap" (default; env HOLOSCENE_EXCHANGE) = ZeRO-1 per segment with
         each hash table's segment exchanged on a side stream as soon as its gradient is final, collectives captured inside the
         iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph.
         table_step: reduce-and-step of the hash tables (below); None = on unless HOLOSCENE_TABLE_STEP=0.  False gives the optimiser
-        path every data-parallel rank runs (zero-fill, scatter into the gradient tables, Adam sweep) in a single process."""
+        path every data-parallel rank runs (zero-fill, scatter into the gradient tables, Adam sweep) in a single process.
+        draw_in_graph: train_step_resident() captures the batch draw as the first node of the iteration's graph when the dataset offers
+        scheduled_draw() (False: one launch in front of every replay -- the A/B of profiles/r06)."""
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
@@ -114,6 +116,8 @@ class Stage1Trainer:
         self.add_objectvio_iter = conf.get_int("train.add_objectvio_iter", default=100000)
         self.iter_step = 0
         self._graphs = {}
+        self.draw_in_graph = bool(draw_in_graph)
+        self._capture_dataset = None    # the dataset whose scheduled draw the graph being captured takes in (train_step_resident)
         # Reduce-and-step (csrc/hash_encode.hip: k_hash_bin_step): in the variants of the whole-iteration graph in which every hash
         # table has ONE gradient producer (all but the background-patch iterations), the tables take their Adam step inside that
         # scatter's reduction; the gradient tables are then never zero-filled, written or read.  HOLOSCENE_TABLE_STEP=0: off (A/B).
@@ -321,7 +325,8 @@ class Stage1Trainer:
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
         sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1])
-        with _net.iteration_prologue(model, tick, sizes, zero=zero) as drawn:
+        # (st["draw"]: the batch itself, drawn and gathered into st["input"] / st["gt"] by that same launch -- train_step_resident)
+        with _net.iteration_prologue(model, tick, sizes, zero=zero, draw=st.get("draw")) as drawn:
             with torch.no_grad():
                 if "rng" in st:     # injected draws (static tensors the caller overwrites before each replay)
                     rng = st["rng"]
@@ -443,8 +448,11 @@ class Stage1Trainer:
     def _train_step_full_graph(self, model_input, ground_truth, rng=None, depths=None):
         self.model.train()
         with_bg = self.model.wants_background(self.iter_step)
-        key = ("full", with_bg, self.iter_step >= self.add_objectvio_iter)
-        entry = self._graphs.get(key)
+        base = ("full", with_bg, self.iter_step >= self.add_objectvio_iter)
+        ds = self._capture_dataset if (rng is None and depths is None) else None      # train_step_resident: a graph that draws its own batches is wanted
+        entry = self._sched_entry(base, ds) if ds is not None else None
+        if entry is None:
+            entry = self._graphs.get(base)
         if rng is not None:
             rng = self._flatten_draws(rng, self.device, self.model.ray_sampler.N_samples_extra)
         if entry is None:
@@ -453,37 +461,75 @@ class Stage1Trainer:
                 st["rng"] = rng       # freshly made device tensors: they become the static block
             if depths is not None:
                 st["depths"] = {k: v.to(self.device).clone() for k, v in depths.items()}
-            self._warm_up(lambda: self._full_body(st, key[1], key[2]))
+            sd = ds.scheduled_draw(st["input"], st["gt"]) if ds is not None else None      # None: this dataset cannot (the batch stays a launch of its own)
+            if sd is not None:
+                st["draw"] = sd
+                sd.before_replay()          # the warm-up passes below launch the draw eagerly: ring and cursor must be in place
+            self._warm_up(lambda: self._full_body(st, base[1], base[2]))
+            if sd is not None:
+                sd.resync()                 # (they advanced the device's batch number: the next before_replay() puts it back)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
-                out, loss_out = self._full_body(st, key[1], key[2])
-            entry = {"graph": g, "static": st, "out": out, "loss": loss_out, "rounds": self.model.ray_sampler._rounds}
-            self._graphs[key] = entry
+                out, loss_out = self._full_body(st, base[1], base[2])
+            entry = {"graph": g, "static": st, "out": out, "loss": loss_out, "rounds": self.model.ray_sampler._rounds, "sched": sd}
+            self._graphs[base + ("sched",) if sd is not None else base] = entry
         st = entry["static"]
-        dl = [st["input"][k] for k in model_input] + [st["gt"][k] for k in ground_truth]
-        sl = list(model_input.values()) + list(ground_truth.values())
-        torch._foreach_copy_(dl, sl)
+        sd = entry.get("sched")
+        if sd is not None:      # the graph draws its own batch: the one the caller peeked at (same batch number, same frame)
+            sd.before_replay()
+        else:
+            dl = [st["input"][k] for k in model_input] + [st["gt"][k] for k in ground_truth]
+            sl = list(model_input.values()) + list(ground_truth.values())
+            torch._foreach_copy_(dl, sl)
+            if ds is not None:  # (peeked, and no graph of its own to draw it: consumed here)
+                ds.next_batch()
         if rng is not None and st["rng"] is not rng:
             self._copy_tree(st["rng"], rng)
         if depths is not None:
             self._copy_tree(st["depths"], {k: v.to(self.device) for k, v in depths.items()})
         entry["graph"].replay()
+        if sd is not None:
+            sd.after_replay()
         self.model.ray_sampler._rounds = entry["rounds"]
         self._after_replay()
         self.iter_step += 1
         return entry["out"], entry["loss"]
 
+    def _sched_entry(self, base, dataset):
+        """The graph of variant `base` that draws its own batches from `dataset` (captured by train_step_resident), or None."""
+        entry = self._graphs.get(base + ("sched",))
+        return entry if entry is not None and entry["sched"].dataset is dataset else None
+
     def train_step_resident(self, dataset):
         """One iteration on a device-resident dataset (anything with next_batch() -> (indices, model_input, ground_truth) and
         write_batch(dst_input, dst_gt)): once the whole-iteration graph of the variant exists, the batch is gathered straight into
-        its static input block -- no intermediate batch tensors, no copies -- and the graph is replayed."""
+        its static input block -- no intermediate batch tensors, no copies -- and the graph is replayed.
+        A dataset that also offers scheduled_draw() / peek_batch() (datasets/pixel_sampler.py: DeviceSchedule) has the draw captured as the graph's
+        FIRST NODE (graphs keyed (..., "sched")): an iteration is then one graph launch and nothing else on the stream -- a launch between two
+        replays left the chip idle for ~14 us around it."""
         if self.use_graph and hasattr(dataset, "write_batch") and self._full_graph_ok():
-            with_bg = self.model.wants_background(self.iter_step)
-            entry = self._graphs.get(("full", with_bg, self.iter_step >= self.add_objectvio_iter))
+            base = ("full", self.model.wants_background(self.iter_step), self.iter_step >= self.add_objectvio_iter)
+            sched_ok = self.draw_in_graph and hasattr(dataset, "scheduled_draw") and hasattr(dataset, "peek_batch")
+            entry = self._sched_entry(base, dataset) if sched_ok else None
             if entry is not None:
+                sd = entry["sched"]
                 self.model.train()
-                dataset.write_batch(entry["static"]["input"], entry["static"]["gt"])
+                sd.before_replay()
                 entry["graph"].replay()
+                sd.after_replay()
+            else:
+                entry = self._graphs.get(base)
+                if entry is not None:
+                    self.model.train()
+                    dataset.write_batch(entry["static"]["input"], entry["static"]["gt"])
+                    entry["graph"].replay()
+                elif sched_ok and base + ("sched",) not in self._graphs:
+                    self._capture_dataset = dataset         # the capture takes the draw in; its first replay draws the batch peeked at here
+                    try:
+                        return self.train_step(*dataset.peek_batch())
+                    finally:
+                        self._capture_dataset = None
+            if entry is not None:
                 self.model.ray_sampler._rounds = entry["rounds"]
                 self._after_replay()
                 self.iter_step += 1

@@ -797,6 +797,33 @@ int hs_draw_gather(const int32_t *class_ptr, const int32_t *class_pix, const int
                    int32_t n_uniform, int32_t total_pixels, int32_t n_out, uint64_t seed, uint64_t counter, int64_t *out,
                    const struct hsGatherJob *jobs, int32_t n_jobs, void *stream);
 
+/* The same launch driven from DEVICE memory, so that it can be a node of the training iteration's graph (an eager launch between two graph
+ * replays costs the chip ~14 us of idle around it): batch number b = cursor[0]; frame f = sched[b % n_sched]; the frame's class lists and
+ * per-frame sources come from frames[f]; the draw's counter is counter_base + b.  The last workgroup to finish stores cursor[0] = b + 1
+ * (cursor[1] is its ticket: zero before the first launch, left zero).  jobs as hs_draw_gather's, with two extensions: jobs[j].src == NULL takes
+ * frames[f].src[j]; jobs[j].idx == NULL gathers row f for every i < n (the frame's pose / intrinsics row).  Every frame must yield n_out rays. */
+typedef struct hsFrameDesc {
+    const int32_t *class_ptr, *class_pix, *out_off;
+    int32_t n_cls, per_class, n_bg, reserved;
+    const void *src[HS_GATHER_MAX_JOBS];
+} hsFrameDesc;
+typedef struct hsDrawSched {
+    const hsFrameDesc *frames;      /* [n_frames] device array */
+    const int32_t *sched;           /* [n_sched] frame of batch b at b % n_sched; the host refills it in stream order */
+    uint64_t *cursor;               /* [2]: next batch number | ticket */
+    uint64_t seed, counter_base;
+    int32_t n_sched, n_frames;
+} hsDrawSched;
+int hs_draw_gather_sched(const hsDrawSched *sched, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *out,
+                         const struct hsGatherJob *jobs, int32_t n_jobs, void *stream);
+/* hs_iter_prologue with hs_draw_gather_sched(draw, n_uniform, total_pixels, n_out, draw_out, gather, n_gather) riding in the same launch, its workgroups
+ * first (draw == NULL: exactly hs_iter_prologue).  Nothing in the prologue reads what the draw writes; as a launch of its own the draw is 22 us of
+ * dependent round trips on four workgroups. */
+int hs_iter_prologue_draw(const struct hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
+                          const float *beta_min, float *beta_out, int32_t n_beta, struct hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
+                          int64_t n_zero, const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out,
+                          const struct hsGatherJob *gather, int32_t n_gather, void *stream);
+
 /* ------------------------------------------------------------------ 8. fused network-input builders
  *
  * Positional encoding (model/embedder.py:11-36, order [v, sin 2^0 v, cos 2^0 v, sin 2^1 v, ...]) and concatenation
