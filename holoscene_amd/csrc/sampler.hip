@@ -675,14 +675,22 @@ __global__ __launch_bounds__(kWave) void k_ray_setup(const float *__restrict__ u
                                                       float *__restrict__ cam_loc, float *__restrict__ depth_scale, float *__restrict__ z0,
                                                       float *__restrict__ beta_init, int R, float divide_factor, float *__restrict__ x,
                                                       float *__restrict__ x01, float offset_shift, float *__restrict__ rot_out,
-                                                      float *__restrict__ beta_work) {
+                                                      float *__restrict__ beta_work, const float *__restrict__ patch_u, int patch) {
     extern __shared__ float lds[];  // [S] stratified depths of this ray
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= R) return;
     if (rot_out && r == 0 && lane < 9) rot_out[lane] = pose[4 * (lane % 3) + lane / 3];   // world -> camera: transpose of the pose rotation
     const float fx = intr[0], sk = intr[1], cx = intr[2], fy = intr[5], cy = intr[6];
     const float ox = offset ? offset[2 * r] + offset_shift : 0.f, oy = offset ? offset[2 * r + 1] + offset_shift : 0.f;
-    const float u = uv[2 * r], v = uv[2 * r + 1];
+    float u, v;
+    if (patch_u) {      // ray r of the patch x patch pixel block whose origin the two draws place inside the image (network.py:919-925: randint over
+                        // [0, W - patch] x [0, H - patch], W = 2 cx, H = 2 cy)
+        u = (float)(r % patch) + floorf(patch_u[0] * (floorf(cx * 2.f) - (float)patch + 1.f));
+        v = (float)(r / patch) + floorf(patch_u[1] * (floorf(cy * 2.f) - (float)patch + 1.f));
+    } else {
+        u = uv[2 * r];
+        v = uv[2 * r + 1];
+    }
     // lift (rend_util.py:112-125) at depth 1, then camera-to-world
     const float x1 = u + ox, y1 = v + oy;
     const float xl = (x1 - cx + cy * sk / fy - sk * y1 / fy) / fx, yl = (y1 - cy) / fy;
@@ -877,14 +885,16 @@ int hs_sampler_final(const float *z_samples, int32_t n_s, const float *z, int32_
 
 int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, const float *intrinsics, const float *t_rand, int32_t S, float near,
                  float far_cap, float bound, float eps, float *ray_dirs, float *cam_loc, float *depth_scale, float *z0, float *beta_init, int32_t R,
-                 float divide_factor, float *x, float *x01, float offset_shift, float *rot_out, float *beta_work, void *stream) {
+                 float divide_factor, float *x, float *x01, float offset_shift, float *rot_out, float *beta_work, const float *patch_u, int32_t patch,
+                 void *stream) {
     if (R <= 0) return HS_OK;
     if (S < 2 || S > 4096) return HS_ERR_ARG;
-    if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
+    if ((!uv && !patch_u) || !pose || !intrinsics || !ray_dirs || !cam_loc || !depth_scale || !z0 || !beta_init) return HS_ERR_NULL;
+    if (patch_u && (patch < 1 || patch * patch != R)) return HS_ERR_ARG;
     if (x && (!x01 || divide_factor == 0.f)) return HS_ERR_ARG;
     k_ray_setup<<<dim3(R), dim3(kWave), S * sizeof(float), (hipStream_t)stream>>>(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps,
                                                                                  ray_dirs, cam_loc, depth_scale, z0, beta_init, R, divide_factor, x, x01, offset_shift, rot_out,
-                                                                                 beta_work);
+                                                                                 beta_work, patch_u, patch);
     return check_launch();
 }
 

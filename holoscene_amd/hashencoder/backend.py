@@ -540,13 +540,16 @@ class _HipBackend:
 
     @staticmethod
     def ray_setup(uv, ray_offset, pose, intrinsics, t_rand, S, near, far_cap, bound, eps, ray_dirs, cam_loc, depth_scale, z0, beta_init,
-                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0, rot_out=None, beta_work=None):
+                  divide_factor=1.0, x=None, x01=None, offset_shift=0.0, rot_out=None, beta_work=None, patch_u=None, patch=0):
+        """patch_u (two U[0,1) draws on the device) with uv = None: the rays of the patch x patch pixel block the draws place (hs_ray_setup)."""
         lib = load_library()
+        R = uv.shape[0] if uv is not None else int(patch) * int(patch)
         _check(lib.hs_ray_setup(_dev(uv, "uv"), _dev(ray_offset, "ray_offset"), _dev(pose, "pose"), _dev(intrinsics, "intrinsics"),
                                 _dev(t_rand, "t_rand"), S, ctypes.c_float(near), ctypes.c_float(far_cap), ctypes.c_float(bound),
                                 ctypes.c_float(eps), _dev(ray_dirs, "ray_dirs"), _dev(cam_loc, "cam_loc"), _dev(depth_scale, "depth_scale"),
-                                _dev(z0, "z0"), _dev(beta_init, "beta_init"), uv.shape[0], ctypes.c_float(divide_factor), _dev(x, "x"),
-                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _dev(rot_out, "rot_out"), _dev(beta_work, "beta_work"), _stream()),
+                                _dev(z0, "z0"), _dev(beta_init, "beta_init"), R, ctypes.c_float(divide_factor), _dev(x, "x"),
+                                _dev(x01, "x01"), ctypes.c_float(offset_shift), _dev(rot_out, "rot_out"), _dev(beta_work, "beta_work"),
+                                _dev(patch_u, "patch_u"), int(patch), _stream()),
                "hs_ray_setup")
 
     # ---- value+Jacobian trunk elementwise stages (include/holoscene_hip.h section 4)

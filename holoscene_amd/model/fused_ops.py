@@ -1534,6 +1534,7 @@ def iteration_prologue(model, flat=None, rng_sizes=None, zero=None, draw=None):
             n = int(np.prod(shp))
             rng[k] = pool[off:off + n].view(shp)
             off += n
+        rng = model.nest_draws(rng)
     prev_w, prev_relay, prev_beta, prev_packs, prev_nrm = _SCOPE.shared_w, _SCOPE.beta, dens._shared, _SCOPE.packs, _SCOPE.normals
     _SCOPE.shared_w, _SCOPE.beta, dens._shared = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}, relay, beta_eff
     _SCOPE.packs = model._pack_iteration()

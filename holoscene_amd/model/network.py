@@ -989,12 +989,31 @@ class HoloSceneNetwork(nn.Module):
         out["color_w0"] = c0 if c0 is not mlp[0].weight else None
         return out
 
-    def uniform_sizes(self, num_rays):
-        """Names and shapes of the U[0, 1) draws of one training iteration (draw_uniforms / iteration_prologue)."""
+    BG_PATCH = 32       # side of the background patch (network.py:919-925)
+
+    def uniform_sizes(self, num_rays, with_bg=False):
+        """Names and shapes of the U[0, 1) draws of one training iteration (draw_uniforms / iteration_prologue).  with_bg: also the background
+        patch's -- its origin and its own sampler's draws ("bg.<name>": nested under "bg" in the rng dictionary, nest_draws)."""
         sm = self.ray_sampler
         R = num_rays
-        return {"ray_offset_u": (1, R, 2), "t_rand": (R, sm.N_samples_eval), "u_final": (R, sm.N_samples), "u_pick": (max(sm.N_samples_extra, 1),),
-                "eik_u": (R,), "eik_uniform_u": (R, 3), "eik_jitter": (2 * R, 3)}
+        sizes = {"ray_offset_u": (1, R, 2), "t_rand": (R, sm.N_samples_eval), "u_final": (R, sm.N_samples), "u_pick": (max(sm.N_samples_extra, 1),),
+                 "eik_u": (R,), "eik_uniform_u": (R, 3), "eik_jitter": (2 * R, 3)}
+        if with_bg:
+            P = self.BG_PATCH ** 2
+            sizes.update({"bg_xy_u": (2,), "bg.t_rand": (P, sm.N_samples_eval), "bg.u_final": (P, sm.N_samples), "bg.u_pick": (max(sm.N_samples_extra, 1),),
+                          "bg.eik_u": (P,)})
+        return sizes
+
+    @staticmethod
+    def nest_draws(rng):
+        """{"bg.t_rand": t, ...} -> {"bg": {"t_rand": t, ...}, ...} (the second sampler dictionary of forward()'s rng)."""
+        out = {}
+        for k, v in rng.items():
+            if k.startswith("bg."):
+                out.setdefault("bg", {})[k[3:]] = v
+            else:
+                out[k] = v
+        return out
 
     def rng_state(self, device):
         """Device-resident (seed, counter, scratch) of this model's Philox stream (hs_iter_prologue): seeded once from torch's default CPU
@@ -1007,12 +1026,12 @@ class HoloSceneNetwork(nn.Module):
             st = self._rng_state = torch.tensor([seed, 0, 0], dtype=torch.int64).to(device)
         return st
 
-    def draw_uniforms(self, num_rays, device):
+    def draw_uniforms(self, num_rays, device, with_bg=False):
         """Every U[0,1) draw of one training iteration from ONE generator launch (the reference draws them where it needs them:
         network.py:773 ray offsets, ray_sampler.py:77 stratified jitter, :238 inverse-CDF draws, :269 extra samples, :279
         Eikonal pick, network.py:846-853 Eikonal points): an `rng` dict for prepare_rays / sample / render whose *_u entries are
         raw draws that the consuming kernels shift / scale / quantise themselves."""
-        sizes = self.uniform_sizes(num_rays)
+        sizes = self.uniform_sizes(num_rays, with_bg)
         total = sum(int(np.prod(v)) for v in sizes.values())
         pool = torch.rand(total, device=device)
         rng, off = {}, 0
@@ -1020,7 +1039,7 @@ class HoloSceneNetwork(nn.Module):
             n = int(np.prod(shp))
             rng[k] = pool[off:off + n].view(shp)
             off += n
-        return rng
+        return self.nest_draws(rng)
 
     def prepare_rays(self, input, rng=None):
         rng = rng or {}
@@ -1052,11 +1071,11 @@ class HoloSceneNetwork(nn.Module):
                 "depth_scale": ray_dirs_tmp[0, :, 2:].contiguous(),
                 "rot": pose[0, :3, :3].permute(1, 0).contiguous()}
 
-    def _setup_rays_fused(self, uv, ray_offset, pose, intrinsics, t_rand=None, offset_shift=0.0):
+    def _setup_rays_fused(self, uv, ray_offset, pose, intrinsics, t_rand=None, offset_shift=0.0, patch_u=None):
         """Rays, depth scale, the sampler's first (stratified uniform) depths and its Lemma-2 beta from one kernel
-        (csrc/sampler.hip: k_ray_setup)."""
-        dev = uv.device
-        R = uv.shape[1]
+        (csrc/sampler.hip: k_ray_setup).  patch_u (uv = None): the rays of the BG_PATCH x BG_PATCH pixel block that two U[0, 1) draws place."""
+        dev = pose.device
+        R = uv.shape[1] if uv is not None else self.BG_PATCH ** 2
         sm = self.ray_sampler
         S = sm.N_samples_eval
         if self.training and t_rand is None:
@@ -1066,12 +1085,12 @@ class HoloSceneNetwork(nn.Module):
                "beta_work": torch.empty(R, device=dev),      # a second copy for the sampler to iterate on (taken by the first sample() call)
                "x0": torch.empty(R * S, 3, device=dev), "x0_grid": torch.empty(R * S, 3, device=dev),   # positions of z0: the sampler's first sweep
                "rot": torch.empty(3, 3, device=dev)}          # pose[0, :3, :3]^T, written by the kernel
-        _be._backend.ray_setup(uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
+        _be._backend.ray_setup(None if uv is None else uv[0].contiguous().float(), None if ray_offset is None else ray_offset[0].contiguous().float(),
                                pose[0].contiguous().float(), intrinsics[0].contiguous().float(),
                                None if t_rand is None else t_rand.to(dev).contiguous(), S, float(sm.uniform_sampler.near),
                                float(sm.uniform_sampler.far), float(self.scene_bounding_sphere), float(sm.eps), out["ray_dirs"], out["cam_loc"],
                                out["depth_scale"], out["z0"], out["beta_init"], float(self.implicit_network.divide_factor), out["x0"], out["x0_grid"], offset_shift, out["rot"],
-                               beta_work=out["beta_work"])
+                               beta_work=out["beta_work"], patch_u=None if patch_u is None else patch_u.contiguous().float(), patch=self.BG_PATCH)
         return out
 
     @contextlib.contextmanager
@@ -1107,7 +1126,16 @@ class HoloSceneNetwork(nn.Module):
         rng = rng or {}
         intrinsics, pose = input["intrinsics"], input["pose"]
         dev = pose.device
-        patch = 32
+        patch = self.BG_PATCH
+        from . import ray_sampler as _rs
+        if "bg_xy_u" in rng and "bg_xy0" not in rng and _rs.SAMPLER_IMPL == "hip" and pose.is_cuda and pose.shape[1] != 7:
+            # raw draws from the iteration's pool: the ray kernel places the patch itself (no origin / pixel-grid tensors: ~13 launches less)
+            bg = self._setup_rays_fused(None, None, pose, intrinsics, (rng.get("bg") or {}).get("t_rand"), patch_u=rng["bg_xy_u"])
+            x0 = (bg.pop("x0"), bg.pop("x0_grid"))
+            bg["z_vals"], _ = self.ray_sampler.get_z_vals(bg["ray_dirs"], bg["cam_loc"], self, idx=0, rng=rng.get("bg"), z0=bg.pop("z0", None),
+                                                          beta_init=bg.pop("beta_init", None), x0=x0)
+            bg.pop("rot", None)
+            return bg
         if "bg_xy0" in rng and torch.is_tensor(rng["bg_xy0"]) and rng["bg_xy0"].device == dev:
             xy0 = rng["bg_xy0"].float()       # already on the device (graph capture: no host->device copy here)
         elif "bg_xy0" in rng:
@@ -1117,7 +1145,6 @@ class HoloSceneNetwork(nn.Module):
             xy0 = torch.floor(torch.rand(2, device=dev) * span)
         gy, gx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
         uv0 = (torch.stack([gx, gy], -1).reshape(1, -1, 2).float() + xy0)
-        from . import ray_sampler as _rs
         if _rs.SAMPLER_IMPL == "hip" and uv0.is_cuda and pose.shape[1] != 7:
             bg = self._setup_rays_fused(uv0, None, pose, intrinsics, (rng.get("bg") or {}).get("t_rand"))
         else:

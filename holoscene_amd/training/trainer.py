@@ -324,7 +324,7 @@ class Stage1Trainer:
         # entered with grad enabled: the renderer differentiates through beta and the normalised weights, the samplers detach them
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
-        sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1])
+        sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1], with_bg)     # (the background patch's draws come from the same pool)
         # (st["draw"]: the batch itself, drawn and gathered into st["input"] / st["gt"] by that same launch -- train_step_resident)
         with _net.iteration_prologue(model, tick, sizes, zero=zero, draw=st.get("draw")) as drawn:
             with torch.no_grad():
@@ -333,11 +333,11 @@ class Stage1Trainer:
                 elif drawn is not None:
                     rng = drawn
                 else:
-                    rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device)    # one generator launch per iteration
+                    rng = model.draw_uniforms(st["input"]["uv"].shape[1], st["input"]["uv"].device, with_bg)    # one generator launch per iteration
                 rays = model.prepare_rays(st["input"], rng)
                 z_vals, z_eik = model.sample(rays, rng)
                 rounds = model.ray_sampler._rounds
-                bg = model.prepare_background(st["input"], rng if "rng" in st else None) if with_bg else None
+                bg = model.prepare_background(st["input"], rng) if with_bg else None
                 model.ray_sampler._rounds = rounds      # report the main pass, not the background patch
                 sampled = {"z_vals": z_vals, "z_eik": z_eik, "bg_z": None if bg is None else bg["z_vals"]}
                 if "depths" in st:  # the caller's depths replace the sampler's downstream of it

@@ -287,7 +287,9 @@ int hs_ray_setup(const float *uv, const float *ray_offset, const float *pose, co
                  float offset_shift /* added to ray_offset: 0, or -0.5 when ray_offset holds raw U[0,1) draws */,
                  float *rot_out /* NULL, or [3,3]: the world-to-camera rotation pose[:3,:3]^T (network.py:917) */,
                  float *beta_work /* NULL, or [R]: a second copy of beta_init -- the sampler's working state, which its update kernels overwrite */,
-                 void *stream);
+                 const float *patch_u /* NULL, or two U[0,1) draws: the rays are the R = patch x patch pixels of a block placed by them (uv unused) --
+                                       * the background patch of network.py:919-925: origin = floor(u * (floor(2 c) - patch + 1)) per axis */,
+                 int32_t patch, void *stream);
 
 /* Sample positions of a sampler round: x [R*S,3] = cam_loc[r] + z[r,s]*ray_dirs[r] (ray_sampler.py:151-153) and
  * x01 = (x/divide_factor + 1)/2, the hash grid's [0,1] coordinates (network.py:176, hashgrid.py:158), in one launch. */
