@@ -1560,6 +1560,86 @@ def test_resident_ns_dataset_gather_equals_indexed_batches():
     assert done >= 8
 
 
+def test_scheduled_draw_serves_the_batches_the_eager_paths_serve():
+    """hs_draw_gather_sched (the batch draw driven from device memory -- a node of the training graph): next_batch() on one scene, the scheduled launch
+    on an identically seeded one, 40 batches incl. ring refills (n_sched = 16) and an eager draw in between (the cursor is put back): same frames, same
+    pixels, same rows; peek_batch() does not consume.  Same for ResidentNSDataset on the reference-shaped fixture (per-frame class lists and images)."""
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.datasets import pixel_sampler as ps
+    a = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, seed=5, device=DEV)
+    b = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, seed=5, device=DEV)
+    _, mi, gt = a.peek_batch()
+    _, mi2, gt2 = a.peek_batch()
+    assert all(torch.equal(mi[k], mi2[k]) for k in mi) and all(torch.equal(gt[k], gt2[k]) for k in gt), "peek_batch() must not consume"
+    dst_i = {k: torch.full_like(v, -3) for k, v in mi.items()}
+    dst_g = {k: torch.full_like(v, -3) for k, v in gt.items()}
+    sd = b.scheduled_draw(dst_i, dst_g)
+    assert isinstance(sd, ps.ScheduledDraw)
+    sd.schedule.n = 16
+    sd.schedule.sched = torch.zeros(16, dtype=torch.int32, device=DEV)
+    sd2 = b.scheduled_draw(dst_i, dst_g)         # (a plan on the resized ring; one schedule per dataset)
+    assert sd2.schedule is sd.schedule
+    for i in range(40):
+        _, mi, gt = a.next_batch()
+        if i == 21:             # an eager batch in between: both paths walk one sequence
+            _, mj, gj = b.next_batch()
+            assert all(torch.equal(mi[k], mj[k]) for k in mi) and all(torch.equal(gt[k], gj[k]) for k in gt)
+            continue
+        sd2.before_replay()
+        sd2.launch()
+        sd2.after_replay()
+        for k in mi:
+            assert torch.equal(mi[k], dst_i[k]), (i, k)
+        for k in gt:
+            assert torch.equal(gt[k], dst_g[k]), (i, k)
+    from test_dataset_cpu import _dataset
+    rec = load("ns_sampler")
+    c, d = _dataset(rec, DEV, seed=3), _dataset(rec, DEV, seed=3)
+    R = int(rec["meta.R"])
+    dst_in = {"uv": torch.zeros(1, R, 2, device=DEV), "pose": torch.zeros(1, 4, 4, device=DEV), "intrinsics": torch.zeros(1, 4, 4, device=DEV)}
+    dst_gt = {"rgb": torch.zeros(1, R, 3, device=DEV), "depth": torch.zeros(1, R, 1, device=DEV), "normal": torch.zeros(1, R, 3, device=DEV),
+              "mask": torch.zeros(1, R, 1, device=DEV), "segs": torch.zeros(1, R, 1, device=DEV)}
+    sn = d.scheduled_draw(dst_in, dst_gt)
+    if sn is None:          # the fixture has a frame with a class below its quota: ragged batches cannot fill a static block (ns_dataset.py:422-427)
+        assert any(d._sampler.count(f) != R for f in range(d.n_images))
+        return
+    for i in range(12):
+        _, si, gi = c.next_batch()
+        sn.before_replay()
+        sn.launch()
+        sn.after_replay()
+        for k, v in si.items():
+            assert torch.equal(dst_in[k], v), (i, k)
+        for k, v in gi.items():
+            assert torch.equal(dst_gt[k], v), (i, k)
+
+
+def test_background_patch_rays_placed_by_the_ray_kernel():
+    """hs_ray_setup(patch_u, patch): the rays of the 32 x 32 patch two U[0, 1) draws place == the rays of the pixel grid the host-side formulation
+    builds from the same draws (network.py:919-925: origin = floor(u * (floor(2 c) - patch + 1)))."""
+    from holoscene_amd.training.trainer import Stage1Trainer, stock_conf
+    conf = stock_conf(num_rays=256, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=0.05, mlp_precision="bf16")
+    tr = Stage1Trainer(conf, device=DEV, optimizer="flat")
+    m = tr.model.train()
+    intr = torch.eye(4, device=DEV)[None].clone()
+    intr[0, 0, 0] = intr[0, 1, 1] = 160.0
+    intr[0, 0, 2], intr[0, 1, 2] = 150.5, 101.0
+    pose = torch.eye(4, device=DEV)[None].clone()
+    pose[0, :3, 3] = torch.tensor([0.1, -0.2, 0.6], device=DEV)
+    P = m.BG_PATCH
+    for u in ([0.0, 0.0], [0.9999, 0.9999], [0.37, 0.81]):
+        pu = torch.tensor(u, device=DEV)
+        t_rand = torch.rand(P * P, m.ray_sampler.N_samples_eval, device=DEV)
+        span = (intr[0, :2, 2] * 2.0).floor() - P + 1
+        xy0 = torch.floor(pu * span)
+        gy, gx = torch.meshgrid(torch.arange(P, device=DEV), torch.arange(P, device=DEV), indexing="ij")
+        uv0 = torch.stack([gx, gy], -1).reshape(1, -1, 2).float() + xy0
+        want = m._setup_rays_fused(uv0, None, pose, intr, t_rand)
+        got = m._setup_rays_fused(None, None, pose, intr, t_rand, patch_u=pu)
+        for k in want:
+            assert torch.equal(want[k], got[k]), (u, k)
+
+
 def test_resident_ns_dataset_equals_the_references_batches_on_the_device():
     """SURVEY 8f rank 4 on the MI355X: the HBM-resident frames, indexed on the device with the reference's own permutation draws,
     give the reference's batches (datasets/ns_dataset.py:409-453; fixture ns_sampler, incl. its ragged batch)."""

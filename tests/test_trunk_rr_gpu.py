@@ -202,6 +202,32 @@ def test_rr_output_cotangent_image(n, K):
         assert torch.allclose(part.sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("n,K,Be", [(1000, 32, 96), (4099, 5, 513), (300, 40, 64)])
+def test_output_cotangent_images_in_one_launch_equal_the_two_launches(n, K, Be):
+    """hs_trunk_rr_gy_split: gy / its column sums of the rendered samples and the [4 Be, KP] cotangent image of the Eikonal points' value+Jacobian rows
+    from ONE launch, bit for bit what hs_trunk_rr_gy and hs_trunk_split_bwd write as two."""
+    from holoscene_amd.hashencoder.backend import _backend as be
+    g = torch.Generator().manual_seed(n + K + Be)
+    KP, planes = (32, ()) if K <= 32 else (64, (2,))
+    g_raw, g_sdf = torch.randn(n, K, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    idx = torch.randint(0, K, (n + Be, 1), generator=g).to(DEV)
+    g_yeik, g_min, g_theta = torch.randn(Be, K, generator=g).to(DEV), torch.randn(Be, 1, generator=g).to(DEV), torch.randn((K + 1) * Be, 3, generator=g).to(DEV)
+    bf = torch.bfloat16
+    gy_a, gy_b = (torch.full(planes + (n, 32), 7.0, device=DEV, dtype=bf) for _ in range(2))
+    pa, pb = (torch.full((be.RR_GY_BLOCKS, KP), 7.0, device=DEV) for _ in range(2))
+    img_a, img_b = (torch.full((4 * Be, KP), 7.0, device=DEV, dtype=bf) for _ in range(2))
+    be.trunk_rr_gy(g_raw, g_sdf, idx[:n], K, gy_a, pa)
+    be.trunk_split_bwd(None, None, idx[n:], None, g_yeik, g_min, g_theta, Be, 0, K, img_a)
+    be.trunk_rr_gy_split(g_raw, g_sdf, idx[:n], K, gy_b, pb, idx[n:].reshape(-1), g_yeik, g_min, g_theta, img_b)
+    assert torch.equal(gy_a.view(torch.int16), gy_b.view(torch.int16)) and torch.equal(pa, pb)
+    assert torch.equal(img_a.view(torch.int16), img_b.view(torch.int16))
+    # absent cotangents (either family's may be missing in a pass)
+    be.trunk_rr_gy(None, g_sdf, idx[:n], K, gy_a, pa)
+    be.trunk_split_bwd(None, None, idx[n:], None, None, None, g_theta, Be, 0, K, img_a)
+    be.trunk_rr_gy_split(None, g_sdf, idx[:n], K, gy_b, pb, idx[n:].reshape(-1), None, None, g_theta, img_b)
+    assert torch.equal(gy_a.view(torch.int16), gy_b.view(torch.int16)) and torch.equal(pa, pb) and torch.equal(img_a.view(torch.int16), img_b.view(torch.int16))
+
+
 def test_fused_forward_equals_the_pair_at_the_benchmarked_size():
     """k_rr_fwd's chunk pipeline (counted vector-memory waits, bare barriers, two rounds of tiles per workgroup) at 100 352 samples:
     every output bit-identical to k_rr_fwd_value + k_rr_fwd_grad, five runs in a row (a race in the pipeline would show as a run
