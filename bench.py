@@ -59,7 +59,9 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="run the post-sampler part eagerly instead of as a captured HIP graph")
     p.add_argument("--optimizer", choices=["flat", "torch"], default="flat")
     p.add_argument("--no-draw-in-graph", action="store_true", help="the batch draw as a launch of its own in front of every graph replay (A/B of "
-                   "Stage1Trainer(draw_in_graph=True): the draw as the first node of the iteration's graph)")
+                   "Stage1Trainer(draw_in_graph=True): the draw inside the iteration's graph)")
+    p.add_argument("--draw-at-head", action="store_true", help="the batch drawn by the iteration's own first launch instead of one iteration ahead, in the "
+                   "colour table's scatter launch of the previous backward pass (A/B: Stage1Trainer(draw_in_graph='head'))")
     p.add_argument("--roofline-steps", type=int, default=6, help="eager iterations after the timed region used to time single kernels")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-second-point", action="store_true", help="skip the beta=0.1 (1 sampler round, dense gradients) point of SURVEY 8(d)")
@@ -550,7 +552,7 @@ def main():
     conf = stock_conf(num_rays=args.rays, S=args.samples, d_out=args.objects, num_levels=args.levels, end_size=args.end_size, logmap=args.logmap, beta=args.beta, mlp_precision=args.precision,
                       learning_rate=5.0e-4 * args.lr_scale, eikonal_mode=args.eikonal)
     tr = Stage1Trainer(conf, device=dev, world_size=world, rank=rank, seed=42, optimizer=args.optimizer,
-                       graph=(not args.no_graph) and args.optimizer == "flat", draw_in_graph=not args.no_draw_in_graph)
+                       graph=(not args.no_graph) and args.optimizer == "flat", draw_in_graph=False if args.no_draw_in_graph else ("head" if args.draw_at_head else True))
     benchmark_model_state(tr.model, args.beta)
     if world > 1:
         dist_util.broadcast_parameters(tr.model)

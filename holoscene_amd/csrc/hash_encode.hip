@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "holoscene_hip.h"
+#include "batch_draw.h"
 #include "adam_math.h"
 
 namespace {
@@ -69,8 +70,8 @@ __device__ __forceinline__ float smoothstep_d(float t) { return 6 * t * (1.0f - 
 
 // blockIdx.x -> (level, chunk).  Schedule 1: block b lands on XCD b%8; XCD x owns
 // levels {x, 15-x, 16+x, 31-x, ...} so cheap coarse and expensive fine levels pair up.
-__device__ __forceinline__ void decode_block(uint32_t L, uint32_t n_chunks, int schedule, uint32_t &level, uint32_t &chunk) {
-    const uint32_t bid = blockIdx.x;
+__device__ __forceinline__ void decode_block(uint32_t L, uint32_t n_chunks, int schedule, uint32_t &level, uint32_t &chunk, uint32_t first = 0u) {
+    const uint32_t bid = blockIdx.x - first;        // (first: workgroups in front of this kernel's own, a multiple of 8 -- the XCD of a block is blockIdx % 8)
     if (schedule == 1) {
         const uint32_t xcd = bid & 7u, j = bid >> 3;
         const uint32_t slot = j / n_chunks;
@@ -771,11 +772,11 @@ void launch_bin_reduce(float *grad_embeddings, const int32_t *offsets, uint32_t 
 
 // ------------------------------------------------------------------------------------ first backward: scatter
 template <int D, int C>
-__global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__restrict__ grad, const float *__restrict__ x,
-                                                                const int32_t *__restrict__ offsets, float *__restrict__ gemb,
-                                                                uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
+__device__ __forceinline__ void hash_bwd_scatter_body(const float *__restrict__ grad, const float *__restrict__ x,
+                                                      const int32_t *__restrict__ offsets, float *__restrict__ gemb,
+                                                      uint32_t B, uint32_t L, const LevelScales &sc, const hsHashLayout &lay, uint32_t n_chunks, uint32_t first) {
     uint32_t level, chunk;
-    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    decode_block(L, n_chunks, lay.schedule, level, chunk, first);
     const uint32_t b = chunk * kThreads + threadIdx.x;
     const LevelInfo li = level_info<D>(offsets, level, sc);
     if (li.table == 0u) return;       // an empty level has no table to scatter into (block-uniform)
@@ -805,6 +806,30 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
     const uint32_t gid = grid_of(lay, b, b < B);
     if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);      // (never with grid_id: the launchers refuse)
     else scatter_cell<D, C>(gemb + grid_entry0(lay, gid, li) * C, li, g, cache, valid, gid);
+}
+
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__restrict__ grad, const float *__restrict__ x,
+                                                                const int32_t *__restrict__ offsets, float *__restrict__ gemb,
+                                                                uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks) {
+    hash_bwd_scatter_body<D, C>(grad, x, offsets, gemb, B, L, sc, lay, n_chunks, 0u);
+}
+
+// The same launch with the NEXT iteration's batch draw riding in front (batch_draw.h; include/holoscene_hip.h: hs_hash_bwd_draw): the draw is a
+// 22-us chain of dependent round trips on a handful of workgroups and nothing in a training iteration reads its static batch block after the loss --
+// as the first link of the next iteration it is on the critical path, under this scatter (39 us on 6 000 workgroups) it is not.  first = the draw's
+// workgroups rounded up to 8, so that the scatter's blocks keep their XCDs.
+struct DrawRider { hsDrawSched draw; int32_t blocks, n_uniform, total_pixels, n_out; int64_t *out; DrawGatherJobs jobs; };
+static_assert(kThreads == kDrawThreads, "the draw's workgroups ride in the scatter's launch");
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter_draw(const float *__restrict__ grad, const float *__restrict__ x,
+                                                                     const int32_t *__restrict__ offsets, float *__restrict__ gemb,
+                                                                     uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks, DrawRider r, uint32_t first) {
+    if (blockIdx.x < first) {
+        if ((int)blockIdx.x < r.blocks) draw_gather_sched_body((int)blockIdx.x, r.blocks, r.draw, r.n_uniform, r.total_pixels, r.n_out, r.out, r.jobs);
+        return;
+    }
+    hash_bwd_scatter_body<D, C>(grad, x, offsets, gemb, B, L, sc, lay, n_chunks, first);
 }
 
 // ------------------------------------------------------------------------------------ first backward: d/dx
@@ -1069,7 +1094,34 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
 int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
                 uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
                 void *stream) {
+    return hs_hash_bwd_draw(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, layout, nullptr, 0, 0, 0, nullptr, nullptr, 0, stream);
+}
+
+int hs_hash_bwd_draw(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                     uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
+                     const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out, const hsGatherJob *gather,
+                     int32_t n_gather, void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
+    DrawRider rider;
+    rider.blocks = 0;
+    if (draw) {     /* hs_draw_gather_sched's arguments and checks; the draw needs a scatter launch to ride in */
+        if (B == 0 || !grad_embeddings) return HS_ERR_ARG;
+        if (!draw->frames || !draw->sched || !draw->cursor || !draw_out) return HS_ERR_NULL;
+        if (draw->n_sched < 1 || draw->n_frames < 1 || n_uniform < 0 || total_pixels < 1 || n_out < 0 || n_gather < 0 || n_gather > HS_GATHER_MAX_JOBS) return HS_ERR_ARG;
+        if (n_gather > 0 && !gather) return HS_ERR_NULL;
+        rider.draw = *draw; rider.n_uniform = n_uniform; rider.total_pixels = total_pixels; rider.n_out = n_out; rider.out = draw_out;
+        rider.jobs.n = n_gather;
+        int64_t most = n_out;
+        for (int i = 0; i < n_gather; i++) {
+            const hsGatherJob &j = gather[i];
+            if (j.n < 0 || j.row_bytes < 0 || (j.row_bytes & 3)) return HS_ERR_ARG;
+            if (j.n > 0 && !j.dst) return HS_ERR_NULL;
+            if (j.idx == draw_out && j.n != n_out) return HS_ERR_ARG;
+            rider.jobs.j[i] = j;
+            most = j.n > most ? j.n : most;
+        }
+        rider.blocks = (int32_t)((most + kDrawThreads - 1) / kDrawThreads);
+    }
     if (layout && layout->step && (B == 0 || !grad_embeddings)) {      // nothing to scatter: the table still takes its step
         if (!offsets || !step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;
         hsHashLayout none = *layout;
@@ -1093,8 +1145,14 @@ int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, 
         apply_bin_dense_switch();
     if (lay.scatter_ws && !lay.ws_clean) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
         dispatch_dc(D, C, [&](auto d, auto c) {
-            k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
-                grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+            if (rider.blocks > 0) {
+                const uint32_t first = ((uint32_t)rider.blocks + 7u) & ~7u;
+                k_hash_bwd_scatter_draw<decltype(d)::value, decltype(c)::value><<<dim3(first + n_chunks * L), dim3(kThreads), 0, st>>>(
+                    grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks, rider, first);
+            } else {
+                k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
+                    grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+            }
             launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, sc, lay, st);
         });
     }

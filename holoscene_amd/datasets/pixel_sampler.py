@@ -117,9 +117,9 @@ class DeviceSchedule:
         self.lo = self.hi = 0           # the ring holds the frames of batches [lo, hi)
         self.cursor_at = None           # the batch number the device cursor is known to hold
 
-    def before_replay(self):
-        b = self.sampler._counter
-        if not (self.lo <= b < self.hi):
+    def ensure_ring(self, b, ahead=0):
+        """The ring holds the frames of batches b .. b + ahead (refilled for b .. b + n - 1 otherwise)."""
+        if not (self.lo <= b and b + ahead < self.hi):
             q = self.frames.queue
             while len(q) < self.n:
                 q.append(self.frames.pick())
@@ -128,9 +128,11 @@ class DeviceSchedule:
                 ring[(b + i) % self.n] = q[i]
             self.sched.copy_(torch.tensor(ring, dtype=torch.int32))     # (stream-ordered behind every replay that read the old content)
             self.lo, self.hi = b, b + self.n
-        if self.cursor_at != b:
-            self.cursor.copy_(torch.tensor([b, 0], dtype=torch.int64))
-            self.cursor_at = b
+
+    def before_replay(self):
+        b = self.sampler._counter
+        self.ensure_ring(b)
+        self.set_cursor(b)
 
     def after_replay(self):
         self.frames.take()
@@ -139,6 +141,11 @@ class DeviceSchedule:
 
     def resync(self):
         self.cursor_at = None
+
+    def set_cursor(self, b):
+        if self.cursor_at != b:
+            self.cursor.copy_(torch.tensor([b, 0], dtype=torch.int64))
+            self.cursor_at = b
 
 
 class ScheduledDraw:
@@ -153,7 +160,31 @@ class ScheduledDraw:
             n_cls, per_class, n_bg = sampler.quotas(f)
             descs.append((ptr, pix, off, n_cls, per_class, n_bg))
         self.plan = _be._backend.draw_sched_plan(descs, jobs, sampler.idx, schedule.sched, schedule.cursor, sampler._seed, 1)
-        self.before_replay, self.after_replay, self.resync = schedule.before_replay, schedule.after_replay, schedule.resync
+        self.before_replay, self.after_replay = schedule.before_replay, schedule.after_replay
+        self.holds = None       # draw-ahead protocol: the batch number the destination block holds (None: unknown)
+
+    def resync(self):
+        self.schedule.resync()
+        self.holds = None
+
+    # ---- draw-ahead: iteration b's graph draws batch b + 1 into the block late in its backward pass (hs_hash_bwd_draw), off the next iteration's
+    # critical path.  The block must hold batch b when the replay starts: it does if the previous replay drew it, else it is drawn here, eagerly.
+    def before_replay_ahead(self):
+        sc = self.schedule
+        b = sc.sampler._counter
+        sc.ensure_ring(b, ahead=1)
+        if self.holds != b or sc.cursor_at != b + 1:
+            sc.set_cursor(b)
+            self.launch()                   # batch b into the block, eagerly; the launch leaves the cursor at b + 1
+            sc.cursor_at = b + 1
+            self.holds = b
+
+    def after_replay_ahead(self):
+        sc = self.schedule
+        sc.frames.take()
+        sc.sampler._counter += 1
+        sc.cursor_at += 1
+        self.holds = sc.sampler._counter
 
     def launch(self):
         from ..hashencoder import backend as _be

@@ -1028,6 +1028,7 @@ class _fused_appearance_wave(torch.autograd.Function):
     def forward(ctx, points, dirs, normals, embeddings, offsets, S, Hres, divide_factor, Wc0, bc0, Wc1, bc1, Wr0, br0, Wr1, br1, Wr2, br2, x01=None):
         ctx.set_materialize_grads(False)
         ctx.table = embeddings if isinstance(embeddings, torch.nn.Parameter) else None
+        ctx.rider = _SCOPE.rider
         if ctx.needs_input_grad[3]:
             _be.expect_scatter(ctx.table)
         be = _be._backend
@@ -1125,8 +1126,12 @@ class _fused_appearance_wave(torch.autograd.Function):
             table = ctx.table
             inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
+            rider = getattr(ctx, "rider", None)
+            take = rider is not None and not rider["done"] and B > 0      # the next batch's draw rides in front of this scatter's workgroups
             be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True)
+                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rider=rider["draw"].args() if take else None)
+            if take:
+                rider["done"] = True
             g_emb = None if inplace else target
             if inplace:
                 _be.scatter_done(table)
@@ -1383,8 +1388,10 @@ class _IterationScope(threading.local):
                 normal map's cotangent there and the colour branch's backward kernel adds its own into it
       beta      {"key": beta_eff, "parts": [...]}: _composite.backward leaves its per-ray partial derivatives w.r.t. beta there instead of launching
                 a sum; _iter_prologue.backward adds them up inside its one launch
-      last      (beta relay, normals relay) of the block that ended last, for assert_relays_consumed()"""
-    shared_w = packs = normals = beta = last = None
+      last      (beta relay, normals relay) of the block that ended last, for assert_relays_consumed()
+      rider     {"draw": ScheduledDraw, "done": bool} or None: the NEXT iteration's batch draw, to ride in the colour table's scatter launch (its
+                forward takes the dict onto ctx; whoever launches the draw sets "done")"""
+    shared_w = packs = normals = beta = last = rider = None
 
 
 _SCOPE = _IterationScope()
@@ -1496,13 +1503,14 @@ class _iter_prologue(torch.autograd.Function):
 
 
 @contextlib.contextmanager
-def iteration_prologue(model, flat=None, rng_sizes=None, zero=None, draw=None):
+def iteration_prologue(model, flat=None, rng_sizes=None, zero=None, draw=None, draw_ahead=None):
     """One launch for everything a Stage-1 iteration needs before its first ray: within the block model.density.get_beta() and
     effective_weights() return the tensors evaluated here (as under density.shared_beta() + shared_effective_weights()), `flat`'s Adam
     state is ticked (training/flat.py: FlatAdam -- its step() then skips the tick launch), and the block yields the `rng` dictionary of
     model.draw_uniforms (views of one pool of U[0, 1) draws from the model's own device-resident Philox stream).  Enter with grad enabled.
     draw: a datasets.pixel_sampler.ScheduledDraw -- the iteration's batch, drawn and gathered by the same launch (as a launch of its own where this
-    model takes the fallback below)."""
+    model takes the fallback below).  draw_ahead: {"draw": ScheduledDraw, "done": False} -- the NEXT iteration's batch, offered to the colour table's scatter
+    launch of this iteration's backward pass (_IterationScope.rider); the caller launches it itself afterwards if nobody took it."""
     lins = [l for l in model.weight_norm_layers() if isinstance(l, WNLinear) and l.weight_v.is_cuda]
     dens = model.density
     dev = dens.beta.device
@@ -1535,15 +1543,16 @@ def iteration_prologue(model, flat=None, rng_sizes=None, zero=None, draw=None):
             rng[k] = pool[off:off + n].view(shp)
             off += n
         rng = model.nest_draws(rng)
-    prev_w, prev_relay, prev_beta, prev_packs, prev_nrm = _SCOPE.shared_w, _SCOPE.beta, dens._shared, _SCOPE.packs, _SCOPE.normals
+    prev_w, prev_relay, prev_beta, prev_packs, prev_nrm, prev_rider = _SCOPE.shared_w, _SCOPE.beta, dens._shared, _SCOPE.packs, _SCOPE.normals, _SCOPE.rider
     _SCOPE.shared_w, _SCOPE.beta, dens._shared = {id(l): fused_cols(W, l) for l, W in zip(lins, Ws)}, relay, beta_eff
+    _SCOPE.rider = draw_ahead
     _SCOPE.packs = model._pack_iteration()
     _SCOPE.normals = {"key": None, "cot": None}
     _SCOPE.last = (relay, _SCOPE.normals)
     try:
         yield rng
     finally:
-        _SCOPE.shared_w, _SCOPE.beta, dens._shared, _SCOPE.packs, _SCOPE.normals = prev_w, prev_relay, prev_beta, prev_packs, prev_nrm
+        _SCOPE.shared_w, _SCOPE.beta, dens._shared, _SCOPE.packs, _SCOPE.normals, _SCOPE.rider = prev_w, prev_relay, prev_beta, prev_packs, prev_nrm, prev_rider
 
 
 def assert_relays_consumed():

@@ -70,8 +70,10 @@ class Stage1Trainer:
         iteration graph (RCCL only); "serial" = the whole exchange after the backward pass, outside the graph.
         table_step: reduce-and-step of the hash tables (below); None = on unless HOLOSCENE_TABLE_STEP=0.  False gives the optimiser
         path every data-parallel rank runs (zero-fill, scatter into the gradient tables, Adam sweep) in a single process.
-        draw_in_graph: train_step_resident() captures the batch draw as the first node of the iteration's graph when the dataset offers
-        scheduled_draw() (False: one launch in front of every replay -- the A/B of profiles/r06)."""
+        draw_in_graph: train_step_resident() captures the batch draw inside the iteration's graph when the dataset offers scheduled_draw():
+        True / "ahead" = iteration k's graph draws batch k + 1, its workgroups riding in the colour table's scatter launch late in the backward
+        pass (off the next iteration's critical path); "head" = batch k drawn by iteration k's first launch; False = one launch in front of every
+        replay (the A/Bs of profiles/r06)."""
         torch.manual_seed(seed)
         self.conf = conf
         self.device = torch.device(device)
@@ -117,6 +119,8 @@ class Stage1Trainer:
         self.iter_step = 0
         self._graphs = {}
         self.draw_in_graph = bool(draw_in_graph)
+        self._draw_ahead = draw_in_graph in (True, "ahead")
+        self._resident_blocks = {}      # id(dataset) -> (dataset, input block, gt block, ScheduledDraw): ONE static batch block for all graph variants
         self._capture_dataset = None    # the dataset whose scheduled draw the graph being captured takes in (train_step_resident)
         # Reduce-and-step (csrc/hash_encode.hip: k_hash_bin_step): in the variants of the whole-iteration graph in which every hash
         # table has ONE gradient producer (all but the background-patch iterations), the tables take their Adam step inside that
@@ -325,8 +329,11 @@ class Stage1Trainer:
         # one launch: beta, every weight-normalised matrix, the iteration's uniform draws, the optimiser tick (csrc/iter_ops.hip)
         # (the serial data-parallel exchange ticks for itself after the replay: training/distributed.py)
         sizes = None if "rng" in st else model.uniform_sizes(st["input"]["uv"].shape[1], with_bg)     # (the background patch's draws come from the same pool)
-        # (st["draw"]: the batch itself, drawn and gathered into st["input"] / st["gt"] by that same launch -- train_step_resident)
-        with _net.iteration_prologue(model, tick, sizes, zero=zero, draw=st.get("draw")) as drawn:
+        # st["draw"] (train_step_resident): the batch is drawn and gathered into st["input"] / st["gt"] inside the graph -- "head": this iteration's, by
+        # the prologue launch; "ahead": the NEXT iteration's, offered to the colour table's scatter launch of this backward pass
+        sd = st.get("draw")
+        rider = {"draw": sd, "done": False} if (sd is not None and self._draw_ahead) else None
+        with _net.iteration_prologue(model, tick, sizes, zero=zero, draw=None if rider is not None else sd, draw_ahead=rider) as drawn:
             with torch.no_grad():
                 if "rng" in st:     # injected draws (static tensors the caller overwrites before each replay)
                     rng = st["rng"]
@@ -350,6 +357,9 @@ class Stage1Trainer:
         loss_out = self.loss(out, st["gt"], call_reg=call_reg)
         with steps:
             loss_out["loss"].backward(gradient=unit_cotangent(loss_out["loss"].device))
+        if rider is not None and not rider["done"]:     # no colour-table scatter in this pass took it along: a launch of its own
+            sd.launch()
+            rider["done"] = True
         self.flat.gather_grads()
         if not torch.cuda.is_current_stream_capturing():
             _net.assert_relays_consumed()       # (warm-up passes: a host-side look at two Python containers)
@@ -456,15 +466,26 @@ class Stage1Trainer:
         if rng is not None:
             rng = self._flatten_draws(rng, self.device, self.model.ray_sampler.N_samples_extra)
         if entry is None:
-            st = {"input": {k: v.clone() for k, v in model_input.items()}, "gt": {k: v.clone() for k, v in ground_truth.items()}}
+            shared = self._resident_blocks.get(id(ds)) if ds is not None else None
+            if shared is not None:      # every graph variant of a dataset reads ONE static batch block (draw-ahead: variant A's graph draws variant B's batch)
+                st = {"input": shared[1], "gt": shared[2]}
+            else:
+                st = {"input": {k: v.clone() for k, v in model_input.items()}, "gt": {k: v.clone() for k, v in ground_truth.items()}}
             if rng is not None:
                 st["rng"] = rng       # freshly made device tensors: they become the static block
             if depths is not None:
                 st["depths"] = {k: v.to(self.device).clone() for k, v in depths.items()}
-            sd = ds.scheduled_draw(st["input"], st["gt"]) if ds is not None else None      # None: this dataset cannot (the batch stays a launch of its own)
+            sd = None
+            if shared is not None:
+                sd = shared[3]
+            elif ds is not None:
+                sd = ds.scheduled_draw(st["input"], st["gt"])      # None: this dataset cannot (the batch stays a launch of its own)
+                if sd is not None:
+                    self._resident_blocks[id(ds)] = (ds, st["input"], st["gt"], sd)
             if sd is not None:
                 st["draw"] = sd
-                sd.before_replay()          # the warm-up passes below launch the draw eagerly: ring and cursor must be in place
+                # the warm-up passes below launch the draw eagerly: ring and cursor must be in place (ahead: and the block hold this batch)
+                sd.before_replay_ahead() if self._draw_ahead else sd.before_replay()
             self._warm_up(lambda: self._full_body(st, base[1], base[2]))
             if sd is not None:
                 sd.resync()                 # (they advanced the device's batch number: the next before_replay() puts it back)
@@ -475,8 +496,8 @@ class Stage1Trainer:
             self._graphs[base + ("sched",) if sd is not None else base] = entry
         st = entry["static"]
         sd = entry.get("sched")
-        if sd is not None:      # the graph draws its own batch: the one the caller peeked at (same batch number, same frame)
-            sd.before_replay()
+        if sd is not None:      # the graph draws its own batches: the one the caller peeked at (same batch number, same frame) is the one it trains on
+            sd.before_replay_ahead() if self._draw_ahead else sd.before_replay()
         else:
             dl = [st["input"][k] for k in model_input] + [st["gt"][k] for k in ground_truth]
             sl = list(model_input.values()) + list(ground_truth.values())
@@ -489,7 +510,7 @@ class Stage1Trainer:
             self._copy_tree(st["depths"], {k: v.to(self.device) for k, v in depths.items()})
         entry["graph"].replay()
         if sd is not None:
-            sd.after_replay()
+            sd.after_replay_ahead() if self._draw_ahead else sd.after_replay()
         self.model.ray_sampler._rounds = entry["rounds"]
         self._after_replay()
         self.iter_step += 1
@@ -514,9 +535,14 @@ class Stage1Trainer:
             if entry is not None:
                 sd = entry["sched"]
                 self.model.train()
-                sd.before_replay()
-                entry["graph"].replay()
-                sd.after_replay()
+                if self._draw_ahead:
+                    sd.before_replay_ahead()
+                    entry["graph"].replay()
+                    sd.after_replay_ahead()
+                else:
+                    sd.before_replay()
+                    entry["graph"].replay()
+                    sd.after_replay()
             else:
                 entry = self._graphs.get(base)
                 if entry is not None:

@@ -821,6 +821,12 @@ int hs_draw_gather_sched(const hsDrawSched *sched, int32_t n_uniform, int32_t to
 /* hs_iter_prologue with hs_draw_gather_sched(draw, n_uniform, total_pixels, n_out, draw_out, gather, n_gather) riding in the same launch, its workgroups
  * first (draw == NULL: exactly hs_iter_prologue).  Nothing in the prologue reads what the draw writes; as a launch of its own the draw is 22 us of
  * dependent round trips on four workgroups. */
+/* hs_hash_bwd with hs_draw_gather_sched(draw, ...) riding in front of the scatter's workgroups (draw == NULL: exactly hs_hash_bwd): the NEXT iteration's
+ * batch, drawn where nothing reads the static batch block any more (after the loss) and where a 22-us latency chain costs nothing (under a 39-us scatter
+ * on 6 000 workgroups) instead of being the next iteration's first link.  Needs a scatter launch (B > 0, grad_embeddings != NULL). */
+int hs_hash_bwd_draw(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                     float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout, const hsDrawSched *draw, int32_t n_uniform,
+                     int32_t total_pixels, int32_t n_out, int64_t *draw_out, const struct hsGatherJob *gather, int32_t n_gather, void *stream);
 int hs_iter_prologue_draw(const struct hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
                           const float *beta_min, float *beta_out, int32_t n_beta, struct hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
                           int64_t n_zero, const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out,

@@ -1614,6 +1614,37 @@ def test_scheduled_draw_serves_the_batches_the_eager_paths_serve():
             assert torch.equal(dst_gt[k], v), (i, k)
 
 
+def test_the_three_places_of_the_batch_draw_train_on_the_same_batches():
+    """Stage1Trainer(draw_in_graph = True / "ahead": iteration k's graph draws batch k + 1 in its colour-table scatter launch (hs_hash_bwd_draw), one static
+    batch block for all graph variants | "head": batch k by iteration k's first launch (hs_iter_prologue_draw) | False: a launch in front of every replay):
+    identically seeded scenes and frozen parameters, 13 iterations across both graph variants (iterations 0 and 10 render the background patch) and one
+    eagerly drawn batch in between -- the three see the same batches: equal objectives iteration by iteration."""
+    from holoscene_amd.training.synthetic import SyntheticScene
+    from holoscene_amd.training.trainer import Stage1Trainer, benchmark_model_state, stock_conf
+    losses = {}
+    for mode in (True, "head", False):
+        torch.manual_seed(3)
+        tr = Stage1Trainer(stock_conf(num_rays=256, S=32, d_out=4, num_levels=16, end_size=512, logmap=15, beta=0.05, mlp_precision="bf16"), device=DEV,
+                           optimizer="flat", graph=True, freeze_parameters=True, draw_in_graph=mode)
+        benchmark_model_state(tr.model, 0.05)
+        scene = SyntheticScene(256, 4, img_res=(64, 64), num_frames=3, seed=9, device=DEV)
+        out = []
+        for i in range(13):
+            if i == 5:      # a batch taken eagerly (and thrown away): every mode skips the same one
+                scene.next_batch()
+            torch.manual_seed(50 + i)       # (the model's own draws come from its Philox stream; this pins anything left to torch's generator)
+            _, lo = tr.train_step_resident(scene)
+            out.append(float(lo["loss"]))
+        assert any(len(k) == 4 and k[3] == "sched" for k in tr._graphs) == (mode is not False), list(tr._graphs)
+        losses[mode] = out
+    ref = losses[False]
+    for mode in (True, "head"):
+        for i, (a, b) in enumerate(zip(ref, losses[mode])):
+            assert abs(a - b) <= 2e-4 * abs(a), (mode, i, a, b)
+    print("PARITY batch draw ahead / at the head / eager: 13 iterations, max relative objective difference",
+          max(abs(a - b) / abs(a) for m in (True, "head") for a, b in zip(ref, losses[m])))
+
+
 def test_background_patch_rays_placed_by_the_ray_kernel():
     """hs_ray_setup(patch_u, patch): the rays of the 32 x 32 patch two U[0, 1) draws place == the rays of the pixel grid the host-side formulation
     builds from the same draws (network.py:919-925: origin = floor(u * (floor(2 c) - patch + 1)))."""
