@@ -29,6 +29,7 @@
 
 #include "holoscene_hip.h"
 #include "batch_draw.h"
+#include "assemble.h"
 #include "adam_math.h"
 
 namespace {
@@ -820,13 +821,21 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter(const float *__re
 // as the first link of the next iteration it is on the critical path, under this scatter (39 us on 6 000 workgroups) it is not.  first = the draw's
 // workgroups rounded up to 8, so that the scatter's blocks keep their XCDs.
 struct DrawRider { hsDrawSched draw; int32_t blocks, n_uniform, total_pixels, n_out; int64_t *out; DrawGatherJobs jobs; };
-static_assert(kThreads == kDrawThreads, "the draw's workgroups ride in the scatter's launch");
+// ... and a backward stage's slice sums (assemble.h: hs_assemble's jobs): their only reader is the end-of-pass epilogue, their inputs are complete before the
+// scatter starts, and as a launch of their own they were 9-11 us between two long kernels
+struct Riders { DrawRider draw; AsmJobs sums; int32_t sum_blocks; };
+static_assert(kThreads == kDrawThreads, "the riders' workgroups are the scatter's size");
+static_assert(sizeof(Riders) < 3200, "kernel arguments: 4 KB in all");
+__device__ __forceinline__ void run_rider(const Riders &r, int block) {     // block < first
+    if (block < r.draw.blocks) draw_gather_sched_body(block, r.draw.blocks, r.draw.draw, r.draw.n_uniform, r.draw.total_pixels, r.draw.n_out, r.draw.out, r.draw.jobs);
+    else if (block - r.draw.blocks < r.sum_blocks) assemble_body(r.sums, block - r.draw.blocks);
+}
 template <int D, int C>
 __global__ __launch_bounds__(kThreads) void k_hash_bwd_scatter_draw(const float *__restrict__ grad, const float *__restrict__ x,
                                                                      const int32_t *__restrict__ offsets, float *__restrict__ gemb,
-                                                                     uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks, DrawRider r, uint32_t first) {
+                                                                     uint32_t B, uint32_t L, LevelScales sc, hsHashLayout lay, uint32_t n_chunks, Riders r, uint32_t first) {
     if (blockIdx.x < first) {
-        if ((int)blockIdx.x < r.blocks) draw_gather_sched_body((int)blockIdx.x, r.blocks, r.draw, r.n_uniform, r.total_pixels, r.n_out, r.out, r.jobs);
+        run_rider(r, (int)blockIdx.x);
         return;
     }
     hash_bwd_scatter_body<D, C>(grad, x, offsets, gemb, B, L, sc, lay, n_chunks, first);
@@ -928,12 +937,12 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd2(const float *__restrict_
 // grad[l,b,c]*ggx[b,d] generalised to an arbitrary g_dydx[l,b,d,c]; like the reference it ignores
 // d/dx of dy_dx (hashgrid.py:101).
 template <int D, int C>
-__global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restrict__ g_feat, const float *__restrict__ g_dydx,
-                                                            const float *__restrict__ x, const int32_t *__restrict__ offsets,
-                                                            float *__restrict__ gemb, uint32_t B, uint32_t L, LevelScales sc,
-                                                            hsHashLayout lay, uint32_t n_chunks) {
+__device__ __forceinline__ void hash_bwd_jac_body(const float *__restrict__ g_feat, const float *__restrict__ g_dydx,
+                                                  const float *__restrict__ x, const int32_t *__restrict__ offsets,
+                                                  float *__restrict__ gemb, uint32_t B, uint32_t L, const LevelScales &sc,
+                                                  const hsHashLayout &lay, uint32_t n_chunks, uint32_t first) {
     uint32_t level, chunk;
-    decode_block(L, n_chunks, lay.schedule, level, chunk);
+    decode_block(L, n_chunks, lay.schedule, level, chunk, first);
     const uint32_t b = chunk * kThreads + threadIdx.x;
     const LevelInfo li = level_info<D>(offsets, level, sc);
     if (li.table == 0u) return;       // an empty level has no table to scatter into (block-uniform)
@@ -999,6 +1008,27 @@ __global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restri
     const uint32_t gid = grid_of(lay, b, b < B);
     if (binned_level<C>(li, lay.scatter_ws)) bin_cell<D, C>(lay, gemb + (size_t)li.offset * C, li, level, g, cache, valid);      // (never with grid_id: the launchers refuse)
     else scatter_cell<D, C>(gemb + grid_entry0(lay, gid, li) * C, li, g, cache, valid, gid);
+}
+
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_jac(const float *__restrict__ g_feat, const float *__restrict__ g_dydx,
+                                                            const float *__restrict__ x, const int32_t *__restrict__ offsets,
+                                                            float *__restrict__ gemb, uint32_t B, uint32_t L, LevelScales sc,
+                                                            hsHashLayout lay, uint32_t n_chunks) {
+    hash_bwd_jac_body<D, C>(g_feat, g_dydx, x, offsets, gemb, B, L, sc, lay, n_chunks, 0u);
+}
+
+// with riders in front (see k_hash_bwd_scatter_draw): the trunk's slice sums
+template <int D, int C>
+__global__ __launch_bounds__(kThreads) void k_hash_bwd_jac_riders(const float *__restrict__ g_feat, const float *__restrict__ g_dydx,
+                                                                   const float *__restrict__ x, const int32_t *__restrict__ offsets,
+                                                                   float *__restrict__ gemb, uint32_t B, uint32_t L, LevelScales sc,
+                                                                   hsHashLayout lay, uint32_t n_chunks, Riders r, uint32_t first) {
+    if (blockIdx.x < first) {
+        run_rider(r, (int)blockIdx.x);
+        return;
+    }
+    hash_bwd_jac_body<D, C>(g_feat, g_dydx, x, offsets, gemb, B, L, sc, lay, n_chunks, first);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -1094,16 +1124,25 @@ int hs_hash_fwd(const float *inputs, const float *embeddings, const int32_t *off
 int hs_hash_bwd(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
                 uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
                 void *stream) {
-    return hs_hash_bwd_draw(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, layout, nullptr, 0, 0, 0, nullptr, nullptr, 0, stream);
+    return hs_hash_bwd_draw(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, layout, nullptr, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0,
+                            stream);
 }
 
 int hs_hash_bwd_draw(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
                      uint32_t C, uint32_t L, float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout,
                      const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out, const hsGatherJob *gather,
-                     int32_t n_gather, void *stream) {
+                     int32_t n_gather, const hsAsmJob *sums, int32_t n_sums, void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
-    DrawRider rider;
+    Riders riders;
+    DrawRider &rider = riders.draw;
     rider.blocks = 0;
+    riders.sum_blocks = 0;
+    if (n_sums > 0) {   /* hs_assemble's jobs; they need a scatter launch to ride in */
+        if (B == 0 || !grad_embeddings) return HS_ERR_ARG;
+        const int rc = fill_asm_jobs(sums, n_sums, riders.sums);
+        if (rc != HS_OK) return rc;
+        riders.sum_blocks = riders.sums.first[n_sums];
+    }
     if (draw) {     /* hs_draw_gather_sched's arguments and checks; the draw needs a scatter launch to ride in */
         if (B == 0 || !grad_embeddings) return HS_ERR_ARG;
         if (!draw->frames || !draw->sched || !draw->cursor || !draw_out) return HS_ERR_NULL;
@@ -1145,10 +1184,10 @@ int hs_hash_bwd_draw(const float *grad, const float *inputs, const int32_t *offs
         apply_bin_dense_switch();
     if (lay.scatter_ws && !lay.ws_clean) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
         dispatch_dc(D, C, [&](auto d, auto c) {
-            if (rider.blocks > 0) {
-                const uint32_t first = ((uint32_t)rider.blocks + 7u) & ~7u;
+            if (rider.blocks + riders.sum_blocks > 0) {
+                const uint32_t first = ((uint32_t)(rider.blocks + riders.sum_blocks) + 7u) & ~7u;
                 k_hash_bwd_scatter_draw<decltype(d)::value, decltype(c)::value><<<dim3(first + n_chunks * L), dim3(kThreads), 0, st>>>(
-                    grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks, rider, first);
+                    grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks, riders, first);
             } else {
                 k_hash_bwd_scatter<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
                     grad, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
@@ -1184,8 +1223,23 @@ int hs_hash_bwd2(const float *grad, const float *inputs, const int32_t *offsets,
 
 int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, void *stream) {
+    return hs_hash_bwd_jac_sums(g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, layout, nullptr, 0, stream);
+}
+
+int hs_hash_bwd_jac_sums(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings,
+                         uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, const hsAsmJob *sums,
+                         int32_t n_sums, void *stream) {
     if (!dims_ok(D, C, L)) return HS_ERR_ARG;
     if (!layout) return HS_ERR_NULL;
+    Riders riders;
+    riders.draw.blocks = 0;
+    riders.sum_blocks = 0;
+    if (n_sums > 0) {   /* hs_assemble's jobs; they need a scatter launch to ride in */
+        if (B == 0 || (!g_feat && !g_dydx && !layout->r1_ux)) return HS_ERR_ARG;
+        const int rc = fill_asm_jobs(sums, n_sums, riders.sums);
+        if (rc != HS_OK) return rc;
+        riders.sum_blocks = riders.sums.first[n_sums];
+    }
     if (B == 0 || (!g_feat && !g_dydx && !layout->r1_ux)) {
         if (!layout->step) return HS_OK;
         if (!offsets || !step_ok(*layout, grad_embeddings)) return HS_ERR_NULL;     // nothing to scatter: the table still takes its step
@@ -1208,8 +1262,14 @@ int hs_hash_bwd_jac(const float *g_feat, const float *g_dydx, const float *input
     apply_bin_dense_switch();
     if (lay.scatter_ws && !lay.ws_clean) k_zero_u32<<<(HS_MAX_LEVELS * kBins + 255) / 256, 256, 0, st>>>((uint32_t *)lay.scatter_ws, HS_MAX_LEVELS * kBins);
     dispatch_dc(D, C, [&](auto d, auto c) {
-        k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
-            g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+        if (riders.sum_blocks > 0) {
+            const uint32_t first = ((uint32_t)riders.sum_blocks + 7u) & ~7u;
+            k_hash_bwd_jac_riders<decltype(d)::value, decltype(c)::value><<<dim3(first + n_chunks * L), dim3(kThreads), 0, st>>>(
+                g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks, riders, first);
+        } else {
+            k_hash_bwd_jac<decltype(d)::value, decltype(c)::value><<<dim3(n_chunks * L), dim3(kThreads), 0, st>>>(
+                g_feat, g_dydx, inputs, offsets, grad_embeddings, B, L, sc, lay, n_chunks);
+        }
         launch_bin_reduce<decltype(d)::value, decltype(c)::value>(grad_embeddings, offsets, L, sc, lay, st);
     });
     return check_launch();

@@ -169,7 +169,7 @@ def load_library():
 def dir_symbols():
     """Every symbol include/holoscene_hip.h declares (kept in sync by tests/test_abi.py)."""
     return ["hs_abi_version", "hs_target_arch", "hs_hash_encode_forward", "hs_hash_encode_backward", "hs_hash_encode_second_backward",
-            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_draw_gather_sched", "hs_hash_bwd_draw", "hs_iter_prologue", "hs_iter_prologue_draw", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_gy_split", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
+            "hs_hash_fwd", "hs_hash_bwd", "hs_hash_bwd2", "hs_hash_bwd_jac", "hs_hash_encode_forward_dt", "hs_hash_encode_backward_dt", "hs_hash_encode_second_backward_dt", "hs_hash_scatter_ws_bytes", "hs_sampler_update", "hs_sampler_draw", "hs_sampler_final", "hs_sampler_step", "hs_sampler_pick", "hs_sampler_draw_step", "hs_sampler_draw_steps", "hs_sampler_tail", "hs_sampler_update_draw", "hs_softplus_tangent_fwd", "hs_softplus_tangent_bwd", "hs_adam_tick", "hs_adam_flat", "hs_adam_flat_shard", "hs_copy_many", "hs_composite_fwd", "hs_composite_bwd", "hs_sdf_mlp_fwd", "hs_sdf_mlp2_pack_bytes", "hs_sdf_mlp2_pack", "hs_sdf_mlp2_fwd", "hs_sdf_mlp2_fwd_wide", "hs_sdf_sweep_fwd", "hs_sdf_mlp32_pack_bytes", "hs_sdf_mlp32_pack", "hs_sdf_mlp32_fwd", "hs_trunk_mlp2_input_column", "hs_trunk_mlp2_fwd", "hs_trunk_mlp2_fwd_wide", "hs_trunk_mlp_fwd", "hs_trunk_mlp_bwd", "hs_trunk_bwd_parts", "hs_trunk_split_fwd", "hs_trunk_split_bwd", "hs_softplus_tangent_bwd_h", "hs_trunk_input_fwd", "hs_trunk_input_bwd", "hs_render_input_fwd", "hs_render_input_bwd", "hs_loss_rays", "hs_loss_eikonal", "hs_loss_stage1", "hs_bg_smooth_loss", "hs_ray_setup", "hs_ray_points", "hs_render_points", "hs_appearance_mask_words", "hs_appearance_fwd", "hs_appearance_bwd", "hs_pack_bf16", "hs_sum_slices", "hs_weight_norm", "hs_gather_rows", "hs_wgrad_rows", "hs_draw_pixels", "hs_draw_gather", "hs_draw_gather_sched", "hs_hash_bwd_draw", "hs_hash_bwd_jac_sums", "hs_iter_prologue", "hs_iter_prologue_draw", "hs_iter_epilogue", "hs_pack_iteration", "hs_trunk_rr_gy", "hs_trunk_rr_gy_split", "hs_trunk_rr_pack_bytes", "hs_trunk_rr_pack", "hs_trunk_rr_fwd_value", "hs_trunk_rr_fwd_wide", "hs_trunk_rr_bwd_value_wide",
             "hs_trunk_rr_fwd_grad", "hs_trunk_rr_fwd", "hs_trunk_rr_bwd_grad", "hs_trunk_rr_bwd_value", "hs_wgrad_pairs", "hs_assemble", "hs_abs_shift", "hs_trunk_pack_all", "hs_appearance2_pack_bytes", "hs_appearance2_enc_column", "hs_appearance2_pack",
             "hs_appearance2_fwd", "hs_appearance2_pack_t_bytes", "hs_appearance2_bwd", "hs_gemm_split_nt", "hs_gemm_split_tn"]
 
@@ -388,9 +388,9 @@ class _HipBackend:
                                ctypes.byref(lay), _stream()), "hs_hash_fwd")
 
     @classmethod
-    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False, grids=None, rider=None):
-        """rider: None or ScheduledDraw.args() = (draw_sched_plan(), n_uniform, total_pixels, n_out): the NEXT iteration's batch drawn by workgroups
-        riding in front of this scatter's (hs_hash_bwd_draw)."""
+    def bwd(cls, grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ws=None, level_major=False, grids=None, rider=None, sums=None):
+        """Workgroups riding in front of this scatter's (hs_hash_bwd_draw) -- rider: None or ScheduledDraw.args() = (draw_sched_plan(), n_uniform,
+        total_pixels, n_out): the NEXT iteration's batch; sums: None or what assemble(jobs, defer=True) returned beside the results: that launch."""
         lib = load_library()
         lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
         step = _table_step(grad_embeddings)
@@ -399,12 +399,18 @@ class _HipBackend:
         head = (_dev(grad, "grad"), _dev(inputs, "inputs"), _dev(offsets, "offsets", torch.int32),
                 _dev(grad_embeddings, "grad_embeddings"), B, D, C, L, ctypes.c_float(S), H, _dev(dy_dx, "dy_dx"),
                 _dev(grad_inputs, "grad_inputs"), ctypes.byref(lay))
-        if rider is None:
+        if rider is None and not sums:
             _check(lib.hs_hash_bwd(*head, _stream()), "hs_hash_bwd")
         else:
-            (dst, darr, n_jobs, keep), n_uniform, total_pixels, n_out = rider
-            _check(lib.hs_hash_bwd_draw(*head, ctypes.byref(dst), int(n_uniform), int(total_pixels), int(n_out), _dev(keep[3], "out", torch.int64), darr, n_jobs,
-                                        _stream()), "hs_hash_bwd_draw")
+            sarr, n_sums = cls._asm_array(sums)
+            if rider is None:
+                dargs = (None, 0, 0, 0, None, None, 0)
+            else:
+                (dst, darr, n_jobs, keep), n_uniform, total_pixels, n_out = rider
+                dargs = (ctypes.byref(dst), int(n_uniform), int(total_pixels), int(n_out), _dev(keep[3], "out", torch.int64), darr, n_jobs)
+            _check(lib.hs_hash_bwd_draw(*head, *dargs, sarr, n_sums, _stream()), "hs_hash_bwd_draw")
+            if sums:
+                sums.clear()
 
     @classmethod
     def bwd2(cls, grad, inputs, offsets, B, D, C, L, S, H, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, grids=None):
@@ -444,9 +450,10 @@ class _HipBackend:
                                                      _dev(grad2_embeddings, "grad2_embeddings", dt), _stream()), "hs_hash_encode_second_backward_dt")
 
     @classmethod
-    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None, rank1=None):
+    def bwd_jac(cls, g_feat, g_dydx, inputs, offsets, grad_embeddings, B, D, C, L, S, H, ws=None, level_major=False, grids=None, rank1=None, sums=None):
         """rank1: None, or (ux fp32 [n, L*C], g fp32 [n, D], scale): the dy_dx cotangent of the first n points is (scale * ux[b, l*C + c]) * g[b, d]
-        and is formed inside the kernel; those rows of g_dydx are not read (g_dydx may be None when n == B)."""
+        and is formed inside the kernel; those rows of g_dydx are not read (g_dydx may be None when n == B).  sums: None or what
+        assemble(jobs, defer=True) returned beside the results: that launch rides in front of this scatter's workgroups (hs_hash_bwd_jac_sums)."""
         lib = load_library()
         lay = cls._layout(B, D, C, L, ws=ws, level_major=level_major, grids=grids)
         if rank1 is not None:
@@ -457,9 +464,21 @@ class _HipBackend:
         step = _table_step(grad_embeddings)
         if step is not None:
             lay.step = ctypes.addressof(step)
-        _check(lib.hs_hash_bwd_jac(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
-                                   _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
-                                   ctypes.c_float(S), H, ctypes.byref(lay), _stream()), "hs_hash_bwd_jac")
+        sarr, n_sums = cls._asm_array(sums)
+        _check(lib.hs_hash_bwd_jac_sums(_dev(g_feat, "g_feat"), _dev(g_dydx, "g_dydx"), _dev(inputs, "inputs"),
+                                        _dev(offsets, "offsets", torch.int32), _dev(grad_embeddings, "grad_embeddings"), B, D, C, L,
+                                        ctypes.c_float(S), H, ctypes.byref(lay), sarr, n_sums, _stream()), "hs_hash_bwd_jac_sums")
+        if sums:
+            sums.clear()
+
+    @staticmethod
+    def _asm_array(pending):
+        """assemble(defer=True)'s pending jobs as hs_assemble's argument pair (None, 0 when there is nothing)."""
+        if not pending:
+            return None, 0
+        if len(pending) > 12:
+            raise RuntimeError("at most HS_ASM_MAX_JOBS jobs ride in one launch")
+        return (hsAsmJob * len(pending))(*[d[0] for d in pending]), len(pending)
 
     # ---- per-ray sampler kernels (include/holoscene_hip.h section 3)
     @staticmethod
@@ -1207,14 +1226,18 @@ class _HipBackend:
     WGRAD_SHAPES = ((256, 256), (256, 128), (32, 256))
 
     @staticmethod
-    def assemble(jobs):
+    def assemble(jobs, defer=False):
         """jobs: [((rows, cols), [term, ...])] with term = (src fp32 or bf16 tensor, ld, col0 or int32 column-map tensor[, red, red_stride]) ->
         fp32 tensors [rows, cols] = the sums of the terms (a job may name its destination: ((rows, cols), terms, (matrix, col0)) writes that
         column window of an existing fp32 matrix and returns the matrix), all in one launch
         (hs_assemble, csrc/small_ops.hip).  The element (r, c) of a term is src.flat[r * ld + col(c) (+ k * red_stride, summed over k < red)];
-        a bf16 source is a stack of split-M weight-gradient partials [red, rows, ld]: its slice sum happens here too."""
+        a bf16 source is a stack of split-M weight-gradient partials [red, rows, ld]: its slice sum happens here too.
+        defer: -> (results, pending): nothing is launched; `pending` goes to bwd(sums=) / bwd_jac(sums=) -- the jobs then ride in front of that table
+        scatter's workgroups -- or to assemble_launch() (at most 12 jobs)."""
         lib = load_library()
         outs, keep = [], []
+        if defer and len(jobs) > 12:
+            raise RuntimeError("assemble(defer=True): at most HS_ASM_MAX_JOBS jobs")
         for k0 in range(0, len(jobs), 12):
             grp = jobs[k0:k0 + 12]
             arr = (hsAsmJob * len(grp))()
@@ -1245,8 +1268,24 @@ class _HipBackend:
                         t.col_map, t.col0 = None, int(col)
                     t.red, t.red_stride = (int(term[3]), int(term[4])) if len(term) > 3 else (1, 0)
                 outs.append(out)
+                keep += [t[0] for t in terms] + [out]
+            if defer:
+                pending = []
+                for a in arr:
+                    c = hsAsmJob()
+                    ctypes.memmove(ctypes.addressof(c), ctypes.addressof(a), ctypes.sizeof(hsAsmJob))
+                    pending.append((c, keep))       # (sources, column maps and destinations stay alive until the launch)
+                return outs, pending
             _check(lib.hs_assemble(arr, len(grp), _stream()), "hs_assemble")
         return outs
+
+    @staticmethod
+    def assemble_launch(pending):
+        """Launch what assemble(defer=True) described and no scatter took along (nothing pending: no launch)."""
+        if pending:
+            arr, n = _HipBackend._asm_array(pending)
+            _check(load_library().hs_assemble(arr, n, _stream()), "hs_assemble")
+            pending.clear()
 
     @staticmethod
     def abs_shift(x, shift=None, gy=None):

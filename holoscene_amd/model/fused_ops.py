@@ -672,6 +672,7 @@ class _trunk_render_rr(torch.autograd.Function):
             g_feat[:, n:].zero_()
             g_dydx[:, n:].zero_()
         gW0 = gW1 = gW2 = gb0 = gb1 = gb2 = None
+        sums = None
         if need_w:      # every weight gradient of the trunk -- both point families -- in ONE launch, one launch for the slice sums
             T, npair = be.tp_rows(n) // 32, 2 if second else 1
             cut = _pair_slices([((256, 256), T, npair, True), ((256, 80), T, npair, True), ((32, 256), T, npair, True)]
@@ -729,13 +730,14 @@ class _trunk_render_rr(torch.autograd.Function):
                 # (into the flat gradient buffer's views when the biases have them): ONE launch (csrc/small_ops.hip: hs_assemble on bf16 stacks)
                 p0, p1, p2 = ctx.bias_params
                 D1, D0, D2 = _DirectGrad(p1, (1, 256)), _DirectGrad(p0, (1, 256)), _DirectGrad(p2, (1, K))
-                gW1, gW0, gW2, gb1, gb0, gb2 = be.assemble([
+                # (their only reader is the end-of-pass epilogue and their inputs are complete: with a table scatter to follow, they ride in its launch)
+                (gW1, gW0, gW2, gb1, gb0, gb2), sums = be.assemble([
                     ((256, 256), [(st1, 256, 0, st1.shape[0], 256 * 256)]),
                     ((256, F_in), [(st0, 128, _xp_columns32(dev), st0.shape[0], 256 * 128)]),
                     ((K, 256), [(st2, 256, 0, st2.shape[0], 32 * 256)] + ([(w2_part, 256, 0, w2_part.shape[0], 32 * 256)] if eik_live else [])),
                     D1.job([(gbz, 0, 0), (csb1, 0, 0, csb1.shape[0], 256)]),
                     D0.job([(gbz, 0, 256), (csb0, 0, 0, csb0.shape[0], 256)]),
-                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])])
+                    D2.job([(gbz, 0, 512), (gb2_part, 0, 0, be.RR_GY_BLOCKS, 32)])], defer=True)
                 gb1, gb0, gb2 = D1.grad(gb1, (256,)), D0.grad(gb0, (256,)), D2.grad(gb2, (K,))
         g_emb = None
         if need_table:      # one value+Jacobian scatter for all B points
@@ -743,10 +745,11 @@ class _trunk_render_rr(torch.autograd.Function):
             inplace = _be.accumulates_into_grad(table)
             target = table.grad if inplace else torch.zeros_like(embeddings)
             be.bwd_jac(g_feat, g_dydx, x01, offsets, target, B, 3, C, L, S, Hres,
-                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rank1=rank1)
+                       ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rank1=rank1, sums=sums if B > 0 else None)
             if inplace:
                 _be.scatter_done(table)
             g_emb = None if inplace else target
+        be.assemble_launch(sums)        # (no scatter took them along)
         return None, None, g_emb, None, None, None, None, gW0, gb0, gW1, gb1, gW2, gb2, None
 
 
@@ -1081,6 +1084,7 @@ class _fused_appearance_wave(torch.autograd.Function):
         gy = torch.empty(B, 32, device=dev, dtype=bf)
         GR1, GR0, GFV, GHC = tp(), tp(), tp(), tp()
         g_featc = torch.empty(L, B, C, device=dev)
+        sums = None
         need_w = ctx.needs_input_grad[8]
         gb2 = torch.empty(tiles, 4, device=dev) if need_w else None
         other = None
@@ -1117,7 +1121,8 @@ class _fused_appearance_wave(torch.autograd.Function):
                                Dbr0.job([stk(c_r0, 0, 0)]),
                                Dbc1.job([stk(c_c1, 0, 0)]),
                                Dbc0.job([stk(c_c0, 0, 0)]),
-                               Dbr2.job([(gb2, 0, 0, tiles, 4)])])
+                               Dbr2.job([(gb2, 0, 0, tiles, 4)])], defer=True)
+            out, sums = out
             gWr2, gWr1, _, _, gWc1, gWc0, gbr1, gbr0, gbc1, gbc0, gbr2 = out
             gWc1, gWc0 = DWc1.grad(gWc1, (256, 256)), DWc0.grad(gWc0, (256, 32))
             gbr1, gbr0, gbc1, gbc0, gbr2 = Dbr1.grad(gbr1, (256,)), Dbr0.grad(gbr0, (256,)), Dbc1.grad(gbc1, (256,)), Dbc0.grad(gbc0, (256,)), Dbr2.grad(gbr2, (3,))
@@ -1129,12 +1134,14 @@ class _fused_appearance_wave(torch.autograd.Function):
             rider = getattr(ctx, "rider", None)
             take = rider is not None and not rider["done"] and B > 0      # the next batch's draw rides in front of this scatter's workgroups
             be.bwd(g_featc, x01, offsets, target, B, 3, C, L, S, Hres, None, None,
-                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rider=rider["draw"].args() if take else None)
+                   ws=be.scatter_workspace(B, 3, C, L, dev) if B >= _BIN_MIN_POINTS else None, level_major=True, rider=rider["draw"].args() if take else None,
+                   sums=sums if B > 0 else None)
             if take:
                 rider["done"] = True
             g_emb = None if inplace else target
             if inplace:
                 _be.scatter_done(table)
+        be.assemble_launch(sums)        # (no scatter took the slice sums along)
         return (None, None, d_normals, g_emb, None, None, None, None, gWc0, gbc0, gWc1, gbc1, gWr0, gbr0, gWr1, gbr1, gWr2, gbr2, None)
 
 

@@ -826,7 +826,13 @@ int hs_draw_gather_sched(const hsDrawSched *sched, int32_t n_uniform, int32_t to
  * on 6 000 workgroups) instead of being the next iteration's first link.  Needs a scatter launch (B > 0, grad_embeddings != NULL). */
 int hs_hash_bwd_draw(const float *grad, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                      float S, uint32_t H, const float *dy_dx, float *grad_inputs, const hsHashLayout *layout, const hsDrawSched *draw, int32_t n_uniform,
-                     int32_t total_pixels, int32_t n_out, int64_t *draw_out, const struct hsGatherJob *gather, int32_t n_gather, void *stream);
+                     int32_t total_pixels, int32_t n_out, int64_t *draw_out, const struct hsGatherJob *gather, int32_t n_gather,
+                     const struct hsAsmJob *sums /* NULL, or hs_assemble(sums, n_sums) riding along as well: slice sums of a backward stage whose inputs are
+                                                  * complete before this launch and whose only reader comes after it */,
+                     int32_t n_sums, void *stream);
+/* hs_hash_bwd_jac with hs_assemble(sums, n_sums) riding in front of the scatter's workgroups (n_sums == 0: exactly hs_hash_bwd_jac). */
+int hs_hash_bwd_jac_sums(const float *g_feat, const float *g_dydx, const float *inputs, const int32_t *offsets, float *grad_embeddings, uint32_t B, uint32_t D,
+                         uint32_t C, uint32_t L, float S, uint32_t H, const hsHashLayout *layout, const struct hsAsmJob *sums, int32_t n_sums, void *stream);
 int hs_iter_prologue_draw(const struct hsWnJob *jobs, int32_t n_jobs, float *rng_pool, int64_t n_rng, uint64_t *rng_state, const float *beta,
                           const float *beta_min, float *beta_out, int32_t n_beta, struct hsAdamState *adam, float beta1, float beta2, double gamma, float *zero,
                           int64_t n_zero, const hsDrawSched *draw, int32_t n_uniform, int32_t total_pixels, int32_t n_out, int64_t *draw_out,
