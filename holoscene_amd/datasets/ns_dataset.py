@@ -110,10 +110,11 @@ class ResidentNSDataset:
 
     def peek_batch(self):
         """next_batch() without consuming it: the next draw -- by any path -- yields the same batch again."""
-        c = self._sampler._counter
+        c, g = self._sampler._counter, self._sampler._gen.get_state()      # (host rule: the generator; device rule: the counter)
         out = self.next_batch()
         self._frames.untake(int(out[0][0]))
         self._sampler._counter = c
+        self._sampler._gen.set_state(g)
         return out
 
     def scheduled_draw(self, dst_input, dst_gt):

@@ -125,10 +125,11 @@ class SyntheticScene:
             out = self.next_batch()
             self._cursor = cur
             return out
-        c = self._sampler._counter
+        c, g = self._sampler._counter, self._sampler._gen.get_state()      # (the host rule of a CPU scene draws from the generator, the device rule from the counter)
         out = self.next_batch()
         self._frames.untake(int(out[0][0]))
         self._sampler._counter = c
+        self._sampler._gen.set_state(g)
         return out
 
     def scheduled_draw(self, dst_input, dst_gt):
